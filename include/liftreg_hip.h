@@ -1,0 +1,203 @@
+/*
+ * liftreg_hip.h — C ABI of libliftreg_hip.so (gfx950 / MI355X).
+ *
+ * The reference (uncbiag/LiftReg) has no FFI of its own: every op on its hot
+ * path is an ATen call from Python.  Each entry point below replaces exactly
+ * one of those call sites (cited as reference file:line, paths relative to
+ * the reference checkout).  The library is what a maintainer binds from the
+ * reference's Python with ctypes; liftreg_amd/_hip.py is
+ * that binding.
+ *
+ * Conventions
+ *  - every pointer marked "dev" is a device pointer owned by the caller; the
+ *    library never allocates, frees or synchronises;
+ *  - pointers marked "host" are read synchronously before the call returns;
+ *  - all launches are asynchronous on `stream` (a hipStream_t passed as
+ *    void*; NULL = the default stream);
+ *  - volumes are (D,W,H) = (axial, coronal, sagittal) with H fastest, batches
+ *    are NCDHW exactly as the reference's tensors;
+ *  - return value: LR_OK (0) or a negative LR_E* code; nothing is thrown
+ *    across the ABI; lr_strerror() turns a code into text;
+ *  - fp32 arithmetic that decides an INDEX (sample coordinates, floor) is done
+ *    with the reference's op order, no FMA contraction, IEEE divide.
+ */
+#ifndef LIFTREG_HIP_H
+#define LIFTREG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LR_OK 0
+#define LR_EINVAL (-1)   /* bad shape / size / flag                         */
+#define LR_ENULL (-2)    /* required pointer is NULL                        */
+#define LR_EUNSUPPORTED (-3) /* combination not built (e.g. Cout not 16/32) */
+#define LR_ELAUNCH (-4)  /* hipLaunch reported an error                     */
+#define LR_EALIGN (-5)   /* pointer/extent not aligned as the kernel needs  */
+
+#define LR_MAX_VIEWS 32  /* emitter poses travel in kernel arguments        */
+
+const char* lr_strerror(int code);
+/* ABI version; bumped when a signature changes. */
+int lr_abi_version(void);
+/* Name of the code object's target ("gfx950"). */
+const char* lr_target_arch(void);
+
+/* ------------------------------------------------------------------------
+ * K1  DRR cone-beam forward projector.
+ * Replaces project_grid_multi + F.grid_sample(3D) + sum + *dx*0.1:
+ *   src/liftreg/utils/sdct_projection_utils.py:15-57 (grid, dx)
+ *   src/liftreg/utils/sdct_projection_utils.py:59-100 (calculate_projection, :81,:85)
+ * and optionally folds calc_relative_atten_coef (:6-9) and the axis-1 flip of
+ * tools/preprocessingDRR.py:135-136 into the volume load.
+ *
+ * out[p,a,b] = 0.1 * dx[p,a,b] * sum_{j<W} trilinear0(vol, sample(p,a,b,j))
+ *
+ * vol_slab : dev, (d1-d0, W, H) — rows d0..d1-1 of the full (D,W,H) volume.
+ *            Taps outside [d0,d1) contribute 0, so partial DRRs of disjoint
+ *            slabs SUM to the full DRR (z-slab sharding).
+ *            Unsharded: d0=0, d1=D.
+ * poses    : host, (P,3) fp32 emitter positions (x,y,z) in voxel units.
+ * spacing  : host, 3 floats (mm).
+ * flags    : LR_DRR_HU_INPUT  vol holds HU; mu=(max(HU,-1000)+1000)/1000*0.2 on load
+ *            LR_DRR_FLIP_W    read plane W-1-j where the reference reads j
+ * nseg     : 1,2,4 or 8 — each ray's W planes are split into nseg runs summed
+ *            by separate lanes (deterministic order); 0 = library default.
+ * out      : dev, (P,Rd,Rh) fp32.
+ */
+#define LR_DRR_HU_INPUT 1
+#define LR_DRR_FLIP_W 2
+int lr_drr_forward_f32(const float* vol_slab, const float* poses, const float* spacing,
+                       float* out, int D, int W, int H, int d0, int d1,
+                       int P, int Rd, int Rh, int flags, int nseg, void* stream);
+
+/* Debug/parity: the un-normalised sample coordinates (pixel units, after
+ * ATen's align_corners=True un-normalise) the projector uses, and dx.
+ * pix: dev (P,Rd,Rh,W,3) ordered (d,w,h); dx: dev (P,Rd,Rh). Either may be NULL. */
+int lr_drr_sample_coords_f32(const float* poses, const float* spacing, float* pix, float* dx,
+                             int D, int W, int H, int P, int Rd, int Rh, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K2  Backprojection (voxel-driven gather of the 2D views).
+ * Replaces backproj_grids_with_poses + F.grid_sample(2D):
+ *   src/liftreg/utils/sdct_projection_utils.py:227-250
+ *   src/liftreg/models/LiftRegDeformSubspaceBackproj.py:85-93
+ *
+ * out[b,p,i,j,k] = bilinear0(proj[b,p], shadow of voxel (i,j,k) for emitter p)
+ *
+ * proj  : dev (B,P,Pw,Ph) fp32
+ * poses : host (P,3) fp32 — ONE geometry for the whole batch, as the reference
+ *         caches the grid of batch element 0 (…Backproj.py:85-87).
+ * out   : dev; element (b,p,i,j,k) at out[b*out_batch_stride + ((p*Ds+i)*W+j)*H+k]
+ *         with Ds=d1-d0 and i in [0,Ds) standing for row d0+i. out_batch_stride
+ *         lets the caller write straight into channels 1..P of the (B,P+1,D,W,H)
+ *         encoder input (the torch.cat of …Backproj.py:95-98).
+ */
+int lr_backproject_f32(const float* proj, const float* poses, float* out,
+                       int B, int P, int Pw, int Ph, int D, int W, int H,
+                       int d0, int d1, int64_t out_batch_stride, void* stream);
+
+/* Debug/parity: detector pixel coordinates of every voxel shadow.
+ * pix: dev (P,D,W,H,2) ordered (Pw axis, Ph axis). */
+int lr_backproject_coords_f32(const float* poses, float* pix, int P, int Pw, int Ph,
+                              int D, int W, int H, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K3  Conv3d(k=3, pad=1, stride 1|2, bias) + LeakyReLU, implicit GEMM on
+ * v_mfma_f32_16x16x4_f32.  Replaces convBlock:
+ *   src/liftreg/layers/layers.py:335-372 as wired at …Backproj.py:29-33,95-100
+ *
+ * lr_conv3d_pack_weights_f32: weight (Cout,Cin,3,3,3) -> MFMA B-operand order.
+ *   packed needs lr_conv3d_packed_floats(Cin,Cout) floats.
+ * lr_conv3d_k3_lrelu_f32:
+ *   in  : dev; LR_LAYOUT_NCDHW (B,Cin,D,W,H) or LR_LAYOUT_NDHWC (B,D,W,H,Cin)
+ *   out : dev; (B,Cout,Do,Wo,Ho) or (B,Do,Wo,Ho,Cout); Xo = (X-1)/stride+1
+ *   negative_slope: LeakyReLU slope; pass 1.0f for "no nonlinearity".
+ *   Supported: Cout in {16,32}; Cin any for NCDHW input, Cin%4==0 for NDHWC.
+ */
+#define LR_LAYOUT_NCDHW 0
+#define LR_LAYOUT_NDHWC 1
+int64_t lr_conv3d_packed_floats(int Cin, int Cout, int in_layout);
+int lr_conv3d_pack_weights_f32(const float* weight, float* packed, int Cin, int Cout,
+                               int in_layout, void* stream);
+int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, const float* bias, float* out,
+                           int B, int Cin, int Cout, int D, int W, int H, int stride,
+                           int in_layout, int out_layout, float negative_slope, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K4  Linear (+ optional LeakyReLU) for the small-batch FC head.
+ * Replaces FullyConnectBlock: src/liftreg/layers/layers.py:413-439
+ * (…Backproj.py:34-39).  y[b,o] = act(sum_k x[b,k]*w[o,k] + bias[o]); B <= 32.
+ */
+int lr_linear_lrelu_f32(const float* x, const float* w, const float* bias, float* y,
+                        int B, int K, int O, float negative_slope, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K5  PCA reconstruction of the displacement field (streaming skinny GEMM).
+ * Replaces F.linear(coefs, pca_vectors, pca_mean): …Backproj.py:42-43,102
+ *   disp[b,m] = sum_l coefs[b,l]*basis[l*ldb+m] + mean[m],  m in [0,M)
+ * basis is the (L,3V) C-contiguous pca_vectors.npy (ldb=3V) or a slab of it.
+ * B <= 32.  M%4==0, pointers 16-byte aligned.
+ */
+int lr_pca_reconstruct_f32(const float* coefs, const float* basis, const float* mean, float* disp,
+                           int B, int L, int64_t M, int64_t ldb, int64_t disp_batch_stride,
+                           void* stream);
+
+/* ------------------------------------------------------------------------
+ * K6+K7  Spatial-transformer warp.  Replaces Bilinear.forward and the
+ * identity-map add: src/liftreg/utils/net_utils.py:9-56, 59-87;
+ * …Backproj.py:54-58 (mask compose), :68-69.
+ *
+ *  phi      = disp + id               (id from three per-axis tables)
+ *  warped   = 2*trilinear((img'+1)/2, phi[(2,1,0)]) - 1   (using_scale)
+ *  img'     = seg ? (img+1)*seg-1 : img
+ *
+ * img   : dev (B,C,Ds_src..)  full source volume (B,C,D,W,H) — always whole.
+ * disp  : dev (B,3,Dn,W,H) with Dn=d1-d0 rows d0..d1-1 (slab) of the field.
+ * id0/id1/id2 : dev, the identity map along D (Dn entries for rows d0..),
+ *         W and H (host-built exactly as identity_map does); NULL,NULL,NULL
+ *         means `disp` already IS phi.
+ * seg   : dev (B,C,D,W,H) or NULL.
+ * phi_out : dev (B,3,Dn,W,H) or NULL.
+ * warped  : dev (B,C,Dn,W,H).
+ * flags : LR_WARP_USING_SCALE, LR_WARP_BORDER (padding_mode='border',
+ *         default zeros), LR_WARP_NEAREST (mode='nearest').
+ */
+#define LR_WARP_USING_SCALE 1
+#define LR_WARP_BORDER 2
+#define LR_WARP_NEAREST 4
+int lr_warp_trilinear_f32(const float* img, const float* seg, const float* disp,
+                          const float* id0, const float* id1, const float* id2,
+                          float* phi_out, float* warped,
+                          int B, int C, int D, int W, int H, int d0, int d1,
+                          int flags, void* stream);
+
+/* target_cp = (img+1)*seg-1 (…Backproj.py:57-58) */
+int lr_mask_compose_f32(const float* img, const float* seg, float* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K8  NCC similarity.  Replaces NCCLoss: src/liftreg/layers/losses.py:14-29
+ * (configured) and the squared per-channel variant src/liftreg/layers/layers.py:238-255.
+ *
+ * lr_ncc_moments_f32: one pass over x,y (R rows of N elements) accumulating
+ *   per row {sum x, sum y, sum xy, sum xx, sum yy} in fp64.
+ *   partial : dev workspace, R*nblk*5 doubles;  moments: dev, R*5 doubles.
+ *   Moments of disjoint slabs ADD (all-reduce them for z-slab sharding).
+ * lr_ncc_loss_from_moments: loss (1 float) and per-row ncc (R floats).
+ *   n_total = elements per row over ALL shards.
+ *   variant LR_NCC_CONFIGURED: 1 - mean_r(cov/sqrt(varx*vary)) with the +1e-10 shifts;
+ *   variant LR_NCC_SQUARED   : 1 - sum_r(cov^2/(varx*vary+1e-12))/n_batch/C (rows=B*C).
+ */
+#define LR_NCC_CONFIGURED 0
+#define LR_NCC_SQUARED 1
+int lr_ncc_moments_f32(const float* x, const float* y, double* partial, double* moments,
+                       int R, int64_t N, int nblk, void* stream);
+int lr_ncc_loss_from_moments(const double* moments, float* loss, float* ncc_rows,
+                             int R, int64_t n_total, int n_batch, int variant, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIFTREG_HIP_H */

@@ -1,0 +1,184 @@
+// backproject.hip — K2: voxel-driven backprojection of P 2D views into a
+// (B,P,D,W,H) feature volume.  HBM-write-bound: 4*P*V bytes out per sample,
+// the views themselves (4*P*Pw*Ph bytes) stay L2-resident.
+//
+// Replaces (reference file:line)
+//   src/liftreg/utils/sdct_projection_utils.py:227-250  backproj_grids_with_poses
+//   src/liftreg/models/LiftRegDeformSubspaceBackproj.py:85-93  F.grid_sample 2D
+//
+// The reference materialises a (1,P,2,D,W,H) grid once and samples it for every
+// batch; here each thread derives the shadow of its 4 consecutive-H voxels in
+// registers (same fp32 op order, no contraction, IEEE divide — so floor() picks
+// the same detector pixel) and re-uses it across the whole batch.
+#include "lr_common.h"
+
+namespace {
+
+// Pixel coordinate along the Pw axis (detector rows) of voxel row x, plane y.
+// grids = (x - ex) * scale + ex ; /proj_w * 2.0 ; ATen un-normalise.
+__device__ __forceinline__ float shadow_pix(float x, float e, float scale, float fsize, int size) {
+  float g = (x - e) * scale;  // torch.mul(grids - poses, scale)
+  g = g + e;                  // + poses[:, :, ::2]
+  g = g / fsize;              // grids[:, :, c] / proj_w
+  g = g * 2.0f;               // * 2.0
+  return lr_unnormalize(g, size);
+}
+
+struct Tap {
+  int i0, i1;    // clamped indices (safe to dereference)
+  float w0, w1;  // weights of floor / floor+1, zeroed when out of range
+};
+
+// ATen's vectorised 2D bilinear (GridSamplerKernel.cpp): w = x - floor(x),
+// e = 1 - w; out-of-range corners are dropped individually (padding 'zeros').
+__device__ __forceinline__ Tap make_tap(float pix, int size) {
+  Tap t;
+  if (!(pix > -1.0f && pix < (float)size)) {  // also catches NaN
+    t.i0 = t.i1 = 0;
+    t.w0 = t.w1 = 0.0f;
+    return t;
+  }
+  const float fl = floorf(pix);
+  const float w = pix - fl;
+  const float e = 1.0f - w;
+  const int i0 = (int)fl, i1 = i0 + 1;
+  t.w0 = (i0 >= 0) ? e : 0.0f;          // i0 < size is implied by pix < size
+  t.w1 = (i1 < size) ? w : 0.0f;        // i1 >= 0 is implied by pix > -1
+  t.i0 = max(i0, 0);
+  t.i1 = min(i1, size - 1);
+  return t;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void backproject_kernel(
+    const float* __restrict__ proj, LrPoses poses, float* __restrict__ out,
+    int B, int P, int Pw, int Ph, int D, int W, int H, int d0, int Ds,
+    int64_t out_batch_stride) {
+  const int HV = H / VEC;
+  const int64_t total = (int64_t)P * Ds * W * HV;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int kv = (int)(idx % HV);
+  int64_t r = idx / HV;
+  const int j = (int)(r % W);
+  r /= W;
+  const int i = (int)(r % Ds);
+  const int p = (int)(r / Ds);
+
+  const float ex = poses.e[p][0], ey = poses.e[p][1], ez = poses.e[p][2];
+  // x = linspace(-d/2, d/2-1, d)[d0+i]; y = linspace(w-1, 0, w)[j]; z likewise.
+  const float x = (float)(d0 + i) - 0.5f * (float)D;
+  const float y = (float)(W - 1 - j);
+  const float scale = ey / (ey - y);  // poses_y / (poses_y - grid_y)
+
+  const Tap ty = make_tap(shadow_pix(x, ex, scale, (float)Pw, Pw), Pw);
+  Tap tx[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const float z = (float)(kv * VEC + v) - 0.5f * (float)H;
+    tx[v] = make_tap(shadow_pix(z, ez, scale, (float)Ph, Ph), Ph);
+  }
+  // nw = s*e, ne = s*w, sw = n*e, se = n*w   (s,n = row weights)
+  float nw[VEC], ne[VEC], sw[VEC], se[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    nw[v] = ty.w0 * tx[v].w0;
+    ne[v] = ty.w0 * tx[v].w1;
+    sw[v] = ty.w1 * tx[v].w0;
+    se[v] = ty.w1 * tx[v].w1;
+  }
+  const int64_t view_sz = (int64_t)Pw * Ph;
+  const float* r0 = proj + (int64_t)p * view_sz + (int64_t)ty.i0 * Ph;
+  const float* r1 = proj + (int64_t)p * view_sz + (int64_t)ty.i1 * Ph;
+  float* o = out + (((int64_t)p * Ds + i) * W + j) * H + (int64_t)kv * VEC;
+  const int64_t pstride = (int64_t)P * view_sz;
+  for (int b = 0; b < B; ++b) {
+    float res[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const float a = r0[tx[v].i0], bq = r0[tx[v].i1];
+      const float c = r1[tx[v].i0], d = r1[tx[v].i1];
+      float acc = a * nw[v];
+      acc = acc + bq * ne[v];
+      acc = acc + c * sw[v];
+      acc = acc + d * se[v];
+      res[v] = acc;
+    }
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<float4*>(o) = make_float4(res[0], res[1], res[2], res[3]);
+    } else {
+      o[0] = res[0];
+    }
+    r0 += pstride;
+    r1 += pstride;
+    o += out_batch_stride;
+  }
+}
+
+__global__ __launch_bounds__(256) void backproject_coords_kernel(
+    LrPoses poses, float* __restrict__ pix, int P, int Pw, int Ph, int D, int W, int H) {
+  const int64_t total = (int64_t)P * D * W * H;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int k = (int)(idx % H);
+  int64_t r = idx / H;
+  const int j = (int)(r % W);
+  r /= W;
+  const int i = (int)(r % D);
+  const int p = (int)(r / D);
+  const float ex = poses.e[p][0], ey = poses.e[p][1], ez = poses.e[p][2];
+  const float x = (float)i - 0.5f * (float)D;
+  const float y = (float)(W - 1 - j);
+  const float z = (float)k - 0.5f * (float)H;
+  const float scale = ey / (ey - y);
+  pix[idx * 2 + 0] = shadow_pix(x, ex, scale, (float)Pw, Pw);
+  pix[idx * 2 + 1] = shadow_pix(z, ez, scale, (float)Ph, Ph);
+}
+
+int fill_poses(LrPoses& lp, const float* poses, int P) {
+  if (!poses) return LR_ENULL;
+  if (P < 1 || P > LR_MAX_VIEWS) return LR_EINVAL;
+  for (int p = 0; p < P; ++p)
+    for (int c = 0; c < 3; ++c) lp.e[p][c] = poses[p * 3 + c];
+  return LR_OK;
+}
+
+}  // namespace
+
+extern "C" int lr_backproject_f32(const float* proj, const float* poses, float* out,
+                                  int B, int P, int Pw, int Ph, int D, int W, int H,
+                                  int d0, int d1, int64_t out_batch_stride, void* stream) {
+  if (!proj || !out) return LR_ENULL;
+  if (B < 1 || Pw < 1 || Ph < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
+  if (d0 < 0 || d1 > D || d1 <= d0) return LR_EINVAL;
+  LrPoses lp;
+  if (int e = fill_poses(lp, poses, P)) return e;
+  const int Ds = d1 - d0;
+  if (out_batch_stride < (int64_t)P * Ds * W * H) return LR_EINVAL;
+  const bool vec4 = (H % 4 == 0) && (out_batch_stride % 4 == 0) &&
+                    ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
+  const int64_t total = (int64_t)P * Ds * W * (vec4 ? H / 4 : H);
+  const int64_t nblk = (total + 255) / 256;
+  if (nblk > 0x7fffffffLL) return LR_EINVAL;
+  if (vec4)
+    hipLaunchKernelGGL(backproject_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, lr_stream(stream),
+                       proj, lp, out, B, P, Pw, Ph, D, W, H, d0, Ds, out_batch_stride);
+  else
+    hipLaunchKernelGGL(backproject_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, lr_stream(stream),
+                       proj, lp, out, B, P, Pw, Ph, D, W, H, d0, Ds, out_batch_stride);
+  return lr_launch_status();
+}
+
+extern "C" int lr_backproject_coords_f32(const float* poses, float* pix, int P, int Pw, int Ph,
+                                         int D, int W, int H, void* stream) {
+  if (!pix) return LR_ENULL;
+  if (Pw < 1 || Ph < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
+  LrPoses lp;
+  if (int e = fill_poses(lp, poses, P)) return e;
+  const int64_t total = (int64_t)P * D * W * H;
+  const int64_t nblk = (total + 255) / 256;
+  if (nblk > 0x7fffffffLL) return LR_EINVAL;
+  hipLaunchKernelGGL(backproject_coords_kernel, dim3((unsigned)nblk), dim3(256), 0,
+                     lr_stream(stream), lp, pix, P, Pw, Ph, D, W, H);
+  return lr_launch_status();
+}

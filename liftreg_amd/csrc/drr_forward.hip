@@ -1,0 +1,260 @@
+// drr_forward.hip — K1: cone-beam DRR forward projector (ray marching, one
+// trilinear sample per coronal plane, sample grid derived in registers).
+//
+// Replaces (reference file:line)
+//   src/liftreg/utils/sdct_projection_utils.py:15-57   project_grid_multi
+//   src/liftreg/utils/sdct_projection_utils.py:59-100  calculate_projection (:81 grid_sample, :85 *0.1)
+//   src/liftreg/utils/sdct_projection_utils.py:6-9     calc_relative_atten_coef (LR_DRR_HU_INPUT)
+//   tools/preprocessingDRR.py:135-136                  np.flip(axis=1)          (LR_DRR_FLIP_W)
+//
+// The reference materialises a (P,Rd,Rh,W,3) fp32 grid (12*P*Rd*Rh*W bytes);
+// this kernel never does.  Lanes of a wavefront walk 64 neighbouring detector
+// columns (the Rh axis pairs with H, the volume's fastest axis), so each of the
+// 8 trilinear taps of a plane is one ~256-byte contiguous run per wavefront.
+// Gather-bound (L2 / Infinity-Cache resident volume), not HBM-bound.
+//
+// Coordinates follow the reference's fp32 op order exactly (no contraction,
+// IEEE divide) because float rounding moves ~50 % of the samples off their
+// coronal plane by up to 7e-5 (SURVEY.md headline fact 6) and floor() must agree.
+#include "lr_common.h"
+
+namespace {
+
+struct RaySetup {
+  float ihx, ihy, ihz;  // unit direction Î
+  float rc;             // 1 / Î_y
+  float dx;             // mm per unit-y step
+};
+
+// project_grid_multi (:31-41): I = pix - e ; dx = ‖(I * (1/I_y)) ⊙ spacing‖ ; Î = I/‖I‖.
+// torch.norm on CPU accumulates with an FMA chain: fma(z,z,fma(y,y,x*x)).
+__device__ __forceinline__ RaySetup ray_setup(int a, int b, int Rd, int Rh, float ex, float ey,
+                                              float ez, float sp0, float sp1, float sp2) {
+  const float px = (float)a - 0.5f * (float)Rd;  // linspace(-res_d/2, res_d/2-1, res_d)[a]
+  const float pz = (float)b - 0.5f * (float)Rh;
+  const float ix = px + (-ex), iy = 0.0f + (-ey), iz = pz + (-ez);
+  const float rcp = 1.0f / iy;
+  const float d0 = (ix * rcp) * sp0, d1 = (iy * rcp) * sp1, d2 = (iz * rcp) * sp2;
+  RaySetup r;
+  r.dx = sqrtf(fmaf(d2, d2, fmaf(d1, d1, d0 * d0)));
+  const float nrm = sqrtf(fmaf(iz, iz, fmaf(iy, iy, ix * ix)));
+  r.ihx = ix / nrm;
+  r.ihy = iy / nrm;
+  r.ihz = iz / nrm;
+  r.rc = 1.0f / r.ihy;
+  return r;
+}
+
+// Sample position on plane y=j in ATen pixel units (d,w,h): grid = Î*T + e (:50-51),
+// normalise (:54-56), un-normalise align_corners=True.
+__device__ __forceinline__ void sample_pix(const RaySetup& r, int j, float ex, float ey, float ez,
+                                           int D, int W, int H, float& pd, float& pw, float& ph) {
+  const float t = r.rc * ((float)j - ey);
+  const float x = r.ihx * t + ex;
+  const float y = r.ihy * t + ey;
+  const float z = r.ihz * t + ez;
+  const float gx = (x / (float)D) * 2.0f;
+  const float gy = ((y - 0.0f) / ((float)W - 1.0f)) * 2.0f + -1.0f;
+  const float gz = (z / (float)H) * 2.0f;
+  pd = lr_unnormalize(gx, D);
+  pw = lr_unnormalize(gy, W);
+  ph = lr_unnormalize(gz, H);
+}
+
+struct Axis {
+  int i0, i1;
+  float w0, w1;  // (i1 - pix), (pix - i0) — ATen's generic 3D kernel
+  bool ok0, ok1;
+};
+
+__device__ __forceinline__ Axis make_axis(float pix, int lo, int hi /*valid: lo <= i < hi*/) {
+  Axis a;
+  // Anything at or beyond one cell outside the volume contributes nothing.
+  if (!(pix > (float)(lo - 1) && pix < (float)hi)) {
+    a.i0 = a.i1 = lo;
+    a.w0 = a.w1 = 0.0f;
+    a.ok0 = a.ok1 = false;
+    return a;
+  }
+  const float fl = floorf(pix);
+  const int i0 = (int)fl, i1 = i0 + 1;
+  a.w0 = (float)i1 - pix;
+  a.w1 = pix - (float)i0;
+  a.ok0 = i0 >= lo;  // i0 < hi implied
+  a.ok1 = i1 < hi;   // i1 >= lo implied
+  a.i0 = max(i0, lo);
+  a.i1 = min(i1, hi - 1);
+  return a;
+}
+
+template <bool HU>
+__device__ __forceinline__ float load_mu(const float* p, bool ok) {
+  float v = *p;
+  if constexpr (HU) {
+    v = (v < -1000.0f) ? -1000.0f : v;         // new_img[new_img < -1000] = -1000
+    v = ((v + 1000.0f) / 1000.0f) * 0.2f;      // (new_img + 1000.) / 1000. * 0.2
+  }
+  return ok ? v : 0.0f;
+}
+
+// blockDim = (64, R): lane ↔ detector column b; row r ↔ (a, segment).
+template <bool HU, bool FLIP>
+__global__ __launch_bounds__(1024) void drr_forward_kernel(
+    const float* __restrict__ vol, LrPoses poses, float sp0, float sp1, float sp2,
+    float* __restrict__ out, int D, int W, int H, int d0, int d1, int P, int Rd, int Rh,
+    int nseg) {
+  extern __shared__ float part[];  // [R][64]
+  const int lane = threadIdx.x, row = threadIdx.y, R = blockDim.y;
+  const int a_per_blk = R / nseg;
+  const int nbx = (Rh + 63) >> 6;
+  // blockIdx.x enumerates (p, a-group, b-chunk), remapped so one XCD walks a
+  // contiguous run of detector rows (they share volume x-rows in its L2).
+  const unsigned nblk = gridDim.x;
+  const unsigned lb = lr_xcd_remap(blockIdx.x, nblk);
+  const int bx = lb % nbx;
+  const int ag = (lb / nbx) % ((Rd + a_per_blk - 1) / a_per_blk);
+  const int p = lb / nbx / ((Rd + a_per_blk - 1) / a_per_blk);
+  const int a = ag * a_per_blk + row / nseg;
+  const int seg = row % nseg;
+  const int b = bx * 64 + lane;
+  const bool live = (a < Rd) && (b < Rh);
+
+  float acc = 0.0f;
+  float dxv = 0.0f;
+  if (live) {
+    const float ex = poses.e[p][0], ey = poses.e[p][1], ez = poses.e[p][2];
+    const RaySetup rs = ray_setup(a, b, Rd, Rh, ex, ey, ez, sp0, sp1, sp2);
+    dxv = rs.dx;
+    const int per = (W + nseg - 1) / nseg;
+    const int j0 = seg * per, j1 = min(W, j0 + per);
+    const int64_t sW = H, sD = (int64_t)W * H;
+    for (int j = j0; j < j1; ++j) {
+      float pd, pw, ph;
+      sample_pix(rs, j, ex, ey, ez, D, W, H, pd, pw, ph);
+      const Axis az = make_axis(pd, d0, d1);  // grid z ↔ D (slab rows only)
+      const Axis ay = make_axis(pw, 0, W);    // grid y ↔ W
+      const Axis ax = make_axis(ph, 0, H);    // grid x ↔ H
+      const int y0 = FLIP ? (W - 1 - ay.i0) : ay.i0;
+      const int y1 = FLIP ? (W - 1 - ay.i1) : ay.i1;
+      const float* p00 = vol + (int64_t)(az.i0 - d0) * sD + (int64_t)y0 * sW;
+      const float* p01 = vol + (int64_t)(az.i0 - d0) * sD + (int64_t)y1 * sW;
+      const float* p10 = vol + (int64_t)(az.i1 - d0) * sD + (int64_t)y0 * sW;
+      const float* p11 = vol + (int64_t)(az.i1 - d0) * sD + (int64_t)y1 * sW;
+      // issue all 8 gathers before any use
+      const float v_tnw = load_mu<HU>(p00 + ax.i0, az.ok0 && ay.ok0 && ax.ok0);
+      const float v_tne = load_mu<HU>(p00 + ax.i1, az.ok0 && ay.ok0 && ax.ok1);
+      const float v_tsw = load_mu<HU>(p01 + ax.i0, az.ok0 && ay.ok1 && ax.ok0);
+      const float v_tse = load_mu<HU>(p01 + ax.i1, az.ok0 && ay.ok1 && ax.ok1);
+      const float v_bnw = load_mu<HU>(p10 + ax.i0, az.ok1 && ay.ok0 && ax.ok0);
+      const float v_bne = load_mu<HU>(p10 + ax.i1, az.ok1 && ay.ok0 && ax.ok1);
+      const float v_bsw = load_mu<HU>(p11 + ax.i0, az.ok1 && ay.ok1 && ax.ok0);
+      const float v_bse = load_mu<HU>(p11 + ax.i1, az.ok1 && ay.ok1 && ax.ok1);
+      // weights: (x-part * y-part) * z-part, corners in ATen's order
+      float s = v_tnw * ((ax.w0 * ay.w0) * az.w0);
+      s = s + v_tne * ((ax.w1 * ay.w0) * az.w0);
+      s = s + v_tsw * ((ax.w0 * ay.w1) * az.w0);
+      s = s + v_tse * ((ax.w1 * ay.w1) * az.w0);
+      s = s + v_bnw * ((ax.w0 * ay.w0) * az.w1);
+      s = s + v_bne * ((ax.w1 * ay.w0) * az.w1);
+      s = s + v_bsw * ((ax.w0 * ay.w1) * az.w1);
+      s = s + v_bse * ((ax.w1 * ay.w1) * az.w1);
+      acc = acc + s;
+    }
+  }
+  if (nseg == 1) {
+    if (live) out[((int64_t)p * Rd + a) * Rh + b] = (acc * dxv) * 0.1f;
+    return;
+  }
+  part[row * 64 + lane] = acc;
+  __syncthreads();
+  if (live && seg == 0) {
+    float s = part[row * 64 + lane];
+    for (int q = 1; q < nseg; ++q) s = s + part[(row + q) * 64 + lane];
+    out[((int64_t)p * Rd + a) * Rh + b] = (s * dxv) * 0.1f;
+  }
+}
+
+__global__ __launch_bounds__(256) void drr_coords_kernel(LrPoses poses, float sp0, float sp1,
+                                                         float sp2, float* __restrict__ pix,
+                                                         float* __restrict__ dx, int D, int W,
+                                                         int H, int P, int Rd, int Rh) {
+  const int64_t total = (int64_t)P * Rd * Rh;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int b = (int)(idx % Rh);
+  const int a = (int)((idx / Rh) % Rd);
+  const int p = (int)(idx / Rh / Rd);
+  const float ex = poses.e[p][0], ey = poses.e[p][1], ez = poses.e[p][2];
+  const RaySetup rs = ray_setup(a, b, Rd, Rh, ex, ey, ez, sp0, sp1, sp2);
+  if (dx) dx[idx] = rs.dx;
+  if (pix) {
+    for (int j = 0; j < W; ++j) {
+      float pd, pw, ph;
+      sample_pix(rs, j, ex, ey, ez, D, W, H, pd, pw, ph);
+      float* o = pix + (idx * W + j) * 3;
+      o[0] = pd;
+      o[1] = pw;
+      o[2] = ph;
+    }
+  }
+}
+
+int fill_poses(LrPoses& lp, const float* poses, int P) {
+  if (!poses) return LR_ENULL;
+  if (P < 1 || P > LR_MAX_VIEWS) return LR_EINVAL;
+  for (int p = 0; p < P; ++p)
+    for (int c = 0; c < 3; ++c) lp.e[p][c] = poses[p * 3 + c];
+  return LR_OK;
+}
+
+}  // namespace
+
+extern "C" int lr_drr_forward_f32(const float* vol_slab, const float* poses, const float* spacing,
+                                  float* out, int D, int W, int H, int d0, int d1, int P, int Rd,
+                                  int Rh, int flags, int nseg, void* stream) {
+  if (!vol_slab || !out || !spacing) return LR_ENULL;
+  if (D < 1 || W < 2 || H < 1 || Rd < 1 || Rh < 1) return LR_EINVAL;
+  if (d0 < 0 || d1 > D || d1 <= d0) return LR_EINVAL;
+  if (flags & ~(LR_DRR_HU_INPUT | LR_DRR_FLIP_W)) return LR_EINVAL;
+  LrPoses lp;
+  if (int e = fill_poses(lp, poses, P)) return e;
+  if (nseg == 0) {
+    // enough lanes to fill 256 CUs x 32 waves, capped at 16 runs per ray
+    const int64_t rays = (int64_t)P * Rd * ((Rh + 63) / 64 * 64);
+    nseg = 1;
+    while (nseg < 16 && rays * nseg < 256LL * 2048 && W / (nseg * 2) >= 8) nseg *= 2;
+  }
+  if (nseg != 1 && nseg != 2 && nseg != 4 && nseg != 8 && nseg != 16) return LR_EINVAL;
+  const int R = nseg > 4 ? nseg : 4;
+  const int a_per_blk = R / nseg;
+  const int64_t nblk = (int64_t)P * ((Rd + a_per_blk - 1) / a_per_blk) * ((Rh + 63) / 64);
+  if (nblk > 0x7fffffffLL) return LR_EINVAL;
+  const dim3 grid((unsigned)nblk), block(64, R);
+  const size_t lds = (size_t)R * 64 * sizeof(float);
+  const bool hu = flags & LR_DRR_HU_INPUT, flip = flags & LR_DRR_FLIP_W;
+#define LR_LAUNCH(HUV, FLV)                                                                    \
+  hipLaunchKernelGGL((drr_forward_kernel<HUV, FLV>), grid, block, lds, lr_stream(stream),      \
+                     vol_slab, lp, spacing[0], spacing[1], spacing[2], out, D, W, H, d0, d1, P, \
+                     Rd, Rh, nseg)
+  if (hu && flip) LR_LAUNCH(true, true);
+  else if (hu) LR_LAUNCH(true, false);
+  else if (flip) LR_LAUNCH(false, true);
+  else LR_LAUNCH(false, false);
+#undef LR_LAUNCH
+  return lr_launch_status();
+}
+
+extern "C" int lr_drr_sample_coords_f32(const float* poses, const float* spacing, float* pix,
+                                        float* dx, int D, int W, int H, int P, int Rd, int Rh,
+                                        void* stream) {
+  if (!spacing) return LR_ENULL;
+  if (!pix && !dx) return LR_ENULL;
+  if (D < 1 || W < 2 || H < 1 || Rd < 1 || Rh < 1) return LR_EINVAL;
+  LrPoses lp;
+  if (int e = fill_poses(lp, poses, P)) return e;
+  const int64_t total = (int64_t)P * Rd * Rh;
+  const int64_t nblk = (total + 255) / 256;
+  hipLaunchKernelGGL(drr_coords_kernel, dim3((unsigned)nblk), dim3(256), 0, lr_stream(stream), lp,
+                     spacing[0], spacing[1], spacing[2], pix, dx, D, W, H, P, Rd, Rh);
+  return lr_launch_status();
+}

@@ -1,0 +1,116 @@
+// linear.hip — K4: small-batch Linear (+LeakyReLU) for the FC head
+// 32(n/32)^3 → 800 → 256 → L.  Weight-streaming GEMV-like kernel: HBM-bound on
+// the weight read (52 MB for FC1 at 256^3); a block owns OT=4 output neurons so
+// the L2-resident activations are re-read 4x less, its 4 wavefronts split K.
+//
+// Replaces (reference file:line)
+//   src/liftreg/layers/layers.py:413-439  FullyConnectBlock
+//   src/liftreg/models/LiftRegDeformSubspaceBackproj.py:34-39
+#include "lr_common.h"
+
+namespace {
+
+constexpr int OT = 4;
+
+template <int BT>
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x,
+                                                     const float* __restrict__ w,
+                                                     const float* __restrict__ bias,
+                                                     float* __restrict__ y, int B, int b_lo, int K,
+                                                     int O, float slope, int vec_ok) {
+  const int o0 = blockIdx.x * OT;
+  float acc[OT][BT];
+#pragma unroll
+  for (int o = 0; o < OT; ++o)
+#pragma unroll
+    for (int b = 0; b < BT; ++b) acc[o][b] = 0.0f;
+
+  const float* wr[OT];
+  const float* xr[BT];
+#pragma unroll
+  for (int o = 0; o < OT; ++o) wr[o] = w + (int64_t)min(o0 + o, O - 1) * K;
+#pragma unroll
+  for (int b = 0; b < BT; ++b) xr[b] = x + (int64_t)min(b_lo + b, B - 1) * K;
+
+  int k_done = 0;
+  if (vec_ok) {
+    const int K4 = K >> 2;
+    for (int k4 = threadIdx.x; k4 < K4; k4 += 256) {
+      float4 wv[OT];
+#pragma unroll
+      for (int o = 0; o < OT; ++o) wv[o] = reinterpret_cast<const float4*>(wr[o])[k4];
+#pragma unroll
+      for (int b = 0; b < BT; ++b) {
+        const float4 xv = reinterpret_cast<const float4*>(xr[b])[k4];
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+          float a = acc[o][b];
+          a = fmaf(wv[o].x, xv.x, a);
+          a = fmaf(wv[o].y, xv.y, a);
+          a = fmaf(wv[o].z, xv.z, a);
+          a = fmaf(wv[o].w, xv.w, a);
+          acc[o][b] = a;
+        }
+      }
+    }
+    k_done = K4 << 2;
+  }
+  for (int k = k_done + threadIdx.x; k < K; k += 256) {
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      const float xv = xr[b][k];
+#pragma unroll
+      for (int o = 0; o < OT; ++o) acc[o][b] = fmaf(wr[o][k], xv, acc[o][b]);
+    }
+  }
+
+  __shared__ float red[4][OT * BT];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 0; o < OT; ++o)
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      const float s = lr_wave_sum(acc[o][b]);
+      if (lane == 0) red[wave][o * BT + b] = s;
+    }
+  __syncthreads();
+  if (threadIdx.x < OT * BT) {
+    const int o = threadIdx.x / BT, b = threadIdx.x % BT;
+    if (o0 + o < O && b_lo + b < B) {
+      float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+      if (bias) s = s + bias[o0 + o];
+      s = s >= 0.0f ? s : s * slope;  // LeakyReLU(slope); slope = 1 → identity
+      y[(int64_t)(b_lo + b) * O + o0 + o] = s;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int lr_linear_lrelu_f32(const float* x, const float* w, const float* bias, float* y,
+                                   int B, int K, int O, float negative_slope, void* stream) {
+  if (!x || !w || !y) return LR_ENULL;
+  if (B < 1 || B > 32 || K < 1 || O < 1) return LR_EINVAL;
+  const int vec_ok = ((K & 3) == 0) &&
+                     (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0);
+  const unsigned nblk = (unsigned)((O + OT - 1) / OT);
+  hipStream_t st = lr_stream(stream);
+  for (int b_lo = 0; b_lo < B;) {
+    const int rem = B - b_lo;
+    if (rem > 4) {
+      hipLaunchKernelGGL(linear_kernel<8>, dim3(nblk), dim3(256), 0, st, x, w, bias, y, B, b_lo, K,
+                         O, negative_slope, vec_ok);
+      b_lo += 8;
+    } else if (rem > 1) {
+      hipLaunchKernelGGL(linear_kernel<4>, dim3(nblk), dim3(256), 0, st, x, w, bias, y, B, b_lo, K,
+                         O, negative_slope, vec_ok);
+      b_lo += 4;
+    } else {
+      hipLaunchKernelGGL(linear_kernel<1>, dim3(nblk), dim3(256), 0, st, x, w, bias, y, B, b_lo, K,
+                         O, negative_slope, vec_ok);
+      b_lo += 1;
+    }
+    if (int e = lr_launch_status()) return e;
+  }
+  return LR_OK;
+}

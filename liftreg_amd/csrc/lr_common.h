@@ -1,0 +1,47 @@
+// lr_common.h — shared device/host helpers for libliftreg_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/liftreg_hip.h"
+
+#define LR_WAVE 64
+
+// Launch check: report, never throw (C ABI).
+static inline int lr_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? LR_OK : LR_ELAUNCH;
+}
+
+static inline hipStream_t lr_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Emitter poses travel by value (kernel-argument segment → SGPR loads).
+struct LrPoses {
+  float e[LR_MAX_VIEWS][3];
+};
+
+// Bijective XCD-aware block remap: hardware deals consecutive block ids
+// round-robin over the 8 XCDs; give each XCD one contiguous chunk of the
+// logical grid so neighbouring tiles share an L2 (speed only, never
+// correctness).
+__device__ __forceinline__ unsigned lr_xcd_remap(unsigned bid, unsigned nblk) {
+  const unsigned xcd = bid & 7u, q = nblk >> 3, r = nblk & 7u;
+  const unsigned base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+// ATen grid_sample un-normalise, align_corners=True:
+// ((g + 1) / 2) * (size - 1)   — aten/src/ATen/native/GridSampler.h
+__device__ __forceinline__ float lr_unnormalize(float g, int size) {
+  return ((g + 1.0f) * 0.5f) * (float)(size - 1);
+}
+
+__device__ __forceinline__ float lr_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double lr_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}

@@ -1,0 +1,240 @@
+// warp.hip — K6+K7(+K9): phi = disp + identity ; spatial-transformer trilinear
+// warp of the moving CT.  Voxel-driven gather: coalesced float4 loads of the
+// three displacement channels, 8 taps per voxel served by L1/L2 (displacements
+// are a few voxels, so a wavefront's taps stay inside a handful of H-rows),
+// float4 stores of phi and of the warped image.
+//
+// Replaces (reference file:line)
+//   src/liftreg/utils/net_utils.py:9-56    Bilinear (channel reorder (2,1,0), grid_sample 3D,
+//                                           (I+1)/2 … *2-1 intensity scaling)
+//   src/liftreg/utils/net_utils.py:59-87   identity_map (passed in as three per-axis tables)
+//   src/liftreg/models/LiftRegDeformSubspaceBackproj.py:54-58  moving_cp = (moving+1)*seg-1
+//   src/liftreg/models/LiftRegDeformSubspaceBackproj.py:68-69  deform_field = disp + id ; warp
+#include "lr_common.h"
+
+namespace {
+
+struct Axis3 {
+  int i0, i1;
+  float w0, w1;
+  bool ok0, ok1;
+};
+
+template <bool BORDER>
+__device__ __forceinline__ Axis3 axis_of(float g, int size) {
+  float pix = lr_unnormalize(g, size);
+  if constexpr (BORDER) pix = fminf((float)(size - 1), fmaxf(pix, 0.0f));  // clip_coordinates
+  Axis3 a;
+  if (!(pix > -1.0f && pix < (float)size)) {
+    a.i0 = a.i1 = 0;
+    a.w0 = a.w1 = 0.0f;
+    a.ok0 = a.ok1 = false;
+    return a;
+  }
+  const float fl = floorf(pix);
+  const int i0 = (int)fl, i1 = i0 + 1;
+  a.w0 = (float)i1 - pix;
+  a.w1 = pix - (float)i0;
+  a.ok0 = i0 >= 0;
+  a.ok1 = i1 < size;
+  a.i0 = max(i0, 0);
+  a.i1 = min(i1, size - 1);
+  return a;
+}
+
+template <bool BORDER>
+__device__ __forceinline__ int nearest_of(float g, int size, bool& ok) {
+  float pix = lr_unnormalize(g, size);
+  if constexpr (BORDER) pix = fminf((float)(size - 1), fmaxf(pix, 0.0f));
+  const float r = rintf(pix);  // std::nearbyint, ties to even
+  ok = (r >= 0.0f) && (r < (float)size);
+  return ok ? (int)r : 0;
+}
+
+template <bool SCALE, bool SEG>
+__device__ __forceinline__ float tap(const float* img, const float* seg, int64_t off, bool ok) {
+  float v = img[off];
+  if constexpr (SEG) v = (v + 1.0f) * seg[off] - 1.0f;  // (moving+1)*moving_seg-1
+  if constexpr (SCALE) v = (v + 1.0f) * 0.5f;           // (input1 + 1) / 2
+  return ok ? v : 0.0f;
+}
+
+template <int VEC, bool SCALE, bool BORDER, bool NEAREST, bool SEG>
+__global__ __launch_bounds__(256) void warp_kernel(
+    const float* __restrict__ img, const float* __restrict__ seg, const float* __restrict__ disp,
+    const float* __restrict__ id0, const float* __restrict__ id1, const float* __restrict__ id2,
+    float* __restrict__ phi_out, float* __restrict__ warped, int B, int C, int D, int W, int H,
+    int Dn) {
+  const int HV = H / VEC;
+  const int64_t per_b = (int64_t)Dn * W * HV;
+  const unsigned nblk_b = (unsigned)((per_b + 255) / 256);  // blocks per batch element
+  const unsigned lb = lr_xcd_remap(blockIdx.x, nblk_b);     // gridDim.x == nblk_b
+  const int b = blockIdx.y;
+  const int64_t idx = (int64_t)lb * 256 + threadIdx.x;
+  if (idx >= per_b) return;
+  const int kv = (int)(idx % HV);
+  const int j = (int)((idx / HV) % W);
+  const int i = (int)(idx / HV / W);
+  const int64_t slabV = (int64_t)Dn * W * H;
+  const int64_t V = (int64_t)D * W * H;
+  const int64_t voff = ((int64_t)i * W + j) * H + (int64_t)kv * VEC;
+
+  float d0v[VEC], d1v[VEC], d2v[VEC];
+  const float* dp = disp + (int64_t)b * 3 * slabV + voff;
+  if constexpr (VEC == 4) {
+    const float4 a = *reinterpret_cast<const float4*>(dp);
+    const float4 bq = *reinterpret_cast<const float4*>(dp + slabV);
+    const float4 c = *reinterpret_cast<const float4*>(dp + 2 * slabV);
+    d0v[0] = a.x; d0v[1] = a.y; d0v[2] = a.z; d0v[3] = a.w;
+    d1v[0] = bq.x; d1v[1] = bq.y; d1v[2] = bq.z; d1v[3] = bq.w;
+    d2v[0] = c.x; d2v[1] = c.y; d2v[2] = c.z; d2v[3] = c.w;
+  } else {
+    d0v[0] = dp[0]; d1v[0] = dp[slabV]; d2v[0] = dp[2 * slabV];
+  }
+  if (id0) {  // deform_field = disp_field + id_transform
+    const float a0 = id0[i], a1 = id1[j];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      d0v[v] = d0v[v] + a0;
+      d1v[v] = d1v[v] + a1;
+      d2v[v] = d2v[v] + id2[kv * VEC + v];
+    }
+  }
+  if (phi_out) {
+    float* pp = phi_out + (int64_t)b * 3 * slabV + voff;
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<float4*>(pp) = make_float4(d0v[0], d0v[1], d0v[2], d0v[3]);
+      *reinterpret_cast<float4*>(pp + slabV) = make_float4(d1v[0], d1v[1], d1v[2], d1v[3]);
+      *reinterpret_cast<float4*>(pp + 2 * slabV) = make_float4(d2v[0], d2v[1], d2v[2], d2v[3]);
+    } else {
+      pp[0] = d0v[0]; pp[slabV] = d1v[0]; pp[2 * slabV] = d2v[0];
+    }
+  }
+
+  const int64_t sD = (int64_t)W * H;
+  for (int c = 0; c < C; ++c) {
+    const float* im = img + ((int64_t)b * C + c) * V;
+    const float* sg = SEG ? seg + ((int64_t)b * C + c) * V : nullptr;
+    float res[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      // grid (x,y,z) = phi channels (2,1,0): x ↔ H, y ↔ W, z ↔ D
+      if constexpr (NEAREST) {
+        bool okx, oky, okz;
+        const int xh = nearest_of<BORDER>(d2v[v], H, okx);
+        const int yw = nearest_of<BORDER>(d1v[v], W, oky);
+        const int zd = nearest_of<BORDER>(d0v[v], D, okz);
+        res[v] = tap<SCALE, SEG>(im, sg, (int64_t)zd * sD + (int64_t)yw * H + xh, okx && oky && okz);
+      } else {
+        const Axis3 ax = axis_of<BORDER>(d2v[v], H);
+        const Axis3 ay = axis_of<BORDER>(d1v[v], W);
+        const Axis3 az = axis_of<BORDER>(d0v[v], D);
+        const int64_t o00 = (int64_t)az.i0 * sD + (int64_t)ay.i0 * H;
+        const int64_t o01 = (int64_t)az.i0 * sD + (int64_t)ay.i1 * H;
+        const int64_t o10 = (int64_t)az.i1 * sD + (int64_t)ay.i0 * H;
+        const int64_t o11 = (int64_t)az.i1 * sD + (int64_t)ay.i1 * H;
+        const float v_tnw = tap<SCALE, SEG>(im, sg, o00 + ax.i0, az.ok0 && ay.ok0 && ax.ok0);
+        const float v_tne = tap<SCALE, SEG>(im, sg, o00 + ax.i1, az.ok0 && ay.ok0 && ax.ok1);
+        const float v_tsw = tap<SCALE, SEG>(im, sg, o01 + ax.i0, az.ok0 && ay.ok1 && ax.ok0);
+        const float v_tse = tap<SCALE, SEG>(im, sg, o01 + ax.i1, az.ok0 && ay.ok1 && ax.ok1);
+        const float v_bnw = tap<SCALE, SEG>(im, sg, o10 + ax.i0, az.ok1 && ay.ok0 && ax.ok0);
+        const float v_bne = tap<SCALE, SEG>(im, sg, o10 + ax.i1, az.ok1 && ay.ok0 && ax.ok1);
+        const float v_bsw = tap<SCALE, SEG>(im, sg, o11 + ax.i0, az.ok1 && ay.ok1 && ax.ok0);
+        const float v_bse = tap<SCALE, SEG>(im, sg, o11 + ax.i1, az.ok1 && ay.ok1 && ax.ok1);
+        float s = v_tnw * ((ax.w0 * ay.w0) * az.w0);
+        s = s + v_tne * ((ax.w1 * ay.w0) * az.w0);
+        s = s + v_tsw * ((ax.w0 * ay.w1) * az.w0);
+        s = s + v_tse * ((ax.w1 * ay.w1) * az.w0);
+        s = s + v_bnw * ((ax.w0 * ay.w0) * az.w1);
+        s = s + v_bne * ((ax.w1 * ay.w0) * az.w1);
+        s = s + v_bsw * ((ax.w0 * ay.w1) * az.w1);
+        s = s + v_bse * ((ax.w1 * ay.w1) * az.w1);
+        res[v] = s;
+      }
+      if constexpr (SCALE) res[v] = res[v] * 2.0f - 1.0f;  // output * 2 - 1
+    }
+    float* wp = warped + ((int64_t)b * C + c) * slabV + voff;
+    if constexpr (VEC == 4)
+      *reinterpret_cast<float4*>(wp) = make_float4(res[0], res[1], res[2], res[3]);
+    else
+      wp[0] = res[0];
+  }
+}
+
+__global__ __launch_bounds__(256) void mask_compose_kernel(const float* __restrict__ img,
+                                                           const float* __restrict__ seg,
+                                                           float* __restrict__ out, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = (img[i] + 1.0f) * seg[i] - 1.0f;
+}
+
+template <int VEC, bool SCALE, bool BORDER, bool NEAREST>
+int launch_warp(const float* img, const float* seg, const float* disp, const float* id0,
+                const float* id1, const float* id2, float* phi_out, float* warped, int B, int C,
+                int D, int W, int H, int Dn, hipStream_t st) {
+  const int64_t per_b = (int64_t)Dn * W * (H / VEC);
+  const int64_t nblk = (per_b + 255) / 256;
+  if (nblk > 0x7fffffffLL || B > 65535) return LR_EINVAL;
+  const dim3 grid((unsigned)nblk, (unsigned)B), block(256);
+  if (seg)
+    hipLaunchKernelGGL((warp_kernel<VEC, SCALE, BORDER, NEAREST, true>), grid, block, 0, st, img,
+                       seg, disp, id0, id1, id2, phi_out, warped, B, C, D, W, H, Dn);
+  else
+    hipLaunchKernelGGL((warp_kernel<VEC, SCALE, BORDER, NEAREST, false>), grid, block, 0, st, img,
+                       seg, disp, id0, id1, id2, phi_out, warped, B, C, D, W, H, Dn);
+  return lr_launch_status();
+}
+
+template <int VEC>
+int dispatch_warp(int flags, const float* img, const float* seg, const float* disp,
+                  const float* id0, const float* id1, const float* id2, float* phi_out,
+                  float* warped, int B, int C, int D, int W, int H, int Dn, hipStream_t st) {
+#define LR_W(S, Bo, N) \
+  return launch_warp<VEC, S, Bo, N>(img, seg, disp, id0, id1, id2, phi_out, warped, B, C, D, W, H, Dn, st)
+  const bool s = flags & LR_WARP_USING_SCALE, bo = flags & LR_WARP_BORDER, n = flags & LR_WARP_NEAREST;
+  if (s) {
+    if (bo) { if (n) LR_W(true, true, true); else LR_W(true, true, false); }
+    else    { if (n) LR_W(true, false, true); else LR_W(true, false, false); }
+  } else {
+    if (bo) { if (n) LR_W(false, true, true); else LR_W(false, true, false); }
+    else    { if (n) LR_W(false, false, true); else LR_W(false, false, false); }
+  }
+#undef LR_W
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int lr_warp_trilinear_f32(const float* img, const float* seg, const float* disp,
+                                     const float* id0, const float* id1, const float* id2,
+                                     float* phi_out, float* warped, int B, int C, int D, int W,
+                                     int H, int d0, int d1, int flags, void* stream) {
+  if (!img || !disp || !warped) return LR_ENULL;
+  if (B < 1 || C < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
+  if (d0 < 0 || d1 > D || d1 <= d0) return LR_EINVAL;
+  if (flags & ~(LR_WARP_USING_SCALE | LR_WARP_BORDER | LR_WARP_NEAREST)) return LR_EINVAL;
+  const bool any_id = id0 || id1 || id2, all_id = id0 && id1 && id2;
+  if (any_id && !all_id) return LR_ENULL;
+  const int Dn = d1 - d0;
+  const bool vec4 = (H % 4 == 0) && aligned16(disp) && aligned16(warped) &&
+                    (!phi_out || aligned16(phi_out));
+  if (vec4)
+    return dispatch_warp<4>(flags, img, seg, disp, id0, id1, id2, phi_out, warped, B, C, D, W, H,
+                            Dn, lr_stream(stream));
+  return dispatch_warp<1>(flags, img, seg, disp, id0, id1, id2, phi_out, warped, B, C, D, W, H, Dn,
+                          lr_stream(stream));
+}
+
+extern "C" int lr_mask_compose_f32(const float* img, const float* seg, float* out, int64_t n,
+                                   void* stream) {
+  if (!img || !seg || !out) return LR_ENULL;
+  if (n < 0) return LR_EINVAL;
+  if (n == 0) return LR_OK;
+  int64_t nblk = (n + 255) / 256;
+  if (nblk > 256 * 16) nblk = 256 * 16;
+  hipLaunchKernelGGL(mask_compose_kernel, dim3((unsigned)nblk), dim3(256), 0, lr_stream(stream),
+                     img, seg, out, n);
+  return lr_launch_status();
+}

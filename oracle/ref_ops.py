@@ -1,0 +1,239 @@
+"""oracle/ref_ops.py — TEST INFRASTRUCTURE ONLY.
+
+CPU restatement of the LiftReg hot path (uncbiag/LiftReg) with the SAME ATen op
+sequence the reference executes (F.grid_sample 2-D/3-D align_corners=True,
+conv3d + LeakyReLU(0.2), linear, mean/sqrt reductions), written against this
+repo's own data flow.  Every function cites the reference file:line it follows
+(paths relative to the reference checkout).
+
+Used as (i) the checker in tests/ and __graft_entry__.smoke(), and (ii) the
+`cpu_baseline` ("kind": "port") leg of bench.py — it is what the reference's
+Python would run on the host cores.  liftreg_amd never imports it.
+
+Parity status: PINNED — tests/test_oracle_golden.py checks every function here
+against golden vectors produced by importing the reference itself
+(tests/golden/make_golden.py), bit-for-bit for sampling grids and indices.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------- a1
+def calc_relative_atten_coef(img):
+    """src/liftreg/utils/sdct_projection_utils.py:6-9."""
+    new_img = np.asarray(img).astype(np.float32).copy()
+    new_img[new_img < -1000] = -1000
+    return (new_img + 1000.) / 1000. * 0.2
+
+
+# --------------------------------------------------------------------------- a2
+def scan_poses(scan_range, proj_num, W, y_scale=3.5):
+    """Emitter poses of calculate_projection_wraper (sdct_projection_utils.py:138-145,155).
+
+    Returns float64 (P,3) in voxel units: poses_scale * W.
+    """
+    angle_half = scan_range / 2.
+    poses_scale = np.ndarray((proj_num, 3), dtype=float)
+    poses_scale[:, 1] = y_scale
+    poses_scale[:, 0] = np.tan(np.linspace(-angle_half, angle_half, num=proj_num) / 180. * np.pi) * 3.
+    poses_scale[:, 2] = np.linspace(-0.2, 0.2, num=proj_num)
+    return poses_scale * W
+
+
+# --------------------------------------------------------------------------- a3
+def project_grid(poses, resolution, obj_shape, spacing, dtype=torch.float32):
+    """Ray/plane sample grid and dx of project_grid_multi (sdct_projection_utils.py:15-57).
+
+    Same per-element fp32 ops as the reference (its two K=1 matmuls at :50-51 are
+    plain products), expressed with broadcasting.  Returns grid (P,Rd,Rh,W,3) in
+    the reference's (x,y,z)=(D,W,H) order, normalised; dx (P,Rd,Rh).
+    """
+    d, w, h = obj_shape
+    res_d, res_h = resolution
+    e = torch.from_numpy(np.asarray(poses)).type(dtype)                    # I0 (:28)
+    lin_x = torch.linspace(-res_d / 2, res_d / 2 - 1, steps=res_d)          # :32
+    lin_y = torch.linspace(-res_h / 2, res_h / 2 - 1, steps=res_h)          # :33
+    I = torch.zeros((res_d, res_h, 3), dtype=dtype)
+    I[:, :, 0] = lin_x[:, None]
+    I[:, :, 2] = lin_y[None, :]
+    I = torch.add(I, -e[:, None, None, :])                                   # (P,Rd,Rh,3) :38
+    dx = torch.mul(I, 1. / I[..., 1:2])                                      # :39
+    I = I / torch.norm(I, dim=3, keepdim=True)                               # :40
+    dx = torch.norm(dx * torch.as_tensor(spacing, dtype=dtype)[None, None], dim=3)  # :41
+    yj = torch.linspace(0, w - 1, w, dtype=dtype)                            # P0 rows (:24-26)
+    t = (1. / I[..., 1])[..., None] * (yj[None, :] - e[:, 1:2])[:, None, None, :]   # T (:50)
+    grid = I[..., None, :] * t[..., None] + e[:, None, None, None, :]        # :51
+    grid[..., 0] = grid[..., 0] / d * 2.0                                    # :54
+    grid[..., 1] = (grid[..., 1] - 0.) / (w - 1.) * 2.0 + -1.                # :55
+    grid[..., 2] = grid[..., 2] / h * 2.0                                    # :56
+    return grid, dx
+
+
+# --------------------------------------------------------------------------- a4
+def drr_forward(img, poses, resolution, spacing):
+    """calculate_projection (sdct_projection_utils.py:59-100) on the CPU.
+
+    img: (D,W,H) fp32 attenuation volume (numpy); returns (P,Rd,Rh) fp32 numpy.
+    """
+    I0 = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32))[None, None]
+    grids, dx = project_grid(poses, resolution, I0.shape[2:], spacing, I0.dtype)
+    grids = torch.flip(grids, [4])                                           # :76
+    p, rd, rh, w = grids.shape[:4]
+    samp = F.grid_sample(I0, grids.reshape(1, 1, 1, -1, 3), align_corners=True)     # :81
+    out = torch.mul(torch.sum(samp.reshape(1, p, rd, rh, w), dim=4), dx).float()
+    out *= 0.1                                                               # :85
+    return out[0].numpy()
+
+
+# --------------------------------------------------------------------------- a6
+def backproj_grid(poses, img_shape, proj_shape):
+    """backproj_grids_with_poses (sdct_projection_utils.py:227-250); poses (1,P,3) fp32 numpy.
+
+    Returns (1,P,2,D,W,H): channel 0 pairs with the detector's Ph axis (grid x),
+    channel 1 with Pw (grid y) — i.e. after the reference's flip(2).
+    """
+    d, w, h = img_shape
+    proj_w, proj_h = proj_shape
+    x = torch.linspace(-d / 2, d / 2 - 1, d)
+    y = torch.linspace(w - 1, 0, w)
+    z = torch.linspace(-h / 2, h / 2 - 1, h)
+    gx, gy, gz = torch.meshgrid(x, y, z, indexing="ij")
+    ps = torch.from_numpy(np.asarray(poses))[..., None, None, None]          # (1,P,3,1,1,1)
+    scale = ps[:, :, 1:2] / (ps[:, :, 1:2] - gy)                              # :239
+    grids = torch.stack((gx, gz), dim=0)[None]                                # (1,2,D,W,H)
+    grids = grids - ps[:, :, ::2]                                             # :241
+    grids = torch.mul(grids, scale) + ps[:, :, ::2]                           # :242
+    grids[:, :, 0] = grids[:, :, 0] / proj_w * 2.0                            # :247
+    grids[:, :, 1] = grids[:, :, 1] / proj_h * 2.0                            # :248
+    return grids.flip(2)                                                      # :250
+
+
+# --------------------------------------------------------------------------- a7
+def backproject(target_proj, poses, img_shape):
+    """Backprojection of model._estimate_flow (LiftRegDeformSubspaceBackproj.py:85-93).
+
+    target_proj (B,P,Pw,Ph) tensor; poses (B,P,3) tensor/array — geometry of batch
+    element 0 is used for every sample, as the reference caches it (:85-87).
+    """
+    B, P, pw, ph = target_proj.shape
+    D, W, H = img_shape
+    p0 = np.asarray(poses, dtype=np.float32)[0:1]
+    g = backproj_grid(p0, (D, W, H), (pw, ph)).permute(0, 1, 3, 4, 5, 2)     # (1,P,D,W,H,2)
+    return F.grid_sample(target_proj.reshape(B * P, 1, pw, ph),
+                         g.expand(B, -1, -1, -1, -1, -1).reshape(B * P, D * W, H, -1),
+                         align_corners=True, padding_mode="zeros").reshape(B, P, D, W, H).detach()
+
+
+# --------------------------------------------------------------------------- a8/a9
+def conv_block(x, weight, bias, stride, slope=0.2):
+    """convBlock (layers/layers.py:335-372): Conv3d(k3,p1) + LeakyReLU(0.2)."""
+    return F.leaky_relu(F.conv3d(x, weight, bias, stride=stride, padding=1), slope)
+
+
+def fc_block(x, weight, bias, slope=0.2):
+    """FullyConnectBlock (layers/layers.py:413-439); slope=None → no nonlinearity."""
+    y = F.linear(x, weight, bias)
+    return y if slope is None else F.leaky_relu(y, slope)
+
+
+# --------------------------------------------------------------------------- a10
+def pca_reconstruct(coefs, pca_vectors_LxM, pca_mean):
+    """F.linear(x, pca_vectors, pca_mean) (…Backproj.py:42-43,102); basis given as the (L,3V) file."""
+    return F.linear(coefs, pca_vectors_LxM.T, pca_mean)
+
+
+# --------------------------------------------------------------------------- a11
+def identity_axis_tables(sz):
+    """The three 1-D tables whose outer broadcast is identity_map(sz) (net_utils.py:59-87).
+
+    Follows the reference's numpy arithmetic: float32 index * float64 spacing
+    (rounded back to float32 under numpy>=2 promotion rules), then *2-1 in float32.
+    """
+    spacing = 1. / (np.array(sz) - 1)
+    tabs = []
+    for d in range(3):
+        t = np.arange(sz[d]).astype(np.float32)
+        t *= spacing[d]
+        t = t * 2 - 1
+        tabs.append(t.astype(np.float32))
+    return tabs
+
+
+def identity_map(sz):
+    """identity_map (net_utils.py:59-87) → (3,D,W,H) float32 tensor."""
+    idm = np.mgrid[0:sz[0], 0:sz[1], 0:sz[2]]
+    idm = np.array(idm.astype(np.float32))
+    spacing = 1. / (np.array(sz) - 1)
+    for d in range(3):
+        idm[d] *= spacing[d]
+        idm[d] = idm[d] * 2 - 1
+    return torch.from_numpy(idm.astype(np.float32))
+
+
+# --------------------------------------------------------------------------- a12
+def warp(img, phi, zero_boundary=True, using_scale=True, mode="bilinear"):
+    """Bilinear.forward (net_utils.py:26-56)."""
+    ordered = torch.zeros_like(phi)
+    ordered[:, 0] = phi[:, 2]
+    ordered[:, 1] = phi[:, 1]
+    ordered[:, 2] = phi[:, 0]
+    pad = "zeros" if zero_boundary else "border"
+    src = (img + 1) / 2 if using_scale else img
+    out = F.grid_sample(src, ordered.permute(0, 2, 3, 4, 1), padding_mode=pad, mode=mode,
+                        align_corners=True)
+    return out * 2 - 1 if using_scale else out
+
+
+# --------------------------------------------------------------------------- a13
+def ncc_loss(inp, target):
+    """Configured NCCLoss (layers/losses.py:14-29)."""
+    inp = inp.reshape(inp.shape[0], -1)
+    target = target.reshape(target.shape[0], -1)
+    a = inp - torch.mean(inp, 1).view(inp.shape[0], 1) + 1e-10
+    b = target - torch.mean(target, 1).view(inp.shape[0], 1) + 1e-10
+    ncc = ((a * b).mean(1)) / torch.sqrt(((a ** 2).mean(1)) * ((b ** 2).mean(1)))
+    return 1 - ncc.mean()
+
+
+def ncc_loss_squared(x, y):
+    """NCCLoss variant (layers/layers.py:238-255)."""
+    n_batch = x.shape[0]
+    shp = [x.shape[0], x.shape[1], -1]
+    x = x.reshape(*shp)
+    y = y.reshape(*shp)
+    xm = x - x.mean(dim=2, keepdim=True)
+    ym = y - y.mean(dim=2, keepdim=True)
+    ncc_sqr = ((xm * ym).mean(dim=2) ** 2) / ((xm ** 2).mean(dim=2) * (ym ** 2).mean(dim=2) + 1e-12)
+    return 1. - ncc_sqr.mean(dim=1).sum() / n_batch
+
+
+# --------------------------------------------------------------------------- a14
+def model_forward(params, inp, pca_vectors_LxM, pca_mean, strides=(1, 2, 2, 2, 2, 2)):
+    """model.forward (LiftRegDeformSubspaceBackproj.py:49-104) on CPU tensors.
+
+    params: state-dict-like {encoders.i.conv.weight/bias, encoders.6.{1,2,3}.fc.weight/bias}.
+    The FC1 width is whatever params hold (the reference hard-codes 32*5^3 for 160^3, :36).
+    """
+    moving, target, target_proj = inp["source"], inp["target"], inp["target_proj"]
+    if "source_label" in inp:
+        moving_cp = (moving + 1) * inp["source_label"] - 1
+        target_cp = (target + 1) * inp["target_label"] - 1
+    else:
+        moving_cp, target_cp = moving, target
+    B, _, D, W, H = moving.shape
+    tv = backproject(target_proj, inp["target_poses"], (D, W, H))
+    x = torch.cat([moving, tv], dim=1)
+    for i, s in enumerate(strides):
+        x = conv_block(x, params[f"encoders.{i}.conv.weight"], params[f"encoders.{i}.conv.bias"], s)
+    x = x.flatten(1)
+    x = fc_block(x, params["encoders.6.1.fc.weight"], params["encoders.6.1.fc.bias"])
+    x = fc_block(x, params["encoders.6.2.fc.weight"], params["encoders.6.2.fc.bias"])
+    coefs = fc_block(x, params["encoders.6.3.fc.weight"], params["encoders.6.3.fc.bias"], slope=None)
+    disp = pca_reconstruct(coefs, pca_vectors_LxM, pca_mean).reshape(B, 3, D, W, H)
+    phi = disp + identity_map((D, W, H))
+    warped = warp(moving_cp, phi, zero_boundary=True, using_scale=True)
+    return {"warped": warped, "phi": phi, "params": disp, "target": target_cp, "pca_coefs": coefs,
+            "target_proj": target_proj, "warped_proj": target_proj, "target_volume": tv}
