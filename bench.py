@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py — registrations/s of the LiftReg hot path on MI355X.
+
+One "step" = one pass of the path over one batch of synthetic input, everything resident in HBM:
+    backproject → conv×6 (fp32 MFMA) → FC×3 → PCA reconstruct → identity add + trilinear warp → NCC
+on BASELINE.json's configs[2]: 256^3 CT, 2×256^2 DRR, batch 8, latent 56, fp32 ("c3").
+Multi-GPU: registrations are independent → one replica per GPU, no data-path collective (weak
+scaling); torch.distributed (RCCL) is used only for the barrier and the max-over-ranks time.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c1|c2|c3] [--no-cpu-baseline]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N … bench.py --gpus N …
+
+Prints ONE JSON line (rank 0).  `roofline` describes the kernel that takes the most time in the
+step, `roofline_backproject` the kernel BASELINE.json's metric names; both are measured live with
+HIP events on the launch stream inside the timed region.  `cpu_baseline` times the torch-CPU oracle
+(oracle/ref_ops.py — the reference's own ATen op sequence) on the host cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {  # BASELINE.json configs (single-GPU ones)
+    "c1": dict(n=64, P=2, R=64, B=1, L=56),
+    "c2": dict(n=128, P=2, R=128, B=4, L=56),
+    "c3": dict(n=256, P=2, R=256, B=8, L=56),
+}
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* fp32-input matrix peak
+
+
+def synth_inputs(cfg, dev, seed=2021):
+    """SURVEY §8(d) synthetic data, generated on the GPU (untimed): ellipsoid CT phantom in HU, moving =
+    target warped by a smooth random displacement, 2-view DRR of the flipped target via the HIP projector,
+    dataset normalisation (Registration2D3DDataset.py:186-209), poses of calculate_projection_wraper."""
+    from liftreg_amd import ops
+    from liftreg_amd.utils.sdct_projection_utils import scan_poses
+    from liftreg_amd.utils.net_utils import identity_axis_tables
+    n, P, R, B = cfg["n"], cfg["P"], cfg["R"], cfg["B"]
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    rs = np.random.RandomState(seed)
+    ax = torch.arange(n, dtype=torch.float32, device=dev)
+    z, y, x = ax[:, None, None], ax[None, :, None], ax[None, None, :]
+    poses = scan_poses(30, P, n)
+    p32 = poses.astype(np.float32)
+    ids = [torch.from_numpy(t).to(dev) for t in identity_axis_tables((n, n, n))]
+    src, tgt, prj = [], [], []
+    for _ in range(B):
+        hu = torch.full((n, n, n), -1000.0, device=dev)
+        for _e in range(8):
+            c = rs.uniform(0.25, 0.75, 3) * n
+            r = rs.uniform(0.1, 0.3, 3) * n
+            val = float(rs.choice([-850.0, 40.0, 400.0]))
+            m = ((z - c[0]) / r[0]) ** 2 + ((y - c[1]) / r[1]) ** 2 + ((x - c[2]) / r[2]) ** 2 < 1
+            hu = torch.where(m, torch.full_like(hu, val), hu)
+        hu = (hu + torch.randn(hu.shape, generator=g, device=dev) * 20).clamp_(-1024, 1000)
+        # DRR of the axis-1-flipped target (dataset orientation), HU→μ folded into the projector
+        drr = ops.drr_forward(hu, p32, (R, R), (2.2, 2.2, 2.2), hu_input=True, flip_w=True)
+        prj.append(drr.clamp(0, 6) / 6 * 2 - 1)
+        t_norm = (hu.clamp(-1000, 0) + 1000) / 1000 * 2 - 1
+        coarse = torch.randn((1, 3, 4, 4, 4), generator=g, device=dev) * 0.02
+        disp = torch.nn.functional.interpolate(coarse, size=(n, n, n), mode="trilinear", align_corners=True)
+        _, mov = ops.warp(t_norm[None, None].contiguous(), disp.contiguous(), ids, None, want_phi=False)
+        tgt.append(t_norm[None])
+        src.append(mov[0])
+    return {"source": torch.stack(src).contiguous(), "target": torch.stack(tgt).contiguous(),
+            "target_proj": torch.stack(prj).contiguous(),
+            "target_poses": torch.from_numpy(np.broadcast_to(p32, (B, P, 3)).copy())}
+
+
+def cpu_baseline(cfg, net, inp, budget_s=30.0):
+    """Torch-CPU oracle (the reference's ATen op sequence) on ONE registration of the same workload."""
+    import psutil
+    from oracle import ref_ops as ro
+    n, L = cfg["n"], cfg["L"]
+    need = 4 * (L * 3 * n ** 3) * 1.3 + 4 * 40 * n ** 3
+    if psutil.virtual_memory().available < need:
+        return {"value": None, "unit": "registrations/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": f"skipped: host has < {need / 2**30:.0f} GiB free for the PCA basis"}
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    one = {k: v[:1].cpu().contiguous() for k, v in inp.items()}
+    vec, mean = net.pca_vectors_LxM.cpu(), net.pca_mean.cpu()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        out = ro.model_forward(sd, one, vec, mean)
+        ro.ncc_loss(out["warped"], out["target"])
+        first = time.perf_counter() - t0
+        times = [first]
+        while sum(times) < budget_s and len(times) < 5:
+            t0 = time.perf_counter()
+            out = ro.model_forward(sd, one, vec, mean)
+            ro.ncc_loss(out["warped"], out["target"])
+            times.append(time.perf_counter() - t0)
+    best = float(np.median(times[1:])) if len(times) > 1 else first
+    return {"value": 1.0 / best, "unit": "registrations/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} x 1 registration (B=1) of the same {n}^3/{cfg['P']}-view workload, "
+                      f"torch {torch.__version__} CPU ops, median of runs after the first; s/reg={best:.3f}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    from liftreg_amd import ops
+    from liftreg_amd.layers.losses import NCCLoss
+    from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+
+    torch.manual_seed(2021)
+    n, P, B, L = cfg["n"], cfg["P"], cfg["B"], cfg["L"]
+    net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:2021"}).to(dev).eval()
+    inp = synth_inputs(cfg, dev, seed=2021 + rank)
+    sim = NCCLoss(check_nan=False)
+
+    def step():
+        out = net(inp)
+        return sim(out["warped"], out["target"])
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            loss = step()
+        fence()
+        with ops.kernel_timer() as kt:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                loss = step()
+            fence()
+            elapsed = time.perf_counter() - t0
+        ksum = kt.summary()
+    assert torch.isfinite(loss), "NCC is not finite"
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    value = world * B * args.steps / elapsed
+
+    # per-kernel roofline numbers from the live HIP-event timings
+    kernels = {}
+    for name, rec in ksum.items():
+        ms = float(np.mean(rec["ms"]))
+        info = rec["info"]
+        launches = len(rec["ms"]) / args.steps
+        k = {"avg_ms": ms, "launches_per_step": launches}
+        if "flops" in info:
+            k.update(bound="mfma", achieved=info["flops"] / (ms * 1e-3) / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s")
+        else:
+            k.update(bound="hbm", achieved=info["bytes"] / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        k["frac"] = k["achieved"] / k["peak"]
+        k["traffic"] = None
+        kernels[name] = k
+    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes per launch, if profiled
+    if os.path.exists(traffic_file):
+        with open(traffic_file) as fh:
+            for name, tb in json.load(fh).get(args.config, {}).items():
+                if name in kernels:
+                    kernels[name]["traffic"] = tb
+    dominant = max(kernels, key=lambda kname: kernels[kname]["avg_ms"] * kernels[kname]["launches_per_step"])
+
+    def roof(name):
+        k = kernels[name]
+        return {"kernel": name, "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
+                "unit": k["unit"], "frac": k["frac"], "traffic": k["traffic"], "avg_ms": k["avg_ms"]}
+
+    result = {
+        "metric": "registrations/sec (256^3 CT, 2-view DRR)" if args.config == "c3" else f"registrations/sec ({args.config})",
+        "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {n}^3 CT, {P}x{cfg['R']}^2 DRR, batch {B}/GPU, latent {L}, "
+                               "backproject+conv6(MFMA f32)+FC3+PCA+warp+NCC", "global_batch": world * B,
+                   "parallelism": f"replicas x{world} (independent registrations, no data-path collective)"},
+        "roofline": roof(dominant),
+        "roofline_backproject": roof("backproject"),
+        "backproj_hbm_GBps": kernels["backproject"]["achieved"],
+        "kernels": {k: {"ms": round(v["avg_ms"], 4), "n": v["launches_per_step"], "frac": round(v["frac"], 4),
+                        "bound": v["bound"]} for k, v in kernels.items()},
+        "ncc_loss": float(loss),
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cfg, net, inp)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

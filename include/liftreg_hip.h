@@ -73,11 +73,14 @@ int lr_drr_forward_f32(const float* vol_slab, const float* poses, const float* s
                        float* out, int D, int W, int H, int d0, int d1,
                        int P, int Rd, int Rh, int flags, int nseg, void* stream);
 
-/* Debug/parity: the un-normalised sample coordinates (pixel units, after
- * ATen's align_corners=True un-normalise) the projector uses, and dx.
+/* Parity / API compatibility (forward_grids_with_poses, sdct_projection_utils.py:252-265):
+ * the sample coordinates the projector uses and dx.
+ * normalized=0: pixel units after ATen's align_corners=True un-normalise;
+ * normalized=1: the reference's [-1,1] grid values before flip (x/D*2, y/(W-1)*2-1, z/H*2).
  * pix: dev (P,Rd,Rh,W,3) ordered (d,w,h); dx: dev (P,Rd,Rh). Either may be NULL. */
 int lr_drr_sample_coords_f32(const float* poses, const float* spacing, float* pix, float* dx,
-                             int D, int W, int H, int P, int Rd, int Rh, void* stream);
+                             int D, int W, int H, int P, int Rd, int Rh, int normalized,
+                             void* stream);
 
 /* ------------------------------------------------------------------------
  * K2  Backprojection (voxel-driven gather of the 2D views).
@@ -99,10 +102,11 @@ int lr_backproject_f32(const float* proj, const float* poses, float* out,
                        int B, int P, int Pw, int Ph, int D, int W, int H,
                        int d0, int d1, int64_t out_batch_stride, void* stream);
 
-/* Debug/parity: detector pixel coordinates of every voxel shadow.
+/* Parity / API compatibility (backproj_grids_with_poses): detector coordinates of every
+ * voxel shadow. normalized=0: pixel units; normalized=1: the reference's [-1,1] grid.
  * pix: dev (P,D,W,H,2) ordered (Pw axis, Ph axis). */
 int lr_backproject_coords_f32(const float* poses, float* pix, int P, int Pw, int Ph,
-                              int D, int W, int H, void* stream);
+                              int D, int W, int H, int normalized, void* stream);
 
 /* ------------------------------------------------------------------------
  * K3  Conv3d(k=3, pad=1, stride 1|2, bias) + LeakyReLU, implicit GEMM on

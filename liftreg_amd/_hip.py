@@ -1,0 +1,81 @@
+"""ctypes binding of libliftreg_hip.so (the C ABI declared in include/liftreg_hip.h).
+
+There is NO CPU or PyTorch fallback: if the library is missing or was built for
+another target, importing the ops raises.  The library is built in-tree by
+`__graft_entry__.build()` / `make -C liftreg_amd/csrc` (hipcc --offload-arch=gfx950).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libliftreg_hip.so")
+
+LR_OK = 0
+LAYOUT_NCDHW, LAYOUT_NDHWC = 0, 1
+DRR_HU_INPUT, DRR_FLIP_W = 1, 2
+WARP_USING_SCALE, WARP_BORDER, WARP_NEAREST = 1, 2, 4
+NCC_CONFIGURED, NCC_SQUARED = 0, 1
+MAX_VIEWS = 32
+
+_p = C.c_void_p
+_i, _i64, _f = C.c_int, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); mirrors include/liftreg_hip.h one to one
+SIGNATURES = {
+    "lr_strerror": (C.c_char_p, [_i]),
+    "lr_abi_version": (_i, []),
+    "lr_target_arch": (C.c_char_p, []),
+    "lr_drr_forward_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "lr_drr_sample_coords_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "lr_backproject_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _p]),
+    "lr_backproject_coords_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "lr_conv3d_packed_floats": (_i64, [_i, _i, _i]),
+    "lr_conv3d_pack_weights_f32": (_i, [_p, _p, _i, _i, _i, _p]),
+    "lr_conv3d_k3_lrelu_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "lr_linear_lrelu_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _p]),
+    "lr_pca_reconstruct_f32": (_i, [_p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _p]),
+    "lr_warp_trilinear_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "lr_mask_compose_f32": (_i, [_p, _p, _p, _i64, _p]),
+    "lr_ncc_moments_f32": (_i, [_p, _p, _p, _p, _i, _i64, _i, _p]),
+    "lr_ncc_loss_from_moments": (_i, [_p, _p, _p, _i, _i64, _i, _i, _p]),
+}
+
+
+class LiftRegHipError(RuntimeError):
+    pass
+
+
+def build_library(force=False, quiet=True):
+    """Compile libliftreg_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j8"] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL if quiet else None)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises LiftRegHipError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LiftRegHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C liftreg_amd/csrc` — liftreg_amd has no CPU/PyTorch fallback path")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        if handle.lr_target_arch() != b"gfx950":
+            raise LiftRegHipError("libliftreg_hip.so was not built for gfx950")
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != LR_OK:
+        raise LiftRegHipError(f"{what}: {lib().lr_strerror(code).decode()} ({code})")

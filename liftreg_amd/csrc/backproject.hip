@@ -16,12 +16,15 @@ namespace {
 
 // Pixel coordinate along the Pw axis (detector rows) of voxel row x, plane y.
 // grids = (x - ex) * scale + ex ; /proj_w * 2.0 ; ATen un-normalise.
-__device__ __forceinline__ float shadow_pix(float x, float e, float scale, float fsize, int size) {
+__device__ __forceinline__ float shadow_grid(float x, float e, float scale, float fsize) {
   float g = (x - e) * scale;  // torch.mul(grids - poses, scale)
   g = g + e;                  // + poses[:, :, ::2]
   g = g / fsize;              // grids[:, :, c] / proj_w
   g = g * 2.0f;               // * 2.0
-  return lr_unnormalize(g, size);
+  return g;
+}
+__device__ __forceinline__ float shadow_pix(float x, float e, float scale, float fsize, int size) {
+  return lr_unnormalize(shadow_grid(x, e, scale, fsize), size);
 }
 
 struct Tap {
@@ -116,7 +119,8 @@ __global__ __launch_bounds__(256) void backproject_kernel(
 }
 
 __global__ __launch_bounds__(256) void backproject_coords_kernel(
-    LrPoses poses, float* __restrict__ pix, int P, int Pw, int Ph, int D, int W, int H) {
+    LrPoses poses, float* __restrict__ pix, int P, int Pw, int Ph, int D, int W, int H,
+    int normalized) {
   const int64_t total = (int64_t)P * D * W * H;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
@@ -131,8 +135,9 @@ __global__ __launch_bounds__(256) void backproject_coords_kernel(
   const float y = (float)(W - 1 - j);
   const float z = (float)k - 0.5f * (float)H;
   const float scale = ey / (ey - y);
-  pix[idx * 2 + 0] = shadow_pix(x, ex, scale, (float)Pw, Pw);
-  pix[idx * 2 + 1] = shadow_pix(z, ez, scale, (float)Ph, Ph);
+  const float gu = shadow_grid(x, ex, scale, (float)Pw), gv = shadow_grid(z, ez, scale, (float)Ph);
+  pix[idx * 2 + 0] = normalized ? gu : lr_unnormalize(gu, Pw);
+  pix[idx * 2 + 1] = normalized ? gv : lr_unnormalize(gv, Ph);
 }
 
 int fill_poses(LrPoses& lp, const float* poses, int P) {
@@ -170,7 +175,7 @@ extern "C" int lr_backproject_f32(const float* proj, const float* poses, float* 
 }
 
 extern "C" int lr_backproject_coords_f32(const float* poses, float* pix, int P, int Pw, int Ph,
-                                         int D, int W, int H, void* stream) {
+                                         int D, int W, int H, int normalized, void* stream) {
   if (!pix) return LR_ENULL;
   if (Pw < 1 || Ph < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
   LrPoses lp;
@@ -179,6 +184,6 @@ extern "C" int lr_backproject_coords_f32(const float* poses, float* pix, int P, 
   const int64_t nblk = (total + 255) / 256;
   if (nblk > 0x7fffffffLL) return LR_EINVAL;
   hipLaunchKernelGGL(backproject_coords_kernel, dim3((unsigned)nblk), dim3(256), 0,
-                     lr_stream(stream), lp, pix, P, Pw, Ph, D, W, H);
+                     lr_stream(stream), lp, pix, P, Pw, Ph, D, W, H, normalized);
   return lr_launch_status();
 }

@@ -47,15 +47,20 @@ __device__ __forceinline__ RaySetup ray_setup(int a, int b, int Rd, int Rh, floa
 
 // Sample position on plane y=j in ATen pixel units (d,w,h): grid = Î*T + e (:50-51),
 // normalise (:54-56), un-normalise align_corners=True.
-__device__ __forceinline__ void sample_pix(const RaySetup& r, int j, float ex, float ey, float ez,
-                                           int D, int W, int H, float& pd, float& pw, float& ph) {
+__device__ __forceinline__ void sample_grid(const RaySetup& r, int j, float ex, float ey, float ez,
+                                            int D, int W, int H, float& gx, float& gy, float& gz) {
   const float t = r.rc * ((float)j - ey);
   const float x = r.ihx * t + ex;
   const float y = r.ihy * t + ey;
   const float z = r.ihz * t + ez;
-  const float gx = (x / (float)D) * 2.0f;
-  const float gy = ((y - 0.0f) / ((float)W - 1.0f)) * 2.0f + -1.0f;
-  const float gz = (z / (float)H) * 2.0f;
+  gx = (x / (float)D) * 2.0f;
+  gy = ((y - 0.0f) / ((float)W - 1.0f)) * 2.0f + -1.0f;
+  gz = (z / (float)H) * 2.0f;
+}
+__device__ __forceinline__ void sample_pix(const RaySetup& r, int j, float ex, float ey, float ez,
+                                           int D, int W, int H, float& pd, float& pw, float& ph) {
+  float gx, gy, gz;
+  sample_grid(r, j, ex, ey, ez, D, W, H, gx, gy, gz);
   pd = lr_unnormalize(gx, D);
   pw = lr_unnormalize(gy, W);
   ph = lr_unnormalize(gz, H);
@@ -177,7 +182,8 @@ __global__ __launch_bounds__(1024) void drr_forward_kernel(
 __global__ __launch_bounds__(256) void drr_coords_kernel(LrPoses poses, float sp0, float sp1,
                                                          float sp2, float* __restrict__ pix,
                                                          float* __restrict__ dx, int D, int W,
-                                                         int H, int P, int Rd, int Rh) {
+                                                         int H, int P, int Rd, int Rh,
+                                                         int normalized) {
   const int64_t total = (int64_t)P * Rd * Rh;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
@@ -190,7 +196,8 @@ __global__ __launch_bounds__(256) void drr_coords_kernel(LrPoses poses, float sp
   if (pix) {
     for (int j = 0; j < W; ++j) {
       float pd, pw, ph;
-      sample_pix(rs, j, ex, ey, ez, D, W, H, pd, pw, ph);
+      if (normalized) sample_grid(rs, j, ex, ey, ez, D, W, H, pd, pw, ph);
+      else sample_pix(rs, j, ex, ey, ez, D, W, H, pd, pw, ph);
       float* o = pix + (idx * W + j) * 3;
       o[0] = pd;
       o[1] = pw;
@@ -246,7 +253,7 @@ extern "C" int lr_drr_forward_f32(const float* vol_slab, const float* poses, con
 
 extern "C" int lr_drr_sample_coords_f32(const float* poses, const float* spacing, float* pix,
                                         float* dx, int D, int W, int H, int P, int Rd, int Rh,
-                                        void* stream) {
+                                        int normalized, void* stream) {
   if (!spacing) return LR_ENULL;
   if (!pix && !dx) return LR_ENULL;
   if (D < 1 || W < 2 || H < 1 || Rd < 1 || Rh < 1) return LR_EINVAL;
@@ -255,6 +262,6 @@ extern "C" int lr_drr_sample_coords_f32(const float* poses, const float* spacing
   const int64_t total = (int64_t)P * Rd * Rh;
   const int64_t nblk = (total + 255) / 256;
   hipLaunchKernelGGL(drr_coords_kernel, dim3((unsigned)nblk), dim3(256), 0, lr_stream(stream), lp,
-                     spacing[0], spacing[1], spacing[2], pix, dx, D, W, H, P, Rd, Rh);
+                     spacing[0], spacing[1], spacing[2], pix, dx, D, W, H, P, Rd, Rh, normalized);
   return lr_launch_status();
 }

@@ -1,0 +1,27 @@
+"""Similarity losses (src/liftreg/layers/losses.py)."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._hip import NCC_CONFIGURED
+from .layers import _no_autograd
+
+
+class NCCLoss(nn.Module):
+    """Configured NCC similarity (layers/losses.py:14-29; cur_task_setting.json:51):
+    1 - mean_b( mean(ab) / sqrt(mean(a²)·mean(b²)) ), a = x-mean(x)+1e-10.
+
+    One streaming pass over both volumes on the GPU.  Like the reference it asserts the
+    result is not NaN (a tiny D2H read); pass check_nan=False to stay asynchronous.
+    """
+
+    def __init__(self, check_nan=True):
+        super().__init__()
+        self.check_nan = check_nan
+
+    def forward(self, input, target):
+        _no_autograd(input, target)
+        loss = ops.ncc_loss(input, target, NCC_CONFIGURED)
+        if self.check_nan:
+            assert not torch.isnan(loss), 'NCC loss is Nan.'
+        return loss

@@ -1,0 +1,193 @@
+"""The configured LiftReg model (cur_task_setting.json:60) on the HIP kernels.
+
+Same constructor, `forward(dict) -> dict` contract, output keys and state-dict keys as
+src/liftreg/models/LiftRegDeformSubspaceBackproj.py:9-113, so the reference's harness
+(`RegistrationNet.py:95,396,410`) can load it through `train.model_class`:
+
+    "model_class": "liftreg_amd.models.LiftRegDeformSubspaceBackproj.model"
+
+Data flow (one registration batch, all on the GPU, no sampling grid is ever materialised):
+    target_proj ──backproject──► channels 1..P of the encoder input (NCDHW, written in place)
+    moving ─────────────────────► channel 0
+    encoder input ─conv0(NCDHW→NDHWC)─conv1..4(NDHWC)─conv5(NDHWC→NCDHW)─► flatten ─FC×3─► coefs
+    coefs ──pca_reconstruct──► disp (B,3,D,W,H)
+    disp, moving(,seg) ──warp (adds the identity map, samples)──► phi, warped
+Differences from the reference that are deliberate: the flatten width is 32·(n/32)³ instead of
+the hard-coded 32·5³ (:36, 160³ only); tensors follow the input's device instead of `.cuda()`
+in the constructor; `opt["pca_path"]` may be "synthetic[:seed]" for benchmarks.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..layers.layers import convBlock, FullyConnectBlock, GaussianSmoothing, _no_autograd
+from ..utils.net_utils import Bilinear, identity_axis_tables
+
+
+def _out_size(n, strides):
+    for s in strides:
+        n = (n - 1) // s + 1
+    return n
+
+
+class model(nn.Module):
+    """Estimates the coefficients of a pre-built PCA subspace of the displacement field.
+
+    :param img_sz: voxel shape [D, W, H]
+    :param opt: mapping with "drr_feature_num" (P), "latent_dim" (L), "pca_path"
+    """
+
+    def __init__(self, img_sz, opt=None):
+        super().__init__()
+        enc_filters = [16, 32, 32, 32, 32, 32]
+        self.input_channel = 2
+        self.output_channel = 3
+        self.img_sz = [int(v) for v in img_sz]
+        self.gaussian_smooth = GaussianSmoothing(4, 8, 2, dim=2)  # state-dict parity only
+        self.drr_feature_num = int(opt["drr_feature_num"])
+        self.latent_dim = int(opt["latent_dim"])
+
+        self.encoders = nn.ModuleList()
+        self.bilinear = Bilinear(zero_boundary=True, using_scale=True)
+        self.strides = [1, 2, 2, 2, 2, 2]
+        last = len(enc_filters) - 1
+        for i, f in enumerate(enc_filters):
+            cin = self.drr_feature_num + 1 if i == 0 else enc_filters[i - 1]
+            self.encoders.append(convBlock(
+                cin, f, stride=self.strides[i], bias=True,
+                in_layout=ops.LAYOUT_NCDHW if i == 0 else ops.LAYOUT_NDHWC,
+                out_layout=ops.LAYOUT_NCDHW if i == last else ops.LAYOUT_NDHWC))
+        flat = enc_filters[-1] * int(np.prod([_out_size(n, self.strides) for n in self.img_sz]))
+        self.encoders.append(nn.Sequential(
+            nn.Flatten(),
+            FullyConnectBlock(flat, 800),
+            FullyConnectBlock(800, 256),
+            FullyConnectBlock(256, self.latent_dim, nonlinear=None)))
+
+        # PCA basis: kept as the (L, 3V) C-contiguous array of pca_vectors.npy; the reference's
+        # `.T` view (…Backproj.py:42) is exposed as the `pca_vectors` property.  Non-persistent
+        # buffers: they follow .to()/.cuda() but stay out of state_dict() like the reference's
+        # plain attributes.
+        M = 3 * int(np.prod(self.img_sz))
+        pca_path = opt["pca_path"]
+        if isinstance(pca_path, str) and pca_path.startswith("synthetic"):
+            self._synthetic_seed = int(pca_path.split(":")[1]) if ":" in pca_path else 2021
+            vec = torch.empty((0, M))
+            mean = torch.empty((0,))
+        else:
+            self._synthetic_seed = None
+            vec = torch.from_numpy(np.load(f"{pca_path}/pca_vectors.npy")).float()
+            mean = torch.from_numpy(np.load(f"{pca_path}/pca_mean.npy")).float()
+            if tuple(vec.shape) != (self.latent_dim, M) or tuple(mean.shape) != (M,):
+                raise ValueError(f"pca_vectors.npy must be ({self.latent_dim},{M}), pca_mean.npy ({M},)")
+        self.register_buffer("pca_vectors_LxM", vec.contiguous(), persistent=False)
+        self.register_buffer("pca_mean", mean.contiguous(), persistent=False)
+
+        t0, t1, t2 = identity_axis_tables(self.img_sz)
+        self.register_buffer("_id0", torch.from_numpy(t0), persistent=False)
+        self.register_buffer("_id1", torch.from_numpy(t1), persistent=False)
+        self.register_buffer("_id2", torch.from_numpy(t2), persistent=False)
+        self._poses = None         # geometry of the first batch's element 0, cached like :85-87
+        self._packed = {}          # conv weights in MFMA operand order, keyed by parameter version
+
+    # ------------------------------------------------------------------ reference-compatible surface
+    @property
+    def pca_vectors(self):
+        return self.pca_vectors_LxM.T
+
+    @property
+    def id_transform(self):
+        return torch.stack(torch.broadcast_tensors(self._id0[:, None, None], self._id1[None, :, None],
+                                                   self._id2[None, None, :]))
+
+    def get_extra_to_plot(self):
+        return None, None
+
+    def get_disp(self):
+        return None, ""
+
+    def reset_geometry(self):
+        """Forget the cached emitter geometry (the reference can only do this by rebuilding the model)."""
+        self._poses = None
+
+    def set_pca(self, vectors_LxM, mean):
+        if tuple(vectors_LxM.shape) != (self.latent_dim, 3 * int(np.prod(self.img_sz))):
+            raise ValueError("basis must be (latent_dim, 3*D*W*H)")
+        self.pca_vectors_LxM = vectors_LxM.contiguous()
+        self.pca_mean = mean.contiguous()
+
+    # ------------------------------------------------------------------ internals
+    def _ensure_pca(self, device):
+        if self.pca_vectors_LxM.numel() == 0:
+            if self._synthetic_seed is None:
+                raise RuntimeError("PCA basis missing")
+            # randn(L,3V)*(0.02/sqrt(L)), mean 0, generated on the device in row chunks
+            g = torch.Generator(device=device)
+            g.manual_seed(self._synthetic_seed)
+            M = 3 * int(np.prod(self.img_sz))
+            vec = torch.empty((self.latent_dim, M), dtype=torch.float32, device=device)
+            for l in range(self.latent_dim):
+                vec[l].normal_(0.0, 0.02 / float(np.sqrt(self.latent_dim)), generator=g)
+            self.pca_vectors_LxM = vec
+            self.pca_mean = torch.zeros((M,), dtype=torch.float32, device=device)
+
+    def _packed_weight(self, i):
+        blk = self.encoders[i]
+        w = blk.conv.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        hit = self._packed.get(i)
+        if hit is None or hit[0] != key:
+            hit = (key, ops.conv3d_pack_weights(w, blk.in_layout))
+            self._packed[i] = hit
+        return hit[1]
+
+    def _estimate_flow(self, moving, target_proj, poses):
+        B, _, D, W, H = moving.shape
+        P = target_proj.shape[1]
+        if self._poses is None:
+            p = poses.detach().cpu().numpy() if isinstance(poses, torch.Tensor) else np.asarray(poses)
+            self._poses = np.ascontiguousarray(p[0], dtype=np.float32)  # poses[0:1] (:87)
+        V = D * W * H
+        # encoder input = cat([moving, target_volume], dim=1) (:95-98), built in place
+        x = torch.empty((B, P + 1, D, W, H), dtype=torch.float32, device=moving.device)
+        x[:, 0:1].copy_(moving)
+        ops.backproject(target_proj, self._poses, (D, W, H), out=x[:, 1:], out_batch_stride=(P + 1) * V)
+        for i in range(6):
+            blk = self.encoders[i]
+            x = ops.conv3d_k3_lrelu(x, blk.conv.weight, blk.conv.bias, blk.stride, in_layout=blk.in_layout,
+                                    out_layout=blk.out_layout, negative_slope=blk._slope,
+                                    packed=self._packed_weight(i))
+        coefs = self.encoders[6](x)
+        disp = ops.pca_reconstruct(coefs, self.pca_vectors_LxM, self.pca_mean).view(B, 3, D, W, H)
+        return coefs, disp
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input):
+        moving = input['source']
+        target = input['target']
+        target_proj = input["target_proj"]
+        _no_autograd(moving, target_proj, *self.parameters())
+        if tuple(moving.shape[2:]) != tuple(self.img_sz):
+            raise ValueError(f"model was built for {self.img_sz}, got {tuple(moving.shape[2:])}")
+        self._ensure_pca(moving.device)
+        if 'source_label' in input:
+            moving_seg = input['source_label']
+            target_cp = ops.mask_compose(target, input['target_label'])   # (target+1)*target_seg-1
+        else:
+            moving_seg = None
+            target_cp = target
+
+        coefs, disp_field = self._estimate_flow(moving, target_proj, input['target_poses'])
+
+        # deform_field = disp + id ; warped = Bilinear(moving_cp, deform_field): one kernel; the mask
+        # compose of moving ((moving+1)*seg-1, :57) happens on the taps
+        deform_field, warped_source = ops.warp(moving, disp_field, (self._id0, self._id1, self._id2),
+                                               moving_seg, using_scale=True, zero_boundary=True)
+        return {"warped": warped_source,
+                "phi": deform_field,
+                "params": disp_field,
+                "target": target_cp,
+                "pca_coefs": coefs,
+                "target_proj": target_proj,
+                "warped_proj": target_proj}

@@ -1,0 +1,360 @@
+"""Tensor-level front-end of the HIP kernels (liftreg_amd/csrc → libliftreg_hip.so).
+
+PyTorch is plumbing here: device memory, the current HIP stream and (elsewhere)
+torch.distributed.  Every function validates its tensors, allocates outputs with
+torch.empty and launches through the C ABI on torch's current stream.  There is no
+CPU path: a CPU tensor or a missing library raises.
+"""
+import contextlib
+
+import numpy as np
+import torch
+
+from . import _hip
+
+LAYOUT_NCDHW, LAYOUT_NDHWC = _hip.LAYOUT_NCDHW, _hip.LAYOUT_NDHWC
+
+
+# ----------------------------------------------------------------------------- helpers
+def _dev(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise _hip.LiftRegHipError(f"{name}: tensor is on {t.device}; liftreg_amd ops run on the GPU only "
+                                   "(no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _host_f32(a, shape_tail, name):
+    """Small host-side parameter (poses, spacing) as a contiguous float32 numpy array."""
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    a = np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+    if a.shape[-len(shape_tail):] != tuple(shape_tail):
+        raise ValueError(f"{name}: expected trailing shape {shape_tail}, got {a.shape}")
+    return a
+
+
+class KernelTimer:
+    """Records a HIP event pair (on the launch stream) around every op while active."""
+
+    def __init__(self):
+        self.records = []  # (name, start, end, info)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, s, e, info in self.records:
+            d = out.setdefault(name, {"ms": [], "info": info})
+            d["ms"].append(s.elapsed_time(e))
+        return out
+
+
+_timer = None
+
+
+@contextlib.contextmanager
+def kernel_timer():
+    """`with kernel_timer() as t:` … t.summary() → {op: {"ms": [per-launch], "info": …}}."""
+    global _timer
+    prev, _timer = _timer, KernelTimer()
+    try:
+        yield _timer
+    finally:
+        _timer = prev
+
+
+@contextlib.contextmanager
+def _timed(name, **info):
+    if _timer is None:
+        yield
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    yield
+    e.record()
+    _timer.records.append((name, s, e, info))
+
+
+# ----------------------------------------------------------------------------- K1 DRR
+def drr_forward(vol, poses, resolution, spacing=(2.2, 2.2, 2.2), *, d0=0, d1=None, full_D=None,
+                hu_input=False, flip_w=False, nseg=0, out=None):
+    """Cone-beam DRR of `vol` (Ds,W,H) = rows [d0,d1) of a (D,W,H) volume → (P,Rd,Rh).
+
+    Replaces calculate_projection (reference sdct_projection_utils.py:59-100).
+    """
+    vol = _dev(vol, "vol")
+    if vol.dim() != 3:
+        raise ValueError("vol must be (D,W,H)")
+    Ds, W, H = vol.shape
+    D = Ds if full_D is None else int(full_D)
+    d1 = D if d1 is None else int(d1)
+    if d1 - d0 != Ds:
+        raise ValueError(f"slab rows [{d0},{d1}) do not match vol.shape[0]={Ds}")
+    poses = _host_f32(poses, (3,), "poses").reshape(-1, 3)
+    sp = _host_f32(spacing, (3,), "spacing")
+    P = poses.shape[0]
+    Rd, Rh = int(resolution[0]), int(resolution[1])
+    if out is None:
+        out = torch.empty((P, Rd, Rh), dtype=torch.float32, device=vol.device)
+    else:
+        out = _dev(out, "out")
+    flags = (_hip.DRR_HU_INPUT if hu_input else 0) | (_hip.DRR_FLIP_W if flip_w else 0)
+    with _timed("drr_forward", bytes=4 * (Ds * W * H + P * Rd * Rh)):
+        _hip.check(_hip.lib().lr_drr_forward_f32(vol.data_ptr(), poses.ctypes.data, sp.ctypes.data,
+                                                 out.data_ptr(), D, W, H, d0, d1, P, Rd, Rh, flags, nseg,
+                                                 _stream()), "lr_drr_forward_f32")
+    return out
+
+
+def drr_sample_coords(poses, spacing, shape, resolution, device, normalized=False):
+    """(pix (P,Rd,Rh,W,3) ordered (d,w,h), dx (P,Rd,Rh)) — the projector's sample grid."""
+    D, W, H = (int(v) for v in shape)
+    Rd, Rh = int(resolution[0]), int(resolution[1])
+    poses = _host_f32(poses, (3,), "poses").reshape(-1, 3)
+    sp = _host_f32(spacing, (3,), "spacing")
+    P = poses.shape[0]
+    pix = torch.empty((P, Rd, Rh, W, 3), dtype=torch.float32, device=device)
+    dx = torch.empty((P, Rd, Rh), dtype=torch.float32, device=device)
+    _dev(pix, "pix")
+    _hip.check(_hip.lib().lr_drr_sample_coords_f32(poses.ctypes.data, sp.ctypes.data, pix.data_ptr(),
+                                                   dx.data_ptr(), D, W, H, P, Rd, Rh, int(normalized),
+                                                   _stream()), "lr_drr_sample_coords_f32")
+    return pix, dx
+
+
+# ----------------------------------------------------------------------------- K2 backprojection
+def backproject(proj, poses, img_shape, *, d0=0, d1=None, out=None, out_batch_stride=None):
+    """(B,P,Pw,Ph) views → (B,P,Ds,W,H) feature volume for ONE emitter geometry `poses` (P,3).
+
+    Replaces backproj_grids_with_poses + F.grid_sample (reference …Backproj.py:85-93).
+    `out` may be a view into a larger buffer whose batch stride is `out_batch_stride`
+    elements (writing straight into channels 1..P of the encoder input).
+    """
+    proj = _dev(proj, "proj")
+    B, P, Pw, Ph = proj.shape
+    D, W, H = (int(v) for v in img_shape)
+    d1 = D if d1 is None else int(d1)
+    Ds = d1 - d0
+    poses = _host_f32(poses, (3,), "poses").reshape(-1, 3)
+    if poses.shape[0] != P:
+        raise ValueError(f"poses has {poses.shape[0]} views, proj has {P}")
+    if out is None:
+        out = torch.empty((B, P, Ds, W, H), dtype=torch.float32, device=proj.device)
+        out_batch_stride = P * Ds * W * H
+        optr = out.data_ptr()
+    else:
+        if not out.is_cuda or out.dtype != torch.float32:
+            raise TypeError("out must be a float32 GPU tensor")
+        if out_batch_stride is None:
+            out = _dev(out, "out")
+            out_batch_stride = P * Ds * W * H
+        optr = out.data_ptr()
+    with _timed("backproject", bytes=4 * (B * P * Ds * W * H + B * P * Pw * Ph), samples=B):
+        _hip.check(_hip.lib().lr_backproject_f32(proj.data_ptr(), poses.ctypes.data, optr, B, P, Pw, Ph, D, W,
+                                                 H, d0, d1, int(out_batch_stride), _stream()),
+                   "lr_backproject_f32")
+    return out
+
+
+def backproject_coords(poses, img_shape, proj_shape, device, normalized=False):
+    """(P,D,W,H,2) detector coordinates (Pw axis, Ph axis) of every voxel's shadow."""
+    D, W, H = (int(v) for v in img_shape)
+    Pw, Ph = int(proj_shape[0]), int(proj_shape[1])
+    poses = _host_f32(poses, (3,), "poses").reshape(-1, 3)
+    P = poses.shape[0]
+    pix = torch.empty((P, D, W, H, 2), dtype=torch.float32, device=device)
+    _dev(pix, "pix")
+    _hip.check(_hip.lib().lr_backproject_coords_f32(poses.ctypes.data, pix.data_ptr(), P, Pw, Ph, D, W, H,
+                                                    int(normalized), _stream()), "lr_backproject_coords_f32")
+    return pix
+
+
+# ----------------------------------------------------------------------------- K3 conv
+def conv3d_pack_weights(weight, in_layout):
+    """(Cout,Cin,3,3,3) → MFMA B-operand order for lr_conv3d_k3_lrelu_f32."""
+    weight = _dev(weight.detach(), "weight")
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    if tuple(weight.shape[2:]) != (3, 3, 3):
+        raise ValueError("kernel must be 3x3x3")
+    n = _hip.lib().lr_conv3d_packed_floats(Cin, Cout, in_layout)
+    if n < 0:
+        _hip.check(int(n), "lr_conv3d_packed_floats")
+    packed = torch.empty((n,), dtype=torch.float32, device=weight.device)
+    _hip.check(_hip.lib().lr_conv3d_pack_weights_f32(weight.data_ptr(), packed.data_ptr(), Cin, Cout, in_layout,
+                                                     _stream()), "lr_conv3d_pack_weights_f32")
+    return packed
+
+
+def conv3d_k3_lrelu(x, weight, bias, stride, *, in_layout=LAYOUT_NCDHW, out_layout=LAYOUT_NCDHW,
+                    negative_slope=0.2, packed=None):
+    """LeakyReLU(Conv3d(k3,p1,stride)(x)+b).  x is (B,Cin,D,W,H) for NCDHW, (B,D,W,H,Cin) for NDHWC.
+
+    Replaces convBlock (reference layers/layers.py:335-372).
+    """
+    x = _dev(x, "x")
+    if x.dim() != 5:
+        raise ValueError("x must be 5-D")
+    if in_layout == LAYOUT_NCDHW:
+        B, Cin, D, W, H = x.shape
+    else:
+        B, D, W, H, Cin = x.shape
+    Cout = weight.shape[0]
+    if weight.shape[1] != Cin:
+        raise ValueError(f"weight expects Cin={weight.shape[1]}, input has {Cin}")
+    if packed is None:
+        packed = conv3d_pack_weights(weight, in_layout)
+    b = None if bias is None else _dev(bias.detach(), "bias")
+    o = lambda n: (n - 1) // stride + 1
+    Do, Wo, Ho = o(D), o(W), o(H)
+    shape = (B, Cout, Do, Wo, Ho) if out_layout == LAYOUT_NCDHW else (B, Do, Wo, Ho, Cout)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    flops = 2.0 * 27 * Cin * Cout * B * Do * Wo * Ho
+    with _timed(f"conv3d_c{Cin}x{Cout}_s{stride}", flops=flops,
+                bytes=4 * (x.numel() + y.numel()), samples=B):
+        _hip.check(_hip.lib().lr_conv3d_k3_lrelu_f32(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B,
+                                                     Cin, Cout, D, W, H, stride, in_layout, out_layout,
+                                                     float(negative_slope), _stream()), "lr_conv3d_k3_lrelu_f32")
+    return y
+
+
+# ----------------------------------------------------------------------------- K4 linear
+def linear_lrelu(x, weight, bias, negative_slope=1.0):
+    """act(x @ W^T + b), B <= 32.  Replaces FullyConnectBlock (reference layers/layers.py:413-439)."""
+    x = _dev(x, "x")
+    w = _dev(weight.detach(), "weight")
+    b = None if bias is None else _dev(bias.detach(), "bias")
+    B, K = x.shape
+    O = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"weight expects K={w.shape[1]}, input has {K}")
+    y = torch.empty((B, O), dtype=torch.float32, device=x.device)
+    with _timed(f"linear_{K}x{O}", bytes=4 * (w.numel() + x.numel() + y.numel())):
+        _hip.check(_hip.lib().lr_linear_lrelu_f32(x.data_ptr(), w.data_ptr(), _ptr(b), y.data_ptr(), B, K, O,
+                                                  float(negative_slope), _stream()), "lr_linear_lrelu_f32")
+    return y
+
+
+# ----------------------------------------------------------------------------- K5 PCA
+def pca_reconstruct(coefs, basis_LxM, mean, *, out=None):
+    """disp (B,M) = coefs (B,L) @ basis (L,M) + mean (M).  Replaces F.linear at …Backproj.py:102.
+
+    `basis_LxM` may be a column slab view (stride(0) >= M) of the full (L,3V) basis.
+    """
+    coefs = _dev(coefs, "coefs")
+    if not basis_LxM.is_cuda or basis_LxM.dtype != torch.float32 or basis_LxM.stride(1) != 1:
+        raise TypeError("basis must be a float32 GPU tensor with unit column stride")
+    mean = _dev(mean, "mean")
+    B, L = coefs.shape
+    M = basis_LxM.shape[1]
+    if basis_LxM.shape[0] != L or mean.shape[0] != M:
+        raise ValueError("basis/mean shape mismatch")
+    if out is None:
+        out = torch.empty((B, M), dtype=torch.float32, device=coefs.device)
+    else:
+        out = _dev(out, "out")
+    with _timed("pca_reconstruct", bytes=4 * (L * M + M + B * M), samples=B):
+        _hip.check(_hip.lib().lr_pca_reconstruct_f32(coefs.data_ptr(), basis_LxM.data_ptr(), mean.data_ptr(),
+                                                     out.data_ptr(), B, L, M, basis_LxM.stride(0), M, _stream()),
+                   "lr_pca_reconstruct_f32")
+    return out
+
+
+# ----------------------------------------------------------------------------- K6/K7 warp
+def warp(img, disp, ids=None, seg=None, *, using_scale=True, zero_boundary=True, mode="bilinear",
+         d0=0, d1=None, want_phi=True):
+    """phi = disp + identity ; warped = Bilinear(img', phi).  Returns (phi or None, warped).
+
+    img (B,C,D,W,H) whole volume; disp (B,3,Dn,W,H) rows [d0,d1); ids = three per-axis
+    identity tables (rows d0.. for axis 0) or None when `disp` already is phi.
+    Replaces Bilinear (reference net_utils.py:9-56) + the add at …Backproj.py:68.
+    """
+    img = _dev(img, "img")
+    disp = _dev(disp, "disp")
+    B, Cc, D, W, H = img.shape
+    d1 = D if d1 is None else int(d1)
+    Dn = d1 - d0
+    if tuple(disp.shape) != (B, 3, Dn, W, H):
+        raise ValueError(f"disp must be {(B, 3, Dn, W, H)}, got {tuple(disp.shape)}")
+    if mode not in ("bilinear", "nearest"):
+        raise ValueError("mode must be 'bilinear' or 'nearest'")
+    sg = None if seg is None else _dev(seg, "seg")
+    if sg is not None and sg.shape != img.shape:
+        raise ValueError("seg must match img")
+    i0 = i1 = i2 = None
+    if ids is not None:
+        i0, i1, i2 = (_dev(t, "id table") for t in ids)
+        if i0.numel() != Dn or i1.numel() != W or i2.numel() != H:
+            raise ValueError("identity tables must have (Dn, W, H) entries")
+    phi = torch.empty_like(disp) if want_phi else None
+    warped = torch.empty((B, Cc, Dn, W, H), dtype=torch.float32, device=img.device)
+    flags = ((_hip.WARP_USING_SCALE if using_scale else 0) | (0 if zero_boundary else _hip.WARP_BORDER) |
+             (_hip.WARP_NEAREST if mode == "nearest" else 0))
+    nb = 4 * (disp.numel() + (phi.numel() if want_phi else 0) + warped.numel() + B * Cc * Dn * W * H)
+    with _timed("warp_trilinear", bytes=nb, samples=B):
+        _hip.check(_hip.lib().lr_warp_trilinear_f32(img.data_ptr(), _ptr(sg), disp.data_ptr(), _ptr(i0),
+                                                    _ptr(i1), _ptr(i2), _ptr(phi), warped.data_ptr(), B, Cc, D,
+                                                    W, H, d0, d1, flags, _stream()), "lr_warp_trilinear_f32")
+    return phi, warped
+
+
+def mask_compose(img, seg):
+    """(img+1)*seg-1  (reference …Backproj.py:57-58)."""
+    img = _dev(img, "img")
+    seg = _dev(seg, "seg")
+    out = torch.empty_like(img)
+    with _timed("mask_compose", bytes=12 * img.numel()):
+        _hip.check(_hip.lib().lr_mask_compose_f32(img.data_ptr(), seg.data_ptr(), out.data_ptr(), img.numel(),
+                                                  _stream()), "lr_mask_compose_f32")
+    return out
+
+
+# ----------------------------------------------------------------------------- K8 NCC
+def ncc_moments(x, y, rows, nblk=None):
+    """Five raw fp64 moments per row: (R,5) = Σx, Σy, Σxy, Σxx, Σyy.  Slab moments add."""
+    x = _dev(x, "x")
+    y = _dev(y, "y")
+    if x.shape != y.shape:
+        raise ValueError("x and y must have the same shape")
+    R = int(rows)
+    N = x.numel() // R
+    if nblk is None:
+        nblk = max(1, min(2048 // R if R < 2048 else 1, (N + 4095) // 4096))
+    partial = torch.empty((R, nblk, 5), dtype=torch.float64, device=x.device)
+    moments = torch.empty((R, 5), dtype=torch.float64, device=x.device)
+    with _timed("ncc_moments", bytes=8 * x.numel()):
+        _hip.check(_hip.lib().lr_ncc_moments_f32(x.data_ptr(), y.data_ptr(), partial.data_ptr(),
+                                                 moments.data_ptr(), R, N, nblk, _stream()), "lr_ncc_moments_f32")
+    return moments
+
+
+def ncc_loss_from_moments(moments, n_total, n_batch, variant=_hip.NCC_CONFIGURED):
+    """(loss scalar tensor, per-row ncc) from (R,5) moments over n_total elements per row."""
+    moments = _dev(moments, "moments", torch.float64)
+    R = moments.shape[0]
+    loss = torch.empty((), dtype=torch.float32, device=moments.device)
+    rows = torch.empty((R,), dtype=torch.float32, device=moments.device)
+    _hip.check(_hip.lib().lr_ncc_loss_from_moments(moments.data_ptr(), loss.data_ptr(), rows.data_ptr(), R,
+                                                   int(n_total), int(n_batch), variant, _stream()),
+               "lr_ncc_loss_from_moments")
+    return loss, rows
+
+
+def ncc_loss(x, y, variant=_hip.NCC_CONFIGURED):
+    """1 - mean NCC.  variant CONFIGURED: rows = batch (layers/losses.py:14-29);
+    SQUARED: rows = batch*channels, squared NCC (layers/layers.py:238-255)."""
+    n_batch = x.shape[0]
+    R = n_batch if variant == _hip.NCC_CONFIGURED else n_batch * x.shape[1]
+    m = ncc_moments(x, y, R)
+    loss, _ = ncc_loss_from_moments(m, x.numel() // R, n_batch, variant)
+    return loss

@@ -1,0 +1,320 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP kernel, called through the C ABI
+(liftreg_amd.ops → libliftreg_hip.so), against
+  (1) the golden vectors produced by the reference itself (tests/golden/*.npz),
+  (2) the oracles (oracle/liftreg_oracle.c scalar C, oracle/ref_ops.py torch-CPU) on seeded inputs.
+
+Bars (BASELINE.json north_star): sampling coordinates and floor indices bit-exact; fp32 values
+within 1e-4 relative (most checks here hold 1e-5 or exact equality with the C oracle, whose
+arithmetic order the kernels share)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+from oracle import ref_ops as ro
+from util import pca_basis_32
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 2e-6
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from liftreg_amd import ops as o
+    from liftreg_amd import _hip
+    _hip.lib()  # fail loudly if the HIP library is missing
+    return o
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def unnorm(g, size):
+    g = g.astype(np.float32)
+    return ((g + np.float32(1)) / np.float32(2)) * np.float32(size - 1)
+
+
+# ------------------------------------------------------------------------------------- K1 DRR
+@pytest.mark.parametrize("tag", ["drr_a", "drr_b", "drr_c"])
+def test_drr_coords_bit_exact(golden, ops, dev, tag):
+    g = golden(tag)
+    shape = g["hu"].shape
+    res = tuple(int(v) for v in g["resolution"])
+    poses = g["poses"].astype(np.float32)
+    pix, dx = ops.drr_sample_coords(poses, g["spacing"], shape, res, dev)
+    D, W, H = shape
+    want = np.stack([unnorm(g["grid"][..., 0], D), unnorm(g["grid"][..., 1], W), unnorm(g["grid"][..., 2], H)], -1)
+    assert np.array_equal(pix.cpu().numpy(), want)                   # every bit of every coordinate
+    assert np.array_equal(np.floor(pix.cpu().numpy()), np.floor(want))
+    assert np.array_equal(dx.cpu().numpy(), g["dx"])
+    grid, _ = ops.drr_sample_coords(poses, g["spacing"], shape, res, dev, normalized=True)
+    assert np.array_equal(grid.cpu().numpy(), g["grid"])             # the reference's own grid tensor
+
+
+@pytest.mark.parametrize("tag", ["drr_a", "drr_b", "drr_c"])
+def test_drr_forward_golden(golden, ops, dev, tag):
+    g = golden(tag)
+    res = tuple(int(v) for v in g["resolution"])
+    poses = g["poses"].astype(np.float32)
+    want_c = co.drr_forward(g["mu"], poses, g["spacing"], res)
+    for nseg in (1, 2, 4):
+        got = ops.drr_forward(T(g["mu"], dev), poses, res, g["spacing"], nseg=nseg).cpu().numpy()
+        np.testing.assert_allclose(got, g["proj"], rtol=RTOL, atol=ATOL)
+        if nseg == 1:
+            assert np.array_equal(got, want_c)                         # same op order as the C oracle
+    got_hu = ops.drr_forward(T(g["hu"], dev), poses, res, g["spacing"], hu_input=True, nseg=1).cpu().numpy()
+    assert np.array_equal(got_hu, want_c)
+    flipped = np.flip(g["hu"], 1).copy()
+    got_fl = ops.drr_forward(T(flipped, dev), poses, res, g["spacing"], hu_input=True, flip_w=True, nseg=1)
+    assert np.array_equal(got_fl.cpu().numpy(), want_c)
+
+
+def test_drr_reference_signatures(golden, ops, dev):
+    from liftreg_amd.utils import sdct_projection_utils as S
+    g = golden("drr_default_receptor")
+    mu = S.calc_relative_atten_coef(g["hu"])
+    assert np.array_equal(mu, ro.calc_relative_atten_coef(g["hu"]))
+    proj, poses = S.calculate_projection_wraper(mu, 30, 4, (2.2, 2.2, 2.2))
+    assert isinstance(proj, np.ndarray) and proj.dtype == np.float32
+    assert np.array_equal(poses, g["poses"])
+    np.testing.assert_allclose(proj, g["proj"], rtol=RTOL, atol=ATOL)
+    proj2 = S.calculate_projection(mu, poses, [12, 12], [1, 1, 1], (2.2, 2.2, 2.2), torch.device("cuda"))
+    np.testing.assert_allclose(proj2, g["proj"], rtol=RTOL, atol=ATOL)
+    with pytest.raises(RuntimeError):
+        S.calculate_projection(mu, poses, [12, 12], [1, 1, 1], (2.2, 2.2, 2.2), torch.device("cpu"))
+
+
+def test_drr_medium_vs_oracles_and_slabs(ops, dev):
+    rs = np.random.RandomState(5)
+    D, W, H, P, R = 40, 36, 44, 3, 48
+    mu = rs.uniform(0, 0.4, (D, W, H)).astype(np.float32)
+    poses = ro.scan_poses(30, P, W)
+    p32 = poses.astype(np.float32)
+    sp = np.array((2.2, 2.2, 2.2), np.float32)
+    want_t = ro.drr_forward(mu, poses, (R, R), sp)
+    want_c = co.drr_forward(mu, p32, sp, (R, R))
+    got = ops.drr_forward(T(mu, dev), p32, (R, R), sp, nseg=1).cpu().numpy()
+    assert np.array_equal(got, want_c)
+    np.testing.assert_allclose(got, want_t, rtol=1e-5, atol=1e-6)
+    got_auto = ops.drr_forward(T(mu, dev), p32, (R, R), sp).cpu().numpy()     # library-chosen nseg
+    np.testing.assert_allclose(got_auto, want_t, rtol=1e-5, atol=1e-6)
+    parts = [ops.drr_forward(T(mu[a:b], dev), p32, (R, R), sp, d0=a, d1=b, full_D=D) for a, b in ((0, 13), (13, 29), (29, D))]
+    np.testing.assert_allclose(sum(parts).cpu().numpy(), want_t, rtol=1e-5, atol=1e-6)     # z-slab partial sums
+
+
+# ------------------------------------------------------------------------------------- K2 backprojection
+@pytest.mark.parametrize("tag", ["bp_a", "bp_b", "bp_c"])
+def test_backproject_golden(golden, ops, dev, tag):
+    g = golden(tag)
+    shape = tuple(int(v) for v in g["shape"])
+    pshape = g["proj"].shape[2:]
+    poses = g["poses"][0]
+    pix = ops.backproject_coords(poses, shape, pshape, dev).cpu().numpy()
+    assert np.array_equal(pix[..., 0], unnorm(g["grid"][0, :, 1], pshape[0]))     # bit-exact coordinates
+    assert np.array_equal(pix[..., 1], unnorm(g["grid"][0, :, 0], pshape[1]))
+    got = ops.backproject(T(g["proj"], dev), poses, shape).cpu().numpy()
+    np.testing.assert_allclose(got, g["volume"], rtol=RTOL, atol=ATOL)
+    assert np.array_equal(got, co.backproject(g["proj"], poses, shape))
+    a, b = 3, shape[0] - 2
+    slab = ops.backproject(T(g["proj"], dev), poses, shape, d0=a, d1=b).cpu().numpy()
+    assert np.array_equal(slab, got[:, :, a:b])
+    from liftreg_amd.utils import sdct_projection_utils as S
+    grid = S.backproj_grids_with_poses(g["poses"][0:1], shape, pshape, device=torch.device("cuda"))
+    assert np.array_equal(grid.cpu().numpy(), g["grid"])                           # API-parity grid, every bit
+
+
+def test_backproject_into_concat_buffer_and_ragged(ops, dev):
+    rs = np.random.RandomState(9)
+    for (D, W, H), (Pw, Ph), P, B in (((20, 18, 24), (22, 26), 2, 3), ((9, 7, 11), (13, 5), 4, 2), ((16, 16, 16), (16, 16), 11, 9)):
+        proj = rs.uniform(-1, 1, (B, P, Pw, Ph)).astype(np.float32)
+        poses = ro.scan_poses(30, P, W).astype(np.float32)
+        want = co.backproject(proj, poses, (D, W, H))
+        want_t = ro.backproject(torch.from_numpy(proj), poses[None], (D, W, H)).numpy()
+        np.testing.assert_allclose(want, want_t, rtol=RTOL, atol=ATOL)
+        buf = torch.full((B, P + 1, D, W, H), -7.0, device=dev)
+        ops.backproject(T(proj, dev), poses, (D, W, H), out=buf[:, 1:], out_batch_stride=(P + 1) * D * W * H)
+        assert np.array_equal(buf[:, 1:].cpu().numpy(), want)
+        assert bool((buf[:, 0] == -7.0).all())                                     # channel 0 untouched
+
+
+# ------------------------------------------------------------------------------------- K6/K7 warp
+@pytest.mark.parametrize("tag", ["warp_a", "warp_b"])
+def test_warp_golden(golden, ops, dev, tag):
+    from liftreg_amd.utils import net_utils as N
+    g = golden(tag)
+    shape = g["img"].shape[2:]
+    assert np.array_equal(N.identity_map(shape, device=dev).cpu().numpy(), g["identity"])
+    assert np.array_equal(N.gen_identity_map(list(shape), 1.0, device=dev).cpu().numpy(), g["identity"])
+    ids = [T(t, dev) for t in N.identity_axis_tables(shape)]
+    img, disp, phi_in = T(g["img"], dev), T(g["disp"], dev), T(g["phi"], dev)
+    cases = {"warped_zeros_scale": (True, True, "bilinear", co.USING_SCALE),
+             "warped_border_scale": (False, True, "bilinear", co.USING_SCALE | co.BORDER),
+             "warped_zeros_noscale": (True, False, "bilinear", 0),
+             "warped_nearest": (True, True, "nearest", co.USING_SCALE | co.NEAREST)}
+    for key, (zb, sc, mode, flags) in cases.items():
+        phi, w = ops.warp(img, disp, ids, None, using_scale=sc, zero_boundary=zb, mode=mode)
+        assert np.array_equal(phi.cpu().numpy(), g["phi"]), key
+        np.testing.assert_allclose(w.cpu().numpy(), g[key], rtol=RTOL, atol=ATOL, err_msg=key)
+        _, cw = co.warp(g["img"], g["disp"], ids=N.identity_axis_tables(shape), flags=flags)
+        assert np.array_equal(w.cpu().numpy(), cw), key                            # same op order as C oracle
+        out = N.Bilinear(zero_boundary=zb, using_scale=sc, mode=mode)(img, phi_in)  # the reference's module API
+        assert np.array_equal(out.cpu().numpy(), w.cpu().numpy()), key
+    _, w = ops.warp(img, disp, ids, None)
+    a, b = 2, shape[0] - 3
+    sphi, sw = ops.warp(img, disp[:, :, a:b].contiguous(), (ids[0][a:b].contiguous(), ids[1], ids[2]), None, d0=a, d1=b)
+    assert np.array_equal(sw.cpu().numpy(), w[:, :, a:b].cpu().numpy())            # z-slab of the output
+
+
+def test_warp_seg_ragged_and_multichannel(ops, dev):
+    rs = np.random.RandomState(3)
+    from liftreg_amd.utils import net_utils as N
+    for shape, B, C in (((9, 11, 13), 2, 1), ((8, 8, 12), 1, 3)):
+        img = rs.uniform(-1, 1, (B, C) + shape).astype(np.float32)
+        seg = (rs.uniform(0, 1, (B, C) + shape) > 0.3).astype(np.float32)
+        disp = rs.normal(0, 0.2, (B, 3) + shape).astype(np.float32)
+        tabs = N.identity_axis_tables(shape)
+        cphi, cw = co.warp(img, disp, ids=tabs, seg=seg, flags=co.USING_SCALE)
+        phi, w = ops.warp(T(img, dev), T(disp, dev), [T(t, dev) for t in tabs], T(seg, dev))
+        assert np.array_equal(phi.cpu().numpy(), cphi) and np.array_equal(w.cpu().numpy(), cw)
+        ref = ro.warp((torch.from_numpy(img) + 1) * torch.from_numpy(seg) - 1, torch.from_numpy(cphi))
+        np.testing.assert_allclose(w.cpu().numpy(), ref.numpy(), rtol=RTOL, atol=ATOL)
+        mc = ops.mask_compose(T(img, dev), T(seg, dev)).cpu().numpy()
+        assert np.array_equal(mc, co.mask_compose(img, seg))
+
+
+# ------------------------------------------------------------------------------------- K8 NCC
+def test_ncc_golden_and_sharded(golden, ops, dev):
+    from liftreg_amd.layers.losses import NCCLoss
+    from liftreg_amd.layers.layers import NCCLoss as NCCSq
+    g = golden("ncc")
+    x, y = T(g["x"], dev), T(g["y"], dev)
+    assert abs(float(NCCLoss()(x, y)) - float(g["loss_configured"])) < 2e-6
+    assert abs(float(NCCSq()(x, y)) - float(g["loss_squared"])) < 2e-6
+    m = ops.ncc_moments(x, y, 3).cpu().numpy()
+    np.testing.assert_allclose(m, co.ncc_moments(g["x"], g["y"], 3), rtol=1e-12)
+    # moments of z-slabs add (the 5-moment all-reduce of SURVEY §8e)
+    xs, ys = x.reshape(3, -1), y.reshape(3, -1)
+    cut = 300
+    m2 = ops.ncc_moments(xs[:, :cut].contiguous(), ys[:, :cut].contiguous(), 3) + \
+        ops.ncc_moments(xs[:, cut:].contiguous(), ys[:, cut:].contiguous(), 3)
+    np.testing.assert_allclose(m2.cpu().numpy(), m, rtol=1e-12)
+    loss, rows = ops.ncc_loss_from_moments(m2, xs.shape[1], 3)
+    assert abs(float(loss) - float(g["loss_configured"])) < 2e-6
+    assert abs(float(NCCLoss()(x, x))) < 1e-6                                       # NCC(x,x) = 1
+
+
+# ------------------------------------------------------------------------------------- K3/K4 conv, fc
+@pytest.mark.parametrize("tag", ["conv_a", "conv_b", "conv_c"])
+def test_conv_golden_all_layouts(golden, ops, dev, tag):
+    g = golden(tag)
+    s = int(g["stride"])
+    x, w, b = T(g["x"], dev), T(g["weight"], dev), T(g["bias"], dev)
+    y = ops.conv3d_k3_lrelu(x, w, b, s)                                            # NCDHW → NCDHW
+    np.testing.assert_allclose(y.cpu().numpy(), g["y"], rtol=1e-4, atol=1e-5)
+    y_cl = ops.conv3d_k3_lrelu(x, w, b, s, out_layout=ops.LAYOUT_NDHWC)             # NCDHW → NDHWC
+    assert np.array_equal(y_cl.permute(0, 4, 1, 2, 3).cpu().numpy(), y.cpu().numpy())
+    if g["x"].shape[1] % 4 == 0:
+        x_cl = x.permute(0, 2, 3, 4, 1).contiguous()
+        y2 = ops.conv3d_k3_lrelu(x_cl, w, b, s, in_layout=ops.LAYOUT_NDHWC, out_layout=ops.LAYOUT_NDHWC)
+        np.testing.assert_allclose(y2.permute(0, 4, 1, 2, 3).cpu().numpy(), g["y"], rtol=1e-4, atol=1e-5)
+        y3 = ops.conv3d_k3_lrelu(x_cl, w, b, s, in_layout=ops.LAYOUT_NDHWC, out_layout=ops.LAYOUT_NCDHW)
+        assert np.array_equal(y3.cpu().numpy(), y2.permute(0, 4, 1, 2, 3).cpu().numpy())
+
+
+def test_conv_medium_vs_oracle(ops, dev):
+    rs = np.random.RandomState(11)
+    torch.manual_seed(11)
+    for cin, cout, s, shape, B in ((3, 16, 1, (20, 33, 37), 2), (12, 16, 1, (10, 9, 18), 1), (16, 32, 2, (24, 17, 40), 2),
+                                   (32, 32, 2, (16, 16, 16), 3), (32, 32, 2, (4, 4, 4), 2), (8, 32, 1, (6, 6, 20), 1)):
+        x = rs.uniform(-1, 1, (B, cin) + shape).astype(np.float32)
+        w = (rs.normal(0, 1, (cout, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32)
+        b = rs.uniform(-0.1, 0.1, cout).astype(np.float32)
+        want = ro.conv_block(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), s).numpy()
+        got = ops.conv3d_k3_lrelu(T(x, dev), T(w, dev), T(b, dev), s).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5, err_msg=str((cin, cout, s, shape)))
+        if cin % 4 == 0:
+            xcl = T(x, dev).permute(0, 2, 3, 4, 1).contiguous()
+            got2 = ops.conv3d_k3_lrelu(xcl, T(w, dev), T(b, dev), s, in_layout=ops.LAYOUT_NDHWC).cpu().numpy()
+            np.testing.assert_allclose(got2, want, rtol=1e-4, atol=1e-5, err_msg="cl " + str((cin, cout, s, shape)))
+
+
+def test_fc_golden_and_sizes(golden, ops, dev):
+    g = golden("fc")
+    h1 = ops.linear_lrelu(T(g["x"], dev), T(g["w1"], dev), T(g["b1"], dev), 0.2)
+    h2 = ops.linear_lrelu(h1, T(g["w2"], dev), T(g["b2"], dev), 1.0)
+    np.testing.assert_allclose(h1.cpu().numpy(), g["h1"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(h2.cpu().numpy(), g["h2"], rtol=1e-5, atol=2e-6)
+    rs = np.random.RandomState(2)
+    for B, K, O in ((8, 16384, 800), (1, 4000, 800), (13, 801, 57), (32, 256, 56)):
+        x = rs.uniform(-1, 1, (B, K)).astype(np.float32)
+        w = (rs.normal(0, 1, (O, K)) / np.sqrt(K)).astype(np.float32)
+        b = rs.uniform(-0.1, 0.1, O).astype(np.float32)
+        want = co.linear_lrelu(x, w, b, 0.2)
+        got = ops.linear_lrelu(T(x, dev), T(w, dev), T(b, dev), 0.2).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------- K5 PCA
+def test_pca_vs_oracle(ops, dev):
+    rs = np.random.RandomState(4)
+    for B, L, M in ((8, 56, 3 * 16 ** 3), (3, 6, 3 * 12 * 10 * 14 // 4 * 4), (16, 9, 4096), (1, 56, 1024)):
+        coefs = rs.normal(0, 1, (B, L)).astype(np.float32)
+        basis = rs.normal(0, 0.02, (L, M)).astype(np.float32)
+        mean = rs.normal(0, 0.01, M).astype(np.float32)
+        want = co.pca_reconstruct(coefs, basis, mean)
+        got = ops.pca_reconstruct(T(coefs, dev), T(basis, dev), T(mean, dev)).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-7)
+        half = M // 2 // 4 * 4                                                      # a column slab of the basis
+        got_s = ops.pca_reconstruct(T(coefs, dev), T(basis, dev)[:, half:], T(mean, dev)[half:].contiguous())
+        assert np.array_equal(got_s.cpu().numpy(), got[:, half:])
+
+
+# ------------------------------------------------------------------------------------- a14 whole model
+def test_model_forward_golden(golden, dev, tmp_path):
+    from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+    from liftreg_amd.utils.general import get_class
+    g = golden("model_32")
+    vec, mean = pca_basis_32(int(g["latent_dim"]), 32, int(g["pca_seed"]))
+    np.save(tmp_path / "pca_vectors.npy", vec)
+    np.save(tmp_path / "pca_mean.npy", mean)
+    cls = get_class("liftreg_amd.models.LiftRegDeformSubspaceBackproj.model")       # the plugin path
+    assert cls is model
+    net = cls([32, 32, 32], {"drr_feature_num": 2, "latent_dim": int(g["latent_dim"]), "pca_path": str(tmp_path)})
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    assert sorted(net.state_dict().keys()) == sorted(sd.keys())                      # the reference's 19 keys
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    inp = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in::")}
+    inp = {k: (v.to(dev) if v.dim() > 3 else v) for k, v in inp.items()}             # set_input: ndim>3 → GPU
+    with torch.no_grad():
+        out = net(inp)
+    assert set(out) == {"warped", "phi", "params", "target", "pca_coefs", "target_proj", "warped_proj"}
+    np.testing.assert_allclose(out["pca_coefs"].cpu().numpy(), g["out::pca_coefs"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out["params"].cpu().numpy(), g["out::params"], rtol=1e-4, atol=1e-6)    # displacement
+    np.testing.assert_allclose(out["phi"].cpu().numpy(), g["out::phi"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(out["warped"].cpu().numpy(), g["out::warped"], rtol=1e-4, atol=2e-5)
+    assert np.array_equal(out["target"].cpu().numpy(), g["out::target"])
+    assert out["warped_proj"] is out["target_proj"]
+    with pytest.raises(NotImplementedError):                                         # no silent autograd fallback
+        net(inp)
+
+
+# ------------------------------------------------------------------------------------- error behaviour
+def test_no_cpu_fallback_and_error_codes(ops, dev):
+    from liftreg_amd import _hip
+    with pytest.raises(_hip.LiftRegHipError):
+        ops.backproject(torch.zeros(1, 2, 4, 4), np.zeros((2, 3), np.float32), (4, 4, 4))   # CPU tensor
+    lib = _hip.lib()
+    assert lib.lr_backproject_f32(None, None, None, 1, 1, 4, 4, 4, 4, 4, 0, 4, 64, None) == -2   # LR_ENULL
+    x = torch.zeros(1, 3, 4, 4, 4, device=dev)
+    with pytest.raises(_hip.LiftRegHipError):
+        ops.conv3d_k3_lrelu(x, torch.zeros(8, 3, 3, 3, 3, device=dev), None, 1)                  # Cout=8 unsupported
+    assert lib.lr_strerror(-3) == b"combination not built into this library"
