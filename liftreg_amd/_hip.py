@@ -65,6 +65,11 @@ def lib():
             raise LiftRegHipError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C liftreg_amd/csrc` — liftreg_amd has no CPU/PyTorch fallback path")
+        # PyTorch-ROCm wheels bundle their own libamdhip64.so.7; the device pointers and streams we are
+        # handed live in THAT runtime.  Import torch first so the dynamic loader resolves our
+        # DT_NEEDED libamdhip64.so.7 to the copy torch already loaded — loading ours first would put a
+        # second HIP runtime (/opt/rocm) in the process, whose launches fail with hipErrorNoDevice.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError here = header/library mismatch

@@ -1,6 +1,8 @@
 // lr_common.h — shared device/host helpers for libliftreg_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "../../include/liftreg_hip.h"
 
@@ -9,10 +11,18 @@
 // Launch check: report, never throw (C ABI).
 static inline int lr_launch_status() {
   hipError_t e = hipGetLastError();
+  if (e != hipSuccess && getenv("LIFTREG_HIP_DEBUG"))
+    fprintf(stderr, "liftreg_hip: launch failed: %s (%s)\n", hipGetErrorName(e), hipGetErrorString(e));
   return e == hipSuccess ? LR_OK : LR_ELAUNCH;
 }
 
-static inline hipStream_t lr_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+// Every launch site converts its `void* stream` through here first, which also drops any stale
+// non-sticky error an earlier runtime call of the host application left behind (hipGetLastError
+// is per-thread state shared with PyTorch), so lr_launch_status() reports THIS launch only.
+static inline hipStream_t lr_stream(void* s) {
+  (void)hipGetLastError();
+  return reinterpret_cast<hipStream_t>(s);
+}
 
 // Emitter poses travel by value (kernel-argument segment → SGPR loads).
 struct LrPoses {

@@ -220,7 +220,7 @@ def conv3d_k3_lrelu(x, weight, bias, stride, *, in_layout=LAYOUT_NCDHW, out_layo
     shape = (B, Cout, Do, Wo, Ho) if out_layout == LAYOUT_NCDHW else (B, Do, Wo, Ho, Cout)
     y = torch.empty(shape, dtype=torch.float32, device=x.device)
     flops = 2.0 * 27 * Cin * Cout * B * Do * Wo * Ho
-    with _timed(f"conv3d_c{Cin}x{Cout}_s{stride}", flops=flops,
+    with _timed(f"conv3d_c{Cin}x{Cout}_s{stride}_{D}", flops=flops,
                 bytes=4 * (x.numel() + y.numel()), samples=B):
         _hip.check(_hip.lib().lr_conv3d_k3_lrelu_f32(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B,
                                                      Cin, Cout, D, W, H, stride, in_layout, out_layout,
