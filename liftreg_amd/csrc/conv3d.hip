@@ -81,9 +81,11 @@ __device__ __forceinline__ f32x4 bias_init(const float* __restrict__ bias, int n
 // K order: channel c, then 7 quads of taps (27 padded to 28); lane group kq=lane>>4
 // owns tap 4q+kq, so one ds_read_b32 per lane feeds one MFMA.
 // ===========================================================================
-constexpr int PD = 4, PW = 4, PH = 64, PCC = 3;  // PCC = channels staged per pass (P=2 views -> Cin=3: one pass)
+constexpr int PD = 4, PW = 4, PH = 64;
 
-template <int S>
+// CC = channels staged per pass: 3 for stride 1 (P=2 views -> Cin=3: a single pass, 31 KB of LDS),
+// 1 for stride 2 (its brick is 4.4x larger; off the model's path).
+template <int S, int CC>
 struct PlanarGeom {
   static constexpr int RH = (PH - 1) * S + 3;   // input extent along H a brick needs (66 | 129)
   static constexpr int RW = (PW - 1) * S + 3;   // 6 | 9
@@ -96,33 +98,29 @@ struct PlanarGeom {
   static constexpr int RPI = 64 / F4;            // rows per wavefront load instruction (3 | 1)
   static constexpr int PS = RW * RSL;            // plane stride
   static constexpr int CS = RD * PS;             // channel stride
-  static constexpr int MAXIT = S == 1 ? (PCC * RD * RW + 4 * RPI - 1) / (4 * RPI) : 1;  // staging iterations per wave
+  static constexpr int NROWS = CC * RD * RW;     // rows per pass
+  static constexpr int MAXIT = (NROWS + 4 * RPI - 1) / (4 * RPI);  // staging iterations per wave
+  static constexpr int T = CC * 7;               // k-steps (tap quads) per pass
 };
 
-template <int NT, int S>
-__global__ __launch_bounds__(256) void conv3d_planar_kernel(const float* __restrict__ in,
+// Persistent: a block walks work items (brick, channel pass) with stride gridDim.x.  While item i
+// runs on the matrix pipe the input window of item i+1 is already in flight (bounds-checked buffer
+// loads: out-of-volume rows/columns and channels >= Cin get an out-of-range offset and read 0, so
+// the loads are unconditional and the brick's zero halo IS the conv's padding).
+template <int NT, int S, int CC>
+__global__ __launch_bounds__(256, 2) void conv3d_planar_kernel(const float* __restrict__ in,
                                                             const float* __restrict__ wp,
                                                             const float* __restrict__ bias,
                                                             float* __restrict__ out, ConvDims d,
-                                                            int out_layout, float slope, int pcc, int vec4) {
-  using G = PlanarGeom<S>;
-  extern __shared__ float brick[];  // [PCC][RD][RW][RSL]
-  int b, dq, wq, hq;
-  block_coords(d, b, dq, wq, hq);
+                                                            int out_layout, float slope, int vec4,
+                                                            int nitems, int npass, int dbg) {
+  using G = PlanarGeom<S, CC>;
+  extern __shared__ __attribute__((aligned(16))) float brick[];  // [CC][RD][RW][RSL]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int do0 = dq * PD, wo0 = wq * PW, ho0 = hq * PH;
   const int col = lane & 15, kq = lane >> 4;
-
-  f32x4 acc[PW][4][NT];  // [tile row along W][tile along H][cout tile]
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const f32x4 bv = bias_init(bias, nt, lane);
-#pragma unroll
-    for (int y = 0; y < PW; ++y)
-#pragma unroll
-      for (int x = 0; x < 4; ++x) acc[y][x][nt] = bv;
-  }
+  constexpr unsigned OOR = 0x80000000u;
+  const int64_t V = (int64_t)d.D * d.W * d.H;
 
   // per-lane LDS offsets of the 7 tap quads (tap 27 is padding: weight 0, address of tap 26)
   int qoff[7];
@@ -132,44 +130,88 @@ __global__ __launch_bounds__(256) void conv3d_planar_kernel(const float* __restr
     const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
     qoff[q] = (wave * S + tz) * G::PS + ty * G::RSL + G::XOFF + tx + col * S;
   }
+  // staging slots of this lane: slot `it` covers window row (it*4+wave)*RPI + lrow, float4 lf4.
+  // Row decode and the offset relative to the window origin do not depend on the brick.
+  const int lrow = lane / G::F4, lf4 = lane - lrow * G::F4;
+  const bool lact = lane < G::RPI * G::F4;
+  unsigned srel[G::MAXIT];   // byte offset from the window origin (or OOR for an unused slot)
+  int sdst[G::MAXIT];        // LDS float index (or -1)
+  short srz[G::MAXIT], sry[G::MAXIT], scc[G::MAXIT];
+#pragma unroll
+  for (int it = 0; it < G::MAXIT; ++it) {
+    const int row = (it * 4 + wave) * G::RPI + lrow;
+    const int cc = row / (G::RD * G::RW), rz = (row / G::RW) % G::RD, ry = row % G::RW;
+    const bool used = lact && row < G::NROWS;
+    scc[it] = (short)cc; srz[it] = (short)rz; sry[it] = (short)ry;
+    srel[it] = used ? (unsigned)(((int64_t)cc * V + ((int64_t)rz * d.W + ry) * d.H + lf4 * 4) * 4) : OOR;
+    sdst[it] = used ? cc * G::CS + rz * G::PS + ry * G::RSL + lf4 * 4 : -1;
+  }
 
-  const int64_t V = (int64_t)d.D * d.W * d.H;
-  const int z_in0 = do0 * S - 1, y_in0 = wo0 * S - 1, x_in0 = ho0 * S - 1;
-  for (int c0 = 0; c0 < d.Cin; c0 += pcc) {
-    const int ncc = min(pcc, d.Cin - c0);
-    if (c0) __syncthreads();  // previous pass has finished reading the brick
-    // ---- stage the brick: all loads of a pass are issued before the first LDS store so their
-    //      latencies overlap (one memory round trip per pass, not one per row)
-    const int nrows = ncc * G::RD * G::RW;
-    if (S == 1 && vec4) {  // (stride-2 planar input is off the model's path: scalar staging only)
-      const int lrow = lane / G::F4, lf4 = lane - lrow * G::F4;
-      const bool lact = lane < G::RPI * G::F4;
-      const int xi = x_in0 - G::XOFF + lf4 * 4;  // multiple of 4: a float4 is entirely in or out
-      const bool xok = xi >= 0 && xi + 3 < d.H;
-      float4 st[G::MAXIT];
+  auto item_coords = [&](int item, int& b, int& dq, int& wq, int& hq, int& pass) {
+    pass = item % npass;
+    int br = item / npass;
+    hq = br % d.nHq; br /= d.nHq;
+    wq = br % d.nWq; br /= d.nWq;
+    dq = br % d.nDq;
+    b = br / d.nDq;
+  };
+  float4 st[G::MAXIT];
+  auto prefetch = [&](int item) {
+    int b, dq, wq, hq, pass;
+    item_coords(item, b, dq, wq, hq, pass);
+    const int c0 = pass * CC;
+    const int z0 = dq * PD * S - 1, y0 = wq * PW * S - 1, x0 = hq * PH * S - 1 - G::XOFF;
+    // window origin (may lie before the tensor: never dereferenced there)
+    const float* org = in + ((int64_t)b * d.Cin + c0) * V + ((int64_t)z0 * d.W + y0) * d.H + x0;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(org), (short)0, 0x7fffffff, 0x00020000);
+    // interior brick (the common case): every row, column and channel of the window exists
+    const bool interior = z0 >= 0 && z0 + G::RD <= d.D && y0 >= 0 && y0 + G::RW <= d.W && x0 >= 0 &&
+                          x0 + G::RSL <= d.H && c0 + CC <= d.Cin;  // wave-uniform
+    if (interior) {
+#pragma unroll
+      for (int it = 0; it < G::MAXIT; ++it)
+        st[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, srel[it], 0, 0));
+    } else {
+      const int xi = x0 + lf4 * 4;
+      const bool xok = xi >= 0 && xi + 3 < d.H;  // multiple of 4 and H % 4 == 0: entirely in or out
 #pragma unroll
       for (int it = 0; it < G::MAXIT; ++it) {
-        const int row = (it * 4 + wave) * G::RPI + lrow;
-        const int cc = row / (G::RD * G::RW), rz = (row / G::RW) % G::RD, ry = row % G::RW;
-        const int zi = z_in0 + rz, yi = y_in0 + ry;
-        const bool ok = lact && row < nrows && xok && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W;
-        st[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok)
-          st[it] = *reinterpret_cast<const float4*>(in + ((int64_t)b * d.Cin + c0 + cc) * V +
-                                                    ((int64_t)zi * d.W + yi) * d.H + xi);
+        const int zi = z0 + srz[it], yi = y0 + sry[it];
+        const bool ok = xok && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W && c0 + scc[it] < d.Cin;
+        const unsigned voff = srel[it] | (ok ? 0u : OOR);
+        st[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
       }
+    }
+  };
+
+  // Work order of a block: bricks brick0, brick0+G, ... and for each brick its npass channel passes
+  // back to back (the accumulators carry across the passes of one brick).
+  const int nbricks = nitems / npass;
+  const int brick0 = (int)lr_xcd_remap(blockIdx.x, gridDim.x);
+  if (brick0 >= nbricks) return;
+  const int my_bricks = (nbricks - brick0 + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int my_units = my_bricks * npass;
+  auto unit_item = [&](int u) { return (brick0 + (u / npass) * (int)gridDim.x) * npass + u % npass; };
+  f32x4 acc[PW * 4][NT];
+  float w[G::T][NT];
+  float a[2][PW * 4];
+
+  // brick of unit u -> LDS (from the prefetched registers, or scalar loads when !vec4)
+  auto stage = [&](int u) {
+    if (vec4) {
 #pragma unroll
-      for (int it = 0; it < G::MAXIT; ++it) {
-        const int row = (it * 4 + wave) * G::RPI + lrow;
-        const int cc = row / (G::RD * G::RW), rz = (row / G::RW) % G::RD, ry = row % G::RW;
-        if (lact && row < nrows)
-          *reinterpret_cast<float4*>(brick + cc * G::CS + rz * G::PS + ry * G::RSL + lf4 * 4) = st[it];
-      }
-    } else {  // H % 4 != 0 or unaligned base: scalar staging of the same window
-      for (int row = wave; row < nrows; row += 4) {
+      for (int it = 0; it < G::MAXIT; ++it)
+        if (sdst[it] >= 0) *reinterpret_cast<float4*>(brick + sdst[it]) = st[it];
+    } else {  // H % 4 != 0 or unaligned base: scalar staging of the same window, no prefetch
+      int b, dq, wq, hq, pass;
+      item_coords(unit_item(u), b, dq, wq, hq, pass);
+      const int c0 = pass * CC;
+      const int z_in0 = dq * PD * S - 1, y_in0 = wq * PW * S - 1, x_in0 = hq * PH * S - 1;
+      for (int row = wave; row < G::NROWS; row += 4) {
         const int cc = row / (G::RD * G::RW), rz = (row / G::RW) % G::RD, ry = row % G::RW;
         const int zi = z_in0 + rz, yi = y_in0 + ry;
-        const bool rowok = zi >= 0 && zi < d.D && yi >= 0 && yi < d.W;
+        const bool rowok = c0 + cc < d.Cin && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W;
         const float* src = in + ((int64_t)b * d.Cin + c0 + cc) * V + ((int64_t)zi * d.W + yi) * d.H;
         float* dst = brick + cc * G::CS + rz * G::PS + ry * G::RSL;
         for (int x = lane; x < G::RSL; x += 64) {
@@ -178,45 +220,126 @@ __global__ __launch_bounds__(256) void conv3d_planar_kernel(const float* __restr
         }
       }
     }
-    // ---- this pass's weights: ncc*7*NT registers per lane
-    float w[PCC][7][NT];
+  };
+  // weights of unit u's pass (MFMA A operand, rows = couts) and, on a brick's first pass, the bias.
+  // The empty asm pins the wait for these conditional loads HERE: otherwise hipcc, unable to count
+  // across the branch, drains vmcnt(0) at their first use inside the sweep — and with it the prefetch.
+  f32x4 bvec[NT];  // bias stays in registers: no vector-memory op (hence no vmcnt wait) per unit
 #pragma unroll
-    for (int cc = 0; cc < PCC; ++cc)
+  for (int nt = 0; nt < NT; ++nt) bvec[nt] = bias_init(bias, nt, lane);
+  auto setup = [&](int u) {
+    const int pass = u % npass, c0 = pass * CC;
+    if (npass > 1 || u == 0) {
 #pragma unroll
-      for (int q = 0; q < 7; ++q)
+      for (int t = 0; t < G::T; ++t)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          w[cc][q][nt] = (cc < ncc) ? wp[(((c0 + cc) * 7 + q) * NT + nt) * 64 + lane] : 0.0f;
-    __syncthreads();
-    // ---- MFMA sweep
+          w[t][nt] = (c0 + t / 7 < d.Cin) ? wp[(((c0 + t / 7) * 7 + t % 7) * NT + nt) * 64 + lane] : 0.0f;
 #pragma unroll
-    for (int cc = 0; cc < PCC; ++cc) {
-      if (cc < ncc) {
+      for (int t = 0; t < G::T; ++t)
 #pragma unroll
-        for (int q = 0; q < 7; ++q) {
-          const float* base = brick + cc * G::CS + qoff[q];
+        for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(w[t][nt]));
+    }
+    if (pass == 0) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int m = 0; m < PW * 4; ++m) acc[m][nt] = bvec[nt];
+    }
+  };
+  auto read_step = [&](int t, float (&dst)[PW * 4]) {
+    const float* base = brick + (t / 7) * G::CS + qoff[t % 7];
+#pragma unroll
+    for (int y = 0; y < PW; ++y)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) dst[y * 4 + x] = base[y * S * G::RSL + x * 16 * S];
+  };
+
+  // Schedule per unit:  sweep(u) | barrier | stage(u+1), store(u), setup(u+1) | barrier | prefetch(u+2)
+  // so the wait for a prefetch never has a just-issued store in front of it (vmcnt is in-order and
+  // counts stores too) and every global load has a whole sweep to land.
+  // timing aid: delay a subset of blocks to de-phase compute and memory phases across the chip
+  {
+    const int mode = (dbg >> 8) & 3, amount = (dbg >> 10) & 63;
+    const bool late = mode == 1 ? (blockIdx.x & 1) : mode == 2 ? (blockIdx.x >= gridDim.x / 2) : mode == 3 ? ((blockIdx.x >> 3) & 1) : false;
+    if (late)
+      for (int i = 0; i < amount; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  if (vec4) prefetch(unit_item(0));
+  stage(0);
+  setup(0);
+  __syncthreads();
+  if (vec4) prefetch(unit_item(min(1, my_units - 1)));
+  for (int u = 0; u < my_units; ++u) {
+    // ---- MFMA sweep, software-pipelined: the 16 LDS reads of step t+1 are issued one per MFMA of
+    //      step t (immediate-offset ds_read: no address arithmetic, no vector memory).
+    if (!(dbg & 4)) {
+    read_step(0, a[0]);
+#pragma unroll
+    for (int t = 0; t < G::T; ++t) {
+      if (t + 1 < G::T) read_step(t + 1, a[(t + 1) & 1]);
+#pragma unroll
+      for (int m = 0; m < PW * 4; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][nt], a[t & 1][m], acc[m][nt], 0, 0, 0);
+      if (t + 1 < G::T) {
+#pragma unroll
+        for (int m = 0; m < PW * 4; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);  // NT MFMAs …
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // … then one LDS read
+        }
+      }
+    }
+    }
+    __syncthreads();  // every wave is done reading the brick
+    if (!(dbg & 2)) stage(min(u + 1, my_units - 1));
+    if (u % npass == npass - 1 && !(dbg & 1)) {
+      int b, dq, wq, hq, pass;
+      item_coords(unit_item(u), b, dq, wq, hq, pass);
+      const int dz = dq * PD + wave;
+      if (dz < d.Do) {
+        if (out_layout == LR_LAYOUT_NDHWC) {
+          // buffer stores from the brick's first voxel: scalar tile offsets, one per-lane offset, and
+          // an out-of-range offset (store dropped) for voxels past the volume's edge
+          const int wo0 = wq * PW, ho0 = hq * PH;
+          float* org = out + ((((int64_t)b * d.Do + dz) * d.Wo + wo0) * d.Ho + ho0) * d.Cout;
+          const __amdgpu_buffer_rsrc_t orsrc =
+              __builtin_amdgcn_make_buffer_rsrc(org, (short)0, 0x7fffffff, 0x00020000);
+          const unsigned lo = (unsigned)((col * d.Cout + (lane >> 4) * 4) * 4);
+          const bool s01 = slope >= 0.0f && slope <= 1.0f;  // then lrelu(v) == max(v, v*slope): 2 VALU, no compare
+          const unsigned rowb = (unsigned)(d.Ho * d.Cout * 4), tileb = (unsigned)(16 * d.Cout * 4);
 #pragma unroll
           for (int y = 0; y < PW; ++y)
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-              const float a = base[y * S * G::RSL + x * 16 * S];
+              const bool ok = wo0 + y < d.Wo && ho0 + x * 16 + col < d.Ho;
+              const unsigned voff = lo | (ok ? 0u : OOR);
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) {
+                f32x4 v = acc[y * 4 + x][nt];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = s01 ? fmaxf(v[r], v[r] * slope) : lrelu(v[r], slope);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, voff,
+                                                       y * rowb + x * tileb + nt * 64, 0);
+              }
+            }
+        } else {
+#pragma unroll
+          for (int y = 0; y < PW; ++y)
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt)
-                acc[y][x][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[cc][q][nt], a, acc[y][x][nt], 0, 0, 0);
-            }
+                store_tile(acc[y * 4 + x][nt], out, d, b, dz, wq * PW + y, hq * PH + x * 16 + col, nt, lane,
+                           out_layout, slope);
         }
       }
     }
+    if (u + 1 < my_units) setup(u + 1);
+    __syncthreads();  // next brick visible in LDS
+    if (vec4 && !(dbg & 2)) prefetch(unit_item(min(u + 2, my_units - 1)));
   }
-  const int dz = do0 + wave;
-  if (dz >= d.Do) return;
-#pragma unroll
-  for (int y = 0; y < PW; ++y)
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        store_tile(acc[y][x][nt], out, d, b, dz, wo0 + y, ho0 + x * 16 + col, nt, lane, out_layout, slope);
 }
 
 // ===========================================================================
@@ -439,21 +562,24 @@ extern "C" int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, co
     else hipLaunchKernelGGL((conv3d_cl_kernel<2, 2>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope);
   } else if (in_layout == LR_LAYOUT_NCDHW) {
     d.nHq = (d.Ho + PH - 1) / PH; d.nWq = (d.Wo + PW - 1) / PW; d.nDq = (d.Do + PD - 1) / PD;
-    const int64_t nblk = (int64_t)B * d.nDq * d.nWq * d.nHq;
-    if (nblk > 0x7fffffffLL) return LR_EINVAL;
-    const dim3 grid((unsigned)nblk);
-    // channels staged per pass: as many as fit 60 KB of LDS (<= PCC, the register budget for weights)
-    const size_t cbytes = (size_t)(stride == 1 ? PlanarGeom<1>::CS : PlanarGeom<2>::CS) * sizeof(float);
-    int pcc = (int)((60 * 1024) / cbytes);
-    if (pcc > PCC) pcc = PCC;
-    if (pcc > Cin) pcc = Cin;
-    if (pcc < 1) pcc = 1;
-    const size_t lds1 = pcc * cbytes, lds2 = pcc * cbytes;
-    const int vec4 = (H % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0);
-    if (NT == 1 && stride == 1) hipLaunchKernelGGL((conv3d_planar_kernel<1, 1>), grid, block, lds1, st, in, packed_w, bias, out, d, out_layout, negative_slope, pcc, vec4);
-    else if (NT == 1) hipLaunchKernelGGL((conv3d_planar_kernel<1, 2>), grid, block, lds2, st, in, packed_w, bias, out, d, out_layout, negative_slope, pcc, vec4);
-    else if (stride == 1) hipLaunchKernelGGL((conv3d_planar_kernel<2, 1>), grid, block, lds1, st, in, packed_w, bias, out, d, out_layout, negative_slope, pcc, vec4);
-    else hipLaunchKernelGGL((conv3d_planar_kernel<2, 2>), grid, block, lds2, st, in, packed_w, bias, out, d, out_layout, negative_slope, pcc, vec4);
+    const int cc = stride == 1 ? 3 : 1;
+    const int npass = (Cin + cc - 1) / cc;
+    const int64_t nitems = (int64_t)B * d.nDq * d.nWq * d.nHq * npass;
+    if (nitems > 0x7fffffffLL) return LR_EINVAL;
+    // 16-byte staging needs aligned rows and a window (cc channels) within 31-bit buffer offsets
+    const int vec4 = (stride == 1) && (H % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0) &&
+                     ((int64_t)cc * D * W * H * 4 + (int64_t)16 * W * H * 4 < 0x7fffffffLL);
+    int64_t resident = 256 * 2;  // persistent blocks: 2 per CU (3 would spill: ~220 VGPRs)
+    if (const char* e = getenv("LIFTREG_CONV0_BLOCKS")) resident = atoi(e);  // tuning aid
+    const dim3 grid((unsigned)(nitems < resident ? nitems : resident));
+    const size_t lds1 = (size_t)3 * PlanarGeom<1, 3>::CS * sizeof(float);
+    const size_t lds2 = (size_t)1 * PlanarGeom<2, 1>::CS * sizeof(float);
+    const int ni = (int)nitems;
+    const int dbg = getenv("LIFTREG_CONV0_DBG") ? atoi(getenv("LIFTREG_CONV0_DBG")) : 0;  // timing ablations only
+    if (NT == 1 && stride == 1) hipLaunchKernelGGL((conv3d_planar_kernel<1, 1, 3>), grid, block, lds1, st, in, packed_w, bias, out, d, out_layout, negative_slope, vec4, ni, npass, dbg);
+    else if (NT == 1) hipLaunchKernelGGL((conv3d_planar_kernel<1, 2, 1>), grid, block, lds2, st, in, packed_w, bias, out, d, out_layout, negative_slope, 0, ni, npass, dbg);
+    else if (stride == 1) hipLaunchKernelGGL((conv3d_planar_kernel<2, 1, 3>), grid, block, lds1, st, in, packed_w, bias, out, d, out_layout, negative_slope, vec4, ni, npass, dbg);
+    else hipLaunchKernelGGL((conv3d_planar_kernel<2, 2, 1>), grid, block, lds2, st, in, packed_w, bias, out, d, out_layout, negative_slope, 0, ni, npass, dbg);
   } else {
     return LR_EINVAL;
   }
