@@ -207,6 +207,14 @@ __global__ __launch_bounds__(256) void backproject_tiled_kernel(
   }
   __syncthreads();
 
+  if (!any) {  // every shadow of this tile misses the detector: exact zeros, nothing to stage or read
+    for (int b = 0; b < B; ++b)
+      for (int jj = 0; jj < BT_TJ && j_base + jj < W; ++jj)
+        for (int ii = 0; ii < BT_TI && i_base + ii < Ds; ++ii)
+          for (int k = tid; k < H; k += 256)
+            out[(int64_t)b * out_batch_stride + (((int64_t)p * Ds + i_base + ii) * W + j_base + jj) * H + k] = 0.0f;
+    return;
+  }
   const int64_t view_sz = (int64_t)Pw * Ph;
   for (int b = 0; b < B; ++b) {
     const float* pv = proj + ((int64_t)b * P + p) * view_sz;

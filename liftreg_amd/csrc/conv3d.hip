@@ -299,41 +299,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_planar_kernel(const float* __re
       item_coords(unit_item(u), b, dq, wq, hq, pass);
       const int dz = dq * PD + wave;
       if (dz < d.Do) {
-        if (out_layout == LR_LAYOUT_NDHWC) {
-          // buffer stores from the brick's first voxel: scalar tile offsets, one per-lane offset, and
-          // an out-of-range offset (store dropped) for voxels past the volume's edge
-          const int wo0 = wq * PW, ho0 = hq * PH;
-          float* org = out + ((((int64_t)b * d.Do + dz) * d.Wo + wo0) * d.Ho + ho0) * d.Cout;
-          const __amdgpu_buffer_rsrc_t orsrc =
-              __builtin_amdgcn_make_buffer_rsrc(org, (short)0, 0x7fffffff, 0x00020000);
-          const unsigned lo = (unsigned)((col * d.Cout + (lane >> 4) * 4) * 4);
-          const bool s01 = slope >= 0.0f && slope <= 1.0f;  // then lrelu(v) == max(v, v*slope): 2 VALU, no compare
-          const unsigned rowb = (unsigned)(d.Ho * d.Cout * 4), tileb = (unsigned)(16 * d.Cout * 4);
+        // (an epilogue on raw_buffer_store_b128 was measured: no faster, and with two co-resident
+        //  blocks per CU it stored corrupted lanes at 256^3 — plain global stores are kept)
 #pragma unroll
-          for (int y = 0; y < PW; ++y)
+        for (int y = 0; y < PW; ++y)
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-              const bool ok = wo0 + y < d.Wo && ho0 + x * 16 + col < d.Ho;
-              const unsigned voff = lo | (ok ? 0u : OOR);
+          for (int x = 0; x < 4; ++x)
 #pragma unroll
-              for (int nt = 0; nt < NT; ++nt) {
-                f32x4 v = acc[y * 4 + x][nt];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = s01 ? fmaxf(v[r], v[r] * slope) : lrelu(v[r], slope);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, voff,
-                                                       y * rowb + x * tileb + nt * 64, 0);
-              }
-            }
-        } else {
-#pragma unroll
-          for (int y = 0; y < PW; ++y)
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt)
-                store_tile(acc[y * 4 + x][nt], out, d, b, dz, wq * PW + y, hq * PH + x * 16 + col, nt, lane,
-                           out_layout, slope);
-        }
+            for (int nt = 0; nt < NT; ++nt)
+              store_tile(acc[y * 4 + x][nt], out, d, b, dz, wq * PW + y, hq * PH + x * 16 + col, nt, lane,
+                         out_layout, slope);
       }
     }
     if (u + 1 < my_units) setup(u + 1);

@@ -133,7 +133,9 @@ def test_backproject_golden(golden, ops, dev, tag):
 
 def test_backproject_into_concat_buffer_and_ragged(ops, dev):
     rs = np.random.RandomState(9)
-    for (D, W, H), (Pw, Ph), P, B in (((20, 18, 24), (22, 26), 2, 3), ((9, 7, 11), (13, 5), 4, 2), ((16, 16, 16), (16, 16), 11, 9)):
+    # (last case: a detector much smaller than the volume → whole tiles whose shadows miss it)
+    for (D, W, H), (Pw, Ph), P, B in (((20, 18, 24), (22, 26), 2, 3), ((9, 7, 11), (13, 5), 4, 2), ((16, 16, 16), (16, 16), 11, 9),
+                                      ((40, 16, 24), (6, 5), 2, 2)):
         proj = rs.uniform(-1, 1, (B, P, Pw, Ph)).astype(np.float32)
         poses = ro.scan_poses(30, P, W).astype(np.float32)
         want = co.backproject(proj, poses, (D, W, H))

@@ -1,0 +1,215 @@
+"""GPU, BASELINE.json's full sizes (256^3 CT, 2x256^2 DRR, B up to 8): size-independent properties
+of the HIP path, where running the CPU oracle would take minutes — plus the C1 configuration
+(64^3, 2x64^2, B=1) end to end against the torch-CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+N = 256
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from liftreg_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def poses():
+    from liftreg_amd.utils.sdct_projection_utils import scan_poses
+    return scan_poses(30, 2, N).astype(np.float32)
+
+
+def test_drr_constant_volume_is_path_length_times_mu(ops, dev, poses):
+    """DRR of a constant-μ cube: 0.1·dx·μ·(#planes whose sample lies inside) — and linear in μ."""
+    mu = 0.2
+    vol = torch.full((N, N, N), mu, device=dev)
+    drr = ops.drr_forward(vol, poses, (N, N), (2.2, 2.2, 2.2))
+    _, dx = ops.drr_sample_coords(poses, (2.2, 2.2, 2.2), (N, N, N), (8, 8), dev)
+    c = drr[:, N // 2 - 4:N // 2 + 4, N // 2 - 4:N // 2 + 4]          # central rays cross all 256 planes inside
+    dxc = float(dx.mean())
+    assert 2.2 <= dxc <= 2.4
+    np.testing.assert_allclose(c.cpu().numpy(), 0.1 * dxc * mu * N, rtol=2e-2)
+    drr2 = ops.drr_forward(vol * 2, poses, (N, N), (2.2, 2.2, 2.2))
+    np.testing.assert_allclose(drr2.cpu().numpy(), 2 * drr.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    assert float(drr.min()) >= 0.0 and torch.isfinite(drr).all()
+
+
+def test_drr_slab_partials_sum_and_nseg_agree(ops, dev, poses):
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    vol = torch.rand((N, N, N), generator=g, device=dev) * 0.3
+    full = ops.drr_forward(vol, poses, (N, N), (2.2, 2.2, 2.2), nseg=1)
+    parts = [ops.drr_forward(vol[a:b].contiguous(), poses, (N, N), (2.2, 2.2, 2.2), d0=a, d1=b, full_D=N, nseg=1)
+             for a, b in ((0, 64), (64, 128), (128, 192), (192, N))]
+    np.testing.assert_allclose(sum(parts).cpu().numpy(), full.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    for nseg in (2, 4, 8, 16):
+        np.testing.assert_allclose(ops.drr_forward(vol, poses, (N, N), (2.2, 2.2, 2.2), nseg=nseg).cpu().numpy(),
+                                   full.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_backproject_constant_view_is_constant_inside_cone(ops, dev, poses):
+    """Backprojecting constant views gives that constant wherever the voxel's shadow is strictly inside
+    the detector, exact zeros where it misses it, and is linear in the views; slabs equal rows."""
+    B, P = 2, 2
+    proj = torch.full((B, P, N, N), 0.75, device=dev)
+    tv = ops.backproject(proj, poses, (N, N, N))
+    pix = ops.backproject_coords(poses, (N, N, N), (N, N), dev)
+    inside = ((pix[..., 0] >= 0) & (pix[..., 0] <= N - 1) & (pix[..., 1] >= 0) & (pix[..., 1] <= N - 1))
+    outside = ((pix[..., 0] <= -1) | (pix[..., 0] >= N) | (pix[..., 1] <= -1) | (pix[..., 1] >= N))
+    assert 0.5 < float(inside.float().mean()) < 1.0
+    for b in range(B):
+        assert float((tv[b][inside] - 0.75).abs().max()) < 1e-6
+        assert float(tv[b][outside].abs().max()) == 0.0
+    g = torch.Generator(device=dev)
+    g.manual_seed(2)
+    p1, p2 = torch.rand((B, P, N, N), generator=g, device=dev), torch.rand((B, P, N, N), generator=g, device=dev)
+    lhs = ops.backproject(p1 + 2 * p2, poses, (N, N, N))
+    rhs = ops.backproject(p1, poses, (N, N, N)) + 2 * ops.backproject(p2, poses, (N, N, N))
+    assert float((lhs - rhs).abs().max()) < 2e-6
+    slab = ops.backproject(p1, poses, (N, N, N), d0=100, d1=140)
+    assert torch.equal(slab, ops.backproject(p1, poses, (N, N, N))[:, :, 100:140])
+
+
+def test_identity_phi_warp_is_identity_and_slabs_match(ops, dev):
+    from liftreg_amd.utils.net_utils import identity_axis_tables
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    img = torch.rand((2, 1, N, N, N), generator=g, device=dev) * 2 - 1
+    ids = [torch.from_numpy(t).to(dev) for t in identity_axis_tables((N, N, N))]
+    zero = torch.zeros((2, 3, N, N, N), device=dev)
+    phi, w = ops.warp(img, zero, ids, None)
+    assert float((w - img).abs().max()) < 1e-4      # identity up to fp32 coordinate rounding (~1e-5 px x white-noise gradient)
+    _, wn = ops.warp(img, zero, ids, None, mode="nearest")
+    assert torch.equal(wn, (img + 1) / 2 * 2 - 1)                       # nearest: exactly the scaled voxel
+    disp = (torch.rand((2, 3, N, N, N), generator=g, device=dev) - 0.5) * 0.05
+    _, wfull = ops.warp(img, disp, ids, None)
+    _, wslab = ops.warp(img, disp[:, :, 64:96].contiguous(), (ids[0][64:96].contiguous(), ids[1], ids[2]), None, d0=64, d1=96)
+    assert torch.equal(wslab, wfull[:, :, 64:96])
+    assert float(wfull.min()) >= -1.0 - 1e-6 and float(wfull.max()) <= 1.0 + 1e-6
+
+
+def test_ncc_properties_full_size(ops, dev):
+    from liftreg_amd.layers.losses import NCCLoss
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    x = torch.rand((4, 1, N, N, N), generator=g, device=dev) * 2 - 1
+    y = torch.rand((4, 1, N, N, N), generator=g, device=dev) * 2 - 1
+    f = NCCLoss()
+    assert abs(float(f(x, x))) < 1e-6                                    # NCC(x,x) = 1
+    assert abs(float(f(x, -x)) - 2.0) < 1e-6                             # NCC(x,-x) = -1
+    assert abs(float(f(x, 3 * x + 0.5))) < 1e-6                          # invariant to affine intensity maps
+    assert abs(float(f(x, y)) - 1.0) < 1e-3                              # independent noise: ~0 correlation
+    assert abs(float(f(x, y)) - float(f(y, x))) < 1e-7                   # symmetric
+    m = ops.ncc_moments(x, y, 4)
+    cut = N ** 3 // 2
+    xs, ys = x.reshape(4, -1), y.reshape(4, -1)
+    m2 = ops.ncc_moments(xs[:, :cut].contiguous(), ys[:, :cut].contiguous(), 4) + \
+        ops.ncc_moments(xs[:, cut:].contiguous(), ys[:, cut:].contiguous(), 4)
+    np.testing.assert_allclose(m2.cpu().numpy(), m.cpu().numpy(), rtol=1e-10)
+    ref = 1 - torch.stack([torch.corrcoef(torch.stack([x[i].flatten().double(), y[i].flatten().double()]))[0, 1] for i in range(4)]).mean()
+    assert abs(float(f(x, y)) - float(ref)) < 1e-6
+
+
+def test_pca_linearity_and_zero_coefs(ops, dev):
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    L, M, B = 56, 3 * 128 ** 3, 8
+    basis = torch.empty((L, M), device=dev).normal_(0, 0.01, generator=g)
+    mean = torch.empty((M,), device=dev).normal_(0, 0.01, generator=g)
+    z = ops.pca_reconstruct(torch.zeros((B, L), device=dev), basis, mean)
+    assert torch.equal(z, mean.expand(B, M))                             # coefs = 0 → the mean, bit for bit
+    e = torch.zeros((B, L), device=dev)
+    e[torch.arange(B), torch.arange(B) * 7] = 1.0
+    one = ops.pca_reconstruct(e, basis, mean)
+    for b in range(B):                                                   # unit coefficient → that basis row + mean
+        assert float((one[b] - (basis[b * 7] + mean)).abs().max()) < 1e-7
+    c1, c2 = torch.randn((B, L), generator=g, device=dev), torch.randn((B, L), generator=g, device=dev)
+    lhs = ops.pca_reconstruct(c1 + c2, basis, mean)
+    rhs = ops.pca_reconstruct(c1, basis, mean) + ops.pca_reconstruct(c2, basis, mean) - mean
+    assert float((lhs - rhs).abs().max()) < 5e-6
+
+
+def test_conv_full_size_all_layers_vs_independent_gpu_conv(ops, dev):
+    """The encoder's conv blocks at C3 size (256^3 → 8^3), every element, in both output layouts, against
+    PyTorch-ROCm's own conv3d (MIOpen) on the same GPU — an implementation that shares no code with ours and
+    is itself tied to the reference by the small-size oracle tests.  Exercises what small shapes cannot:
+    the persistent brick loop of the first block (hundreds of bricks per workgroup, two workgroups per CU)
+    and 31-bit buffer offsets of the channels-last blocks."""
+    F = torch.nn.functional
+    g = torch.Generator(device=dev)
+    g.manual_seed(6)
+    x = torch.rand((2, 3, N, N, N), generator=g, device=dev) * 2 - 1
+    chans = [(3, 16, 1), (16, 32, 2), (32, 32, 2), (32, 32, 2), (32, 32, 2), (32, 32, 2)]
+    cur_ncdhw = x
+    for i, (ci, co, s) in enumerate(chans):
+        w = torch.randn((co, ci, 3, 3, 3), generator=g, device=dev) / (27 * ci) ** 0.5
+        b = torch.randn((co,), generator=g, device=dev) * 0.1
+        ref = F.leaky_relu(F.conv3d(cur_ncdhw, w, b, stride=s, padding=1), 0.2)
+        if i == 0:
+            y_nc = ops.conv3d_k3_lrelu(cur_ncdhw, w, b, s)
+            y_cl = ops.conv3d_k3_lrelu(cur_ncdhw, w, b, s, out_layout=ops.LAYOUT_NDHWC)
+        else:
+            xin = cur_ncdhw.permute(0, 2, 3, 4, 1).contiguous()
+            y_nc = ops.conv3d_k3_lrelu(xin, w, b, s, in_layout=ops.LAYOUT_NDHWC, out_layout=ops.LAYOUT_NCDHW)
+            y_cl = ops.conv3d_k3_lrelu(xin, w, b, s, in_layout=ops.LAYOUT_NDHWC, out_layout=ops.LAYOUT_NDHWC)
+        assert torch.equal(y_cl.permute(0, 4, 1, 2, 3), y_nc), f"layer {i}: layouts disagree"
+        err = (y_nc - ref).abs()
+        tol = 1e-4 * ref.abs() + 2e-5
+        bad = (err > tol).nonzero()
+        # Any disagreement is arbitrated on the CPU (torch CPU conv on the 3x3x3 neighbourhood): MIOpen itself
+        # returns a wrong constant for the first three voxels of this very input at batch 2 (observed on
+        # ROCm 7.2 / MI355X), so neither GPU implementation is taken on trust.
+        assert bad.shape[0] <= 256, f"layer {i}: {bad.shape[0]} disagreements, max err {float(err.max()):.3e}"
+        for bi, _, z, yy, xx in {(r[0], 0, r[2], r[3], r[4]) for r in bad.tolist()}:
+            zi, yi, xi = z * s, yy * s, xx * s
+            crop = torch.zeros((1, ci, 3, 3, 3))
+            for dz in range(3):
+                for dy in range(3):
+                    for dx in range(3):
+                        a, bb, c = zi + dz - 1, yi + dy - 1, xi + dx - 1
+                        if 0 <= a < cur_ncdhw.shape[2] and 0 <= bb < cur_ncdhw.shape[3] and 0 <= c < cur_ncdhw.shape[4]:
+                            crop[0, :, dz, dy, dx] = cur_ncdhw[bi, :, a, bb, c].cpu()
+            want = F.leaky_relu(F.conv3d(crop, w.cpu(), b.cpu()), 0.2).flatten()
+            got = y_nc[bi, :, z, yy, xx].cpu()
+            np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=2e-5,
+                                       err_msg=f"layer {i} voxel {(bi, z, yy, xx)}: CPU arbitration says OUR kernel is wrong")
+        cur_ncdhw = y_nc          # feed the next layer with the (CPU-arbitrated) output
+        del y_cl, err, tol
+
+
+def test_c1_config_end_to_end_vs_oracle(dev):
+    """BASELINE configs[0]: 64^3 CT, 2x64^2 DRR, disp_subspace model, batch 1 — whole path vs the torch-CPU oracle."""
+    from liftreg_amd import ops
+    from liftreg_amd.layers.losses import NCCLoss
+    from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+    from oracle import ref_ops as ro
+    n, P, L = 64, 2, 56
+    torch.manual_seed(2021)
+    rs = np.random.RandomState(2021)
+    net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:5"}).to(dev).eval()
+    hu = np.clip(rs.normal(-400, 300, (n, n, n)), -1024, 1000).astype(np.float32)
+    poses = ro.scan_poses(30, P, n)
+    mu = ro.calc_relative_atten_coef(np.flip(hu, 1).copy())
+    drr_ref = ro.drr_forward(mu, poses, (n, n), (2.2, 2.2, 2.2))
+    drr = ops.drr_forward(torch.from_numpy(hu).to(dev), poses.astype(np.float32), (n, n), (2.2, 2.2, 2.2), hu_input=True, flip_w=True)
+    np.testing.assert_allclose(drr.cpu().numpy(), drr_ref, rtol=1e-4, atol=1e-5)
+    norm = lambda v: ((np.clip(v, -1000, 0) + 1000) / 1000 * 2 - 1).astype(np.float32)
+    inp = {"source": torch.from_numpy(norm(np.roll(hu, 2, 0)))[None, None], "target": torch.from_numpy(norm(hu))[None, None],
+           "target_proj": torch.from_numpy((np.clip(drr_ref, 0, 6) / 6 * 2 - 1).astype(np.float32))[None],
+           "target_poses": torch.from_numpy(poses.astype(np.float32))[None]}
+    with torch.no_grad():
+        out = net({k: (v.to(dev) if v.dim() > 3 else v) for k, v in inp.items()})
+        loss = NCCLoss()(out["warped"], out["target"])
+        ref = ro.model_forward({k: v.cpu() for k, v in net.state_dict().items()}, inp, net.pca_vectors_LxM.cpu(), net.pca_mean.cpu())
+        ref_loss = ro.ncc_loss(ref["warped"], ref["target"])
+    np.testing.assert_allclose(out["params"].cpu().numpy(), ref["params"].numpy(), rtol=1e-4, atol=1e-6)   # displacement field
+    np.testing.assert_allclose(out["warped"].cpu().numpy(), ref["warped"].numpy(), rtol=1e-4, atol=2e-5)
+    assert abs(float(loss) - float(ref_loss)) < 1e-5
