@@ -102,6 +102,24 @@ __device__ __forceinline__ float load_mu(const float* p, bool ok) {
   return ok ? v : 0.0f;
 }
 
+template <bool HU>
+__device__ __forceinline__ float mu_of(float v) {
+  if constexpr (HU) {
+    v = (v < -1000.0f) ? -1000.0f : v;
+    v = ((v + 1000.0f) / 1000.0f) * 0.2f;
+  }
+  return v;
+}
+template <bool HU>
+__device__ __forceinline__ void load_mu_pair(const float* p, int shift, bool ok0, bool ok1, float& v0,
+                                             float& v1) {
+  typedef float f32x2 __attribute__((ext_vector_type(2), aligned(4)));
+  const f32x2 q = *reinterpret_cast<const f32x2*>(p);
+  const float a = mu_of<HU>(shift > 0 ? q.y : q.x), b = mu_of<HU>(shift < 0 ? q.x : q.y);
+  v0 = ok0 ? a : 0.0f;
+  v1 = ok1 ? b : 0.0f;
+}
+
 // blockDim = (64, R): lane ↔ detector column b; row r ↔ (a, segment).
 template <bool HU, bool FLIP>
 __global__ __launch_bounds__(1024) void drr_forward_kernel(
@@ -145,15 +163,26 @@ __global__ __launch_bounds__(1024) void drr_forward_kernel(
       const float* p01 = vol + (int64_t)(az.i0 - d0) * sD + (int64_t)y1 * sW;
       const float* p10 = vol + (int64_t)(az.i1 - d0) * sD + (int64_t)y0 * sW;
       const float* p11 = vol + (int64_t)(az.i1 - d0) * sD + (int64_t)y1 * sW;
-      // issue all 8 gathers before any use
-      const float v_tnw = load_mu<HU>(p00 + ax.i0, az.ok0 && ay.ok0 && ax.ok0);
-      const float v_tne = load_mu<HU>(p00 + ax.i1, az.ok0 && ay.ok0 && ax.ok1);
-      const float v_tsw = load_mu<HU>(p01 + ax.i0, az.ok0 && ay.ok1 && ax.ok0);
-      const float v_tse = load_mu<HU>(p01 + ax.i1, az.ok0 && ay.ok1 && ax.ok1);
-      const float v_bnw = load_mu<HU>(p10 + ax.i0, az.ok1 && ay.ok0 && ax.ok0);
-      const float v_bne = load_mu<HU>(p10 + ax.i1, az.ok1 && ay.ok0 && ax.ok1);
-      const float v_bsw = load_mu<HU>(p11 + ax.i0, az.ok1 && ay.ok1 && ax.ok0);
-      const float v_bse = load_mu<HU>(p11 + ax.i1, az.ok1 && ay.ok1 && ax.ok1);
+      // the two H-taps of a corner pair are neighbours: one 8-byte gather fetches both (halves the
+      // gather instructions); xb = clamp(floor, 0, H-2), the in-range tap is picked out of the pair
+      float v_tnw, v_tne, v_tsw, v_tse, v_bnw, v_bne, v_bsw, v_bse;
+      if (H >= 2) {
+        const int x0 = ax.ok0 ? ax.i0 : ax.i1 - 1;  // unclamped floor (or -1 when nothing is in range)
+        const int xb = min(max(x0, 0), H - 2), shift = x0 - xb;
+        load_mu_pair<HU>(p00 + xb, shift, az.ok0 && ay.ok0 && ax.ok0, az.ok0 && ay.ok0 && ax.ok1, v_tnw, v_tne);
+        load_mu_pair<HU>(p01 + xb, shift, az.ok0 && ay.ok1 && ax.ok0, az.ok0 && ay.ok1 && ax.ok1, v_tsw, v_tse);
+        load_mu_pair<HU>(p10 + xb, shift, az.ok1 && ay.ok0 && ax.ok0, az.ok1 && ay.ok0 && ax.ok1, v_bnw, v_bne);
+        load_mu_pair<HU>(p11 + xb, shift, az.ok1 && ay.ok1 && ax.ok0, az.ok1 && ay.ok1 && ax.ok1, v_bsw, v_bse);
+      } else {
+        v_tnw = load_mu<HU>(p00 + ax.i0, az.ok0 && ay.ok0 && ax.ok0);
+        v_tne = load_mu<HU>(p00 + ax.i1, az.ok0 && ay.ok0 && ax.ok1);
+        v_tsw = load_mu<HU>(p01 + ax.i0, az.ok0 && ay.ok1 && ax.ok0);
+        v_tse = load_mu<HU>(p01 + ax.i1, az.ok0 && ay.ok1 && ax.ok1);
+        v_bnw = load_mu<HU>(p10 + ax.i0, az.ok1 && ay.ok0 && ax.ok0);
+        v_bne = load_mu<HU>(p10 + ax.i1, az.ok1 && ay.ok0 && ax.ok1);
+        v_bsw = load_mu<HU>(p11 + ax.i0, az.ok1 && ay.ok1 && ax.ok0);
+        v_bse = load_mu<HU>(p11 + ax.i1, az.ok1 && ay.ok1 && ax.ok1);
+      }
       // weights: (x-part * y-part) * z-part, corners in ATen's order
       float s = v_tnw * ((ax.w0 * ay.w0) * az.w0);
       s = s + v_tne * ((ax.w1 * ay.w0) * az.w0);

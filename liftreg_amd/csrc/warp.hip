@@ -59,6 +59,30 @@ __device__ __forceinline__ float tap(const float* img, const float* seg, int64_t
   return ok ? v : 0.0f;
 }
 
+// The two x-taps of a corner pair are neighbours in memory: one 8-byte gather (dword-aligned
+// global_load_dwordx2) fetches both, halving the gather instructions the texture addresser sees.
+// xb = clamp(i0, 0, H-2) is the pair's base column; at the volume's x faces the in-range tap is
+// picked out of the pair and the other one is dropped by its ok flag, exactly as before.
+template <bool SCALE, bool SEG>
+__device__ __forceinline__ void tap_pair(const float* img, const float* seg, int64_t rowoff, int xb,
+                                         int shift, bool ok0, bool ok1, float& v0, float& v1) {
+  typedef float f32x2 __attribute__((ext_vector_type(2), aligned(4)));
+  const f32x2 p = *reinterpret_cast<const f32x2*>(img + rowoff + xb);
+  float a = shift > 0 ? p.y : p.x;   // tap i0   (shift = i0 - xb in {-1,0,+1})
+  float b = shift < 0 ? p.x : p.y;   // tap i0+1
+  if constexpr (SEG) {
+    const f32x2 q = *reinterpret_cast<const f32x2*>(seg + rowoff + xb);
+    a = (a + 1.0f) * (shift > 0 ? q.y : q.x) - 1.0f;  // (moving+1)*moving_seg-1
+    b = (b + 1.0f) * (shift < 0 ? q.x : q.y) - 1.0f;
+  }
+  if constexpr (SCALE) {
+    a = (a + 1.0f) * 0.5f;  // (input1 + 1) / 2
+    b = (b + 1.0f) * 0.5f;
+  }
+  v0 = ok0 ? a : 0.0f;
+  v1 = ok1 ? b : 0.0f;
+}
+
 template <int VEC, bool SCALE, bool BORDER, bool NEAREST, bool SEG>
 __global__ __launch_bounds__(256) void warp_kernel(
     const float* __restrict__ img, const float* __restrict__ seg, const float* __restrict__ disp,
@@ -133,14 +157,25 @@ __global__ __launch_bounds__(256) void warp_kernel(
         const int64_t o01 = (int64_t)az.i0 * sD + (int64_t)ay.i1 * H;
         const int64_t o10 = (int64_t)az.i1 * sD + (int64_t)ay.i0 * H;
         const int64_t o11 = (int64_t)az.i1 * sD + (int64_t)ay.i1 * H;
-        const float v_tnw = tap<SCALE, SEG>(im, sg, o00 + ax.i0, az.ok0 && ay.ok0 && ax.ok0);
-        const float v_tne = tap<SCALE, SEG>(im, sg, o00 + ax.i1, az.ok0 && ay.ok0 && ax.ok1);
-        const float v_tsw = tap<SCALE, SEG>(im, sg, o01 + ax.i0, az.ok0 && ay.ok1 && ax.ok0);
-        const float v_tse = tap<SCALE, SEG>(im, sg, o01 + ax.i1, az.ok0 && ay.ok1 && ax.ok1);
-        const float v_bnw = tap<SCALE, SEG>(im, sg, o10 + ax.i0, az.ok1 && ay.ok0 && ax.ok0);
-        const float v_bne = tap<SCALE, SEG>(im, sg, o10 + ax.i1, az.ok1 && ay.ok0 && ax.ok1);
-        const float v_bsw = tap<SCALE, SEG>(im, sg, o11 + ax.i0, az.ok1 && ay.ok1 && ax.ok0);
-        const float v_bse = tap<SCALE, SEG>(im, sg, o11 + ax.i1, az.ok1 && ay.ok1 && ax.ok1);
+        float v_tnw, v_tne, v_tsw, v_tse, v_bnw, v_bne, v_bsw, v_bse;
+        if (H >= 2) {
+          // unclamped floor: ax.i0 was clamped up from -1 exactly when tap 0 is out of range
+          const int x0 = ax.ok0 ? ax.i0 : ax.i1 - 1;
+          const int xb = min(max(x0, 0), H - 2), shift = x0 - xb;
+          tap_pair<SCALE, SEG>(im, sg, o00, xb, shift, az.ok0 && ay.ok0 && ax.ok0, az.ok0 && ay.ok0 && ax.ok1, v_tnw, v_tne);
+          tap_pair<SCALE, SEG>(im, sg, o01, xb, shift, az.ok0 && ay.ok1 && ax.ok0, az.ok0 && ay.ok1 && ax.ok1, v_tsw, v_tse);
+          tap_pair<SCALE, SEG>(im, sg, o10, xb, shift, az.ok1 && ay.ok0 && ax.ok0, az.ok1 && ay.ok0 && ax.ok1, v_bnw, v_bne);
+          tap_pair<SCALE, SEG>(im, sg, o11, xb, shift, az.ok1 && ay.ok1 && ax.ok0, az.ok1 && ay.ok1 && ax.ok1, v_bsw, v_bse);
+        } else {
+          v_tnw = tap<SCALE, SEG>(im, sg, o00 + ax.i0, az.ok0 && ay.ok0 && ax.ok0);
+          v_tne = tap<SCALE, SEG>(im, sg, o00 + ax.i1, az.ok0 && ay.ok0 && ax.ok1);
+          v_tsw = tap<SCALE, SEG>(im, sg, o01 + ax.i0, az.ok0 && ay.ok1 && ax.ok0);
+          v_tse = tap<SCALE, SEG>(im, sg, o01 + ax.i1, az.ok0 && ay.ok1 && ax.ok1);
+          v_bnw = tap<SCALE, SEG>(im, sg, o10 + ax.i0, az.ok1 && ay.ok0 && ax.ok0);
+          v_bne = tap<SCALE, SEG>(im, sg, o10 + ax.i1, az.ok1 && ay.ok0 && ax.ok1);
+          v_bsw = tap<SCALE, SEG>(im, sg, o11 + ax.i0, az.ok1 && ay.ok1 && ax.ok0);
+          v_bse = tap<SCALE, SEG>(im, sg, o11 + ax.i1, az.ok1 && ay.ok1 && ax.ok1);
+        }
         float s = v_tnw * ((ax.w0 * ay.w0) * az.w0);
         s = s + v_tne * ((ax.w1 * ay.w0) * az.w0);
         s = s + v_tsw * ((ax.w0 * ay.w1) * az.w0);

@@ -3,6 +3,7 @@
 import csv
 import glob
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -13,7 +14,9 @@ for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), rec
         k = row.get("Kernel_Name", "")
         if "at::native" in k or "rocclr" in k:
             continue
-        short = k.split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+        short = re.sub(r"^void\s+", "", k).replace("(anonymous namespace)::", "")
+        m = re.match(r"([A-Za-z0-9_]+(<[^>]*>)?)", short)
+        short = m.group(1) if m else short[:60]
         agg[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, cs in sorted(agg.items()):
     n = max(len(v) for v in cs.values())
