@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libliftreg_hip.so")
 
 LR_OK = 0
-LAYOUT_NCDHW, LAYOUT_NDHWC = 0, 1
+LAYOUT_NCDHW, LAYOUT_NDHWC, LAYOUT_NDHWC_HPS = 0, 1, 2
 DRR_HU_INPUT, DRR_FLIP_W = 1, 2
 WARP_USING_SCALE, WARP_BORDER, WARP_NEAREST = 1, 2, 4
 NCC_CONFIGURED, NCC_SQUARED = 0, 1

@@ -57,6 +57,10 @@ __device__ __forceinline__ void store_tile(const f32x4& acc, float* __restrict__
   if (out_layout == LR_LAYOUT_NDHWC) {
     float* o = out + ((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + ho) * d.Cout + c0;
     *reinterpret_cast<f32x4*>(o) = v;
+  } else if (out_layout == LR_LAYOUT_NDHWC_HPS) {  // even voxels of the row first, then the odd ones
+    const int hp = (ho & 1) * ((d.Ho + 1) >> 1) + (ho >> 1);
+    float* o = out + ((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + hp) * d.Cout + c0;
+    *reinterpret_cast<f32x4*>(o) = v;
   } else {
     const int64_t vo = (int64_t)d.Do * d.Wo * d.Ho;
     float* o = out + ((int64_t)b * d.Cout + c0) * vo + ((int64_t)dz * d.Wo + wo) * d.Ho + ho;
@@ -326,7 +330,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_planar_kernel(const float* __re
 constexpr int MT = 4;
 constexpr int TD = 4;
 
-template <int NT, int STRIDE>
+// PS: the input rows are parity-split along H (LR_LAYOUT_NDHWC_HPS: even voxels, then odd voxels), which
+// makes every stride-2 tap of a 16-voxel tile ONE contiguous run — 8 full cache lines per load instead of
+// 16 half-used ones (the texture addresser, not the matrix pipe, bounds the plain stride-2 layout).
+template <int NT, int STRIDE, bool PS>
 __global__ __launch_bounds__(256) void conv3d_cl_kernel(const float* __restrict__ in,
                                                         const float4* __restrict__ wp,
                                                         const float* __restrict__ bias,
@@ -355,13 +362,15 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(const float* __restrict_
   // this wavefront's input window (it may lie before the tensor: never dereferenced there).  A tap
   // that falls into the conv's zero padding gets an out-of-range offset, for which the hardware
   // returns 0 — no branch, no select, so the loads stay unconditional and pipeline (guide T8).
-  const int zi0 = dz * STRIDE - 1, yw0 = wo0 * STRIDE - 1, xh0 = hq * 16 * STRIDE - 1;
+  const int zi0 = dz * STRIDE - 1, yw0 = wo0 * STRIDE - 1;
+  const int xh0 = PS ? hq * 16 - 1 : hq * 16 * STRIDE - 1;  // PS: position inside a parity half-row
   const int64_t inb = (int64_t)b * d.D * d.W * d.H * d.Cin;
   const float* wbase = in + inb + (((int64_t)zi0 * d.W + yw0) * d.H + xh0) * d.Cin;
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wbase), (short)0, 0x7fffffff, 0x00020000);
   constexpr unsigned OOR = 0x80000000u;
-  const unsigned lvoff = (unsigned)(col * STRIDE * d.Cin * 4 + kq * 16);
+  const unsigned lvoff = (unsigned)(col * (PS ? 1 : STRIDE) * d.Cin * 4 + kq * 16);
+  const int half_h = (d.H + 1) >> 1;  // PS: the odd voxels of a row start here
   unsigned nvmask[MT];  // bit tap CLEAR = that tap of this lane's voxel in tile mt is inside the tensor
   {
     const int xi0 = ho * STRIDE - 1;
@@ -396,7 +405,10 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(const float* __restrict_
   auto load_step = [&](int s, float4 (&a)[MT], float4 (&bw)[NT]) {
     const int tap = s / CB, cb = s - tap * CB;  // wave-uniform
     const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
-    const unsigned soff = (unsigned)(((tz * d.W + ty) * d.H + tx) * d.Cin * 4 + cb * 64);
+    // PS (stride 2): tap tx reads voxel 2*ho+tx-1 — tx=1: even half, index ho; tx=0: odd half, index ho-1;
+    // tx=2: odd half, index ho (xh0 already carries the -1)
+    const int xs = PS ? (tx == 1 ? 1 : half_h + (tx >> 1)) : tx;
+    const unsigned soff = (unsigned)(((tz * d.W + ty) * d.H + xs) * d.Cin * 4 + cb * 64);
     // branch-free: bit 31 of the offset is set (=> out of range => 0) unless tap and channel are valid
     const unsigned coor = (cb * 16 + kq * 4 < d.Cin) ? 0u : OOR;
 #pragma unroll
@@ -479,7 +491,7 @@ __global__ void pack_planar_kernel(const float* __restrict__ w, float* __restric
 extern "C" int64_t lr_conv3d_packed_floats(int Cin, int Cout, int in_layout) {
   if (Cin < 1 || (Cout != 16 && Cout != 32)) return LR_EUNSUPPORTED;
   const int NT = Cout / 16;
-  if (in_layout == LR_LAYOUT_NDHWC) return (int64_t)27 * ((Cin + 15) / 16) * NT * 64 * 4;
+  if (in_layout == LR_LAYOUT_NDHWC || in_layout == LR_LAYOUT_NDHWC_HPS) return (int64_t)27 * ((Cin + 15) / 16) * NT * 64 * 4;
   if (in_layout == LR_LAYOUT_NCDHW) return (int64_t)Cin * 7 * NT * 64;
   return LR_EINVAL;
 }
@@ -490,7 +502,7 @@ extern "C" int lr_conv3d_pack_weights_f32(const float* weight, float* packed, in
   if (Cin < 1) return LR_EINVAL;
   if (Cout != 16 && Cout != 32) return LR_EUNSUPPORTED;
   const int NT = Cout / 16;
-  if (in_layout == LR_LAYOUT_NDHWC) {
+  if (in_layout == LR_LAYOUT_NDHWC || in_layout == LR_LAYOUT_NDHWC_HPS) {
     if (Cin % 4) return LR_EUNSUPPORTED;
     const int CB = (Cin + 15) / 16;
     const int total = 27 * CB * NT * 64;
@@ -514,16 +526,19 @@ extern "C" int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, co
   if (B < 1 || Cin < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
   if (stride != 1 && stride != 2) return LR_EUNSUPPORTED;
   if (Cout != 16 && Cout != 32) return LR_EUNSUPPORTED;
-  if (out_layout != LR_LAYOUT_NCDHW && out_layout != LR_LAYOUT_NDHWC) return LR_EINVAL;
-  if (out_layout == LR_LAYOUT_NDHWC && (reinterpret_cast<uintptr_t>(out) & 15u)) return LR_EALIGN;
+  if (out_layout != LR_LAYOUT_NCDHW && out_layout != LR_LAYOUT_NDHWC && out_layout != LR_LAYOUT_NDHWC_HPS)
+    return LR_EINVAL;
+  if (out_layout != LR_LAYOUT_NCDHW && (reinterpret_cast<uintptr_t>(out) & 15u)) return LR_EALIGN;
   ConvDims d;
   d.B = B; d.Cin = Cin; d.Cout = Cout; d.D = D; d.W = W; d.H = H;
   d.Do = (D - 1) / stride + 1; d.Wo = (W - 1) / stride + 1; d.Ho = (H - 1) / stride + 1;
   hipStream_t st = lr_stream(stream);
   const int NT = Cout / 16;
   const dim3 block(256);
-  if (in_layout == LR_LAYOUT_NDHWC) {
+  if (in_layout == LR_LAYOUT_NDHWC || in_layout == LR_LAYOUT_NDHWC_HPS) {
+    const bool ps = in_layout == LR_LAYOUT_NDHWC_HPS;
     if (Cin % 4) return LR_EUNSUPPORTED;
+    if (ps && (stride != 2 || (H & 1))) return LR_EUNSUPPORTED;  // parity-split rows feed stride-2 blocks only
     if (reinterpret_cast<uintptr_t>(in) & 15u) return LR_EALIGN;
     if ((int64_t)12 * W * H * Cin + 4096 >= 0x7fffffffLL) return LR_EINVAL;  // 32-bit buffer offsets of a 3-plane window
     d.nHq = (d.Ho + 15) / 16; d.nWq = (d.Wo + MT - 1) / MT; d.nDq = (d.Do + TD - 1) / TD;
@@ -531,10 +546,12 @@ extern "C" int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, co
     if (nblk > 0x7fffffffLL) return LR_EINVAL;
     const dim3 grid((unsigned)nblk);
     const float4* wt = reinterpret_cast<const float4*>(packed_w);
-    if (NT == 1 && stride == 1) hipLaunchKernelGGL((conv3d_cl_kernel<1, 1>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope);
-    else if (NT == 1) hipLaunchKernelGGL((conv3d_cl_kernel<1, 2>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope);
-    else if (stride == 1) hipLaunchKernelGGL((conv3d_cl_kernel<2, 1>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope);
-    else hipLaunchKernelGGL((conv3d_cl_kernel<2, 2>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope);
+    if (ps && NT == 1) hipLaunchKernelGGL((conv3d_cl_kernel<1, 2, true>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope);
+    else if (ps) hipLaunchKernelGGL((conv3d_cl_kernel<2, 2, true>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope);
+    else if (NT == 1 && stride == 1) hipLaunchKernelGGL((conv3d_cl_kernel<1, 1, false>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope);
+    else if (NT == 1) hipLaunchKernelGGL((conv3d_cl_kernel<1, 2, false>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope);
+    else if (stride == 1) hipLaunchKernelGGL((conv3d_cl_kernel<2, 1, false>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope);
+    else hipLaunchKernelGGL((conv3d_cl_kernel<2, 2, false>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope);
   } else if (in_layout == LR_LAYOUT_NCDHW) {
     d.nHq = (d.Ho + PH - 1) / PH; d.nWq = (d.Wo + PW - 1) / PW; d.nDq = (d.Do + PD - 1) / PD;
     const int cc = stride == 1 ? 3 : 1;

@@ -12,7 +12,7 @@ import torch
 
 from . import _hip
 
-LAYOUT_NCDHW, LAYOUT_NDHWC = _hip.LAYOUT_NCDHW, _hip.LAYOUT_NDHWC
+LAYOUT_NCDHW, LAYOUT_NDHWC, LAYOUT_NDHWC_HPS = _hip.LAYOUT_NCDHW, _hip.LAYOUT_NDHWC, _hip.LAYOUT_NDHWC_HPS
 
 
 # ----------------------------------------------------------------------------- helpers
@@ -199,6 +199,8 @@ def conv3d_pack_weights(weight, in_layout):
 def conv3d_k3_lrelu(x, weight, bias, stride, *, in_layout=LAYOUT_NCDHW, out_layout=LAYOUT_NCDHW,
                     negative_slope=0.2, packed=None):
     """LeakyReLU(Conv3d(k3,p1,stride)(x)+b).  x is (B,Cin,D,W,H) for NCDHW, (B,D,W,H,Cin) for NDHWC.
+    LAYOUT_NDHWC_HPS is NDHWC with every H row parity-split (even voxels, then odd): the private layout
+    between a block and a following stride-2 block (see `hps_to_ndhwc`).
 
     Replaces convBlock (reference layers/layers.py:335-372).
     """
@@ -226,6 +228,13 @@ def conv3d_k3_lrelu(x, weight, bias, stride, *, in_layout=LAYOUT_NCDHW, out_layo
                                                      Cin, Cout, D, W, H, stride, in_layout, out_layout,
                                                      float(negative_slope), _stream()), "lr_conv3d_k3_lrelu_f32")
     return y
+
+
+def hps_to_ndhwc(y):
+    """Undo the parity split of LAYOUT_NDHWC_HPS along H (tests / debugging)."""
+    H = y.shape[3]
+    h = torch.arange(H, device=y.device)
+    return y[:, :, :, (h & 1) * ((H + 1) // 2) + (h >> 1)]
 
 
 # ----------------------------------------------------------------------------- K4 linear

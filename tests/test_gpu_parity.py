@@ -231,6 +231,27 @@ def test_conv_golden_all_layouts(golden, ops, dev, tag):
         assert np.array_equal(y3.cpu().numpy(), y2.permute(0, 4, 1, 2, 3).cpu().numpy())
 
 
+def test_conv_parity_split_layout(ops, dev):
+    """LAYOUT_NDHWC_HPS (even voxels of a row, then odd) as a block's output and as a stride-2 block's input
+    gives bit-identical results to plain NDHWC."""
+    rs = np.random.RandomState(21)
+    for (D, W, H), B in (((10, 9, 20), 2), ((7, 8, 34), 1), ((16, 16, 64), 1)):
+        x = T(rs.uniform(-1, 1, (B, 3, D, W, H)).astype(np.float32), dev)
+        w0 = T((rs.normal(0, 1, (16, 3, 3, 3, 3)) / 9).astype(np.float32), dev)
+        b0 = T(rs.uniform(-0.1, 0.1, 16).astype(np.float32), dev)
+        w1 = T((rs.normal(0, 1, (32, 16, 3, 3, 3)) / 20).astype(np.float32), dev)
+        b1 = T(rs.uniform(-0.1, 0.1, 32).astype(np.float32), dev)
+        y = ops.conv3d_k3_lrelu(x, w0, b0, 1, out_layout=ops.LAYOUT_NDHWC)
+        y_ps = ops.conv3d_k3_lrelu(x, w0, b0, 1, out_layout=ops.LAYOUT_NDHWC_HPS)
+        assert torch.equal(ops.hps_to_ndhwc(y_ps), y)
+        z = ops.conv3d_k3_lrelu(y, w1, b1, 2, in_layout=ops.LAYOUT_NDHWC, out_layout=ops.LAYOUT_NDHWC)
+        z_ps = ops.conv3d_k3_lrelu(y_ps, w1, b1, 2, in_layout=ops.LAYOUT_NDHWC_HPS, out_layout=ops.LAYOUT_NDHWC)
+        assert torch.equal(z_ps, z)
+    from liftreg_amd import _hip
+    with pytest.raises(_hip.LiftRegHipError):                                     # odd H cannot be parity-split
+        ops.conv3d_k3_lrelu(torch.zeros(1, 4, 4, 5, 16, device=dev), w1, b1, 2, in_layout=ops.LAYOUT_NDHWC_HPS)
+
+
 def test_conv_medium_vs_oracle(ops, dev):
     rs = np.random.RandomState(11)
     torch.manual_seed(11)
