@@ -123,8 +123,9 @@ int lr_backproject_coords_f32(const float* poses, float* pix, int P, int Pw, int
  */
 #define LR_LAYOUT_NCDHW 0
 #define LR_LAYOUT_NDHWC 1
-/* NDHWC with every H row parity-split (even voxels first, then the odd ones): a private layout between a
- * block and a following stride-2 block, whose tap loads it makes contiguous.  H must be even. */
+/* Channels-last with every (b,d,w) row stored as [C/16][parity of h][H/2][16 floats] (even voxels of a
+ * 16-channel block first, then its odd voxels): a private layout between a block and a following
+ * stride-2 block, whose tap loads it makes contiguous runs.  H even, C % 16 == 0. */
 #define LR_LAYOUT_NDHWC_HPS 2
 int64_t lr_conv3d_packed_floats(int Cin, int Cout, int in_layout);
 int lr_conv3d_pack_weights_f32(const float* weight, float* packed, int Cin, int Cout,

@@ -58,8 +58,9 @@ __device__ __forceinline__ void store_tile(const f32x4& acc, float* __restrict__
     float* o = out + ((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + ho) * d.Cout + c0;
     *reinterpret_cast<f32x4*>(o) = v;
   } else if (out_layout == LR_LAYOUT_NDHWC_HPS) {  // even voxels of the row first, then the odd ones
-    const int hp = (ho & 1) * ((d.Ho + 1) >> 1) + (ho >> 1);
-    float* o = out + ((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + hp) * d.Cout + c0;
+    // row = [channel block of 16][parity][Ho/2][16 floats]
+    const int hp = (ho & 1) * (d.Ho >> 1) + (ho >> 1);
+    float* o = out + (((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho * d.Cout + ((c0 >> 4) * d.Ho + hp) * 16 + (c0 & 15);
     *reinterpret_cast<f32x4*>(o) = v;
   } else {
     const int64_t vo = (int64_t)d.Do * d.Wo * d.Ho;
@@ -365,11 +366,12 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(const float* __restrict_
   const int zi0 = dz * STRIDE - 1, yw0 = wo0 * STRIDE - 1;
   const int xh0 = PS ? hq * 16 - 1 : hq * 16 * STRIDE - 1;  // PS: position inside a parity half-row
   const int64_t inb = (int64_t)b * d.D * d.W * d.H * d.Cin;
-  const float* wbase = in + inb + (((int64_t)zi0 * d.W + yw0) * d.H + xh0) * d.Cin;
+  const float* wbase = in + inb + ((int64_t)zi0 * d.W + yw0) * d.H * d.Cin + (int64_t)xh0 * (PS ? 16 : d.Cin);
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wbase), (short)0, 0x7fffffff, 0x00020000);
   constexpr unsigned OOR = 0x80000000u;
-  const unsigned lvoff = (unsigned)(col * (PS ? 1 : STRIDE) * d.Cin * 4 + kq * 16);
+  // PS rows are [channel block of 16][parity][H/2][16 floats]: neighbouring voxels of a half-row are 64 B apart
+  const unsigned lvoff = PS ? (unsigned)(col * 64 + kq * 16) : (unsigned)(col * STRIDE * d.Cin * 4 + kq * 16);
   const int half_h = (d.H + 1) >> 1;  // PS: the odd voxels of a row start here
   unsigned nvmask[MT];  // bit tap CLEAR = that tap of this lane's voxel in tile mt is inside the tensor
   {
@@ -408,7 +410,8 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(const float* __restrict_
     // PS (stride 2): tap tx reads voxel 2*ho+tx-1 — tx=1: even half, index ho; tx=0: odd half, index ho-1;
     // tx=2: odd half, index ho (xh0 already carries the -1)
     const int xs = PS ? (tx == 1 ? 1 : half_h + (tx >> 1)) : tx;
-    const unsigned soff = (unsigned)(((tz * d.W + ty) * d.H + xs) * d.Cin * 4 + cb * 64);
+    const unsigned soff = PS ? (unsigned)(((tz * d.W + ty) * d.H * d.Cin + (cb * 2 * half_h + xs) * 16) * 4)
+                             : (unsigned)(((tz * d.W + ty) * d.H + xs) * d.Cin * 4 + cb * 64);
     // branch-free: bit 31 of the offset is set (=> out of range => 0) unless tap and channel are valid
     const unsigned coor = (cb * 16 + kq * 4 < d.Cin) ? 0u : OOR;
 #pragma unroll
@@ -529,6 +532,7 @@ extern "C" int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, co
   if (out_layout != LR_LAYOUT_NCDHW && out_layout != LR_LAYOUT_NDHWC && out_layout != LR_LAYOUT_NDHWC_HPS)
     return LR_EINVAL;
   if (out_layout != LR_LAYOUT_NCDHW && (reinterpret_cast<uintptr_t>(out) & 15u)) return LR_EALIGN;
+  if (out_layout == LR_LAYOUT_NDHWC_HPS && (((H - 1) / stride + 1) & 1)) return LR_EUNSUPPORTED;  // needs an even output H
   ConvDims d;
   d.B = B; d.Cin = Cin; d.Cout = Cout; d.D = D; d.W = W; d.H = H;
   d.Do = (D - 1) / stride + 1; d.Wo = (W - 1) / stride + 1; d.Ho = (H - 1) / stride + 1;
@@ -538,7 +542,7 @@ extern "C" int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, co
   if (in_layout == LR_LAYOUT_NDHWC || in_layout == LR_LAYOUT_NDHWC_HPS) {
     const bool ps = in_layout == LR_LAYOUT_NDHWC_HPS;
     if (Cin % 4) return LR_EUNSUPPORTED;
-    if (ps && (stride != 2 || (H & 1))) return LR_EUNSUPPORTED;  // parity-split rows feed stride-2 blocks only
+    if (ps && (stride != 2 || (H & 1) || (Cin & 15))) return LR_EUNSUPPORTED;  // parity-split rows feed stride-2 blocks only
     if (reinterpret_cast<uintptr_t>(in) & 15u) return LR_EALIGN;
     if ((int64_t)12 * W * H * Cin + 4096 >= 0x7fffffffLL) return LR_EINVAL;  // 32-bit buffer offsets of a 3-plane window
     d.nHq = (d.Ho + 15) / 16; d.nWq = (d.Wo + MT - 1) / MT; d.nDq = (d.Do + TD - 1) / TD;

@@ -54,11 +54,12 @@ class model(nn.Module):
         last = len(enc_filters) - 1
         for i, f in enumerate(enc_filters):
             cin = self.drr_feature_num + 1 if i == 0 else enc_filters[i - 1]
-            # activations between blocks are channels-last; block 0 → block 1 additionally parity-split
-            # along H (contiguous stride-2 tap loads for the largest stride-2 block) when H is even
-            hps = self.img_sz[2] % 2 == 0
-            lay_in = ops.LAYOUT_NCDHW if i == 0 else (ops.LAYOUT_NDHWC_HPS if (i == 1 and hps) else ops.LAYOUT_NDHWC)
-            lay_out = ops.LAYOUT_NCDHW if i == last else (ops.LAYOUT_NDHWC_HPS if (i == 0 and hps) else ops.LAYOUT_NDHWC)
+            # activations between blocks are channels-last; when a block's output H is even it is written
+            # parity-split (LAYOUT_NDHWC_HPS) so the following stride-2 block's tap loads are contiguous
+            h_in = _out_size(self.img_sz[2], self.strides[:i])          # H of this block's input
+            h_out = _out_size(self.img_sz[2], self.strides[:i + 1])
+            lay_in = ops.LAYOUT_NCDHW if i == 0 else (ops.LAYOUT_NDHWC_HPS if h_in % 2 == 0 else ops.LAYOUT_NDHWC)
+            lay_out = ops.LAYOUT_NCDHW if i == last else (ops.LAYOUT_NDHWC_HPS if h_out % 2 == 0 else ops.LAYOUT_NDHWC)
             self.encoders.append(convBlock(cin, f, stride=self.strides[i], bias=True, in_layout=lay_in,
                                            out_layout=lay_out))
         flat = enc_filters[-1] * int(np.prod([_out_size(n, self.strides) for n in self.img_sz]))

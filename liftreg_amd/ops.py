@@ -231,10 +231,11 @@ def conv3d_k3_lrelu(x, weight, bias, stride, *, in_layout=LAYOUT_NCDHW, out_layo
 
 
 def hps_to_ndhwc(y):
-    """Undo the parity split of LAYOUT_NDHWC_HPS along H (tests / debugging)."""
-    H = y.shape[3]
+    """LAYOUT_NDHWC_HPS → plain NDHWC (tests / debugging): rows are [C/16][parity][H/2][16]."""
+    B, D, W, H, C = y.shape
     h = torch.arange(H, device=y.device)
-    return y[:, :, :, (h & 1) * ((H + 1) // 2) + (h >> 1)]
+    rows = y.reshape(B, D, W, C // 16, H, 16)[:, :, :, :, (h & 1) * (H // 2) + (h >> 1)]
+    return rows.permute(0, 1, 2, 4, 3, 5).reshape(B, D, W, H, C)
 
 
 # ----------------------------------------------------------------------------- K4 linear

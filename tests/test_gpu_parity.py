@@ -247,6 +247,13 @@ def test_conv_parity_split_layout(ops, dev):
         z = ops.conv3d_k3_lrelu(y, w1, b1, 2, in_layout=ops.LAYOUT_NDHWC, out_layout=ops.LAYOUT_NDHWC)
         z_ps = ops.conv3d_k3_lrelu(y_ps, w1, b1, 2, in_layout=ops.LAYOUT_NDHWC_HPS, out_layout=ops.LAYOUT_NDHWC)
         assert torch.equal(z_ps, z)
+        if z.shape[3] % 2 == 0:                                                    # 32-channel rows: [2 blocks][parity][H/2][16]
+            w2 = T((rs.normal(0, 1, (32, 32, 3, 3, 3)) / 29).astype(np.float32), dev)
+            z_hps = ops.conv3d_k3_lrelu(y_ps, w1, b1, 2, in_layout=ops.LAYOUT_NDHWC_HPS, out_layout=ops.LAYOUT_NDHWC_HPS)
+            assert torch.equal(ops.hps_to_ndhwc(z_hps), z)
+            q = ops.conv3d_k3_lrelu(z, w2, b1, 2, in_layout=ops.LAYOUT_NDHWC, out_layout=ops.LAYOUT_NCDHW)
+            q_ps = ops.conv3d_k3_lrelu(z_hps, w2, b1, 2, in_layout=ops.LAYOUT_NDHWC_HPS, out_layout=ops.LAYOUT_NCDHW)
+            assert torch.equal(q_ps, q)
     from liftreg_amd import _hip
     with pytest.raises(_hip.LiftRegHipError):                                     # odd H cannot be parity-split
         ops.conv3d_k3_lrelu(torch.zeros(1, 4, 4, 5, 16, device=dev), w1, b1, 2, in_layout=ops.LAYOUT_NDHWC_HPS)
