@@ -24,6 +24,27 @@
 //   src/liftreg/models/LiftRegDeformSubspaceBackproj.py:29-33,95-100 (6 blocks, strides 1,2,2,2,2,2)
 #include "lr_common.h"
 
+#ifdef LR_CONV0_STAMPS
+// Diagnostic build only (make stamps): per-phase cycle sums of the persistent planar kernel.
+__device__ unsigned long long g_lr_stamps[8];
+extern "C" int lr_debug_read_stamps(unsigned long long* host8, int reset) {
+  if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_lr_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lr_stamps), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#define LR_STAMP(slot)                                                         \
+  do {                                                                         \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();              \
+    stamp_acc[slot] += now_ - stamp_t;                                         \
+    stamp_t = now_;                                                            \
+  } while (0)
+#else
+#define LR_STAMP(slot) do {} while (0)
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -112,8 +133,12 @@ struct PlanarGeom {
 // runs on the matrix pipe the input window of item i+1 is already in flight (bounds-checked buffer
 // loads: out-of-volume rows/columns and channels >= Cin get an out-of-range offset and read 0, so
 // the loads are unconditional and the brick's zero halo IS the conv's padding).
-template <int NT, int S, int CC>
-__global__ __launch_bounds__(256, 2) void conv3d_planar_kernel(const float* __restrict__ in,
+// SINGLE (Cin <= CC, one channel pass per brick — the model's case): the sweep is output-stationary per
+// PAIR of tiles: 2 live accumulators instead of 16, and each pair is stored the moment its CC*7 k-steps
+// are done, so the 64 KB a block writes per brick drains under the MFMAs of the following pairs instead of
+// stalling the wave in one 16-store burst (stamped build: that burst cost as much as the whole sweep).
+template <int NT, int S, int CC, bool SINGLE>
+__global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(const float* __restrict__ in,
                                                             const float* __restrict__ wp,
                                                             const float* __restrict__ bias,
                                                             float* __restrict__ out, ConvDims d,
@@ -245,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_planar_kernel(const float* __re
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(w[t][nt]));
     }
-    if (pass == 0) {
+    if (!SINGLE && pass == 0) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -270,6 +295,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_planar_kernel(const float* __re
     if (late)
       for (int i = 0; i < amount; ++i) __builtin_amdgcn_s_sleep(127);
   }
+#ifdef LR_CONV0_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+#endif
   if (vec4) prefetch(unit_item(0));
   stage(0);
   setup(0);
@@ -278,6 +307,62 @@ __global__ __launch_bounds__(256, 2) void conv3d_planar_kernel(const float* __re
   for (int u = 0; u < my_units; ++u) {
     // ---- MFMA sweep, software-pipelined: the 16 LDS reads of step t+1 are issued one per MFMA of
     //      step t (immediate-offset ds_read: no address arithmetic, no vector memory).
+    if constexpr (SINGLE) {
+      if (!(dbg & 4)) {
+        int b, dq, wq, hq, pass;
+        item_coords(unit_item(u), b, dq, wq, hq, pass);
+        const int dz = dq * PD + wave;
+        const bool zok = dz < d.Do && !(dbg & 1);
+        constexpr int NS = (PW * 4 / 2) * G::T;  // (tile pair, k-step) sequence, fully unrolled
+        float ar[2][2];
+        auto rd = [&](int sidx, float (&dst)[2]) {
+          const int p = sidx / G::T, t = sidx % G::T;
+          const float* base = brick + (t / 7) * G::CS + qoff[t % 7];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int m = 2 * p + h;
+            dst[h] = base[(m / 4) * S * G::RSL + (m % 4) * 16 * S];
+          }
+        };
+        rd(0, ar[0]);
+        f32x4 pacc[2][NT];
+#pragma clang loop unroll(full)
+        for (int p = 0; p < PW * 4 / 2; ++p)
+#pragma clang loop unroll(full)
+        for (int t = 0; t < G::T; ++t) {
+          const int sidx = p * G::T + t;
+          if (t == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) pacc[h][nt] = bvec[nt];
+          }
+          if (sidx + 1 < NS) rd(sidx + 1, ar[(sidx + 1) & 1]);
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              pacc[h][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][nt], ar[sidx & 1][h], pacc[h][nt], 0, 0, 0);
+          if (sidx + 1 < NS) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);  // NT MFMAs …
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // … then one LDS read
+            }
+          }
+          if (t == G::T - 1 && zok) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int m = 2 * p + h;
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                store_tile(pacc[h][nt], out, d, b, dz, wq * PW + m / 4, hq * PH + (m % 4) * 16 + col, nt, lane,
+                           out_layout, slope);
+            }
+          }
+        }
+      }
+    } else {
     if (!(dbg & 4)) {
     read_step(0, a[0]);
 #pragma unroll
@@ -297,9 +382,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_planar_kernel(const float* __re
       }
     }
     }
+    }
+    LR_STAMP(0);  // sweep
     __syncthreads();  // every wave is done reading the brick
+    LR_STAMP(1);  // barrier A
     if (!(dbg & 2)) stage(min(u + 1, my_units - 1));
-    if (u % npass == npass - 1 && !(dbg & 1)) {
+    LR_STAMP(2);  // stage (waits for the prefetch)
+    if (!SINGLE && u % npass == npass - 1 && !(dbg & 1)) {
       int b, dq, wq, hq, pass;
       item_coords(unit_item(u), b, dq, wq, hq, pass);
       const int dz = dq * PD + wave;
@@ -316,10 +405,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_planar_kernel(const float* __re
                          out_layout, slope);
       }
     }
+    LR_STAMP(3);  // stores (+ address math)
     if (u + 1 < my_units) setup(u + 1);
+    LR_STAMP(4);  // setup
     __syncthreads();  // next brick visible in LDS
+    LR_STAMP(5);  // barrier B
     if (vec4 && !(dbg & 2)) prefetch(unit_item(min(u + 2, my_units - 1)));
+    LR_STAMP(6);  // prefetch issue
   }
+#ifdef LR_CONV0_STAMPS
+  if (lane == 0 && wave == 1)
+    for (int i = 0; i < 7; ++i) atomicAdd(&g_lr_stamps[i], stamp_acc[i]);
+#endif
 }
 
 // ===========================================================================
@@ -565,17 +662,29 @@ extern "C" int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, co
     // 16-byte staging needs aligned rows and a window (cc channels) within 31-bit buffer offsets
     const int vec4 = (stride == 1) && (H % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0) &&
                      ((int64_t)cc * D * W * H * 4 + (int64_t)16 * W * H * 4 < 0x7fffffffLL);
-    int64_t resident = 256 * 2;  // persistent blocks: 2 per CU (3 would spill: ~220 VGPRs)
+    const bool single = npass == 1;
+    int64_t resident = 256 * (single ? 3 : 2);  // persistent blocks per CU (registers: <=168 | <=256 per lane)
     if (const char* e = getenv("LIFTREG_CONV0_BLOCKS")) resident = atoi(e);  // tuning aid
     const dim3 grid((unsigned)(nitems < resident ? nitems : resident));
     const size_t lds1 = (size_t)3 * PlanarGeom<1, 3>::CS * sizeof(float);
     const size_t lds2 = (size_t)1 * PlanarGeom<2, 1>::CS * sizeof(float);
     const int ni = (int)nitems;
     const int dbg = getenv("LIFTREG_CONV0_DBG") ? atoi(getenv("LIFTREG_CONV0_DBG")) : 0;  // timing ablations only
-    if (NT == 1 && stride == 1) hipLaunchKernelGGL((conv3d_planar_kernel<1, 1, 3>), grid, block, lds1, st, in, packed_w, bias, out, d, out_layout, negative_slope, vec4, ni, npass, dbg);
-    else if (NT == 1) hipLaunchKernelGGL((conv3d_planar_kernel<1, 2, 1>), grid, block, lds2, st, in, packed_w, bias, out, d, out_layout, negative_slope, 0, ni, npass, dbg);
-    else if (stride == 1) hipLaunchKernelGGL((conv3d_planar_kernel<2, 1, 3>), grid, block, lds1, st, in, packed_w, bias, out, d, out_layout, negative_slope, vec4, ni, npass, dbg);
-    else hipLaunchKernelGGL((conv3d_planar_kernel<2, 2, 1>), grid, block, lds2, st, in, packed_w, bias, out, d, out_layout, negative_slope, 0, ni, npass, dbg);
+#define LR_PL(NTV, SV, CCV, SGL, LDSV, V4)                                                                   \
+  hipLaunchKernelGGL((conv3d_planar_kernel<NTV, SV, CCV, SGL>), grid, block, LDSV, st, in, packed_w, bias, out, d, \
+                     out_layout, negative_slope, V4, ni, npass, dbg)
+    if (stride == 1) {
+      if (NT == 1 && single) LR_PL(1, 1, 3, true, lds1, vec4);
+      else if (NT == 1) LR_PL(1, 1, 3, false, lds1, vec4);
+      else if (single) LR_PL(2, 1, 3, true, lds1, vec4);
+      else LR_PL(2, 1, 3, false, lds1, vec4);
+    } else {
+      if (NT == 1 && single) LR_PL(1, 2, 1, true, lds2, 0);
+      else if (NT == 1) LR_PL(1, 2, 1, false, lds2, 0);
+      else if (single) LR_PL(2, 2, 1, true, lds2, 0);
+      else LR_PL(2, 2, 1, false, lds2, 0);
+    }
+#undef LR_PL
   } else {
     return LR_EINVAL;
   }

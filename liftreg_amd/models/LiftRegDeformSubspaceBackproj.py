@@ -147,6 +147,14 @@ class model(nn.Module):
         return hit[1]
 
     def _estimate_flow(self, moving, target_proj, poses):
+        coefs = self.encode(moving, target_proj, poses)
+        B, _, D, W, H = moving.shape
+        disp = ops.pca_reconstruct(coefs, self.pca_vectors_LxM, self.pca_mean).view(B, 3, D, W, H)
+        return coefs, disp
+
+    def encode(self, moving, target_proj, poses):
+        """MFMA-bound half: backprojection → 6 conv blocks → FC head → PCA coefficients (B,L)."""
+        self._ensure_pca(moving.device)
         B, _, D, W, H = moving.shape
         P = target_proj.shape[1]
         if self._poses is None:
@@ -162,9 +170,17 @@ class model(nn.Module):
             x = ops.conv3d_k3_lrelu(x, blk.conv.weight, blk.conv.bias, blk.stride, in_layout=blk.in_layout,
                                     out_layout=blk.out_layout, negative_slope=blk._slope,
                                     packed=self._packed_weight(i))
-        coefs = self.encoders[6](x)
+        return self.encoders[6](x)
+
+    def decode(self, moving, coefs, moving_seg=None):
+        """HBM-bound half: PCA reconstruction → identity add + trilinear warp.  Returns (disp, phi, warped)."""
+        B, _, D, W, H = moving.shape
         disp = ops.pca_reconstruct(coefs, self.pca_vectors_LxM, self.pca_mean).view(B, 3, D, W, H)
-        return coefs, disp
+        # deform_field = disp + id ; warped = Bilinear(moving_cp, deform_field): one kernel; the mask
+        # compose of moving ((moving+1)*seg-1, :57) happens on the taps
+        phi, warped = ops.warp(moving, disp, (self._id0, self._id1, self._id2), moving_seg,
+                               using_scale=True, zero_boundary=True)
+        return disp, phi, warped
 
     # ------------------------------------------------------------------ forward
     def forward(self, input):
@@ -182,12 +198,8 @@ class model(nn.Module):
             moving_seg = None
             target_cp = target
 
-        coefs, disp_field = self._estimate_flow(moving, target_proj, input['target_poses'])
-
-        # deform_field = disp + id ; warped = Bilinear(moving_cp, deform_field): one kernel; the mask
-        # compose of moving ((moving+1)*seg-1, :57) happens on the taps
-        deform_field, warped_source = ops.warp(moving, disp_field, (self._id0, self._id1, self._id2),
-                                               moving_seg, using_scale=True, zero_boundary=True)
+        coefs = self.encode(moving, target_proj, input['target_poses'])
+        disp_field, deform_field, warped_source = self.decode(moving, coefs, moving_seg)
         return {"warped": warped_source,
                 "phi": deform_field,
                 "params": disp_field,
