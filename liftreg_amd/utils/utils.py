@@ -1,0 +1,24 @@
+"""Output helpers with the reference's file formats (src/liftreg/utils/utils.py)."""
+import os
+
+import numpy as np
+
+
+def save_deformations(phis, fname_list, output_path):
+    """`{id}_phi.npy` = (phi+1)/2 as float32 (B,3,D,W,H → one file per sample), utils/utils.py:57-68.
+
+    The reference also writes a `.nii.gz` through nibabel (un-installed here); only the `.npy` the
+    evaluation scripts read (tools/evaluate_dir_lab.py:176-178) is produced.
+    """
+    phis = (phis.detach().cpu().numpy() if hasattr(phis, "detach") else np.asarray(phis))
+    phis = (phis + 1.) / 2.
+    for i, name in enumerate(fname_list):
+        np.save(os.path.join(output_path, f"{name}_phi.npy"), phis[i].astype(np.float32))
+
+
+def sigmoid_decay(ep, static=5, k=5):
+    """factor = k/(k+exp((ep-static)/k)) after `static` epochs, 1 before (utils/utils.py:93-107)."""
+    if ep < static:
+        return float(1.)
+    ep = ep - static
+    return float(k / (k + np.exp(ep / k)))

@@ -348,3 +348,35 @@ def test_no_cpu_fallback_and_error_codes(ops, dev):
     with pytest.raises(_hip.LiftRegHipError):
         ops.conv3d_k3_lrelu(x, torch.zeros(8, 3, 3, 3, 3, device=dev), None, 1)                  # Cout=8 unsupported
     assert lib.lr_strerror(-3) == b"combination not built into this library"
+
+
+# ------------------------------------------------------------------------------------- f3/f4: file pipeline
+def test_preprocessing_drr_cli_matches_reference_files(dev, tmp_path):
+    """The reference's tools/preprocessingDRR.py flow on a tiny dataset: same folder layout, same files."""
+    from liftreg_amd.tools import preprocessingDRR as tool
+    from liftreg_amd.utils.utils import save_deformations
+    rs = np.random.RandomState(8)
+    root = tmp_path / "data"
+    (root / "preprocessed").mkdir(parents=True)
+    shape = (12, 10, 14)
+    vols = {}
+    for phase, ids in (("train", ["a1", "a2"]), ("val", ["v1"])):
+        (root / phase).mkdir()
+        np.save(root / phase / "data_id.npy", np.array(ids))
+        for d in ids:
+            for kind in ("source", "target"):
+                vols[(d, kind)] = np.clip(rs.normal(-500, 400, shape), -1024, 1000).astype(np.float32)
+                np.save(root / "preprocessed" / f"{d}_{kind}.npy", vols[(d, kind)])
+    assert tool.main(["-d", str(root), "--drr_folder_name", "t", "--scan_range", "30", "--scan_num", "3",
+                      "--receptor_w", "11", "--receptor_h", "9"]) == 0
+    out = root / "drr" / "t" / "drr"
+    poses = np.load(out / "poses.npy")
+    assert np.array_equal(poses, ro.scan_poses(30, 3, shape[1])) and poses.dtype == np.float64
+    for (d, kind), hu in vols.items():
+        got = np.load(out / f"{d}_{kind}_proj.npy")
+        want = ro.drr_forward(ro.calc_relative_atten_coef(np.flip(hu, axis=1)), poses, (9, 11), (2.2, 2.2, 2.2))
+        assert got.dtype == np.float32 and got.shape == (3, 9, 11)
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+    phi = torch.from_numpy(rs.uniform(-1, 1, (2, 3, 4, 5, 6)).astype(np.float32)).to(dev)
+    save_deformations(phi, ["x", "y"], str(tmp_path))
+    assert np.array_equal(np.load(tmp_path / "y_phi.npy"), ((phi[1].cpu().numpy() + 1.) / 2.).astype(np.float32))
