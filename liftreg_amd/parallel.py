@@ -90,3 +90,145 @@ def ncc_loss_sharded(x_slab, y_slab, n_total, group=None, variant=NCC_CONFIGURED
     m = _all_reduce_sum(m, group)
     loss, _ = ops.ncc_loss_from_moments(m, n_total, n_batch, variant)
     return loss
+
+
+# ======================================================================================================
+# z-slab sharded forward of the whole model ("a8 convs: 1-voxel halo exchange per layer")
+# ======================================================================================================
+class DistComm:
+    """Communication of ONE local rank over torch.distributed (nccl = RCCL over xGMI, or gloo)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank, self.world = world(group)
+        self.ranks = [self.rank]
+
+    def shift_up(self, planes):
+        """planes[0] = this rank's top plane → returns [the plane of rank-1] ([None] on rank 0).
+        Neighbour point-to-point: on xGMI each pair has its own link, so all exchanges run concurrently."""
+        recv = torch.empty_like(planes[0]) if self.rank > 0 else None
+        reqs = []
+        if self.rank + 1 < self.world:
+            reqs.append(dist.isend(planes[0], self.rank + 1, group=self.group))
+        if self.rank > 0:
+            reqs.append(dist.irecv(recv, self.rank - 1, group=self.group))
+        for r in reqs:
+            r.wait()
+        return [recv]
+
+    def all_gather_cat(self, pieces, dim):
+        parts = [torch.empty_like(pieces[0]) for _ in range(self.world)]
+        dist.all_gather(parts, pieces[0].contiguous(), group=self.group)
+        return [torch.cat(parts, dim=dim)]
+
+    def all_reduce_sum(self, ts):
+        dist.all_reduce(ts[0], op=dist.ReduceOp.SUM, group=self.group)
+        return ts
+
+
+class LocalComm:
+    """All `world` ranks simulated in one process (tests: N virtual ranks on one GPU)."""
+
+    def __init__(self, world_size):
+        self.world = int(world_size)
+        self.ranks = list(range(self.world))
+
+    def shift_up(self, planes):
+        return [None] + [p.clone() for p in planes[:-1]]
+
+    def all_gather_cat(self, pieces, dim):
+        full = torch.cat(pieces, dim=dim)
+        return [full for _ in pieces]
+
+    def all_reduce_sum(self, ts):
+        total = sum(ts[1:], ts[0].clone())
+        return [total.clone() for _ in ts]
+
+
+class SlabShardedRegistration:
+    """One registration batch sharded by z-slab (axis D) over `comm.world` ranks.
+
+    Per rank: rows [d0,d1) of the feature volume, of every encoder activation (halved per stride-2 block),
+    of the displacement field, phi and the warped image.  Replicated: the moving volume and the 2-D views
+    (small), the FC head.  Exchanged: one activation plane per stride-2 block from the rank below (halo),
+    the 32·(n/32)³ encoder features (all-gather), five NCC moments per sample (all-reduce).
+    Needs D % (32·world) == 0 so slabs stay aligned through the five stride-2 blocks.
+    """
+
+    def __init__(self, net, comm, sim_variant=NCC_CONFIGURED):
+        self.net, self.comm, self.variant = net, comm, sim_variant
+        D = net.img_sz[0]
+        if D % (32 * comm.world):
+            raise ValueError(f"D={D} must be a multiple of 32*world={32 * comm.world} for slab sharding")
+
+    def _d_axis(self, layout):
+        return 2 if layout == ops.LAYOUT_NCDHW else 1
+
+    def forward(self, inputs):
+        """inputs: one dict per LOCAL rank (len(comm.ranks)) with the replicated `source`, `target_proj`,
+        `target_poses`, optional whole `target` (sliced here).  Returns one dict per local rank with the
+        slabs `warped`, `phi`, `params` (rows d0:d1), replicated `pca_coefs`, the scalar `sim_loss`."""
+        net, comm = self.net, self.comm
+        D, W, H = net.img_sz
+        P = net.drr_feature_num
+        nloc = len(comm.ranks)
+        bounds = [slab_bounds(D, comm.world, r) for r in comm.ranks]
+        acts = []
+        # ---- block 0 (stride 1): both halo planes come from replicated data → no communication
+        for inp, (d0, d1) in zip(inputs, bounds):
+            moving, proj = inp["source"], inp["target_proj"]
+            net._ensure_pca(moving.device)
+            if net._poses is None:
+                p = inp["target_poses"]
+                p = p.detach().cpu().numpy() if isinstance(p, torch.Tensor) else p
+                net._poses = p[0].astype("float32").copy()
+            lo, hi = max(d0 - 1, 0), min(d1 + 1, D)
+            B = moving.shape[0]
+            x = torch.empty((B, P + 1, hi - lo, W, H), dtype=torch.float32, device=moving.device)
+            x[:, 0:1].copy_(moving[:, :, lo:hi])
+            x[:, 1:].copy_(ops.backproject(proj, net._poses, (D, W, H), d0=lo, d1=hi))
+            blk = net.encoders[0]
+            y = ops.conv3d_k3_lrelu(x, blk.conv.weight, blk.conv.bias, 1, in_layout=blk.in_layout,
+                                    out_layout=blk.out_layout, negative_slope=blk._slope,
+                                    packed=net._packed_weight(0))
+            ax = self._d_axis(blk.out_layout)
+            acts.append(y.narrow(ax, d0 - lo, d1 - d0).contiguous())
+        # ---- blocks 1..5 (stride 2): one halo plane from the rank below per block
+        for i in range(1, 6):
+            blk = net.encoders[i]
+            ax = self._d_axis(blk.in_layout)
+            tops = [a.narrow(ax, a.shape[ax] - 1, 1).contiguous() for a in acts]
+            halos = comm.shift_up(tops)
+            nxt = []
+            for a, h in zip(acts, halos):
+                plane = torch.zeros_like(a.narrow(ax, 0, 1)) if h is None else h   # rank 0: the conv's zero padding
+                # rows [r0-2, r1): the extra leading plane only aligns the stride phase (its output is dropped)
+                xin = torch.cat([torch.zeros_like(plane), plane, a], dim=ax)
+                y = ops.conv3d_k3_lrelu(xin, blk.conv.weight, blk.conv.bias, 2, in_layout=blk.in_layout,
+                                        out_layout=blk.out_layout, negative_slope=blk._slope,
+                                        packed=net._packed_weight(i))
+                axo = self._d_axis(blk.out_layout)
+                nxt.append(y.narrow(axo, 1, y.shape[axo] - 1).contiguous())
+            acts = nxt
+        # ---- FC head on the gathered features (replicated), then the slab-local decode
+        feats = comm.all_gather_cat(acts, dim=2)     # last block writes NCDHW: (B,32,rows,·,·)
+        outs = []
+        moms = []
+        for inp, f, (d0, d1) in zip(inputs, feats, bounds):
+            coefs = net.encoders[6](f.contiguous())
+            moving = inp["source"]
+            disp = pca_reconstruct_slab(coefs, net.pca_vectors_LxM, net.pca_mean, (D, W, H), d0, d1)
+            phi, warped = warp_slab(moving, disp.contiguous(), (net._id0, net._id1, net._id2), d0, d1,
+                                    seg=inp.get("source_label"))
+            out = {"warped": warped, "phi": phi, "params": disp, "pca_coefs": coefs}
+            if "target" in inp:
+                tgt = inp["target"][:, :, d0:d1].contiguous()
+                rows = warped.shape[0] if self.variant == NCC_CONFIGURED else warped.shape[0] * warped.shape[1]
+                moms.append(ops.ncc_moments(warped, tgt, rows))
+            outs.append(out)
+        if moms:
+            moms = comm.all_reduce_sum(moms)
+            for out, m, inp in zip(outs, moms, inputs):
+                B = inp["source"].shape[0]
+                out["sim_loss"], _ = ops.ncc_loss_from_moments(m, D * W * H * (inp["source"].shape[1]), B, self.variant)
+        return outs

@@ -1,0 +1,43 @@
+"""GPU: the z-slab sharded forward of the whole model (liftreg_amd.parallel.SlabShardedRegistration) run as
+2 and 4 virtual ranks on one GPU (LocalComm) reproduces the unsharded model: every rank's slab of the
+displacement field, phi and the warped image equals the corresponding rows, the PCA coefficients are
+replicated, and the NCC from all-reduced moments equals the unsharded NCC."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,world", [(64, 2), (128, 4), (128, 2)])
+def test_slab_sharded_forward_equals_unsharded(n, world):
+    from liftreg_amd import parallel as par
+    from liftreg_amd.layers.losses import NCCLoss
+    from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+    from liftreg_amd.utils.sdct_projection_utils import scan_poses
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    P, L, B = 2, 12, 2
+    net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:9"}).to(dev).eval()
+    poses = scan_poses(30, P, n).astype(np.float32)
+    inp = {"source": torch.rand((B, 1, n, n, n), generator=g, device=dev) * 2 - 1,
+           "target": torch.rand((B, 1, n, n, n), generator=g, device=dev) * 2 - 1,
+           "target_proj": torch.rand((B, P, n, n), generator=g, device=dev) * 2 - 1,
+           "target_poses": torch.from_numpy(np.broadcast_to(poses, (B, P, 3)).copy())}
+    with torch.no_grad():
+        ref = net(inp)
+        ref_loss = NCCLoss()(ref["warped"], ref["target"])
+        sharded = par.SlabShardedRegistration(net, par.LocalComm(world))
+        outs = sharded.forward([inp] * world)
+    assert len(outs) == world
+    for r, out in enumerate(outs):
+        d0, d1 = par.slab_bounds(n, world, r)
+        assert torch.equal(out["pca_coefs"], ref["pca_coefs"]), f"rank {r}: coefficients differ"
+        assert torch.equal(out["params"], ref["params"][:, :, d0:d1])
+        assert torch.equal(out["phi"], ref["phi"][:, :, d0:d1])
+        assert torch.equal(out["warped"], ref["warped"][:, :, d0:d1])
+        assert abs(float(out["sim_loss"]) - float(ref_loss)) < 1e-6
+    with pytest.raises(ValueError):
+        par.SlabShardedRegistration(net, par.LocalComm(3))

@@ -1,7 +1,8 @@
 """CPU, world_size 2, gloo: the N>1 host logic of liftreg_amd.parallel — slab bounds, the partial-DRR
-all-reduce, the NCC-moment all-reduce, and the collective-free slabs — reproduces the unsharded
-result.  There is no GPU here, so the test (and only the test) injects an oracle-backed stand-in for
-`liftreg_amd.parallel.ops`; the product default is the HIP ops and has no CPU path."""
+all-reduce, the NCC-moment all-reduce, the collective-free slabs, and the slab-sharded forward of the
+whole model (halo send/recv, feature all-gather) — reproduces the unsharded result.  There is no GPU here,
+so the tests (and only the tests) inject an oracle-backed stand-in for the `ops` module the product
+code calls; the product default is the HIP ops and has no CPU path."""
 import os
 import socket
 import sys
@@ -16,19 +17,63 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class OracleOps:
-    """Same call signatures as liftreg_amd.ops for the functions parallel.py uses, on CPU tensors."""
+    """Same call signatures as liftreg_amd.ops for what parallel.py / the model use, on CPU tensors."""
+    LAYOUT_NCDHW, LAYOUT_NDHWC, LAYOUT_NDHWC_HPS = 0, 1, 2
 
     def __init__(self):
         from oracle import c_oracle as co
-        self.co = co
+        from oracle import ref_ops as ro
+        self.co, self.ro = co, ro
+
+    # ---- layouts (mirror of LR_LAYOUT_*) -------------------------------------------------------
+    def _to_ncdhw(self, x, layout):
+        if layout == self.LAYOUT_NCDHW:
+            return x
+        if layout == self.LAYOUT_NDHWC_HPS:
+            x = self.hps_to_ndhwc(x)
+        return x.permute(0, 4, 1, 2, 3).contiguous()
+
+    def _from_ncdhw(self, y, layout):
+        if layout == self.LAYOUT_NCDHW:
+            return y.contiguous()
+        y = y.permute(0, 2, 3, 4, 1).contiguous()
+        if layout == self.LAYOUT_NDHWC_HPS:
+            B, D, W, H, C = y.shape
+            h = torch.arange(H)
+            inv = torch.empty(H, dtype=torch.long)
+            inv[(h & 1) * (H // 2) + (h >> 1)] = h
+            y = y.reshape(B, D, W, H, C // 16, 16)[:, :, :, inv].permute(0, 1, 2, 4, 3, 5).reshape(B, D, W, H, C)
+        return y
+
+    def hps_to_ndhwc(self, y):
+        B, D, W, H, C = y.shape
+        h = torch.arange(H)
+        rows = y.reshape(B, D, W, C // 16, H, 16)[:, :, :, :, (h & 1) * (H // 2) + (h >> 1)]
+        return rows.permute(0, 1, 2, 4, 3, 5).reshape(B, D, W, H, C)
+
+    # ---- ops -------------------------------------------------------------------------------------
+    def conv3d_pack_weights(self, weight, in_layout):
+        return None
+
+    def conv3d_k3_lrelu(self, x, weight, bias, stride, *, in_layout=0, out_layout=0, negative_slope=0.2, packed=None):
+        y = self.ro.conv_block(self._to_ncdhw(x, in_layout), weight.detach(), bias.detach(), stride, negative_slope)
+        return self._from_ncdhw(y, out_layout)
+
+    def linear_lrelu(self, x, weight, bias, negative_slope=1.0):
+        y = torch.nn.functional.linear(x, weight.detach(), bias.detach())
+        return y if negative_slope == 1.0 else torch.nn.functional.leaky_relu(y, negative_slope)
 
     def drr_forward(self, vol, poses, resolution, spacing, *, d0=0, d1=None, full_D=None, **kw):
         out = self.co.drr_forward(vol.numpy(), np.asarray(poses, np.float32), np.asarray(spacing, np.float32),
                                   resolution, d0=d0, d1=d1, full_D=full_D)
         return torch.from_numpy(out)
 
-    def backproject(self, proj, poses, img_shape, *, d0=0, d1=None, **kw):
-        return torch.from_numpy(self.co.backproject(proj.numpy(), np.asarray(poses, np.float32), img_shape, d0=d0, d1=d1))
+    def backproject(self, proj, poses, img_shape, *, d0=0, d1=None, out=None, **kw):
+        res = torch.from_numpy(self.co.backproject(proj.numpy(), np.asarray(poses, np.float32), img_shape, d0=d0, d1=d1))
+        if out is not None:      # the model writes straight into channels 1..P of the encoder input
+            out.copy_(res)
+            return out
+        return res
 
     def pca_reconstruct(self, coefs, basis, mean):
         return torch.from_numpy(self.co.pca_reconstruct(coefs.numpy(), basis.numpy(), mean.numpy()))
@@ -37,6 +82,9 @@ class OracleOps:
         phi, w = self.co.warp(img.numpy(), disp.numpy(), ids=[t.numpy() for t in ids],
                               seg=None if seg is None else seg.numpy(), d0=d0, d1=d1)
         return torch.from_numpy(phi), torch.from_numpy(w)
+
+    def mask_compose(self, img, seg):
+        return torch.from_numpy(self.co.mask_compose(img.numpy(), seg.numpy()))
 
     def ncc_moments(self, x, y, rows):
         return torch.from_numpy(self.co.ncc_moments(x.numpy(), y.numpy(), rows))
@@ -50,17 +98,26 @@ class OracleOps:
         return torch.tensor(1.0 - rows.mean(), dtype=torch.float32), torch.from_numpy(rows.astype(np.float32))
 
 
+def _inject(shim):
+    """Test-only: route every `ops.` call of the host-side modules to the oracle shim."""
+    import liftreg_amd.parallel as par
+    import liftreg_amd.models.LiftRegDeformSubspaceBackproj as mod
+    import liftreg_amd.layers.layers as lay
+    par.ops = mod.ops = lay.ops = shim
+    return par, mod
+
+
 def _worker(rank, world_size, port, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.set_num_threads(1)
+    torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
     try:
-        from liftreg_amd import parallel as par
         from oracle import c_oracle as co
         from oracle import ref_ops as ro
-        par.ops = OracleOps()  # test-only injection
+        shim = OracleOps()
+        par, mod = _inject(shim)
         rs = np.random.RandomState(11)
         D, W, H, P, R, B, L = 13, 10, 12, 3, 14, 2, 5
         d0, d1 = par.slab_bounds(D, world_size, rank)
@@ -97,9 +154,30 @@ def _worker(rank, world_size, port, q):
         owned[par.shard_items(11, world_size, rank)] = 1
         dist.all_reduce(owned)
         assert bool((owned == 1).all())
+
+        # ---- the whole model, slab-sharded over the two ranks (halo isend/irecv, all_gather, all_reduce)
+        n = 64
+        torch.manual_seed(5)
+        net = mod.model([n, n, n], {"drr_feature_num": 2, "latent_dim": 4, "pca_path": "synthetic:3"}).eval()
+        g = torch.Generator().manual_seed(5)
+        net.set_pca(torch.randn((4, 3 * n ** 3), generator=g) * 0.01, torch.zeros(3 * n ** 3))
+        inp = {"source": torch.rand((1, 1, n, n, n), generator=g) * 2 - 1,
+               "target": torch.rand((1, 1, n, n, n), generator=g) * 2 - 1,
+               "target_proj": torch.rand((1, 2, n, n), generator=g) * 2 - 1,
+               "target_poses": torch.from_numpy(ro.scan_poses(30, 2, n).astype(np.float32))[None]}
+        with torch.no_grad():
+            ref = net(inp)                                                     # unsharded, through the same shim
+            out = par.SlabShardedRegistration(net, par.DistComm()).forward([inp])[0]
+        s0, s1 = par.slab_bounds(n, world_size, rank)
+        np.testing.assert_allclose(out["pca_coefs"].numpy(), ref["pca_coefs"].numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(out["params"].numpy(), ref["params"][:, :, s0:s1].numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(out["warped"].numpy(), ref["warped"][:, :, s0:s1].numpy(), rtol=1e-4, atol=1e-5)
+        want_loss = ro.ncc_loss(ref["warped"], ref["target"])
+        assert abs(float(out["sim_loss"]) - float(want_loss)) < 1e-5
         q.put((rank, "ok"))
     except Exception as e:  # surface the failure in the parent
-        q.put((rank, repr(e)))
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()[-600:]))
     finally:
         dist.destroy_process_group()
 
@@ -115,7 +193,7 @@ def test_slab_bounds_partition():
     assert sorted(sum((shard_items(10, 4, r) for r in range(4)), [])) == list(range(10))
 
 
-@pytest.mark.timeout(300)
+@pytest.mark.timeout(600)
 def test_two_rank_sharding_matches_unsharded():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -126,7 +204,7 @@ def test_two_rank_sharding_matches_unsharded():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in procs]
+    res = [q.get(timeout=500) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
