@@ -1,0 +1,117 @@
+"""GPU: the shapes of BASELINE.json's other configurations as parity cases (fp32):
+  C2  128^3, 2x128^2, batch 4                         — whole forward vs the torch-CPU oracle
+  C4  11-view limited-angle DRR, z-slab sharded       — 128^3 stand-in (4 virtual ranks) vs the unsharded forward,
+                                                        and its 12-channel first block vs the CPU oracle
+  C5  384^3 volume with a 2x512^2 detector            — projector, backprojection, first conv block and warp on
+                                                        a non-256 volume whose detector differs from the volume
+                                                        (crops checked against the CPU oracles; full-size oracle
+                                                        runs would take minutes)
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+from oracle import ref_ops as ro
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _net(n, P, L, dev, seed):
+    from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+    torch.manual_seed(seed)
+    return model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": f"synthetic:{seed}"}).to(dev).eval()
+
+
+def _inputs(n, P, R, B, dev, seed):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    poses = ro.scan_poses(30, P, n).astype(np.float32)
+    return {"source": torch.rand((B, 1, n, n, n), generator=g, device=dev) * 2 - 1,
+            "target": torch.rand((B, 1, n, n, n), generator=g, device=dev) * 2 - 1,
+            "target_proj": torch.rand((B, P, R, R), generator=g, device=dev) * 2 - 1,
+            "target_poses": torch.from_numpy(np.broadcast_to(poses, (B, P, 3)).copy())}
+
+
+def test_c2_forward_vs_oracle(dev):
+    from liftreg_amd.layers.losses import NCCLoss
+    n, P, L, B = 128, 2, 16, 4
+    net = _net(n, P, L, dev, 12)
+    inp = _inputs(n, P, n, B, dev, 12)
+    with torch.no_grad():
+        out = net(inp)
+        loss = NCCLoss()(out["warped"], out["target"])
+        ref = ro.model_forward({k: v.cpu() for k, v in net.state_dict().items()}, {k: v.cpu() for k, v in inp.items()},
+                               net.pca_vectors_LxM.cpu(), net.pca_mean.cpu())
+    np.testing.assert_allclose(out["pca_coefs"].cpu().numpy(), ref["pca_coefs"].numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out["params"].cpu().numpy(), ref["params"].numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(out["warped"].cpu().numpy(), ref["warped"].numpy(), rtol=1e-4, atol=2e-5)
+    assert abs(float(loss) - float(ro.ncc_loss(ref["warped"], ref["target"]))) < 1e-5
+
+
+def test_c4_eleven_views_sharded(dev):
+    from liftreg_amd import ops, parallel as par
+    n, P, L, B = 128, 11, 8, 1
+    net = _net(n, P, L, dev, 4)
+    inp = _inputs(n, P, n, B, dev, 4)
+    with torch.no_grad():
+        ref = net(inp)
+        outs = par.SlabShardedRegistration(net, par.LocalComm(4)).forward([inp] * 4)
+        for r, o in enumerate(outs):
+            d0, d1 = par.slab_bounds(n, 4, r)
+            assert torch.equal(o["pca_coefs"], ref["pca_coefs"])
+            assert torch.equal(o["warped"], ref["warped"][:, :, d0:d1])
+        # the 12-channel first block (4 channel passes per brick) against the CPU oracle on a crop
+        blk = net.encoders[0]
+        x = torch.cat([inp["source"], ops.backproject(inp["target_proj"], inp["target_poses"][0].numpy(), (n, n, n))], 1)
+        y = ops.conv3d_k3_lrelu(x, blk.conv.weight, blk.conv.bias, 1)
+        crop = x[:, :, 40:72, 50:82, 0:40].cpu()
+        want = ro.conv_block(crop, blk.conv.weight.cpu(), blk.conv.bias.cpu(), 1)
+    np.testing.assert_allclose(y[:, :, 41:71, 51:81, 0:39].cpu().numpy(), want[:, :, 1:-1, 1:-1, 0:39].numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_c5_shapes_384_volume_512_detector(dev):
+    from liftreg_amd import ops
+    from liftreg_amd.utils.net_utils import identity_axis_tables
+    n, R, P = 384, 512, 2
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    poses64 = ro.scan_poses(30, P, n)
+    poses = poses64.astype(np.float32)
+    sp = np.array((2.2, 2.2, 2.2), np.float32)
+    # projector: coordinates bit-exact against the C oracle on a detector patch, DRR on whole rows
+    vol = torch.rand((n, n, n), generator=g, device=dev) * 0.3
+    drr = ops.drr_forward(vol, poses, (R, R), sp, nseg=1)
+    pix, dx = ops.drr_sample_coords(poses, sp, (n, n, n), (R, R), dev)
+    cpix, cdx = co.drr_sample_coords(poses, sp, (n, n, n), (R, R))
+    assert np.array_equal(dx.cpu().numpy(), cdx)
+    assert np.array_equal(pix[:, 200:216].cpu().numpy(), cpix[:, 200:216])
+    want = co.drr_forward(vol.cpu().numpy(), poses, sp, (R, R))
+    assert np.array_equal(drr.cpu().numpy(), want)
+    # backprojection of 512^2 views into 384^3
+    proj = torch.rand((1, P, R, R), generator=g, device=dev) * 2 - 1
+    tv = ops.backproject(proj, poses, (n, n, n))
+    bpix = ops.backproject_coords(poses, (n, n, n), (R, R), dev)
+    assert np.array_equal(bpix[:, 100:104].cpu().numpy(), co.backproject_coords(poses, (n, n, n), (R, R))[:, 100:104])
+    assert np.array_equal(tv[:, :, 300:308].cpu().numpy(), co.backproject(proj.cpu().numpy(), poses, (n, n, n), d0=300, d1=308))
+    # first conv block on the 384^3 encoder input and the warp of a 384^3 volume: crops against the oracles
+    moving = torch.rand((1, 1, n, n, n), generator=g, device=dev) * 2 - 1
+    x = torch.cat([moving, tv], 1)
+    w = torch.randn((16, 3, 3, 3, 3), generator=g, device=dev) / 9
+    b = torch.randn((16,), generator=g, device=dev) * 0.1
+    y = ops.conv3d_k3_lrelu(x, w, b, 1)
+    wantc = ro.conv_block(x[:, :, 350:384, 0:34, 330:384].cpu(), w.cpu(), b.cpu(), 1)
+    np.testing.assert_allclose(y[:, :, 351:384, 0:33, 331:384].cpu().numpy(), wantc[:, :, 1:, :-1, 1:].numpy(), rtol=1e-4, atol=1e-5)
+    disp = (torch.rand((1, 3, n, n, n), generator=g, device=dev) - 0.5) * 0.04
+    tabs = identity_axis_tables((n, n, n))
+    ids = [torch.from_numpy(t).to(dev) for t in tabs]
+    phi, warped = ops.warp(moving, disp, ids, None)
+    cphi, cw = co.warp(moving.cpu().numpy(), disp[:, :, 190:198].cpu().numpy(), ids=(tabs[0][190:198], tabs[1], tabs[2]),
+                       d0=190, d1=198)
+    assert np.array_equal(phi[:, :, 190:198].cpu().numpy(), cphi) and np.array_equal(warped[:, :, 190:198].cpu().numpy(), cw)
