@@ -205,6 +205,16 @@ int lr_ncc_moments_f32(const float* x, const float* y, double* partial, double* 
 int lr_ncc_loss_from_moments(const double* moments, float* loss, float* ncc_rows,
                              int R, int64_t n_total, int n_batch, int variant, void* stream);
 
+/* ------------------------------------------------------------------------
+ * a16 (regulariser part)  mean over (B,D,W,H) of sum_{c,axis} (d_axis disp_c)^2.
+ * Replaces compute_reg_loss: src/liftreg/losses/SubspaceLoss.py:51-67 (mermaid FD_torch(spacing*2),
+ * spacing = 1/(shape-1)).  PARITY UNPINNED: the stencil is mermaid's (absent); assumed central
+ * differences with linearly extrapolated faces.
+ * disp: dev (B,3,D,W,H); partial: dev workspace B*nblk doubles; out: dev 1 float.
+ */
+int lr_disp_reg_f32(const float* disp, double* partial, float* out, int B, int D, int W, int H,
+                    int nblk, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

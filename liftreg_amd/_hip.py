@@ -40,6 +40,7 @@ SIGNATURES = {
     "lr_mask_compose_f32": (_i, [_p, _p, _p, _i64, _p]),
     "lr_ncc_moments_f32": (_i, [_p, _p, _p, _p, _i, _i64, _i, _p]),
     "lr_ncc_loss_from_moments": (_i, [_p, _p, _p, _i, _i64, _i, _i, _p]),
+    "lr_disp_reg_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
 }
 
 

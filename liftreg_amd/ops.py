@@ -368,3 +368,22 @@ def ncc_loss(x, y, variant=_hip.NCC_CONFIGURED):
     m = ncc_moments(x, y, R)
     loss, _ = ncc_loss_from_moments(m, x.numel() // R, n_batch, variant)
     return loss
+
+
+# ----------------------------------------------------------------------------- a16 regulariser
+def disp_reg(disp, nblk=None):
+    """mean_{b,voxel} Σ_{c,axis} (∂_axis disp_c)² — the regulariser of SubspaceLoss (reference
+    losses/SubspaceLoss.py:51-67).  PARITY UNPINNED: mermaid's stencil is assumed (central differences,
+    linearly extrapolated faces, spacing 2/(shape-1))."""
+    disp = _dev(disp, "disp")
+    B, C3, D, W, H = disp.shape
+    if C3 != 3:
+        raise ValueError("disp must be (B,3,D,W,H)")
+    if nblk is None:
+        nblk = max(1, min(2048 // B if B < 2048 else 1, (D * W * H + 1023) // 1024))
+    partial = torch.empty((B, nblk), dtype=torch.float64, device=disp.device)
+    out = torch.empty((), dtype=torch.float32, device=disp.device)
+    with _timed("disp_reg", bytes=4 * disp.numel()):
+        _hip.check(_hip.lib().lr_disp_reg_f32(disp.data_ptr(), partial.data_ptr(), out.data_ptr(), B, D, W, H, nblk,
+                                              _stream()), "lr_disp_reg_f32")
+    return out

@@ -237,3 +237,38 @@ def model_forward(params, inp, pca_vectors_LxM, pca_mean, strides=(1, 2, 2, 2, 2
     warped = warp(moving_cp, phi, zero_boundary=True, using_scale=True)
     return {"warped": warped, "phi": phi, "params": disp, "target": target_cp, "pca_coefs": coefs,
             "target_proj": target_proj, "warped_proj": target_proj, "target_volume": tv}
+
+
+# --------------------------------------------------------------------------- a16
+def sigmoid_decay(ep, static=5, k=5):
+    """utils/utils.py:93-107."""
+    if ep < static:
+        return float(1.)
+    return float(k / (k + np.exp((ep - static) / k)))
+
+
+def disp_reg(disp):
+    """compute_reg_loss (losses/SubspaceLoss.py:51-67).  PARITY UNPINNED — mermaid 0.3.2 is absent; ASSUMED
+    stencil: dXc = (I[x+1]-I[x-1])*0.5/spacing, linearly extrapolated faces (one-sided differences there),
+    spacing = 2/(shape-1) (the reference passes FD_torch(spacing*2) with spacing = 1/(shape-1))."""
+    total = torch.zeros(disp.shape[0], *disp.shape[2:], dtype=disp.dtype)
+    for c in range(3):
+        f = disp[:, c]
+        for ax in (1, 2, 3):
+            n = f.shape[ax]
+            inv_h = 0.5 * (n - 1)
+            g = torch.zeros_like(f)
+            sl = lambda a, b: tuple(slice(a, b) if i == ax else slice(None) for i in range(4))
+            g[sl(1, n - 1)] = (f[sl(2, n)] - f[sl(0, n - 2)]) * (0.5 * inv_h)
+            g[sl(0, 1)] = (f[sl(1, 2)] - f[sl(0, 1)]) * inv_h
+            g[sl(n - 1, n)] = (f[sl(n - 1, n)] - f[sl(n - 2, n - 1)]) * inv_h
+            total = total + g ** 2
+    return total.mean()
+
+
+def subspace_loss(output, epoch, initial_reg_factor=0.01, min_reg_factor=0.01, reg_factor_decay_from=2):
+    """loss.forward (losses/SubspaceLoss.py:20-49) with the configured NCC similarity."""
+    sim = ncc_loss(output["warped"], output["target"])
+    reg = disp_reg(output["params"])
+    factor = float(max(sigmoid_decay(epoch, static=reg_factor_decay_from, k=2) * initial_reg_factor, min_reg_factor))
+    return {"total_loss": sim + factor * reg, "sim_loss": float(sim), "reg_loss": float(reg)}

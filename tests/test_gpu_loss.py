@@ -1,0 +1,45 @@
+"""GPU: the SubspaceLoss plugin (a16) — NCC similarity + displacement regulariser — against the torch-CPU
+restatement.  The regulariser's stencil is mermaid's (absent, parity UNPINNED): both sides implement the
+documented assumption, so this test pins the kernel to the restatement, not to the reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops as ro
+
+pytestmark = pytest.mark.gpu
+
+
+def test_subspace_loss_plugin_vs_restatement():
+    from liftreg_amd import ops
+    from liftreg_amd.utils.general import get_class
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(17)
+    cls = get_class("liftreg_amd.losses.SubspaceLoss.loss")
+    opt = {"sim_class": "liftreg_amd.layers.losses.NCCLoss", "initial_reg_factor": 0.01, "min_reg_factor": 0.01,
+           "reg_factor_decay_from": 2}                                   # cur_task_setting.json:47-52
+    f = cls(opt)
+    for shape, B in (((12, 10, 14), 2), ((9, 16, 33), 1), ((2, 2, 2), 3)):
+        warped = rs.uniform(-1, 1, (B, 1) + shape).astype(np.float32)
+        target = (0.7 * warped + 0.3 * rs.uniform(-1, 1, warped.shape)).astype(np.float32)
+        disp = rs.normal(0, 0.05, (B, 3) + shape).astype(np.float32)
+        out = {"warped": torch.from_numpy(warped).to(dev), "target": torch.from_numpy(target).to(dev),
+               "params": torch.from_numpy(disp).to(dev), "pca_coefs": None, "epoch": 5}
+        with torch.no_grad():
+            got = f(out)
+        want = ro.subspace_loss({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in out.items()}, 5)
+        assert set(got) == {"total_loss", "sim_loss", "reg_loss"}
+        assert isinstance(got["sim_loss"], float) and isinstance(got["reg_loss"], float)
+        assert abs(got["sim_loss"] - want["sim_loss"]) < 2e-6
+        assert abs(got["reg_loss"] - want["reg_loss"]) < 1e-5 * max(1.0, abs(want["reg_loss"]))
+        assert abs(float(got["total_loss"]) - float(want["total_loss"])) < 1e-5
+    assert f.get_reg_factor(0) == 0.01 and f.get_reg_factor(50) == 0.01   # shipped config: constant factor
+    big = cls({"initial_reg_factor": 10, "min_reg_factor": 1e-3, "reg_factor_decay_from": 10})
+    assert big.get_reg_factor(3) == 10.0 and abs(big.get_reg_factor(12) - 10 * ro.sigmoid_decay(12, 10, 2)) < 1e-9
+    # properties at full size: constant field → 0; linear ramp → its squared slope (central == one-sided)
+    n = 256
+    const = torch.full((1, 3, n, n, n), 0.3, device=dev)
+    assert float(ops.disp_reg(const)) == 0.0
+    ramp = torch.zeros((1, 3, n, n, n), device=dev)
+    ramp[:, 0] = torch.linspace(-1, 1, n, device=dev)[:, None, None] * 0.05    # 0.05·x along D in normalised units
+    assert abs(float(ops.disp_reg(ramp)) - 0.05 ** 2) < 1e-7
