@@ -215,6 +215,28 @@ int lr_ncc_loss_from_moments(const double* moments, float* loss, float* ncc_rows
 int lr_disp_reg_f32(const float* disp, double* partial, float* out, int B, int D, int W, int H,
                     int nblk, void* stream);
 
+/* ========================================================================
+ * Backward kernels of the training step (the reference gets these from ATen autograd at
+ * RegistrationNet.py:401 `losses["total_loss"].backward()`).
+ * ------------------------------------------------------------------------
+ * d loss/d x of the NCC similarity (x = warped; the target has no gradient).  `moments` (R,5) as produced
+ * by lr_ncc_moments_f32 (all-reduced when sharded), `gout` = dev pointer to the upstream scalar gradient. */
+int lr_ncc_bwd_f32(const float* x, const float* y, const double* moments, const float* gout, float* gx,
+                   int R, int64_t N, int64_t n_total, int variant, void* stream);
+/* d/d disp of lr_warp_trilinear_f32 (bilinear mode; the moving image has no gradient).  Same arguments as
+ * the forward; gwarped (B,C,Dn,W,H) in, gdisp (B,3,Dn,W,H) out.  flags: USING_SCALE, BORDER. */
+int lr_warp_bwd_disp_f32(const float* img, const float* seg, const float* disp, const float* id0,
+                         const float* id1, const float* id2, const float* gwarped, float* gdisp, int B,
+                         int C, int D, int W, int H, int d0, int d1, int flags, void* stream);
+/* d/d coefs of lr_pca_reconstruct_f32: gcoefs (B,L) = gdisp (B,M) · basis^T.  B <= 8.
+ * partial: dev workspace nblk*B*L floats. */
+int lr_pca_bwd_coef_f32(const float* gdisp, const float* basis, float* partial, float* gcoefs, int B,
+                        int L, int64_t M, int64_t ldb, int64_t gdisp_batch_stride, int nblk, void* stream);
+/* Backward of lr_linear_lrelu_f32: y = its (post-activation) output, gy = upstream gradient.
+ * gx (B,K) and/or (gw (O,K), gb (O)) may be NULL to skip. */
+int lr_linear_bwd_f32(const float* x, const float* w, const float* y, const float* gy, float* gx,
+                      float* gw, float* gb, int B, int K, int O, float negative_slope, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

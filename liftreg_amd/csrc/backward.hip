@@ -1,0 +1,326 @@
+// backward.hip — gradients of the memory-bound ops for the training step (SURVEY §8 f2,
+// reference RegistrationNet.py:389-406: loss.backward()).  The reference gets these from ATen autograd;
+// each kernel states the formula it implements and is tested against torch autograd of the CPU oracle.
+//
+//   NCC          d loss / d warped                         (layers/losses.py:14-29 backward)
+//   warp         d / d disp  (the moving image has no grad) (net_utils.py:26-52 + …Backproj.py:68 backward)
+//   PCA          d / d coefs = g_disp · basis^T             (…Backproj.py:102 backward, second basis read)
+//   Linear       d / d x, d / d W, d / d b with the LeakyReLU mask (layers/layers.py:432-438 backward)
+#include "lr_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------ NCC
+// loss = 1 - (1/R) sum_r ncc_r ;  configured: ncc = (cov+e2)/s, s = sqrt((vx+e2)(vy+e2))
+//   d ncc / d x_i = (1/n) [ yc_i / s - ncc * xc_i / (vx+e2) ]
+// squared: v = cov^2/(vx*vy+1e-12):  d v / d x_i = (2/n) [ cov*yc_i*q - cov^2*vy*xc_i ] / q^2,  q = vx*vy+1e-12
+__global__ __launch_bounds__(256) void ncc_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                      const double* __restrict__ moments,
+                                                      const float* __restrict__ gout, float* __restrict__ gx,
+                                                      int R, int64_t N, double n_total, int variant) {
+  const int r = blockIdx.y;
+  const double* m = moments + (int64_t)r * 5;
+  const double n = n_total;
+  const double mx = m[0] / n, my = m[1] / n;
+  const double cov = m[2] / n - mx * my, vx = m[3] / n - mx * mx, vy = m[4] / n - my * my;
+  const double g = -(double)(*gout) / (double)R;  // d loss / d ncc_r
+  double cy, cx;                                  // gx_i = cy * (y_i - my) + cx * (x_i - mx)
+  if (variant == LR_NCC_CONFIGURED) {
+    const double e2 = 1e-20, s = sqrt((vx + e2) * (vy + e2));
+    const double ncc = (cov + e2) / s;
+    cy = g / (n * s);
+    cx = -g * ncc / (n * (vx + e2));
+  } else {
+    const double q = vx * vy + 1e-12;
+    cy = g * 2.0 * cov / (n * q);
+    cx = -g * 2.0 * cov * cov * vy / (n * q * q);
+  }
+  const float fcy = (float)cy, fcx = (float)cx, fmx = (float)mx, fmy = (float)my;
+  const float* xr = x + (int64_t)r * N;
+  const float* yr = y + (int64_t)r * N;
+  float* gr = gx + (int64_t)r * N;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride)
+    gr[i] = fmaf(fcy, yr[i] - fmy, fcx * (xr[i] - fmx));
+}
+
+// ------------------------------------------------------------------------------------------------ warp
+struct AxisB {
+  int i0, i1;
+  float w0, w1;
+  bool ok0, ok1;
+  float gmul;  // d pix / d phi (0 when 'border' clipping is active)
+};
+
+template <bool BORDER>
+__device__ __forceinline__ AxisB axis_b(float g, int size) {
+  float pix = ((g + 1.0f) * 0.5f) * (float)(size - 1);
+  AxisB a;
+  a.gmul = 0.5f * (float)(size - 1);
+  if constexpr (BORDER) {  // clip_coordinates_set_grad: zero gradient outside [0, size-1]
+    if (!(pix > 0.0f && pix < (float)(size - 1))) a.gmul = 0.0f;
+    pix = fminf((float)(size - 1), fmaxf(pix, 0.0f));
+  }
+  if (!(pix > -1.0f && pix < (float)size)) {
+    a.i0 = a.i1 = 0;
+    a.w0 = a.w1 = 0.0f;
+    a.ok0 = a.ok1 = false;
+    return a;
+  }
+  const float fl = floorf(pix);
+  const int i0 = (int)fl, i1 = i0 + 1;
+  a.w0 = (float)i1 - pix;
+  a.w1 = pix - (float)i0;
+  a.ok0 = i0 >= 0;
+  a.ok1 = i1 < size;
+  a.i0 = max(i0, 0);
+  a.i1 = min(i1, size - 1);
+  return a;
+}
+
+// g_disp[c_axis] = sum_channels g_warped * (scale ? 2 : 1) * dS/dpix_axis * (size_axis-1)/2,
+// dS/dx = sum_{cy,cz} wy*wz*(val[x1]-val[x0]) (out-of-range corners are 0), likewise y, z.
+template <bool SCALE, bool BORDER, bool SEG>
+__global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__ img, const float* __restrict__ seg,
+                                                       const float* __restrict__ disp, const float* __restrict__ id0,
+                                                       const float* __restrict__ id1, const float* __restrict__ id2,
+                                                       const float* __restrict__ gw, float* __restrict__ gdisp,
+                                                       int B, int C, int D, int W, int H, int Dn) {
+  const int64_t per_b = (int64_t)Dn * W * H;
+  const int b = blockIdx.y;
+  const int64_t idx = (int64_t)lr_xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+  if (idx >= per_b) return;
+  const int k = (int)(idx % H), j = (int)((idx / H) % W), i = (int)(idx / H / W);
+  const int64_t V = (int64_t)D * W * H, sD = (int64_t)W * H;
+  const float* dp = disp + (int64_t)b * 3 * per_b + idx;
+  float p0 = dp[0], p1 = dp[per_b], p2 = dp[2 * per_b];
+  if (id0) { p0 = p0 + id0[i]; p1 = p1 + id1[j]; p2 = p2 + id2[k]; }
+  const AxisB ax = axis_b<BORDER>(p2, H), ay = axis_b<BORDER>(p1, W), az = axis_b<BORDER>(p0, D);
+  float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+  for (int c = 0; c < C; ++c) {
+    const float* im = img + ((int64_t)b * C + c) * V;
+    const float* sg = SEG ? seg + ((int64_t)b * C + c) * V : nullptr;
+    float v[2][2][2];
+#pragma unroll
+    for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+      for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+        for (int cx = 0; cx < 2; ++cx) {
+          const bool ok = (cz ? az.ok1 : az.ok0) && (cy ? ay.ok1 : ay.ok0) && (cx ? ax.ok1 : ax.ok0);
+          const int64_t off = (int64_t)(cz ? az.i1 : az.i0) * sD + (int64_t)(cy ? ay.i1 : ay.i0) * H + (cx ? ax.i1 : ax.i0);
+          float t = im[off];
+          if constexpr (SEG) t = (t + 1.0f) * sg[off] - 1.0f;
+          if constexpr (SCALE) t = (t + 1.0f) * 0.5f;
+          v[cz][cy][cx] = ok ? t : 0.0f;
+        }
+    const float wz[2] = {az.w0, az.w1}, wy[2] = {ay.w0, ay.w1}, wx[2] = {ax.w0, ax.w1};
+    float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        dx += wy[a] * wz[q] * (v[q][a][1] - v[q][a][0]);
+        dy += wx[a] * wz[q] * (v[q][1][a] - v[q][0][a]);
+        dz += wx[a] * wy[q] * (v[1][q][a] - v[0][q][a]);
+      }
+    const float g = gw[((int64_t)b * C + c) * per_b + idx] * (SCALE ? 2.0f : 1.0f);
+    gx += g * dx;
+    gy += g * dy;
+    gz += g * dz;
+  }
+  float* go = gdisp + (int64_t)b * 3 * per_b + idx;
+  go[0] = gz * az.gmul;          // disp channel 0 <-> D
+  go[per_b] = gy * ay.gmul;      // channel 1 <-> W
+  go[2 * per_b] = gx * ax.gmul;  // channel 2 <-> H
+}
+
+// ------------------------------------------------------------------------------------------------ PCA
+// gcoefs[b][l] = sum_m g[b][m] * basis[l][m].  grid (m-blocks, l-groups of LG): a block keeps LG x BT
+// accumulators per thread, streams its m-range once per l-group; per-block partials, then a fixed-order reduce.
+constexpr int LG = 8;
+template <int BT>
+__global__ __launch_bounds__(256) void pca_bwd_kernel(const float* __restrict__ g, const float* __restrict__ basis,
+                                                      float* __restrict__ partial, int B, int L, int64_t M,
+                                                      int64_t ldb, int64_t gstride) {
+  const int l0 = blockIdx.y * LG;
+  float acc[LG][BT];
+#pragma unroll
+  for (int a = 0; a < LG; ++a)
+#pragma unroll
+    for (int b = 0; b < BT; ++b) acc[a][b] = 0.0f;
+  const int64_t step = (int64_t)gridDim.x * 256 * 4;
+  for (int64_t m = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; m < M; m += step) {
+    f32x4 gv[BT];
+#pragma unroll
+    for (int b = 0; b < BT; ++b)
+      gv[b] = b < B ? *reinterpret_cast<const f32x4*>(g + (int64_t)b * gstride + m) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < LG; ++a) {
+      if (l0 + a < L) {
+        const f32x4 bv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(basis + (int64_t)(l0 + a) * ldb + m));
+#pragma unroll
+        for (int b = 0; b < BT; ++b)
+          acc[a][b] = fmaf(gv[b].x, bv.x, fmaf(gv[b].y, bv.y, fmaf(gv[b].z, bv.z, fmaf(gv[b].w, bv.w, acc[a][b]))));
+      }
+    }
+  }
+  __shared__ float red[4][LG * BT];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int a = 0; a < LG; ++a)
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      const float s = lr_wave_sum(acc[a][b]);
+      if (lane == 0) red[wave][a * BT + b] = s;
+    }
+  __syncthreads();
+  if (threadIdx.x < LG * BT) {
+    const int a = threadIdx.x / BT, b = threadIdx.x % BT;
+    if (l0 + a < L && b < B)
+      partial[((int64_t)blockIdx.x * B + b) * L + l0 + a] =
+          (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                           int nblk, int n) {
+  // out[i] = sum_blk partial[blk][i], fixed order, fp64 accumulate
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int k = 0; k < nblk; ++k) s += (double)partial[(int64_t)k * n + i];
+  out[i] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------ Linear
+__device__ __forceinline__ float lrelu_grad(float gy, float y, float slope) { return y > 0.0f ? gy : gy * slope; }
+
+// gw[o][k] = sum_b gpre[b][o] x[b][k] ; gb[o] = sum_b gpre[b][o]
+__global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ gy, float* __restrict__ gw,
+                                                           float* __restrict__ gb, int B, int K, int O, float slope) {
+  const int o = blockIdx.y;
+  __shared__ float gp[32];
+  if (threadIdx.x < 32)
+    gp[threadIdx.x] = threadIdx.x < B ? lrelu_grad(gy[(int64_t)threadIdx.x * O + o], y[(int64_t)threadIdx.x * O + o], slope) : 0.0f;
+  __syncthreads();
+  if (gb && blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) s += gp[b];
+    gb[o] = s;
+  }
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < K; k += gridDim.x * 256) {
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) s = fmaf(gp[b], x[(int64_t)b * K + k], s);
+    gw[(int64_t)o * K + k] = s;
+  }
+}
+
+// gx[b][k] = sum_o gpre[b][o] w[o][k]
+template <int BT>
+__global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* __restrict__ w, const float* __restrict__ y,
+                                                           const float* __restrict__ gy, float* __restrict__ gx,
+                                                           int B, int b_lo, int K, int O, float slope) {
+  extern __shared__ float gpre[];  // [O][BT]
+  for (int t = threadIdx.x; t < O * BT; t += 256) {
+    const int o = t / BT, b = b_lo + t % BT;
+    gpre[t] = b < B ? lrelu_grad(gy[(int64_t)b * O + o], y[(int64_t)b * O + o], slope) : 0.0f;
+  }
+  __syncthreads();
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  float acc[BT];
+#pragma unroll
+  for (int b = 0; b < BT; ++b) acc[b] = 0.0f;
+  for (int o = 0; o < O; ++o) {
+    const float wv = w[(int64_t)o * K + k];
+#pragma unroll
+    for (int b = 0; b < BT; ++b) acc[b] = fmaf(gpre[o * BT + b], wv, acc[b]);
+  }
+#pragma unroll
+  for (int b = 0; b < BT; ++b)
+    if (b_lo + b < B) gx[(int64_t)(b_lo + b) * K + k] = acc[b];
+}
+
+}  // namespace
+
+extern "C" int lr_ncc_bwd_f32(const float* x, const float* y, const double* moments, const float* gout, float* gx,
+                              int R, int64_t N, int64_t n_total, int variant, void* stream) {
+  if (!x || !y || !moments || !gout || !gx) return LR_ENULL;
+  if (R < 1 || R > 65535 || N < 1 || n_total < N) return LR_EINVAL;
+  if (variant != LR_NCC_CONFIGURED && variant != LR_NCC_SQUARED) return LR_EINVAL;
+  int64_t nblk = (N + 255) / 256;
+  if (nblk > 4096) nblk = 4096;
+  hipLaunchKernelGGL(ncc_bwd_kernel, dim3((unsigned)nblk, (unsigned)R), dim3(256), 0, lr_stream(stream), x, y,
+                     moments, gout, gx, R, N, (double)n_total, variant);
+  return lr_launch_status();
+}
+
+extern "C" int lr_warp_bwd_disp_f32(const float* img, const float* seg, const float* disp, const float* id0,
+                                    const float* id1, const float* id2, const float* gwarped, float* gdisp, int B,
+                                    int C, int D, int W, int H, int d0, int d1, int flags, void* stream) {
+  if (!img || !disp || !gwarped || !gdisp) return LR_ENULL;
+  if (B < 1 || B > 65535 || C < 1 || D < 1 || W < 1 || H < 1 || d0 < 0 || d1 > D || d1 <= d0) return LR_EINVAL;
+  if (flags & ~(LR_WARP_USING_SCALE | LR_WARP_BORDER)) return LR_EUNSUPPORTED;  // nearest mode has no gradient
+  const bool any_id = id0 || id1 || id2, all_id = id0 && id1 && id2;
+  if (any_id && !all_id) return LR_ENULL;
+  const int Dn = d1 - d0;
+  const int64_t nblk = ((int64_t)Dn * W * H + 255) / 256;
+  if (nblk > 0x7fffffffLL) return LR_EINVAL;
+  const dim3 grid((unsigned)nblk, (unsigned)B), block(256);
+  hipStream_t st = lr_stream(stream);
+  const bool sc = flags & LR_WARP_USING_SCALE, bo = flags & LR_WARP_BORDER;
+#define LR_WB(S, Bo, G) hipLaunchKernelGGL((warp_bwd_kernel<S, Bo, G>), grid, block, 0, st, img, seg, disp, id0, id1, id2, gwarped, gdisp, B, C, D, W, H, Dn)
+  if (seg) {
+    if (sc) { if (bo) LR_WB(true, true, true); else LR_WB(true, false, true); }
+    else    { if (bo) LR_WB(false, true, true); else LR_WB(false, false, true); }
+  } else {
+    if (sc) { if (bo) LR_WB(true, true, false); else LR_WB(true, false, false); }
+    else    { if (bo) LR_WB(false, true, false); else LR_WB(false, false, false); }
+  }
+#undef LR_WB
+  return lr_launch_status();
+}
+
+extern "C" int lr_pca_bwd_coef_f32(const float* gdisp, const float* basis, float* partial, float* gcoefs, int B,
+                                   int L, int64_t M, int64_t ldb, int64_t gdisp_batch_stride, int nblk,
+                                   void* stream) {
+  if (!gdisp || !basis || !partial || !gcoefs) return LR_ENULL;
+  if (B < 1 || B > 8 || L < 1 || M < 4 || ldb < M || gdisp_batch_stride < M || nblk < 1 || nblk > 65535)
+    return B > 8 ? LR_EUNSUPPORTED : LR_EINVAL;
+  if ((M & 3) || (ldb & 3) || (gdisp_batch_stride & 3)) return LR_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(gdisp) | reinterpret_cast<uintptr_t>(basis)) & 15u) return LR_EALIGN;
+  hipStream_t st = lr_stream(stream);
+  const dim3 grid((unsigned)nblk, (unsigned)((L + LG - 1) / LG));
+  if (B > 4) hipLaunchKernelGGL(pca_bwd_kernel<8>, grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
+  else hipLaunchKernelGGL(pca_bwd_kernel<4>, grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
+  if (int e = lr_launch_status()) return e;
+  const int n = B * L;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partial, gcoefs, nblk, n);
+  return lr_launch_status();
+}
+
+extern "C" int lr_linear_bwd_f32(const float* x, const float* w, const float* y, const float* gy, float* gx,
+                                 float* gw, float* gb, int B, int K, int O, float negative_slope, void* stream) {
+  if (!x || !w || !y || !gy) return LR_ENULL;
+  if (B < 1 || B > 32 || K < 1 || O < 1 || O > 65535) return LR_EINVAL;
+  hipStream_t st = lr_stream(stream);
+  if (gw) {
+    int kb = (K + 255) / 256;
+    if (kb > 64) kb = 64;
+    hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((unsigned)kb, (unsigned)O), dim3(256), 0, st, x, y, gy, gw, gb, B, K, O, negative_slope);
+    if (int e = lr_launch_status()) return e;
+  }
+  if (gx) {
+    const unsigned nb = (unsigned)((K + 255) / 256);
+    for (int b_lo = 0; b_lo < B; b_lo += 8) {
+      if ((size_t)O * 8 * 4 > 64 * 1024) return LR_EUNSUPPORTED;
+      hipLaunchKernelGGL(linear_bwd_x_kernel<8>, dim3(nb), dim3(256), (size_t)O * 8 * 4, st, w, y, gy, gx, B, b_lo, K, O, negative_slope);
+      if (int e = lr_launch_status()) return e;
+    }
+  }
+  return LR_OK;
+}

@@ -1,0 +1,76 @@
+"""Tensor-level front-end of the backward kernels (liftreg_amd/csrc/backward.hip, conv3d_bwd.hip).
+
+Same rules as liftreg_amd.ops: GPU tensors only, outputs allocated here, launches on torch's current stream,
+no CPU/PyTorch fallback.
+"""
+import torch
+
+from . import _hip
+from .ops import _dev, _ptr, _stream, _timed
+
+
+def ncc_bwd(x, y, moments, gout, n_total, variant=_hip.NCC_CONFIGURED):
+    """d loss / d x for loss = 1 - mean_r ncc_r (x = warped).  `gout`: 0-dim GPU tensor (upstream gradient)."""
+    x, y = _dev(x, "x"), _dev(y, "y")
+    moments = _dev(moments, "moments", torch.float64)
+    gout = _dev(gout.reshape(()).to(torch.float32), "gout")
+    R = moments.shape[0]
+    N = x.numel() // R
+    gx = torch.empty_like(x)
+    with _timed("ncc_bwd", bytes=12 * x.numel()):
+        _hip.check(_hip.lib().lr_ncc_bwd_f32(x.data_ptr(), y.data_ptr(), moments.data_ptr(), gout.data_ptr(),
+                                             gx.data_ptr(), R, N, int(n_total), variant, _stream()), "lr_ncc_bwd_f32")
+    return gx
+
+
+def warp_bwd_disp(img, disp, ids, seg, gwarped, *, using_scale=True, zero_boundary=True, d0=0, d1=None):
+    """d / d disp of ops.warp (bilinear).  Returns (B,3,Dn,W,H)."""
+    img, disp, gwarped = _dev(img, "img"), _dev(disp, "disp"), _dev(gwarped, "gwarped")
+    B, C, D, W, H = img.shape
+    d1 = D if d1 is None else int(d1)
+    sg = None if seg is None else _dev(seg, "seg")
+    i0 = i1 = i2 = None
+    if ids is not None:
+        i0, i1, i2 = (_dev(t, "id table") for t in ids)
+    gdisp = torch.empty_like(disp)
+    flags = (_hip.WARP_USING_SCALE if using_scale else 0) | (0 if zero_boundary else _hip.WARP_BORDER)
+    with _timed("warp_bwd_disp", bytes=4 * (2 * disp.numel() + gwarped.numel())):
+        _hip.check(_hip.lib().lr_warp_bwd_disp_f32(img.data_ptr(), _ptr(sg), disp.data_ptr(), _ptr(i0), _ptr(i1),
+                                                   _ptr(i2), gwarped.data_ptr(), gdisp.data_ptr(), B, C, D, W, H, d0,
+                                                   d1, flags, _stream()), "lr_warp_bwd_disp_f32")
+    return gdisp
+
+
+def pca_bwd_coef(gdisp, basis_LxM, nblk=None):
+    """gcoefs (B,L) = gdisp (B,M) @ basis (L,M)^T — the second read of the PCA basis."""
+    gdisp = _dev(gdisp, "gdisp")
+    B = gdisp.shape[0]
+    g2 = gdisp.reshape(B, -1)
+    L, M = basis_LxM.shape
+    if g2.shape[1] != M or basis_LxM.stride(1) != 1:
+        raise ValueError("gdisp/basis shape mismatch")
+    if nblk is None:
+        nblk = max(1, min(512, M // 4096))
+    partial = torch.empty((nblk, B, L), dtype=torch.float32, device=gdisp.device)
+    gcoefs = torch.empty((B, L), dtype=torch.float32, device=gdisp.device)
+    with _timed("pca_bwd_coef", bytes=4 * (L * M + ((L + 7) // 8) * B * M)):
+        _hip.check(_hip.lib().lr_pca_bwd_coef_f32(g2.data_ptr(), basis_LxM.data_ptr(), partial.data_ptr(),
+                                                  gcoefs.data_ptr(), B, L, M, basis_LxM.stride(0), M, nblk, _stream()),
+                   "lr_pca_bwd_coef_f32")
+    return gcoefs
+
+
+def linear_bwd(x, weight, y, gy, negative_slope=1.0, need_gx=True):
+    """Backward of ops.linear_lrelu: returns (gx or None, gw, gb)."""
+    x, y, gy = _dev(x, "x"), _dev(y, "y"), _dev(gy, "gy")
+    w = _dev(weight.detach(), "weight")
+    B, K = x.shape
+    O = w.shape[0]
+    gx = torch.empty_like(x) if need_gx else None
+    gw = torch.empty_like(w)
+    gb = torch.empty((O,), dtype=torch.float32, device=x.device)
+    with _timed(f"linear_bwd_{K}x{O}", bytes=4 * (2 * w.numel() + gw.numel())):
+        _hip.check(_hip.lib().lr_linear_bwd_f32(x.data_ptr(), w.data_ptr(), y.data_ptr(), gy.data_ptr(), _ptr(gx),
+                                                gw.data_ptr(), gb.data_ptr(), B, K, O, float(negative_slope), _stream()),
+                   "lr_linear_bwd_f32")
+    return gx, gw, gb

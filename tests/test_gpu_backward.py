@@ -1,0 +1,82 @@
+"""GPU: backward kernels of the training step against torch autograd of the CPU oracle
+(oracle/ref_ops.py — the reference's own op sequence, differentiated by ATen exactly as the reference's
+`loss.backward()` does, RegistrationNet.py:401)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops as ro
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_ncc_backward(dev):
+    from liftreg_amd import ops, ops_bwd
+    rs = np.random.RandomState(1)
+    for variant, f in ((0, ro.ncc_loss), (1, ro.ncc_loss_squared)):
+        x = rs.uniform(-1, 1, (3, 2, 6, 7, 8)).astype(np.float32)
+        y = (0.5 * x + 0.5 * rs.uniform(-1, 1, x.shape)).astype(np.float32)
+        xt = torch.from_numpy(x).requires_grad_(True)
+        (f(xt, torch.from_numpy(y)) * 1.7).backward()
+        R = 3 if variant == 0 else 6
+        m = ops.ncc_moments(T(x, dev), T(y, dev), R)
+        gx = ops_bwd.ncc_bwd(T(x, dev), T(y, dev), m, torch.tensor(1.7, device=dev), x.size // R, variant)
+        np.testing.assert_allclose(gx.cpu().numpy(), xt.grad.numpy(), rtol=2e-4, atol=1e-8)
+
+
+def test_warp_backward_wrt_displacement(dev):
+    from liftreg_amd import ops_bwd
+    rs = np.random.RandomState(2)
+    for shape, B, C, use_seg, zb in (((9, 11, 13), 2, 1, False, True), ((8, 8, 12), 1, 2, True, True), ((6, 7, 8), 1, 1, False, False)):
+        img = rs.uniform(-1, 1, (B, C) + shape).astype(np.float32)
+        seg = (rs.uniform(0, 1, (B, C) + shape) > 0.3).astype(np.float32) if use_seg else None
+        disp = rs.normal(0, 0.25, (B, 3) + shape).astype(np.float32)
+        gw = rs.normal(0, 1, (B, C) + shape).astype(np.float32)
+        tabs = ro.identity_axis_tables(shape)
+        d = torch.from_numpy(disp).requires_grad_(True)
+        src = torch.from_numpy(img)
+        if use_seg:
+            src = (src + 1) * torch.from_numpy(seg) - 1
+        out = ro.warp(src, d + ro.identity_map(shape), zero_boundary=zb, using_scale=True)
+        out.backward(torch.from_numpy(gw))
+        got = ops_bwd.warp_bwd_disp(T(img, dev), T(disp, dev), [T(t, dev) for t in tabs], None if seg is None else T(seg, dev),
+                                    T(gw, dev), using_scale=True, zero_boundary=zb)
+        np.testing.assert_allclose(got.cpu().numpy(), d.grad.numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_pca_backward_wrt_coefficients(dev):
+    from liftreg_amd import ops_bwd
+    rs = np.random.RandomState(3)
+    for B, L, M in ((8, 56, 3 * 24 ** 3), (3, 5, 4096), (1, 9, 3 * 8 * 8 * 12)):
+        g = rs.normal(0, 1, (B, M)).astype(np.float32)
+        basis = rs.normal(0, 0.02, (L, M)).astype(np.float32)
+        want = g.astype(np.float64) @ basis.astype(np.float64).T
+        got = ops_bwd.pca_bwd_coef(T(g, dev), T(basis, dev)).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+
+
+def test_linear_backward(dev):
+    from liftreg_amd import ops, ops_bwd
+    rs = np.random.RandomState(4)
+    for B, K, O, slope in ((8, 16384, 800, 0.2), (8, 800, 256, 0.2), (5, 256, 56, 1.0), (2, 37, 5, 0.2)):
+        x = rs.uniform(-1, 1, (B, K)).astype(np.float32)
+        w = (rs.normal(0, 1, (O, K)) / np.sqrt(K)).astype(np.float32)
+        b = rs.uniform(-0.1, 0.1, O).astype(np.float32)
+        gy = rs.normal(0, 1, (B, O)).astype(np.float32)
+        xt, wt, bt = (torch.from_numpy(a).requires_grad_(True) for a in (x, w, b))
+        ro.fc_block(xt, wt, bt, None if slope == 1.0 else slope).backward(torch.from_numpy(gy))
+        y = ops.linear_lrelu(T(x, dev), T(w, dev), T(b, dev), slope)
+        gx, gw, gb = ops_bwd.linear_bwd(T(x, dev), T(w, dev), y, T(gy, dev), slope)
+        np.testing.assert_allclose(gx.cpu().numpy(), xt.grad.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(gw.cpu().numpy(), wt.grad.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(gb.cpu().numpy(), bt.grad.numpy(), rtol=1e-4, atol=1e-5)
