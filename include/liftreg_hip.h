@@ -236,6 +236,24 @@ int lr_pca_bwd_coef_f32(const float* gdisp, const float* basis, float* partial, 
  * gx (B,K) and/or (gw (O,K), gb (O)) may be NULL to skip. */
 int lr_linear_bwd_f32(const float* x, const float* w, const float* y, const float* gy, float* gx,
                       float* gw, float* gb, int B, int K, int O, float negative_slope, void* stream);
+/* Backward of lr_conv3d_k3_lrelu_f32 (three steps):
+ *  1. lr_lrelu_bwd_f32: gpre = gy * (y > 0 ? 1 : slope) written as plain NDHWC (B,D,W,H,C), C in {16,32};
+ *     gy / y (the block's saved output) may be in any LR_LAYOUT_*; gb (C) = sum over voxels (optional;
+ *     gb_partial: nblk*C floats of workspace).  D,W,H = the block's OUTPUT size.
+ *  2. lr_conv3d_dgrad_f32 (stride-2 blocks): gx (B,D,W,H,Cx) NDHWC from gpre (B,Do,Wo,Ho,Cg) NDHWC and
+ *     packed_wT = lr_conv3d_pack_weights_f32 of the weight TRANSPOSED to (Cin,Cout,3,3,3), layout NDHWC.
+ *     D,W,H = the block's INPUT size; Cx = Cin in {16,32}.
+ *  3. lr_conv3d_wgrad_f32: gw (Cout,Cin,3,3,3) from the block's saved input x (any layout) and gpre.
+ *     partial: lr_conv3d_wgrad_partial_floats(...) floats of workspace; nblk persistent blocks. */
+int lr_lrelu_bwd_f32(const float* gy, int gy_layout, const float* y, int y_layout, float* gpre,
+                     float* gb_partial, float* gb, int B, int C, int D, int W, int H,
+                     float negative_slope, int nblk, void* stream);
+int lr_conv3d_dgrad_f32(const float* gpre, const float* packed_wT, float* gx, int B, int Cg, int Cx,
+                        int D, int W, int H, int stride, void* stream);
+int64_t lr_conv3d_wgrad_partial_floats(int Cin, int Cout, int x_layout, int nblk);
+int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gpre, float* partial, float* gw,
+                        int B, int Cin, int Cout, int D, int W, int H, int stride, int nblk,
+                        void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,374 @@
+// conv3d_bwd.hip — backward of convBlock (Conv3d k3 p1 + LeakyReLU) for the training step.
+// The reference obtains these from ATen/cuDNN autograd (RegistrationNet.py:401); here:
+//
+//   lr_lrelu_bwd_f32      gpre = gy * (y > 0 ? 1 : slope)  (+ bias gradient), any activation layout -> NDHWC
+//   lr_conv3d_dgrad_f32   data gradient of a stride-2 block (blocks 1..5): parity-class gather on the fp32
+//                         MFMA with the forward kernel's structure (bounds-checked buffer loads, pipelined)
+//   lr_conv3d_wgrad_f32   weight gradient of any block as an MFMA reduction over voxels
+//                         (D[cout][(tap,cin)] += gpre^T · X), persistent blocks + fixed-order reduce
+//
+// Replaces: autograd of src/liftreg/layers/layers.py:365-369 as wired at …Backproj.py:29-33,95-100.
+#include "lr_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOR = 0x80000000u;
+
+// element offset of (b, c, z, y, x) in a tensor of the given layout
+__device__ __forceinline__ int64_t act_off(int layout, int b, int c, int z, int y, int x, int C, int D, int W, int H) {
+  if (layout == LR_LAYOUT_NCDHW) return ((((int64_t)b * C + c) * D + z) * W + y) * H + x;
+  const int64_t row = (((int64_t)b * D + z) * W + y) * H * C;
+  if (layout == LR_LAYOUT_NDHWC) return row + (int64_t)x * C + c;
+  const int hp = (x & 1) * (H >> 1) + (x >> 1);  // LR_LAYOUT_NDHWC_HPS: [C/16][parity][H/2][16]
+  return row + ((int64_t)(c >> 4) * H + hp) * 16 + (c & 15);
+}
+
+// ------------------------------------------------------------------------------------------ LeakyReLU bwd
+// One thread per (voxel, 4 channels) of the NDHWC output; per-block channel sums for the bias gradient.
+__global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict__ gy, int gy_layout,
+                                                        const float* __restrict__ y, int y_layout,
+                                                        float* __restrict__ gpre, float* __restrict__ gb_partial,
+                                                        int B, int C, int D, int W, int H, float slope) {
+  __shared__ float bsum[32];
+  if (threadIdx.x < 32) bsum[threadIdx.x] = 0.0f;
+  __syncthreads();
+  const int C4 = C >> 2;
+  const int64_t total = (int64_t)B * D * W * H * C4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // blockDim (256) is a multiple of C4 (4 | 8): a thread keeps the same channel quad in every iteration
+  const int c0 = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) % C4) * 4;
+  float local[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    int64_t v = idx / C4;
+    const int x = (int)(v % H); v /= H;
+    const int yy = (int)(v % W); v /= W;
+    const int z = (int)(v % D);
+    const int b = (int)(v / D);
+    f32x4 g;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float gv = gy[act_off(gy_layout, b, c0 + r, z, yy, x, C, D, W, H)];
+      const float yv = y[act_off(y_layout, b, c0 + r, z, yy, x, C, D, W, H)];
+      g[r] = yv > 0.0f ? gv : gv * slope;
+      local[r] += g[r];
+    }
+    *reinterpret_cast<f32x4*>(gpre + ((((int64_t)b * D + z) * W + yy) * H + x) * C + c0) = g;
+  }
+  if (gb_partial) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(&bsum[c0 + r], local[r]);  // LDS atomics, <= 32 channels
+    __syncthreads();
+    if (threadIdx.x < C) gb_partial[(int64_t)blockIdx.x * C + threadIdx.x] = bsum[threadIdx.x];
+  }
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                           int nblk, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int k = 0; k < nblk; ++k) s += (double)partial[(int64_t)k * n + i];
+  out[i] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------------ dgrad (stride 2)
+// gx[b, x, ci] = sum_{tap, co} gpre[b, (x + 1 - tap)/2, co] * W[co][ci][tap]   over taps with (x+1-tap) even per axis
+// GEMM view as the forward: rows = ci (the block's input channels, 16|32 -> NT tiles), cols = 16 voxels of gx
+// consecutive along H, k = (tap, co).  Brick per block: 4 planes x 4 rows x 16 voxels of gx.
+struct DgDims {
+  int B, Cg, Cx, D, W, H, Do, Wo, Ho;  // gx is (B,D,W,H,Cx); gpre is (B,Do,Wo,Ho,Cg)
+  int nHq, nWq, nDq;
+};
+constexpr int DMT = 4;
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv3d_dgrad_kernel(const float* __restrict__ gpre,
+                                                           const float4* __restrict__ wp,
+                                                           float* __restrict__ gx, DgDims d) {
+  const unsigned lb = lr_xcd_remap(blockIdx.x, gridDim.x);
+  const int hq = lb % d.nHq, wq = (lb / d.nHq) % d.nWq, dq = (lb / d.nHq / d.nWq) % d.nDq;
+  const int b = lb / d.nHq / d.nWq / d.nDq;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int z = dq * 4 + wave;
+  if (z >= d.D) return;
+  const int y0 = wq * DMT;
+  const int col = lane & 15, kq = lane >> 4;
+  const int x = hq * 16 + col;
+  const int CB = (d.Cg + 15) >> 4;
+
+  f32x4 acc[DMT][NT];
+#pragma unroll
+  for (int mt = 0; mt < DMT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const float* base = gpre + (int64_t)b * d.Do * d.Wo * d.Ho * d.Cg;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, 0x7fffffff, 0x00020000);
+  // per lane: source column offset for each tx (valid when (x+1-tx) is even and in range)
+  unsigned lvoff[3];
+  unsigned xok = 0u;
+#pragma unroll
+  for (int tx = 0; tx < 3; ++tx) {
+    const int t = x + 1 - tx;
+    const bool ok = x < d.H && t >= 0 && !(t & 1) && (t >> 1) < d.Ho;
+    lvoff[tx] = (unsigned)(((ok ? (t >> 1) : 0) * d.Cg + kq * 4) * 4);
+    xok |= ok ? (1u << tx) : 0u;
+  }
+  // per tile (row y0+mt) and per wave (plane z): source row / plane and validity for each ty / tz
+  int srow[DMT][3];
+  unsigned nvmask[DMT];  // bit tap CLEAR = valid
+  int splane[3];
+  unsigned zok = 0u;
+#pragma unroll
+  for (int tz = 0; tz < 3; ++tz) {
+    const int t = z + 1 - tz;
+    const bool ok = t >= 0 && !(t & 1) && (t >> 1) < d.Do;
+    splane[tz] = ok ? (t >> 1) : 0;
+    zok |= ok ? (1u << tz) : 0u;
+  }
+#pragma unroll
+  for (int mt = 0; mt < DMT; ++mt) {
+    unsigned m = 0u;
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+      const int t = y0 + mt + 1 - ty;
+      const bool oky = (y0 + mt < d.W) && t >= 0 && !(t & 1) && (t >> 1) < d.Wo;
+      srow[mt][ty] = oky ? (t >> 1) : 0;
+#pragma unroll
+      for (int tz = 0; tz < 3; ++tz)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx)
+          if (oky && ((zok >> tz) & 1u) && ((xok >> tx) & 1u)) m |= 1u << ((tz * 3 + ty) * 3 + tx);
+    }
+    nvmask[mt] = ~m;
+  }
+
+  const int NS = 27 * CB;
+  auto load_step = [&](int s, float4 (&a)[DMT], float4 (&bw)[NT]) {
+    const int tap = s / CB, cb = s - tap * CB;
+    const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+    const unsigned coor = (cb * 16 + kq * 4 < d.Cg) ? 0u : OOR;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bw[nt] = wp[((int64_t)s * NT + nt) * 64 + lane];
+    const unsigned lv = tx == 0 ? lvoff[0] : (tx == 1 ? lvoff[1] : lvoff[2]);
+#pragma unroll
+    for (int mt = 0; mt < DMT; ++mt) {
+      const int sr = ty == 0 ? srow[mt][0] : (ty == 1 ? srow[mt][1] : srow[mt][2]);
+      const int sp = tz == 0 ? splane[0] : (tz == 1 ? splane[1] : splane[2]);  // no dynamic register indexing
+      const unsigned soff = (unsigned)((((sp * d.Wo) + sr) * d.Ho * d.Cg + cb * 16) * 4);
+      const unsigned voff = lv | coor | ((nvmask[mt] >> tap) << 31);
+      a[mt] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+    }
+  };
+  auto mfma_step = [&](const float4 (&a)[DMT], const float4 (&bw)[NT]) {
+#pragma unroll
+    for (int mt = 0; mt < DMT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[nt].x, a[mt].x, acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[nt].y, a[mt].y, acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[nt].z, a[mt].z, acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[nt].w, a[mt].w, acc[mt][nt], 0, 0, 0);
+      }
+  };
+  float4 a0[DMT], a1[DMT], b0[NT], b1[NT];
+  load_step(0, a0, b0);
+  for (int s = 0; s + 1 < NS; s += 2) {
+    load_step(s + 1, a1, b1);
+    mfma_step(a0, b0);
+    load_step(min(s + 2, NS - 1), a0, b0);
+    mfma_step(a1, b1);
+  }
+  if (NS & 1) mfma_step(a0, b0);
+  if (x < d.H) {
+#pragma unroll
+    for (int mt = 0; mt < DMT; ++mt)
+      if (y0 + mt < d.W)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          *reinterpret_cast<f32x4*>(gx + ((((int64_t)b * d.D + z) * d.W + y0 + mt) * d.H + x) * d.Cx + nt * 16 + kq * 4) =
+              acc[mt][nt];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+// gw[co][ci][tap] = sum_{b, o} gpre[b, o, co] * X[b, ci, s*o + tap - 1]
+// MFMA: rows = co (NTC tiles of 16), cols = 16 "columns" n of an N-tile, k = 4 consecutive output voxels
+// along Ho.  Column n of N-tile j stands for one (tap, ci): channels-last X: j = (tap, 16-channel block),
+// n = ci in the block; planar X: j*16+n = ci*27 + tap.  Each lane carries, per N-tile it owns, the packed
+// descriptor of its column (channel offset and tap); the 4 waves of a block split the N-tiles.
+struct WgDims {
+  int B, Cin, Cout, D, W, H, Do, Wo, Ho, stride, x_layout;
+  int ntiles;  // N-tiles in total
+};
+constexpr int WG_MAXT = 14;  // N-tiles per wave (27 taps * 2 channel blocks / 4 waves, rounded up)
+
+template <int NTC>
+__global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restrict__ xin,
+                                                           const float* __restrict__ gpre,
+                                                           float* __restrict__ partial, WgDims d, int64_t ngroups) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 15, kq = lane >> 4;
+  // this lane's column descriptor for each N-tile of the wave
+  int64_t coff[WG_MAXT];
+  int ctap[WG_MAXT];  // tz | ty<<2 | tx<<4 | valid<<6
+  const int64_t V = (int64_t)d.D * d.W * d.H;
+#pragma unroll
+  for (int t = 0; t < WG_MAXT; ++t) {
+    const int j = wave + 4 * t;
+    int tap = 0, ci = 0;
+    bool ok = j < d.ntiles;
+    if (d.x_layout == LR_LAYOUT_NCDHW) {
+      const int n = j * 16 + col;
+      ci = n / 27; tap = n - ci * 27;
+      ok = ok && ci < d.Cin;
+    } else {
+      const int cbn = (d.Cin + 15) >> 4;
+      tap = j / cbn;
+      ci = (j - tap * cbn) * 16 + col;
+      ok = ok && ci < d.Cin && tap < 27;
+    }
+    ctap[t] = (tap / 9) | (((tap / 3) % 3) << 2) | ((tap % 3) << 4) | (ok ? 64 : 0);
+    if (d.x_layout == LR_LAYOUT_NCDHW) coff[t] = (int64_t)ci * V;
+    else if (d.x_layout == LR_LAYOUT_NDHWC) coff[t] = ci;
+    else coff[t] = (int64_t)(ci >> 4) * d.H * 16 + (ci & 15);  // HPS: channel block offset inside a row
+  }
+  f32x4 acc[WG_MAXT][NTC];
+#pragma unroll
+  for (int t = 0; t < WG_MAXT; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int hog = (d.Ho + 3) >> 2;  // groups of 4 output voxels per row
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    int64_t r = grp;
+    const int hg = (int)(r % hog); r /= hog;
+    const int wo = (int)(r % d.Wo); r /= d.Wo;
+    const int dz = (int)(r % d.Do);
+    const int b = (int)(r / d.Do);
+    const int ho = hg * 4 + kq;
+    const bool vok = ho < d.Ho;
+    // A operand: gpre[b, dz, wo, ho, co]
+    float a[NTC];
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt)
+      a[nt] = vok ? gpre[((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + ho) * d.Cout + nt * 16 + col] : 0.0f;
+    const int zi0 = dz * d.stride - 1, yi0 = wo * d.stride - 1, xi0 = ho * d.stride - 1;
+    const int64_t xb = (int64_t)b * d.Cin * V;
+#pragma unroll
+    for (int t = 0; t < WG_MAXT; ++t) {
+      if (wave + 4 * t >= d.ntiles) break;  // wave-uniform: this wave owns no further N-tile
+      const int zi = zi0 + (ctap[t] & 3), yi = yi0 + ((ctap[t] >> 2) & 3), xi = xi0 + ((ctap[t] >> 4) & 3);
+      const bool ok = vok && (ctap[t] & 64) && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W && xi >= 0 && xi < d.H;
+      int64_t off;
+      if (d.x_layout == LR_LAYOUT_NCDHW) off = xb + coff[t] + ((int64_t)zi * d.W + yi) * d.H + xi;
+      else if (d.x_layout == LR_LAYOUT_NDHWC) off = xb + (((int64_t)zi * d.W + yi) * d.H + xi) * d.Cin + coff[t];
+      else off = xb + ((int64_t)zi * d.W + yi) * d.H * d.Cin + coff[t] + (int64_t)((xi & 1) * (d.H >> 1) + (xi >> 1)) * 16;
+      const float xv = ok ? xin[off] : 0.0f;
+#pragma unroll
+      for (int nt = 0; nt < NTC; ++nt)
+        acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nt], xv, acc[t][nt], 0, 0, 0);
+    }
+  }
+  // partial[block][co][n]: lane holds co = nt*16 + kq*4 + r of column (j*16 + col)
+  const int ncols = d.ntiles * 16;
+#pragma unroll
+  for (int t = 0; t < WG_MAXT; ++t) {
+    const int j = wave + 4 * t;
+    if (j < d.ntiles) {
+#pragma unroll
+      for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          partial[((int64_t)blockIdx.x * d.Cout + nt * 16 + kq * 4 + r) * ncols + j * 16 + col] = acc[t][nt][r];
+    }
+  }
+}
+
+// columns -> (Cout, Cin, 27) weight layout
+__global__ void wgrad_finish_kernel(const float* __restrict__ partial, float* __restrict__ gw, int nblk, int Cout,
+                                    int Cin, int ncols, int x_layout) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Cout * Cin * 27) return;
+  const int tap = idx % 27, ci = (idx / 27) % Cin, co = idx / 27 / Cin;
+  const int cbn = (Cin + 15) >> 4;
+  const int n = x_layout == LR_LAYOUT_NCDHW ? ci * 27 + tap : (tap * cbn + (ci >> 4)) * 16 + (ci & 15);
+  double s = 0.0;
+  for (int k = 0; k < nblk; ++k) s += (double)partial[((int64_t)k * Cout + co) * ncols + n];
+  gw[idx] = (float)s;
+}
+
+}  // namespace
+
+extern "C" int lr_lrelu_bwd_f32(const float* gy, int gy_layout, const float* y, int y_layout, float* gpre,
+                                float* gb_partial, float* gb, int B, int C, int D, int W, int H,
+                                float negative_slope, int nblk, void* stream) {
+  if (!gy || !y || !gpre) return LR_ENULL;
+  if (B < 1 || D < 1 || W < 1 || H < 1 || nblk < 1 || nblk > 65535) return LR_EINVAL;
+  if (C != 16 && C != 32) return LR_EUNSUPPORTED;
+  if ((gy_layout == LR_LAYOUT_NDHWC_HPS || y_layout == LR_LAYOUT_NDHWC_HPS) && (H & 1)) return LR_EUNSUPPORTED;
+  if ((gb != nullptr) != (gb_partial != nullptr)) return LR_ENULL;
+  hipStream_t st = lr_stream(stream);
+  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, st, gy, gy_layout, y, y_layout, gpre,
+                     gb_partial, B, C, D, W, H, negative_slope);
+  if (int e = lr_launch_status()) return e;
+  if (gb) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, gb_partial, gb, nblk, C);
+    return lr_launch_status();
+  }
+  return LR_OK;
+}
+
+extern "C" int lr_conv3d_dgrad_f32(const float* gpre, const float* packed_wT, float* gx, int B, int Cg, int Cx,
+                                   int D, int W, int H, int stride, void* stream) {
+  if (!gpre || !packed_wT || !gx) return LR_ENULL;
+  if (stride != 2) return LR_EUNSUPPORTED;  // blocks 1..5; block 0's input needs no gradient
+  if (Cx != 16 && Cx != 32) return LR_EUNSUPPORTED;
+  if (Cg % 4 || B < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(gpre) | reinterpret_cast<uintptr_t>(gx)) & 15u) return LR_EALIGN;
+  DgDims d;
+  d.B = B; d.Cg = Cg; d.Cx = Cx; d.D = D; d.W = W; d.H = H;
+  d.Do = (D - 1) / 2 + 1; d.Wo = (W - 1) / 2 + 1; d.Ho = (H - 1) / 2 + 1;
+  if ((int64_t)d.Do * d.Wo * d.Ho * Cg * 4 >= 0x7fffffffLL) return LR_EINVAL;  // 31-bit buffer offsets per batch element
+  d.nHq = (H + 15) / 16; d.nWq = (W + DMT - 1) / DMT; d.nDq = (D + 3) / 4;
+  const int64_t nblk = (int64_t)B * d.nDq * d.nWq * d.nHq;
+  if (nblk > 0x7fffffffLL) return LR_EINVAL;
+  const float4* wt = reinterpret_cast<const float4*>(packed_wT);
+  hipStream_t st = lr_stream(stream);
+  if (Cx == 16) hipLaunchKernelGGL(conv3d_dgrad_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, gpre, wt, gx, d);
+  else hipLaunchKernelGGL(conv3d_dgrad_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, gpre, wt, gx, d);
+  return lr_launch_status();
+}
+
+extern "C" int64_t lr_conv3d_wgrad_partial_floats(int Cin, int Cout, int x_layout, int nblk) {
+  const int ntiles = x_layout == LR_LAYOUT_NCDHW ? (Cin * 27 + 15) / 16 : 27 * ((Cin + 15) / 16);
+  return (int64_t)nblk * Cout * ntiles * 16;
+}
+
+extern "C" int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gpre, float* partial, float* gw,
+                                   int B, int Cin, int Cout, int D, int W, int H, int stride, int nblk,
+                                   void* stream) {
+  if (!x || !gpre || !partial || !gw) return LR_ENULL;
+  if (B < 1 || Cin < 1 || D < 1 || W < 1 || H < 1 || nblk < 1 || nblk > 65535) return LR_EINVAL;
+  if ((stride != 1 && stride != 2) || (Cout != 16 && Cout != 32)) return LR_EUNSUPPORTED;
+  if (x_layout == LR_LAYOUT_NDHWC_HPS && ((H & 1) || (Cin & 15))) return LR_EUNSUPPORTED;
+  WgDims d;
+  d.B = B; d.Cin = Cin; d.Cout = Cout; d.D = D; d.W = W; d.H = H; d.stride = stride; d.x_layout = x_layout;
+  d.Do = (D - 1) / stride + 1; d.Wo = (W - 1) / stride + 1; d.Ho = (H - 1) / stride + 1;
+  d.ntiles = x_layout == LR_LAYOUT_NCDHW ? (Cin * 27 + 15) / 16 : 27 * ((Cin + 15) / 16);
+  if (d.ntiles > 4 * WG_MAXT) return LR_EUNSUPPORTED;  // Cin <= 32 channels-last, <= 33 planar
+  const int64_t ngroups = (int64_t)B * d.Do * d.Wo * ((d.Ho + 3) / 4);
+  hipStream_t st = lr_stream(stream);
+  if (Cout == 16) hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, x, gpre, partial, d, ngroups);
+  else hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, x, gpre, partial, d, ngroups);
+  if (int e = lr_launch_status()) return e;
+  const int n = Cout * Cin * 27;
+  hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partial, gw, nblk, Cout, Cin,
+                     d.ntiles * 16, x_layout);
+  return lr_launch_status();
+}

@@ -60,6 +60,58 @@ def pca_bwd_coef(gdisp, basis_LxM, nblk=None):
     return gcoefs
 
 
+def _act_dims(t, layout):
+    """(B, C, D, W, H) of an activation tensor stored in `layout`."""
+    if layout == _hip.LAYOUT_NCDHW:
+        B, C, D, W, H = t.shape
+    else:
+        B, D, W, H, C = t.shape
+    return B, C, D, W, H
+
+
+def conv3d_bwd(x, x_layout, weight, y, y_layout, gy, gy_layout, stride, negative_slope=0.2, need_gx=True,
+               nblk=512):
+    """Backward of ops.conv3d_k3_lrelu.  x / y: the block's saved input / output (any layout), gy: gradient of
+    the output.  Returns (gx NDHWC (B,D,W,H,Cin) or None, gw (Cout,Cin,3,3,3), gb (Cout))."""
+    x, y, gy = _dev(x, "x"), _dev(y, "y"), _dev(gy, "gy")
+    w = _dev(weight.detach(), "weight")
+    Cout, Cin = w.shape[0], w.shape[1]
+    B, Cx, D, W, H = _act_dims(x, x_layout)
+    _, Cy, Do, Wo, Ho = _act_dims(y, y_layout)
+    if Cx != Cin or Cy != Cout or _act_dims(gy, gy_layout) != (B, Cout, Do, Wo, Ho):
+        raise ValueError("conv3d_bwd: shape mismatch")
+    dev = x.device
+    lib = _hip.lib()
+    # 1. LeakyReLU mask (+ bias gradient) → gpre, plain NDHWC
+    gpre = torch.empty((B, Do, Wo, Ho, Cout), dtype=torch.float32, device=dev)
+    nb1 = max(1, min(1024, (gpre.numel() // 4 + 255) // 256))
+    gb_part = torch.empty((nb1, Cout), dtype=torch.float32, device=dev)
+    gb = torch.empty((Cout,), dtype=torch.float32, device=dev)
+    with _timed(f"lrelu_bwd_c{Cout}_{Do}", bytes=12 * gpre.numel()):
+        _hip.check(lib.lr_lrelu_bwd_f32(gy.data_ptr(), gy_layout, y.data_ptr(), y_layout, gpre.data_ptr(),
+                                        gb_part.data_ptr(), gb.data_ptr(), B, Cout, Do, Wo, Ho, float(negative_slope),
+                                        nb1, _stream()), "lr_lrelu_bwd_f32")
+    # 2. data gradient (stride-2 blocks only; the encoder's first block has no input gradient)
+    gx = None
+    if need_gx:
+        from .ops import conv3d_pack_weights
+        packed_t = conv3d_pack_weights(w.transpose(0, 1).contiguous(), _hip.LAYOUT_NDHWC)
+        gx = torch.empty((B, D, W, H, Cin), dtype=torch.float32, device=dev)
+        with _timed(f"conv3d_dgrad_c{Cout}x{Cin}_{D}", flops=2.0 * 27 * Cin * Cout * B * Do * Wo * Ho,
+                    bytes=4 * (gpre.numel() + gx.numel())):
+            _hip.check(lib.lr_conv3d_dgrad_f32(gpre.data_ptr(), packed_t.data_ptr(), gx.data_ptr(), B, Cout, Cin, D, W,
+                                               H, stride, _stream()), "lr_conv3d_dgrad_f32")
+    # 3. weight gradient
+    npart = lib.lr_conv3d_wgrad_partial_floats(Cin, Cout, x_layout, nblk)
+    partial = torch.empty((npart,), dtype=torch.float32, device=dev)
+    gw = torch.empty_like(w)
+    with _timed(f"conv3d_wgrad_c{Cin}x{Cout}_{D}", flops=2.0 * 27 * Cin * Cout * B * Do * Wo * Ho,
+                bytes=4 * (x.numel() + gpre.numel())):
+        _hip.check(lib.lr_conv3d_wgrad_f32(x.data_ptr(), x_layout, gpre.data_ptr(), partial.data_ptr(), gw.data_ptr(),
+                                           B, Cin, Cout, D, W, H, stride, nblk, _stream()), "lr_conv3d_wgrad_f32")
+    return gx, gw, gb
+
+
 def linear_bwd(x, weight, y, gy, negative_slope=1.0, need_gx=True):
     """Backward of ops.linear_lrelu: returns (gx or None, gw, gb)."""
     x, y, gy = _dev(x, "x"), _dev(y, "y"), _dev(gy, "gy")

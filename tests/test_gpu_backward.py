@@ -80,3 +80,49 @@ def test_linear_backward(dev):
         np.testing.assert_allclose(gx.cpu().numpy(), xt.grad.numpy(), rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(gw.cpu().numpy(), wt.grad.numpy(), rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(gb.cpu().numpy(), bt.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_conv_block_backward_all_layouts(dev):
+    """dgrad (stride-2 blocks), wgrad and bias gradient of convBlock against torch autograd, for every
+    activation layout the encoder uses (planar first block; NDHWC / parity-split in between; NCDHW at the end)."""
+    from liftreg_amd import ops, ops_bwd
+    rs = np.random.RandomState(6)
+    L = ops
+    cases = [  # cin, cout, stride, shape, B, x_layout, y_layout, gy_layout
+        (3, 16, 1, (6, 7, 20), 2, L.LAYOUT_NCDHW, L.LAYOUT_NDHWC_HPS, L.LAYOUT_NDHWC),
+        (5, 16, 1, (5, 6, 9), 1, L.LAYOUT_NCDHW, L.LAYOUT_NDHWC, L.LAYOUT_NDHWC),
+        (16, 32, 2, (8, 10, 20), 2, L.LAYOUT_NDHWC_HPS, L.LAYOUT_NDHWC_HPS, L.LAYOUT_NDHWC),
+        (16, 32, 2, (7, 9, 11), 1, L.LAYOUT_NDHWC, L.LAYOUT_NDHWC, L.LAYOUT_NDHWC),
+        (32, 32, 2, (8, 8, 16), 2, L.LAYOUT_NDHWC_HPS, L.LAYOUT_NCDHW, L.LAYOUT_NCDHW),
+        (32, 32, 2, (4, 6, 6), 3, L.LAYOUT_NDHWC, L.LAYOUT_NDHWC, L.LAYOUT_NDHWC),
+    ]
+
+    def to_layout(t_ncdhw, lay):
+        if lay == L.LAYOUT_NCDHW:
+            return t_ncdhw.contiguous()
+        cl = t_ncdhw.permute(0, 2, 3, 4, 1).contiguous()
+        if lay == L.LAYOUT_NDHWC_HPS:
+            B, D, W, H, C = cl.shape
+            h = torch.arange(H, device=cl.device)
+            inv = torch.empty(H, dtype=torch.long, device=cl.device)
+            inv[(h & 1) * (H // 2) + (h >> 1)] = h
+            cl = cl.reshape(B, D, W, H, C // 16, 16)[:, :, :, inv].permute(0, 1, 2, 4, 3, 5).reshape(B, D, W, H, C).contiguous()
+        return cl
+
+    for cin, cout, s, shape, B, xl, yl, gl in cases:
+        x = rs.uniform(-1, 1, (B, cin) + shape).astype(np.float32)
+        w = (rs.normal(0, 1, (cout, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32)
+        b = rs.uniform(-0.1, 0.1, cout).astype(np.float32)
+        xt, wt, bt = (torch.from_numpy(a).requires_grad_(True) for a in (x, w, b))
+        yref = ro.conv_block(xt, wt, bt, s)
+        gy = rs.normal(0, 1, tuple(yref.shape)).astype(np.float32)
+        yref.backward(torch.from_numpy(gy))
+        xd = to_layout(T(x, dev), xl)
+        yd = ops.conv3d_k3_lrelu(xd, T(w, dev), T(b, dev), s, in_layout=xl, out_layout=yl)
+        gx, gw, gb = ops_bwd.conv3d_bwd(xd, xl, T(w, dev), yd, yl, to_layout(T(gy, dev), gl), gl, s, need_gx=(s == 2), nblk=8)
+        tag = str((cin, cout, s, shape))
+        np.testing.assert_allclose(gw.cpu().numpy(), wt.grad.numpy(), rtol=2e-4, atol=2e-5, err_msg="gw " + tag)
+        np.testing.assert_allclose(gb.cpu().numpy(), bt.grad.numpy(), rtol=2e-4, atol=2e-5, err_msg="gb " + tag)
+        if s == 2:
+            np.testing.assert_allclose(gx.permute(0, 4, 1, 2, 3).cpu().numpy(), xt.grad.numpy(), rtol=2e-4, atol=2e-5,
+                                       err_msg="gx " + tag)
