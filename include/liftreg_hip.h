@@ -249,7 +249,10 @@ int lr_lrelu_bwd_f32(const float* gy, int gy_layout, const float* y, int y_layou
                      float* gb_partial, float* gb, int B, int C, int D, int W, int H,
                      float negative_slope, int nblk, void* stream);
 int lr_conv3d_dgrad_f32(const float* gpre, const float* packed_wT, float* gx, int B, int Cg, int Cx,
-                        int D, int W, int H, int stride, void* stream);
+                        int D, int W, int H, int stride, int gx_layout /* NDHWC | NDHWC_HPS */, void* stream);
+/* Gradient of lr_disp_reg_f32 w.r.t. disp (gout = dev pointer to the upstream scalar gradient). */
+int lr_disp_reg_bwd_f32(const float* disp, const float* gout, float* gdisp, int B, int D, int W, int H,
+                        void* stream);
 int64_t lr_conv3d_wgrad_partial_floats(int Cin, int Cout, int x_layout, int nblk);
 int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gpre, float* partial, float* gw,
                         int B, int Cin, int Cout, int D, int W, int H, int stride, int nblk,

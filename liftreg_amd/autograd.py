@@ -1,0 +1,117 @@
+"""torch.autograd.Function wrappers: forward and backward both run on the HIP kernels
+(liftreg_amd.ops / liftreg_amd.ops_bwd), so the reference's training step
+(RegistrationNet.py:389-406: model(input) → loss(output) → total_loss.backward() → optimizer.step())
+works unchanged on this package.  Autograd itself is PyTorch plumbing; no ATen compute kernel is used
+for any op on the path.
+"""
+import torch
+
+from . import _hip, ops, ops_bwd
+
+
+class ConvBlockFn(torch.autograd.Function):
+    """LeakyReLU(Conv3d k3 p1 (x) + b) in any of the activation layouts."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, in_layout, out_layout, slope, packed):
+        y = ops.conv3d_k3_lrelu(x, weight, bias, stride, in_layout=in_layout, out_layout=out_layout,
+                                negative_slope=slope, packed=packed)
+        ctx.save_for_backward(x, weight, y)
+        ctx.cfg = (stride, in_layout, out_layout, slope, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        stride, in_layout, out_layout, slope, has_bias = ctx.cfg
+        need_gx = ctx.needs_input_grad[0]
+        if need_gx and (in_layout == _hip.LAYOUT_NCDHW or stride != 2):
+            raise NotImplementedError("data gradient is built for the channels-last stride-2 blocks only "
+                                      "(the encoder's first block receives data, not activations)")
+        gx, gw, gb = ops_bwd.conv3d_bwd(x, in_layout, weight, y, out_layout, gy.contiguous(), out_layout, stride,
+                                        slope, need_gx=need_gx)
+        return gx, gw, (gb if has_bias else None), None, None, None, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, slope):
+        y = ops.linear_lrelu(x, weight, bias, slope)
+        ctx.save_for_backward(x, weight, y)
+        ctx.cfg = (slope, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        slope, has_bias = ctx.cfg
+        gx, gw, gb = ops_bwd.linear_bwd(x, weight, y, gy.contiguous(), slope, need_gx=ctx.needs_input_grad[0])
+        return gx, gw, (gb if has_bias else None), None
+
+
+class PCAFn(torch.autograd.Function):
+    """disp = coefs @ basis + mean; only the coefficients receive a gradient (the basis is data)."""
+
+    @staticmethod
+    def forward(ctx, coefs, basis_LxM, mean):
+        ctx.save_for_backward(basis_LxM)
+        return ops.pca_reconstruct(coefs, basis_LxM, mean)
+
+    @staticmethod
+    def backward(ctx, gdisp):
+        (basis,) = ctx.saved_tensors
+        return ops_bwd.pca_bwd_coef(gdisp.contiguous(), basis), None, None
+
+
+class WarpFn(torch.autograd.Function):
+    """(phi, warped) = warp(img, disp): gradient w.r.t. disp only (phi = disp + id passes its gradient through)."""
+
+    @staticmethod
+    def forward(ctx, img, disp, id0, id1, id2, seg, using_scale, zero_boundary):
+        phi, warped = ops.warp(img, disp, (id0, id1, id2), seg, using_scale=using_scale, zero_boundary=zero_boundary)
+        ctx.save_for_backward(img, disp, id0, id1, id2, seg if seg is not None else img.new_empty(0))
+        ctx.cfg = (using_scale, zero_boundary, seg is not None)
+        ctx.set_materialize_grads(False)
+        return phi, warped
+
+    @staticmethod
+    def backward(ctx, gphi, gwarped):
+        img, disp, id0, id1, id2, seg = ctx.saved_tensors
+        using_scale, zero_boundary, has_seg = ctx.cfg
+        g = None
+        if gwarped is not None:
+            g = ops_bwd.warp_bwd_disp(img, disp, (id0, id1, id2), seg if has_seg else None, gwarped.contiguous(),
+                                      using_scale=using_scale, zero_boundary=zero_boundary)
+        if gphi is not None:
+            g = gphi if g is None else g + gphi
+        return None, g, None, None, None, None, None, None
+
+
+class NCCFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, variant):
+        n_batch = x.shape[0]
+        rows = n_batch if variant == _hip.NCC_CONFIGURED else n_batch * x.shape[1]
+        m = ops.ncc_moments(x, y, rows)
+        loss, _ = ops.ncc_loss_from_moments(m, x.numel() // rows, n_batch, variant)
+        ctx.save_for_backward(x, y, m)
+        ctx.cfg = (variant, x.numel() // rows)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, y, m = ctx.saved_tensors
+        variant, n = ctx.cfg
+        return ops_bwd.ncc_bwd(x.contiguous(), y.contiguous(), m, gout, n, variant).view_as(x), None, None
+
+
+class DispRegFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp):
+        ctx.save_for_backward(disp)
+        return ops.disp_reg(disp)
+
+    @staticmethod
+    def backward(ctx, gout):
+        (disp,) = ctx.saved_tensors
+        return ops_bwd.disp_reg_bwd(disp.contiguous(), gout)

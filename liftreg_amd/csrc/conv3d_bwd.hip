@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 struct DgDims {
   int B, Cg, Cx, D, W, H, Do, Wo, Ho;  // gx is (B,D,W,H,Cx); gpre is (B,Do,Wo,Ho,Cg)
   int nHq, nWq, nDq;
+  int gx_layout;  // LR_LAYOUT_NDHWC or LR_LAYOUT_NDHWC_HPS (the layout of the block's saved input)
 };
 constexpr int DMT = 4;
 
@@ -190,8 +191,13 @@ __global__ __launch_bounds__(256) void conv3d_dgrad_kernel(const float* __restri
       if (y0 + mt < d.W)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          *reinterpret_cast<f32x4*>(gx + ((((int64_t)b * d.D + z) * d.W + y0 + mt) * d.H + x) * d.Cx + nt * 16 + kq * 4) =
-              acc[mt][nt];
+        {
+          const int64_t row = (((int64_t)b * d.D + z) * d.W + y0 + mt) * d.H * d.Cx;
+          const int64_t o = d.gx_layout == LR_LAYOUT_NDHWC
+                                ? row + (int64_t)x * d.Cx + nt * 16 + kq * 4
+                                : row + ((int64_t)nt * d.H + ((x & 1) * (d.H >> 1) + (x >> 1))) * 16 + kq * 4;
+          *reinterpret_cast<f32x4*>(gx + o) = acc[mt][nt];
+        }
   }
 }
 
@@ -325,17 +331,20 @@ extern "C" int lr_lrelu_bwd_f32(const float* gy, int gy_layout, const float* y, 
 }
 
 extern "C" int lr_conv3d_dgrad_f32(const float* gpre, const float* packed_wT, float* gx, int B, int Cg, int Cx,
-                                   int D, int W, int H, int stride, void* stream) {
+                                   int D, int W, int H, int stride, int gx_layout, void* stream) {
   if (!gpre || !packed_wT || !gx) return LR_ENULL;
   if (stride != 2) return LR_EUNSUPPORTED;  // blocks 1..5; block 0's input needs no gradient
   if (Cx != 16 && Cx != 32) return LR_EUNSUPPORTED;
   if (Cg % 4 || B < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
+  if (gx_layout != LR_LAYOUT_NDHWC && gx_layout != LR_LAYOUT_NDHWC_HPS) return LR_EINVAL;
+  if (gx_layout == LR_LAYOUT_NDHWC_HPS && (H & 1)) return LR_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(gpre) | reinterpret_cast<uintptr_t>(gx)) & 15u) return LR_EALIGN;
   DgDims d;
   d.B = B; d.Cg = Cg; d.Cx = Cx; d.D = D; d.W = W; d.H = H;
   d.Do = (D - 1) / 2 + 1; d.Wo = (W - 1) / 2 + 1; d.Ho = (H - 1) / 2 + 1;
   if ((int64_t)d.Do * d.Wo * d.Ho * Cg * 4 >= 0x7fffffffLL) return LR_EINVAL;  // 31-bit buffer offsets per batch element
   d.nHq = (H + 15) / 16; d.nWq = (W + DMT - 1) / DMT; d.nDq = (D + 3) / 4;
+  d.gx_layout = gx_layout;
   const int64_t nblk = (int64_t)B * d.nDq * d.nWq * d.nHq;
   if (nblk > 0x7fffffffLL) return LR_EINVAL;
   const float4* wt = reinterpret_cast<const float4*>(packed_wT);

@@ -72,7 +72,7 @@ def _act_dims(t, layout):
 def conv3d_bwd(x, x_layout, weight, y, y_layout, gy, gy_layout, stride, negative_slope=0.2, need_gx=True,
                nblk=512):
     """Backward of ops.conv3d_k3_lrelu.  x / y: the block's saved input / output (any layout), gy: gradient of
-    the output.  Returns (gx NDHWC (B,D,W,H,Cin) or None, gw (Cout,Cin,3,3,3), gb (Cout))."""
+    the output.  Returns (gx (B,D,W,H,Cin) in x's own channels-last layout or None, gw (Cout,Cin,3,3,3), gb (Cout))."""
     x, y, gy = _dev(x, "x"), _dev(y, "y"), _dev(gy, "gy")
     w = _dev(weight.detach(), "weight")
     Cout, Cin = w.shape[0], w.shape[1]
@@ -99,8 +99,9 @@ def conv3d_bwd(x, x_layout, weight, y, y_layout, gy, gy_layout, stride, negative
         gx = torch.empty((B, D, W, H, Cin), dtype=torch.float32, device=dev)
         with _timed(f"conv3d_dgrad_c{Cout}x{Cin}_{D}", flops=2.0 * 27 * Cin * Cout * B * Do * Wo * Ho,
                     bytes=4 * (gpre.numel() + gx.numel())):
+            gxl = x_layout if x_layout != _hip.LAYOUT_NCDHW else _hip.LAYOUT_NDHWC   # grad in the layout of x itself
             _hip.check(lib.lr_conv3d_dgrad_f32(gpre.data_ptr(), packed_t.data_ptr(), gx.data_ptr(), B, Cout, Cin, D, W,
-                                               H, stride, _stream()), "lr_conv3d_dgrad_f32")
+                                               H, stride, gxl, _stream()), "lr_conv3d_dgrad_f32")
     # 3. weight gradient
     npart = lib.lr_conv3d_wgrad_partial_floats(Cin, Cout, x_layout, nblk)
     partial = torch.empty((npart,), dtype=torch.float32, device=dev)
@@ -126,3 +127,15 @@ def linear_bwd(x, weight, y, gy, negative_slope=1.0, need_gx=True):
                                                 gw.data_ptr(), gb.data_ptr(), B, K, O, float(negative_slope), _stream()),
                    "lr_linear_bwd_f32")
     return gx, gw, gb
+
+
+def disp_reg_bwd(disp, gout):
+    """Gradient of ops.disp_reg w.r.t. disp (same assumed mermaid stencil; parity unpinned)."""
+    disp = _dev(disp, "disp")
+    gout = _dev(gout.reshape(()).to(torch.float32), "gout")
+    B, _, D, W, H = disp.shape
+    g = torch.empty_like(disp)
+    with _timed("disp_reg_bwd", bytes=8 * disp.numel()):
+        _hip.check(_hip.lib().lr_disp_reg_bwd_f32(disp.data_ptr(), gout.data_ptr(), g.data_ptr(), B, D, W, H, _stream()),
+                   "lr_disp_reg_bwd_f32")
+    return g

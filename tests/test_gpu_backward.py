@@ -124,5 +124,17 @@ def test_conv_block_backward_all_layouts(dev):
         np.testing.assert_allclose(gw.cpu().numpy(), wt.grad.numpy(), rtol=2e-4, atol=2e-5, err_msg="gw " + tag)
         np.testing.assert_allclose(gb.cpu().numpy(), bt.grad.numpy(), rtol=2e-4, atol=2e-5, err_msg="gb " + tag)
         if s == 2:
-            np.testing.assert_allclose(gx.permute(0, 4, 1, 2, 3).cpu().numpy(), xt.grad.numpy(), rtol=2e-4, atol=2e-5,
+            gx_plain = ops.hps_to_ndhwc(gx) if xl == L.LAYOUT_NDHWC_HPS else gx        # grad comes in x's own layout
+            np.testing.assert_allclose(gx_plain.permute(0, 4, 1, 2, 3).cpu().numpy(), xt.grad.numpy(), rtol=2e-4, atol=2e-5,
                                        err_msg="gx " + tag)
+
+
+def test_disp_reg_backward(dev):
+    from liftreg_amd import ops_bwd
+    rs = np.random.RandomState(7)
+    for shape, B in (((6, 7, 9), 2), ((2, 3, 2), 1), ((12, 5, 8), 1)):
+        disp = rs.normal(0, 0.1, (B, 3) + shape).astype(np.float32)
+        d = torch.from_numpy(disp).requires_grad_(True)
+        (ro.disp_reg(d) * 0.3).backward()
+        got = ops_bwd.disp_reg_bwd(T(disp, dev), torch.tensor(0.3, device=dev))
+        np.testing.assert_allclose(got.cpu().numpy(), d.grad.numpy(), rtol=1e-4, atol=1e-7)
