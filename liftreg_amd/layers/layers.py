@@ -1,7 +1,7 @@
 """Network building blocks used by the configured model, with the reference's class names,
 constructor arguments and state-dict keys (src/liftreg/layers/layers.py), running on the
-HIP kernels.  Forward only in this round: the training backward kernels are a "next" row
-(DESIGN.md), so a call that needs autograd raises instead of silently using another backend."""
+HIP kernels, forward and backward (liftreg_amd.autograd): `loss.backward()` of the reference's training
+step reaches the parameters through the HIP backward kernels, never through another backend."""
 import math
 import numbers
 
@@ -9,14 +9,8 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..autograd import ConvBlockFn, LinearFn, NCCFn
 from .._hip import NCC_SQUARED
-
-
-def _no_autograd(*tensors):
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        raise NotImplementedError(
-            "liftreg_amd: backward kernels are not built yet (forward/inference path only); "
-            "call under torch.no_grad()")
 
 
 class convBlock(nn.Module):
@@ -45,10 +39,9 @@ class convBlock(nn.Module):
         else:
             raise NotImplementedError("fused epilogue supports LeakyReLU or None")
 
-    def forward(self, x):
-        _no_autograd(x, self.conv.weight)
-        return ops.conv3d_k3_lrelu(x, self.conv.weight, self.conv.bias, self.stride, in_layout=self.in_layout,
-                                   out_layout=self.out_layout, negative_slope=self._slope)
+    def forward(self, x, packed=None):
+        return ConvBlockFn.apply(x, self.conv.weight, self.conv.bias, self.stride, self.in_layout, self.out_layout,
+                                 self._slope, packed)
 
 
 class FullyConnectBlock(nn.Module):
@@ -66,16 +59,14 @@ class FullyConnectBlock(nn.Module):
             raise NotImplementedError("fused epilogue supports LeakyReLU or None")
 
     def forward(self, x):
-        _no_autograd(x, self.fc.weight)
-        return ops.linear_lrelu(x, self.fc.weight, self.fc.bias, self._slope)
+        return LinearFn.apply(x, self.fc.weight, self.fc.bias, self._slope)
 
 
 class NCCLoss(nn.Module):
     """Squared, per-channel NCC variant (layers/layers.py:238-255)."""
 
     def forward(self, x, y):
-        _no_autograd(x, y)
-        return ops.ncc_loss(x, y, NCC_SQUARED)
+        return NCCFn.apply(x, y, NCC_SQUARED)
 
 
 class GaussianSmoothing(nn.Module):

@@ -2,9 +2,8 @@
 import torch
 import torch.nn as nn
 
-from .. import ops
+from ..autograd import NCCFn
 from .._hip import NCC_CONFIGURED
-from .layers import _no_autograd
 
 
 class NCCLoss(nn.Module):
@@ -20,8 +19,7 @@ class NCCLoss(nn.Module):
         self.check_nan = check_nan
 
     def forward(self, input, target):
-        _no_autograd(input, target)
-        loss = ops.ncc_loss(input, target, NCC_CONFIGURED)
+        loss = NCCFn.apply(input, target, NCC_CONFIGURED)
         if self.check_nan:
             assert not torch.isnan(loss), 'NCC loss is Nan.'
         return loss

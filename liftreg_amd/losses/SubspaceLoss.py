@@ -4,12 +4,11 @@
 
 total = sim(warped, target) + reg_factor(epoch) · reg(params); reg on the HIP one-pass kernel.
 The regulariser's finite-difference stencil is mermaid's (un-vendored, absent): PARITY UNPINNED —
-see liftreg_amd/csrc/reg.hip for the assumed stencil.  Forward value only this round (no autograd).
+see liftreg_amd/csrc/reg.hip for the assumed stencil.  `total_loss.backward()` runs the HIP backward kernels.
 """
 import torch.nn as nn
 
-from .. import ops
-from ..layers.layers import _no_autograd
+from ..autograd import DispRegFn
 from ..utils.general import get_class
 from ..utils.utils import sigmoid_decay
 
@@ -35,7 +34,6 @@ class loss(nn.Module):
     def forward(self, input):
         warped, target, params = input["warped"], input["target"], input["params"]
         epoch = input["epoch"]
-        _no_autograd(warped, params)
         sim_loss = self.sim(warped, target)
         reg_loss = self.compute_reg_loss(params)
         total_loss = self.sim_factor * sim_loss + self.get_reg_factor(epoch) * reg_loss
@@ -47,4 +45,4 @@ class loss(nn.Module):
                          self.initial_reg_factor, self.min_reg_factor))
 
     def compute_reg_loss(self, affine_param):
-        return ops.disp_reg(affine_param)
+        return DispRegFn.apply(affine_param)

@@ -21,7 +21,8 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..layers.layers import convBlock, FullyConnectBlock, GaussianSmoothing, _no_autograd
+from ..autograd import PCAFn, WarpFn
+from ..layers.layers import convBlock, FullyConnectBlock, GaussianSmoothing
 from ..utils.net_utils import Bilinear, identity_axis_tables
 
 
@@ -166,20 +167,16 @@ class model(nn.Module):
         x[:, 0:1].copy_(moving)
         ops.backproject(target_proj, self._poses, (D, W, H), out=x[:, 1:], out_batch_stride=(P + 1) * V)
         for i in range(6):
-            blk = self.encoders[i]
-            x = ops.conv3d_k3_lrelu(x, blk.conv.weight, blk.conv.bias, blk.stride, in_layout=blk.in_layout,
-                                    out_layout=blk.out_layout, negative_slope=blk._slope,
-                                    packed=self._packed_weight(i))
+            x = self.encoders[i](x, packed=self._packed_weight(i))
         return self.encoders[6](x)
 
     def decode(self, moving, coefs, moving_seg=None):
         """HBM-bound half: PCA reconstruction → identity add + trilinear warp.  Returns (disp, phi, warped)."""
         B, _, D, W, H = moving.shape
-        disp = ops.pca_reconstruct(coefs, self.pca_vectors_LxM, self.pca_mean).view(B, 3, D, W, H)
+        disp = PCAFn.apply(coefs, self.pca_vectors_LxM, self.pca_mean).view(B, 3, D, W, H)
         # deform_field = disp + id ; warped = Bilinear(moving_cp, deform_field): one kernel; the mask
         # compose of moving ((moving+1)*seg-1, :57) happens on the taps
-        phi, warped = ops.warp(moving, disp, (self._id0, self._id1, self._id2), moving_seg,
-                               using_scale=True, zero_boundary=True)
+        phi, warped = WarpFn.apply(moving, disp, self._id0, self._id1, self._id2, moving_seg, True, True)
         return disp, phi, warped
 
     # ------------------------------------------------------------------ forward
@@ -187,7 +184,6 @@ class model(nn.Module):
         moving = input['source']
         target = input['target']
         target_proj = input["target_proj"]
-        _no_autograd(moving, target_proj, *self.parameters())
         if tuple(moving.shape[2:]) != tuple(self.img_sz):
             raise ValueError(f"model was built for {self.img_sz}, got {tuple(moving.shape[2:])}")
         self._ensure_pca(moving.device)

@@ -271,4 +271,4 @@ def subspace_loss(output, epoch, initial_reg_factor=0.01, min_reg_factor=0.01, r
     sim = ncc_loss(output["warped"], output["target"])
     reg = disp_reg(output["params"])
     factor = float(max(sigmoid_decay(epoch, static=reg_factor_decay_from, k=2) * initial_reg_factor, min_reg_factor))
-    return {"total_loss": sim + factor * reg, "sim_loss": float(sim), "reg_loss": float(reg)}
+    return {"total_loss": sim + factor * reg, "sim_loss": float(sim.detach()), "reg_loss": float(reg.detach())}

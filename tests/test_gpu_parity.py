@@ -333,8 +333,9 @@ def test_model_forward_golden(golden, dev, tmp_path):
     np.testing.assert_allclose(out["warped"].cpu().numpy(), g["out::warped"], rtol=1e-4, atol=2e-5)
     assert np.array_equal(out["target"].cpu().numpy(), g["out::target"])
     assert out["warped_proj"] is out["target_proj"]
-    with pytest.raises(NotImplementedError):                                         # no silent autograd fallback
-        net(inp)
+    out2 = net(inp)                                  # with grad enabled: same values, graph of HIP Functions only
+    assert torch.equal(out2["warped"], out["warped"]) and out2["warped"].grad_fn is not None
+    assert type(out2["warped"].grad_fn).__name__ == "WarpFnBackward"
 
 
 # ------------------------------------------------------------------------------------- error behaviour

@@ -1,0 +1,116 @@
+"""GPU: the reference's training step (RegistrationNet.py:389-406 — model(input) → loss(output) →
+total_loss.backward() → optimizer.step()) through the HIP forward AND backward kernels, against torch autograd of
+the CPU oracle (oracle/ref_ops.py: model_forward + subspace_loss, differentiated by ATen like the reference's own step).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops as ro
+
+pytestmark = pytest.mark.gpu
+
+LOSS_OPT = {"initial_reg_factor": 0.01, "min_reg_factor": 0.01, "reg_factor_decay_from": 2}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _net(shape, P, L, dev, seed):
+    from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+    torch.manual_seed(seed)
+    return model(list(shape), {"drr_feature_num": P, "latent_dim": L, "pca_path": f"synthetic:{seed}"}).to(dev)
+
+
+def _inputs(shape, P, R, B, seed, labels):
+    rs = np.random.RandomState(seed)
+    poses = ro.scan_poses(30, P, shape[0]).astype(np.float32)
+    inp = {"source": torch.from_numpy(rs.uniform(-1, 1, (B, 1) + tuple(shape)).astype(np.float32)),
+           "target": torch.from_numpy(rs.uniform(-1, 1, (B, 1) + tuple(shape)).astype(np.float32)),
+           "target_proj": torch.from_numpy(rs.uniform(-1, 1, (B, P, R, R)).astype(np.float32)),
+           "target_poses": torch.from_numpy(np.broadcast_to(poses, (B, P, 3)).copy())}
+    if labels:
+        inp["source_label"] = torch.from_numpy((rs.uniform(0, 1, (B, 1) + tuple(shape)) > 0.2).astype(np.float32))
+        inp["target_label"] = torch.from_numpy((rs.uniform(0, 1, (B, 1) + tuple(shape)) > 0.2).astype(np.float32))
+    return inp
+
+
+def _cpu_step(sd, inp, vec, mean, epoch):
+    params = {k: v.detach().cpu().clone().requires_grad_(v.dtype == torch.float32 and "gaussian" not in k)
+              for k, v in sd.items()}
+    out = ro.model_forward(params, inp, vec, mean)
+    loss = ro.subspace_loss(out, epoch, **LOSS_OPT)
+    loss["total_loss"].backward()
+    return loss, params
+
+
+@pytest.mark.parametrize("shape,P,L,B,labels", [((32, 32, 32), 2, 8, 2, False), ((32, 28, 36), 3, 5, 1, True)])
+def test_training_step_gradients(dev, shape, P, L, B, labels):
+    """Every parameter gradient of one step, HIP backward vs ATen autograd of the oracle.  The second case has
+    odd intermediate extents, so both channels-last layouts (plain and parity-split) are on the path."""
+    from liftreg_amd.losses.SubspaceLoss import loss as SubspaceLoss
+    net = _net(shape, P, L, dev, 5).train()
+    inp = _inputs(shape, P, 32, B, 5, labels)
+    crit = SubspaceLoss(dict(LOSS_OPT))
+    out = net({k: v.to(dev) if k != "target_poses" else v for k, v in inp.items()})
+    assert out["warped"].requires_grad and out["params"].requires_grad
+    out["epoch"] = 0
+    got = crit(out)
+    got["total_loss"].backward()
+
+    want, params = _cpu_step(net.state_dict(), inp, net.pca_vectors_LxM.cpu(), net.pca_mean.cpu(), 0)
+    assert abs(float(got["total_loss"]) - float(want["total_loss"])) < 1e-5
+    assert abs(got["sim_loss"] - want["sim_loss"]) < 1e-5 and abs(got["reg_loss"] - want["reg_loss"]) < 1e-6
+    named = dict(net.named_parameters())
+    assert len(named) == 18
+    for k, p in named.items():
+        g, w = p.grad.cpu().numpy(), params[k].grad.numpy()
+        scale = np.abs(w).max()
+        assert scale > 0, k
+        np.testing.assert_allclose(g, w, rtol=1e-3, atol=2e-4 * scale, err_msg=k)
+
+
+def test_adam_steps_follow_the_cpu_trajectory(dev):
+    """Six optimizer steps (torch.optim.Adam, as the reference uses) on one fixed batch: the loss goes down and
+    tracks the CPU oracle's trajectory."""
+    from liftreg_amd.losses.SubspaceLoss import loss as SubspaceLoss
+    shape, P, L, B = (32, 32, 32), 2, 8, 2
+    net = _net(shape, P, L, dev, 9).train()
+    inp = _inputs(shape, P, 32, B, 9, False)
+    net._ensure_pca(dev)
+    vec, mean = net.pca_vectors_LxM.cpu() * 40, net.pca_mean.cpu()      # a basis large enough to move voxels
+    net.set_pca(vec.to(dev), mean.to(dev))
+    cpu = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    cpu_params = {k: v.requires_grad_(True) for k, v in cpu.items() if "gaussian" not in k}
+    crit = SubspaceLoss(dict(LOSS_OPT))
+    opt_g = torch.optim.Adam(net.parameters(), lr=2e-4)
+    opt_c = torch.optim.Adam(list(cpu_params.values()), lr=2e-4)
+    dinp = {k: v.to(dev) if k != "target_poses" else v for k, v in inp.items()}
+    lg, lc = [], []
+    for step in range(6):
+        opt_g.zero_grad()
+        out = net(dinp)
+        out["epoch"] = step
+        l = crit(out)["total_loss"]
+        l.backward()
+        opt_g.step()
+        lg.append(float(l))
+        opt_c.zero_grad()
+        lo = ro.subspace_loss(ro.model_forward({**cpu, **cpu_params}, inp, vec, mean), step, **LOSS_OPT)["total_loss"]
+        lo.backward()
+        opt_c.step()
+        lc.append(float(lo))
+    assert lg[-1] < lg[0]
+    np.testing.assert_allclose(lg, lc, rtol=0, atol=2e-4)
+
+
+def test_inference_builds_no_graph(dev):
+    """Under no_grad the same modules run without saving activations (the serving path)."""
+    net = _net((32, 32, 32), 2, 8, dev, 3).eval()
+    inp = _inputs((32, 32, 32), 2, 32, 1, 3, False)
+    with torch.no_grad():
+        out = net({k: v.to(dev) if k != "target_poses" else v for k, v in inp.items()})
+    assert not out["warped"].requires_grad and out["warped"].grad_fn is None

@@ -103,7 +103,8 @@ def _inject(shim):
     import liftreg_amd.parallel as par
     import liftreg_amd.models.LiftRegDeformSubspaceBackproj as mod
     import liftreg_amd.layers.layers as lay
-    par.ops = mod.ops = lay.ops = shim
+    import liftreg_amd.autograd as ag
+    par.ops = mod.ops = lay.ops = ag.ops = shim
     return par, mod
 
 
