@@ -296,6 +296,260 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------- wgrad, channels-last X, stride 2 (blocks 1..5)
+// Same GEMM view (rows = co, cols = (tap, 16-channel block), k = 4 consecutive output voxels along Ho), but the
+// operands come from LDS: a persistent block walks bricks = one output row segment of HB voxels, stages the
+// 3x3x(2HB+1) input window (bounds-checked buffer loads: the zero halo is the conv's padding) and the HB x Cout
+// gradient segment, and the window of brick i+1 is in flight while brick i is on the matrix pipe.
+// LDS window layout [pz*3+py][cb][pos][16] with the columns parity-split (even window columns first): the 4
+// voxels of a k-step are then 16 floats apart for every tap — bank-conflict-free 256-byte wavefront reads.
+template <int CB, int NTC>
+struct WclGeom {
+  static constexpr int HB = 32 / CB;             // output voxels per brick
+  static constexpr int NCP = 2 * HB + 1;         // window columns
+  static constexpr int XF4 = 9 * CB * NCP * 4;   // float4 chunks of the window
+  static constexpr int XIT = (XF4 + 255) / 256;
+  static constexpr int GF4 = HB * NTC * 4;       // float4 chunks of the gradient segment (<= 256)
+  static constexpr int T = (27 * CB + 3) / 4;    // N-tiles per wave
+};
+
+template <int CB, int NTC, bool HPS>
+__global__ __launch_bounds__(256, 2) void conv3d_wgrad_cl_kernel(const float* __restrict__ xin,
+                                                                 const float* __restrict__ gpre,
+                                                                 float* __restrict__ partial, WgDims d, int nbricks) {
+  using G = WclGeom<CB, NTC>;
+  constexpr int Cin = CB * 16, Cout = NTC * 16, HB = G::HB;
+  __shared__ __attribute__((aligned(16))) float xs[G::XF4 * 4];
+  __shared__ __attribute__((aligned(16))) float gs[HB * NTC * 16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nseg = (d.Ho + HB - 1) / HB;
+
+  // staging slots: chunk q = it*256 + tid of the window, decoded once (brick-independent)
+  unsigned xrel[G::XIT];
+  int xdec[G::XIT];  // pz | py<<2 | pc<<4 | used<<12
+#pragma unroll
+  for (int it = 0; it < G::XIT; ++it) {
+    const int q = it * 256 + tid;
+    const bool used = q < G::XF4;
+    const int c4 = q & 3, pos = (q >> 2) % G::NCP, rc = (q >> 2) / G::NCP;
+    const int cb = rc % CB, row9 = used ? rc / CB : 0;
+    const int pz = row9 / 3, py = row9 % 3;
+    const int pc = pos <= HB ? 2 * pos : 2 * (pos - HB - 1) + 1;
+    xdec[it] = pz | (py << 2) | (pc << 4) | (used ? 1 << 12 : 0);
+    if (HPS)
+      xrel[it] = (unsigned)((((pz * d.W + py) * d.H * Cin) + cb * d.H * 16 +
+                             ((pc & 1) ? (pc - 1) / 2 : (d.H >> 1) - 1 + pc / 2) * 16 + c4 * 4) * 4);
+    else
+      xrel[it] = (unsigned)(((((pz * d.W + py) * d.H + pc) * Cin) + cb * 16 + c4 * 4) * 4);
+  }
+  // N-tiles of this wave: j = wave + 4t -> (tap, cb); LDS float offset of the tile's first voxel
+  int boff[G::T];
+#pragma unroll
+  for (int t = 0; t < G::T; ++t) {
+    const int j = min(wave + 4 * t, 27 * CB - 1);
+    const int tap = j / CB, cb = j % CB;
+    const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+    boff[t] = (((tz * 3 + ty) * CB + cb) * G::NCP + (tx == 1 ? HB + 1 : (tx >> 1))) * 16 + lane;
+  }
+  f32x4 acc[G::T][NTC];
+#pragma unroll
+  for (int t = 0; t < G::T; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 xst[G::XIT], gst;
+  auto prefetch = [&](int brick) {
+    const bool live = brick < nbricks;
+    int r = live ? brick : 0;
+    const int hseg = r % nseg; r /= nseg;
+    const int wo = r % d.Wo; r /= d.Wo;
+    const int dz = r % d.Do;
+    const int b = r / d.Do;
+    const int ho0 = hseg * HB;
+    const int zi0 = 2 * dz - 1, yi0 = 2 * wo - 1, xi0 = 2 * ho0 - 1;
+    const float* xb = xin + (int64_t)b * d.D * d.W * d.H * Cin;
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), (short)0, 0x7fffffff, 0x00020000);
+    const unsigned org = HPS ? (unsigned)((((zi0 * d.W + yi0) * d.H * Cin) + ho0 * 16) * 4)
+                             : (unsigned)(((((zi0 * d.W + yi0) * d.H + xi0) * Cin)) * 4);
+#pragma unroll
+    for (int it = 0; it < G::XIT; ++it) {
+      const int zi = zi0 + (xdec[it] & 3), yi = yi0 + ((xdec[it] >> 2) & 3), xi = xi0 + ((xdec[it] >> 4) & 255);
+      const bool ok = live && (xdec[it] >> 12) && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W && xi >= 0 && xi < d.H;
+      const unsigned voff = ok ? org + xrel[it] : OOR;
+      xst[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, 0));
+    }
+    const float* gb = gpre + ((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + ho0) * Cout;
+    const __amdgpu_buffer_rsrc_t rg =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gb), (short)0, 0x7fffffff, 0x00020000);
+    const bool gok = live && tid < G::GF4 && ho0 + tid / (NTC * 4) < d.Ho;
+    gst = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rg, gok ? (unsigned)tid * 16u : OOR, 0, 0));
+  };
+
+  int brick = blockIdx.x;
+  prefetch(brick);
+  for (; brick < nbricks; brick += gridDim.x) {
+    __syncthreads();  // the previous brick's reads are done
+#pragma unroll
+    for (int it = 0; it < G::XIT; ++it)
+      if ((xdec[it] >> 12) & 1) *reinterpret_cast<float4*>(xs + (it * 256 + tid) * 4) = xst[it];
+    if (tid < G::GF4) {
+      const int i = tid / (NTC * 4), c4 = tid % (NTC * 4);
+      *reinterpret_cast<float4*>(gs + ((c4 >> 2) * HB + i) * 16 + (c4 & 3) * 4) = gst;
+    }
+    __syncthreads();
+    prefetch(brick + (int)gridDim.x);
+#pragma unroll
+    for (int ks = 0; ks < HB / 4; ++ks) {
+      float a[NTC];
+#pragma unroll
+      for (int nt = 0; nt < NTC; ++nt) a[nt] = gs[nt * HB * 16 + ks * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < G::T; ++t) {
+        const float bv = xs[boff[t] + ks * 64];
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt)
+          acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nt], bv, acc[t][nt], 0, 0, 0);
+      }
+    }
+  }
+  const int col = lane & 15, kq = lane >> 4;
+  const int ncols = 27 * CB * 16;
+#pragma unroll
+  for (int t = 0; t < G::T; ++t) {
+    const int j = wave + 4 * t;
+    if (j < 27 * CB) {
+#pragma unroll
+      for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          partial[((int64_t)blockIdx.x * Cout + nt * 16 + kq * 4 + r) * ncols + j * 16 + col] = acc[t][nt][r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------- wgrad, planar X, stride 1 (the first block)
+// Columns c = ci*27 + tap (NTL tiles of 16); the 4 waves of a block split the VOXELS (one brick row each) and
+// every wave carries all NTL tiles.  Brick = 4 rows x 64 voxels of one plane; k-group g of a k-step owns voxels
+// 16q + 4g + s (s = the k-step within a quad), so a lane's B operands of a quad are 4 consecutive floats of one
+// window row.  The gradient rows sit in LDS as [voxel][16] with 16 floats of padding after every 4 voxels
+// (conflict-free A reads).
+template <int NTL>
+struct WplGeom {
+  static constexpr int CMAX = NTL * 16 / 27;     // 3 | 12 input channels
+  static constexpr int RS = 72;                  // window row: x = h0-4 .. h0+67
+  static constexpr int CS = 18 * RS;             // channel stride (3 planes x 6 rows)
+  static constexpr int XF4 = CMAX * 18 * 18;     // float4 chunks of the window
+  static constexpr int XIT = (XF4 + 255) / 256;
+  static constexpr int GP = 16 * 80;             // padded gradient row
+};
+
+template <int NTL>
+__global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_kernel(const float* __restrict__ xin,
+                                                                     const float* __restrict__ gpre,
+                                                                     float* __restrict__ partial, WgDims d,
+                                                                     int nbricks) {
+  using G = WplGeom<NTL>;
+  __shared__ __attribute__((aligned(16))) float xs[G::XF4 * 4];
+  __shared__ __attribute__((aligned(16))) float gs[4 * G::GP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, kq = lane >> 4;
+  const int64_t V = (int64_t)d.D * d.W * d.H;
+  const int nH = (d.H + 63) / 64, nW = (d.W + 3) / 4;
+
+  unsigned xrel[G::XIT];
+  int xdec[G::XIT];  // rz | ry<<2 | cc<<5 | f4<<9 | used<<14
+#pragma unroll
+  for (int it = 0; it < G::XIT; ++it) {
+    const int q = it * 256 + tid;
+    const bool used = q < G::XF4;
+    const int row = used ? q / 18 : 0, f4 = q % 18;
+    const int cc = row / 18, rz = (row / 6) % 3, ry = row % 6;
+    xdec[it] = rz | (ry << 2) | (cc << 5) | (f4 << 9) | ((used && cc < d.Cin) ? 1 << 14 : 0);
+    xrel[it] = (unsigned)(((int64_t)cc * V + ((int64_t)rz * d.W + ry) * d.H + f4 * 4) * 4);
+  }
+  int bbase[NTL];
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) {
+    int c = j * 16 + col;
+    if (c >= 27 * d.Cin) c = 0;  // unused column: computed, never stored
+    const int ci = c / 27, tap = c % 27;
+    const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+    bbase[j] = ci * G::CS + (tz * 6 + ty + wave) * G::RS + tx + 3 + 4 * kq;
+  }
+  f32x4 acc[NTL];
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 xst[G::XIT], gst[4];
+  auto prefetch = [&](int brick) {
+    const bool live = brick < nbricks;
+    int r = live ? brick : 0;
+    const int hq = r % nH; r /= nH;
+    const int wq = r % nW; r /= nW;
+    const int z = r % d.D;
+    const int b = r / d.D;
+    const int h0 = hq * 64, y0 = wq * 4;
+    const float* xb = xin + (int64_t)b * d.Cin * V;
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), (short)0, 0x7fffffff, 0x00020000);
+    const unsigned org = (unsigned)(((((int64_t)(z - 1) * d.W + (y0 - 1)) * d.H) + h0 - 4) * 4);
+#pragma unroll
+    for (int it = 0; it < G::XIT; ++it) {
+      const int zi = z - 1 + (xdec[it] & 3), yi = y0 - 1 + ((xdec[it] >> 2) & 7), xi = h0 - 4 + ((xdec[it] >> 9) & 31) * 4;
+      const bool ok = live && (xdec[it] >> 14) && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W && xi >= 0 && xi < d.H;
+      xst[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? org + xrel[it] : OOR, 0, 0));
+    }
+    const float* gb = gpre + ((((int64_t)b * d.D + z) * d.W + y0) * d.H + h0) * 16;
+    const __amdgpu_buffer_rsrc_t rg =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gb), (short)0, 0x7fffffff, 0x00020000);
+    const bool vok = live && h0 + (tid >> 2) < d.H;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const bool ok = vok && y0 + rr < d.W;
+      gst[rr] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                               rg, ok ? (unsigned)((rr * d.H * 16 + tid * 4) * 4) : OOR, 0, 0));
+    }
+  };
+
+  int brick = blockIdx.x;
+  prefetch(brick);
+  for (; brick < nbricks; brick += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < G::XIT; ++it)
+      if (it * 256 + tid < G::XF4) *reinterpret_cast<float4*>(xs + (it * 256 + tid) * 4) = xst[it];
+    {
+      const int v = tid >> 2, c4 = tid & 3;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        *reinterpret_cast<float4*>(gs + rr * G::GP + (v + (v >> 2)) * 16 + c4 * 4) = gst[rr];
+    }
+    __syncthreads();
+    prefetch(brick + (int)gridDim.x);
+    const float* ga = gs + wave * G::GP + kq * 80 + col;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float a = ga[(20 * q + s) * 16];
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xs[bbase[j] + 16 * q + s], acc[j], 0, 0, 0);
+      }
+  }
+  const int ncols = d.ntiles * 16;
+  const int64_t pb = (int64_t)blockIdx.x * 4 + wave;
+#pragma unroll
+  for (int j = 0; j < NTL; ++j)
+    if (j < d.ntiles) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) partial[(pb * 16 + kq * 4 + r) * ncols + j * 16 + col] = acc[j][r];
+    }
+}
+
 // columns -> (Cout, Cin, 27) weight layout
 __global__ void wgrad_finish_kernel(const float* __restrict__ partial, float* __restrict__ gw, int nblk, int Cout,
                                     int Cin, int ncols, int x_layout) {
@@ -356,7 +610,8 @@ extern "C" int lr_conv3d_dgrad_f32(const float* gpre, const float* packed_wT, fl
 
 extern "C" int64_t lr_conv3d_wgrad_partial_floats(int Cin, int Cout, int x_layout, int nblk) {
   const int ntiles = x_layout == LR_LAYOUT_NCDHW ? (Cin * 27 + 15) / 16 : 27 * ((Cin + 15) / 16);
-  return (int64_t)nblk * Cout * ntiles * 16;
+  // the planar fast path keeps one partial per WAVE (its waves split the voxels): 4 per block
+  return (int64_t)nblk * (x_layout == LR_LAYOUT_NCDHW ? 4 : 1) * Cout * ntiles * 16;
 }
 
 extern "C" int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gpre, float* partial, float* gw,
@@ -373,6 +628,48 @@ extern "C" int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gp
   if (d.ntiles > 4 * WG_MAXT) return LR_EUNSUPPORTED;  // Cin <= 32 channels-last, <= 33 planar
   const int64_t ngroups = (int64_t)B * d.Do * d.Wo * ((d.Ho + 3) / 4);
   hipStream_t st = lr_stream(stream);
+  const bool al16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gpre)) & 15u) == 0;
+  const int64_t V = (int64_t)D * W * H;
+  int nparts = 0;  // > 0: a fast path ran and left this many partials
+  if (x_layout != LR_LAYOUT_NCDHW && stride == 2 && (Cin == 16 || Cin == 32) && al16 && V * Cin * 4 < 0x7fffffffLL) {
+    // blocks 1..5: LDS-staged bricks (one output row segment each)
+    const int hb = 32 / (Cin / 16);
+    const int64_t nbricks = (int64_t)B * d.Do * d.Wo * ((d.Ho + hb - 1) / hb);
+    if (nbricks < 0x7fffffffLL) {
+      const unsigned grid = (unsigned)(nbricks < nblk ? nbricks : nblk);
+      const bool hps = x_layout == LR_LAYOUT_NDHWC_HPS;
+#define LR_WCL(CBV, NTCV)                                                                                          \
+  do {                                                                                                             \
+    if (hps) hipLaunchKernelGGL((conv3d_wgrad_cl_kernel<CBV, NTCV, true>), dim3(grid), dim3(256), 0, st, x, gpre,  \
+                                partial, d, (int)nbricks);                                                         \
+    else hipLaunchKernelGGL((conv3d_wgrad_cl_kernel<CBV, NTCV, false>), dim3(grid), dim3(256), 0, st, x, gpre,     \
+                            partial, d, (int)nbricks);                                                             \
+  } while (0)
+      if (Cin == 16 && Cout == 16) LR_WCL(1, 1);
+      else if (Cin == 16) LR_WCL(1, 2);
+      else if (Cout == 16) LR_WCL(2, 1);
+      else LR_WCL(2, 2);
+#undef LR_WCL
+      nparts = (int)grid;
+    }
+  } else if (x_layout == LR_LAYOUT_NCDHW && stride == 1 && Cout == 16 && Cin <= 12 && H % 4 == 0 && al16 &&
+             (V * Cin + 8 * (int64_t)W * H) * 4 < 0x7fffffffLL) {
+    // the first block: planar input, the waves split the voxels of a 4-row brick
+    const int64_t nbricks = (int64_t)B * D * ((W + 3) / 4) * ((H + 63) / 64);
+    if (nbricks < 0x7fffffffLL) {
+      const unsigned grid = (unsigned)(nbricks < nblk ? nbricks : nblk);
+      if (Cin <= 3) hipLaunchKernelGGL(conv3d_wgrad_planar_kernel<6>, dim3(grid), dim3(256), 0, st, x, gpre, partial, d, (int)nbricks);
+      else hipLaunchKernelGGL(conv3d_wgrad_planar_kernel<21>, dim3(grid), dim3(256), 0, st, x, gpre, partial, d, (int)nbricks);
+      nparts = (int)grid * 4;
+    }
+  }
+  if (nparts) {
+    if (int e = lr_launch_status()) return e;
+    const int n = Cout * Cin * 27;
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partial, gw, nparts, Cout, Cin,
+                       d.ntiles * 16, x_layout);
+    return lr_launch_status();
+  }
   if (Cout == 16) hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, x, gpre, partial, d, ngroups);
   else hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, x, gpre, partial, d, ngroups);
   if (int e = lr_launch_status()) return e;

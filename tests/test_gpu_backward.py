@@ -91,6 +91,9 @@ def test_conv_block_backward_all_layouts(dev):
     cases = [  # cin, cout, stride, shape, B, x_layout, y_layout, gy_layout
         (3, 16, 1, (6, 7, 20), 2, L.LAYOUT_NCDHW, L.LAYOUT_NDHWC_HPS, L.LAYOUT_NDHWC),
         (5, 16, 1, (5, 6, 9), 1, L.LAYOUT_NCDHW, L.LAYOUT_NDHWC, L.LAYOUT_NDHWC),
+        (12, 16, 1, (4, 5, 8), 2, L.LAYOUT_NCDHW, L.LAYOUT_NDHWC_HPS, L.LAYOUT_NDHWC),
+        (3, 16, 1, (9, 13, 72), 1, L.LAYOUT_NCDHW, L.LAYOUT_NDHWC_HPS, L.LAYOUT_NDHWC),
+        (16, 32, 2, (9, 12, 70), 1, L.LAYOUT_NDHWC_HPS, L.LAYOUT_NDHWC, L.LAYOUT_NDHWC),
         (16, 32, 2, (8, 10, 20), 2, L.LAYOUT_NDHWC_HPS, L.LAYOUT_NDHWC_HPS, L.LAYOUT_NDHWC),
         (16, 32, 2, (7, 9, 11), 1, L.LAYOUT_NDHWC, L.LAYOUT_NDHWC, L.LAYOUT_NDHWC),
         (32, 32, 2, (8, 8, 16), 2, L.LAYOUT_NDHWC_HPS, L.LAYOUT_NCDHW, L.LAYOUT_NCDHW),
