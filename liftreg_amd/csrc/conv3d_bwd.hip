@@ -75,8 +75,11 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------ dgrad (stride 2)
 // gx[b, x, ci] = sum_{tap, co} gpre[b, (x + 1 - tap)/2, co] * W[co][ci][tap]   over taps with (x+1-tap) even per axis
-// GEMM view as the forward: rows = ci (the block's input channels, 16|32 -> NT tiles), cols = 16 voxels of gx
-// consecutive along H, k = (tap, co).  Brick per block: 4 planes x 4 rows x 16 voxels of gx.
+// GEMM view as the forward: rows = ci (the block's input channels, 16|32 -> NT tiles), cols = 16 voxels of gx,
+// k = (tap, co).  A block owns ONE parity class (pz,py,px) of gx: along an axis an even coordinate takes tap 1
+// only and an odd one taps 0 and 2, so the class fixes its 1|2|4|8 taps and no MFMA multiplies a structural zero.
+// Its 16 columns are 16 same-parity voxels (2 apart along H; contiguous in the parity-split layout); brick per
+// block: 4 planes x 4 rows x 16 voxels of the class.
 struct DgDims {
   int B, Cg, Cx, D, W, H, Do, Wo, Ho;  // gx is (B,D,W,H,Cx); gpre is (B,Do,Wo,Ho,Cg)
   int nHq, nWq, nDq;
@@ -88,81 +91,59 @@ template <int NT>
 __global__ __launch_bounds__(256) void conv3d_dgrad_kernel(const float* __restrict__ gpre,
                                                            const float4* __restrict__ wp,
                                                            float* __restrict__ gx, DgDims d) {
-  const unsigned lb = lr_xcd_remap(blockIdx.x, gridDim.x);
-  const int hq = lb % d.nHq, wq = (lb / d.nHq) % d.nWq, dq = (lb / d.nHq / d.nWq) % d.nDq;
-  const int b = lb / d.nHq / d.nWq / d.nDq;
+  // a block walks the 8 parity classes of its tile back to back (they read the same gpre tile and together fill
+  // one 8 x 8 x 32 brick of gx), the 8-tap class first
+  unsigned t = lr_xcd_remap(blockIdx.x, gridDim.x);
+  const int hq = t % d.nHq; t /= d.nHq;
+  const int wq = t % d.nWq; t /= d.nWq;
+  const int dq = t % d.nDq;
+  const int b = t / d.nDq;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int z = dq * 4 + wave;
-  if (z >= d.D) return;
-  const int y0 = wq * DMT;
+  const int zq = dq * 4 + wave;
+  const int yq0 = wq * DMT;
   const int col = lane & 15, kq = lane >> 4;
-  const int x = hq * 16 + col;
+  const int xq = hq * 16 + col;
   const int CB = (d.Cg + 15) >> 4;
-
+  const float* base = gpre + (int64_t)b * d.Do * d.Wo * d.Ho * d.Cg;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, 0x7fffffff, 0x00020000);
+  const unsigned lv = (unsigned)((xq * d.Cg + kq * 4) * 4);
+  float4 a0[DMT], a1[DMT], b0[NT], b1[NT];
+  for (int cls = 7; cls >= 0; --cls) {
+  const int px = cls & 1, py = (cls >> 1) & 1, pz = cls >> 2;
+  const int z = 2 * zq + pz, x = 2 * xq + px;
+  if (z >= d.D) continue;  // wave-uniform
   f32x4 acc[DMT][NT];
 #pragma unroll
   for (int mt = 0; mt < DMT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // lane mask per source column shift ox: OOR when the gx voxel or its source column does not exist
+  const unsigned xinv0 = (x < d.H && xq < d.Ho) ? 0u : OOR;
+  const unsigned xinv1 = (x < d.H && xq + 1 < d.Ho) ? 0u : OOR;
 
-  const float* base = gpre + (int64_t)b * d.Do * d.Wo * d.Ho * d.Cg;
-  const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, 0x7fffffff, 0x00020000);
-  // per lane: source column offset for each tx (valid when (x+1-tx) is even and in range)
-  unsigned lvoff[3];
-  unsigned xok = 0u;
-#pragma unroll
-  for (int tx = 0; tx < 3; ++tx) {
-    const int t = x + 1 - tx;
-    const bool ok = x < d.H && t >= 0 && !(t & 1) && (t >> 1) < d.Ho;
-    lvoff[tx] = (unsigned)(((ok ? (t >> 1) : 0) * d.Cg + kq * 4) * 4);
-    xok |= ok ? (1u << tx) : 0u;
-  }
-  // per tile (row y0+mt) and per wave (plane z): source row / plane and validity for each ty / tz
-  int srow[DMT][3];
-  unsigned nvmask[DMT];  // bit tap CLEAR = valid
-  int splane[3];
-  unsigned zok = 0u;
-#pragma unroll
-  for (int tz = 0; tz < 3; ++tz) {
-    const int t = z + 1 - tz;
-    const bool ok = t >= 0 && !(t & 1) && (t >> 1) < d.Do;
-    splane[tz] = ok ? (t >> 1) : 0;
-    zok |= ok ? (1u << tz) : 0u;
-  }
-#pragma unroll
-  for (int mt = 0; mt < DMT; ++mt) {
-    unsigned m = 0u;
-#pragma unroll
-    for (int ty = 0; ty < 3; ++ty) {
-      const int t = y0 + mt + 1 - ty;
-      const bool oky = (y0 + mt < d.W) && t >= 0 && !(t & 1) && (t >> 1) < d.Wo;
-      srow[mt][ty] = oky ? (t >> 1) : 0;
-#pragma unroll
-      for (int tz = 0; tz < 3; ++tz)
-#pragma unroll
-        for (int tx = 0; tx < 3; ++tx)
-          if (oky && ((zok >> tz) & 1u) && ((xok >> tx) & 1u)) m |= 1u << ((tz * 3 + ty) * 3 + tx);
-    }
-    nvmask[mt] = ~m;
-  }
-
-  const int NS = 27 * CB;
+  const int NS = (1 << (px + py + pz)) * CB;
   auto load_step = [&](int s, float4 (&a)[DMT], float4 (&bw)[NT]) {
-    const int tap = s / CB, cb = s - tap * CB;
-    const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
-    const unsigned coor = (cb * 16 + kq * 4 < d.Cg) ? 0u : OOR;
+    const int tapi = s / CB, cb = s - tapi * CB;
+    // class-local tap -> (tap index of the 3x3x3 kernel, source shift): parity 0: tap 1, shift 0;
+    // parity 1: taps 0 (source q+1) and 2 (source q)
+    const int ix = tapi & px, r1 = tapi >> px, iy = r1 & py, iz = (r1 >> py) & pz;
+    const int tx = px ? 2 * ix : 1, ox = px ? 1 - ix : 0;
+    const int ty = py ? 2 * iy : 1, oy = py ? 1 - iy : 0;
+    const int tz = pz ? 2 * iz : 1, oz = pz ? 1 - iz : 0;
+    const int sfull = ((tz * 3 + ty) * 3 + tx) * CB + cb;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bw[nt] = wp[((int64_t)s * NT + nt) * 64 + lane];
-    const unsigned lv = tx == 0 ? lvoff[0] : (tx == 1 ? lvoff[1] : lvoff[2]);
+    for (int nt = 0; nt < NT; ++nt) bw[nt] = wp[((int64_t)sfull * NT + nt) * 64 + lane];
+    const unsigned coor = (cb * 16 + kq * 4 < d.Cg) ? 0u : OOR;
+    const unsigned lvx = lv | coor | (ox ? xinv1 : xinv0);
+    const int zs = zq + oz;
 #pragma unroll
     for (int mt = 0; mt < DMT; ++mt) {
-      const int sr = ty == 0 ? srow[mt][0] : (ty == 1 ? srow[mt][1] : srow[mt][2]);
-      const int sp = tz == 0 ? splane[0] : (tz == 1 ? splane[1] : splane[2]);  // no dynamic register indexing
-      const unsigned soff = (unsigned)((((sp * d.Wo) + sr) * d.Ho * d.Cg + cb * 16) * 4);
-      const unsigned voff = lv | coor | ((nvmask[mt] >> tap) << 31);
-      a[mt] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+      const int ys = yq0 + mt + oy;
+      const bool ok = zs < d.Do && ys < d.Wo && 2 * (yq0 + mt) + py < d.W;  // wave-uniform
+      const unsigned soff = ok ? (unsigned)(((((zs * d.Wo) + ys) * d.Ho + ox) * d.Cg + cb * 16) * 4) : 0u;
+      a[mt] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lvx | (ok ? 0u : OOR), soff, 0));
     }
   };
   auto mfma_step = [&](const float4 (&a)[DMT], const float4 (&bw)[NT]) {
@@ -176,7 +157,6 @@ __global__ __launch_bounds__(256) void conv3d_dgrad_kernel(const float* __restri
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[nt].w, a[mt].w, acc[mt][nt], 0, 0, 0);
       }
   };
-  float4 a0[DMT], a1[DMT], b0[NT], b1[NT];
   load_step(0, a0, b0);
   for (int s = 0; s + 1 < NS; s += 2) {
     load_step(s + 1, a1, b1);
@@ -187,18 +167,20 @@ __global__ __launch_bounds__(256) void conv3d_dgrad_kernel(const float* __restri
   if (NS & 1) mfma_step(a0, b0);
   if (x < d.H) {
 #pragma unroll
-    for (int mt = 0; mt < DMT; ++mt)
-      if (y0 + mt < d.W)
+    for (int mt = 0; mt < DMT; ++mt) {
+      const int y = 2 * (yq0 + mt) + py;
+      if (y < d.W)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-        {
-          const int64_t row = (((int64_t)b * d.D + z) * d.W + y0 + mt) * d.H * d.Cx;
+        for (int nt = 0; nt < NT; ++nt) {
+          const int64_t row = (((int64_t)b * d.D + z) * d.W + y) * d.H * d.Cx;
           const int64_t o = d.gx_layout == LR_LAYOUT_NDHWC
                                 ? row + (int64_t)x * d.Cx + nt * 16 + kq * 4
-                                : row + ((int64_t)nt * d.H + ((x & 1) * (d.H >> 1) + (x >> 1))) * 16 + kq * 4;
+                                : row + ((int64_t)nt * d.H + (px * (d.H >> 1) + xq)) * 16 + kq * 4;
           *reinterpret_cast<f32x4*>(gx + o) = acc[mt][nt];
         }
+    }
   }
+  }  // parity classes
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
@@ -308,13 +290,15 @@ struct WclGeom {
   static constexpr int HB = 32 / CB;             // output voxels per brick
   static constexpr int NCP = 2 * HB + 1;         // window columns
   static constexpr int XF4 = 9 * CB * NCP * 4;   // float4 chunks of the window
-  static constexpr int XIT = (XF4 + 255) / 256;
+  static constexpr int NW = 4 * CB;              // waves per block: 27*CB N-tiles, 7 per wave
+  static constexpr int NTH = NW * 64;
+  static constexpr int XIT = (XF4 + NTH - 1) / NTH;
   static constexpr int GF4 = HB * NTC * 4;       // float4 chunks of the gradient segment (<= 256)
-  static constexpr int T = (27 * CB + 3) / 4;    // N-tiles per wave
+  static constexpr int T = (27 * CB + NW - 1) / NW;  // N-tiles per wave
 };
 
 template <int CB, int NTC, bool HPS>
-__global__ __launch_bounds__(256, 2) void conv3d_wgrad_cl_kernel(const float* __restrict__ xin,
+__global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_kernel(const float* __restrict__ xin,
                                                                  const float* __restrict__ gpre,
                                                                  float* __restrict__ partial, WgDims d, int nbricks) {
   using G = WclGeom<CB, NTC>;
@@ -330,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_cl_kernel(const float* __
   int xdec[G::XIT];  // pz | py<<2 | pc<<4 | used<<12
 #pragma unroll
   for (int it = 0; it < G::XIT; ++it) {
-    const int q = it * 256 + tid;
+    const int q = it * G::NTH + tid;
     const bool used = q < G::XF4;
     const int c4 = q & 3, pos = (q >> 2) % G::NCP, rc = (q >> 2) / G::NCP;
     const int cb = rc % CB, row9 = used ? rc / CB : 0;
@@ -343,11 +327,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_cl_kernel(const float* __
     else
       xrel[it] = (unsigned)(((((pz * d.W + py) * d.H + pc) * Cin) + cb * 16 + c4 * 4) * 4);
   }
-  // N-tiles of this wave: j = wave + 4t -> (tap, cb); LDS float offset of the tile's first voxel
+  // N-tiles of this wave: j = wave + NW*t -> (tap, cb); LDS float offset of the tile's first voxel
   int boff[G::T];
 #pragma unroll
   for (int t = 0; t < G::T; ++t) {
-    const int j = min(wave + 4 * t, 27 * CB - 1);
+    const int j = min(wave + G::NW * t, 27 * CB - 1);
     const int tap = j / CB, cb = j % CB;
     const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
     boff[t] = (((tz * 3 + ty) * CB + cb) * G::NCP + (tx == 1 ? HB + 1 : (tx >> 1))) * 16 + lane;
@@ -393,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_cl_kernel(const float* __
     __syncthreads();  // the previous brick's reads are done
 #pragma unroll
     for (int it = 0; it < G::XIT; ++it)
-      if ((xdec[it] >> 12) & 1) *reinterpret_cast<float4*>(xs + (it * 256 + tid) * 4) = xst[it];
+      if ((xdec[it] >> 12) & 1) *reinterpret_cast<float4*>(xs + (it * G::NTH + tid) * 4) = xst[it];
     if (tid < G::GF4) {
       const int i = tid / (NTC * 4), c4 = tid % (NTC * 4);
       *reinterpret_cast<float4*>(gs + ((c4 >> 2) * HB + i) * 16 + (c4 & 3) * 4) = gst;
@@ -418,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_cl_kernel(const float* __
   const int ncols = 27 * CB * 16;
 #pragma unroll
   for (int t = 0; t < G::T; ++t) {
-    const int j = wave + 4 * t;
+    const int j = wave + G::NW * t;
     if (j < 27 * CB) {
 #pragma unroll
       for (int nt = 0; nt < NTC; ++nt)
@@ -550,17 +534,24 @@ __global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_ke
     }
 }
 
-// columns -> (Cout, Cin, 27) weight layout
+// partial[k][co][n] summed over the nblk partials in double (fixed order), column n -> (ci, tap) of gw
 __global__ void wgrad_finish_kernel(const float* __restrict__ partial, float* __restrict__ gw, int nblk, int Cout,
                                     int Cin, int ncols, int x_layout) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= Cout * Cin * 27) return;
-  const int tap = idx % 27, ci = (idx / 27) % Cin, co = idx / 27 / Cin;
-  const int cbn = (Cin + 15) >> 4;
-  const int n = x_layout == LR_LAYOUT_NCDHW ? ci * 27 + tap : (tap * cbn + (ci >> 4)) * 16 + (ci & 15);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // (co, n): consecutive threads read consecutive floats
+  if (t >= Cout * ncols) return;
+  const int co = t / ncols, n = t - co * ncols;
+  int ci, tap;
+  if (x_layout == LR_LAYOUT_NCDHW) {
+    ci = n / 27; tap = n - ci * 27;
+  } else {
+    const int cbn = (Cin + 15) >> 4, j = n >> 4;
+    tap = j / cbn; ci = (j - tap * cbn) * 16 + (n & 15);
+  }
+  if (ci >= Cin || tap >= 27) return;
   double s = 0.0;
-  for (int k = 0; k < nblk; ++k) s += (double)partial[((int64_t)k * Cout + co) * ncols + n];
-  gw[idx] = (float)s;
+  const int64_t step = (int64_t)Cout * ncols;
+  for (int k = 0; k < nblk; ++k) s += (double)partial[k * step + t];
+  gw[((int64_t)co * Cin + ci) * 27 + tap] = (float)s;
 }
 
 }  // namespace
@@ -597,9 +588,9 @@ extern "C" int lr_conv3d_dgrad_f32(const float* gpre, const float* packed_wT, fl
   d.B = B; d.Cg = Cg; d.Cx = Cx; d.D = D; d.W = W; d.H = H;
   d.Do = (D - 1) / 2 + 1; d.Wo = (W - 1) / 2 + 1; d.Ho = (H - 1) / 2 + 1;
   if ((int64_t)d.Do * d.Wo * d.Ho * Cg * 4 >= 0x7fffffffLL) return LR_EINVAL;  // 31-bit buffer offsets per batch element
-  d.nHq = (H + 15) / 16; d.nWq = (W + DMT - 1) / DMT; d.nDq = (D + 3) / 4;
+  d.nHq = ((H + 1) / 2 + 15) / 16; d.nWq = ((W + 1) / 2 + DMT - 1) / DMT; d.nDq = ((D + 1) / 2 + 3) / 4;
   d.gx_layout = gx_layout;
-  const int64_t nblk = (int64_t)B * d.nDq * d.nWq * d.nHq;
+  const int64_t nblk = (int64_t)B * d.nDq * d.nWq * d.nHq;  // tiles of 4 x 4 x 16 voxels per parity class
   if (nblk > 0x7fffffffLL) return LR_EINVAL;
   const float4* wt = reinterpret_cast<const float4*>(packed_wT);
   hipStream_t st = lr_stream(stream);
@@ -640,10 +631,10 @@ extern "C" int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gp
       const bool hps = x_layout == LR_LAYOUT_NDHWC_HPS;
 #define LR_WCL(CBV, NTCV)                                                                                          \
   do {                                                                                                             \
-    if (hps) hipLaunchKernelGGL((conv3d_wgrad_cl_kernel<CBV, NTCV, true>), dim3(grid), dim3(256), 0, st, x, gpre,  \
-                                partial, d, (int)nbricks);                                                         \
-    else hipLaunchKernelGGL((conv3d_wgrad_cl_kernel<CBV, NTCV, false>), dim3(grid), dim3(256), 0, st, x, gpre,     \
-                            partial, d, (int)nbricks);                                                             \
+    if (hps) hipLaunchKernelGGL((conv3d_wgrad_cl_kernel<CBV, NTCV, true>), dim3(grid), dim3(256 * CBV), 0, st, x,  \
+                                gpre, partial, d, (int)nbricks);                                                   \
+    else hipLaunchKernelGGL((conv3d_wgrad_cl_kernel<CBV, NTCV, false>), dim3(grid), dim3(256 * CBV), 0, st, x,     \
+                            gpre, partial, d, (int)nbricks);                                                       \
   } while (0)
       if (Cin == 16 && Cout == 16) LR_WCL(1, 1);
       else if (Cin == 16) LR_WCL(1, 2);
@@ -665,16 +656,16 @@ extern "C" int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gp
   }
   if (nparts) {
     if (int e = lr_launch_status()) return e;
-    const int n = Cout * Cin * 27;
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partial, gw, nparts, Cout, Cin,
+    const int n = Cout * d.ntiles * 16;
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, partial, gw, nparts, Cout, Cin,
                        d.ntiles * 16, x_layout);
     return lr_launch_status();
   }
   if (Cout == 16) hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, x, gpre, partial, d, ngroups);
   else hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, x, gpre, partial, d, ngroups);
   if (int e = lr_launch_status()) return e;
-  const int n = Cout * Cin * 27;
-  hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partial, gw, nblk, Cout, Cin,
+  const int n = Cout * d.ntiles * 16;
+  hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, partial, gw, nblk, Cout, Cin,
                      d.ntiles * 16, x_layout);
   return lr_launch_status();
 }
