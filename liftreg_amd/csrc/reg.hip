@@ -96,6 +96,104 @@ __global__ __launch_bounds__(256) void disp_reg_bwd_kernel(const float* __restri
   }
 }
 
+
+// ---- vectorised variants (H % 4 == 0, 16-byte aligned): a thread owns 4 consecutive voxels of a row; the
+// neighbouring rows/planes arrive as float4 (L2 hits), so HBM sees each displacement value about once.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void disp_reg_vec_kernel(const float* __restrict__ disp, double* __restrict__ partial,
+                                                           int D, int W, int H, float ihd, float ihw, float ihh) {
+  const int b = blockIdx.y;
+  const int64_t V = (int64_t)D * W * H;
+  const float* base = disp + (int64_t)b * 3 * V;
+  const unsigned H4 = (unsigned)H >> 2, nq = (unsigned)(V >> 2);
+  double acc = 0.0;
+  for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < nq; q += gridDim.x * 256u) {
+    const unsigned row = q / H4;
+    const int k = (int)(q - row * H4) * 4, j = (int)(row % (unsigned)W), i = (int)(row / (unsigned)W);
+    // clamped neighbours: at a face the one-sided difference (f[1]-f[0])/h uses the centre itself
+    const int64_t o = (int64_t)q * 4;
+    const int64_t oym = j > 0 ? -(int64_t)H : 0, oyp = j < W - 1 ? (int64_t)H : 0;
+    const int64_t ozm = i > 0 ? -(int64_t)W * H : 0, ozp = i < D - 1 ? (int64_t)W * H : 0;
+    const float cd = (i == 0 || i == D - 1) ? ihd : 0.5f * ihd;
+    const float cw = (j == 0 || j == W - 1) ? ihw : 0.5f * ihw;
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* p = base + c * V + o;
+      const f32x4 f = *reinterpret_cast<const f32x4*>(p);
+      const f32x4 ym = *reinterpret_cast<const f32x4*>(p + oym), yp = *reinterpret_cast<const f32x4*>(p + oyp);
+      const f32x4 zm = *reinterpret_cast<const f32x4*>(p + ozm), zp = *reinterpret_cast<const f32x4*>(p + ozp);
+      const float xl = k > 0 ? p[-1] : f[0], xr = k + 4 < H ? p[4] : f[3];
+      const f32x4 dz = (zp - zm) * cd, dy = (yp - ym) * cw;
+      f32x4 dx;
+      dx[0] = (f[1] - xl) * (k == 0 ? ihh : 0.5f * ihh);
+      dx[1] = (f[2] - f[0]) * (0.5f * ihh);
+      dx[2] = (f[3] - f[1]) * (0.5f * ihh);
+      dx[3] = (xr - f[2]) * (k + 4 == H ? ihh : 0.5f * ihh);
+      const f32x4 t = dz * dz + dy * dy + dx * dx;
+      s += (t[0] + t[1]) + (t[2] + t[3]);
+    }
+    acc += (double)s;
+  }
+  __shared__ double red[4];
+  acc = lr_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(int64_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// gradient along one axis at sample i from the 5-point neighbourhood (values outside the axis are never selected):
+// G(i) = [i>=1] c(i-1) d(i-1) - [i<=n-2] c(i+1) d(i+1) + [i==n-1] c d(n-1) - [i==0] c d(0),  d(q) = c(q)(f[up]-f[dn])
+__device__ __forceinline__ float axis_g5(float fm2, float fm1, float f0, float fp1, float fp2, int i, int n, float ih) {
+  const float h = 0.5f * ih;
+  float g = 0.0f;
+  if (i >= 1) g += (i == 1) ? ih * (ih * (f0 - fm1)) : h * (h * (f0 - fm2));
+  if (i <= n - 2) g -= (i == n - 2) ? ih * (ih * (fp1 - f0)) : h * (h * (fp2 - f0));
+  if (i == n - 1) g += ih * (ih * (f0 - fm1));
+  if (i == 0) g -= ih * (ih * (fp1 - f0));
+  return g;
+}
+
+__global__ __launch_bounds__(256) void disp_reg_bwd_vec_kernel(const float* __restrict__ disp,
+                                                               const float* __restrict__ gout,
+                                                               float* __restrict__ gdisp, int B, int D, int W, int H,
+                                                               float ihd, float ihw, float ihh) {
+  const int64_t V = (int64_t)D * W * H;
+  const float scale = (*gout) * 2.0f / (float)((double)B * (double)V);
+  const unsigned H4 = (unsigned)H >> 2;
+  const unsigned nq = (unsigned)(((int64_t)B * 3 * V) >> 2);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < nq; q += gridDim.x * 256u) {
+    const unsigned row = q / H4;
+    const int k = (int)(q - row * H4) * 4, j = (int)(row % (unsigned)W), i = (int)((row / (unsigned)W) % (unsigned)D);
+    const float* p = disp + (int64_t)q * 4;
+    const int64_t sy = H, sz = (int64_t)W * H;
+    const f32x4 f = *reinterpret_cast<const f32x4*>(p);
+    // the +-1 neighbours only matter next to a face; +-2 everywhere else
+    const bool yb = j < 2 || j > W - 3, zb = i < 2 || i > D - 3;
+    const f32x4 ym2 = j >= 2 ? *reinterpret_cast<const f32x4*>(p - 2 * sy) : zero;
+    const f32x4 yp2 = j <= W - 3 ? *reinterpret_cast<const f32x4*>(p + 2 * sy) : zero;
+    const f32x4 ym1 = (yb && j >= 1) ? *reinterpret_cast<const f32x4*>(p - sy) : zero;
+    const f32x4 yp1 = (yb && j <= W - 2) ? *reinterpret_cast<const f32x4*>(p + sy) : zero;
+    const f32x4 zm2 = i >= 2 ? *reinterpret_cast<const f32x4*>(p - 2 * sz) : zero;
+    const f32x4 zp2 = i <= D - 3 ? *reinterpret_cast<const f32x4*>(p + 2 * sz) : zero;
+    const f32x4 zm1 = (zb && i >= 1) ? *reinterpret_cast<const f32x4*>(p - sz) : zero;
+    const f32x4 zp1 = (zb && i <= D - 2) ? *reinterpret_cast<const f32x4*>(p + sz) : zero;
+    const f32x4 l = k >= 4 ? *reinterpret_cast<const f32x4*>(p - 4) : zero;
+    const f32x4 r = k + 4 < H ? *reinterpret_cast<const f32x4*>(p + 4) : zero;
+    const float e[12] = {l[0], l[1], l[2], l[3], f[0], f[1], f[2], f[3], r[0], r[1], r[2], r[3]};
+    f32x4 g;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      g[t] = axis_g5(zm2[t], zm1[t], f[t], zp1[t], zp2[t], i, D, ihd) +
+             axis_g5(ym2[t], ym1[t], f[t], yp1[t], yp2[t], j, W, ihw) +
+             axis_g5(e[2 + t], e[3 + t], e[4 + t], e[5 + t], e[6 + t], k + t, H, ihh);
+    }
+    *reinterpret_cast<f32x4*>(gdisp + (int64_t)q * 4) = g * scale;
+  }
+}
+
 }  // namespace
 
 extern "C" int lr_disp_reg_bwd_f32(const float* disp, const float* gout, float* gdisp, int B, int D, int W, int H,
@@ -105,7 +203,16 @@ extern "C" int lr_disp_reg_bwd_f32(const float* disp, const float* gout, float* 
   const float ihd = D > 1 ? 0.5f * (float)(D - 1) : 0.0f;
   const float ihw = W > 1 ? 0.5f * (float)(W - 1) : 0.0f;
   const float ihh = H > 1 ? 0.5f * (float)(H - 1) : 0.0f;
-  int64_t nblk = ((int64_t)B * 3 * D * W * H + 255) / 256;
+  const int64_t total = (int64_t)B * 3 * D * W * H;
+  if (H % 4 == 0 && H >= 8 && total / 4 < 0xffffffffLL &&
+      ((reinterpret_cast<uintptr_t>(disp) | reinterpret_cast<uintptr_t>(gdisp)) & 15u) == 0) {
+    int64_t nb = (total / 4 + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(disp_reg_bwd_vec_kernel, dim3((unsigned)nb), dim3(256), 0, lr_stream(stream), disp, gout, gdisp,
+                       B, D, W, H, ihd, ihw, ihh);
+    return lr_launch_status();
+  }
+  int64_t nblk = (total + 255) / 256;
   if (nblk > 8192) nblk = 8192;
   hipLaunchKernelGGL(disp_reg_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, lr_stream(stream), disp, gout, gdisp, B,
                      D, W, H, ihd, ihw, ihh);
@@ -121,8 +228,12 @@ extern "C" int lr_disp_reg_f32(const float* disp, double* partial, float* out, i
   const float ihw = W > 1 ? 0.5f * (float)(W - 1) : 0.0f;
   const float ihh = H > 1 ? 0.5f * (float)(H - 1) : 0.0f;
   hipStream_t st = lr_stream(stream);
-  hipLaunchKernelGGL(disp_reg_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, disp, partial, D,
-                     W, H, ihd, ihw, ihh);
+  if (H % 4 == 0 && H >= 8 && (int64_t)D * W * H / 4 < 0xffffffffLL && (reinterpret_cast<uintptr_t>(disp) & 15u) == 0)
+    hipLaunchKernelGGL(disp_reg_vec_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, disp, partial, D, W,
+                       H, ihd, ihw, ihh);
+  else
+    hipLaunchKernelGGL(disp_reg_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, disp, partial, D,
+                       W, H, ihd, ihw, ihh);
   if (int e = lr_launch_status()) return e;
   hipLaunchKernelGGL(disp_reg_final_kernel, dim3(1), dim3(256), 0, st, partial, out, B * nblk,
                      (double)B * D * W * H);

@@ -135,7 +135,7 @@ def test_conv_block_backward_all_layouts(dev):
 def test_disp_reg_backward(dev):
     from liftreg_amd import ops_bwd
     rs = np.random.RandomState(7)
-    for shape, B in (((6, 7, 9), 2), ((2, 3, 2), 1), ((12, 5, 8), 1)):
+    for shape, B in (((6, 7, 9), 2), ((2, 3, 2), 1), ((12, 5, 8), 1), ((3, 2, 16), 2), ((5, 9, 12), 1), ((2, 4, 8), 1), ((3, 4, 20), 1)):
         disp = rs.normal(0, 0.1, (B, 3) + shape).astype(np.float32)
         d = torch.from_numpy(disp).requires_grad_(True)
         (ro.disp_reg(d) * 0.3).backward()

@@ -19,7 +19,7 @@ def test_subspace_loss_plugin_vs_restatement():
     opt = {"sim_class": "liftreg_amd.layers.losses.NCCLoss", "initial_reg_factor": 0.01, "min_reg_factor": 0.01,
            "reg_factor_decay_from": 2}                                   # cur_task_setting.json:47-52
     f = cls(opt)
-    for shape, B in (((12, 10, 14), 2), ((9, 16, 33), 1), ((2, 2, 2), 3)):
+    for shape, B in (((12, 10, 14), 2), ((9, 16, 33), 1), ((2, 2, 2), 3), ((7, 5, 16), 2), ((2, 3, 8), 1), ((4, 2, 12), 1)):
         warped = rs.uniform(-1, 1, (B, 1) + shape).astype(np.float32)
         target = (0.7 * warped + 0.3 * rs.uniform(-1, 1, warped.shape)).astype(np.float32)
         disp = rs.normal(0, 0.05, (B, 3) + shape).astype(np.float32)
