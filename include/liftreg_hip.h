@@ -242,20 +242,26 @@ int lr_linear_bwd_f32(const float* x, const float* w, const float* y, const floa
  *     gb_partial: nblk*C floats of workspace).  D,W,H = the block's OUTPUT size.
  *  2. lr_conv3d_dgrad_f32 (stride-2 blocks): gx (B,D,W,H,Cx) NDHWC from gpre (B,Do,Wo,Ho,Cg) NDHWC and
  *     packed_wT = lr_conv3d_pack_weights_f32 of the weight TRANSPOSED to (Cin,Cout,3,3,3), layout NDHWC.
- *     D,W,H = the block's INPUT size; Cx = Cin in {16,32}.
- *  3. lr_conv3d_wgrad_f32: gw (Cout,Cin,3,3,3) from the block's saved input x (any layout) and gpre.
- *     partial: lr_conv3d_wgrad_partial_floats(...) floats of workspace; nblk persistent blocks. */
+ *     D,W,H = the block's INPUT size; Cx = Cin in {16,32}.  x_saved (nullable): the block's saved input,
+ *     i.e. the PRODUCER block's LeakyReLU output, in x_layout (NDHWC | NDHWC_HPS); when given, the result
+ *     is multiplied by (x_saved > 0 ? 1 : negative_slope) in the epilogue — it is then the producer's gpre
+ *     and step 1 is skipped for the producer (write it as plain NDHWC: gx_layout = LR_LAYOUT_NDHWC).
+ *  3. lr_conv3d_wgrad_f32: gw (Cout,Cin,3,3,3) from the block's saved input x (any layout) and gpre;
+ *     gb (Cout, nullable) = sum of gpre over voxels (the bias gradient; free on the fast paths — a spare
+ *     MFMA column multiplies by ones).  partial: lr_conv3d_wgrad_partial_floats(...) floats of workspace;
+ *     nblk persistent blocks. */
 int lr_lrelu_bwd_f32(const float* gy, int gy_layout, const float* y, int y_layout, float* gpre,
                      float* gb_partial, float* gb, int B, int C, int D, int W, int H,
                      float negative_slope, int nblk, void* stream);
 int lr_conv3d_dgrad_f32(const float* gpre, const float* packed_wT, float* gx, int B, int Cg, int Cx,
-                        int D, int W, int H, int stride, int gx_layout /* NDHWC | NDHWC_HPS */, void* stream);
+                        int D, int W, int H, int stride, int gx_layout /* NDHWC | NDHWC_HPS */,
+                        const float* x_saved, int x_layout, float negative_slope, void* stream);
 /* Gradient of lr_disp_reg_f32 w.r.t. disp (gout = dev pointer to the upstream scalar gradient). */
 int lr_disp_reg_bwd_f32(const float* disp, const float* gout, float* gdisp, int B, int D, int W, int H,
                         void* stream);
 int64_t lr_conv3d_wgrad_partial_floats(int Cin, int Cout, int x_layout, int nblk);
 int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gpre, float* partial, float* gw,
-                        int B, int Cin, int Cout, int D, int W, int H, int stride, int nblk,
+                        float* gb, int B, int Cin, int Cout, int D, int W, int H, int stride, int nblk,
                         void* stream);
 
 #ifdef __cplusplus

@@ -46,10 +46,10 @@ SIGNATURES = {
     "lr_pca_bwd_coef_f32": (_i, [_p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _i, _p]),
     "lr_linear_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p]),
     "lr_lrelu_bwd_f32": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
-    "lr_conv3d_dgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "lr_conv3d_dgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _f, _p]),
     "lr_disp_reg_bwd_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "lr_conv3d_wgrad_partial_floats": (_i64, [_i, _i, _i, _i]),
-    "lr_conv3d_wgrad_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "lr_conv3d_wgrad_f32": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
 }
 
 

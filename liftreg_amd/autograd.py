@@ -10,27 +10,35 @@ from . import _hip, ops, ops_bwd
 
 
 class ConvBlockFn(torch.autograd.Function):
-    """LeakyReLU(Conv3d k3 p1 (x) + b) in any of the activation layouts."""
+    """LeakyReLU(Conv3d k3 p1 (x) + b) in any of the activation layouts.
+
+    `premasked_grad`: the gradient this block receives already went through this block's LeakyReLU mask (the
+    consumer block applied it in its data-gradient epilogue) and is plain NDHWC.  `mask_input_slope`: this block
+    is such a consumer — its input is the producer block's LeakyReLU output with that slope.  The model sets the
+    two consistently along the encoder chain; a stand-alone convBlock uses neither.
+    """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, in_layout, out_layout, slope, packed):
+    def forward(ctx, x, weight, bias, stride, in_layout, out_layout, slope, packed, premasked_grad=False,
+                mask_input_slope=None):
         y = ops.conv3d_k3_lrelu(x, weight, bias, stride, in_layout=in_layout, out_layout=out_layout,
                                 negative_slope=slope, packed=packed)
         ctx.save_for_backward(x, weight, y)
-        ctx.cfg = (stride, in_layout, out_layout, slope, bias is not None)
+        ctx.cfg = (stride, in_layout, out_layout, slope, bias is not None, premasked_grad, mask_input_slope)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, weight, y = ctx.saved_tensors
-        stride, in_layout, out_layout, slope, has_bias = ctx.cfg
+        stride, in_layout, out_layout, slope, has_bias, premasked, in_slope = ctx.cfg
         need_gx = ctx.needs_input_grad[0]
         if need_gx and (in_layout == _hip.LAYOUT_NCDHW or stride != 2):
             raise NotImplementedError("data gradient is built for the channels-last stride-2 blocks only "
                                       "(the encoder's first block receives data, not activations)")
         gx, gw, gb = ops_bwd.conv3d_bwd(x, in_layout, weight, y, out_layout, gy.contiguous(), out_layout, stride,
-                                        slope, need_gx=need_gx)
-        return gx, gw, (gb if has_bias else None), None, None, None, None, None
+                                        slope, need_gx=need_gx, gy_is_gpre=premasked,
+                                        mask_input_slope=in_slope if need_gx else None)
+        return gx, gw, (gb if has_bias else None), None, None, None, None, None, None, None
 
 
 class LinearFn(torch.autograd.Function):

@@ -84,13 +84,16 @@ struct DgDims {
   int B, Cg, Cx, D, W, H, Do, Wo, Ho;  // gx is (B,D,W,H,Cx); gpre is (B,Do,Wo,Ho,Cg)
   int nHq, nWq, nDq;
   int gx_layout;  // LR_LAYOUT_NDHWC or LR_LAYOUT_NDHWC_HPS (the layout of the block's saved input)
+  int xs_layout;  // layout of xsave (the block's saved input = the producer block's activation)
+  float slope;    // the producer's LeakyReLU slope (used when xsave != nullptr)
 };
 constexpr int DMT = 4;
 
 template <int NT>
 __global__ __launch_bounds__(256) void conv3d_dgrad_kernel(const float* __restrict__ gpre,
                                                            const float4* __restrict__ wp,
-                                                           float* __restrict__ gx, DgDims d) {
+                                                           float* __restrict__ gx,
+                                                           const float* __restrict__ xsave, DgDims d) {
   // a block walks the 8 parity classes of its tile back to back (they read the same gpre tile and together fill
   // one 8 x 8 x 32 brick of gx), the 8-tap class first
   unsigned t = lr_xcd_remap(blockIdx.x, gridDim.x);
@@ -123,6 +126,23 @@ __global__ __launch_bounds__(256) void conv3d_dgrad_kernel(const float* __restri
   const unsigned xinv0 = (x < d.H && xq < d.Ho) ? 0u : OOR;
   const unsigned xinv1 = (x < d.H && xq + 1 < d.Ho) ? 0u : OOR;
 
+  // the producer's activation at this class's voxels (mask of the fused epilogue), in flight during the k-loop
+  f32x4 xv[DMT][NT];
+  if (xsave) {
+#pragma unroll
+    for (int mt = 0; mt < DMT; ++mt) {
+      const int y = 2 * (yq0 + mt) + py;
+      const bool ok = x < d.H && y < d.W;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int64_t row = (((int64_t)b * d.D + z) * d.W + (ok ? y : 0)) * d.H * d.Cx;
+        const int64_t xo = d.xs_layout == LR_LAYOUT_NDHWC
+                               ? row + (int64_t)(ok ? x : 0) * d.Cx + nt * 16 + kq * 4
+                               : row + ((int64_t)nt * d.H + (ok ? px * (d.H >> 1) + xq : 0)) * 16 + kq * 4;
+        xv[mt][nt] = *reinterpret_cast<const f32x4*>(xsave + xo);
+      }
+    }
+  }
   const int NS = (1 << (px + py + pz)) * CB;
   auto load_step = [&](int s, float4 (&a)[DMT], float4 (&bw)[NT]) {
     const int tapi = s / CB, cb = s - tapi * CB;
@@ -176,7 +196,12 @@ __global__ __launch_bounds__(256) void conv3d_dgrad_kernel(const float* __restri
           const int64_t o = d.gx_layout == LR_LAYOUT_NDHWC
                                 ? row + (int64_t)x * d.Cx + nt * 16 + kq * 4
                                 : row + ((int64_t)nt * d.H + (px * (d.H >> 1) + xq)) * 16 + kq * 4;
-          *reinterpret_cast<f32x4*>(gx + o) = acc[mt][nt];
+          f32x4 v = acc[mt][nt];
+          if (xsave) {  // gradient through the producer's LeakyReLU: its output is this block's saved input
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = xv[mt][nt][r] > 0.0f ? v[r] : v[r] * d.slope;
+          }
+          *reinterpret_cast<f32x4*>(gx + o) = v;
         }
     }
   }
@@ -303,11 +328,12 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
                                                                  float* __restrict__ partial, WgDims d, int nbricks) {
   using G = WclGeom<CB, NTC>;
   constexpr int Cin = CB * 16, Cout = NTC * 16, HB = G::HB;
-  __shared__ __attribute__((aligned(16))) float xs[G::XF4 * 4];
+  __shared__ __attribute__((aligned(16))) float xs[G::XF4 * 4 + HB * 16];  // + a tile of ones (bias gradient)
   __shared__ __attribute__((aligned(16))) float gs[HB * NTC * 16];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nseg = (d.Ho + HB - 1) / HB;
+  for (int i = tid; i < HB * 16; i += G::NTH) xs[G::XF4 * 4 + i] = 1.0f;
 
   // staging slots: chunk q = it*256 + tid of the window, decoded once (brick-independent)
   unsigned xrel[G::XIT];
@@ -331,10 +357,12 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
   int boff[G::T];
 #pragma unroll
   for (int t = 0; t < G::T; ++t) {
-    const int j = min(wave + G::NW * t, 27 * CB - 1);
+    const int jr = wave + G::NW * t;  // tile 27*CB (one spare slot exists) multiplies by ones: sum of gpre = gb
+    const int j = min(jr, 27 * CB - 1);
     const int tap = j / CB, cb = j % CB;
     const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
-    boff[t] = (((tz * 3 + ty) * CB + cb) * G::NCP + (tx == 1 ? HB + 1 : (tx >> 1))) * 16 + lane;
+    boff[t] = (jr == 27 * CB ? G::XF4 * 4
+                             : (((tz * 3 + ty) * CB + cb) * G::NCP + (tx == 1 ? HB + 1 : (tx >> 1))) * 16) + lane;
   }
   f32x4 acc[G::T][NTC];
 #pragma unroll
@@ -399,11 +427,11 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
     }
   }
   const int col = lane & 15, kq = lane >> 4;
-  const int ncols = 27 * CB * 16;
+  const int ncols = (27 * CB + 1) * 16;
 #pragma unroll
   for (int t = 0; t < G::T; ++t) {
     const int j = wave + G::NW * t;
-    if (j < 27 * CB) {
+    if (j <= 27 * CB) {
 #pragma unroll
       for (int nt = 0; nt < NTC; ++nt)
 #pragma unroll
@@ -435,11 +463,12 @@ __global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_ke
                                                                      float* __restrict__ partial, WgDims d,
                                                                      int nbricks) {
   using G = WplGeom<NTL>;
-  __shared__ __attribute__((aligned(16))) float xs[G::XF4 * 4];
+  __shared__ __attribute__((aligned(16))) float xs[G::XF4 * 4 + 80];  // + ones (the bias-gradient column)
   __shared__ __attribute__((aligned(16))) float gs[4 * G::GP];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, kq = lane >> 4;
+  if (tid < 80) xs[G::XF4 * 4 + tid] = 1.0f;
   const int64_t V = (int64_t)d.D * d.W * d.H;
   const int nH = (d.H + 63) / 64, nW = (d.W + 3) / 4;
 
@@ -458,10 +487,11 @@ __global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_ke
 #pragma unroll
   for (int j = 0; j < NTL; ++j) {
     int c = j * 16 + col;
-    if (c >= 27 * d.Cin) c = 0;  // unused column: computed, never stored
+    const bool ones = c == 27 * d.Cin;  // the first spare column multiplies by ones: sum of gpre = gb
+    if (c >= 27 * d.Cin) c = 0;         // other unused columns: computed, never read
     const int ci = c / 27, tap = c % 27;
     const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
-    bbase[j] = ci * G::CS + (tz * 6 + ty + wave) * G::RS + tx + 3 + 4 * kq;
+    bbase[j] = ones ? G::XF4 * 4 + 4 * kq : ci * G::CS + (tz * 6 + ty + wave) * G::RS + tx + 3 + 4 * kq;
   }
   f32x4 acc[NTL];
 #pragma unroll
@@ -535,8 +565,8 @@ __global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_ke
 }
 
 // partial[k][co][n] summed over the nblk partials in double (fixed order), column n -> (ci, tap) of gw
-__global__ void wgrad_finish_kernel(const float* __restrict__ partial, float* __restrict__ gw, int nblk, int Cout,
-                                    int Cin, int ncols, int x_layout) {
+__global__ void wgrad_finish_kernel(const float* __restrict__ partial, float* __restrict__ gw, float* __restrict__ gb,
+                                    int nblk, int Cout, int Cin, int ncols, int x_layout, int gb_col) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;  // (co, n): consecutive threads read consecutive floats
   if (t >= Cout * ncols) return;
   const int co = t / ncols, n = t - co * ncols;
@@ -547,11 +577,30 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ partial, float* __
     const int cbn = (Cin + 15) >> 4, j = n >> 4;
     tap = j / cbn; ci = (j - tap * cbn) * 16 + (n & 15);
   }
-  if (ci >= Cin || tap >= 27) return;
+  const bool is_gb = gb != nullptr && n == gb_col;  // the ones column of the fast paths
+  if (!is_gb && (ci >= Cin || tap >= 27)) return;
   double s = 0.0;
   const int64_t step = (int64_t)Cout * ncols;
   for (int k = 0; k < nblk; ++k) s += (double)partial[k * step + t];
-  gw[((int64_t)co * Cin + ci) * 27 + tap] = (float)s;
+  if (is_gb) gb[co] = (float)s;
+  else gw[((int64_t)co * Cin + ci) * 27 + tap] = (float)s;
+}
+
+// bias gradient on the generic path: per-block channel sums of gpre (B*V, C) -> partial -> sum_partials_kernel
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ gpre, float* __restrict__ partial,
+                                                          int64_t nvox, int C) {
+  __shared__ float red[256];
+  const int c = threadIdx.x % C, lanes = 256 / C;  // C in {16, 32}
+  double s = 0.0;
+  for (int64_t v = (int64_t)blockIdx.x * lanes + threadIdx.x / C; v < nvox; v += (int64_t)gridDim.x * lanes)
+    s += (double)gpre[v * C + c];
+  red[threadIdx.x] = (float)s;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float t = 0.0f;
+    for (int i = threadIdx.x; i < 256; i += C) t += red[i];
+    partial[(int64_t)blockIdx.x * C + threadIdx.x] = t;
+  }
 }
 
 }  // namespace
@@ -576,7 +625,8 @@ extern "C" int lr_lrelu_bwd_f32(const float* gy, int gy_layout, const float* y, 
 }
 
 extern "C" int lr_conv3d_dgrad_f32(const float* gpre, const float* packed_wT, float* gx, int B, int Cg, int Cx,
-                                   int D, int W, int H, int stride, int gx_layout, void* stream) {
+                                   int D, int W, int H, int stride, int gx_layout, const float* x_saved,
+                                   int x_layout, float negative_slope, void* stream) {
   if (!gpre || !packed_wT || !gx) return LR_ENULL;
   if (stride != 2) return LR_EUNSUPPORTED;  // blocks 1..5; block 0's input needs no gradient
   if (Cx != 16 && Cx != 32) return LR_EUNSUPPORTED;
@@ -590,23 +640,28 @@ extern "C" int lr_conv3d_dgrad_f32(const float* gpre, const float* packed_wT, fl
   if ((int64_t)d.Do * d.Wo * d.Ho * Cg * 4 >= 0x7fffffffLL) return LR_EINVAL;  // 31-bit buffer offsets per batch element
   d.nHq = ((H + 1) / 2 + 15) / 16; d.nWq = ((W + 1) / 2 + DMT - 1) / DMT; d.nDq = ((D + 1) / 2 + 3) / 4;
   d.gx_layout = gx_layout;
+  if (x_saved && x_layout != LR_LAYOUT_NDHWC && x_layout != LR_LAYOUT_NDHWC_HPS) return LR_EINVAL;
+  if (x_saved && x_layout == LR_LAYOUT_NDHWC_HPS && (H & 1)) return LR_EUNSUPPORTED;
+  if (x_saved && (reinterpret_cast<uintptr_t>(x_saved) & 15u)) return LR_EALIGN;
+  d.xs_layout = x_layout; d.slope = negative_slope;
   const int64_t nblk = (int64_t)B * d.nDq * d.nWq * d.nHq;  // tiles of 4 x 4 x 16 voxels per parity class
   if (nblk > 0x7fffffffLL) return LR_EINVAL;
   const float4* wt = reinterpret_cast<const float4*>(packed_wT);
   hipStream_t st = lr_stream(stream);
-  if (Cx == 16) hipLaunchKernelGGL(conv3d_dgrad_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, gpre, wt, gx, d);
-  else hipLaunchKernelGGL(conv3d_dgrad_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, gpre, wt, gx, d);
+  if (Cx == 16) hipLaunchKernelGGL(conv3d_dgrad_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, gpre, wt, gx, x_saved, d);
+  else hipLaunchKernelGGL(conv3d_dgrad_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, gpre, wt, gx, x_saved, d);
   return lr_launch_status();
 }
 
 extern "C" int64_t lr_conv3d_wgrad_partial_floats(int Cin, int Cout, int x_layout, int nblk) {
-  const int ntiles = x_layout == LR_LAYOUT_NCDHW ? (Cin * 27 + 15) / 16 : 27 * ((Cin + 15) / 16);
-  // the planar fast path keeps one partial per WAVE (its waves split the voxels): 4 per block
+  // planar: ceil((27*Cin + 1)/16) tiles (one spare column carries the bias gradient), one partial per WAVE of
+  // the fast path (its waves split the voxels); channels-last: 27*ceil(Cin/16) tiles + the ones tile
+  const int ntiles = x_layout == LR_LAYOUT_NCDHW ? (Cin * 27 + 16) / 16 : 27 * ((Cin + 15) / 16) + 1;
   return (int64_t)nblk * (x_layout == LR_LAYOUT_NCDHW ? 4 : 1) * Cout * ntiles * 16;
 }
 
 extern "C" int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gpre, float* partial, float* gw,
-                                   int B, int Cin, int Cout, int D, int W, int H, int stride, int nblk,
+                                   float* gb, int B, int Cin, int Cout, int D, int W, int H, int stride, int nblk,
                                    void* stream) {
   if (!x || !gpre || !partial || !gw) return LR_ENULL;
   if (B < 1 || Cin < 1 || D < 1 || W < 1 || H < 1 || nblk < 1 || nblk > 65535) return LR_EINVAL;
@@ -656,16 +711,30 @@ extern "C" int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gp
   }
   if (nparts) {
     if (int e = lr_launch_status()) return e;
-    const int n = Cout * d.ntiles * 16;
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, partial, gw, nparts, Cout, Cin,
-                       d.ntiles * 16, x_layout);
+    // fast-path partials carry one extra column/tile: the sum of gpre (bias gradient)
+    const int planar = x_layout == LR_LAYOUT_NCDHW;
+    const int ncols = planar ? d.ntiles * 16 : (d.ntiles + 1) * 16;
+    const int n = Cout * ncols;
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, partial, gw, gb, nparts, Cout, Cin,
+                       ncols, x_layout, planar ? 27 * Cin : d.ntiles * 16);
     return lr_launch_status();
   }
   if (Cout == 16) hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, x, gpre, partial, d, ngroups);
   else hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, x, gpre, partial, d, ngroups);
   if (int e = lr_launch_status()) return e;
   const int n = Cout * d.ntiles * 16;
-  hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, partial, gw, nblk, Cout, Cin,
-                     d.ntiles * 16, x_layout);
-  return lr_launch_status();
+  hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, partial, gw, (float*)nullptr, nblk,
+                     Cout, Cin, d.ntiles * 16, x_layout, -1);
+  if (int e = lr_launch_status()) return e;
+  if (gb) {  // generic path: the bias gradient from its own reduction (partial is free again: stream order)
+    const int64_t nvox = (int64_t)B * d.Do * d.Wo * d.Ho;
+    int64_t cap = (int64_t)nblk * d.ntiles * 16;  // rows of Cout floats the workspace holds
+    if (cap > 1024) cap = 1024;
+    const int nb = (int)(nvox < cap ? nvox : cap);
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(nb), dim3(256), 0, st, gpre, partial, nvox, Cout);
+    if (int e = lr_launch_status()) return e;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, gb, nb, Cout);
+    return lr_launch_status();
+  }
+  return LR_OK;
 }

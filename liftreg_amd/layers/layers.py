@@ -32,6 +32,9 @@ class convBlock(nn.Module):
         self.residual = None
         self.stride = stride
         self.in_layout, self.out_layout = in_layout, out_layout
+        # backward chaining inside an encoder (set by the model, see autograd.ConvBlockFn)
+        self.premasked_grad = False
+        self.mask_input_slope = None
         if nonlinear is None:
             self._slope = 1.0
         elif isinstance(nonlinear, nn.LeakyReLU):
@@ -41,7 +44,7 @@ class convBlock(nn.Module):
 
     def forward(self, x, packed=None):
         return ConvBlockFn.apply(x, self.conv.weight, self.conv.bias, self.stride, self.in_layout, self.out_layout,
-                                 self._slope, packed)
+                                 self._slope, packed, self.premasked_grad, self.mask_input_slope)
 
 
 class FullyConnectBlock(nn.Module):

@@ -63,6 +63,11 @@ class model(nn.Module):
             lay_out = ops.LAYOUT_NCDHW if i == last else (ops.LAYOUT_NDHWC_HPS if h_out % 2 == 0 else ops.LAYOUT_NDHWC)
             self.encoders.append(convBlock(cin, f, stride=self.strides[i], bias=True, in_layout=lay_in,
                                            out_layout=lay_out))
+        # backward chaining: block i+1's data gradient applies block i's LeakyReLU mask in its epilogue and hands
+        # block i its pre-activation gradient directly (one pass over the big activations less per block)
+        for i in range(last):
+            self.encoders[i].premasked_grad = True
+            self.encoders[i + 1].mask_input_slope = self.encoders[i]._slope
         flat = enc_filters[-1] * int(np.prod([_out_size(n, self.strides) for n in self.img_sz]))
         self.encoders.append(nn.Sequential(
             nn.Flatten(),

@@ -70,46 +70,63 @@ def _act_dims(t, layout):
 
 
 def conv3d_bwd(x, x_layout, weight, y, y_layout, gy, gy_layout, stride, negative_slope=0.2, need_gx=True,
-               nblk=512):
+               nblk=512, gy_is_gpre=False, mask_input_slope=None):
     """Backward of ops.conv3d_k3_lrelu.  x / y: the block's saved input / output (any layout), gy: gradient of
-    the output.  Returns (gx (B,D,W,H,Cin) in x's own channels-last layout or None, gw (Cout,Cin,3,3,3), gb (Cout))."""
+    the output.  Returns (gx, gw (Cout,Cin,3,3,3), gb (Cout)); gx is (B,D,W,H,Cin) in x's own channels-last
+    layout, or None.
+
+    Chaining across blocks (what the model does): with `mask_input_slope` = the PRODUCER block's LeakyReLU slope,
+    the data-gradient epilogue also applies the producer's mask (its output is this block's saved input), so the
+    returned gx is the producer's pre-activation gradient in plain NDHWC; the producer then passes it with
+    `gy_is_gpre=True` and skips its own mask pass.  The bias gradient comes out of the weight-gradient kernel.
+    """
     x, y, gy = _dev(x, "x"), _dev(y, "y"), _dev(gy, "gy")
     w = _dev(weight.detach(), "weight")
     Cout, Cin = w.shape[0], w.shape[1]
     B, Cx, D, W, H = _act_dims(x, x_layout)
     _, Cy, Do, Wo, Ho = _act_dims(y, y_layout)
+    if gy_is_gpre:
+        gy_layout = _hip.LAYOUT_NDHWC
     if Cx != Cin or Cy != Cout or _act_dims(gy, gy_layout) != (B, Cout, Do, Wo, Ho):
         raise ValueError("conv3d_bwd: shape mismatch")
     dev = x.device
     lib = _hip.lib()
-    # 1. LeakyReLU mask (+ bias gradient) → gpre, plain NDHWC
-    gpre = torch.empty((B, Do, Wo, Ho, Cout), dtype=torch.float32, device=dev)
-    nb1 = max(1, min(1024, (gpre.numel() // 4 + 255) // 256))
-    gb_part = torch.empty((nb1, Cout), dtype=torch.float32, device=dev)
-    gb = torch.empty((Cout,), dtype=torch.float32, device=dev)
-    with _timed(f"lrelu_bwd_c{Cout}_{Do}", bytes=12 * gpre.numel()):
-        _hip.check(lib.lr_lrelu_bwd_f32(gy.data_ptr(), gy_layout, y.data_ptr(), y_layout, gpre.data_ptr(),
-                                        gb_part.data_ptr(), gb.data_ptr(), B, Cout, Do, Wo, Ho, float(negative_slope),
-                                        nb1, _stream()), "lr_lrelu_bwd_f32")
+    # 1. LeakyReLU mask → gpre, plain NDHWC (skipped when the consumer block's data gradient already applied it)
+    if gy_is_gpre:
+        gpre = gy
+    else:
+        gpre = torch.empty((B, Do, Wo, Ho, Cout), dtype=torch.float32, device=dev)
+        nb1 = max(1, min(1024, (gpre.numel() // 4 + 255) // 256))
+        with _timed(f"lrelu_bwd_c{Cout}_{Do}", bytes=12 * gpre.numel()):
+            _hip.check(lib.lr_lrelu_bwd_f32(gy.data_ptr(), gy_layout, y.data_ptr(), y_layout, gpre.data_ptr(),
+                                            None, None, B, Cout, Do, Wo, Ho, float(negative_slope), nb1, _stream()),
+                       "lr_lrelu_bwd_f32")
     # 2. data gradient (stride-2 blocks only; the encoder's first block has no input gradient)
     gx = None
     if need_gx:
         from .ops import conv3d_pack_weights
         packed_t = conv3d_pack_weights(w.transpose(0, 1).contiguous(), _hip.LAYOUT_NDHWC)
         gx = torch.empty((B, D, W, H, Cin), dtype=torch.float32, device=dev)
+        fuse = mask_input_slope is not None
+        if fuse and x_layout == _hip.LAYOUT_NCDHW:
+            raise ValueError("mask_input_slope needs a channels-last saved input")
+        gxl = _hip.LAYOUT_NDHWC if (fuse or x_layout == _hip.LAYOUT_NCDHW) else x_layout
         with _timed(f"conv3d_dgrad_c{Cout}x{Cin}_{D}", flops=2.0 * 27 * Cin * Cout * B * Do * Wo * Ho,
-                    bytes=4 * (gpre.numel() + gx.numel())):
-            gxl = x_layout if x_layout != _hip.LAYOUT_NCDHW else _hip.LAYOUT_NDHWC   # grad in the layout of x itself
+                    bytes=4 * (gpre.numel() + gx.numel() * (2 if fuse else 1))):
             _hip.check(lib.lr_conv3d_dgrad_f32(gpre.data_ptr(), packed_t.data_ptr(), gx.data_ptr(), B, Cout, Cin, D, W,
-                                               H, stride, gxl, _stream()), "lr_conv3d_dgrad_f32")
-    # 3. weight gradient
+                                               H, stride, gxl, x.data_ptr() if fuse else None, x_layout,
+                                               float(mask_input_slope) if fuse else 1.0, _stream()),
+                       "lr_conv3d_dgrad_f32")
+    # 3. weight gradient (+ bias gradient)
     npart = lib.lr_conv3d_wgrad_partial_floats(Cin, Cout, x_layout, nblk)
     partial = torch.empty((npart,), dtype=torch.float32, device=dev)
     gw = torch.empty_like(w)
+    gb = torch.empty((Cout,), dtype=torch.float32, device=dev)
     with _timed(f"conv3d_wgrad_c{Cin}x{Cout}_{D}", flops=2.0 * 27 * Cin * Cout * B * Do * Wo * Ho,
                 bytes=4 * (x.numel() + gpre.numel())):
         _hip.check(lib.lr_conv3d_wgrad_f32(x.data_ptr(), x_layout, gpre.data_ptr(), partial.data_ptr(), gw.data_ptr(),
-                                           B, Cin, Cout, D, W, H, stride, nblk, _stream()), "lr_conv3d_wgrad_f32")
+                                           gb.data_ptr(), B, Cin, Cout, D, W, H, stride, nblk, _stream()),
+                   "lr_conv3d_wgrad_f32")
     return gx, gw, gb
 
 

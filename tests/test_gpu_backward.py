@@ -130,6 +130,15 @@ def test_conv_block_backward_all_layouts(dev):
             gx_plain = ops.hps_to_ndhwc(gx) if xl == L.LAYOUT_NDHWC_HPS else gx        # grad comes in x's own layout
             np.testing.assert_allclose(gx_plain.permute(0, 4, 1, 2, 3).cpu().numpy(), xt.grad.numpy(), rtol=2e-4, atol=2e-5,
                                        err_msg="gx " + tag)
+            # chained form the model uses: the incoming gradient is already this block's gpre (plain NDHWC), and the
+            # data-gradient epilogue applies the PRODUCER's LeakyReLU mask (sign of this block's saved input)
+            gpre = torch.where(T(yref.detach().numpy(), dev) > 0, T(gy, dev), 0.2 * T(gy, dev))
+            gx2, gw2, gb2 = ops_bwd.conv3d_bwd(xd, xl, T(w, dev), yd, yl, to_layout(gpre, L.LAYOUT_NDHWC), None, s,
+                                               nblk=8, gy_is_gpre=True, mask_input_slope=0.3)
+            want = np.where(x > 0, xt.grad.numpy(), 0.3 * xt.grad.numpy())
+            np.testing.assert_allclose(gx2.permute(0, 4, 1, 2, 3).cpu().numpy(), want, rtol=2e-4, atol=2e-5, err_msg="gx2 " + tag)
+            np.testing.assert_allclose(gw2.cpu().numpy(), wt.grad.numpy(), rtol=2e-4, atol=2e-5, err_msg="gw2 " + tag)
+            np.testing.assert_allclose(gb2.cpu().numpy(), bt.grad.numpy(), rtol=2e-4, atol=2e-5, err_msg="gb2 " + tag)
 
 
 def test_disp_reg_backward(dev):
