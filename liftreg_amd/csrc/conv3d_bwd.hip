@@ -208,6 +208,146 @@ __global__ __launch_bounds__(256) void conv3d_dgrad_kernel(const float* __restri
   }  // parity classes
 }
 
+// LDS-staged variant (Cg in {16,32}): the (4+1) x (4+1) x (16+1) gpre voxels a tile needs are loaded ONCE
+// (bounds-checked: rows/columns past the gradient read 0) and every (class, tap) operand is a conflict-free
+// ds_read_b128 — the direct-load kernel above re-fetches each gpre voxel up to 27 times through the L1.
+// The two classes that differ in px are computed back to back and stored together, so a plain-NDHWC gx receives
+// both 64-byte halves of a 128-byte line from the same wave.
+template <int NT, int CB>
+__global__ __launch_bounds__(256, 2) void conv3d_dgrad_lds_kernel(const float* __restrict__ gpre,
+                                                                  const float4* __restrict__ wp,
+                                                                  float* __restrict__ gx,
+                                                                  const float* __restrict__ xsave, DgDims d) {
+  constexpr int CG = CB * 16, VS = CG + 4, C4 = CG / 4, NVOX = 5 * 5 * 17, NCH = NVOX * C4;
+  constexpr int NIT = (NCH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float ts[NVOX * VS];
+  unsigned t = lr_xcd_remap(blockIdx.x, gridDim.x);
+  const int hq = t % d.nHq; t /= d.nHq;
+  const int wq = t % d.nWq; t /= d.nWq;
+  const int dq = t % d.nDq;
+  const int b = t / d.nDq;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int zq0 = dq * 4, yq0 = wq * DMT, xq0 = hq * 16;
+  {
+    const float* base = gpre + (int64_t)b * d.Do * d.Wo * d.Ho * CG;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, 0x7fffffff, 0x00020000);
+    float4 st[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = it * 256 + tid;
+      const int vox = q / C4, c4 = q % C4;
+      const int xx = vox % 17, r = vox / 17, yy = r % 5, zz = r / 5;
+      const int zs = zq0 + zz, ys = yq0 + yy, xs = xq0 + xx;
+      const bool ok = q < NCH && zs < d.Do && ys < d.Wo && xs < d.Ho;
+      const unsigned voff = ok ? (unsigned)(((((zs * d.Wo) + ys) * d.Ho + xs) * CG + c4 * 4) * 4) : OOR;
+      st[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = it * 256 + tid;
+      if (q < NCH) *reinterpret_cast<float4*>(ts + (q / C4) * VS + (q % C4) * 4) = st[it];
+    }
+  }
+  __syncthreads();
+  const int zq = zq0 + wave;
+  const int col = lane & 15, kq = lane >> 4;
+  const int xq = xq0 + col;
+  const float* lts = ts + col * VS + kq * 4;
+  float4 a0[DMT], a1[DMT], b0[NT], b1[NT];
+  for (int pp = 3; pp >= 0; --pp) {
+    const int py = pp & 1, pz = pp >> 1;
+    const int z = 2 * zq + pz;
+    if (z >= d.D) continue;  // wave-uniform; no barrier below
+    f32x4 accp[2][DMT][NT];
+    f32x4 xv[2][DMT][NT];
+#pragma unroll
+    for (int px = 1; px >= 0; --px) {
+      const int x = 2 * xq + px;
+      if (xsave) {
+#pragma unroll
+        for (int mt = 0; mt < DMT; ++mt) {
+          const int y = 2 * (yq0 + mt) + py;
+          const bool ok = x < d.H && y < d.W;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int64_t row = (((int64_t)b * d.D + z) * d.W + (ok ? y : 0)) * d.H * d.Cx;
+            const int64_t xo = d.xs_layout == LR_LAYOUT_NDHWC
+                                   ? row + (int64_t)(ok ? x : 0) * d.Cx + nt * 16 + kq * 4
+                                   : row + ((int64_t)nt * d.H + (ok ? px * (d.H >> 1) + xq : 0)) * 16 + kq * 4;
+            xv[px][mt][nt] = *reinterpret_cast<const f32x4*>(xsave + xo);
+          }
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < DMT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) accp[px][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int NS = (1 << (px + py + pz)) * CB;
+      auto load_step = [&](int s, float4 (&a)[DMT], float4 (&bw)[NT]) {
+        const int tapi = s / CB, cb = s - tapi * CB;
+        const int ix = tapi & px, r1 = tapi >> px, iy = r1 & py, iz = (r1 >> py) & pz;
+        const int tx = px ? 2 * ix : 1, ox = px ? 1 - ix : 0;
+        const int ty = py ? 2 * iy : 1, oy = py ? 1 - iy : 0;
+        const int tz = pz ? 2 * iz : 1, oz = pz ? 1 - iz : 0;
+        const int sfull = ((tz * 3 + ty) * 3 + tx) * CB + cb;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bw[nt] = wp[((int64_t)sfull * NT + nt) * 64 + lane];
+        const float* src = lts + (((wave + oz) * 5 + oy) * 17 + ox) * VS + cb * 16;
+#pragma unroll
+        for (int mt = 0; mt < DMT; ++mt) a[mt] = *reinterpret_cast<const float4*>(src + mt * 17 * VS);
+      };
+      auto mfma_step = [&](const float4 (&a)[DMT], const float4 (&bw)[NT]) {
+#pragma unroll
+        for (int mt = 0; mt < DMT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            f32x4 c = accp[px][mt][nt];
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[nt].x, a[mt].x, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[nt].y, a[mt].y, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[nt].z, a[mt].z, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[nt].w, a[mt].w, c, 0, 0, 0);
+            accp[px][mt][nt] = c;
+          }
+      };
+      load_step(0, a0, b0);
+      for (int s2 = 0; s2 + 1 < NS; s2 += 2) {
+        load_step(s2 + 1, a1, b1);
+        mfma_step(a0, b0);
+        load_step(min(s2 + 2, NS - 1), a0, b0);
+        mfma_step(a1, b1);
+      }
+      if (NS & 1) mfma_step(a0, b0);
+    }
+    // store both px classes of this (pz, py) together
+#pragma unroll
+    for (int mt = 0; mt < DMT; ++mt) {
+      const int y = 2 * (yq0 + mt) + py;
+      if (y < d.W) {
+        const int64_t row = (((int64_t)b * d.D + z) * d.W + y) * d.H * d.Cx;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int px = 0; px < 2; ++px) {
+            const int x = 2 * xq + px;
+            if (x < d.H) {
+              const int64_t o = d.gx_layout == LR_LAYOUT_NDHWC
+                                    ? row + (int64_t)x * d.Cx + nt * 16 + kq * 4
+                                    : row + ((int64_t)nt * d.H + (px * (d.H >> 1) + xq)) * 16 + kq * 4;
+              f32x4 v = accp[px][mt][nt];
+              if (xsave) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = xv[px][mt][nt][r] > 0.0f ? v[r] : v[r] * d.slope;
+              }
+              *reinterpret_cast<f32x4*>(gx + o) = v;
+            }
+          }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ wgrad
 // gw[co][ci][tap] = sum_{b, o} gpre[b, o, co] * X[b, ci, s*o + tap - 1]
 // MFMA: rows = co (NTC tiles of 16), cols = 16 "columns" n of an N-tile, k = 4 consecutive output voxels
@@ -648,8 +788,13 @@ extern "C" int lr_conv3d_dgrad_f32(const float* gpre, const float* packed_wT, fl
   if (nblk > 0x7fffffffLL) return LR_EINVAL;
   const float4* wt = reinterpret_cast<const float4*>(packed_wT);
   hipStream_t st = lr_stream(stream);
-  if (Cx == 16) hipLaunchKernelGGL(conv3d_dgrad_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, gpre, wt, gx, x_saved, d);
-  else hipLaunchKernelGGL(conv3d_dgrad_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, gpre, wt, gx, x_saved, d);
+  const dim3 grid((unsigned)nblk), blk(256);
+  if (Cg == 32 && Cx == 16) hipLaunchKernelGGL((conv3d_dgrad_lds_kernel<1, 2>), grid, blk, 0, st, gpre, wt, gx, x_saved, d);
+  else if (Cg == 32) hipLaunchKernelGGL((conv3d_dgrad_lds_kernel<2, 2>), grid, blk, 0, st, gpre, wt, gx, x_saved, d);
+  else if (Cg == 16 && Cx == 16) hipLaunchKernelGGL((conv3d_dgrad_lds_kernel<1, 1>), grid, blk, 0, st, gpre, wt, gx, x_saved, d);
+  else if (Cg == 16) hipLaunchKernelGGL((conv3d_dgrad_lds_kernel<2, 1>), grid, blk, 0, st, gpre, wt, gx, x_saved, d);
+  else if (Cx == 16) hipLaunchKernelGGL(conv3d_dgrad_kernel<1>, grid, blk, 0, st, gpre, wt, gx, x_saved, d);
+  else hipLaunchKernelGGL(conv3d_dgrad_kernel<2>, grid, blk, 0, st, gpre, wt, gx, x_saved, d);
   return lr_launch_status();
 }
 
