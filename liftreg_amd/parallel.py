@@ -232,3 +232,79 @@ class SlabShardedRegistration:
                 B = inp["source"].shape[0]
                 out["sim_loss"], _ = ops.ncc_loss_from_moments(m, D * W * H * (inp["source"].shape[1]), B, self.variant)
         return outs
+
+
+class GradientAllReduce:
+    """Data-parallel training ("only training needs a collective: all-reduce of gradients").
+
+    The parameters' `.grad` tensors are views into a few flat fp32 buckets, so a step needs one collective per
+    bucket (≈54 MB in all at 256³: fewer, larger messages — what point-to-point xGMI rings want) and no
+    flatten/unflatten copies.  Buckets follow the order gradients appear in backward: the FC head
+    (`head_prefix`, 52 of the 54 MB) is complete before the conv backward even starts, so its all-reduce is
+    launched from an autograd hook and runs on RCCL's stream underneath the ≈40 ms of conv backward kernels;
+    the small encoder bucket goes out when backward ends.
+
+        ddp = GradientAllReduce(net)            # after net.to(device)
+        for batch in loader:
+            ddp.zero_grad()                     # one memset per bucket (do not use set_to_none=True)
+            loss(net(batch)).backward()
+            ddp.finish()                        # wait + average
+            optimizer.step()
+    """
+
+    def __init__(self, module, group=None, head_prefix="encoders.6."):
+        self.group = group
+        self.rank, self.world = world(group)
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        split = [[p for n, p in named if n.startswith(head_prefix)], [p for n, p in named if not n.startswith(head_prefix)]]
+        self.buckets = []
+        for params in split:
+            if not params:
+                continue
+            flat = torch.zeros(sum(p.numel() for p in params), dtype=params[0].dtype, device=params[0].device)
+            o = 0
+            for p in params:
+                p.grad = flat[o:o + p.numel()].view_as(p)
+                o += p.numel()
+            self.buckets.append({"flat": flat, "params": params, "pending": len(params), "work": None})
+        self._hooks = []
+        for bk in self.buckets:
+            for p in bk["params"]:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bk)))
+
+    def _make_hook(self, bk):
+        def hook(_param):
+            bk["pending"] -= 1
+            if bk["pending"] == 0:
+                self._launch(bk)
+        return hook
+
+    def _launch(self, bk):
+        if self.world > 1 and bk["work"] is None:
+            bk["work"] = dist.all_reduce(bk["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def zero_grad(self):
+        for bk in self.buckets:
+            bk["flat"].zero_()
+            bk["pending"] = len(bk["params"])
+            bk["work"] = None
+
+    def finish(self):
+        """Wait for the collectives (launching any whose hook did not fire, e.g. unused parameters) and average."""
+        for bk in self.buckets:
+            self._launch(bk)
+            if bk["work"] is not None:
+                bk["work"].wait()
+                bk["flat"].mul_(1.0 / self.world)
+            for p in bk["params"]:          # autograd must have accumulated in place into the bucket views
+                if p.grad is None or p.grad.data_ptr() < bk["flat"].data_ptr() or \
+                        p.grad.data_ptr() >= bk["flat"].data_ptr() + bk["flat"].numel() * bk["flat"].element_size():
+                    raise RuntimeError("a parameter's .grad left its bucket (zero_grad(set_to_none=True)?)")
+
+    def nbytes(self):
+        return sum(bk["flat"].numel() * bk["flat"].element_size() for bk in self.buckets)
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

@@ -114,3 +114,32 @@ def test_inference_builds_no_graph(dev):
     with torch.no_grad():
         out = net({k: v.to(dev) if k != "target_poses" else v for k, v in inp.items()})
     assert not out["warped"].requires_grad and out["warped"].grad_fn is None
+
+
+def test_gradient_buckets_on_the_model(dev):
+    """GradientAllReduce's flat buckets receive the HIP backward's gradients in place (world size 1 here; the
+    2-rank averaging itself is covered on gloo in test_sharding_gloo.py)."""
+    from liftreg_amd.losses.SubspaceLoss import loss as SubspaceLoss
+    from liftreg_amd.parallel import GradientAllReduce
+    shape, P, L, B = (32, 32, 32), 2, 8, 2
+    net = _net(shape, P, L, dev, 5).train()
+    inp = _inputs(shape, P, 32, B, 5, False)
+    dinp = {k: v.to(dev) if k != "target_poses" else v for k, v in inp.items()}
+    crit = SubspaceLoss(dict(LOSS_OPT))
+
+    def run():
+        out = net(dinp)
+        out["epoch"] = 0
+        crit(out)["total_loss"].backward()
+
+    run()
+    plain = {n: p.grad.clone() for n, p in net.named_parameters()}
+    ddp = GradientAllReduce(net)
+    assert [len(b["params"]) for b in ddp.buckets] == [6, 12]
+    for _ in range(2):
+        ddp.zero_grad()
+        run()
+        ddp.finish()
+        for n, p in net.named_parameters():
+            assert torch.equal(p.grad, plain[n]), n
+    ddp.remove()

@@ -209,3 +209,68 @@ def test_two_rank_sharding_matches_unsharded():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+# ------------------------------------------------------------------------------- data-parallel training collective
+def _ddp_worker(rank, world_size, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from liftreg_amd.parallel import GradientAllReduce
+
+        class Net(torch.nn.Module):                      # same naming split as the model: encoders.6.* = FC head
+            def __init__(self):
+                super().__init__()
+                self.encoders = torch.nn.ModuleList([torch.nn.Linear(6, 6) for _ in range(6)] +
+                                                    [torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))])
+
+            def forward(self, x):
+                for m in self.encoders:
+                    x = m(x)
+                return x
+
+        torch.manual_seed(3)                              # identical replicas
+        net = Net()
+        ddp = GradientAllReduce(net)
+        assert len(ddp.buckets) == 2 and ddp.nbytes() == 4 * sum(p.numel() for p in net.parameters())
+        xs = [torch.randn(4, 6, generator=torch.Generator().manual_seed(100 + r)) for r in range(world_size)]
+        for step in range(2):                             # second step checks zero_grad / hook re-arming
+            ddp.zero_grad()
+            net(xs[rank]).square().sum().backward()
+            ddp.finish()
+            ref = Net()
+            ref.load_state_dict(net.state_dict())
+            tot = sum(ref(x).square().sum() for x in xs) / world_size
+            tot.backward()
+            for (n, p), (_, pr) in zip(net.named_parameters(), ref.named_parameters()):
+                assert torch.allclose(p.grad, pr.grad, rtol=1e-5, atol=1e-6), n
+                assert any(p.grad.data_ptr() >= b["flat"].data_ptr() and
+                           p.grad.data_ptr() < b["flat"].data_ptr() + 4 * b["flat"].numel() for b in ddp.buckets)
+            torch.optim.SGD(net.parameters(), lr=0.01).step()
+        ddp.remove()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()[-1500:]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_allreduce():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=250) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
