@@ -264,6 +264,20 @@ int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gpre, float* 
                         float* gb, int B, int Cin, int Cout, int D, int W, int H, int stride, int nblk,
                         void* stream);
 
+/* ---- data-side prologue and evaluation reductions -------------------------------------
+ * lr_normalize_clip_f32: out = ((clamp(in, lo, hi) - lo) / (hi - lo)) * 2 - 1
+ *   (dataset/Registration2D3DDataset.py:196-199,207: _normalize_intensity with linear_clip and a clip_range).
+ * lr_label_overlap_f32: counts[3] (int64, device) = |pred==label|, |gt==label|, |both| over n elements
+ *   (utils/metrics.py:83-121 cal_metric; dice/iou/recall/precision follow on the host).  partial: nblk*3 uint64.
+ * lr_jacobi_det_stats_f32: out[2] (double, device) = sum of |det J| over voxels with det J < 0, and their count,
+ *   for a (B,3,D,W,H) map; sp* = the finite-difference spacing per axis (utils/utils.py:20-55
+ *   compute_jacobi_map passes spacing*span).  partial: B*nblk*2 doubles.  Stencil assumed (mermaid): parity unpinned. */
+int lr_normalize_clip_f32(const float* in, float* out, int64_t n, float lo, float hi, void* stream);
+int lr_label_overlap_f32(const float* pred, const float* gt, float label, int64_t n, void* partial, int nblk,
+                         int64_t* counts, void* stream);
+int lr_jacobi_det_stats_f32(const float* map, int B, int D, int W, int H, float sp0, float sp1, float sp2,
+                            double* partial, int nblk, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,9 @@ SIGNATURES = {
     "lr_lrelu_bwd_f32": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "lr_conv3d_dgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _f, _p]),
     "lr_disp_reg_bwd_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "lr_normalize_clip_f32": (_i, [_p, _p, _i64, _f, _f, _p]),
+    "lr_label_overlap_f32": (_i, [_p, _p, _f, _i64, _p, _i, _p, _p]),
+    "lr_jacobi_det_stats_f32": (_i, [_p, _i, _i, _i, _i, _f, _f, _f, _p, _i, _p, _p]),
     "lr_conv3d_wgrad_partial_floats": (_i64, [_i, _i, _i, _i]),
     "lr_conv3d_wgrad_f32": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
 }

@@ -387,3 +387,50 @@ def disp_reg(disp, nblk=None):
         _hip.check(_hip.lib().lr_disp_reg_f32(disp.data_ptr(), partial.data_ptr(), out.data_ptr(), B, D, W, H, nblk,
                                               _stream()), "lr_disp_reg_f32")
     return out
+
+
+# ----------------------------------------------------------------------------- f3/f4: prologue and evaluation
+def normalize_clip(img, lo, hi, out=None):
+    """((clamp(img, lo, hi) - lo)/(hi - lo))*2 - 1 — the dataset's intensity normalisation
+    (reference dataset/Registration2D3DDataset.py:196-199,207) as a GPU-side prologue."""
+    img = _dev(img, "img")
+    if out is None:
+        out = torch.empty_like(img)
+    with _timed("normalize_clip", bytes=8 * img.numel()):
+        _hip.check(_hip.lib().lr_normalize_clip_f32(img.data_ptr(), out.data_ptr(), img.numel(), float(lo), float(hi),
+                                                    _stream()), "lr_normalize_clip_f32")
+    return out
+
+
+def label_overlap(pred, gt, label=1.0, nblk=1024):
+    """int64 GPU tensor [|pred==label|, |gt==label|, |both|] (reference utils/metrics.py:83-121)."""
+    pred, gt = _dev(pred, "pred"), _dev(gt, "gt")
+    if pred.numel() != gt.numel():
+        raise ValueError("pred and gt must have the same number of elements")
+    nblk = max(1, min(int(nblk), (pred.numel() + 255) // 256))
+    partial = torch.empty((nblk, 3), dtype=torch.int64, device=pred.device)
+    counts = torch.empty((3,), dtype=torch.int64, device=pred.device)
+    with _timed("label_overlap", bytes=8 * pred.numel()):
+        _hip.check(_hip.lib().lr_label_overlap_f32(pred.data_ptr(), gt.data_ptr(), float(label), pred.numel(),
+                                                   partial.data_ptr(), nblk, counts.data_ptr(), _stream()),
+                   "lr_label_overlap_f32")
+    return counts
+
+
+def jacobi_det_stats(phi, spacing, nblk=None):
+    """float64 GPU tensor [Σ|det J| over folded voxels, number of folded voxels] for a (B,3,D,W,H) map;
+    `spacing` = the three finite-difference spacings (reference utils/utils.py:20-55).  Assumed mermaid stencil."""
+    phi = _dev(phi, "phi")
+    B, C3, D, W, H = phi.shape
+    if C3 != 3:
+        raise ValueError("map must be (B,3,D,W,H)")
+    if nblk is None:
+        nblk = max(1, min(2048 // B if B < 2048 else 1, (D * W * H + 255) // 256))
+    partial = torch.empty((B * nblk * 2,), dtype=torch.float64, device=phi.device)
+    out = torch.empty((2,), dtype=torch.float64, device=phi.device)
+    sp = [float(v) for v in spacing]
+    with _timed("jacobi_det_stats", bytes=4 * phi.numel()):
+        _hip.check(_hip.lib().lr_jacobi_det_stats_f32(phi.data_ptr(), B, D, W, H, sp[0], sp[1], sp[2],
+                                                      partial.data_ptr(), nblk, out.data_ptr(), _stream()),
+                   "lr_jacobi_det_stats_f32")
+    return out

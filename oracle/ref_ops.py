@@ -272,3 +272,51 @@ def subspace_loss(output, epoch, initial_reg_factor=0.01, min_reg_factor=0.01, r
     reg = disp_reg(output["params"])
     factor = float(max(sigmoid_decay(epoch, static=reg_factor_decay_from, k=2) * initial_reg_factor, min_reg_factor))
     return {"total_loss": sim + factor * reg, "sim_loss": float(sim.detach()), "reg_loss": float(reg.detach())}
+
+
+# --------------------------------------------------------------------------- f3 / f4 (prologue, evaluation)
+def normalize_clip(img, lo, hi):
+    """_normalize_intensity(linear_clip=True, clip_range=[lo,hi]) (dataset/Registration2D3DDataset.py:196-199,207),
+    float32 arithmetic like numpy's with python-int scalars."""
+    x = np.array(img, dtype=np.float32, copy=True)
+    x[x < lo] = lo
+    x[x > hi] = hi
+    x = (x - np.float32(lo)) / np.float32(hi - lo)
+    return x * np.float32(2) - np.float32(1)
+
+
+def cal_metric(label_pred, label_gt, label=1):
+    """utils/metrics.py:83-121 from the three set sizes."""
+    eps = 1e-11
+    p, g = np.asarray(label_pred).ravel() == label, np.asarray(label_gt).ravel() == label
+    n_p, n_g, n_b = int(p.sum()), int(g.sum()), int((p & g).sum())
+    tp, fn, fp, union = float(n_b), float(n_g - n_b), float(n_p - n_b), n_p + n_g - n_b
+    if n_g != 0:
+        return {"iou": tp / (float(union) + eps), "dice": 2 * tp / (2 * tp + fn + fp + eps),
+                "recall": tp / (tp + fn + eps), "precision": tp / (tp + fp + eps)}
+    v = 0. if n_p > 0 else 1.
+    return {"iou": v, "dice": v, "recall": v, "precision": v}
+
+
+def _fd_c(f, axis, h):
+    """ASSUMED mermaid stencil (see disp_reg): central differences, one-sided at the two faces."""
+    f = np.asarray(f, dtype=np.float32)
+    d = np.empty_like(f)
+    n = f.shape[axis]
+    sl = lambda a, b: tuple(slice(a, b) if ax == axis else slice(None) for ax in range(f.ndim))
+    ih = np.float32(1.0 / h)
+    d[sl(1, n - 1)] = (f[sl(2, n)] - f[sl(0, n - 2)]) * (np.float32(0.5) * ih)
+    d[sl(0, 1)] = (f[sl(1, 2)] - f[sl(0, 1)]) * ih
+    d[sl(n - 1, n)] = (f[sl(n - 1, n)] - f[sl(n - 2, n - 1)]) * ih
+    return d
+
+
+def compute_jacobi_map(phi, spacing, use_01=False):
+    """utils/utils.py:20-55 (values over the whole volume, as the reference returns).  PARITY UNPINNED (mermaid FD_np)."""
+    phi = np.asarray(phi, dtype=np.float32)
+    sp = np.asarray(spacing, dtype=np.float64) * (1.0 if use_01 else 2.0)
+    m = [[_fd_c(phi[:, c], ax + 1, np.float32(sp[ax])) for ax in range(3)] for c in range(3)]
+    (a, b, c), (d, e, f), (g, h, i) = m
+    det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g)
+    neg = det < 0
+    return float(-(det[neg].astype(np.float64)).sum()) / phi.shape[0], float(neg.sum()) / phi.shape[0]

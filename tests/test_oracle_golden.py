@@ -164,3 +164,13 @@ def test_model_forward(golden):
     np.testing.assert_allclose(disp.reshape(g["out::params"].shape), g["out::params"], rtol=1e-5, atol=1e-7)
     # mask compose (…Backproj.py:57-58)
     assert np.array_equal(co.mask_compose(g["in::target"], g["in::target_label"]), g["out::target"])
+
+
+def test_prologue_and_overlap_metric(golden):
+    """f3/f4: the oracle's intensity normalisation and overlap metric against the imported reference."""
+    g = golden("metrics")
+    assert np.array_equal(ro.normalize_clip(g["hu"], -1000, 0), g["hu_norm"])
+    assert np.array_equal(ro.normalize_clip(g["drr"], 0, 6), g["drr_norm"])
+    for k in range(int(g["n_cases"])):
+        r = ro.cal_metric(g[f"pred{k}"], g[f"gt{k}"])
+        assert [r["iou"], r["dice"], r["recall"], r["precision"]] == list(g[f"res{k}"])
