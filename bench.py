@@ -119,6 +119,9 @@ def main():
                     help="2: batch i's HBM-bound decode half overlaps batch i+1's MFMA-bound encode half on two HIP "
                          "streams (measured +1.3 %% at C3: every kernel already fills the chip; per-kernel timings "
                          "are only meaningful with 1)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from one captured HIP graph (launch-bound small configs c1/c2); the "
+                         "per-kernel table then comes from one extra eager step outside the timed region")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -151,6 +154,13 @@ def main():
 
         def step():
             return reg.submit(inp)[1]
+    elif args.graph:
+        from liftreg_amd.pipeline import GraphedRegistrar
+        greg = GraphedRegistrar(net, inp, sim=sim)
+
+        def step():
+            greg.graph.replay()          # inputs already sit in the graph's static buffers (resident in HBM)
+            return greg.static_out[1]
     else:
         def step():
             out = net(inp)
@@ -173,6 +183,12 @@ def main():
             fence()
             elapsed = time.perf_counter() - t0
         ksum = kt.summary()
+        if args.graph:                    # a replay records no per-launch events: take them from one eager step
+            with ops.kernel_timer() as kt:
+                out = net(inp)
+                sim(out["warped"], out["target"])
+                torch.cuda.synchronize()
+            ksum = {k: {"ms": v["ms"] * args.steps, "info": v["info"]} for k, v in kt.summary().items()}
     assert torch.isfinite(loss), "NCC is not finite"
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -216,7 +232,7 @@ def main():
         "config": {"workload": f"{args.config}: {n}^3 CT, {P}x{cfg['R']}^2 DRR, batch {B}/GPU, latent {L}, "
                                "backproject+conv6(MFMA f32)+FC3+PCA+warp+NCC", "global_batch": world * B,
                    "parallelism": f"replicas x{world} (independent registrations, no data-path collective)",
-                   "streams": args.streams},
+                   "streams": args.streams, "hip_graph": bool(args.graph)},
         "roofline": roof(dominant),
         "roofline_backproject": roof("backproject"),
         "backproj_hbm_GBps": kernels["backproject"]["achieved"],

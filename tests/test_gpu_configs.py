@@ -115,3 +115,24 @@ def test_c5_shapes_384_volume_512_detector(dev):
     cphi, cw = co.warp(moving.cpu().numpy(), disp[:, :, 190:198].cpu().numpy(), ids=(tabs[0][190:198], tabs[1], tabs[2]),
                        d0=190, d1=198)
     assert np.array_equal(phi[:, :, 190:198].cpu().numpy(), cphi) and np.array_equal(warped[:, :, 190:198].cpu().numpy(), cw)
+
+
+def test_c1_graph_replay_matches_eager(dev):
+    """C1 shape (64³, 2×64², B=1): the forward + NCC captured in one HIP graph gives the eager results bit for bit,
+    for the captured batch and for a second batch copied into the static inputs."""
+    from liftreg_amd.layers.losses import NCCLoss
+    from liftreg_amd.pipeline import GraphedRegistrar
+    n, P, L, B = 64, 2, 56, 1
+    net = _net(n, P, L, dev, 21)
+    sim = NCCLoss(check_nan=False)
+    b0, b1 = _inputs(n, P, n, B, dev, 21), _inputs(n, P, n, B, dev, 22)
+    reg = GraphedRegistrar(net, b0, sim=sim)
+    for batch in (b0, b1, b0):
+        with torch.no_grad():
+            want = net(batch)
+            want_loss = sim(want["warped"], want["target"])
+        out, loss = reg(batch)
+        torch.cuda.synchronize()
+        for k in ("pca_coefs", "params", "phi", "warped"):
+            assert torch.equal(out[k], want[k]), k
+        assert torch.equal(loss, want_loss)
