@@ -119,6 +119,9 @@ def main():
                     help="2: batch i's HBM-bound decode half overlaps batch i+1's MFMA-bound encode half on two HIP "
                          "streams (measured +1.3 %% at C3: every kernel already fills the chip; per-kernel timings "
                          "are only meaningful with 1)")
+    ap.add_argument("--conv-dtype", default="fp32", choices=("fp32", "bf16"),
+                    help='bf16: activations between the conv blocks stored as bfloat16, blocks 1..5 on the bf16 MFMA '
+                         '(configs C4/C5); NOT the headline configuration — the JSON line says so in "dtype"')
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from one captured HIP graph (launch-bound small configs c1/c2); the "
                          "per-kernel table then comes from one extra eager step outside the timed region")
@@ -144,7 +147,8 @@ def main():
 
     torch.manual_seed(2021)
     n, P, B, L = cfg["n"], cfg["P"], cfg["B"], cfg["L"]
-    net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:2021"}).to(dev).eval()
+    net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:2021",
+                            "conv_dtype": args.conv_dtype}).to(dev).eval()
     inp = synth_inputs(cfg, dev, seed=2021 + rank)
     sim = NCCLoss(check_nan=False)
 
@@ -204,8 +208,9 @@ def main():
         info = rec["info"]
         launches = len(rec["ms"]) / args.steps
         k = {"avg_ms": ms, "launches_per_step": launches}
-        if "flops" in info:
-            k.update(bound="mfma", achieved=info["flops"] / (ms * 1e-3) / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s")
+        if "flops" in info and info.get("bound", "mfma") == "mfma":
+            k.update(bound="mfma", achieved=info["flops"] / (ms * 1e-3) / 1e12,
+                     peak=info.get("peak_tf", MFMA_F32_PEAK_TF), unit="TFLOP/s")
         else:
             k.update(bound="hbm", achieved=info["bytes"] / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
         k["frac"] = k["achieved"] / k["peak"]
@@ -228,7 +233,8 @@ def main():
         "metric": "registrations/sec (256^3 CT, 2-view DRR)" if args.config == "c3" else f"registrations/sec ({args.config})",
         "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if args.conv_dtype == "fp32" else "bf16 conv blocks 1-5 (f32 elsewhere)",
+        "data": "synthetic",
         "config": {"workload": f"{args.config}: {n}^3 CT, {P}x{cfg['R']}^2 DRR, batch {B}/GPU, latent {L}, "
                                "backproject+conv6(MFMA f32)+FC3+PCA+warp+NCC", "global_batch": world * B,
                    "parallelism": f"replicas x{world} (independent registrations, no data-path collective)",

@@ -127,6 +127,11 @@ int lr_backproject_coords_f32(const float* poses, float* pix, int P, int Pw, int
  * 16-channel block first, then its odd voxels): a private layout between a block and a following
  * stride-2 block, whose tap loads it makes contiguous runs.  H even, C % 16 == 0. */
 #define LR_LAYOUT_NDHWC_HPS 2
+/* bf16 storage (BASELINE configs C4/C5: "bf16 convs"): channels-last (B,D,W,H,C) of 2-byte bfloat16, plain or
+ * with every row parity-split along H as [parity of h][H/2][C].  lr_conv3d_k3_lrelu_f32 accepts them as
+ * out_layout (fp32 compute, output rounded to nearest-even bf16); lr_conv3d_k3_lrelu_bf16 takes them as input. */
+#define LR_LAYOUT_BF16_NDHWC 3
+#define LR_LAYOUT_BF16_NDHWC_HPS 4
 int64_t lr_conv3d_packed_floats(int Cin, int Cout, int in_layout);
 int lr_conv3d_pack_weights_f32(const float* weight, float* packed, int Cin, int Cout,
                                int in_layout, void* stream);
@@ -263,6 +268,18 @@ int64_t lr_conv3d_wgrad_partial_floats(int Cin, int Cout, int x_layout, int nblk
 int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gpre, float* partial, float* gw,
                         float* gb, int B, int Cin, int Cout, int D, int W, int H, int stride, int nblk,
                         void* stream);
+
+/* ---- bf16 variant of the stride-2 encoder blocks (Cin, Cout in {16,32}; v_mfma_f32_16x16x32_bf16, fp32
+ * accumulate, bias/LeakyReLU in fp32, output rounded to bf16 — or fp32 NCDHW for the last block).
+ * in: bf16 LR_LAYOUT_BF16_NDHWC[_HPS]; packed_w: lr_conv3d_packed_bf16_bytes(...) bytes written by
+ * lr_conv3d_pack_weights_bf16 from the fp32 (Cout,Cin,3,3,3) parameter; out_layout: LR_LAYOUT_NCDHW (fp32) or a
+ * bf16 layout.  lr_cast_f32_to_bf16: elementwise round-to-nearest-even (layout-preserving). */
+int64_t lr_conv3d_packed_bf16_bytes(int Cin, int Cout);
+int lr_conv3d_pack_weights_bf16(const float* weight, void* packed, int Cin, int Cout, void* stream);
+int lr_conv3d_k3_lrelu_bf16(const void* in, const void* packed_w, const float* bias, void* out, int B, int Cin,
+                            int Cout, int D, int W, int H, int stride, int in_layout, int out_layout,
+                            float negative_slope, void* stream);
+int lr_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 
 /* ---- data-side prologue and evaluation reductions -------------------------------------
  * lr_normalize_clip_f32: out = ((clamp(in, lo, hi) - lo) / (hi - lo)) * 2 - 1

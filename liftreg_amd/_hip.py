@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(CSRC, "libliftreg_hip.so")
 
 LR_OK = 0
 LAYOUT_NCDHW, LAYOUT_NDHWC, LAYOUT_NDHWC_HPS = 0, 1, 2
+LAYOUT_BF16_NDHWC, LAYOUT_BF16_NDHWC_HPS = 3, 4
 DRR_HU_INPUT, DRR_FLIP_W = 1, 2
 WARP_USING_SCALE, WARP_BORDER, WARP_NEAREST = 1, 2, 4
 NCC_CONFIGURED, NCC_SQUARED = 0, 1
@@ -48,6 +49,10 @@ SIGNATURES = {
     "lr_lrelu_bwd_f32": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "lr_conv3d_dgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _f, _p]),
     "lr_disp_reg_bwd_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "lr_conv3d_packed_bf16_bytes": (_i64, [_i, _i]),
+    "lr_conv3d_pack_weights_bf16": (_i, [_p, _p, _i, _i, _p]),
+    "lr_conv3d_k3_lrelu_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "lr_cast_f32_to_bf16": (_i, [_p, _p, _i64, _p]),
     "lr_normalize_clip_f32": (_i, [_p, _p, _i64, _f, _f, _p]),
     "lr_label_overlap_f32": (_i, [_p, _p, _f, _i64, _p, _i, _p, _p]),
     "lr_jacobi_det_stats_f32": (_i, [_p, _i, _i, _i, _i, _f, _f, _f, _p, _i, _p, _p]),

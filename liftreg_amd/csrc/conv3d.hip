@@ -78,6 +78,15 @@ __device__ __forceinline__ void store_tile(const f32x4& acc, float* __restrict__
   if (out_layout == LR_LAYOUT_NDHWC) {
     float* o = out + ((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + ho) * d.Cout + c0;
     *reinterpret_cast<f32x4*>(o) = v;
+  } else if (out_layout == LR_LAYOUT_BF16_NDHWC || out_layout == LR_LAYOUT_BF16_NDHWC_HPS) {
+    // bf16 storage (C4/C5): 4 couts of one voxel = one 8-byte store; rows plain or [parity][Ho/2][Cout]
+    const int hp = out_layout == LR_LAYOUT_BF16_NDHWC_HPS ? (ho & 1) * (d.Ho >> 1) + (ho >> 1) : ho;
+    unsigned short* o = reinterpret_cast<unsigned short*>(out) +
+                        ((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + hp) * d.Cout + c0;
+    unsigned short h[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = __builtin_bit_cast(unsigned short, (__bf16)v[r]);  // round to nearest even
+    *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
   } else if (out_layout == LR_LAYOUT_NDHWC_HPS) {  // even voxels of the row first, then the odd ones
     // row = [channel block of 16][parity][Ho/2][16 floats]
     const int hp = (ho & 1) * (d.Ho >> 1) + (ho >> 1);
@@ -626,10 +635,12 @@ extern "C" int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, co
   if (B < 1 || Cin < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
   if (stride != 1 && stride != 2) return LR_EUNSUPPORTED;
   if (Cout != 16 && Cout != 32) return LR_EUNSUPPORTED;
-  if (out_layout != LR_LAYOUT_NCDHW && out_layout != LR_LAYOUT_NDHWC && out_layout != LR_LAYOUT_NDHWC_HPS)
+  if (out_layout != LR_LAYOUT_NCDHW && out_layout != LR_LAYOUT_NDHWC && out_layout != LR_LAYOUT_NDHWC_HPS &&
+      out_layout != LR_LAYOUT_BF16_NDHWC && out_layout != LR_LAYOUT_BF16_NDHWC_HPS)
     return LR_EINVAL;
   if (out_layout != LR_LAYOUT_NCDHW && (reinterpret_cast<uintptr_t>(out) & 15u)) return LR_EALIGN;
-  if (out_layout == LR_LAYOUT_NDHWC_HPS && (((H - 1) / stride + 1) & 1)) return LR_EUNSUPPORTED;  // needs an even output H
+  if ((out_layout == LR_LAYOUT_NDHWC_HPS || out_layout == LR_LAYOUT_BF16_NDHWC_HPS) && (((H - 1) / stride + 1) & 1))
+    return LR_EUNSUPPORTED;  // needs an even output H
   ConvDims d;
   d.B = B; d.Cin = Cin; d.Cout = Cout; d.D = D; d.W = W; d.H = H;
   d.Do = (D - 1) / stride + 1; d.Wo = (W - 1) / stride + 1; d.Ho = (H - 1) / stride + 1;

@@ -1,0 +1,267 @@
+// conv3d_bf16.hip — the bf16 variant of the encoder's stride-2 blocks (BASELINE configs C4/C5: "bf16 convs").
+// Activations are stored as bf16 channels-last (half the HBM bytes of the fp32 path), weights are rounded to
+// bf16 once, products are exact and accumulate in fp32 on v_mfma_f32_16x16x32_bf16 (16x the fp32 MFMA rate), so
+// the blocks that are matrix-pipe-bound in fp32 become HBM/L2-bound here.  The first block keeps its fp32 input
+// (CT volume + backprojection) and fp32 MFMA and only rounds its OUTPUT to bf16 (conv3d.hip, out_layout 3|4).
+//
+//   K order of one MFMA (32 k-values): Cin = 32: one tap, lane group kq owns channels 8kq..8kq+7;
+//                                      Cin = 16: two taps, groups 0,1 the first tap, groups 2,3 the second.
+//   So every lane's B operand is ONE 16-byte load of 8 consecutive bf16 channels of its voxel.
+//
+// Replaces (reference file:line): src/liftreg/layers/layers.py:365-369 under torch.cuda.amp-style bf16 storage
+// (the reference itself ships fp32 only; the bf16 numerics contract is stated in DESIGN.md §4c and restated on the
+// CPU in oracle/ref_ops.py:conv_block_bf16).
+#include "lr_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+constexpr int MT = 4, TD = 4;
+
+struct ConvDimsH {
+  int B, Cin, Cout, D, W, H, Do, Wo, Ho;
+  int nHq, nWq, nDq;
+};
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.0f ? v : v * slope; }
+
+// round-to-nearest-even fp32 -> bf16 (the hardware conversion of gfx950)
+__device__ __forceinline__ u16 to_bf16(float v) {
+  const __bf16 h = (__bf16)v;
+  return __builtin_bit_cast(u16, h);
+}
+
+// lane l holds couts nt*16 + (l>>4)*4 + {0..3} of voxel (l&15)
+__device__ __forceinline__ void store_tile_any(const f32x4& acc, void* __restrict__ out, const ConvDimsH& d, int b, int dz,
+                                               int wo, int ho, int nt, int lane, int out_layout, float slope) {
+  if (wo >= d.Wo || ho >= d.Ho) return;
+  const int c0 = nt * 16 + (lane >> 4) * 4;
+  f32x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = lrelu(acc[r], slope);
+  if (out_layout == LR_LAYOUT_NCDHW) {  // fp32, the reference's layout (last block -> Flatten)
+    const int64_t vo = (int64_t)d.Do * d.Wo * d.Ho;
+    float* o = reinterpret_cast<float*>(out) + ((int64_t)b * d.Cout + c0) * vo + ((int64_t)dz * d.Wo + wo) * d.Ho + ho;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r * vo] = v[r];
+    return;
+  }
+  const int hp = out_layout == LR_LAYOUT_BF16_NDHWC_HPS ? (ho & 1) * (d.Ho >> 1) + (ho >> 1) : ho;
+  u16* o = reinterpret_cast<u16*>(out) + ((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + hp) * d.Cout + c0;
+  const unsigned lo = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
+  const unsigned hi = (unsigned)to_bf16(v[2]) | ((unsigned)to_bf16(v[3]) << 16);
+  *reinterpret_cast<uint2*>(o) = make_uint2(lo, hi);
+}
+
+// CIN32: Cin == 32 (else 16).  PS: input rows parity-split along H ([parity][H/2][Cin]).
+template <int NT, bool CIN32, bool PS>
+__global__ __launch_bounds__(256) void conv3d_cl_bf16_kernel(const u16* __restrict__ in, const u32x4* __restrict__ wp,
+                                                             const float* __restrict__ bias, void* __restrict__ out,
+                                                             ConvDimsH d, int out_layout, float slope) {
+  constexpr int CIN = CIN32 ? 32 : 16, VB = CIN * 2;  // bytes per voxel
+  const unsigned lb = lr_xcd_remap(blockIdx.x, gridDim.x);
+  const int hq = lb % d.nHq, wq = (lb / d.nHq) % d.nWq, dq = (lb / d.nHq / d.nWq) % d.nDq;
+  const int b = lb / d.nHq / d.nWq / d.nDq;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int dz = dq * TD + wave;
+  if (dz >= d.Do) return;
+  const int wo0 = wq * MT;
+  const int col = lane & 15, kq = lane >> 4;
+  const int ho = hq * 16 + col;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = bias[nt * 16 + kq * 4 + r];
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = bv;
+  }
+
+  // window origin = the (-1,-1,-1) corner of this wavefront's input window; padding taps get an out-of-range
+  // offset and read 0 (unconditional, branch-free loads)
+  const int zi0 = dz * 2 - 1, yw0 = wo0 * 2 - 1;
+  const int xh0 = PS ? hq * 16 - 1 : hq * 32 - 1;
+  const int64_t inb = (int64_t)b * d.D * d.W * d.H * CIN;
+  const u16* wbase = in + inb + ((int64_t)zi0 * d.W + yw0) * d.H * CIN + (int64_t)xh0 * CIN;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(wbase), (short)0, 0x7fffffff, 0x00020000);
+  const int half_h = (d.H + 1) >> 1;
+  const unsigned lvoff = (unsigned)(col * (PS ? 1 : 2) * VB + (CIN32 ? kq : (kq & 1)) * 16);
+  unsigned nvmask[MT];  // bit tap CLEAR = tap inside the tensor (bits 27.. stay set: the padding tap of Cin=16)
+  {
+    const int xi0 = ho * 2 - 1;
+    unsigned zx = 0u;
+#pragma unroll
+    for (int tz = 0; tz < 3; ++tz)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx)
+        if (ho < d.Ho && zi0 + tz >= 0 && zi0 + tz < d.D && xi0 + tx >= 0 && xi0 + tx < d.H) zx |= 1u << (tz * 3 + tx);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int yi0 = (wo0 + mt) * 2 - 1;
+      unsigned m = 0u;
+#pragma unroll
+      for (int tz = 0; tz < 3; ++tz)
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx)
+            if ((wo0 + mt < d.Wo) && yi0 + ty >= 0 && yi0 + ty < d.W && ((zx >> (tz * 3 + tx)) & 1u))
+              m |= 1u << ((tz * 3 + ty) * 3 + tx);
+      nvmask[mt] = ~m;
+    }
+  }
+  const unsigned row_bytes = (unsigned)(2 * d.H * VB);
+  auto tap_off = [&](int tap) -> unsigned {  // byte offset of a tap inside the window (wave-uniform)
+    const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+    const int xs = PS ? (tx == 1 ? 1 : half_h + (tx >> 1)) : tx;
+    return (unsigned)((((tz * d.W + ty) * d.H) + xs) * VB);
+  };
+
+  constexpr int NS = CIN32 ? 27 : 14;
+  auto load_step = [&](int s, u32x4 (&a)[MT], u32x4 (&bw)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bw[nt] = wp[((int64_t)s * NT + nt) * 64 + lane];
+    unsigned toff;
+    int mytap;
+    if (CIN32) {
+      toff = tap_off(s);
+      mytap = s;
+    } else {
+      const unsigned ta = tap_off(2 * s), tb = tap_off(min(2 * s + 1, 26));
+      toff = (kq >> 1) ? tb : ta;
+      mytap = 2 * s + (kq >> 1);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const unsigned voff = (lvoff + toff) | ((nvmask[mt] >> mytap) << 31);
+      a[mt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, mt * row_bytes, 0);
+    }
+  };
+  auto mfma_step = [&](const u32x4 (&a)[MT], const u32x4 (&bw)[NT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[nt]),
+                                                              __builtin_bit_cast(bf16x8, a[mt]), acc[mt][nt], 0, 0, 0);
+  };
+  u32x4 a0[MT], a1[MT], b0[NT], b1[NT];
+  load_step(0, a0, b0);
+  for (int s = 0; s + 1 < NS; s += 2) {
+    load_step(s + 1, a1, b1);
+    mfma_step(a0, b0);
+    load_step(min(s + 2, NS - 1), a0, b0);
+    mfma_step(a1, b1);
+  }
+  if (NS & 1) mfma_step(a0, b0);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) store_tile_any(acc[mt][nt], out, d, b, dz, wo0 + mt, ho, nt, lane, out_layout, slope);
+}
+
+// packed[(s*NT + nt)*64 + lane] = the 8 bf16 weights W[co = nt*16 + (lane&15)][k-block lane>>4] of MFMA step s
+__global__ void pack_bf16_kernel(const float* __restrict__ w, u32x4* __restrict__ packed, int Cin, int Cout, int NT) {
+  const int NS = Cin == 32 ? 27 : 14;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= NS * NT * 64) return;
+  const int lane = idx & 63, nt = (idx >> 6) % NT, s = (idx >> 6) / NT;
+  const int co = nt * 16 + (lane & 15), kq = lane >> 4;
+  unsigned r[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    unsigned pair = 0u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = 2 * m + h;
+      const int tap = Cin == 32 ? s : 2 * s + (kq >> 1);
+      const int ci = Cin == 32 ? kq * 8 + i : (kq & 1) * 8 + i;
+      const float v = (tap < 27 && co < Cout) ? w[((int64_t)co * Cin + ci) * 27 + tap] : 0.0f;
+      pair |= (unsigned)to_bf16(v) << (16 * h);
+    }
+    r[m] = pair;
+  }
+  packed[idx] = (u32x4){r[0], r[1], r[2], r[3]};
+}
+
+// fp32 -> bf16 storage of a channels-last tensor (tests, and a model whose first block is fed bf16 upstream)
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ in, u16* __restrict__ out, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = to_bf16(in[i]);
+}
+
+}  // namespace
+
+extern "C" int64_t lr_conv3d_packed_bf16_bytes(int Cin, int Cout) {
+  if ((Cin != 16 && Cin != 32) || (Cout != 16 && Cout != 32)) return LR_EUNSUPPORTED;
+  return (int64_t)(Cin == 32 ? 27 : 14) * (Cout / 16) * 64 * 16;
+}
+
+extern "C" int lr_conv3d_pack_weights_bf16(const float* weight, void* packed, int Cin, int Cout, void* stream) {
+  if (!weight || !packed) return LR_ENULL;
+  if ((Cin != 16 && Cin != 32) || (Cout != 16 && Cout != 32)) return LR_EUNSUPPORTED;
+  if (reinterpret_cast<uintptr_t>(packed) & 15u) return LR_EALIGN;
+  const int total = (Cin == 32 ? 27 : 14) * (Cout / 16) * 64;
+  hipLaunchKernelGGL(pack_bf16_kernel, dim3((total + 255) / 256), dim3(256), 0, lr_stream(stream), weight,
+                     reinterpret_cast<u32x4*>(packed), Cin, Cout, Cout / 16);
+  return lr_launch_status();
+}
+
+extern "C" int lr_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream) {
+  if (!in || !out) return LR_ENULL;
+  if (n < 0) return LR_EINVAL;
+  if (n == 0) return LR_OK;
+  int64_t nblk = (n + 255) / 256;
+  if (nblk > 16384) nblk = 16384;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)nblk), dim3(256), 0, lr_stream(stream), in,
+                     reinterpret_cast<u16*>(out), n);
+  return lr_launch_status();
+}
+
+extern "C" int lr_conv3d_k3_lrelu_bf16(const void* in, const void* packed_w, const float* bias, void* out, int B,
+                                       int Cin, int Cout, int D, int W, int H, int stride, int in_layout,
+                                       int out_layout, float negative_slope, void* stream) {
+  if (!in || !packed_w || !out) return LR_ENULL;
+  if (B < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
+  if (stride != 2 || (Cin != 16 && Cin != 32) || (Cout != 16 && Cout != 32)) return LR_EUNSUPPORTED;
+  if (in_layout != LR_LAYOUT_BF16_NDHWC && in_layout != LR_LAYOUT_BF16_NDHWC_HPS) return LR_EINVAL;
+  if (out_layout != LR_LAYOUT_NCDHW && out_layout != LR_LAYOUT_BF16_NDHWC && out_layout != LR_LAYOUT_BF16_NDHWC_HPS)
+    return LR_EINVAL;
+  const bool ps = in_layout == LR_LAYOUT_BF16_NDHWC_HPS;
+  if (ps && (H & 1)) return LR_EUNSUPPORTED;
+  ConvDimsH d;
+  d.B = B; d.Cin = Cin; d.Cout = Cout; d.D = D; d.W = W; d.H = H;
+  d.Do = (D - 1) / 2 + 1; d.Wo = (W - 1) / 2 + 1; d.Ho = (H - 1) / 2 + 1;
+  if (out_layout == LR_LAYOUT_BF16_NDHWC_HPS && (d.Ho & 1)) return LR_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(packed_w)) & 15u) return LR_EALIGN;
+  if (out_layout != LR_LAYOUT_NCDHW && (reinterpret_cast<uintptr_t>(out) & 7u)) return LR_EALIGN;
+  if ((int64_t)12 * W * H * Cin * 2 + 4096 >= 0x7fffffffLL) return LR_EINVAL;  // 31-bit offsets inside a window
+  d.nHq = (d.Ho + 15) / 16; d.nWq = (d.Wo + MT - 1) / MT; d.nDq = (d.Do + TD - 1) / TD;
+  const int64_t nblk = (int64_t)B * d.nDq * d.nWq * d.nHq;
+  if (nblk > 0x7fffffffLL) return LR_EINVAL;
+  const dim3 grid((unsigned)nblk), block(256);
+  hipStream_t st = lr_stream(stream);
+  const u16* x = reinterpret_cast<const u16*>(in);
+  const u32x4* wt = reinterpret_cast<const u32x4*>(packed_w);
+#define LR_BF(NTV, C32, PSV) \
+  hipLaunchKernelGGL((conv3d_cl_bf16_kernel<NTV, C32, PSV>), grid, block, 0, st, x, wt, bias, out, d, out_layout, negative_slope)
+  const int NT = Cout / 16;
+  if (Cin == 32) {
+    if (NT == 2) { if (ps) LR_BF(2, true, true); else LR_BF(2, true, false); }
+    else         { if (ps) LR_BF(1, true, true); else LR_BF(1, true, false); }
+  } else {
+    if (NT == 2) { if (ps) LR_BF(2, false, true); else LR_BF(2, false, false); }
+    else         { if (ps) LR_BF(1, false, true); else LR_BF(1, false, false); }
+  }
+#undef LR_BF
+  return lr_launch_status();
+}

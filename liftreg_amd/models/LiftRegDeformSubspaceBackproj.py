@@ -26,6 +26,14 @@ from ..layers.layers import convBlock, FullyConnectBlock, GaussianSmoothing
 from ..utils.net_utils import Bilinear, identity_axis_tables
 
 
+def _opt(opt, key, default):
+    """ParameterDict-style `opt[(key, default, comment)]` with a plain-dict fallback (optional, non-reference keys)."""
+    try:
+        return opt[(key, default, "")]
+    except (KeyError, TypeError):
+        return opt.get(key, default) if hasattr(opt, "get") else default
+
+
 def _out_size(n, strides):
     for s in strides:
         n = (n - 1) // s + 1
@@ -63,6 +71,18 @@ class model(nn.Module):
             lay_out = ops.LAYOUT_NCDHW if i == last else (ops.LAYOUT_NDHWC_HPS if h_out % 2 == 0 else ops.LAYOUT_NDHWC)
             self.encoders.append(convBlock(cin, f, stride=self.strides[i], bias=True, in_layout=lay_in,
                                            out_layout=lay_out))
+        # optional (non-reference) key "conv_dtype": "bf16" stores the activations between the blocks as bfloat16
+        # and runs blocks 1..5 on the bf16 MFMA (BASELINE configs C4/C5); inference only, default "fp32"
+        self.conv_dtype = str(_opt(opt, "conv_dtype", "fp32"))
+        if self.conv_dtype not in ("fp32", "bf16"):
+            raise ValueError('conv_dtype must be "fp32" or "bf16"')
+        self._bf16_layouts = []
+        for i in range(len(enc_filters)):
+            h_in = _out_size(self.img_sz[2], self.strides[:i])
+            h_out = _out_size(self.img_sz[2], self.strides[:i + 1])
+            lin = ops.LAYOUT_NCDHW if i == 0 else (ops.LAYOUT_BF16_NDHWC_HPS if h_in % 2 == 0 else ops.LAYOUT_BF16_NDHWC)
+            lout = ops.LAYOUT_NCDHW if i == last else (ops.LAYOUT_BF16_NDHWC_HPS if h_out % 2 == 0 else ops.LAYOUT_BF16_NDHWC)
+            self._bf16_layouts.append((lin, lout))
         # backward chaining: block i+1's data gradient applies block i's LeakyReLU mask in its epilogue and hands
         # block i its pre-activation gradient directly (one pass over the big activations less per block)
         for i in range(last):
@@ -142,14 +162,14 @@ class model(nn.Module):
             self.pca_vectors_LxM = vec
             self.pca_mean = torch.zeros((M,), dtype=torch.float32, device=device)
 
-    def _packed_weight(self, i):
+    def _packed_weight(self, i, bf16=False):
         blk = self.encoders[i]
         w = blk.conv.weight
         key = (w.data_ptr(), w._version, str(w.device))
-        hit = self._packed.get(i)
+        hit = self._packed.get((i, bf16))
         if hit is None or hit[0] != key:
-            hit = (key, ops.conv3d_pack_weights(w, blk.in_layout))
-            self._packed[i] = hit
+            hit = (key, ops.conv3d_pack_weights_bf16(w) if bf16 else ops.conv3d_pack_weights(w, blk.in_layout))
+            self._packed[(i, bf16)] = hit
         return hit[1]
 
     def _estimate_flow(self, moving, target_proj, poses):
@@ -171,6 +191,20 @@ class model(nn.Module):
         x = torch.empty((B, P + 1, D, W, H), dtype=torch.float32, device=moving.device)
         x[:, 0:1].copy_(moving)
         ops.backproject(target_proj, self._poses, (D, W, H), out=x[:, 1:], out_batch_stride=(P + 1) * V)
+        if self.conv_dtype == "bf16":
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                raise NotImplementedError('conv_dtype="bf16" is an inference path: call under torch.no_grad()')
+            for i in range(6):
+                blk = self.encoders[i]
+                lin, lout = self._bf16_layouts[i]
+                if i == 0:       # fp32 input and fp32 MFMA, output rounded to bf16
+                    x = ops.conv3d_k3_lrelu(x, blk.conv.weight, blk.conv.bias, blk.stride, in_layout=lin, out_layout=lout,
+                                            negative_slope=blk._slope, packed=self._packed_weight(0))
+                else:
+                    x = ops.conv3d_k3_lrelu_bf16(x, blk.conv.weight, blk.conv.bias, blk.stride, in_layout=lin,
+                                                 out_layout=lout, negative_slope=blk._slope,
+                                                 packed=self._packed_weight(i, bf16=True))
+            return self.encoders[6](x)
         for i in range(6):
             x = self.encoders[i](x, packed=self._packed_weight(i))
         return self.encoders[6](x)

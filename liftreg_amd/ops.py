@@ -13,6 +13,8 @@ import torch
 from . import _hip
 
 LAYOUT_NCDHW, LAYOUT_NDHWC, LAYOUT_NDHWC_HPS = _hip.LAYOUT_NCDHW, _hip.LAYOUT_NDHWC, _hip.LAYOUT_NDHWC_HPS
+LAYOUT_BF16_NDHWC, LAYOUT_BF16_NDHWC_HPS = _hip.LAYOUT_BF16_NDHWC, _hip.LAYOUT_BF16_NDHWC_HPS
+MFMA_BF16_PEAK_TF = 2516.6   # dense bf16 MFMA peak of MI355X (TFLOP/s) — roofline denominator of the bf16 blocks
 
 
 # ----------------------------------------------------------------------------- helpers
@@ -220,14 +222,69 @@ def conv3d_k3_lrelu(x, weight, bias, stride, *, in_layout=LAYOUT_NCDHW, out_layo
     o = lambda n: (n - 1) // stride + 1
     Do, Wo, Ho = o(D), o(W), o(H)
     shape = (B, Cout, Do, Wo, Ho) if out_layout == LAYOUT_NCDHW else (B, Do, Wo, Ho, Cout)
-    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    bf16_out = out_layout in (_hip.LAYOUT_BF16_NDHWC, _hip.LAYOUT_BF16_NDHWC_HPS)   # fp32 compute, bf16 storage
+    y = torch.empty(shape, dtype=torch.bfloat16 if bf16_out else torch.float32, device=x.device)
     flops = 2.0 * 27 * Cin * Cout * B * Do * Wo * Ho
-    with _timed(f"conv3d_c{Cin}x{Cout}_s{stride}_{D}", flops=flops,
-                bytes=4 * (x.numel() + y.numel()), samples=B):
+    with _timed(f"conv3d_c{Cin}x{Cout}_s{stride}_{D}" + ("_bf16out" if bf16_out else ""), flops=flops,
+                bytes=4 * x.numel() + y.numel() * y.element_size(), samples=B):
         _hip.check(_hip.lib().lr_conv3d_k3_lrelu_f32(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B,
                                                      Cin, Cout, D, W, H, stride, in_layout, out_layout,
                                                      float(negative_slope), _stream()), "lr_conv3d_k3_lrelu_f32")
     return y
+
+
+def conv3d_pack_weights_bf16(weight):
+    """(Cout,Cin,3,3,3) fp32 parameter → bf16 MFMA operand order for lr_conv3d_k3_lrelu_bf16 (uint8 buffer)."""
+    weight = _dev(weight.detach(), "weight")
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    n = _hip.lib().lr_conv3d_packed_bf16_bytes(Cin, Cout)
+    if n < 0:
+        _hip.check(int(n), "lr_conv3d_packed_bf16_bytes")
+    packed = torch.empty((n,), dtype=torch.uint8, device=weight.device)
+    _hip.check(_hip.lib().lr_conv3d_pack_weights_bf16(weight.data_ptr(), packed.data_ptr(), Cin, Cout, _stream()),
+               "lr_conv3d_pack_weights_bf16")
+    return packed
+
+
+def conv3d_k3_lrelu_bf16(x, weight, bias, stride, *, in_layout, out_layout, negative_slope=0.2, packed=None):
+    """bf16-storage variant of conv3d_k3_lrelu for the stride-2 blocks (C4/C5 "bf16 convs"): x is a bfloat16
+    (B,D,W,H,Cin) tensor in LAYOUT_BF16_NDHWC[_HPS]; fp32 accumulate, bias and LeakyReLU; the output is bfloat16
+    channels-last, or float32 NCDHW for the last block."""
+    x = _dev(x, "x", torch.bfloat16)
+    B, D, W, H, Cin = x.shape
+    Cout = weight.shape[0]
+    if weight.shape[1] != Cin:
+        raise ValueError(f"weight expects Cin={weight.shape[1]}, input has {Cin}")
+    if packed is None:
+        packed = conv3d_pack_weights_bf16(weight)
+    b = None if bias is None else _dev(bias.detach(), "bias")
+    o = lambda n: (n - 1) // stride + 1
+    Do, Wo, Ho = o(D), o(W), o(H)
+    if out_layout == LAYOUT_NCDHW:
+        y = torch.empty((B, Cout, Do, Wo, Ho), dtype=torch.float32, device=x.device)
+    else:
+        y = torch.empty((B, Do, Wo, Ho, Cout), dtype=torch.bfloat16, device=x.device)
+    with _timed(f"conv3d_bf16_c{Cin}x{Cout}_s{stride}_{D}", flops=2.0 * 27 * Cin * Cout * B * Do * Wo * Ho,
+                bytes=2 * x.numel() + y.numel() * y.element_size(), samples=B, peak_tf=MFMA_BF16_PEAK_TF, bound="hbm"):
+        _hip.check(_hip.lib().lr_conv3d_k3_lrelu_bf16(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B, Cin,
+                                                      Cout, D, W, H, stride, in_layout, out_layout,
+                                                      float(negative_slope), _stream()), "lr_conv3d_k3_lrelu_bf16")
+    return y
+
+
+def cast_bf16(x):
+    """fp32 → bfloat16 (round to nearest even), same shape/order."""
+    x = _dev(x, "x")
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _hip.check(_hip.lib().lr_cast_f32_to_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "lr_cast_f32_to_bf16")
+    return y
+
+
+def bf16_hps_to_ndhwc(y):
+    """LAYOUT_BF16_NDHWC_HPS → plain channels-last (tests): rows are [parity][H/2][C]."""
+    H = y.shape[3]
+    h = torch.arange(H, device=y.device)
+    return y[:, :, :, (h & 1) * (H // 2) + (h >> 1)]
 
 
 def hps_to_ndhwc(y):

@@ -320,3 +320,27 @@ def compute_jacobi_map(phi, spacing, use_01=False):
     det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g)
     neg = det < 0
     return float(-(det[neg].astype(np.float64)).sum()) / phi.shape[0], float(neg.sum()) / phi.shape[0]
+
+
+# --------------------------------------------------------------------------- bf16 storage variant (configs C4/C5)
+def _bf16(t):
+    """Round to nearest-even bfloat16 and back (the values a bf16 tensor holds)."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def conv_block_bf16(x, weight, bias, stride, slope=0.2, round_out=True):
+    """The numerics contract of lr_conv3d_k3_lrelu_bf16: bf16-representable inputs, weights rounded to bf16,
+    exact products accumulated in fp32, fp32 bias + LeakyReLU, output rounded to bf16 (not for the last block)."""
+    y = F.leaky_relu(F.conv3d(_bf16(x), _bf16(weight), bias, stride=stride, padding=1), slope)
+    return _bf16(y) if round_out else y
+
+
+def encoder_bf16(params, x, strides=(1, 2, 2, 2, 2, 2)):
+    """conv_dtype="bf16" of the model: block 0 in fp32 with a bf16-rounded output, blocks 1..5 as conv_block_bf16."""
+    for i, s in enumerate(strides):
+        w, b = params[f"encoders.{i}.conv.weight"], params[f"encoders.{i}.conv.bias"]
+        if i == 0:
+            x = _bf16(conv_block(x, w, b, s))
+        else:
+            x = conv_block_bf16(x, w, b, s, round_out=(i != len(strides) - 1))
+    return x

@@ -1,0 +1,119 @@
+"""GPU: the bf16-storage variant of the encoder (BASELINE configs C4/C5: "bf16 convs") against its CPU restatement
+(oracle/ref_ops.py: conv_block_bf16 / encoder_bf16 — bf16-rounded operands, exact products, fp32 accumulation).
+The two differ only by fp32 summation order, which can flip a final bf16 rounding (one bf16 ulp = 2^-8 relative), so
+the bar is: ≥99.5 % of the values identical, the rest within one bf16 ulp."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops as ro
+
+pytestmark = pytest.mark.gpu
+ULP = 2.0 ** -7   # spacing of bf16 relative to the value (8 significant bits)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _close_bf16(got, want, tag):
+    got, want = np.asarray(got, np.float32), np.asarray(want, np.float32)
+    same = got == want
+    assert same.mean() >= 0.995, (tag, same.mean())
+    np.testing.assert_allclose(got, want, rtol=ULP, atol=1e-6, err_msg=tag)
+
+
+def _to_hps(t):       # plain (B,D,W,H,C) → [parity][H/2][C] rows
+    H = t.shape[3]
+    h = torch.arange(H, device=t.device)
+    inv = torch.empty(H, dtype=torch.long, device=t.device)
+    inv[(h & 1) * (H // 2) + (h >> 1)] = h
+    return t[:, :, :, inv].contiguous()
+
+
+def test_bf16_blocks_all_layouts(dev):
+    from liftreg_amd import ops
+    rs = np.random.RandomState(31)
+    L = ops
+    cases = [  # cin, cout, shape, B, in_layout, out_layout
+        (16, 32, (8, 10, 20), 2, L.LAYOUT_BF16_NDHWC_HPS, L.LAYOUT_BF16_NDHWC_HPS),
+        (16, 32, (7, 9, 11), 1, L.LAYOUT_BF16_NDHWC, L.LAYOUT_BF16_NDHWC),
+        (32, 32, (8, 8, 16), 2, L.LAYOUT_BF16_NDHWC_HPS, L.LAYOUT_NCDHW),
+        (32, 32, (5, 6, 7), 3, L.LAYOUT_BF16_NDHWC, L.LAYOUT_BF16_NDHWC_HPS),
+        (32, 16, (6, 6, 36), 1, L.LAYOUT_BF16_NDHWC_HPS, L.LAYOUT_BF16_NDHWC),
+        (16, 16, (4, 5, 34), 1, L.LAYOUT_BF16_NDHWC_HPS, L.LAYOUT_BF16_NDHWC),
+    ]
+    for cin, cout, shape, B, il, ol in cases:
+        x = torch.from_numpy(rs.uniform(-1, 1, (B, cin) + shape).astype(np.float32)).to(torch.bfloat16)
+        w = torch.from_numpy((rs.normal(0, 1, (cout, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32))
+        b = torch.from_numpy(rs.uniform(-0.1, 0.1, cout).astype(np.float32))
+        want = ro.conv_block_bf16(x.float(), w, b, 2, round_out=(ol != L.LAYOUT_NCDHW))
+        xd = x.permute(0, 2, 3, 4, 1).contiguous().to(dev)
+        if il == L.LAYOUT_BF16_NDHWC_HPS:
+            xd = _to_hps(xd)
+        y = ops.conv3d_k3_lrelu_bf16(xd, w.to(dev), b.to(dev), 2, in_layout=il, out_layout=ol)
+        tag = str((cin, cout, shape, il, ol))
+        if ol == L.LAYOUT_NCDHW:
+            assert y.dtype == torch.float32
+            np.testing.assert_allclose(y.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-6, err_msg=tag)
+        else:
+            assert y.dtype == torch.bfloat16
+            if ol == L.LAYOUT_BF16_NDHWC_HPS:
+                y = ops.bf16_hps_to_ndhwc(y)
+            _close_bf16(y.float().permute(0, 4, 1, 2, 3).cpu().numpy(), want.numpy(), tag)
+
+
+def test_first_block_bf16_store_and_cast(dev):
+    """Block 0 (fp32 MFMA) writing bf16 rows, and the stand-alone cast: both round to nearest even like torch."""
+    from liftreg_amd import ops
+    rs = np.random.RandomState(32)
+    x = torch.from_numpy(rs.uniform(-1, 1, (2, 3, 6, 7, 20)).astype(np.float32))
+    w = torch.from_numpy((rs.normal(0, 1, (16, 3, 3, 3, 3)) / 9).astype(np.float32))
+    b = torch.from_numpy(rs.uniform(-0.1, 0.1, 16).astype(np.float32))
+    want = ro._bf16(ro.conv_block(x, w, b, 1))
+    for ol in (ops.LAYOUT_BF16_NDHWC, ops.LAYOUT_BF16_NDHWC_HPS):
+        y = ops.conv3d_k3_lrelu(x.to(dev), w.to(dev), b.to(dev), 1, out_layout=ol)
+        assert y.dtype == torch.bfloat16
+        if ol == ops.LAYOUT_BF16_NDHWC_HPS:
+            y = ops.bf16_hps_to_ndhwc(y)
+        _close_bf16(y.float().permute(0, 4, 1, 2, 3).cpu().numpy(), want.numpy(), f"conv0 {ol}")
+    v = torch.from_numpy(rs.normal(0, 3, 100003).astype(np.float32))
+    assert torch.equal(ops.cast_bf16(v.to(dev)).cpu(), v.to(torch.bfloat16))
+
+
+def test_model_bf16_encoder_vs_oracle_and_fp32(dev):
+    """conv_dtype="bf16": PCA coefficients against the CPU restatement of the same bf16 contract, and the distance
+    to the fp32 model (the precision price of bf16 storage, reported not hidden)."""
+    from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+    from liftreg_amd import ops
+    n, P, Lat, B = 64, 2, 8, 2
+    torch.manual_seed(7)
+    net = model([n, n, n], {"drr_feature_num": P, "latent_dim": Lat, "pca_path": "synthetic:7", "conv_dtype": "bf16"}).to(dev).eval()
+    ref32 = model([n, n, n], {"drr_feature_num": P, "latent_dim": Lat, "pca_path": "synthetic:7"}).to(dev).eval()
+    ref32.load_state_dict(net.state_dict())
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    poses = ro.scan_poses(30, P, n).astype(np.float32)
+    inp = {"source": torch.rand((B, 1, n, n, n), generator=g, device=dev) * 2 - 1,
+           "target": torch.rand((B, 1, n, n, n), generator=g, device=dev) * 2 - 1,
+           "target_proj": torch.rand((B, P, n, n), generator=g, device=dev) * 2 - 1,
+           "target_poses": torch.from_numpy(np.broadcast_to(poses, (B, P, 3)).copy())}
+    with torch.no_grad():
+        out = net(inp)
+        out32 = ref32(inp)
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    tv = ops.backproject(inp["target_proj"], poses, (n, n, n)).cpu()
+    feat = ro.encoder_bf16(sd, torch.cat([inp["source"].cpu(), tv], 1)).flatten(1)
+    h = ro.fc_block(feat, sd["encoders.6.1.fc.weight"], sd["encoders.6.1.fc.bias"])
+    h = ro.fc_block(h, sd["encoders.6.2.fc.weight"], sd["encoders.6.2.fc.bias"])
+    want = ro.fc_block(h, sd["encoders.6.3.fc.weight"], sd["encoders.6.3.fc.bias"], slope=None)
+    got = out["pca_coefs"].cpu().numpy()
+    scale = np.abs(want.numpy()).max()
+    assert np.abs(got - want.numpy()).max() <= 2e-3 * scale          # rounding flips only
+    d32 = np.abs(got - out32["pca_coefs"].cpu().numpy()).max() / scale
+    assert d32 < 5e-2, d32                                             # bf16 storage vs fp32: a few 1e-3 in practice
+    assert out["warped"].dtype == torch.float32                         # fp32 warp, as configs C4/C5 state
+    with pytest.raises(NotImplementedError):
+        net(inp)                                                       # bf16 mode is inference-only

@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class OracleOps:
     """Same call signatures as liftreg_amd.ops for what parallel.py / the model use, on CPU tensors."""
     LAYOUT_NCDHW, LAYOUT_NDHWC, LAYOUT_NDHWC_HPS = 0, 1, 2
+    LAYOUT_BF16_NDHWC, LAYOUT_BF16_NDHWC_HPS = 3, 4
 
     def __init__(self):
         from oracle import c_oracle as co
