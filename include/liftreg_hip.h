@@ -280,6 +280,13 @@ int lr_conv3d_k3_lrelu_bf16(const void* in, const void* packed_w, const float* b
                             int Cout, int D, int W, int H, int stride, int in_layout, int out_layout,
                             float negative_slope, void* stream);
 int lr_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+/* The first block of the bf16 variant: fp32 NCDHW input (CT + backprojection; rounded to bf16 on the way into
+ * the MFMA), stride 1, any Cin (passes of 3 channels), bf16 channels-last output (out_layout 3|4).
+ * packed_w: lr_conv3d_packed_bf16_planar_bytes(...) bytes from lr_conv3d_pack_weights_bf16_planar. */
+int64_t lr_conv3d_packed_bf16_planar_bytes(int Cin, int Cout);
+int lr_conv3d_pack_weights_bf16_planar(const float* weight, void* packed, int Cin, int Cout, void* stream);
+int lr_conv3d_first_bf16(const float* in, const void* packed_w, const float* bias, void* out, int B, int Cin,
+                         int Cout, int D, int W, int H, int out_layout, float negative_slope, void* stream);
 
 /* ---- data-side prologue and evaluation reductions -------------------------------------
  * lr_normalize_clip_f32: out = ((clamp(in, lo, hi) - lo) / (hi - lo)) * 2 - 1

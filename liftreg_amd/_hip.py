@@ -53,6 +53,9 @@ SIGNATURES = {
     "lr_conv3d_pack_weights_bf16": (_i, [_p, _p, _i, _i, _p]),
     "lr_conv3d_k3_lrelu_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "lr_cast_f32_to_bf16": (_i, [_p, _p, _i64, _p]),
+    "lr_conv3d_packed_bf16_planar_bytes": (_i64, [_i, _i]),
+    "lr_conv3d_pack_weights_bf16_planar": (_i, [_p, _p, _i, _i, _p]),
+    "lr_conv3d_first_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "lr_normalize_clip_f32": (_i, [_p, _p, _i64, _f, _f, _p]),
     "lr_label_overlap_f32": (_i, [_p, _p, _f, _i64, _p, _i, _p, _p]),
     "lr_jacobi_det_stats_f32": (_i, [_p, _i, _i, _i, _i, _f, _f, _f, _p, _i, _p, _p]),

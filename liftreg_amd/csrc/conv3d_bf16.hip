@@ -169,6 +169,200 @@ __global__ __launch_bounds__(256) void conv3d_cl_bf16_kernel(const u16* __restri
     for (int nt = 0; nt < NT; ++nt) store_tile_any(acc[mt][nt], out, d, b, dz, wo0 + mt, ho, nt, lane, out_layout, slope);
 }
 
+// ===========================================================================================================
+// First block (planar fp32 input, stride 1) on the bf16 MFMA.  Brick = 4 planes (one per wave) x 4 rows x 64
+// voxels.  K order: 27 window rows (channel, tz, ty) x 4 columns (tx = 0..2 and a zero-weight 4th) = 108 -> 128 =
+// four 16x16x32 MFMAs per 16-voxel tile (the fp32 kernel needs 21 16x16x4 MFMAs = 10x the matrix-pipe time): the
+// block turns from MFMA-bound into LDS/HBM-bound.  The input window of a 3-channel pass is rounded to bf16 ONCE
+// while it is staged, and it is kept twice in LDS — the second copy shifted by one element — so that the 4
+// consecutive bf16 a lane needs from a window row (tx = 0..3 at its voxel) always start on a 4-byte boundary in
+// one of the copies: a lane's 8 k-values of an MFMA are two ds_read2_b32 at per-lane row bases + immediate tile
+// offsets, with no conversion and no packing in the sweep.  More than 3 input channels (C4: 11 views + CT = 12)
+// run as passes over the same accumulators.
+constexpr int PH = 64, PW = 4, PD = 4, XOFF = 3;
+constexpr int RB = 76;            // bf16 elements per staged window row (72 + the shift, 8-byte multiple)
+constexpr int WROWS = 3 * 36;     // window rows per pass: 3 channels x 6 planes x 6 rows
+constexpr int COPYB = WROWS * RB; // element offset of the shifted copy
+
+__device__ __forceinline__ unsigned pack2_bf16(float a, float b) { return (unsigned)to_bf16(a) | ((unsigned)to_bf16(b) << 16); }
+
+// SINGLE (Cin <= 3, the model's case): one pass, so a tile's accumulator lives only for its 4 MFMAs and is stored
+// at once — a quarter of the registers, twice the resident blocks, stores spread over the sweep.
+template <int NT, bool SINGLE>
+__global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv0_bf16_kernel(const float* __restrict__ in, const u32x4* __restrict__ wp,
+                                                            const float* __restrict__ bias, void* __restrict__ out,
+                                                            ConvDimsH d, int out_layout, float slope, int vec4) {
+  __shared__ __attribute__((aligned(16))) u16 brick[2 * WROWS * RB];
+  const unsigned lb = lr_xcd_remap(blockIdx.x, gridDim.x);
+  const int hq = lb % d.nHq, wq = (lb / d.nHq) % d.nWq, dq = (lb / d.nHq / d.nWq) % d.nDq;
+  const int b = lb / d.nHq / d.nWq / d.nDq;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, kq = lane >> 4;
+  const int z0 = dq * PD, y0 = wq * PW, x0 = hq * PH;
+  const int64_t V = (int64_t)d.D * d.W * d.H;
+
+  // per-lane element offsets of the two window rows of each MFMA: k = m*32 + kq*8 + h*4 + tx -> row m*8 + kq*2 + h.
+  // The lane's first window column is XOFF + 16t + col: odd -> read the shifted copy (at column + 1, even again).
+  int rbase[4][2];
+  {
+    const int odd = (XOFF + col) & 1;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int rr = m * 8 + kq * 2 + h;
+        if (rr >= 27) rr = 0;  // zero weights: any staged row
+        const int c = rr / 9, tz = (rr / 3) % 3, ty = rr % 3;
+        rbase[m][h] = (c * 36 + (wave + tz) * 6 + ty) * RB + XOFF + col + (odd ? COPYB + 1 : 0);
+      }
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) u16*)brick;  // LDS byte offset
+  f32x4 acc[SINGLE ? 1 : PW * 4][NT];
+  f32x4 bvec[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = bias[nt * 16 + kq * 4 + r];
+    }
+    bvec[nt] = bv;
+#pragma unroll
+    for (int t = 0; t < (SINGLE ? 1 : PW * 4); ++t) acc[t][nt] = bv;
+  }
+  const int dz = z0 + wave;
+  const int npass = (d.Cin + 2) / 3;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int c0 = pass * 3;
+    if (pass) __syncthreads();  // the previous pass is done reading the brick
+    if (vec4) {  // 16-byte loads from the aligned window x0-4 .. x0+67 (H % 4 == 0: a float4 is all in or all out)
+      const float* xb = in + ((int64_t)b * d.Cin + c0) * V;
+      const __amdgpu_buffer_rsrc_t rsrc =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), (short)0, 0x7fffffff, 0x00020000);
+      f32x4 st[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int q = it * 256 + tid;
+        const int row = q / 18, f4 = q - row * 18;
+        const int cc = row / 36, rz = (row / 6) % 6, ry = row % 6;
+        const int zi = z0 - 1 + rz, yi = y0 - 1 + ry, xi = x0 - 4 + f4 * 4;
+        const bool ok = q < WROWS * 18 && c0 + cc < d.Cin && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W && xi >= 0 && xi < d.H;
+        const unsigned voff = ok ? (unsigned)(((int64_t)cc * V + ((int64_t)zi * d.W + yi) * d.H + xi) * 4) : 0x80000000u;
+        st[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+      }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int q = it * 256 + tid;
+        if (q < WROWS * 18) {
+          const int row = q / 18, f4 = q - row * 18;
+          const unsigned lo = pack2_bf16(st[it][0], st[it][1]), hi = pack2_bf16(st[it][2], st[it][3]);
+          u16* a = brick + row * RB + f4 * 4;
+          *reinterpret_cast<uint2*>(a) = make_uint2(lo, hi);                    // copy A: elements e..e+3
+          u16* sh = a + COPYB + 1;                                              // copy B: the same at e+1..e+4
+          sh[0] = (u16)lo;
+          *reinterpret_cast<unsigned*>(sh + 1) = (lo >> 16) | (hi << 16);
+          sh[3] = (u16)(hi >> 16);
+        }
+      }
+    } else {  // unaligned rows: scalar staging of the same window
+      for (int row = wave; row < WROWS; row += 4) {
+        const int cc = row / 36, rz = (row / 6) % 6, ry = row % 6;
+        const int zi = z0 - 1 + rz, yi = y0 - 1 + ry;
+        const bool rowok = c0 + cc < d.Cin && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W;
+        const float* src = in + ((int64_t)b * d.Cin + c0 + cc) * V + ((int64_t)zi * d.W + yi) * d.H;
+        for (int x = lane; x < 72; x += 64) {
+          const int xi = x0 - 4 + x;
+          const u16 v = to_bf16((rowok && xi >= 0 && xi < d.H) ? src[xi] : 0.0f);
+          brick[row * RB + x] = v;
+          brick[COPYB + row * RB + x + 1] = v;
+        }
+      }
+    }
+    u32x4 w[4][NT];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) w[m][nt] = wp[(((int64_t)pass * 4 + m) * NT + nt) * 64 + lane];
+    __syncthreads();
+    // ds_read2_b32 by hand: the 4 bf16 of a window row start on a 4-byte (not 8-byte) boundary, and a
+    // 4-byte-aligned ds_read_b64 (what the compiler picks for such a pair) runs several times slower here.
+    // The wait takes the tile's 8 results as in/out operands: nothing that uses them can be scheduled above it.
+    // (Issuing tile i+1's reads ahead of tile i's MFMAs measured no faster: the sweep is VALU/issue-bound.)
+#pragma unroll
+    for (int r = 0; r < PW; ++r)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ti = SINGLE ? 0 : r * 4 + t;
+        unsigned long long pr[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3"
+                         : "=v"(pr[m][h])
+                         : "v"(lds0 + (unsigned)rbase[m][h] * 2u), "n"((r * RB + t * 16) / 2), "n"((r * RB + t * 16) / 2 + 1)
+                         : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(pr[0][0]), "+v"(pr[0][1]), "+v"(pr[1][0]), "+v"(pr[1][1]), "+v"(pr[2][0]), "+v"(pr[2][1]),
+                       "+v"(pr[3][0]), "+v"(pr[3][1])
+                     :
+                     : "memory");
+        if (SINGLE) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[0][nt] = bvec[nt];
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const u32x4 bv = {(unsigned)pr[m][0], (unsigned)(pr[m][0] >> 32), (unsigned)pr[m][1], (unsigned)(pr[m][1] >> 32)};
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[ti][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[m][nt]),
+                                                                  __builtin_bit_cast(bf16x8, bv), acc[ti][nt], 0, 0, 0);
+        }
+        if (SINGLE && dz < d.D) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            store_tile_any(acc[0][nt], out, d, b, dz, y0 + r, x0 + t * 16 + col, nt, lane, out_layout, slope);
+        }
+      }
+  }
+  if (!SINGLE && dz < d.D) {
+#pragma unroll
+    for (int r = 0; r < PW; ++r)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          store_tile_any(acc[r * 4 + t][nt], out, d, b, dz, y0 + r, x0 + t * 16 + col, nt, lane, out_layout, slope);
+  }
+}
+
+// packed[((pass*4 + m)*NT + nt)*64 + lane]: k = m*32 + kq*8 + h*4 + tx -> window row rr = m*8 + kq*2 + h =
+// (c, tz, ty), W[co = nt*16 + (lane&15)][channel pass*3 + c][tap (tz,ty,tx)], zero for tx = 3 and rr >= 27
+__global__ void pack_bf16_planar_kernel(const float* __restrict__ w, u32x4* __restrict__ packed, int Cin, int Cout,
+                                        int NT) {
+  const int npass = (Cin + 2) / 3;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= npass * 4 * NT * 64) return;
+  const int lane = idx & 63, nt = (idx >> 6) % NT, m = (idx >> 6) / NT % 4, pass = (idx >> 6) / NT / 4;
+  const int co = nt * 16 + (lane & 15), kq = lane >> 4;
+  unsigned r[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    unsigned pair = 0u;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int i = 2 * p + hh, rr = m * 8 + kq * 2 + (i >> 2), tx = i & 3;
+      const int ci = pass * 3 + rr / 9, tap = ((rr / 3) % 3) * 9 + (rr % 3) * 3 + tx;
+      const float v = (rr < 27 && tx < 3 && ci < Cin && co < Cout) ? w[((int64_t)co * Cin + ci) * 27 + tap] : 0.0f;
+      pair |= (unsigned)to_bf16(v) << (16 * hh);
+    }
+    r[p] = pair;
+  }
+  packed[idx] = (u32x4){r[0], r[1], r[2], r[3]};
+}
+
 // packed[(s*NT + nt)*64 + lane] = the 8 bf16 weights W[co = nt*16 + (lane&15)][k-block lane>>4] of MFMA step s
 __global__ void pack_bf16_kernel(const float* __restrict__ w, u32x4* __restrict__ packed, int Cin, int Cout, int NT) {
   const int NS = Cin == 32 ? 27 : 14;
@@ -213,6 +407,50 @@ extern "C" int lr_conv3d_pack_weights_bf16(const float* weight, void* packed, in
   const int total = (Cin == 32 ? 27 : 14) * (Cout / 16) * 64;
   hipLaunchKernelGGL(pack_bf16_kernel, dim3((total + 255) / 256), dim3(256), 0, lr_stream(stream), weight,
                      reinterpret_cast<u32x4*>(packed), Cin, Cout, Cout / 16);
+  return lr_launch_status();
+}
+
+extern "C" int64_t lr_conv3d_packed_bf16_planar_bytes(int Cin, int Cout) {
+  if (Cin < 1 || (Cout != 16 && Cout != 32)) return LR_EUNSUPPORTED;
+  return (int64_t)((Cin + 2) / 3) * 4 * (Cout / 16) * 64 * 16;
+}
+
+extern "C" int lr_conv3d_pack_weights_bf16_planar(const float* weight, void* packed, int Cin, int Cout, void* stream) {
+  if (!weight || !packed) return LR_ENULL;
+  if (Cin < 1 || (Cout != 16 && Cout != 32)) return LR_EUNSUPPORTED;
+  if (reinterpret_cast<uintptr_t>(packed) & 15u) return LR_EALIGN;
+  const int total = ((Cin + 2) / 3) * 4 * (Cout / 16) * 64;
+  hipLaunchKernelGGL(pack_bf16_planar_kernel, dim3((total + 255) / 256), dim3(256), 0, lr_stream(stream), weight,
+                     reinterpret_cast<u32x4*>(packed), Cin, Cout, Cout / 16);
+  return lr_launch_status();
+}
+
+// The encoder's first block in the bf16 variant: fp32 NCDHW input (rounded to bf16 on the way into the MFMA),
+// stride 1, bf16 channels-last output.
+extern "C" int lr_conv3d_first_bf16(const float* in, const void* packed_w, const float* bias, void* out, int B, int Cin,
+                                    int Cout, int D, int W, int H, int out_layout, float negative_slope,
+                                    void* stream) {
+  if (!in || !packed_w || !out) return LR_ENULL;
+  if (B < 1 || Cin < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
+  if (Cout != 16 && Cout != 32) return LR_EUNSUPPORTED;
+  if (out_layout != LR_LAYOUT_BF16_NDHWC && out_layout != LR_LAYOUT_BF16_NDHWC_HPS) return LR_EINVAL;
+  if (out_layout == LR_LAYOUT_BF16_NDHWC_HPS && (H & 1)) return LR_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(packed_w) & 15u) || (reinterpret_cast<uintptr_t>(out) & 7u)) return LR_EALIGN;
+  ConvDimsH d;
+  d.B = B; d.Cin = Cin; d.Cout = Cout; d.D = D; d.W = W; d.H = H; d.Do = D; d.Wo = W; d.Ho = H;
+  d.nHq = (H + PH - 1) / PH; d.nWq = (W + PW - 1) / PW; d.nDq = (D + PD - 1) / PD;
+  const int64_t nblk = (int64_t)B * d.nDq * d.nWq * d.nHq;
+  if (nblk > 0x7fffffffLL) return LR_EINVAL;
+  const int vec4 = (H % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0) &&
+                   ((int64_t)3 * D * W * H * 4 + (int64_t)16 * W * H * 4 < 0x7fffffffLL);
+  const dim3 grid((unsigned)nblk), block(256);
+  hipStream_t st = lr_stream(stream);
+  const u32x4* wt = reinterpret_cast<const u32x4*>(packed_w);
+#define LR_C0(NTV, SG) \
+  hipLaunchKernelGGL((conv0_bf16_kernel<NTV, SG>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope, vec4)
+  if (Cout == 16) { if (Cin <= 3) LR_C0(1, true); else LR_C0(1, false); }
+  else            { if (Cin <= 3) LR_C0(2, true); else LR_C0(2, false); }
+#undef LR_C0
   return lr_launch_status();
 }
 

@@ -704,11 +704,26 @@ __global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_ke
     }
 }
 
-// partial[k][co][n] summed over the nblk partials in double (fixed order), column n -> (ci, tap) of gw
-__global__ void wgrad_finish_kernel(const float* __restrict__ partial, float* __restrict__ gw, float* __restrict__ gb,
-                                    int nblk, int Cout, int Cin, int ncols, int x_layout, int gb_col) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // (co, n): consecutive threads read consecutive floats
-  if (t >= Cout * ncols) return;
+// partial[k][co][n] summed over the nblk partials in double (fixed order), column n -> (ci, tap) of gw.
+// Block = 64 columns x 16 slices of k: consecutive threads read consecutive floats, the 16 slice sums meet in LDS.
+__global__ __launch_bounds__(1024) void wgrad_finish_kernel(const float* __restrict__ partial, float* __restrict__ gw,
+                                                            float* __restrict__ gb, int nblk, int Cout, int Cin,
+                                                            int ncols, int x_layout, int gb_col) {
+  __shared__ double red[16][64];
+  const int tx = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + tx;  // (co, n)
+  const bool live = t < Cout * ncols;
+  double s = 0.0;
+  if (live) {
+    const int64_t step = (int64_t)Cout * ncols;
+    const int per = (nblk + 15) / 16, k0 = sl * per, k1 = min(nblk, k0 + per);
+    for (int k = k0; k < k1; ++k) s += (double)partial[k * step + t];
+  }
+  red[sl][tx] = s;
+  __syncthreads();
+  if (sl != 0 || !live) return;
+#pragma unroll
+  for (int i = 1; i < 16; ++i) s += red[i][tx];
   const int co = t / ncols, n = t - co * ncols;
   int ci, tap;
   if (x_layout == LR_LAYOUT_NCDHW) {
@@ -717,13 +732,8 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ partial, float* __
     const int cbn = (Cin + 15) >> 4, j = n >> 4;
     tap = j / cbn; ci = (j - tap * cbn) * 16 + (n & 15);
   }
-  const bool is_gb = gb != nullptr && n == gb_col;  // the ones column of the fast paths
-  if (!is_gb && (ci >= Cin || tap >= 27)) return;
-  double s = 0.0;
-  const int64_t step = (int64_t)Cout * ncols;
-  for (int k = 0; k < nblk; ++k) s += (double)partial[k * step + t];
-  if (is_gb) gb[co] = (float)s;
-  else gw[((int64_t)co * Cin + ci) * 27 + tap] = (float)s;
+  if (gb != nullptr && n == gb_col) gb[co] = (float)s;  // the ones column of the fast paths
+  else if (ci < Cin && tap < 27) gw[((int64_t)co * Cin + ci) * 27 + tap] = (float)s;
 }
 
 // bias gradient on the generic path: per-block channel sums of gpre (B*V, C) -> partial -> sum_partials_kernel
@@ -860,7 +870,7 @@ extern "C" int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gp
     const int planar = x_layout == LR_LAYOUT_NCDHW;
     const int ncols = planar ? d.ntiles * 16 : (d.ntiles + 1) * 16;
     const int n = Cout * ncols;
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, partial, gw, gb, nparts, Cout, Cin,
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, partial, gw, gb, nparts, Cout, Cin,
                        ncols, x_layout, planar ? 27 * Cin : d.ntiles * 16);
     return lr_launch_status();
   }
@@ -868,7 +878,7 @@ extern "C" int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gp
   else hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, x, gpre, partial, d, ngroups);
   if (int e = lr_launch_status()) return e;
   const int n = Cout * d.ntiles * 16;
-  hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, partial, gw, (float*)nullptr, nblk,
+  hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, partial, gw, (float*)nullptr, nblk,
                      Cout, Cin, d.ntiles * 16, x_layout, -1);
   if (int e = lr_launch_status()) return e;
   if (gb) {  // generic path: the bias gradient from its own reduction (partial is free again: stream order)

@@ -168,7 +168,11 @@ class model(nn.Module):
         key = (w.data_ptr(), w._version, str(w.device))
         hit = self._packed.get((i, bf16))
         if hit is None or hit[0] != key:
-            hit = (key, ops.conv3d_pack_weights_bf16(w) if bf16 else ops.conv3d_pack_weights(w, blk.in_layout))
+            if bf16:
+                pk = ops.conv3d_pack_weights_bf16_planar(w) if i == 0 else ops.conv3d_pack_weights_bf16(w)
+            else:
+                pk = ops.conv3d_pack_weights(w, blk.in_layout)
+            hit = (key, pk)
             self._packed[(i, bf16)] = hit
         return hit[1]
 
@@ -197,9 +201,9 @@ class model(nn.Module):
             for i in range(6):
                 blk = self.encoders[i]
                 lin, lout = self._bf16_layouts[i]
-                if i == 0:       # fp32 input and fp32 MFMA, output rounded to bf16
-                    x = ops.conv3d_k3_lrelu(x, blk.conv.weight, blk.conv.bias, blk.stride, in_layout=lin, out_layout=lout,
-                                            negative_slope=blk._slope, packed=self._packed_weight(0))
+                if i == 0:       # fp32 input, rounded to bf16 on the way into the MFMA
+                    x = ops.conv3d_first_bf16(x, blk.conv.weight, blk.conv.bias, out_layout=lout,
+                                              negative_slope=blk._slope, packed=self._packed_weight(0, bf16=True))
                 else:
                     x = ops.conv3d_k3_lrelu_bf16(x, blk.conv.weight, blk.conv.bias, blk.stride, in_layout=lin,
                                                  out_layout=lout, negative_slope=blk._slope,

@@ -272,6 +272,39 @@ def conv3d_k3_lrelu_bf16(x, weight, bias, stride, *, in_layout, out_layout, nega
     return y
 
 
+def conv3d_pack_weights_bf16_planar(weight):
+    """(Cout,Cin,3,3,3) fp32 → bf16 operand order of lr_conv3d_first_bf16 (passes of 3 input channels)."""
+    weight = _dev(weight.detach(), "weight")
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    n = _hip.lib().lr_conv3d_packed_bf16_planar_bytes(Cin, Cout)
+    if n < 0:
+        _hip.check(int(n), "lr_conv3d_packed_bf16_planar_bytes")
+    packed = torch.empty((n,), dtype=torch.uint8, device=weight.device)
+    _hip.check(_hip.lib().lr_conv3d_pack_weights_bf16_planar(weight.data_ptr(), packed.data_ptr(), Cin, Cout, _stream()),
+               "lr_conv3d_pack_weights_bf16_planar")
+    return packed
+
+
+def conv3d_first_bf16(x, weight, bias, *, out_layout, negative_slope=0.2, packed=None):
+    """The encoder's first block in the bf16 variant: x float32 (B,Cin,D,W,H), stride 1, output bfloat16
+    (B,D,W,H,Cout) in LAYOUT_BF16_NDHWC[_HPS].  Inputs are rounded to bf16 on the way into the MFMA."""
+    x = _dev(x, "x")
+    B, Cin, D, W, H = x.shape
+    Cout = weight.shape[0]
+    if weight.shape[1] != Cin:
+        raise ValueError(f"weight expects Cin={weight.shape[1]}, input has {Cin}")
+    if packed is None:
+        packed = conv3d_pack_weights_bf16_planar(weight)
+    b = None if bias is None else _dev(bias.detach(), "bias")
+    y = torch.empty((B, D, W, H, Cout), dtype=torch.bfloat16, device=x.device)
+    with _timed(f"conv3d_bf16_c{Cin}x{Cout}_s1_{D}", flops=2.0 * 27 * Cin * Cout * B * D * W * H,
+                bytes=4 * x.numel() + 2 * y.numel(), samples=B, peak_tf=MFMA_BF16_PEAK_TF, bound="hbm"):
+        _hip.check(_hip.lib().lr_conv3d_first_bf16(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B, Cin, Cout,
+                                                   D, W, H, out_layout, float(negative_slope), _stream()),
+                   "lr_conv3d_first_bf16")
+    return y
+
+
 def cast_bf16(x):
     """fp32 → bfloat16 (round to nearest even), same shape/order."""
     x = _dev(x, "x")

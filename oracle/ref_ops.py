@@ -336,11 +336,9 @@ def conv_block_bf16(x, weight, bias, stride, slope=0.2, round_out=True):
 
 
 def encoder_bf16(params, x, strides=(1, 2, 2, 2, 2, 2)):
-    """conv_dtype="bf16" of the model: block 0 in fp32 with a bf16-rounded output, blocks 1..5 as conv_block_bf16."""
+    """conv_dtype="bf16" of the model: every block as conv_block_bf16 (block 0 rounds its fp32 input on the way in);
+    the last block's output stays fp32."""
     for i, s in enumerate(strides):
         w, b = params[f"encoders.{i}.conv.weight"], params[f"encoders.{i}.conv.bias"]
-        if i == 0:
-            x = _bf16(conv_block(x, w, b, s))
-        else:
-            x = conv_block_bf16(x, w, b, s, round_out=(i != len(strides) - 1))
+        x = conv_block_bf16(x, w, b, s, round_out=(i != len(strides) - 1))
     return x

@@ -79,6 +79,20 @@ def test_first_block_bf16_store_and_cast(dev):
         if ol == ops.LAYOUT_BF16_NDHWC_HPS:
             y = ops.bf16_hps_to_ndhwc(y)
         _close_bf16(y.float().permute(0, 4, 1, 2, 3).cpu().numpy(), want.numpy(), f"conv0 {ol}")
+    # the bf16-MFMA first block: inputs rounded to bf16 too; 3 channels (one pass), 12 channels (4 passes, C4's
+    # 11 views + CT), a 5-channel ragged last pass, H not a multiple of 4 (scalar staging) and Cout = 32
+    for cin, cout, shape, B in ((3, 16, (6, 7, 20), 2), (12, 16, (5, 4, 72), 1), (5, 32, (4, 9, 13), 1), (3, 16, (9, 6, 130), 1)):
+        x = torch.from_numpy(rs.uniform(-1, 1, (B, cin) + shape).astype(np.float32))
+        w = torch.from_numpy((rs.normal(0, 1, (cout, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32))
+        b = torch.from_numpy(rs.uniform(-0.1, 0.1, cout).astype(np.float32))
+        want = ro.conv_block_bf16(x, w, b, 1)
+        for ol in (ops.LAYOUT_BF16_NDHWC, ops.LAYOUT_BF16_NDHWC_HPS):
+            if ol == ops.LAYOUT_BF16_NDHWC_HPS and shape[2] % 2:
+                continue
+            y = ops.conv3d_first_bf16(x.to(dev), w.to(dev), b.to(dev), out_layout=ol)
+            if ol == ops.LAYOUT_BF16_NDHWC_HPS:
+                y = ops.bf16_hps_to_ndhwc(y)
+            _close_bf16(y.float().permute(0, 4, 1, 2, 3).cpu().numpy(), want.numpy(), f"first_bf16 {cin} {cout} {shape} {ol}")
     v = torch.from_numpy(rs.normal(0, 3, 100003).astype(np.float32))
     assert torch.equal(ops.cast_bf16(v.to(dev)).cpu(), v.to(torch.bfloat16))
 

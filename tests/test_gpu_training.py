@@ -62,7 +62,7 @@ def test_training_step_gradients(dev, shape, P, L, B, labels):
     got["total_loss"].backward()
 
     want, params = _cpu_step(net.state_dict(), inp, net.pca_vectors_LxM.cpu(), net.pca_mean.cpu(), 0)
-    assert abs(float(got["total_loss"]) - float(want["total_loss"])) < 1e-5
+    assert abs(float(got["total_loss"].detach()) - float(want["total_loss"].detach())) < 1e-5
     assert abs(got["sim_loss"] - want["sim_loss"]) < 1e-5 and abs(got["reg_loss"] - want["reg_loss"]) < 1e-6
     named = dict(net.named_parameters())
     assert len(named) == 18
