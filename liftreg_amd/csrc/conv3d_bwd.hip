@@ -230,7 +230,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_dgrad_lds_kernel(const float* _
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int zq0 = dq * 4, yq0 = wq * DMT, xq0 = hq * 16;
   {
-    const float* base = gpre + (int64_t)b * d.Do * d.Wo * d.Ho * CG;
+    // resource = the tile's own origin: offsets stay inside five planes whatever the volume size
+    const float* base = gpre + ((((int64_t)b * d.Do + zq0) * d.Wo + yq0) * d.Ho + xq0) * CG;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, 0x7fffffff, 0x00020000);
     float4 st[NIT];
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_dgrad_lds_kernel(const float* _
       const int xx = vox % 17, r = vox / 17, yy = r % 5, zz = r / 5;
       const int zs = zq0 + zz, ys = yq0 + yy, xs = xq0 + xx;
       const bool ok = q < NCH && zs < d.Do && ys < d.Wo && xs < d.Ho;
-      const unsigned voff = ok ? (unsigned)(((((zs * d.Wo) + ys) * d.Ho + xs) * CG + c4 * 4) * 4) : OOR;
+      const unsigned voff = ok ? (unsigned)(((((zz * d.Wo) + yy) * d.Ho + xx) * CG + c4 * 4) * 4) : OOR;
       st[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
     }
 #pragma unroll
@@ -520,16 +521,18 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
     const int b = r / d.Do;
     const int ho0 = hseg * HB;
     const int zi0 = 2 * dz - 1, yi0 = 2 * wo - 1, xi0 = 2 * ho0 - 1;
-    const float* xb = xin + (int64_t)b * d.D * d.W * d.H * Cin;
+    // resource = the window's own origin (it may lie before the tensor: never dereferenced there), so the byte
+    // offsets stay inside three planes whatever the volume size
+    const float* xb = xin + (int64_t)b * d.D * d.W * d.H * Cin +
+                      (HPS ? ((int64_t)zi0 * d.W + yi0) * d.H * Cin + (int64_t)ho0 * 16
+                           : (((int64_t)zi0 * d.W + yi0) * d.H + xi0) * Cin);
     const __amdgpu_buffer_rsrc_t rx =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), (short)0, 0x7fffffff, 0x00020000);
-    const unsigned org = HPS ? (unsigned)((((zi0 * d.W + yi0) * d.H * Cin) + ho0 * 16) * 4)
-                             : (unsigned)(((((zi0 * d.W + yi0) * d.H + xi0) * Cin)) * 4);
 #pragma unroll
     for (int it = 0; it < G::XIT; ++it) {
       const int zi = zi0 + (xdec[it] & 3), yi = yi0 + ((xdec[it] >> 2) & 3), xi = xi0 + ((xdec[it] >> 4) & 255);
       const bool ok = live && (xdec[it] >> 12) && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W && xi >= 0 && xi < d.H;
-      const unsigned voff = ok ? org + xrel[it] : OOR;
+      const unsigned voff = ok ? xrel[it] : OOR;
       xst[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, 0));
     }
     const float* gb = gpre + ((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + ho0) * Cout;
@@ -787,7 +790,8 @@ extern "C" int lr_conv3d_dgrad_f32(const float* gpre, const float* packed_wT, fl
   DgDims d;
   d.B = B; d.Cg = Cg; d.Cx = Cx; d.D = D; d.W = W; d.H = H;
   d.Do = (D - 1) / 2 + 1; d.Wo = (W - 1) / 2 + 1; d.Ho = (H - 1) / 2 + 1;
-  if ((int64_t)d.Do * d.Wo * d.Ho * Cg * 4 >= 0x7fffffffLL) return LR_EINVAL;  // 31-bit buffer offsets per batch element
+  const bool lds_path = Cg == 16 || Cg == 32;  // tile-relative offsets (five planes); the direct kernel: per batch element
+  if ((lds_path ? (int64_t)6 * d.Wo * d.Ho * Cg * 4 : (int64_t)d.Do * d.Wo * d.Ho * Cg * 4) >= 0x7fffffffLL) return LR_EINVAL;
   d.nHq = ((H + 1) / 2 + 15) / 16; d.nWq = ((W + 1) / 2 + DMT - 1) / DMT; d.nDq = ((D + 1) / 2 + 3) / 4;
   d.gx_layout = gx_layout;
   if (x_saved && x_layout != LR_LAYOUT_NDHWC && x_layout != LR_LAYOUT_NDHWC_HPS) return LR_EINVAL;
@@ -832,7 +836,8 @@ extern "C" int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gp
   const bool al16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gpre)) & 15u) == 0;
   const int64_t V = (int64_t)D * W * H;
   int nparts = 0;  // > 0: a fast path ran and left this many partials
-  if (x_layout != LR_LAYOUT_NCDHW && stride == 2 && (Cin == 16 || Cin == 32) && al16 && V * Cin * 4 < 0x7fffffffLL) {
+  if (x_layout != LR_LAYOUT_NCDHW && stride == 2 && (Cin == 16 || Cin == 32) && al16 &&
+      (int64_t)4 * W * H * Cin * 4 < 0x7fffffffLL) {  // a 3-plane window within 31-bit offsets
     // blocks 1..5: LDS-staged bricks (one output row segment each)
     const int hb = 32 / (Cin / 16);
     const int64_t nbricks = (int64_t)B * d.Do * d.Wo * ((d.Ho + hb - 1) / hb);

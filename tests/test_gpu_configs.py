@@ -136,3 +136,43 @@ def test_c1_graph_replay_matches_eager(dev):
         for k in ("pca_coefs", "params", "phi", "warped"):
             assert torch.equal(out[k], want[k]), k
         assert torch.equal(loss, want_loss)
+
+
+def test_c5_conv_backward_at_384(dev):
+    """C5 is the training configuration (384³): block 1's weight and data gradient at that size, where the saved
+    input (16 ch x 384³ x 4 B = 3.6 GB) is past 31-bit byte offsets.  A sparse pre-activation gradient (a few
+    single voxels, including both corners) makes the exact answer a handful of gathered input values."""
+    from liftreg_amd import ops, ops_bwd
+    n, Cin, Cout = 384, 16, 32
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    x = torch.rand((1, n, n, n, Cin), generator=g, device=dev) * 2 - 1            # plain NDHWC
+    w = (torch.rand((Cout, Cin, 3, 3, 3), generator=g, device=dev) - 0.5) * 0.2
+    no = n // 2
+    pts = [((0, 0, 0), 3, 1.5), ((no - 1, no - 1, no - 1), 31, -2.0), ((100, 7, 150), 0, 0.75), ((191, 0, 64), 17, 1.25),
+           ((5, 190, 3), 9, -0.5)]
+    gpre = torch.zeros((1, no, no, no, Cout), device=dev)
+    for (z, y, xx), co, val in pts:
+        gpre[0, z, y, xx, co] = val
+    ydummy = torch.empty_like(gpre)
+    gx, gw, gb = ops_bwd.conv3d_bwd(x, ops.LAYOUT_NDHWC, w, ydummy, ops.LAYOUT_NDHWC, gpre, ops.LAYOUT_NDHWC, 2,
+                                    gy_is_gpre=True)
+    want_gw = torch.zeros_like(w)
+    want_gb = torch.zeros(Cout, device=dev)
+    abs_sum = 0.0
+    for (z, y, xx), co, val in pts:
+        want_gb[co] += val
+        for tz in range(3):
+            for ty in range(3):
+                for tx in range(3):
+                    zi, yi, xi = 2 * z + tz - 1, 2 * y + ty - 1, 2 * xx + tx - 1
+                    if min(zi, yi, xi) < 0 or max(zi, yi, xi) >= n:
+                        continue
+                    want_gw[co, :, tz, ty, tx] += val * x[0, zi, yi, xi]
+                    # data gradient at that input voxel = val * W[co, :, tap] (the points are far apart)
+                    np.testing.assert_allclose(gx[0, zi, yi, xi].cpu().numpy(), (val * w[co, :, tz, ty, tx]).cpu().numpy(),
+                                               rtol=1e-5, atol=1e-7)
+                    abs_sum += float((val * w[co, :, tz, ty, tx]).abs().sum())
+    np.testing.assert_allclose(gw.cpu().numpy(), want_gw.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gb.cpu().numpy(), want_gb.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    assert abs(float(gx.abs().sum(dtype=torch.float64)) - abs_sum) < 1e-3 * abs_sum      # and nothing anywhere else
