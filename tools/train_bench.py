@@ -21,7 +21,8 @@ from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model  # noqa: E402
 from liftreg_amd.utils.sdct_projection_utils import scan_poses  # noqa: E402
 
 CONFIGS = {"c1": dict(n=64, P=2, R=64, B=1, L=56), "c2": dict(n=128, P=2, R=128, B=4, L=56),
-           "c3": dict(n=256, P=2, R=256, B=8, L=56)}
+           "c3": dict(n=256, P=2, R=256, B=8, L=56),
+           "c5": dict(n=384, P=2, R=512, B=4, L=56)}   # C5 per GPU: batch 32 over 8 GPUs
 
 
 def main():
