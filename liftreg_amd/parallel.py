@@ -171,7 +171,7 @@ class SlabShardedRegistration:
         net, comm = self.net, self.comm
         D, W, H = net.img_sz
         P = net.drr_feature_num
-        nloc = len(comm.ranks)
+        bf16 = getattr(net, "conv_dtype", "fp32") == "bf16"
         bounds = [slab_bounds(D, comm.world, r) for r in comm.ranks]
         acts = []
         # ---- block 0 (stride 1): both halo planes come from replicated data → no communication
@@ -188,15 +188,21 @@ class SlabShardedRegistration:
             x[:, 0:1].copy_(moving[:, :, lo:hi])
             x[:, 1:].copy_(ops.backproject(proj, net._poses, (D, W, H), d0=lo, d1=hi))
             blk = net.encoders[0]
-            y = ops.conv3d_k3_lrelu(x, blk.conv.weight, blk.conv.bias, 1, in_layout=blk.in_layout,
-                                    out_layout=blk.out_layout, negative_slope=blk._slope,
-                                    packed=net._packed_weight(0))
-            ax = self._d_axis(blk.out_layout)
+            if bf16:   # conv_dtype="bf16" (C4): bf16 activations, and bf16 halo planes on the wire
+                lay_out = net._bf16_layouts[0][1]
+                y = ops.conv3d_first_bf16(x, blk.conv.weight, blk.conv.bias, out_layout=lay_out,
+                                          negative_slope=blk._slope, packed=net._packed_weight(0, bf16=True))
+            else:
+                lay_out = blk.out_layout
+                y = ops.conv3d_k3_lrelu(x, blk.conv.weight, blk.conv.bias, 1, in_layout=blk.in_layout,
+                                        out_layout=lay_out, negative_slope=blk._slope, packed=net._packed_weight(0))
+            ax = self._d_axis(lay_out)
             acts.append(y.narrow(ax, d0 - lo, d1 - d0).contiguous())
         # ---- blocks 1..5 (stride 2): one halo plane from the rank below per block
         for i in range(1, 6):
             blk = net.encoders[i]
-            ax = self._d_axis(blk.in_layout)
+            lay_in, lay_out = net._bf16_layouts[i] if bf16 else (blk.in_layout, blk.out_layout)
+            ax = self._d_axis(lay_in)
             tops = [a.narrow(ax, a.shape[ax] - 1, 1).contiguous() for a in acts]
             halos = comm.shift_up(tops)
             nxt = []
@@ -204,10 +210,15 @@ class SlabShardedRegistration:
                 plane = torch.zeros_like(a.narrow(ax, 0, 1)) if h is None else h   # rank 0: the conv's zero padding
                 # rows [r0-2, r1): the extra leading plane only aligns the stride phase (its output is dropped)
                 xin = torch.cat([torch.zeros_like(plane), plane, a], dim=ax)
-                y = ops.conv3d_k3_lrelu(xin, blk.conv.weight, blk.conv.bias, 2, in_layout=blk.in_layout,
-                                        out_layout=blk.out_layout, negative_slope=blk._slope,
-                                        packed=net._packed_weight(i))
-                axo = self._d_axis(blk.out_layout)
+                if bf16:
+                    y = ops.conv3d_k3_lrelu_bf16(xin, blk.conv.weight, blk.conv.bias, 2, in_layout=lay_in,
+                                                 out_layout=lay_out, negative_slope=blk._slope,
+                                                 packed=net._packed_weight(i, bf16=True))
+                else:
+                    y = ops.conv3d_k3_lrelu(xin, blk.conv.weight, blk.conv.bias, 2, in_layout=lay_in,
+                                            out_layout=lay_out, negative_slope=blk._slope,
+                                            packed=net._packed_weight(i))
+                axo = self._d_axis(lay_out)
                 nxt.append(y.narrow(axo, 1, y.shape[axo] - 1).contiguous())
             acts = nxt
         # ---- FC head on the gathered features (replicated), then the slab-local decode

@@ -9,8 +9,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,world", [(64, 2), (128, 4), (128, 2)])
-def test_slab_sharded_forward_equals_unsharded(n, world):
+@pytest.mark.parametrize("n,world,conv_dtype", [(64, 2, "fp32"), (128, 4, "fp32"), (128, 2, "fp32"), (128, 4, "bf16")])
+def test_slab_sharded_forward_equals_unsharded(n, world, conv_dtype):
     from liftreg_amd import parallel as par
     from liftreg_amd.layers.losses import NCCLoss
     from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
@@ -20,7 +20,10 @@ def test_slab_sharded_forward_equals_unsharded(n, world):
     g = torch.Generator(device=dev)
     g.manual_seed(3)
     P, L, B = 2, 12, 2
-    net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:9"}).to(dev).eval()
+    if conv_dtype == "bf16":
+        P = 11      # C4: 11-view limited-angle DRR, bf16 convs, 4-way z-slab sharding (bf16 halo planes on the wire)
+    net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:9",
+                            "conv_dtype": conv_dtype}).to(dev).eval()
     poses = scan_poses(30, P, n).astype(np.float32)
     inp = {"source": torch.rand((B, 1, n, n, n), generator=g, device=dev) * 2 - 1,
            "target": torch.rand((B, 1, n, n, n), generator=g, device=dev) * 2 - 1,
