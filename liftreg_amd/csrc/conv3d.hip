@@ -658,8 +658,9 @@ extern "C" int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, co
     if (nblk > 0x7fffffffLL) return LR_EINVAL;
     const dim3 grid((unsigned)nblk);
     const float4* wt = reinterpret_cast<const float4*>(packed_w);
-    if (ps && NT == 1) hipLaunchKernelGGL((conv3d_cl_kernel<1, 2, true>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope);
-    else if (ps) hipLaunchKernelGGL((conv3d_cl_kernel<2, 2, true>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope);
+    const size_t occ_lds = getenv("LIFTREG_CONV_LDS") ? (size_t)atoi(getenv("LIFTREG_CONV_LDS")) : 0;  // tuning aid: caps resident blocks
+    if (ps && NT == 1) hipLaunchKernelGGL((conv3d_cl_kernel<1, 2, true>), grid, block, occ_lds, st, in, wt, bias, out, d, out_layout, negative_slope);
+    else if (ps) hipLaunchKernelGGL((conv3d_cl_kernel<2, 2, true>), grid, block, occ_lds, st, in, wt, bias, out, d, out_layout, negative_slope);
     else if (NT == 1 && stride == 1) hipLaunchKernelGGL((conv3d_cl_kernel<1, 1, false>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope);
     else if (NT == 1) hipLaunchKernelGGL((conv3d_cl_kernel<1, 2, false>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope);
     else if (stride == 1) hipLaunchKernelGGL((conv3d_cl_kernel<2, 1, false>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope);

@@ -79,14 +79,15 @@ def main():
             if i == 0:
                 x = rnd(B, ci, size, size, size)
                 lay = ops.LAYOUT_NCDHW
-            else:
+            else:   # the model's layouts: rows parity-split along H whenever H is even
                 x = rnd(B, size, size, size, ci)
-                lay = ops.LAYOUT_NDHWC
+                lay = ops.LAYOUT_NDHWC_HPS if size % 2 == 0 else ops.LAYOUT_NDHWC
             w = rnd(co, ci, 3, 3, 3) / (27 * ci) ** 0.5
             bb = rnd(co) * 0.1
             pk = ops.conv3d_pack_weights(w, lay)
             so = (size - 1) // s + 1
-            f = lambda: ops.conv3d_k3_lrelu(x, w, bb, s, in_layout=lay, out_layout=ops.LAYOUT_NDHWC, packed=pk)
+            lay_out = ops.LAYOUT_NCDHW if i == 5 else (ops.LAYOUT_NDHWC_HPS if so % 2 == 0 else ops.LAYOUT_NDHWC)
+            f = lambda: ops.conv3d_k3_lrelu(x, w, bb, s, in_layout=lay, out_layout=lay_out, packed=pk)
             report(f"conv{i} {ci}->{co} s{s} @{size}", timeit(f, a.iters), flops=2.0 * 27 * ci * co * B * so ** 3)
             del x
         size = (size - 1) // s + 1
