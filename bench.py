@@ -229,6 +229,35 @@ def main():
         return {"kernel": name, "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
                 "unit": k["unit"], "frac": k["frac"], "traffic": k["traffic"], "avg_ms": k["avg_ms"]}
 
+    # the projector on its own and the simulate+register rate — outside the timed region
+    drr = None
+    if rank == 0:
+        from liftreg_amd.utils.sdct_projection_utils import scan_poses
+        p32 = scan_poses(30, P, n).astype(np.float32)
+        vols = (inp["target"][:, 0] + 1) * 500 - 1000                   # back to HU: the projector folds HU→μ
+        R = cfg["R"]
+
+        def project():
+            return [ops.drr_forward(vols[b], p32, (R, R), (2.2, 2.2, 2.2), hu_input=True, flip_w=True) for b in range(B)]
+
+        with torch.no_grad():
+            project()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                project()
+            torch.cuda.synchronize()
+            t_drr = (time.perf_counter() - t0) / 5                       # B volumes, P views each
+            t0 = time.perf_counter()
+            for _ in range(5):
+                project()
+                step()
+            torch.cuda.synchronize()
+            t_both = (time.perf_counter() - t0) / 5
+        drr = {"volumes_per_s": B / t_drr, "projections_per_s": B * P / t_drr, "ms_per_volume": t_drr / B * 1e3,
+               "simulate_plus_register_per_s": B / t_both,
+               "note": f"{P} views of {R}x{R} per {n}^3 volume, HU->mu and the axis-1 flip folded into the projector"}
+
     result = {
         "metric": "registrations/sec (256^3 CT, 2-view DRR)" if args.config == "c3" else f"registrations/sec ({args.config})",
         "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -245,6 +274,7 @@ def main():
         "kernels": {k: {"ms": round(v["avg_ms"], 4), "n": v["launches_per_step"], "frac": round(v["frac"], 4),
                         "bound": v["bound"]} for k, v in kernels.items()},
         "ncc_loss": float(loss),
+        "drr_forward": drr,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, net, inp)
