@@ -32,6 +32,7 @@ CONFIGS = {  # BASELINE.json configs (single-GPU ones)
     "c1": dict(n=64, P=2, R=64, B=1, L=56),
     "c2": dict(n=128, P=2, R=128, B=4, L=56),
     "c3": dict(n=256, P=2, R=256, B=8, L=56),
+    "c4": dict(n=256, P=11, R=256, B=4, L=56),   # C4 per GPU (batch 16 over 4 GPUs), unsharded here; use --conv-dtype bf16
 }
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* fp32-input matrix peak
