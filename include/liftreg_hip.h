@@ -132,6 +132,9 @@ int lr_backproject_coords_f32(const float* poses, float* pix, int P, int Pw, int
  * out_layout (fp32 compute, output rounded to nearest-even bf16); lr_conv3d_k3_lrelu_bf16 takes them as input. */
 #define LR_LAYOUT_BF16_NDHWC 3
 #define LR_LAYOUT_BF16_NDHWC_HPS 4
+/* fp32 NCDHW whose values the forward rounded to bf16 on the way into the MFMA (the saved input of
+ * lr_conv3d_first_bf16): accepted as x_layout by lr_conv3d_wgrad_f32, which rounds the same way while staging. */
+#define LR_LAYOUT_NCDHW_RBF16 5
 int64_t lr_conv3d_packed_floats(int Cin, int Cout, int in_layout);
 int lr_conv3d_pack_weights_f32(const float* weight, float* packed, int Cin, int Cout,
                                int in_layout, void* stream);

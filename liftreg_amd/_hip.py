@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(CSRC, "libliftreg_hip.so")
 
 LR_OK = 0
 LAYOUT_NCDHW, LAYOUT_NDHWC, LAYOUT_NDHWC_HPS = 0, 1, 2
-LAYOUT_BF16_NDHWC, LAYOUT_BF16_NDHWC_HPS = 3, 4
+LAYOUT_BF16_NDHWC, LAYOUT_BF16_NDHWC_HPS, LAYOUT_NCDHW_RBF16 = 3, 4, 5
 DRR_HU_INPUT, DRR_FLIP_W = 1, 2
 WARP_USING_SCALE, WARP_BORDER, WARP_NEAREST = 1, 2, 4
 NCC_CONFIGURED, NCC_SQUARED = 0, 1

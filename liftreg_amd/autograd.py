@@ -41,6 +41,48 @@ class ConvBlockFn(torch.autograd.Function):
         return gx, gw, (gb if has_bias else None), None, None, None, None, None, None, None
 
 
+class EncoderBf16Fn(torch.autograd.Function):
+    """The six conv blocks of the bf16 variant (conv_dtype="bf16") as ONE autograd node: the activations between the
+    blocks are bfloat16 tensors in private layouts, which autograd could not carry gradients for (a gradient must
+    have its tensor's dtype), so the chain is walked here.  Forward: lr_conv3d_first_bf16 + lr_conv3d_k3_lrelu_bf16.
+    Backward: fp32 gradient math on the bf16-rounded saved activations and weights — exactly the gradient of the
+    forward's arithmetic (oracle: ATen autograd of ref_ops.encoder_bf16): LeakyReLU mask of the last block, then per
+    block the weight/bias gradient and the data gradient fused with the producer's mask (ops_bwd.conv3d_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, layouts, slopes, strides, packed, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        acts = [x]
+        for i in range(6):
+            lin, lout = layouts[i]
+            if i == 0:
+                y = ops.conv3d_first_bf16(acts[-1], ws[0], bs[0], out_layout=lout, negative_slope=slopes[0], packed=packed[0])
+            else:
+                y = ops.conv3d_k3_lrelu_bf16(acts[-1], ws[i], bs[i], strides[i], in_layout=lin, out_layout=lout,
+                                             negative_slope=slopes[i], packed=packed[i])
+            acts.append(y)
+        ctx.save_for_backward(*acts, *ws)
+        ctx.cfg = (layouts, slopes, strides, [b is not None for b in bs])
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, gfeat):
+        layouts, slopes, strides, has_bias = ctx.cfg
+        acts, ws = ctx.saved_tensors[:7], ctx.saved_tensors[7:]
+        grads = [None] * 12
+        g = gfeat.contiguous()
+        for i in range(5, -1, -1):
+            lin, lout = layouts[i]
+            x_layout = _hip.LAYOUT_NCDHW_RBF16 if i == 0 else lin
+            gx, gw, gb = ops_bwd.conv3d_bwd(acts[i], x_layout, ws[i], acts[i + 1], lout, g, lout, strides[i], slopes[i],
+                                            need_gx=(i > 0), gy_is_gpre=(i < 5),
+                                            mask_input_slope=(slopes[i - 1] if i > 0 else None), round_weights=True)
+            grads[2 * i] = gw
+            grads[2 * i + 1] = gb if has_bias[i] else None
+            g = gx
+        return (None, None, None, None, None, *grads)
+
+
 class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, slope):

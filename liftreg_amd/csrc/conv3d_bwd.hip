@@ -15,6 +15,18 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned OOR = 0x80000000u;
+typedef unsigned short u16;
+
+// 4 bf16 (8 bytes) -> 4 floats (exact)
+__device__ __forceinline__ f32x4 bf16x4_to_f32(uint2 p) {
+  f32x4 v;
+  v[0] = __builtin_bit_cast(float, p.x << 16);
+  v[1] = __builtin_bit_cast(float, p.x & 0xffff0000u);
+  v[2] = __builtin_bit_cast(float, p.y << 16);
+  v[3] = __builtin_bit_cast(float, p.y & 0xffff0000u);
+  return v;
+}
+__device__ __forceinline__ float round_bf16(float v) { return (float)(__bf16)v; }  // nearest even, like the forward
 
 // element offset of (b, c, z, y, x) in a tensor of the given layout
 __device__ __forceinline__ int64_t act_off(int layout, int b, int c, int z, int y, int x, int C, int D, int W, int H) {
@@ -80,6 +92,18 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 // only and an odd one taps 0 and 2, so the class fixes its 1|2|4|8 taps and no MFMA multiplies a structural zero.
 // Its 16 columns are 16 same-parity voxels (2 apart along H; contiguous in the parity-split layout); brick per
 // block: 4 planes x 4 rows x 16 voxels of the class.
+// 4 channels (nt*16 + kq*4 ..) of the block's saved input at one voxel, for the LeakyReLU mask of the fused epilogue.
+// x: the voxel's column, hp: its position in a parity-split row; fp32 layouts 1|2, bf16 storage 3|4.
+__device__ __forceinline__ f32x4 load_mask_src(const float* xsave, int layout, int64_t row, int x, int hp, int nt, int kq,
+                                               int H, int Cx) {
+  const int c = nt * 16 + kq * 4;
+  if (layout == LR_LAYOUT_NDHWC) return *reinterpret_cast<const f32x4*>(xsave + row + (int64_t)x * Cx + c);
+  if (layout == LR_LAYOUT_NDHWC_HPS) return *reinterpret_cast<const f32x4*>(xsave + row + ((int64_t)nt * H + hp) * 16 + kq * 4);
+  const u16* xb = reinterpret_cast<const u16*>(xsave);  // bf16: rows [H][C] or [parity][H/2][C]
+  const int64_t o = row + (int64_t)(layout == LR_LAYOUT_BF16_NDHWC ? x : hp) * Cx + c;
+  return bf16x4_to_f32(*reinterpret_cast<const uint2*>(xb + o));
+}
+
 struct DgDims {
   int B, Cg, Cx, D, W, H, Do, Wo, Ho;  // gx is (B,D,W,H,Cx); gpre is (B,Do,Wo,Ho,Cg)
   int nHq, nWq, nDq;
@@ -136,10 +160,7 @@ __global__ __launch_bounds__(256) void conv3d_dgrad_kernel(const float* __restri
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int64_t row = (((int64_t)b * d.D + z) * d.W + (ok ? y : 0)) * d.H * d.Cx;
-        const int64_t xo = d.xs_layout == LR_LAYOUT_NDHWC
-                               ? row + (int64_t)(ok ? x : 0) * d.Cx + nt * 16 + kq * 4
-                               : row + ((int64_t)nt * d.H + (ok ? px * (d.H >> 1) + xq : 0)) * 16 + kq * 4;
-        xv[mt][nt] = *reinterpret_cast<const f32x4*>(xsave + xo);
+        xv[mt][nt] = load_mask_src(xsave, d.xs_layout, row, ok ? x : 0, ok ? px * (d.H >> 1) + xq : 0, nt, kq, d.H, d.Cx);
       }
     }
   }
@@ -274,10 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_dgrad_lds_kernel(const float* _
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             const int64_t row = (((int64_t)b * d.D + z) * d.W + (ok ? y : 0)) * d.H * d.Cx;
-            const int64_t xo = d.xs_layout == LR_LAYOUT_NDHWC
-                                   ? row + (int64_t)(ok ? x : 0) * d.Cx + nt * 16 + kq * 4
-                                   : row + ((int64_t)nt * d.H + (ok ? px * (d.H >> 1) + xq : 0)) * 16 + kq * 4;
-            xv[px][mt][nt] = *reinterpret_cast<const f32x4*>(xsave + xo);
+            xv[px][mt][nt] = load_mask_src(xsave, d.xs_layout, row, ok ? x : 0, ok ? px * (d.H >> 1) + xq : 0, nt, kq, d.H, d.Cx);
           }
         }
       }
@@ -463,7 +481,9 @@ struct WclGeom {
   static constexpr int T = (27 * CB + NW - 1) / NW;  // N-tiles per wave
 };
 
-template <int CB, int NTC, bool HPS>
+// XB: the saved input is bf16 storage (rows [H][C] or, HPS, [parity][H/2][C]) — 8-byte loads expanded to fp32 on the
+// way into the same LDS image (the bf16-forward training variant: fp32 gradient math on the bf16-rounded activations)
+template <int CB, int NTC, bool HPS, bool XB>
 __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_kernel(const float* __restrict__ xin,
                                                                  const float* __restrict__ gpre,
                                                                  float* __restrict__ partial, WgDims d, int nbricks) {
@@ -488,9 +508,11 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
     const int pz = row9 / 3, py = row9 % 3;
     const int pc = pos <= HB ? 2 * pos : 2 * (pos - HB - 1) + 1;
     xdec[it] = pz | (py << 2) | (pc << 4) | (used ? 1 << 12 : 0);
-    if (HPS)
-      xrel[it] = (unsigned)((((pz * d.W + py) * d.H * Cin) + cb * d.H * 16 +
-                             ((pc & 1) ? (pc - 1) / 2 : (d.H >> 1) - 1 + pc / 2) * 16 + c4 * 4) * 4);
+    const int hprel = (pc & 1) ? (pc - 1) / 2 : (d.H >> 1) - 1 + pc / 2;  // parity-split position relative to ho0
+    if (XB)
+      xrel[it] = (unsigned)(((((pz * d.W + py) * d.H + (HPS ? hprel : pc)) * Cin) + cb * 16 + c4 * 4) * 2);
+    else if (HPS)
+      xrel[it] = (unsigned)((((pz * d.W + py) * d.H * Cin) + cb * d.H * 16 + hprel * 16 + c4 * 4) * 4);
     else
       xrel[it] = (unsigned)(((((pz * d.W + py) * d.H + pc) * Cin) + cb * 16 + c4 * 4) * 4);
   }
@@ -523,17 +545,24 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
     const int zi0 = 2 * dz - 1, yi0 = 2 * wo - 1, xi0 = 2 * ho0 - 1;
     // resource = the window's own origin (it may lie before the tensor: never dereferenced there), so the byte
     // offsets stay inside three planes whatever the volume size
-    const float* xb = xin + (int64_t)b * d.D * d.W * d.H * Cin +
-                      (HPS ? ((int64_t)zi0 * d.W + yi0) * d.H * Cin + (int64_t)ho0 * 16
-                           : (((int64_t)zi0 * d.W + yi0) * d.H + xi0) * Cin);
+    const int64_t xorg = (int64_t)b * d.D * d.W * d.H * Cin +
+                         (XB ? (((int64_t)zi0 * d.W + yi0) * d.H + (HPS ? ho0 : xi0)) * Cin
+                             : HPS ? ((int64_t)zi0 * d.W + yi0) * d.H * Cin + (int64_t)ho0 * 16
+                                   : (((int64_t)zi0 * d.W + yi0) * d.H + xi0) * Cin);
+    const void* xb = XB ? (const void*)(reinterpret_cast<const u16*>(xin) + xorg) : (const void*)(xin + xorg);
     const __amdgpu_buffer_rsrc_t rx =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), (short)0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(xb), (short)0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int it = 0; it < G::XIT; ++it) {
       const int zi = zi0 + (xdec[it] & 3), yi = yi0 + ((xdec[it] >> 2) & 3), xi = xi0 + ((xdec[it] >> 4) & 255);
       const bool ok = live && (xdec[it] >> 12) && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W && xi >= 0 && xi < d.H;
       const unsigned voff = ok ? xrel[it] : OOR;
-      xst[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, 0));
+      if (XB) {
+        const f32x4 v = bf16x4_to_f32(__builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rx, voff, 0, 0)));
+        xst[it] = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        xst[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, 0));
+      }
     }
     const float* gb = gpre + ((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + ho0) * Cout;
     const __amdgpu_buffer_rsrc_t rg =
@@ -604,7 +633,7 @@ template <int NTL>
 __global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_kernel(const float* __restrict__ xin,
                                                                      const float* __restrict__ gpre,
                                                                      float* __restrict__ partial, WgDims d,
-                                                                     int nbricks) {
+                                                                     int nbricks, int round_x) {
   using G = WplGeom<NTL>;
   __shared__ __attribute__((aligned(16))) float xs[G::XF4 * 4 + 80];  // + ones (the bias-gradient column)
   __shared__ __attribute__((aligned(16))) float gs[4 * G::GP];
@@ -677,7 +706,13 @@ __global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_ke
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < G::XIT; ++it)
-      if (it * 256 + tid < G::XF4) *reinterpret_cast<float4*>(xs + (it * 256 + tid) * 4) = xst[it];
+      if (it * 256 + tid < G::XF4) {
+        float4 v = xst[it];
+        if (round_x) {  // the forward rounded this input to bf16 on its way into the MFMA (lr_conv3d_first_bf16)
+          v.x = round_bf16(v.x); v.y = round_bf16(v.y); v.z = round_bf16(v.z); v.w = round_bf16(v.w);
+        }
+        *reinterpret_cast<float4*>(xs + (it * 256 + tid) * 4) = v;
+      }
     {
       const int v = tid >> 2, c4 = tid & 3;
 #pragma unroll
@@ -794,8 +829,10 @@ extern "C" int lr_conv3d_dgrad_f32(const float* gpre, const float* packed_wT, fl
   if ((lds_path ? (int64_t)6 * d.Wo * d.Ho * Cg * 4 : (int64_t)d.Do * d.Wo * d.Ho * Cg * 4) >= 0x7fffffffLL) return LR_EINVAL;
   d.nHq = ((H + 1) / 2 + 15) / 16; d.nWq = ((W + 1) / 2 + DMT - 1) / DMT; d.nDq = ((D + 1) / 2 + 3) / 4;
   d.gx_layout = gx_layout;
-  if (x_saved && x_layout != LR_LAYOUT_NDHWC && x_layout != LR_LAYOUT_NDHWC_HPS) return LR_EINVAL;
-  if (x_saved && x_layout == LR_LAYOUT_NDHWC_HPS && (H & 1)) return LR_EUNSUPPORTED;
+  if (x_saved && x_layout != LR_LAYOUT_NDHWC && x_layout != LR_LAYOUT_NDHWC_HPS && x_layout != LR_LAYOUT_BF16_NDHWC &&
+      x_layout != LR_LAYOUT_BF16_NDHWC_HPS)
+    return LR_EINVAL;
+  if (x_saved && (x_layout == LR_LAYOUT_NDHWC_HPS || x_layout == LR_LAYOUT_BF16_NDHWC_HPS) && (H & 1)) return LR_EUNSUPPORTED;
   if (x_saved && (reinterpret_cast<uintptr_t>(x_saved) & 15u)) return LR_EALIGN;
   d.xs_layout = x_layout; d.slope = negative_slope;
   const int64_t nblk = (int64_t)B * d.nDq * d.nWq * d.nHq;  // tiles of 4 x 4 x 16 voxels per parity class
@@ -813,6 +850,7 @@ extern "C" int lr_conv3d_dgrad_f32(const float* gpre, const float* packed_wT, fl
 }
 
 extern "C" int64_t lr_conv3d_wgrad_partial_floats(int Cin, int Cout, int x_layout, int nblk) {
+  if (x_layout == LR_LAYOUT_NCDHW_RBF16) x_layout = LR_LAYOUT_NCDHW;  // planar either way
   // planar: ceil((27*Cin + 1)/16) tiles (one spare column carries the bias gradient), one partial per WAVE of
   // the fast path (its waves split the voxels); channels-last: 27*ceil(Cin/16) tiles + the ones tile
   const int ntiles = x_layout == LR_LAYOUT_NCDHW ? (Cin * 27 + 16) / 16 : 27 * ((Cin + 15) / 16) + 1;
@@ -826,6 +864,13 @@ extern "C" int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gp
   if (B < 1 || Cin < 1 || D < 1 || W < 1 || H < 1 || nblk < 1 || nblk > 65535) return LR_EINVAL;
   if ((stride != 1 && stride != 2) || (Cout != 16 && Cout != 32)) return LR_EUNSUPPORTED;
   if (x_layout == LR_LAYOUT_NDHWC_HPS && ((H & 1) || (Cin & 15))) return LR_EUNSUPPORTED;
+  // bf16-forward training variant: x is bf16 storage (3|4), or the fp32 first-block input that the forward rounded (5)
+  const bool xbf = x_layout == LR_LAYOUT_BF16_NDHWC || x_layout == LR_LAYOUT_BF16_NDHWC_HPS;
+  const bool xround = x_layout == LR_LAYOUT_NCDHW_RBF16;
+  if (xbf && x_layout == LR_LAYOUT_BF16_NDHWC_HPS && (H & 1)) return LR_EUNSUPPORTED;
+  const int x_layout_in = x_layout;
+  if (xround) x_layout = LR_LAYOUT_NCDHW;
+  if (xbf) x_layout = x_layout_in == LR_LAYOUT_BF16_NDHWC_HPS ? LR_LAYOUT_NDHWC_HPS : LR_LAYOUT_NDHWC;  // same column order
   WgDims d;
   d.B = B; d.Cin = Cin; d.Cout = Cout; d.D = D; d.W = W; d.H = H; d.stride = stride; d.x_layout = x_layout;
   d.Do = (D - 1) / stride + 1; d.Wo = (W - 1) / stride + 1; d.Ho = (H - 1) / stride + 1;
@@ -844,18 +889,19 @@ extern "C" int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gp
     if (nbricks < 0x7fffffffLL) {
       const unsigned grid = (unsigned)(nbricks < nblk ? nbricks : nblk);
       const bool hps = x_layout == LR_LAYOUT_NDHWC_HPS;
-#define LR_WCL(CBV, NTCV)                                                                                          \
-  do {                                                                                                             \
-    if (hps) hipLaunchKernelGGL((conv3d_wgrad_cl_kernel<CBV, NTCV, true>), dim3(grid), dim3(256 * CBV), 0, st, x,  \
-                                gpre, partial, d, (int)nbricks);                                                   \
-    else hipLaunchKernelGGL((conv3d_wgrad_cl_kernel<CBV, NTCV, false>), dim3(grid), dim3(256 * CBV), 0, st, x,     \
-                            gpre, partial, d, (int)nbricks);                                                       \
+#define LR_WCL1(CBV, NTCV, HP, XBV) \
+  hipLaunchKernelGGL((conv3d_wgrad_cl_kernel<CBV, NTCV, HP, XBV>), dim3(grid), dim3(256 * CBV), 0, st, x, gpre, partial, d, (int)nbricks)
+#define LR_WCL(CBV, NTCV)                                                       \
+  do {                                                                          \
+    if (hps) { if (xbf) LR_WCL1(CBV, NTCV, true, true); else LR_WCL1(CBV, NTCV, true, false); }     \
+    else     { if (xbf) LR_WCL1(CBV, NTCV, false, true); else LR_WCL1(CBV, NTCV, false, false); }   \
   } while (0)
       if (Cin == 16 && Cout == 16) LR_WCL(1, 1);
       else if (Cin == 16) LR_WCL(1, 2);
       else if (Cout == 16) LR_WCL(2, 1);
       else LR_WCL(2, 2);
 #undef LR_WCL
+#undef LR_WCL1
       nparts = (int)grid;
     }
   } else if (x_layout == LR_LAYOUT_NCDHW && stride == 1 && Cout == 16 && Cin <= 12 && H % 4 == 0 && al16 &&
@@ -864,8 +910,8 @@ extern "C" int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gp
     const int64_t nbricks = (int64_t)B * D * ((W + 3) / 4) * ((H + 63) / 64);
     if (nbricks < 0x7fffffffLL) {
       const unsigned grid = (unsigned)(nbricks < nblk ? nbricks : nblk);
-      if (Cin <= 3) hipLaunchKernelGGL(conv3d_wgrad_planar_kernel<6>, dim3(grid), dim3(256), 0, st, x, gpre, partial, d, (int)nbricks);
-      else hipLaunchKernelGGL(conv3d_wgrad_planar_kernel<21>, dim3(grid), dim3(256), 0, st, x, gpre, partial, d, (int)nbricks);
+      if (Cin <= 3) hipLaunchKernelGGL(conv3d_wgrad_planar_kernel<6>, dim3(grid), dim3(256), 0, st, x, gpre, partial, d, (int)nbricks, (int)xround);
+      else hipLaunchKernelGGL(conv3d_wgrad_planar_kernel<21>, dim3(grid), dim3(256), 0, st, x, gpre, partial, d, (int)nbricks, (int)xround);
       nparts = (int)grid * 4;
     }
   }
@@ -879,6 +925,7 @@ extern "C" int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gp
                        ncols, x_layout, planar ? 27 * Cin : d.ntiles * 16);
     return lr_launch_status();
   }
+  if (xbf || xround) return LR_EUNSUPPORTED;  // the generic kernel reads fp32 activations only
   if (Cout == 16) hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, x, gpre, partial, d, ngroups);
   else hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, x, gpre, partial, d, ngroups);
   if (int e = lr_launch_status()) return e;

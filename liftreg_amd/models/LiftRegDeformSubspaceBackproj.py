@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..autograd import PCAFn, WarpFn
+from ..autograd import EncoderBf16Fn, PCAFn, WarpFn
 from ..layers.layers import convBlock, FullyConnectBlock, GaussianSmoothing
 from ..utils.net_utils import Bilinear, identity_axis_tables
 
@@ -72,7 +72,8 @@ class model(nn.Module):
             self.encoders.append(convBlock(cin, f, stride=self.strides[i], bias=True, in_layout=lay_in,
                                            out_layout=lay_out))
         # optional (non-reference) key "conv_dtype": "bf16" stores the activations between the blocks as bfloat16
-        # and runs blocks 1..5 on the bf16 MFMA (BASELINE configs C4/C5); inference only, default "fp32"
+        # and runs the blocks on the bf16 MFMA (BASELINE configs C4/C5); training computes fp32 gradients of that
+        # bf16-forward arithmetic (autograd.EncoderBf16Fn); default "fp32"
         self.conv_dtype = str(_opt(opt, "conv_dtype", "fp32"))
         if self.conv_dtype not in ("fp32", "bf16"):
             raise ValueError('conv_dtype must be "fp32" or "bf16"')
@@ -195,9 +196,14 @@ class model(nn.Module):
         x = torch.empty((B, P + 1, D, W, H), dtype=torch.float32, device=moving.device)
         x[:, 0:1].copy_(moving)
         ops.backproject(target_proj, self._poses, (D, W, H), out=x[:, 1:], out_batch_stride=(P + 1) * V)
+        if self.conv_dtype == "bf16" and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training: bf16 forward, fp32 gradient math on the bf16-rounded activations — one autograd node
+            blks = [self.encoders[i] for i in range(6)]
+            packed = [self._packed_weight(i, bf16=True) for i in range(6)]
+            wb = [t for blk in blks for t in (blk.conv.weight, blk.conv.bias)]
+            feat = EncoderBf16Fn.apply(x, self._bf16_layouts, [blk._slope for blk in blks], self.strides, packed, *wb)
+            return self.encoders[6](feat)
         if self.conv_dtype == "bf16":
-            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-                raise NotImplementedError('conv_dtype="bf16" is an inference path: call under torch.no_grad()')
             for i in range(6):
                 blk = self.encoders[i]
                 lin, lout = self._bf16_layouts[i]

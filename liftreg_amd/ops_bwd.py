@@ -62,7 +62,7 @@ def pca_bwd_coef(gdisp, basis_LxM, nblk=None):
 
 def _act_dims(t, layout):
     """(B, C, D, W, H) of an activation tensor stored in `layout`."""
-    if layout == _hip.LAYOUT_NCDHW:
+    if layout in (_hip.LAYOUT_NCDHW, _hip.LAYOUT_NCDHW_RBF16):
         B, C, D, W, H = t.shape
     else:
         B, D, W, H, C = t.shape
@@ -70,7 +70,7 @@ def _act_dims(t, layout):
 
 
 def conv3d_bwd(x, x_layout, weight, y, y_layout, gy, gy_layout, stride, negative_slope=0.2, need_gx=True,
-               nblk=512, gy_is_gpre=False, mask_input_slope=None):
+               nblk=512, gy_is_gpre=False, mask_input_slope=None, round_weights=False):
     """Backward of ops.conv3d_k3_lrelu.  x / y: the block's saved input / output (any layout), gy: gradient of
     the output.  Returns (gx, gw (Cout,Cin,3,3,3), gb (Cout)); gx is (B,D,W,H,Cin) in x's own channels-last
     layout, or None.
@@ -79,9 +79,20 @@ def conv3d_bwd(x, x_layout, weight, y, y_layout, gy, gy_layout, stride, negative
     the data-gradient epilogue also applies the producer's mask (its output is this block's saved input), so the
     returned gx is the producer's pre-activation gradient in plain NDHWC; the producer then passes it with
     `gy_is_gpre=True` and skips its own mask pass.  The bias gradient comes out of the weight-gradient kernel.
+
+    bf16-forward training (conv_dtype="bf16"): x / y may be bfloat16 tensors in LAYOUT_BF16_NDHWC[_HPS] (the first
+    block: its fp32 input with x_layout=LAYOUT_NCDHW_RBF16); gradients stay fp32; `round_weights` makes the data
+    gradient use the bf16-rounded weights the forward multiplied by.
     """
-    x, y, gy = _dev(x, "x"), _dev(y, "y"), _dev(gy, "gy")
+    bf_layouts = (_hip.LAYOUT_BF16_NDHWC, _hip.LAYOUT_BF16_NDHWC_HPS)
+    x = _dev(x, "x", torch.bfloat16 if x_layout in bf_layouts else torch.float32)
+    y = _dev(y, "y", torch.bfloat16 if y_layout in bf_layouts else torch.float32)
+    gy = _dev(gy, "gy")
+    if y_layout in bf_layouts and not gy_is_gpre:
+        raise ValueError("a bf16 block output needs the chained form (gy_is_gpre=True)")
     w = _dev(weight.detach(), "weight")
+    if round_weights:
+        w = w.to(torch.bfloat16).to(torch.float32)
     Cout, Cin = w.shape[0], w.shape[1]
     B, Cx, D, W, H = _act_dims(x, x_layout)
     _, Cy, Do, Wo, Ho = _act_dims(y, y_layout)
@@ -108,8 +119,10 @@ def conv3d_bwd(x, x_layout, weight, y, y_layout, gy, gy_layout, stride, negative
         packed_t = conv3d_pack_weights(w.transpose(0, 1).contiguous(), _hip.LAYOUT_NDHWC)
         gx = torch.empty((B, D, W, H, Cin), dtype=torch.float32, device=dev)
         fuse = mask_input_slope is not None
-        if fuse and x_layout == _hip.LAYOUT_NCDHW:
+        if fuse and x_layout in (_hip.LAYOUT_NCDHW, _hip.LAYOUT_NCDHW_RBF16):
             raise ValueError("mask_input_slope needs a channels-last saved input")
+        if x_layout in bf_layouts and not fuse:
+            raise ValueError("a bf16 saved input needs the chained form (mask_input_slope)")
         gxl = _hip.LAYOUT_NDHWC if (fuse or x_layout == _hip.LAYOUT_NCDHW) else x_layout
         with _timed(f"conv3d_dgrad_c{Cout}x{Cin}_{D}", flops=2.0 * 27 * Cin * Cout * B * Do * Wo * Ho,
                     bytes=4 * (gpre.numel() + gx.numel() * (2 if fuse else 1))):
@@ -123,7 +136,7 @@ def conv3d_bwd(x, x_layout, weight, y, y_layout, gy, gy_layout, stride, negative
     gw = torch.empty_like(w)
     gb = torch.empty((Cout,), dtype=torch.float32, device=dev)
     with _timed(f"conv3d_wgrad_c{Cin}x{Cout}_{D}", flops=2.0 * 27 * Cin * Cout * B * Do * Wo * Ho,
-                bytes=4 * (x.numel() + gpre.numel())):
+                bytes=x.numel() * x.element_size() + 4 * gpre.numel()):
         _hip.check(lib.lr_conv3d_wgrad_f32(x.data_ptr(), x_layout, gpre.data_ptr(), partial.data_ptr(), gw.data_ptr(),
                                            gb.data_ptr(), B, Cin, Cout, D, W, H, stride, nblk, _stream()),
                    "lr_conv3d_wgrad_f32")

@@ -211,7 +211,7 @@ def ncc_loss_squared(x, y):
 
 
 # --------------------------------------------------------------------------- a14
-def model_forward(params, inp, pca_vectors_LxM, pca_mean, strides=(1, 2, 2, 2, 2, 2)):
+def model_forward(params, inp, pca_vectors_LxM, pca_mean, strides=(1, 2, 2, 2, 2, 2), conv_dtype="fp32"):
     """model.forward (LiftRegDeformSubspaceBackproj.py:49-104) on CPU tensors.
 
     params: state-dict-like {encoders.i.conv.weight/bias, encoders.6.{1,2,3}.fc.weight/bias}.
@@ -226,8 +226,11 @@ def model_forward(params, inp, pca_vectors_LxM, pca_mean, strides=(1, 2, 2, 2, 2
     B, _, D, W, H = moving.shape
     tv = backproject(target_proj, inp["target_poses"], (D, W, H))
     x = torch.cat([moving, tv], dim=1)
-    for i, s in enumerate(strides):
-        x = conv_block(x, params[f"encoders.{i}.conv.weight"], params[f"encoders.{i}.conv.bias"], s)
+    if conv_dtype == "bf16":      # the build's bf16 storage variant (not in the reference): see encoder_bf16
+        x = encoder_bf16(params, x, strides)
+    else:
+        for i, s in enumerate(strides):
+            x = conv_block(x, params[f"encoders.{i}.conv.weight"], params[f"encoders.{i}.conv.bias"], s)
     x = x.flatten(1)
     x = fc_block(x, params["encoders.6.1.fc.weight"], params["encoders.6.1.fc.bias"])
     x = fc_block(x, params["encoders.6.2.fc.weight"], params["encoders.6.2.fc.bias"])

@@ -129,5 +129,52 @@ def test_model_bf16_encoder_vs_oracle_and_fp32(dev):
     d32 = np.abs(got - out32["pca_coefs"].cpu().numpy()).max() / scale
     assert d32 < 5e-2, d32                                             # bf16 storage vs fp32: a few 1e-3 in practice
     assert out["warped"].dtype == torch.float32                         # fp32 warp, as configs C4/C5 state
-    with pytest.raises(NotImplementedError):
-        net(inp)                                                       # bf16 mode is inference-only
+
+
+def test_bf16_forward_training_gradients(dev):
+    """C5: "bf16 convs + fp32 warp, training loop with NCC loss backward".  conv_dtype="bf16" under autograd: bf16
+    forward, fp32 gradient math on the bf16-rounded activations and weights.  Oracle: ATen autograd of the CPU
+    restatement of the same arithmetic (casts are straight-through).  The two forwards agree up to rare one-ulp bf16
+    rounding flips, so gradients agree to a few 1e-3 of their scale, not to fp32 round-off."""
+    from liftreg_amd.losses.SubspaceLoss import loss as SubspaceLoss
+    from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+    shape, P, L, B = (32, 32, 32), 2, 8, 2
+    torch.manual_seed(11)
+    net = model(list(shape), {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:11", "conv_dtype": "bf16"}).to(dev).train()
+    rs = np.random.RandomState(11)
+    poses = ro.scan_poses(30, P, shape[0]).astype(np.float32)
+    inp = {"source": torch.from_numpy(rs.uniform(-1, 1, (B, 1) + shape).astype(np.float32)),
+           "target": torch.from_numpy(rs.uniform(-1, 1, (B, 1) + shape).astype(np.float32)),
+           "target_proj": torch.from_numpy(rs.uniform(-1, 1, (B, P, 32, 32)).astype(np.float32)),
+           "target_poses": torch.from_numpy(np.broadcast_to(poses, (B, P, 3)).copy())}
+    opt = {"initial_reg_factor": 0.01, "min_reg_factor": 0.01, "reg_factor_decay_from": 2}
+    out = net({k: v.to(dev) if k != "target_poses" else v for k, v in inp.items()})
+    out["epoch"] = 0
+    got = SubspaceLoss(dict(opt))(out)
+    got["total_loss"].backward()
+
+    params = {k: v.detach().cpu().clone().requires_grad_("gaussian" not in k) for k, v in net.state_dict().items()}
+    ref = ro.model_forward(params, inp, net.pca_vectors_LxM.cpu(), net.pca_mean.cpu(), conv_dtype="bf16")
+    want = ro.subspace_loss(ref, 0, **opt)
+    want["total_loss"].backward()
+    assert abs(float(got["total_loss"].detach()) - float(want["total_loss"].detach())) < 1e-4
+    for k, p in net.named_parameters():
+        g, w = p.grad.cpu().numpy().ravel(), params[k].grad.numpy().ravel()
+        scale = np.abs(w).max()
+        assert scale > 0, k
+        assert np.abs(g - w).max() <= 2e-2 * scale, (k, np.abs(g - w).max() / scale)
+        assert float(np.dot(g, w) / (np.linalg.norm(g) * np.linalg.norm(w))) > 0.9995, k
+    # and a few optimizer steps reduce the loss
+    optim = torch.optim.Adam(net.parameters(), lr=2e-4)
+    dinp = {k: v.to(dev) if k != "target_poses" else v for k, v in inp.items()}
+    net.set_pca(net.pca_vectors_LxM * 40, net.pca_mean)
+    losses = []
+    for step in range(6):
+        optim.zero_grad()
+        o = net(dinp)
+        o["epoch"] = step
+        l = SubspaceLoss(dict(opt))(o)["total_loss"]
+        l.backward()
+        optim.step()
+        losses.append(float(l.detach()))
+    assert losses[-1] < losses[0]

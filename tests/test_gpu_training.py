@@ -97,12 +97,12 @@ def test_adam_steps_follow_the_cpu_trajectory(dev):
         l = crit(out)["total_loss"]
         l.backward()
         opt_g.step()
-        lg.append(float(l))
+        lg.append(float(l.detach()))
         opt_c.zero_grad()
         lo = ro.subspace_loss(ro.model_forward({**cpu, **cpu_params}, inp, vec, mean), step, **LOSS_OPT)["total_loss"]
         lo.backward()
         opt_c.step()
-        lc.append(float(lo))
+        lc.append(float(lo.detach()))
     assert lg[-1] < lg[0]
     np.testing.assert_allclose(lg, lc, rtol=0, atol=2e-4)
 
