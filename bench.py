@@ -257,7 +257,7 @@ def main():
             t_both = (time.perf_counter() - t0) / 5
         drr = {"volumes_per_s": B / t_drr, "projections_per_s": B * P / t_drr, "ms_per_volume": t_drr / B * 1e3,
                "simulate_plus_register_per_s": B / t_both,
-               "note": f"{P} views of {R}x{R} per {n}^3 volume, HU->mu and the axis-1 flip folded into the projector"}
+               "note": f"{P} views of {R}x{R} per {n}^3 volume, HU->mu as a one-pass prologue (lr_hu_to_mu_f32), the axis-1 flip folded into the projector"}
 
     result = {
         "metric": "registrations/sec (256^3 CT, 2-view DRR)" if args.config == "c3" else f"registrations/sec ({args.config})",

@@ -78,6 +78,10 @@ int lr_drr_forward_f32(const float* vol_slab, const float* poses, const float* s
  * normalized=0: pixel units after ATen's align_corners=True un-normalise;
  * normalized=1: the reference's [-1,1] grid values before flip (x/D*2, y/(W-1)*2-1, z/H*2).
  * pix: dev (P,Rd,Rh,W,3) ordered (d,w,h); dx: dev (P,Rd,Rh). Either may be NULL. */
+/* calc_relative_atten_coef (sdct_projection_utils.py:6-9): mu = ((max(HU,-1000)+1000)/1000)*0.2, one pass over the
+ * volume.  Cheaper than LR_DRR_HU_INPUT (which converts per tap) whenever a volume is projected from more than a
+ * handful of rays per voxel; bit-identical results. */
+int lr_hu_to_mu_f32(const float* hu, float* mu, int64_t n, void* stream);
 int lr_drr_sample_coords_f32(const float* poses, const float* spacing, float* pix, float* dx,
                              int D, int W, int H, int P, int Rd, int Rh, int normalized,
                              void* stream);

@@ -29,6 +29,7 @@ SIGNATURES = {
     "lr_abi_version": (_i, []),
     "lr_target_arch": (C.c_char_p, []),
     "lr_drr_forward_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "lr_hu_to_mu_f32": (_i, [_p, _p, _i64, _p]),
     "lr_drr_sample_coords_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "lr_backproject_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _p]),
     "lr_backproject_coords_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -235,6 +235,13 @@ __global__ __launch_bounds__(256) void drr_coords_kernel(LrPoses poses, float sp
   }
 }
 
+// calc_relative_atten_coef (sdct_projection_utils.py:6-9) as its own pass: one conversion per VOXEL.  Folded into the
+// projector's taps (LR_DRR_HU_INPUT) the same IEEE divide runs once per TAP — 16x as often at 256^3 / 2x256^2.
+__global__ __launch_bounds__(256) void hu_to_mu_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = mu_of<true>(in[i]);
+}
+
 int fill_poses(LrPoses& lp, const float* poses, int P) {
   if (!poses) return LR_ENULL;
   if (P < 1 || P > LR_MAX_VIEWS) return LR_EINVAL;
@@ -258,7 +265,7 @@ extern "C" int lr_drr_forward_f32(const float* vol_slab, const float* poses, con
     // enough lanes to fill 256 CUs x 32 waves, capped at 16 runs per ray
     const int64_t rays = (int64_t)P * Rd * ((Rh + 63) / 64 * 64);
     nseg = 1;
-    while (nseg < 16 && rays * nseg < 256LL * 2048 && W / (nseg * 2) >= 8) nseg *= 2;
+    while (nseg < 16 && rays * nseg < 256LL * 4096 && W / (nseg * 2) >= 8) nseg *= 2;  // measured: 8 runs at 2x256^2
   }
   if (nseg != 1 && nseg != 2 && nseg != 4 && nseg != 8 && nseg != 16) return LR_EINVAL;
   const int R = nseg > 4 ? nseg : 4;
@@ -277,6 +284,16 @@ extern "C" int lr_drr_forward_f32(const float* vol_slab, const float* poses, con
   else if (flip) LR_LAUNCH(false, true);
   else LR_LAUNCH(false, false);
 #undef LR_LAUNCH
+  return lr_launch_status();
+}
+
+extern "C" int lr_hu_to_mu_f32(const float* hu, float* mu, int64_t n, void* stream) {
+  if (!hu || !mu) return LR_ENULL;
+  if (n < 0) return LR_EINVAL;
+  if (n == 0) return LR_OK;
+  int64_t nblk = (n + 255) / 256;
+  if (nblk > 16384) nblk = 16384;
+  hipLaunchKernelGGL(hu_to_mu_kernel, dim3((unsigned)nblk), dim3(256), 0, lr_stream(stream), hu, mu, n);
   return lr_launch_status();
 }
 
