@@ -53,9 +53,10 @@ __device__ __forceinline__ void sample_grid(const RaySetup& r, int j, float ex, 
   const float x = r.ihx * t + ex;
   const float y = r.ihy * t + ey;
   const float z = r.ihz * t + ez;
-  gx = (x / (float)D) * 2.0f;
+  // x / 2^k == x * 2^-k bit for bit (exact scaling), so power-of-two extents skip the IEEE divide sequence
+  gx = ((D & (D - 1)) == 0 ? x * (1.0f / (float)D) : x / (float)D) * 2.0f;
   gy = ((y - 0.0f) / ((float)W - 1.0f)) * 2.0f + -1.0f;
-  gz = (z / (float)H) * 2.0f;
+  gz = ((H & (H - 1)) == 0 ? z * (1.0f / (float)H) : z / (float)H) * 2.0f;
 }
 __device__ __forceinline__ void sample_pix(const RaySetup& r, int j, float ex, float ey, float ez,
                                            int D, int W, int H, float& pd, float& pw, float& ph) {
