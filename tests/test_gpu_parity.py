@@ -349,6 +349,30 @@ def test_no_cpu_fallback_and_error_codes(ops, dev):
     with pytest.raises(_hip.LiftRegHipError):
         ops.conv3d_k3_lrelu(x, torch.zeros(8, 3, 3, 3, 3, device=dev), None, 1)                  # Cout=8 unsupported
     assert lib.lr_strerror(-3) == b"combination not built into this library"
+    # every later entry point keeps the contract: negative code, no exception, nothing launched
+    ENULL, EINVAL, EUNSUP = -2, -1, -3
+    z = torch.zeros(4096, device=dev)
+    p = z.data_ptr()
+    assert lib.lr_normalize_clip_f32(None, p, 16, 0.0, 1.0, None) == ENULL
+    assert lib.lr_normalize_clip_f32(p, p, 16, 1.0, 1.0, None) == EINVAL                      # empty clip range
+    assert lib.lr_label_overlap_f32(p, p, 1.0, 16, None, 4, p, None) == ENULL
+    assert lib.lr_jacobi_det_stats_f32(p, 1, 2, 2, 2, 0.0, 1.0, 1.0, p, 1, p, None) == EINVAL  # zero spacing
+    assert lib.lr_hu_to_mu_f32(None, p, 4, None) == ENULL
+    assert lib.lr_conv3d_k3_lrelu_bf16(p, p, None, p, 1, 16, 32, 4, 4, 4, 1, 3, 3, 0.2, None) == EUNSUP   # stride 1
+    assert lib.lr_conv3d_k3_lrelu_bf16(p, p, None, p, 1, 16, 32, 4, 4, 4, 2, 1, 3, 0.2, None) == EINVAL   # fp32 layout id
+    assert lib.lr_conv3d_k3_lrelu_bf16(p, p, None, p, 1, 16, 32, 4, 4, 5, 2, 4, 3, 0.2, None) == EUNSUP   # parity split, odd H
+    assert lib.lr_conv3d_first_bf16(p, p, None, p, 1, 3, 8, 4, 4, 4, 3, 0.2, None) == EUNSUP              # Cout = 8
+    assert lib.lr_conv3d_packed_bf16_bytes(8, 16) == EUNSUP
+    assert lib.lr_conv3d_dgrad_f32(p, p, p, 1, 32, 16, 4, 4, 4, 1, 1, None, 1, 0.2, None) == EUNSUP       # stride 1
+    assert lib.lr_conv3d_dgrad_f32(p, p, p, 1, 32, 16, 4, 4, 4, 2, 0, None, 1, 0.2, None) == EINVAL       # planar gx
+    assert lib.lr_conv3d_dgrad_f32(p, p, p, 1, 32, 16, 4, 4, 4, 2, 1, p, 0, 0.2, None) == EINVAL          # planar mask source
+    assert lib.lr_conv3d_wgrad_f32(p, 1, p, None, p, None, 1, 16, 32, 4, 4, 4, 2, 8, None) == ENULL       # no workspace
+    assert lib.lr_conv3d_wgrad_f32(p, 1, p, p, p, None, 1, 16, 8, 4, 4, 4, 2, 8, None) == EUNSUP          # Cout = 8
+    assert lib.lr_conv3d_wgrad_f32(p, 3, p, p, p, None, 1, 20, 16, 4, 4, 4, 2, 8, None) == EUNSUP         # bf16 x, Cin = 20
+    assert lib.lr_disp_reg_bwd_f32(p, None, p, 1, 2, 2, 2, None) == ENULL
+    assert lib.lr_pca_bwd_coef_f32(None, p, p, p, 1, 1, 4, 4, 4, 1, None) == ENULL
+    torch.cuda.synchronize()                                                               # and the device is still healthy
+    assert float(z.sum()) == 0.0
 
 
 # ------------------------------------------------------------------------------------- f3/f4: file pipeline
