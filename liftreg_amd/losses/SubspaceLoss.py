@@ -1,10 +1,17 @@
-"""Loss plugin with the reference's interface (src/liftreg/losses/SubspaceLoss.py:10-67):
+"""The loss plugin of the subspace model on the HIP kernels.
 
-    "loss_class": "liftreg_amd.losses.SubspaceLoss.loss",  "loss": {"sim_class": "liftreg_amd.layers.losses.NCCLoss", …}
+Drop-in for `train.loss_class` (interface of the reference's src/liftreg/losses/SubspaceLoss.py:10-67):
 
-total = sim(warped, target) + reg_factor(epoch) · reg(params); reg on the HIP one-pass kernel.
-The regulariser's finite-difference stencil is mermaid's (un-vendored, absent): PARITY UNPINNED —
-see liftreg_amd/csrc/reg.hip for the assumed stencil.  `total_loss.backward()` runs the HIP backward kernels.
+    "loss_class": "liftreg_amd.losses.SubspaceLoss.loss",
+    "loss": {"sim_class": "liftreg_amd.layers.losses.NCCLoss", "initial_reg_factor": …, …}
+
+    total = similarity(warped, target) + λ(epoch) · R(params)
+    λ(epoch) = max(sigmoid_decay(epoch, static=reg_factor_decay_from, k=2) · initial_reg_factor, min_reg_factor)
+    R        = mean over voxels of Σ_{component, axis} (∂_axis disp_component)²      (one streaming HIP pass)
+
+R's finite-difference stencil lives in `mermaid` (un-vendored, absent from the reference checkout): PARITY UNPINNED,
+the assumed stencil is documented in liftreg_amd/csrc/reg.hip.  Both terms are autograd nodes whose backward runs
+HIP kernels (liftreg_amd.autograd), so `out["total_loss"].backward()` works as in the reference's training step.
 """
 import torch.nn as nn
 
@@ -12,37 +19,46 @@ from ..autograd import DispRegFn
 from ..utils.general import get_class
 from ..utils.utils import sigmoid_decay
 
+# option name → (default, description); read once at construction, ParameterDict- or dict-style
+_OPTIONS = {
+    "sim_class": ("liftreg_amd.layers.losses.NCCLoss", "Similarity class"),
+    "initial_reg_factor": (10, "initial regularization factor"),
+    "min_reg_factor": (1e-3, "minimum regularization factor"),
+    "reg_factor_decay_from": (10, "regularization factor starts to decay from # epoch"),
+}
+_DECAY_K = 2
 
-def _opt(opt, key, default, comment=""):
-    """ParameterDict-style `opt[(key, default, comment)]` with a plain-dict fallback."""
-    try:
-        return opt[(key, default, comment)]
-    except (KeyError, TypeError):
-        return opt.get(key, default) if hasattr(opt, "get") else default
+
+def _read(opt, name):
+    default, text = _OPTIONS[name]
+    try:                                   # ParameterDict registers the default and the comment on first access
+        return opt[(name, default, text)]
+    except (KeyError, TypeError):          # plain mapping
+        getter = getattr(opt, "get", None)
+        return getter(name, default) if getter else default
 
 
 class loss(nn.Module):
+    """`forward(model_output_dict_with_epoch) -> {"total_loss": Tensor, "sim_loss": float, "reg_loss": float}`."""
+
     def __init__(self, opt):
         super().__init__()
+        for name in ("initial_reg_factor", "min_reg_factor", "reg_factor_decay_from"):
+            setattr(self, name, _read(opt, name))
+        self.sim = get_class(_read(opt, "sim_class"))()
         self.sim_factor = 1.
-        self.sim = get_class(_opt(opt, "sim_class", "liftreg_amd.layers.losses.NCCLoss", "Similarity class"))()
-        self.initial_reg_factor = _opt(opt, 'initial_reg_factor', 10, 'initial regularization factor')
-        self.min_reg_factor = _opt(opt, 'min_reg_factor', 1e-3, 'minimum regularization factor')
-        self.reg_factor_decay_from = _opt(opt, 'reg_factor_decay_from', 10,
-                                          'regularization factor starts to decay from # epoch')
-
-    def forward(self, input):
-        warped, target, params = input["warped"], input["target"], input["params"]
-        epoch = input["epoch"]
-        sim_loss = self.sim(warped, target)
-        reg_loss = self.compute_reg_loss(params)
-        total_loss = self.sim_factor * sim_loss + self.get_reg_factor(epoch) * reg_loss
-        return {"total_loss": total_loss, "sim_loss": sim_loss.item(), "reg_loss": reg_loss.item()}
 
     def get_reg_factor(self, epoch):
-        decay_factor = 2
-        return float(max(sigmoid_decay(epoch, static=self.reg_factor_decay_from, k=decay_factor) *
-                         self.initial_reg_factor, self.min_reg_factor))
+        """λ(epoch): constant `initial_reg_factor` until `reg_factor_decay_from`, then a sigmoid decay, floored."""
+        scheduled = sigmoid_decay(epoch, static=self.reg_factor_decay_from, k=_DECAY_K) * self.initial_reg_factor
+        return float(max(scheduled, self.min_reg_factor))
 
-    def compute_reg_loss(self, affine_param):
-        return DispRegFn.apply(affine_param)
+    def compute_reg_loss(self, disp):
+        """R(disp) for a (B,3,D,W,H) displacement field in normalised coordinates."""
+        return DispRegFn.apply(disp)
+
+    def forward(self, input):
+        similarity = self.sim(input["warped"], input["target"])
+        smoothness = self.compute_reg_loss(input["params"])
+        total = self.sim_factor * similarity + self.get_reg_factor(input["epoch"]) * smoothness
+        return {"total_loss": total, "sim_loss": similarity.item(), "reg_loss": smoothness.item()}
