@@ -295,6 +295,16 @@ int lr_conv3d_pack_weights_bf16_planar(const float* weight, void* packed, int Ci
 int lr_conv3d_first_bf16(const float* in, const void* packed_w, const float* bias, void* out, int B, int Cin,
                          int Cout, int D, int W, int H, int out_layout, float negative_slope, void* stream);
 
+/* bf16-gradient training variant: the pre-activation gradients between the blocks are stored as bf16 plain
+ * channels-last (what bf16 mixed precision does).  lr_conv3d_dgrad_bf16: gx (B,D,W,H,Cx) bf16 = the PRODUCER's
+ * pre-activation gradient (its LeakyReLU mask, read from x_saved = this block's saved bf16 input, is applied in the
+ * epilogue) from gpre (B,Do,Wo,Ho,32) bf16; packed_wT = lr_conv3d_pack_weights_bf16 of the weight transposed to
+ * (Cin,Cout,3,3,3).  lr_conv3d_wgrad_bf16g_f32 = lr_conv3d_wgrad_f32 reading such a gpre (gw, gb stay fp32). */
+int lr_conv3d_dgrad_bf16(const void* gpre, const void* packed_wT, void* gx, int B, int Cg, int Cx, int D, int W, int H,
+                         const void* x_saved, int x_layout, float negative_slope, void* stream);
+int lr_conv3d_wgrad_bf16g_f32(const float* x, int x_layout, const void* gpre_bf16, float* partial, float* gw, float* gb,
+                              int B, int Cin, int Cout, int D, int W, int H, int stride, int nblk, void* stream);
+
 /* ---- data-side prologue and evaluation reductions -------------------------------------
  * lr_normalize_clip_f32: out = ((clamp(in, lo, hi) - lo) / (hi - lo)) * 2 - 1
  *   (dataset/Registration2D3DDataset.py:196-199,207: _normalize_intensity with linear_clip and a clip_range).

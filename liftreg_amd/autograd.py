@@ -50,7 +50,7 @@ class EncoderBf16Fn(torch.autograd.Function):
     block the weight/bias gradient and the data gradient fused with the producer's mask (ops_bwd.conv3d_bwd)."""
 
     @staticmethod
-    def forward(ctx, x, layouts, slopes, strides, packed, *wb):
+    def forward(ctx, x, layouts, slopes, strides, packed, grad_bf16, *wb):
         ws, bs = wb[0::2], wb[1::2]
         acts = [x]
         for i in range(6):
@@ -62,15 +62,26 @@ class EncoderBf16Fn(torch.autograd.Function):
                                              negative_slope=slopes[i], packed=packed[i])
             acts.append(y)
         ctx.save_for_backward(*acts, *ws)
-        ctx.cfg = (layouts, slopes, strides, [b is not None for b in bs])
+        ctx.cfg = (layouts, slopes, strides, [b is not None for b in bs], grad_bf16)
         return acts[-1]
 
     @staticmethod
     def backward(ctx, gfeat):
-        layouts, slopes, strides, has_bias = ctx.cfg
+        layouts, slopes, strides, has_bias, grad_bf16 = ctx.cfg
         acts, ws = ctx.saved_tensors[:7], ctx.saved_tensors[7:]
         grads = [None] * 12
         g = gfeat.contiguous()
+        if grad_bf16:
+            # bf16-gradient variant (opt "grad_dtype": "bf16"): the pre-activation gradients between the blocks are
+            # rounded to bf16 — the data gradient then runs on the bf16 MFMA and moves half the bytes
+            g = ops.cast_bf16(ops_bwd.lrelu_bwd(g, layouts[5][1], acts[6], layouts[5][1], slopes[5]))
+            for i in range(5, -1, -1):
+                x_layout = _hip.LAYOUT_NCDHW_RBF16 if i == 0 else layouts[i][0]
+                g, gw, gb = ops_bwd.conv3d_bwd_bf16g(acts[i], x_layout, ws[i], g, strides[i],
+                                                     mask_input_slope=(slopes[i - 1] if i > 0 else None))
+                grads[2 * i] = gw
+                grads[2 * i + 1] = gb if has_bias[i] else None
+            return (None, None, None, None, None, None, *grads)
         for i in range(5, -1, -1):
             lin, lout = layouts[i]
             x_layout = _hip.LAYOUT_NCDHW_RBF16 if i == 0 else lin
@@ -80,7 +91,7 @@ class EncoderBf16Fn(torch.autograd.Function):
             grads[2 * i] = gw
             grads[2 * i + 1] = gb if has_bias[i] else None
             g = gx
-        return (None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, *grads)
 
 
 class LinearFn(torch.autograd.Function):

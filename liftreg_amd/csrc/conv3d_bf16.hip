@@ -361,6 +361,120 @@ __global__ void pack_bf16_planar_kernel(const float* __restrict__ w, u32x4* __re
   packed[idx] = (u32x4){r[0], r[1], r[2], r[3]};
 }
 
+// ===========================================================================================================
+// Data gradient of a stride-2 block with bf16 gradients (the bf16-gradient training variant): gpre (B,Do,Wo,Ho,32)
+// and the result are bf16 plain channels-last, the weights are the bf16-rounded ones the forward multiplied by
+// (packed TRANSPOSED with pack_bf16_kernel: rows = the block's input channels, k = its 32 output channels), the
+// accumulation is fp32.  Same scheme as conv3d_dgrad_lds_kernel (conv3d_bwd.hip): a block stages the 5x5x17 gpre
+// voxels of its tile once in LDS and walks the 8 parity classes of gx; here one 16x16x32 MFMA covers a whole tap,
+// so the kernel is bound by its HBM traffic (gpre + the mask source in, gx out), not by the matrix pipe.
+// The epilogue multiplies by the producer's LeakyReLU mask (xsave = this block's saved bf16 input) and rounds to bf16.
+struct DgDimsH {
+  int B, Cx, D, W, H, Do, Wo, Ho, nHq, nWq, nDq, xs_layout;
+  float slope;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv3d_dgrad_bf16_kernel(const u16* __restrict__ gpre, const u32x4* __restrict__ wp,
+                                                                   u16* __restrict__ gx, const u16* __restrict__ xsave,
+                                                                   DgDimsH d) {
+  constexpr int CG = 32, VS = CG + 8, NVOX = 5 * 5 * 17, NCH = NVOX * 4;  // 16-byte chunks: 4 per voxel
+  constexpr int NIT = (NCH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) u16 ts[NVOX * VS];
+  unsigned t = lr_xcd_remap(blockIdx.x, gridDim.x);
+  const int hq = t % d.nHq; t /= d.nHq;
+  const int wq = t % d.nWq; t /= d.nWq;
+  const int dq = t % d.nDq;
+  const int b = t / d.nDq;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int zq0 = dq * 4, yq0 = wq * 4, xq0 = hq * 16;
+  {
+    const u16* base = gpre + ((((int64_t)b * d.Do + zq0) * d.Wo + yq0) * d.Ho + xq0) * CG;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(base), (short)0, 0x7fffffff, 0x00020000);
+    u32x4 st[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = it * 256 + tid;
+      const int vox = q >> 2, c8 = q & 3;
+      const int xx = vox % 17, r = vox / 17, yy = r % 5, zz = r / 5;
+      const bool ok = q < NCH && zq0 + zz < d.Do && yq0 + yy < d.Wo && xq0 + xx < d.Ho;
+      const unsigned voff = ok ? (unsigned)(((((zz * d.Wo) + yy) * d.Ho + xx) * CG + c8 * 8) * 2) : 0x80000000u;
+      st[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = it * 256 + tid;
+      if (q < NCH) *reinterpret_cast<u32x4*>(ts + (q >> 2) * VS + (q & 3) * 8) = st[it];
+    }
+  }
+  __syncthreads();
+  const int zq = zq0 + wave;
+  const int col = lane & 15, kq = lane >> 4;
+  const int xq = xq0 + col;
+  const u16* lts = ts + col * VS + kq * 8;
+  for (int pp = 3; pp >= 0; --pp) {
+    const int py = pp & 1, pz = pp >> 1;
+    const int z = 2 * zq + pz;
+    if (z >= d.D) continue;  // wave-uniform; no barrier below
+    f32x4 accp[2][4][NT];
+#pragma unroll
+    for (int px = 1; px >= 0; --px) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) accp[px][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int ntap = 1 << (px + py + pz);
+      for (int tapi = 0; tapi < ntap; ++tapi) {
+        const int ix = tapi & px, r1 = tapi >> px, iy = r1 & py, iz = (r1 >> py) & pz;
+        const int tx = px ? 2 * ix : 1, ox = px ? 1 - ix : 0;
+        const int ty = py ? 2 * iy : 1, oy = py ? 1 - iy : 0;
+        const int tz = pz ? 2 * iz : 1, oz = pz ? 1 - iz : 0;
+        const int tap = (tz * 3 + ty) * 3 + tx;
+        u32x4 bw[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bw[nt] = wp[((int64_t)tap * NT + nt) * 64 + lane];
+        const u16* src = lts + (((wave + oz) * 5 + oy) * 17 + ox) * VS;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const u32x4 a = *reinterpret_cast<const u32x4*>(src + mt * 17 * VS);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            accp[px][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[nt]),
+                                                                      __builtin_bit_cast(bf16x8, a), accp[px][mt][nt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int y = 2 * (yq0 + mt) + py;
+      if (y >= d.W) continue;
+      const int64_t row = (((int64_t)b * d.D + z) * d.W + y) * d.H * d.Cx;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          const int x = 2 * xq + px;
+          if (x >= d.H) continue;
+          const int c = nt * 16 + kq * 4;
+          // the producer's activation (bf16) at this voxel: rows [H][C] or [parity][H/2][C]
+          const int64_t xo = row + (int64_t)(d.xs_layout == LR_LAYOUT_BF16_NDHWC ? x : px * (d.H >> 1) + xq) * d.Cx + c;
+          const uint2 xs = *reinterpret_cast<const uint2*>(xsave + xo);
+          const short s0 = (short)(xs.x & 0xffffu), s1 = (short)(xs.x >> 16), s2 = (short)(xs.y & 0xffffu), s3 = (short)(xs.y >> 16);
+          f32x4 v = accp[px][mt][nt];
+          v[0] = s0 > 0 ? v[0] : v[0] * d.slope;   // bf16 > 0  <=>  its bit pattern as int16 > 0
+          v[1] = s1 > 0 ? v[1] : v[1] * d.slope;
+          v[2] = s2 > 0 ? v[2] : v[2] * d.slope;
+          v[3] = s3 > 0 ? v[3] : v[3] * d.slope;
+          const unsigned lo = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
+          const unsigned hi = (unsigned)to_bf16(v[2]) | ((unsigned)to_bf16(v[3]) << 16);
+          *reinterpret_cast<uint2*>(gx + row + (int64_t)x * d.Cx + c) = make_uint2(lo, hi);
+        }
+    }
+  }
+}
+
 // packed[(s*NT + nt)*64 + lane] = the 8 bf16 weights W[co = nt*16 + (lane&15)][k-block lane>>4] of MFMA step s
 __global__ void pack_bf16_kernel(const float* __restrict__ w, u32x4* __restrict__ packed, int Cin, int Cout, int NT) {
   const int NS = Cin == 32 ? 27 : 14;
@@ -449,6 +563,35 @@ extern "C" int lr_conv3d_first_bf16(const float* in, const void* packed_w, const
   if (Cout == 16) { if (Cin <= 3) LR_C0(1, true); else LR_C0(1, false); }
   else            { if (Cin <= 3) LR_C0(2, true); else LR_C0(2, false); }
 #undef LR_C0
+  return lr_launch_status();
+}
+
+extern "C" int lr_conv3d_dgrad_bf16(const void* gpre, const void* packed_wT, void* gx, int B, int Cg, int Cx, int D,
+                                    int W, int H, const void* x_saved, int x_layout, float negative_slope,
+                                    void* stream) {
+  if (!gpre || !packed_wT || !gx || !x_saved) return LR_ENULL;
+  if (Cg != 32 || (Cx != 16 && Cx != 32)) return LR_EUNSUPPORTED;
+  if (B < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
+  if (x_layout != LR_LAYOUT_BF16_NDHWC && x_layout != LR_LAYOUT_BF16_NDHWC_HPS) return LR_EINVAL;
+  if (x_layout == LR_LAYOUT_BF16_NDHWC_HPS && (H & 1)) return LR_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(gpre) | reinterpret_cast<uintptr_t>(packed_wT)) & 15u) return LR_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(gx) | reinterpret_cast<uintptr_t>(x_saved)) & 7u) return LR_EALIGN;
+  DgDimsH d;
+  d.B = B; d.Cx = Cx; d.D = D; d.W = W; d.H = H;
+  d.Do = (D - 1) / 2 + 1; d.Wo = (W - 1) / 2 + 1; d.Ho = (H - 1) / 2 + 1;
+  if ((int64_t)6 * d.Wo * d.Ho * Cg * 2 >= 0x7fffffffLL) return LR_EINVAL;
+  d.nHq = ((H + 1) / 2 + 15) / 16; d.nWq = ((W + 1) / 2 + 3) / 4; d.nDq = ((D + 1) / 2 + 3) / 4;
+  d.xs_layout = x_layout; d.slope = negative_slope;
+  const int64_t nblk = (int64_t)B * d.nDq * d.nWq * d.nHq;
+  if (nblk > 0x7fffffffLL) return LR_EINVAL;
+  const dim3 grid((unsigned)nblk), blk(256);
+  hipStream_t st = lr_stream(stream);
+  const u16* g = reinterpret_cast<const u16*>(gpre);
+  const u32x4* wt = reinterpret_cast<const u32x4*>(packed_wT);
+  u16* o = reinterpret_cast<u16*>(gx);
+  const u16* xs = reinterpret_cast<const u16*>(x_saved);
+  if (Cx == 16) hipLaunchKernelGGL(conv3d_dgrad_bf16_kernel<1>, grid, blk, 0, st, g, wt, o, xs, d);
+  else hipLaunchKernelGGL(conv3d_dgrad_bf16_kernel<2>, grid, blk, 0, st, g, wt, o, xs, d);
   return lr_launch_status();
 }
 

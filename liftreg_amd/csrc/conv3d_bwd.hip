@@ -486,7 +486,8 @@ struct WclGeom {
 template <int CB, int NTC, bool HPS, bool XB>
 __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_kernel(const float* __restrict__ xin,
                                                                  const float* __restrict__ gpre,
-                                                                 float* __restrict__ partial, WgDims d, int nbricks) {
+                                                                 float* __restrict__ partial, WgDims d, int nbricks,
+                                                                 int gbf /* gpre is bf16 storage */) {
   using G = WclGeom<CB, NTC>;
   constexpr int Cin = CB * 16, Cout = NTC * 16, HB = G::HB;
   __shared__ __attribute__((aligned(16))) float xs[G::XF4 * 4 + HB * 16];  // + a tile of ones (bias gradient)
@@ -564,11 +565,17 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
         xst[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, 0));
       }
     }
-    const float* gb = gpre + ((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + ho0) * Cout;
+    const int64_t gorg = ((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + ho0) * Cout;
+    const void* gb = gbf ? (const void*)(reinterpret_cast<const u16*>(gpre) + gorg) : (const void*)(gpre + gorg);
     const __amdgpu_buffer_rsrc_t rg =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gb), (short)0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(gb), (short)0, 0x7fffffff, 0x00020000);
     const bool gok = live && tid < G::GF4 && ho0 + tid / (NTC * 4) < d.Ho;
-    gst = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rg, gok ? (unsigned)tid * 16u : OOR, 0, 0));
+    if (gbf) {
+      const f32x4 v = bf16x4_to_f32(__builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rg, gok ? (unsigned)tid * 8u : OOR, 0, 0)));
+      gst = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      gst = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rg, gok ? (unsigned)tid * 16u : OOR, 0, 0));
+    }
   };
 
   int brick = blockIdx.x;
@@ -633,7 +640,7 @@ template <int NTL>
 __global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_kernel(const float* __restrict__ xin,
                                                                      const float* __restrict__ gpre,
                                                                      float* __restrict__ partial, WgDims d,
-                                                                     int nbricks, int round_x) {
+                                                                     int nbricks, int round_x, int gbf) {
   using G = WplGeom<NTL>;
   __shared__ __attribute__((aligned(16))) float xs[G::XF4 * 4 + 80];  // + ones (the bias-gradient column)
   __shared__ __attribute__((aligned(16))) float gs[4 * G::GP];
@@ -688,15 +695,21 @@ __global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_ke
       const bool ok = live && (xdec[it] >> 14) && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W && xi >= 0 && xi < d.H;
       xst[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? org + xrel[it] : OOR, 0, 0));
     }
-    const float* gb = gpre + ((((int64_t)b * d.D + z) * d.W + y0) * d.H + h0) * 16;
+    const int64_t gorg = ((((int64_t)b * d.D + z) * d.W + y0) * d.H + h0) * 16;
+    const void* gb = gbf ? (const void*)(reinterpret_cast<const u16*>(gpre) + gorg) : (const void*)(gpre + gorg);
     const __amdgpu_buffer_rsrc_t rg =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gb), (short)0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(gb), (short)0, 0x7fffffff, 0x00020000);
     const bool vok = live && h0 + (tid >> 2) < d.H;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const bool ok = vok && y0 + rr < d.W;
-      gst[rr] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                                               rg, ok ? (unsigned)((rr * d.H * 16 + tid * 4) * 4) : OOR, 0, 0));
+      const unsigned el = (unsigned)(rr * d.H * 16 + tid * 4);  // element offset of this thread's 4 channels
+      if (gbf) {
+        const f32x4 v = bf16x4_to_f32(__builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rg, ok ? el * 2u : OOR, 0, 0)));
+        gst[rr] = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        gst[rr] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? el * 4u : OOR, 0, 0));
+      }
     }
   };
 
@@ -857,9 +870,8 @@ extern "C" int64_t lr_conv3d_wgrad_partial_floats(int Cin, int Cout, int x_layou
   return (int64_t)nblk * (x_layout == LR_LAYOUT_NCDHW ? 4 : 1) * Cout * ntiles * 16;
 }
 
-extern "C" int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gpre, float* partial, float* gw,
-                                   float* gb, int B, int Cin, int Cout, int D, int W, int H, int stride, int nblk,
-                                   void* stream) {
+static int wgrad_impl(const float* x, int x_layout, const float* gpre, int gbf, float* partial, float* gw, float* gb,
+                      int B, int Cin, int Cout, int D, int W, int H, int stride, int nblk, void* stream) {
   if (!x || !gpre || !partial || !gw) return LR_ENULL;
   if (B < 1 || Cin < 1 || D < 1 || W < 1 || H < 1 || nblk < 1 || nblk > 65535) return LR_EINVAL;
   if ((stride != 1 && stride != 2) || (Cout != 16 && Cout != 32)) return LR_EUNSUPPORTED;
@@ -890,7 +902,7 @@ extern "C" int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gp
       const unsigned grid = (unsigned)(nbricks < nblk ? nbricks : nblk);
       const bool hps = x_layout == LR_LAYOUT_NDHWC_HPS;
 #define LR_WCL1(CBV, NTCV, HP, XBV) \
-  hipLaunchKernelGGL((conv3d_wgrad_cl_kernel<CBV, NTCV, HP, XBV>), dim3(grid), dim3(256 * CBV), 0, st, x, gpre, partial, d, (int)nbricks)
+  hipLaunchKernelGGL((conv3d_wgrad_cl_kernel<CBV, NTCV, HP, XBV>), dim3(grid), dim3(256 * CBV), 0, st, x, gpre, partial, d, (int)nbricks, gbf)
 #define LR_WCL(CBV, NTCV)                                                       \
   do {                                                                          \
     if (hps) { if (xbf) LR_WCL1(CBV, NTCV, true, true); else LR_WCL1(CBV, NTCV, true, false); }     \
@@ -910,8 +922,8 @@ extern "C" int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gp
     const int64_t nbricks = (int64_t)B * D * ((W + 3) / 4) * ((H + 63) / 64);
     if (nbricks < 0x7fffffffLL) {
       const unsigned grid = (unsigned)(nbricks < nblk ? nbricks : nblk);
-      if (Cin <= 3) hipLaunchKernelGGL(conv3d_wgrad_planar_kernel<6>, dim3(grid), dim3(256), 0, st, x, gpre, partial, d, (int)nbricks, (int)xround);
-      else hipLaunchKernelGGL(conv3d_wgrad_planar_kernel<21>, dim3(grid), dim3(256), 0, st, x, gpre, partial, d, (int)nbricks, (int)xround);
+      if (Cin <= 3) hipLaunchKernelGGL(conv3d_wgrad_planar_kernel<6>, dim3(grid), dim3(256), 0, st, x, gpre, partial, d, (int)nbricks, (int)xround, gbf);
+      else hipLaunchKernelGGL(conv3d_wgrad_planar_kernel<21>, dim3(grid), dim3(256), 0, st, x, gpre, partial, d, (int)nbricks, (int)xround, gbf);
       nparts = (int)grid * 4;
     }
   }
@@ -925,7 +937,7 @@ extern "C" int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gp
                        ncols, x_layout, planar ? 27 * Cin : d.ntiles * 16);
     return lr_launch_status();
   }
-  if (xbf || xround) return LR_EUNSUPPORTED;  // the generic kernel reads fp32 activations only
+  if (xbf || xround || gbf) return LR_EUNSUPPORTED;  // the generic kernel reads fp32 activations and gradients only
   if (Cout == 16) hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, x, gpre, partial, d, ngroups);
   else hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, x, gpre, partial, d, ngroups);
   if (int e = lr_launch_status()) return e;
@@ -944,4 +956,18 @@ extern "C" int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gp
     return lr_launch_status();
   }
   return LR_OK;
+}
+
+extern "C" int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gpre, float* partial, float* gw,
+                                   float* gb, int B, int Cin, int Cout, int D, int W, int H, int stride, int nblk,
+                                   void* stream) {
+  return wgrad_impl(x, x_layout, gpre, 0, partial, gw, gb, B, Cin, Cout, D, W, H, stride, nblk, stream);
+}
+
+// Same with the pre-activation gradient stored as bf16 plain channels-last (the bf16-gradient training variant).
+extern "C" int lr_conv3d_wgrad_bf16g_f32(const float* x, int x_layout, const void* gpre_bf16, float* partial, float* gw,
+                                         float* gb, int B, int Cin, int Cout, int D, int W, int H, int stride,
+                                         int nblk, void* stream) {
+  return wgrad_impl(x, x_layout, reinterpret_cast<const float*>(gpre_bf16), 1, partial, gw, gb, B, Cin, Cout, D, W, H,
+                    stride, nblk, stream);
 }

@@ -77,6 +77,11 @@ class model(nn.Module):
         self.conv_dtype = str(_opt(opt, "conv_dtype", "fp32"))
         if self.conv_dtype not in ("fp32", "bf16"):
             raise ValueError('conv_dtype must be "fp32" or "bf16"')
+        # with conv_dtype "bf16": "grad_dtype": "bf16" also stores the pre-activation gradients between the blocks
+        # as bf16 (data gradient on the bf16 MFMA); default "fp32" = the exact gradient of the bf16 forward
+        self.grad_dtype = str(_opt(opt, "grad_dtype", "fp32"))
+        if self.grad_dtype not in ("fp32", "bf16") or (self.grad_dtype == "bf16" and self.conv_dtype != "bf16"):
+            raise ValueError('grad_dtype must be "fp32", or "bf16" together with conv_dtype "bf16"')
         self._bf16_layouts = []
         for i in range(len(enc_filters)):
             h_in = _out_size(self.img_sz[2], self.strides[:i])
@@ -201,7 +206,8 @@ class model(nn.Module):
             blks = [self.encoders[i] for i in range(6)]
             packed = [self._packed_weight(i, bf16=True) for i in range(6)]
             wb = [t for blk in blks for t in (blk.conv.weight, blk.conv.bias)]
-            feat = EncoderBf16Fn.apply(x, self._bf16_layouts, [blk._slope for blk in blks], self.strides, packed, *wb)
+            feat = EncoderBf16Fn.apply(x, self._bf16_layouts, [blk._slope for blk in blks], self.strides, packed,
+                                       self.grad_dtype == "bf16", *wb)
             return self.encoders[6](feat)
         if self.conv_dtype == "bf16":
             for i in range(6):

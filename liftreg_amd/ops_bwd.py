@@ -143,6 +143,58 @@ def conv3d_bwd(x, x_layout, weight, y, y_layout, gy, gy_layout, stride, negative
     return gx, gw, gb
 
 
+def lrelu_bwd(gy, gy_layout, y, y_layout, negative_slope=0.2):
+    """gpre = gy * (y > 0 ? 1 : slope) as plain NDHWC fp32 (the first step of conv3d_bwd on its own)."""
+    gy, y = _dev(gy, "gy"), _dev(y, "y")
+    B, C, D, W, H = _act_dims(y, y_layout)
+    gpre = torch.empty((B, D, W, H, C), dtype=torch.float32, device=y.device)
+    nb1 = max(1, min(1024, (gpre.numel() // 4 + 255) // 256))
+    with _timed(f"lrelu_bwd_c{C}_{D}", bytes=12 * gpre.numel()):
+        _hip.check(_hip.lib().lr_lrelu_bwd_f32(gy.data_ptr(), gy_layout, y.data_ptr(), y_layout, gpre.data_ptr(), None,
+                                               None, B, C, D, W, H, float(negative_slope), nb1, _stream()),
+                   "lr_lrelu_bwd_f32")
+    return gpre
+
+
+def conv3d_bwd_bf16g(x, x_layout, weight, gpre, stride, mask_input_slope=None, nblk=512):
+    """conv3d_bwd of the bf16-GRADIENT training variant: `gpre` (B,Do,Wo,Ho,Cout) is a bfloat16 plain channels-last
+    pre-activation gradient; x the block's saved input (bf16 LAYOUT_BF16_NDHWC[_HPS], or the first block's fp32 input
+    with LAYOUT_NCDHW_RBF16).  Returns (the PRODUCER's pre-activation gradient as bf16 plain channels-last — its
+    LeakyReLU mask applied with `mask_input_slope` — or None, gw fp32, gb fp32)."""
+    bf_layouts = (_hip.LAYOUT_BF16_NDHWC, _hip.LAYOUT_BF16_NDHWC_HPS)
+    x = _dev(x, "x", torch.bfloat16 if x_layout in bf_layouts else torch.float32)
+    gpre = _dev(gpre, "gpre", torch.bfloat16)
+    w = _dev(weight.detach(), "weight")
+    Cout, Cin = w.shape[0], w.shape[1]
+    B, Cx, D, W, H = _act_dims(x, x_layout)
+    o = lambda n: (n - 1) // stride + 1
+    if Cx != Cin or tuple(gpre.shape) != (B, o(D), o(W), o(H), Cout):
+        raise ValueError("conv3d_bwd_bf16g: shape mismatch")
+    lib, dev = _hip.lib(), x.device
+    gx = None
+    if mask_input_slope is not None:
+        if x_layout not in bf_layouts:
+            raise ValueError("the data gradient needs the bf16 saved input (mask source)")
+        from .ops import conv3d_pack_weights_bf16
+        packed_t = conv3d_pack_weights_bf16(w.transpose(0, 1).contiguous())     # rounds like the forward's pack
+        gx = torch.empty((B, D, W, H, Cin), dtype=torch.bfloat16, device=dev)
+        with _timed(f"conv3d_dgrad_bf16_c{Cout}x{Cin}_{D}", flops=2.0 * 27 * Cin * Cout * gpre.numel() / Cout,
+                    bytes=2 * (gpre.numel() + 2 * gx.numel())):
+            _hip.check(lib.lr_conv3d_dgrad_bf16(gpre.data_ptr(), packed_t.data_ptr(), gx.data_ptr(), B, Cout, Cin, D, W, H,
+                                                x.data_ptr(), x_layout, float(mask_input_slope), _stream()),
+                       "lr_conv3d_dgrad_bf16")
+    npart = lib.lr_conv3d_wgrad_partial_floats(Cin, Cout, x_layout, nblk)
+    partial = torch.empty((npart,), dtype=torch.float32, device=dev)
+    gw = torch.empty_like(w)
+    gb = torch.empty((Cout,), dtype=torch.float32, device=dev)
+    with _timed(f"conv3d_wgrad_c{Cin}x{Cout}_{D}_bf16g", flops=2.0 * 27 * Cin * Cout * gpre.numel() / Cout,
+                bytes=x.numel() * x.element_size() + 2 * gpre.numel()):
+        _hip.check(lib.lr_conv3d_wgrad_bf16g_f32(x.data_ptr(), x_layout, gpre.data_ptr(), partial.data_ptr(), gw.data_ptr(),
+                                                 gb.data_ptr(), B, Cin, Cout, D, W, H, stride, nblk, _stream()),
+                   "lr_conv3d_wgrad_bf16g_f32")
+    return gx, gw, gb
+
+
 def linear_bwd(x, weight, y, gy, negative_slope=1.0, need_gx=True):
     """Backward of ops.linear_lrelu: returns (gx or None, gw, gb)."""
     x, y, gy = _dev(x, "x"), _dev(y, "y"), _dev(gy, "gy")

@@ -211,7 +211,8 @@ def ncc_loss_squared(x, y):
 
 
 # --------------------------------------------------------------------------- a14
-def model_forward(params, inp, pca_vectors_LxM, pca_mean, strides=(1, 2, 2, 2, 2, 2), conv_dtype="fp32"):
+def model_forward(params, inp, pca_vectors_LxM, pca_mean, strides=(1, 2, 2, 2, 2, 2), conv_dtype="fp32",
+                  grad_dtype="fp32"):
     """model.forward (LiftRegDeformSubspaceBackproj.py:49-104) on CPU tensors.
 
     params: state-dict-like {encoders.i.conv.weight/bias, encoders.6.{1,2,3}.fc.weight/bias}.
@@ -227,7 +228,7 @@ def model_forward(params, inp, pca_vectors_LxM, pca_mean, strides=(1, 2, 2, 2, 2
     tv = backproject(target_proj, inp["target_poses"], (D, W, H))
     x = torch.cat([moving, tv], dim=1)
     if conv_dtype == "bf16":      # the build's bf16 storage variant (not in the reference): see encoder_bf16
-        x = encoder_bf16(params, x, strides)
+        x = encoder_bf16(params, x, strides, grad_bf16=(grad_dtype == "bf16"))
     else:
         for i, s in enumerate(strides):
             x = conv_block(x, params[f"encoders.{i}.conv.weight"], params[f"encoders.{i}.conv.bias"], s)
@@ -327,21 +328,40 @@ def compute_jacobi_map(phi, spacing, use_01=False):
 
 # --------------------------------------------------------------------------- bf16 storage variant (configs C4/C5)
 def _bf16(t):
-    """Round to nearest-even bfloat16 and back (the values a bf16 tensor holds)."""
-    return t.to(torch.bfloat16).to(torch.float32)
+    """Round to nearest-even bfloat16 and back (the values a bf16 tensor holds).  Under autograd the cast is
+    straight-through (the gradient passes unrounded): where the build rounds GRADIENTS it says so explicitly
+    (_RoundGradBf16), so the two training variants stay distinguishable."""
+    r = t.detach().to(torch.bfloat16).to(torch.float32)
+    return t + (r - t.detach()) if t.requires_grad else r
 
 
-def conv_block_bf16(x, weight, bias, stride, slope=0.2, round_out=True):
+class _RoundGradBf16(torch.autograd.Function):
+    """Identity whose backward rounds the gradient to bf16 (the storage of the bf16-gradient training variant)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf16(g)
+
+
+def conv_block_bf16(x, weight, bias, stride, slope=0.2, round_out=True, grad_bf16=False):
     """The numerics contract of lr_conv3d_k3_lrelu_bf16: bf16-representable inputs, weights rounded to bf16,
-    exact products accumulated in fp32, fp32 bias + LeakyReLU, output rounded to bf16 (not for the last block)."""
-    y = F.leaky_relu(F.conv3d(_bf16(x), _bf16(weight), bias, stride=stride, padding=1), slope)
+    exact products accumulated in fp32, fp32 bias + LeakyReLU, output rounded to bf16 (not for the last block).
+    grad_bf16: the gradient w.r.t. the pre-activation is rounded to bf16 before it goes on (grad_dtype="bf16")."""
+    pre = F.conv3d(_bf16(x), _bf16(weight), bias, stride=stride, padding=1)
+    if grad_bf16:
+        pre = _RoundGradBf16.apply(pre)
+    y = F.leaky_relu(pre, slope)
     return _bf16(y) if round_out else y
 
 
-def encoder_bf16(params, x, strides=(1, 2, 2, 2, 2, 2)):
+def encoder_bf16(params, x, strides=(1, 2, 2, 2, 2, 2), grad_bf16=False):
     """conv_dtype="bf16" of the model: every block as conv_block_bf16 (block 0 rounds its fp32 input on the way in);
     the last block's output stays fp32."""
     for i, s in enumerate(strides):
         w, b = params[f"encoders.{i}.conv.weight"], params[f"encoders.{i}.conv.bias"]
-        x = conv_block_bf16(x, w, b, s, round_out=(i != len(strides) - 1))
+        x = conv_block_bf16(x, w, b, s, round_out=(i != len(strides) - 1), grad_bf16=grad_bf16)
     return x
