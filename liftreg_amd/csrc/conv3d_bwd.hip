@@ -620,6 +620,151 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
   }
 }
 
+// ------------------------------------------------------------------- wgrad on the bf16 MFMA (bf16-gradient variant)
+// x (bf16 channels-last) and gpre (bf16 plain) both enter v_mfma_f32_16x16x32_bf16 with K = 32 output voxels of one
+// row segment: 8x the fp32 kernel's k per instruction at 2x its rate.  Both operands are K-STRIDED in their
+// channels-last LDS images ([voxel][16 channels], 32-byte rows), which is what gfx950's transposing LDS read is
+// for: ds_read_b64_tr_b16 hands lane i of a 16-lane group column (= channel) i of a 4-row (= 4-voxel) block, so two
+// reads give a lane its 8 consecutive voxels of one channel.  Same bricks, same window image (parity-split columns:
+// a tap's voxels are consecutive rows), same N-tile split and ones tile (bias gradient) as conv3d_wgrad_cl_kernel.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+template <int CB, int NTC, bool HPS>
+__global__ __launch_bounds__(256 * CB, 2) void conv3d_wgrad_cl_bf16_kernel(const u16* __restrict__ xin,
+                                                                           const u16* __restrict__ gpre,
+                                                                           float* __restrict__ partial, WgDims d,
+                                                                           int nbricks) {
+  constexpr int Cin = CB * 16, Cout = NTC * 16, HB = 32, NCP = 2 * HB + 1, NW = 4 * CB, NTH = NW * 64;
+  constexpr int T = (27 * CB + NW - 1) / NW;
+  constexpr int XCH = 9 * NCP * (Cin / 8);  // 16-byte chunks of the window
+  constexpr int XIT = (XCH + NTH - 1) / NTH;
+  constexpr int XBYTES = 9 * CB * NCP * 32, ONES = XBYTES, GOFF = XBYTES + HB * 32;  // window | ones tile | gradient segment
+  __shared__ __attribute__((aligned(16))) unsigned char lds[GOFF + NTC * HB * 32];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nseg = (d.Ho + HB - 1) / HB;
+  for (int i = tid; i < HB * 16; i += NTH) reinterpret_cast<u16*>(lds + ONES)[i] = 0x3f80;  // bf16 1.0
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+
+  // staging slots (brick-independent decode): chunk q -> (row9, pos, c8)
+  unsigned xrel[XIT], xdst[XIT];
+  int xdec[XIT];  // pz | py<<2 | pc<<4 | used<<12
+#pragma unroll
+  for (int it = 0; it < XIT; ++it) {
+    const int q = it * NTH + tid;
+    const bool used = q < XCH;
+    const int c8 = q % (Cin / 8), vox = q / (Cin / 8);
+    const int pos = vox % NCP, row9 = used ? vox / NCP : 0;
+    const int pz = row9 / 3, py = row9 % 3;
+    const int pc = pos <= HB ? 2 * pos : 2 * (pos - HB - 1) + 1;
+    const int hprel = (pc & 1) ? (pc - 1) / 2 : (d.H >> 1) - 1 + pc / 2;
+    xdec[it] = pz | (py << 2) | (pc << 4) | (used ? 1 << 12 : 0);
+    xrel[it] = (unsigned)(((((pz * d.W + py) * d.H + (HPS ? hprel : pc)) * Cin) + c8 * 8) * 2);
+    xdst[it] = (unsigned)((((row9 * CB + (c8 >> 1)) * NCP + pos) * 32) + (c8 & 1) * 16);
+  }
+  // transposed-read lane address inside a 32-row (voxel) x 16-channel tile: group kq = lane>>4 owns voxels 8kq..8kq+7;
+  // lane 4q+p of the group supplies row q of the 4-row block, columns 4p..4p+3 (8 bytes); second read: +4 rows
+  const int kq = lane >> 4, lq = (lane >> 2) & 3, lp = lane & 3;
+  const unsigned ltr = (unsigned)((kq * 8 + lq) * 32 + lp * 8);
+  unsigned boff[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int jr = wave + NW * t;
+    const int j = min(jr, 27 * CB - 1);
+    const int tap = j / CB, cb = j % CB;
+    const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+    boff[t] = lds0 + ltr + (jr == 27 * CB ? (unsigned)ONES
+                                           : (unsigned)((((tz * 3 + ty) * CB + cb) * NCP + (tx == 1 ? HB + 1 : (tx >> 1))) * 32));
+  }
+  const unsigned aoff = lds0 + GOFF + ltr;
+  f32x4 acc[T][NTC];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4_t xst[XIT], gst;
+  auto prefetch = [&](int brick) {
+    const bool live = brick < nbricks;
+    int r = live ? brick : 0;
+    const int hseg = r % nseg; r /= nseg;
+    const int wo = r % d.Wo; r /= d.Wo;
+    const int dz = r % d.Do;
+    const int b = r / d.Do;
+    const int ho0 = hseg * HB;
+    const int zi0 = 2 * dz - 1, yi0 = 2 * wo - 1, xi0 = 2 * ho0 - 1;
+    const u16* xb = xin + (int64_t)b * d.D * d.W * d.H * Cin + (((int64_t)zi0 * d.W + yi0) * d.H + (HPS ? ho0 : xi0)) * Cin;
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(xb), (short)0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+      const int zi = zi0 + (xdec[it] & 3), yi = yi0 + ((xdec[it] >> 2) & 3), xi = xi0 + ((xdec[it] >> 4) & 255);
+      const bool ok = live && (xdec[it] >> 12) && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W && xi >= 0 && xi < d.H;
+      xst[it] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xrel[it] : OOR, 0, 0);
+    }
+    const u16* gb = gpre + ((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + ho0) * Cout;
+    const __amdgpu_buffer_rsrc_t rg =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(gb), (short)0, 0x7fffffff, 0x00020000);
+    const bool gok = live && tid < HB * (Cout / 8) && ho0 + tid / (Cout / 8) < d.Ho;
+    gst = __builtin_amdgcn_raw_buffer_load_b128(rg, gok ? (unsigned)tid * 16u : OOR, 0, 0);
+  };
+
+  int brick = blockIdx.x;
+  prefetch(brick);
+  for (; brick < nbricks; brick += gridDim.x) {
+    __syncthreads();  // the previous brick's reads are done
+#pragma unroll
+    for (int it = 0; it < XIT; ++it)
+      if ((xdec[it] >> 12) & 1) *reinterpret_cast<u32x4_t*>(lds + xdst[it]) = xst[it];
+    if (tid < HB * (Cout / 8)) {
+      const int i = tid / (Cout / 8), c8 = tid % (Cout / 8);
+      *reinterpret_cast<u32x4_t*>(lds + GOFF + ((c8 >> 1) * HB + i) * 32 + (c8 & 1) * 16) = gst;
+    }
+    __syncthreads();
+    prefetch(brick + (int)gridDim.x);
+    // operands: 2 transposed reads each (rows +0..3 and +4..7 of the lane group's 8 voxels); all lanes take part
+    unsigned long long ar[NTC][2], br[T][2];
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ar[nt][h]) : "v"(aoff), "n"(nt * HB * 32 + h * 128) : "memory");
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(br[t][h]) : "v"(boff[t]), "n"(h * 128) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt) asm volatile("" : "+v"(ar[nt][0]), "+v"(ar[nt][1]));
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      asm volatile("" : "+v"(br[t][0]), "+v"(br[t][1]));
+      const u32x4_t bv = {(unsigned)br[t][0], (unsigned)(br[t][0] >> 32), (unsigned)br[t][1], (unsigned)(br[t][1] >> 32)};
+#pragma unroll
+      for (int nt = 0; nt < NTC; ++nt) {
+        const u32x4_t av = {(unsigned)ar[nt][0], (unsigned)(ar[nt][0] >> 32), (unsigned)ar[nt][1], (unsigned)(ar[nt][1] >> 32)};
+        acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, bv),
+                                                             acc[t][nt], 0, 0, 0);
+      }
+    }
+  }
+  const int col = lane & 15;
+  const int ncols = (27 * CB + 1) * 16;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int j = wave + NW * t;
+    if (j <= 27 * CB) {
+#pragma unroll
+      for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          partial[((int64_t)blockIdx.x * Cout + nt * 16 + kq * 4 + r) * ncols + j * 16 + col] = acc[t][nt][r];
+    }
+  }
+}
+
 // ------------------------------------------------------------------- wgrad, planar X, stride 1 (the first block)
 // Columns c = ci*27 + tap (NTL tiles of 16); the 4 waves of a block split the VOXELS (one brick row each) and
 // every wave carries all NTL tiles.  Brick = 4 rows x 64 voxels of one plane; k-group g of a k-step owns voxels
@@ -898,7 +1043,26 @@ static int wgrad_impl(const float* x, int x_layout, const float* gpre, int gbf, 
     // blocks 1..5: LDS-staged bricks (one output row segment each)
     const int hb = 32 / (Cin / 16);
     const int64_t nbricks = (int64_t)B * d.Do * d.Wo * ((d.Ho + hb - 1) / hb);
-    if (nbricks < 0x7fffffffLL) {
+    if (gbf && xbf) {  // both operands bf16: the bf16-MFMA kernel (32-voxel bricks)
+      const int64_t nb32 = (int64_t)B * d.Do * d.Wo * ((d.Ho + 31) / 32);
+      if (nb32 < 0x7fffffffLL) {
+        const unsigned grid = (unsigned)(nb32 < nblk ? nb32 : nblk);
+        const bool hps = x_layout == LR_LAYOUT_NDHWC_HPS;
+        const u16* xh = reinterpret_cast<const u16*>(x);
+        const u16* gh = reinterpret_cast<const u16*>(gpre);
+#define LR_WB(CBV, NTCV)                                                                                              \
+  do {                                                                                                                \
+    if (hps) hipLaunchKernelGGL((conv3d_wgrad_cl_bf16_kernel<CBV, NTCV, true>), dim3(grid), dim3(256 * CBV), 0, st, xh, gh, partial, d, (int)nb32); \
+    else hipLaunchKernelGGL((conv3d_wgrad_cl_bf16_kernel<CBV, NTCV, false>), dim3(grid), dim3(256 * CBV), 0, st, xh, gh, partial, d, (int)nb32);    \
+  } while (0)
+        if (Cin == 16 && Cout == 16) LR_WB(1, 1);
+        else if (Cin == 16) LR_WB(1, 2);
+        else if (Cout == 16) LR_WB(2, 1);
+        else LR_WB(2, 2);
+#undef LR_WB
+        nparts = (int)grid;
+      }
+    } else if (nbricks < 0x7fffffffLL) {
       const unsigned grid = (unsigned)(nbricks < nblk ? nbricks : nblk);
       const bool hps = x_layout == LR_LAYOUT_NDHWC_HPS;
 #define LR_WCL1(CBV, NTCV, HP, XBV) \
