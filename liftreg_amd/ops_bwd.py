@@ -70,7 +70,7 @@ def _act_dims(t, layout):
 
 
 def conv3d_bwd(x, x_layout, weight, y, y_layout, gy, gy_layout, stride, negative_slope=0.2, need_gx=True,
-               nblk=512, gy_is_gpre=False, mask_input_slope=None, round_weights=False):
+               nblk=1024, gy_is_gpre=False, mask_input_slope=None, round_weights=False):
     """Backward of ops.conv3d_k3_lrelu.  x / y: the block's saved input / output (any layout), gy: gradient of
     the output.  Returns (gx, gw (Cout,Cin,3,3,3), gb (Cout)); gx is (B,D,W,H,Cin) in x's own channels-last
     layout, or None.
@@ -156,7 +156,7 @@ def lrelu_bwd(gy, gy_layout, y, y_layout, negative_slope=0.2):
     return gpre
 
 
-def conv3d_bwd_bf16g(x, x_layout, weight, gpre, stride, mask_input_slope=None, nblk=512):
+def conv3d_bwd_bf16g(x, x_layout, weight, gpre, stride, mask_input_slope=None, nblk=1024):
     """conv3d_bwd of the bf16-GRADIENT training variant: `gpre` (B,Do,Wo,Ho,Cout) is a bfloat16 plain channels-last
     pre-activation gradient; x the block's saved input (bf16 LAYOUT_BF16_NDHWC[_HPS], or the first block's fp32 input
     with LAYOUT_NCDHW_RBF16).  Returns (the PRODUCER's pre-activation gradient as bf16 plain channels-last — its
