@@ -120,6 +120,8 @@ def main():
                     help="2: batch i's HBM-bound decode half overlaps batch i+1's MFMA-bound encode half on two HIP "
                          "streams (measured +1.3 %% at C3: every kernel already fills the chip; per-kernel timings "
                          "are only meaningful with 1)")
+    ap.add_argument("--pca-dtype", default="fp32", choices=("fp32", "bf16"),
+                    help="bf16: the PCA basis stored as bfloat16 in HBM (opt-in, not the headline configuration)")
     ap.add_argument("--conv-dtype", default="fp32", choices=("fp32", "bf16"),
                     help='bf16: activations between the conv blocks stored as bfloat16, blocks 1..5 on the bf16 MFMA '
                          '(configs C4/C5); NOT the headline configuration — the JSON line says so in "dtype"')
@@ -149,7 +151,7 @@ def main():
     torch.manual_seed(2021)
     n, P, B, L = cfg["n"], cfg["P"], cfg["B"], cfg["L"]
     net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:2021",
-                            "conv_dtype": args.conv_dtype}).to(dev).eval()
+                            "conv_dtype": args.conv_dtype, "pca_dtype": args.pca_dtype}).to(dev).eval()
     inp = synth_inputs(cfg, dev, seed=2021 + rank)
     sim = NCCLoss(check_nan=False)
 
@@ -263,7 +265,9 @@ def main():
         "metric": "registrations/sec (256^3 CT, 2-view DRR)" if args.config == "c3" else f"registrations/sec ({args.config})",
         "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32" if args.conv_dtype == "fp32" else "bf16 conv blocks 1-5 (f32 elsewhere)",
+        "vs_baseline": None,
+        "dtype": "f32" if (args.conv_dtype, args.pca_dtype) == ("fp32", "fp32") else
+                 f"conv blocks {args.conv_dtype}, PCA basis storage {args.pca_dtype}, f32 elsewhere",
         "data": "synthetic",
         "config": {"workload": f"{args.config}: {n}^3 CT, {P}x{cfg['R']}^2 DRR, batch {B}/GPU, latent {L}, "
                                "backproject+conv6(MFMA f32)+FC3+PCA+warp+NCC", "global_batch": world * B,

@@ -276,6 +276,13 @@ int lr_conv3d_wgrad_f32(const float* x, int x_layout, const float* gpre, float* 
                         float* gb, int B, int Cin, int Cout, int D, int W, int H, int stride, int nblk,
                         void* stream);
 
+/* PCA with the basis stored as bf16 (L, ldb): an opt-in storage format that halves the bytes of the two HBM-bound
+ * basis passes (model option "pca_dtype": "bf16"); everything else (coefficients, mean, accumulate, disp) fp32. */
+int lr_pca_reconstruct_bf16basis_f32(const float* coefs, const void* basis_bf16, const float* mean, float* disp,
+                                     int B, int L, int64_t M, int64_t ldb, int64_t disp_batch_stride, void* stream);
+int lr_pca_bwd_coef_bf16basis_f32(const float* gdisp, const void* basis_bf16, float* partial, float* gcoefs, int B,
+                                  int L, int64_t M, int64_t ldb, int64_t gdisp_batch_stride, int nblk, void* stream);
+
 /* ---- bf16 variant of the stride-2 encoder blocks (Cin, Cout in {16,32}; v_mfma_f32_16x16x32_bf16, fp32
  * accumulate, bias/LeakyReLU in fp32, output rounded to bf16 — or fp32 NCDHW for the last block).
  * in: bf16 LR_LAYOUT_BF16_NDHWC[_HPS]; packed_w: lr_conv3d_packed_bf16_bytes(...) bytes written by

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
 // gcoefs[b][l] = sum_m g[b][m] * basis[l][m].  grid (m-blocks, l-groups of LG): a block keeps LG x BT
 // accumulators per thread, streams its m-range once per l-group; per-block partials, then a fixed-order reduce.
 constexpr int LG = 8;
-template <int BT>
+template <int BT, bool BF /* bf16-stored basis */>
 __global__ __launch_bounds__(256) void pca_bwd_kernel(const float* __restrict__ g, const float* __restrict__ basis,
                                                       float* __restrict__ partial, int B, int L, int64_t M,
                                                       int64_t ldb, int64_t gstride) {
@@ -160,7 +160,18 @@ __global__ __launch_bounds__(256) void pca_bwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int a = 0; a < LG; ++a) {
       if (l0 + a < L) {
-        const f32x4 bv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(basis + (int64_t)(l0 + a) * ldb + m));
+        f32x4 bv;
+        if (BF) {
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 raw = __builtin_nontemporal_load(
+              reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(basis) + (int64_t)(l0 + a) * ldb + m));
+          bv[0] = __builtin_bit_cast(float, raw.x << 16);
+          bv[1] = __builtin_bit_cast(float, raw.x & 0xffff0000u);
+          bv[2] = __builtin_bit_cast(float, raw.y << 16);
+          bv[3] = __builtin_bit_cast(float, raw.y & 0xffff0000u);
+        } else {
+          bv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(basis + (int64_t)(l0 + a) * ldb + m));
+        }
 #pragma unroll
         for (int b = 0; b < BT; ++b)
           acc[a][b] = fmaf(gv[b].x, bv.x, fmaf(gv[b].y, bv.y, fmaf(gv[b].z, bv.z, fmaf(gv[b].w, bv.w, acc[a][b]))));
@@ -285,22 +296,37 @@ extern "C" int lr_warp_bwd_disp_f32(const float* img, const float* seg, const fl
   return lr_launch_status();
 }
 
-extern "C" int lr_pca_bwd_coef_f32(const float* gdisp, const float* basis, float* partial, float* gcoefs, int B,
+static int pca_bwd_impl(bool bf, const float* gdisp, const float* basis, float* partial, float* gcoefs, int B,
                                    int L, int64_t M, int64_t ldb, int64_t gdisp_batch_stride, int nblk,
                                    void* stream) {
   if (!gdisp || !basis || !partial || !gcoefs) return LR_ENULL;
   if (B < 1 || B > 8 || L < 1 || M < 4 || ldb < M || gdisp_batch_stride < M || nblk < 1 || nblk > 65535)
     return B > 8 ? LR_EUNSUPPORTED : LR_EINVAL;
   if ((M & 3) || (ldb & 3) || (gdisp_batch_stride & 3)) return LR_EALIGN;
-  if ((reinterpret_cast<uintptr_t>(gdisp) | reinterpret_cast<uintptr_t>(basis)) & 15u) return LR_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(gdisp) & 15u) || (reinterpret_cast<uintptr_t>(basis) & (bf ? 7u : 15u))) return LR_EALIGN;
   hipStream_t st = lr_stream(stream);
   const dim3 grid((unsigned)nblk, (unsigned)((L + LG - 1) / LG));
-  if (B > 4) hipLaunchKernelGGL(pca_bwd_kernel<8>, grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
-  else hipLaunchKernelGGL(pca_bwd_kernel<4>, grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
+  if (B > 4 && bf) hipLaunchKernelGGL((pca_bwd_kernel<8, true>), grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
+  else if (B > 4) hipLaunchKernelGGL((pca_bwd_kernel<8, false>), grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
+  else if (bf) hipLaunchKernelGGL((pca_bwd_kernel<4, true>), grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
+  else hipLaunchKernelGGL((pca_bwd_kernel<4, false>), grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
   if (int e = lr_launch_status()) return e;
   const int n = B * L;
   hipLaunchKernelGGL(sum_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partial, gcoefs, nblk, n);
   return lr_launch_status();
+}
+
+extern "C" int lr_pca_bwd_coef_f32(const float* gdisp, const float* basis, float* partial, float* gcoefs, int B,
+                                   int L, int64_t M, int64_t ldb, int64_t gdisp_batch_stride, int nblk,
+                                   void* stream) {
+  return pca_bwd_impl(false, gdisp, basis, partial, gcoefs, B, L, M, ldb, gdisp_batch_stride, nblk, stream);
+}
+
+extern "C" int lr_pca_bwd_coef_bf16basis_f32(const float* gdisp, const void* basis_bf16, float* partial,
+                                             float* gcoefs, int B, int L, int64_t M, int64_t ldb,
+                                             int64_t gdisp_batch_stride, int nblk, void* stream) {
+  return pca_bwd_impl(true, gdisp, reinterpret_cast<const float*>(basis_bf16), partial, gcoefs, B, L, M, ldb,
+                      gdisp_batch_stride, nblk, stream);
 }
 
 extern "C" int lr_linear_bwd_f32(const float* x, const float* w, const float* y, const float* gy, float* gx,

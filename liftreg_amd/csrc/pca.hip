@@ -12,7 +12,9 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int BT>
+// BF: the basis is bf16 storage (half the bytes of this HBM-bound kernel); 4 elements = one 8-byte load, exact
+// expansion to fp32, the arithmetic is unchanged.
+template <int BT, bool BF>
 __global__ __launch_bounds__(256) void pca_kernel(const float* __restrict__ coefs,
                                                   const float* __restrict__ basis,
                                                   const float* __restrict__ mean,
@@ -33,7 +35,18 @@ __global__ __launch_bounds__(256) void pca_kernel(const float* __restrict__ coef
   const float* bp = basis + m;
 #pragma unroll 8
   for (int l = 0; l < L; ++l) {
-    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(bp + (int64_t)l * ldb));
+    f32x4 v;
+    if (BF) {
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 raw = __builtin_nontemporal_load(
+          reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(basis) + (int64_t)l * ldb + m));
+      v[0] = __builtin_bit_cast(float, raw.x << 16);
+      v[1] = __builtin_bit_cast(float, raw.x & 0xffff0000u);
+      v[2] = __builtin_bit_cast(float, raw.y << 16);
+      v[3] = __builtin_bit_cast(float, raw.y & 0xffff0000u);
+    } else {
+      v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(bp + (int64_t)l * ldb));
+    }
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
       const float c = cs[l * BT + b];
@@ -50,15 +63,14 @@ __global__ __launch_bounds__(256) void pca_kernel(const float* __restrict__ coef
 
 }  // namespace
 
-extern "C" int lr_pca_reconstruct_f32(const float* coefs, const float* basis, const float* mean,
-                                      float* disp, int B, int L, int64_t M, int64_t ldb,
-                                      int64_t disp_batch_stride, void* stream) {
+static int pca_impl(const float* coefs, const float* basis, bool bf, const float* mean, float* disp, int B, int L,
+                    int64_t M, int64_t ldb, int64_t disp_batch_stride, void* stream) {
   if (!coefs || !basis || !mean || !disp) return LR_ENULL;
   if (B < 1 || B > 32 || L < 1 || L > 4096 || M < 4 || ldb < M || disp_batch_stride < M)
     return LR_EINVAL;
   if ((M & 3) || (ldb & 3) || (disp_batch_stride & 3)) return LR_EALIGN;
   if ((reinterpret_cast<uintptr_t>(basis) | reinterpret_cast<uintptr_t>(mean) |
-       reinterpret_cast<uintptr_t>(disp)) & 15u)
+       reinterpret_cast<uintptr_t>(disp)) & (bf ? 7u : 15u))
     return LR_EALIGN;
   const int64_t nblk = (M / 4 + 255) / 256;
   if (nblk > 0x7fffffffLL) return LR_EINVAL;
@@ -67,19 +79,40 @@ extern "C" int lr_pca_reconstruct_f32(const float* coefs, const float* basis, co
   for (int b_lo = 0; b_lo < B;) {
     const int rem = B - b_lo;
     if (rem > 4) {
-      hipLaunchKernelGGL(pca_kernel<8>, dim3((unsigned)nblk), dim3(256), (size_t)L * 8 * 4, st,
-                         coefs, basis, mean, disp, B, b_lo, L, M, ldb, disp_batch_stride);
+      if (bf) hipLaunchKernelGGL((pca_kernel<8, true>), dim3((unsigned)nblk), dim3(256), (size_t)L * 8 * 4, st,
+                                 coefs, basis, mean, disp, B, b_lo, L, M, ldb, disp_batch_stride);
+      else hipLaunchKernelGGL((pca_kernel<8, false>), dim3((unsigned)nblk), dim3(256), (size_t)L * 8 * 4, st,
+                              coefs, basis, mean, disp, B, b_lo, L, M, ldb, disp_batch_stride);
       b_lo += 8;
     } else if (rem > 1) {
-      hipLaunchKernelGGL(pca_kernel<4>, dim3((unsigned)nblk), dim3(256), (size_t)L * 4 * 4, st,
-                         coefs, basis, mean, disp, B, b_lo, L, M, ldb, disp_batch_stride);
+      if (bf) hipLaunchKernelGGL((pca_kernel<4, true>), dim3((unsigned)nblk), dim3(256), (size_t)L * 4 * 4, st,
+                                 coefs, basis, mean, disp, B, b_lo, L, M, ldb, disp_batch_stride);
+      else hipLaunchKernelGGL((pca_kernel<4, false>), dim3((unsigned)nblk), dim3(256), (size_t)L * 4 * 4, st,
+                              coefs, basis, mean, disp, B, b_lo, L, M, ldb, disp_batch_stride);
       b_lo += 4;
     } else {
-      hipLaunchKernelGGL(pca_kernel<1>, dim3((unsigned)nblk), dim3(256), (size_t)L * 1 * 4, st,
-                         coefs, basis, mean, disp, B, b_lo, L, M, ldb, disp_batch_stride);
+      if (bf) hipLaunchKernelGGL((pca_kernel<1, true>), dim3((unsigned)nblk), dim3(256), (size_t)L * 1 * 4, st,
+                                 coefs, basis, mean, disp, B, b_lo, L, M, ldb, disp_batch_stride);
+      else hipLaunchKernelGGL((pca_kernel<1, false>), dim3((unsigned)nblk), dim3(256), (size_t)L * 1 * 4, st,
+                              coefs, basis, mean, disp, B, b_lo, L, M, ldb, disp_batch_stride);
       b_lo += 1;
     }
     if (int e = lr_launch_status()) return e;
   }
   return LR_OK;
+}
+
+extern "C" int lr_pca_reconstruct_f32(const float* coefs, const float* basis, const float* mean,
+                                      float* disp, int B, int L, int64_t M, int64_t ldb,
+                                      int64_t disp_batch_stride, void* stream) {
+  return pca_impl(coefs, basis, false, mean, disp, B, L, M, ldb, disp_batch_stride, stream);
+}
+
+// Same with the basis stored as bf16 (L, ldb) — an opt-in storage format for the 11 GB basis (model option
+// "pca_dtype": "bf16"); coefficients, mean, accumulation and the displacement field stay fp32.
+extern "C" int lr_pca_reconstruct_bf16basis_f32(const float* coefs, const void* basis_bf16, const float* mean,
+                                                float* disp, int B, int L, int64_t M, int64_t ldb,
+                                                int64_t disp_batch_stride, void* stream) {
+  return pca_impl(coefs, reinterpret_cast<const float*>(basis_bf16), true, mean, disp, B, L, M, ldb, disp_batch_stride,
+                  stream);
 }

@@ -89,6 +89,11 @@ class model(nn.Module):
             lin = ops.LAYOUT_NCDHW if i == 0 else (ops.LAYOUT_BF16_NDHWC_HPS if h_in % 2 == 0 else ops.LAYOUT_BF16_NDHWC)
             lout = ops.LAYOUT_NCDHW if i == last else (ops.LAYOUT_BF16_NDHWC_HPS if h_out % 2 == 0 else ops.LAYOUT_BF16_NDHWC)
             self._bf16_layouts.append((lin, lout))
+        # optional (non-reference) key "pca_dtype": "bf16" keeps the (L,3V) basis as bfloat16 in HBM (half the bytes of
+        # the two basis passes; coefficients, mean and the displacement field stay fp32); default "fp32"
+        self.pca_dtype = str(_opt(opt, "pca_dtype", "fp32"))
+        if self.pca_dtype not in ("fp32", "bf16"):
+            raise ValueError('pca_dtype must be "fp32" or "bf16"')
         # backward chaining: block i+1's data gradient applies block i's LeakyReLU mask in its epilogue and hands
         # block i its pre-activation gradient directly (one pass over the big activations less per block)
         for i in range(last):
@@ -150,7 +155,7 @@ class model(nn.Module):
     def set_pca(self, vectors_LxM, mean):
         if tuple(vectors_LxM.shape) != (self.latent_dim, 3 * int(np.prod(self.img_sz))):
             raise ValueError("basis must be (latent_dim, 3*D*W*H)")
-        self.pca_vectors_LxM = vectors_LxM.contiguous()
+        self.pca_vectors_LxM = self._basis_storage(vectors_LxM.contiguous())
         self.pca_mean = mean.contiguous()
 
     # ------------------------------------------------------------------ internals
@@ -165,8 +170,13 @@ class model(nn.Module):
             vec = torch.empty((self.latent_dim, M), dtype=torch.float32, device=device)
             for l in range(self.latent_dim):
                 vec[l].normal_(0.0, 0.02 / float(np.sqrt(self.latent_dim)), generator=g)
-            self.pca_vectors_LxM = vec
+            self.pca_vectors_LxM = self._basis_storage(vec)
             self.pca_mean = torch.zeros((M,), dtype=torch.float32, device=device)
+        elif self.pca_dtype == "bf16" and self.pca_vectors_LxM.dtype != torch.bfloat16:
+            self.pca_vectors_LxM = self._basis_storage(self.pca_vectors_LxM)     # a basis loaded from pca_path
+
+    def _basis_storage(self, vec):
+        return vec.to(torch.bfloat16) if self.pca_dtype == "bf16" else vec.to(torch.float32)
 
     def _packed_weight(self, i, bf16=False):
         blk = self.encoders[i]

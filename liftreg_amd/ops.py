@@ -365,8 +365,9 @@ def pca_reconstruct(coefs, basis_LxM, mean, *, out=None):
     `basis_LxM` may be a column slab view (stride(0) >= M) of the full (L,3V) basis.
     """
     coefs = _dev(coefs, "coefs")
-    if not basis_LxM.is_cuda or basis_LxM.dtype != torch.float32 or basis_LxM.stride(1) != 1:
-        raise TypeError("basis must be a float32 GPU tensor with unit column stride")
+    if not basis_LxM.is_cuda or basis_LxM.dtype not in (torch.float32, torch.bfloat16) or basis_LxM.stride(1) != 1:
+        raise TypeError("basis must be a float32 (or bfloat16-stored) GPU tensor with unit column stride")
+    bf = basis_LxM.dtype == torch.bfloat16
     mean = _dev(mean, "mean")
     B, L = coefs.shape
     M = basis_LxM.shape[1]
@@ -376,10 +377,10 @@ def pca_reconstruct(coefs, basis_LxM, mean, *, out=None):
         out = torch.empty((B, M), dtype=torch.float32, device=coefs.device)
     else:
         out = _dev(out, "out")
-    with _timed("pca_reconstruct", bytes=4 * (L * M + M + B * M), samples=B):
-        _hip.check(_hip.lib().lr_pca_reconstruct_f32(coefs.data_ptr(), basis_LxM.data_ptr(), mean.data_ptr(),
-                                                     out.data_ptr(), B, L, M, basis_LxM.stride(0), M, _stream()),
-                   "lr_pca_reconstruct_f32")
+    fn = _hip.lib().lr_pca_reconstruct_bf16basis_f32 if bf else _hip.lib().lr_pca_reconstruct_f32
+    with _timed("pca_reconstruct" + ("_bf16basis" if bf else ""), bytes=(2 if bf else 4) * L * M + 4 * (M + B * M), samples=B):
+        _hip.check(fn(coefs.data_ptr(), basis_LxM.data_ptr(), mean.data_ptr(), out.data_ptr(), B, L, M,
+                      basis_LxM.stride(0), M, _stream()), "lr_pca_reconstruct_f32")
     return out
 
 

@@ -53,10 +53,11 @@ def pca_bwd_coef(gdisp, basis_LxM, nblk=None):
         nblk = max(1, min(512, M // 4096))
     partial = torch.empty((nblk, B, L), dtype=torch.float32, device=gdisp.device)
     gcoefs = torch.empty((B, L), dtype=torch.float32, device=gdisp.device)
-    with _timed("pca_bwd_coef", bytes=4 * (L * M + ((L + 7) // 8) * B * M)):
-        _hip.check(_hip.lib().lr_pca_bwd_coef_f32(g2.data_ptr(), basis_LxM.data_ptr(), partial.data_ptr(),
-                                                  gcoefs.data_ptr(), B, L, M, basis_LxM.stride(0), M, nblk, _stream()),
-                   "lr_pca_bwd_coef_f32")
+    bf = basis_LxM.dtype == torch.bfloat16
+    fn = _hip.lib().lr_pca_bwd_coef_bf16basis_f32 if bf else _hip.lib().lr_pca_bwd_coef_f32
+    with _timed("pca_bwd_coef" + ("_bf16basis" if bf else ""), bytes=(2 if bf else 4) * L * M + 4 * ((L + 7) // 8) * B * M):
+        _hip.check(fn(g2.data_ptr(), basis_LxM.data_ptr(), partial.data_ptr(), gcoefs.data_ptr(), B, L, M,
+                      basis_LxM.stride(0), M, nblk, _stream()), "lr_pca_bwd_coef_f32")
     return gcoefs
 
 

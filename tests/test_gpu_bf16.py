@@ -215,3 +215,31 @@ def test_bf16_gradient_block_backward(dev):
         _close_bf16(gx.float().permute(0, 4, 1, 2, 3).cpu().numpy(), want_gx.numpy(), "gx " + tag)
         np.testing.assert_allclose(gw.cpu().numpy(), wr.grad.numpy(), rtol=2e-4, atol=2e-4, err_msg="gw " + tag)
         np.testing.assert_allclose(gb.cpu().numpy(), b0.grad.numpy(), rtol=2e-4, atol=2e-4, err_msg="gb " + tag)
+
+
+def test_pca_with_bf16_stored_basis(dev):
+    """pca_dtype="bf16": the basis is rounded to bf16 ONCE (storage); reconstruction and its coefficient gradient are
+    then the fp32 ops on those values — identical to the fp32 kernels fed the rounded basis."""
+    from liftreg_amd import ops, ops_bwd
+    from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+    rs = np.random.RandomState(51)
+    for B, Lat, M in ((8, 56, 3 * 20 ** 3), (3, 5, 4096), (1, 9, 3 * 8 * 8 * 12)):
+        basis = torch.from_numpy(rs.normal(0, 0.02, (Lat, M)).astype(np.float32)).to(dev)
+        mean = torch.from_numpy(rs.normal(0, 0.01, M).astype(np.float32)).to(dev)
+        coefs = torch.from_numpy(rs.normal(0, 1, (B, Lat)).astype(np.float32)).to(dev)
+        g = torch.from_numpy(rs.normal(0, 1, (B, M)).astype(np.float32)).to(dev)
+        bq = basis.to(torch.bfloat16)
+        assert torch.equal(ops.pca_reconstruct(coefs, bq, mean), ops.pca_reconstruct(coefs, bq.float(), mean))
+        assert torch.equal(ops_bwd.pca_bwd_coef(g, bq), ops_bwd.pca_bwd_coef(g, bq.float()))
+        want = coefs.double().cpu() @ bq.double().cpu() + mean.double().cpu()
+        np.testing.assert_allclose(ops.pca_reconstruct(coefs, bq, mean).cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-6)
+    net = model([32, 32, 32], {"drr_feature_num": 2, "latent_dim": 8, "pca_path": "synthetic:5", "pca_dtype": "bf16"}).to(dev).eval()
+    net._ensure_pca(dev)
+    assert net.pca_vectors_LxM.dtype == torch.bfloat16 and net.pca_mean.dtype == torch.float32
+    poses = ro.scan_poses(30, 2, 32).astype(np.float32)
+    inp = {"source": torch.rand((1, 1, 32, 32, 32), device=dev) * 2 - 1, "target": torch.rand((1, 1, 32, 32, 32), device=dev),
+           "target_proj": torch.rand((1, 2, 32, 32), device=dev), "target_poses": torch.from_numpy(poses[None].copy())}
+    with torch.no_grad():
+        out = net(inp)
+    ref = out["pca_coefs"].double().cpu() @ net.pca_vectors_LxM.double().cpu()
+    np.testing.assert_allclose(out["params"].reshape(1, -1).cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-7)

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--config", default="c3")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pca-dtype", default="fp32", choices=("fp32", "bf16"),
+                    help="bf16: the PCA basis stored as bfloat16 in HBM (opt-in, not the headline configuration)")
     ap.add_argument("--conv-dtype", default="fp32", choices=("fp32", "bf16"),
                     help="bf16: bf16 forward of the conv blocks, fp32 gradients of that arithmetic (config C5)")
     ap.add_argument("--grad-dtype", default="fp32", choices=("fp32", "bf16"),
@@ -40,7 +42,8 @@ def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(2021)
     net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:2021",
-                            "conv_dtype": a.conv_dtype, "grad_dtype": a.grad_dtype}).to(dev).train()
+                            "conv_dtype": a.conv_dtype, "grad_dtype": a.grad_dtype,
+                            "pca_dtype": a.pca_dtype}).to(dev).train()
     crit = SubspaceLoss({"initial_reg_factor": 0.01, "min_reg_factor": 0.01, "reg_factor_decay_from": 2})
     opt = torch.optim.Adam(net.parameters(), lr=1e-4, eps=1e-5)
     g = torch.Generator(device=dev)
@@ -84,7 +87,7 @@ def main():
             row["GB/s"] = round(info["bytes"] / avg / 1e6, 0)
         rows.append(row)
     rows.sort(key=lambda r: -r["ms"] * r["launches"])
-    print(json.dumps({"config": a.config, "conv_dtype": a.conv_dtype, "grad_dtype": a.grad_dtype, "ms_per_train_step": round(ms, 3), "samples_per_s": round(B / ms * 1e3, 1),
+    print(json.dumps({"config": a.config, "conv_dtype": a.conv_dtype, "grad_dtype": a.grad_dtype, "pca_dtype": a.pca_dtype, "ms_per_train_step": round(ms, 3), "samples_per_s": round(B / ms * 1e3, 1),
                       "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
     for r in rows:
         print(json.dumps(r))
