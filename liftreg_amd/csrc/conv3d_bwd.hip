@@ -900,6 +900,162 @@ __global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_ke
     }
 }
 
+// ------------------------------------------------------------------- wgrad of the first block on the bf16 MFMA
+// (bf16-gradient variant).  K = 32 voxels of a row per v_mfma_f32_16x16x32_bf16.  A = gpre^T: transposing LDS reads of
+// the [voxel][16 co] image, as in conv3d_wgrad_cl_bf16_kernel.  B = X: a lane's column is one (channel, tap) and its
+// 8 k-values are 8 consecutive voxels of a window row starting at 32ks + 8kq + tx + 3 — a 16-byte read only if that
+// start is a multiple of 8 elements, so the bf16 window is kept in THREE copies shifted by tx (copy_tx[j] =
+// window[j + tx + 3]); the lane picks the copy of its tap and every B operand is one aligned ds_read_b128.
+// x is rounded to bf16 while staged — the rounding lr_conv3d_first_bf16 applied in the forward.
+template <int NTL>
+__global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_bf16_kernel(const float* __restrict__ xin,
+                                                                                           const u16* __restrict__ gpre,
+                                                                                           float* __restrict__ partial,
+                                                                                           WgDims d, int nbricks) {
+  constexpr int CMAX = NTL * 16 / 27;          // 3 | 12 input channels
+  constexpr int ROWS = CMAX * 18;              // window rows (channel, plane, row)
+  constexpr int CPY = ROWS * 64;               // elements of one shifted copy (64 per row)
+  constexpr int XF4 = ROWS * 18;               // float4 chunks of the fp32 window (72 columns)
+  constexpr int XIT = (XF4 + 255) / 256;
+  constexpr int ONES = 3 * CPY, GOFF = ONES + 64;  // element offsets: copies | ones row | gradient rows
+  __shared__ __attribute__((aligned(16))) u16 lds[GOFF + 4 * 64 * 16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, kq = lane >> 4;
+  const int64_t V = (int64_t)d.D * d.W * d.H;
+  const int nH = (d.H + 63) / 64, nW = (d.W + 3) / 4;
+  if (tid < 64) lds[ONES + tid] = 0x3f80;  // bf16 1.0
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) u16*)lds;
+
+  unsigned xrel[XIT];
+  int xdec[XIT];  // rz | ry<<2 | cc<<5 | f4<<9 | used<<14
+#pragma unroll
+  for (int it = 0; it < XIT; ++it) {
+    const int q = it * 256 + tid;
+    const bool used = q < XF4;
+    const int row = used ? q / 18 : 0, f4 = q % 18;
+    const int cc = row / 18, rz = (row / 6) % 3, ry = row % 6;
+    xdec[it] = rz | (ry << 2) | (cc << 5) | (f4 << 9) | ((used && cc < d.Cin) ? 1 << 14 : 0);
+    xrel[it] = (unsigned)(((int64_t)cc * V + ((int64_t)rz * d.W + ry) * d.H + f4 * 4) * 4);
+  }
+  // B operand: per N-tile the lane's byte address of (copy tx)[ci][tz][ty + wave][8kq]
+  unsigned bbase[NTL];
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) {
+    int c = j * 16 + col;
+    const bool ones = c == 27 * d.Cin;  // the first spare column multiplies by ones: sum of gpre = gb
+    if (c >= 27 * d.Cin) c = 0;
+    const int ci = c / 27, tap = c % 27;
+    const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+    bbase[j] = lds0 + 2u * (unsigned)(ones ? ONES + 8 * kq : tx * CPY + (ci * 18 + tz * 6 + ty + wave) * 64 + 8 * kq);
+  }
+  // A operand: transposing reads of this wave's gradient row image [64 voxels][16 co]
+  const unsigned aoff = lds0 + 2u * (unsigned)(GOFF + wave * 64 * 16) + (unsigned)((kq * 8 + ((lane >> 2) & 3)) * 32 + (lane & 3) * 8);
+  f32x4 acc[NTL];
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 xst[XIT];
+  u32x4_t gst[2];
+  auto prefetch = [&](int brick) {
+    const bool live = brick < nbricks;
+    int r = live ? brick : 0;
+    const int hq = r % nH; r /= nH;
+    const int wq = r % nW; r /= nW;
+    const int z = r % d.D;
+    const int b = r / d.D;
+    const int h0 = hq * 64, y0 = wq * 4;
+    const float* xb = xin + (int64_t)b * d.Cin * V;
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), (short)0, 0x7fffffff, 0x00020000);
+    const unsigned org = (unsigned)(((((int64_t)(z - 1) * d.W + (y0 - 1)) * d.H) + h0 - 4) * 4);
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+      const int zi = z - 1 + (xdec[it] & 3), yi = y0 - 1 + ((xdec[it] >> 2) & 7), xi = h0 - 4 + ((xdec[it] >> 9) & 31) * 4;
+      const bool ok = live && (xdec[it] >> 14) && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W && xi >= 0 && xi < d.H;
+      xst[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? org + xrel[it] : OOR, 0, 0));
+    }
+    // gradient rows: 4 rows x 64 voxels x 16 co bf16 = 512 chunks of 16 bytes, 2 per thread
+    const u16* gb = gpre + ((((int64_t)b * d.D + z) * d.W + y0) * d.H + h0) * 16;
+    const __amdgpu_buffer_rsrc_t rg =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(gb), (short)0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int ch = k * 256 + tid, rr = ch >> 7, v = (ch >> 1) & 63, half = ch & 1;
+      const bool ok = live && y0 + rr < d.W && h0 + v < d.H;
+      gst[k] = __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? (unsigned)(((rr * d.H + v) * 16 + half * 8) * 2) : OOR, 0, 0);
+    }
+  };
+
+  int brick = blockIdx.x;
+  prefetch(brick);
+  for (; brick < nbricks; brick += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+      const int q = it * 256 + tid;
+      if (q < XF4) {
+        const int row = q / 18, f4 = q - row * 18;
+        // copy_t[j] = window[j + t + 3]: this chunk (window 4f4..4f4+3) lands at j0 = 4f4 - t - 3 of copy t.
+        const unsigned h0 = __builtin_bit_cast(u16, (__bf16)xst[it].x), h1 = __builtin_bit_cast(u16, (__bf16)xst[it].y);
+        const unsigned h2 = __builtin_bit_cast(u16, (__bf16)xst[it].z), h3 = __builtin_bit_cast(u16, (__bf16)xst[it].w);
+        u16* r0 = lds + row * 64;
+        // t = 1: j0 = 4(f4-1), an aligned 8-byte store, wholly inside or outside the 64 columns
+        if (f4 >= 1 && f4 <= 16) *reinterpret_cast<uint2*>(r0 + CPY + 4 * (f4 - 1)) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+        // t = 0: j0 = 4(f4-1) + 1 -> 2 + 4 + 2 bytes; t = 2: j0 = 4(f4-2) + 3 -> 2 + 4 + 2 bytes (the 4-byte piece is aligned)
+        {
+          const int j0 = 4 * (f4 - 1) + 1;
+          if (j0 >= 0 && j0 < 64) r0[j0] = (u16)h0;
+          if (j0 + 1 >= 0 && j0 + 2 < 64) *reinterpret_cast<unsigned*>(r0 + j0 + 1) = h1 | (h2 << 16);
+          if (j0 + 3 >= 0 && j0 + 3 < 64) r0[j0 + 3] = (u16)h3;
+        }
+        {
+          u16* r2 = r0 + 2 * CPY;
+          const int j0 = 4 * (f4 - 2) + 3;
+          if (j0 >= 0 && j0 < 64) r2[j0] = (u16)h0;
+          if (j0 + 1 >= 0 && j0 + 2 < 64) *reinterpret_cast<unsigned*>(r2 + j0 + 1) = h1 | (h2 << 16);
+          if (j0 + 3 >= 0 && j0 + 3 < 64) r2[j0 + 3] = (u16)h3;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int ch = k * 256 + tid, rr = ch >> 7, v = (ch >> 1) & 63, half = ch & 1;
+      *reinterpret_cast<u32x4_t*>(lds + GOFF + (rr * 64 + v) * 16 + half * 8) = gst[k];
+    }
+    __syncthreads();
+    prefetch(brick + (int)gridDim.x);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      unsigned long long ar[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ar[h]) : "v"(aoff), "n"(ks * 32 * 32 + h * 128) : "memory");
+      u32x4_t bv[NTL];
+#pragma unroll
+      for (int j = 0; j < NTL; ++j)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bv[j]) : "v"(bbase[j]), "n"(ks * 64) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("" : "+v"(ar[0]), "+v"(ar[1]));
+      const u32x4_t av = {(unsigned)ar[0], (unsigned)(ar[0] >> 32), (unsigned)ar[1], (unsigned)(ar[1] >> 32)};
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) {
+        asm volatile("" : "+v"(bv[j]));
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, bv[j]),
+                                                         acc[j], 0, 0, 0);
+      }
+    }
+  }
+  const int ncols = d.ntiles * 16;
+  const int64_t pb = (int64_t)blockIdx.x * 4 + wave;
+#pragma unroll
+  for (int j = 0; j < NTL; ++j)
+    if (j < d.ntiles) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) partial[(pb * 16 + kq * 4 + r) * ncols + j * 16 + col] = acc[j][r];
+    }
+}
+
 // partial[k][co][n] summed over the nblk partials in double (fixed order), column n -> (ci, tap) of gw.
 // Block = 64 columns x 16 slices of k: consecutive threads read consecutive floats, the 16 slice sums meet in LDS.
 __global__ __launch_bounds__(1024) void wgrad_finish_kernel(const float* __restrict__ partial, float* __restrict__ gw,
@@ -1086,7 +1242,11 @@ static int wgrad_impl(const float* x, int x_layout, const float* gpre, int gbf, 
     const int64_t nbricks = (int64_t)B * D * ((W + 3) / 4) * ((H + 63) / 64);
     if (nbricks < 0x7fffffffLL) {
       const unsigned grid = (unsigned)(nbricks < nblk ? nbricks : nblk);
-      if (Cin <= 3) hipLaunchKernelGGL(conv3d_wgrad_planar_kernel<6>, dim3(grid), dim3(256), 0, st, x, gpre, partial, d, (int)nbricks, (int)xround, gbf);
+      if (gbf && xround && Cin <= 3)
+        hipLaunchKernelGGL(conv3d_wgrad_planar_bf16_kernel<6>, dim3(grid), dim3(256), 0, st, x, reinterpret_cast<const u16*>(gpre), partial, d, (int)nbricks);
+      else if (gbf && xround)
+        hipLaunchKernelGGL(conv3d_wgrad_planar_bf16_kernel<21>, dim3(grid), dim3(256), 0, st, x, reinterpret_cast<const u16*>(gpre), partial, d, (int)nbricks);
+      else if (Cin <= 3) hipLaunchKernelGGL(conv3d_wgrad_planar_kernel<6>, dim3(grid), dim3(256), 0, st, x, gpre, partial, d, (int)nbricks, (int)xround, gbf);
       else hipLaunchKernelGGL(conv3d_wgrad_planar_kernel<21>, dim3(grid), dim3(256), 0, st, x, gpre, partial, d, (int)nbricks, (int)xround, gbf);
       nparts = (int)grid * 4;
     }

@@ -14,6 +14,7 @@ from . import _hip
 
 LAYOUT_NCDHW, LAYOUT_NDHWC, LAYOUT_NDHWC_HPS = _hip.LAYOUT_NCDHW, _hip.LAYOUT_NDHWC, _hip.LAYOUT_NDHWC_HPS
 LAYOUT_BF16_NDHWC, LAYOUT_BF16_NDHWC_HPS = _hip.LAYOUT_BF16_NDHWC, _hip.LAYOUT_BF16_NDHWC_HPS
+LAYOUT_NCDHW_RBF16 = _hip.LAYOUT_NCDHW_RBF16
 MFMA_BF16_PEAK_TF = 2516.6   # dense bf16 MFMA peak of MI355X (TFLOP/s) — roofline denominator of the bf16 blocks
 
 

@@ -243,3 +243,23 @@ def test_pca_with_bf16_stored_basis(dev):
         out = net(inp)
     ref = out["pca_coefs"].double().cpu() @ net.pca_vectors_LxM.double().cpu()
     np.testing.assert_allclose(out["params"].reshape(1, -1).cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_bf16_gradient_first_block_weight_gradient(dev):
+    """Block 0 in the bf16-gradient variant: fp32 planar input (rounded to bf16 like the forward did), bf16 gradient;
+    3 input channels, 12 (C4) and a ragged 5; rows longer and shorter than one 64-voxel brick."""
+    from liftreg_amd import ops, ops_bwd
+    rs = np.random.RandomState(43)
+    for cin, shape, B in ((3, (6, 7, 72), 2), (12, (4, 5, 8), 1), (5, (3, 9, 132), 1), (3, (9, 4, 64), 1)):
+        cout = 16
+        x = torch.from_numpy(rs.uniform(-1, 1, (B, cin) + shape).astype(np.float32))
+        w = torch.from_numpy((rs.normal(0, 1, (cout, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32))
+        g = torch.from_numpy(rs.normal(0, 1, (B, cout) + shape).astype(np.float32)).to(torch.bfloat16)
+        wr, b0 = w.clone().requires_grad_(True), torch.zeros(cout, requires_grad=True)
+        torch.nn.functional.conv3d(ro._bf16(x), ro._bf16(wr), b0, stride=1, padding=1).backward(g.float())
+        gd = g.permute(0, 2, 3, 4, 1).contiguous().to(dev)
+        gx, gw, gb = ops_bwd.conv3d_bwd_bf16g(x.to(dev), ops.LAYOUT_NCDHW_RBF16, w.to(dev), gd, 1, nblk=8)
+        assert gx is None
+        tag = str((cin, shape))
+        np.testing.assert_allclose(gw.cpu().numpy(), wr.grad.numpy(), rtol=2e-4, atol=3e-4, err_msg="gw " + tag)
+        np.testing.assert_allclose(gb.cpu().numpy(), b0.grad.numpy(), rtol=2e-4, atol=3e-4, err_msg="gb " + tag)
