@@ -1,8 +1,12 @@
 // conv3d_bf16.hip — the bf16 variant of the encoder's stride-2 blocks (BASELINE configs C4/C5: "bf16 convs").
 // Activations are stored as bf16 channels-last (half the HBM bytes of the fp32 path), weights are rounded to
 // bf16 once, products are exact and accumulate in fp32 on v_mfma_f32_16x16x32_bf16 (16x the fp32 MFMA rate), so
-// the blocks that are matrix-pipe-bound in fp32 become HBM/L2-bound here.  The first block keeps its fp32 input
-// (CT volume + backprojection) and fp32 MFMA and only rounds its OUTPUT to bf16 (conv3d.hip, out_layout 3|4).
+// the blocks that are matrix-pipe-bound in fp32 become HBM/L2-bound here.
+//
+//   conv3d_cl_bf16_kernel     blocks 1..5 (bf16 channels-last in, bf16 channels-last or fp32 NCDHW out)
+//   conv0_bf16_kernel         the first block: fp32 NCDHW input rounded to bf16 while it is staged
+//   conv3d_dgrad_bf16_kernel  data gradient with bf16 gradients (the bf16-gradient training variant)
+//   pack / cast helpers
 //
 //   K order of one MFMA (32 k-values): Cin = 32: one tap, lane group kq owns channels 8kq..8kq+7;
 //                                      Cin = 16: two taps, groups 0,1 the first tap, groups 2,3 the second.

@@ -1,11 +1,20 @@
 // conv3d_bwd.hip — backward of convBlock (Conv3d k3 p1 + LeakyReLU) for the training step.
 // The reference obtains these from ATen/cuDNN autograd (RegistrationNet.py:401); here:
 //
-//   lr_lrelu_bwd_f32      gpre = gy * (y > 0 ? 1 : slope)  (+ bias gradient), any activation layout -> NDHWC
-//   lr_conv3d_dgrad_f32   data gradient of a stride-2 block (blocks 1..5): parity-class gather on the fp32
-//                         MFMA with the forward kernel's structure (bounds-checked buffer loads, pipelined)
-//   lr_conv3d_wgrad_f32   weight gradient of any block as an MFMA reduction over voxels
-//                         (D[cout][(tap,cin)] += gpre^T · X), persistent blocks + fixed-order reduce
+//   lr_lrelu_bwd_f32      gpre = gy * (y > 0 ? 1 : slope), any activation layout -> plain NDHWC (the last block only:
+//                         the other blocks get their mask from the consumer's data-gradient epilogue)
+//   lr_conv3d_dgrad_f32   data gradient of a stride-2 block (blocks 1..5), one parity class of gx at a time so no
+//                         MFMA multiplies a structural zero; conv3d_dgrad_lds_kernel stages the gpre tile in LDS
+//                         (Cg in {16,32}), conv3d_dgrad_kernel loads it directly (any Cg % 4 == 0); optional fused
+//                         LeakyReLU mask of the producer block (fp32 or bf16-stored activation)
+//   lr_conv3d_wgrad_f32   weight (+ bias) gradient: D[cout][(tap,cin)] += gpre^T · X over voxels on the MFMA,
+//                         persistent blocks, per-block partials, fixed-order double reduce (wgrad_finish_kernel):
+//                           conv3d_wgrad_cl_kernel        channels-last x, stride 2 (fp32 or bf16-stored x / gpre)
+//                           conv3d_wgrad_planar_kernel    the first block (planar x, stride 1)
+//                           conv3d_wgrad_cl_bf16_kernel   } bf16-gradient variant: v_mfma_f32_16x16x32_bf16 with
+//                           conv3d_wgrad_planar_bf16_kernel } transposing LDS reads (ds_read_b64_tr_b16)
+//                           conv3d_wgrad_kernel           generic fallback (odd shapes, unaligned rows)
+//   (the bf16-gradient data gradient, lr_conv3d_dgrad_bf16, lives in conv3d_bf16.hip)
 //
 // Replaces: autograd of src/liftreg/layers/layers.py:365-369 as wired at …Backproj.py:29-33,95-100.
 #include "lr_common.h"

@@ -1,4 +1,4 @@
-"""Tensor-level front-end of the backward kernels (liftreg_amd/csrc/backward.hip, conv3d_bwd.hip).
+"""Tensor-level front-end of the backward kernels (liftreg_amd/csrc/backward.hip, conv3d_bwd.hip, conv3d_bf16.hip, reg.hip).
 
 Same rules as liftreg_amd.ops: GPU tensors only, outputs allocated here, launches on torch's current stream,
 no CPU/PyTorch fallback.
