@@ -176,3 +176,26 @@ def test_c5_conv_backward_at_384(dev):
     np.testing.assert_allclose(gw.cpu().numpy(), want_gw.cpu().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(gb.cpu().numpy(), want_gb.cpu().numpy(), rtol=1e-6, atol=1e-6)
     assert abs(float(gx.abs().sum(dtype=torch.float64)) - abs_sum) < 1e-3 * abs_sum      # and nothing anywhere else
+
+
+def test_reference_native_size_160(dev):
+    """The reference's own configuration (cur_task_setting.json: 160³ volumes, drr_feature_num 4, latent_dim 56;
+    the hard-coded Linear(4000, 800) of …Backproj.py:36): whole forward + configured NCC against the CPU oracle.
+    160 → 80 → 40 → 20 → 10 → 5: both channels-last layouts (parity-split and plain) are on the path."""
+    from liftreg_amd.layers.losses import NCCLoss
+    n, P, L, B = 160, 4, 56, 1
+    net = _net(n, P, L, dev, 33)
+    assert net.encoders[6][1].fc.in_features == 4000
+    inp = _inputs(n, P, 240, B, dev, 33)                       # 1.5x receptor, the reference's default detector size
+    with torch.no_grad():
+        out = net(inp)
+        loss = NCCLoss()(out["warped"], out["target"])
+        ref = ro.model_forward({k: v.cpu() for k, v in net.state_dict().items()}, {k: v.cpu() for k, v in inp.items()},
+                               net.pca_vectors_LxM.cpu(), net.pca_mean.cpu())
+    np.testing.assert_allclose(out["pca_coefs"].cpu().numpy(), ref["pca_coefs"].numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out["params"].cpu().numpy(), ref["params"].numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(out["phi"].cpu().numpy(), ref["phi"].numpy(), rtol=1e-4, atol=1e-6)
+    # white-noise moving image: one grey level per voxel of slope, so a 1e-6 difference in phi (≈1e-4 voxel) shows up
+    # as up to a few 1e-5 in a handful of the 4 M warped values
+    np.testing.assert_allclose(out["warped"].cpu().numpy(), ref["warped"].numpy(), rtol=1e-4, atol=6e-5)
+    assert abs(float(loss) - float(ro.ncc_loss(ref["warped"], ref["target"]))) < 1e-5
