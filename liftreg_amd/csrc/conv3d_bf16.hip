@@ -190,7 +190,8 @@ __device__ __forceinline__ unsigned pack2_bf16(float a, float b) { return (unsig
 
 // SINGLE (Cin <= 3, the model's case): one pass, so a tile's accumulator lives only for its 4 MFMAs and is stored
 // at once — a quarter of the registers, twice the resident blocks, stores spread over the sweep.
-template <int NT, bool SINGLE>
+// HPSOUT: output rows parity-split (compile time: the store address is a per-lane base + a constant per tile).
+template <int NT, bool SINGLE, bool HPSOUT>
 __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv0_bf16_kernel(const float* __restrict__ in, const u32x4* __restrict__ wp,
                                                             const float* __restrict__ bias, void* __restrict__ out,
                                                             ConvDimsH d, int out_layout, float slope, int vec4) {
@@ -234,6 +235,22 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv0_bf16_kernel(const
     for (int t = 0; t < (SINGLE ? 1 : PW * 4); ++t) acc[t][nt] = bv;
   }
   const int dz = z0 + wave;
+  // store of tile (r, t): bf16 rows of Cout channels; this lane's voxel is x0 + 16t + col.  x0 is a multiple of 64,
+  // so in a parity-split row the lane sits at (col&1)*(H/2) + x0/2 + col/2 and a tile advances 8 positions.
+  const int hp_lane = HPSOUT ? (col & 1) * (d.H >> 1) + (x0 >> 1) + (col >> 1) : x0 + col;
+  u16* const out_lane = reinterpret_cast<u16*>(out) + ((((int64_t)b * d.D + dz) * d.W + y0) * d.H + hp_lane) * d.Cout + kq * 4;
+  const int64_t row_el = (int64_t)d.H * d.Cout;
+  auto store_tile = [&](const f32x4 (&a)[NT], int r, int t) {
+    if (dz >= d.D || y0 + r >= d.W || x0 + t * 16 + col >= d.H) return;
+    u16* o = out_lane + r * row_el + t * (HPSOUT ? 8 : 16) * d.Cout;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = lrelu(a[nt][q], slope);
+      *reinterpret_cast<uint2*>(o + nt * 16) = make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+    }
+  };
   const int npass = (d.Cin + 2) / 3;
   for (int pass = 0; pass < npass; ++pass) {
     const int c0 = pass * 3;
@@ -322,21 +339,14 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv0_bf16_kernel(const
             acc[ti][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[m][nt]),
                                                                   __builtin_bit_cast(bf16x8, bv), acc[ti][nt], 0, 0, 0);
         }
-        if (SINGLE && dz < d.D) {
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            store_tile_any(acc[0][nt], out, d, b, dz, y0 + r, x0 + t * 16 + col, nt, lane, out_layout, slope);
-        }
+        if (SINGLE) store_tile(acc[0], r, t);
       }
   }
-  if (!SINGLE && dz < d.D) {
+  if (!SINGLE) {
 #pragma unroll
     for (int r = 0; r < PW; ++r)
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          store_tile_any(acc[r * 4 + t][nt], out, d, b, dz, y0 + r, x0 + t * 16 + col, nt, lane, out_layout, slope);
+      for (int t = 0; t < 4; ++t) store_tile(acc[r * 4 + t], r, t);
   }
 }
 
@@ -562,8 +572,13 @@ extern "C" int lr_conv3d_first_bf16(const float* in, const void* packed_w, const
   const dim3 grid((unsigned)nblk), block(256);
   hipStream_t st = lr_stream(stream);
   const u32x4* wt = reinterpret_cast<const u32x4*>(packed_w);
-#define LR_C0(NTV, SG) \
-  hipLaunchKernelGGL((conv0_bf16_kernel<NTV, SG>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope, vec4)
+#define LR_C0(NTV, SG)                                                                                                   \
+  do {                                                                                                                    \
+    if (out_layout == LR_LAYOUT_BF16_NDHWC_HPS)                                                                           \
+      hipLaunchKernelGGL((conv0_bf16_kernel<NTV, SG, true>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope, vec4);  \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((conv0_bf16_kernel<NTV, SG, false>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope, vec4); \
+  } while (0)
   if (Cout == 16) { if (Cin <= 3) LR_C0(1, true); else LR_C0(1, false); }
   else            { if (Cin <= 3) LR_C0(2, true); else LR_C0(2, false); }
 #undef LR_C0
