@@ -67,9 +67,12 @@ __device__ __forceinline__ void block_coords(const ConvDims& d, int& b, int& dq,
 
 // One 16-voxel x 16-cout accumulator tile -> memory.  Lane l holds couts
 // nt*16 + (l>>4)*4 + {0..3} of voxel (l&15).
+// OUTL >= 0 fixes the layout at compile time (no branch per store); -1 = the runtime value.
+template <int OUTL = -1>
 __device__ __forceinline__ void store_tile(const f32x4& acc, float* __restrict__ out,
                                            const ConvDims& d, int b, int dz, int wo, int ho, int nt,
-                                           int lane, int out_layout, float slope) {
+                                           int lane, int out_layout_rt, float slope) {
+  const int out_layout = OUTL >= 0 ? OUTL : out_layout_rt;
   if (wo >= d.Wo || ho >= d.Ho) return;
   const int c0 = nt * 16 + (lane >> 4) * 4;
   f32x4 v;
@@ -146,7 +149,7 @@ struct PlanarGeom {
 // PAIR of tiles: 2 live accumulators instead of 16, and each pair is stored the moment its CC*7 k-steps
 // are done, so the 64 KB a block writes per brick drains under the MFMAs of the following pairs instead of
 // stalling the wave in one 16-store burst (stamped build: that burst cost as much as the whole sweep).
-template <int NT, int S, int CC, bool SINGLE>
+template <int NT, int S, int CC, bool SINGLE, int OUTL = -1>
 __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(const float* __restrict__ in,
                                                             const float* __restrict__ wp,
                                                             const float* __restrict__ bias,
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
               const int m = 2 * p + h;
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt)
-                store_tile(pacc[h][nt], out, d, b, dz, wq * PW + m / 4, hq * PH + (m % 4) * 16 + col, nt, lane,
+                store_tile<OUTL>(pacc[h][nt], out, d, b, dz, wq * PW + m / 4, hq * PH + (m % 4) * 16 + col, nt, lane,
                            out_layout, slope);
             }
           }
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
           for (int x = 0; x < 4; ++x)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              store_tile(acc[y * 4 + x][nt], out, d, b, dz, wq * PW + y, hq * PH + x * 16 + col, nt, lane,
+              store_tile<OUTL>(acc[y * 4 + x][nt], out, d, b, dz, wq * PW + y, hq * PH + x * 16 + col, nt, lane,
                          out_layout, slope);
       }
     }
@@ -682,7 +685,13 @@ extern "C" int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, co
 #define LR_PL(NTV, SV, CCV, SGL, LDSV, V4)                                                                   \
   hipLaunchKernelGGL((conv3d_planar_kernel<NTV, SV, CCV, SGL>), grid, block, LDSV, st, in, packed_w, bias, out, d, \
                      out_layout, negative_slope, V4, ni, npass, dbg)
-    if (stride == 1) {
+    if (stride == 1 && NT == 1 && single && out_layout == LR_LAYOUT_NDHWC_HPS) {        // the model's first block
+      hipLaunchKernelGGL((conv3d_planar_kernel<1, 1, 3, true, LR_LAYOUT_NDHWC_HPS>), grid, block, lds1, st, in, packed_w, bias,
+                         out, d, out_layout, negative_slope, vec4, ni, npass, dbg);
+    } else if (stride == 1 && NT == 1 && single && out_layout == LR_LAYOUT_NDHWC) {
+      hipLaunchKernelGGL((conv3d_planar_kernel<1, 1, 3, true, LR_LAYOUT_NDHWC>), grid, block, lds1, st, in, packed_w, bias,
+                         out, d, out_layout, negative_slope, vec4, ni, npass, dbg);
+    } else if (stride == 1) {
       if (NT == 1 && single) LR_PL(1, 1, 3, true, lds1, vec4);
       else if (NT == 1) LR_PL(1, 1, 3, false, lds1, vec4);
       else if (single) LR_PL(2, 1, 3, true, lds1, vec4);
