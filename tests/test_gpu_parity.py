@@ -135,7 +135,10 @@ def test_backproject_into_concat_buffer_and_ragged(ops, dev):
     rs = np.random.RandomState(9)
     # (last case: a detector much smaller than the volume → whole tiles whose shadows miss it)
     for (D, W, H), (Pw, Ph), P, B in (((20, 18, 24), (22, 26), 2, 3), ((9, 7, 11), (13, 5), 4, 2), ((16, 16, 16), (16, 16), 11, 9),
-                                      ((40, 16, 24), (6, 5), 2, 2)):
+                                      ((40, 16, 24), (6, 5), 2, 2),
+                                      # rows longer than 1024 voxels and a detector too wide for the LDS tile: the
+                                      # direct-gather kernel instead of the tiled one
+                                      ((2, 3, 1100), (8, 10), 1, 1), ((4, 4, 8), (6, 1000), 2, 1), ((3, 2, 1028), (5, 7), 1, 2)):
         proj = rs.uniform(-1, 1, (B, P, Pw, Ph)).astype(np.float32)
         poses = ro.scan_poses(30, P, W).astype(np.float32)
         want = co.backproject(proj, poses, (D, W, H))
