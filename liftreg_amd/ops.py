@@ -212,8 +212,18 @@ def conv3d_pack_weights(weight, in_layout):
     return packed
 
 
+def _conv_out(out, shape, dtype, device):
+    """The output tensor of a conv wrapper: freshly allocated, or the caller's contiguous `out` (e.g. a plane range
+    of a larger halo-padded buffer, see parallel.SlabShardedRegistration)."""
+    if out is None:
+        return torch.empty(shape, dtype=dtype, device=device)
+    if tuple(out.shape) != tuple(shape) or out.dtype != dtype or not out.is_contiguous() or not out.is_cuda:
+        raise ValueError(f"out must be a contiguous {dtype} GPU tensor of shape {tuple(shape)}")
+    return out
+
+
 def conv3d_k3_lrelu(x, weight, bias, stride, *, in_layout=LAYOUT_NCDHW, out_layout=LAYOUT_NCDHW,
-                    negative_slope=0.2, packed=None):
+                    negative_slope=0.2, packed=None, out=None):
     """LeakyReLU(Conv3d(k3,p1,stride)(x)+b).  x is (B,Cin,D,W,H) for NCDHW, (B,D,W,H,Cin) for NDHWC.
     LAYOUT_NDHWC_HPS is NDHWC with every H row parity-split (even voxels, then odd): the private layout
     between a block and a following stride-2 block (see `hps_to_ndhwc`).
@@ -237,7 +247,7 @@ def conv3d_k3_lrelu(x, weight, bias, stride, *, in_layout=LAYOUT_NCDHW, out_layo
     Do, Wo, Ho = o(D), o(W), o(H)
     shape = (B, Cout, Do, Wo, Ho) if out_layout == LAYOUT_NCDHW else (B, Do, Wo, Ho, Cout)
     bf16_out = out_layout in (_hip.LAYOUT_BF16_NDHWC, _hip.LAYOUT_BF16_NDHWC_HPS)   # fp32 compute, bf16 storage
-    y = torch.empty(shape, dtype=torch.bfloat16 if bf16_out else torch.float32, device=x.device)
+    y = _conv_out(out, shape, torch.bfloat16 if bf16_out else torch.float32, x.device)
     flops = 2.0 * 27 * Cin * Cout * B * Do * Wo * Ho
     with _timed(f"conv3d_c{Cin}x{Cout}_s{stride}_{D}" + ("_bf16out" if bf16_out else ""), flops=flops,
                 bytes=4 * x.numel() + y.numel() * y.element_size(), samples=B):
@@ -260,7 +270,7 @@ def conv3d_pack_weights_bf16(weight):
     return packed
 
 
-def conv3d_k3_lrelu_bf16(x, weight, bias, stride, *, in_layout, out_layout, negative_slope=0.2, packed=None):
+def conv3d_k3_lrelu_bf16(x, weight, bias, stride, *, in_layout, out_layout, negative_slope=0.2, packed=None, out=None):
     """bf16-storage variant of conv3d_k3_lrelu for the stride-2 blocks (C4/C5 "bf16 convs"): x is a bfloat16
     (B,D,W,H,Cin) tensor in LAYOUT_BF16_NDHWC[_HPS]; fp32 accumulate, bias and LeakyReLU; the output is bfloat16
     channels-last, or float32 NCDHW for the last block."""
@@ -275,9 +285,9 @@ def conv3d_k3_lrelu_bf16(x, weight, bias, stride, *, in_layout, out_layout, nega
     o = lambda n: (n - 1) // stride + 1
     Do, Wo, Ho = o(D), o(W), o(H)
     if out_layout == LAYOUT_NCDHW:
-        y = torch.empty((B, Cout, Do, Wo, Ho), dtype=torch.float32, device=x.device)
+        y = _conv_out(out, (B, Cout, Do, Wo, Ho), torch.float32, x.device)
     else:
-        y = torch.empty((B, Do, Wo, Ho, Cout), dtype=torch.bfloat16, device=x.device)
+        y = _conv_out(out, (B, Do, Wo, Ho, Cout), torch.bfloat16, x.device)
     with _timed(f"conv3d_bf16_c{Cin}x{Cout}_s{stride}_{D}", flops=2.0 * 27 * Cin * Cout * B * Do * Wo * Ho,
                 bytes=2 * x.numel() + y.numel() * y.element_size(), samples=B, peak_tf=MFMA_BF16_PEAK_TF, bound="hbm"):
         _hip.check(_hip.lib().lr_conv3d_k3_lrelu_bf16(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B, Cin,
@@ -299,7 +309,7 @@ def conv3d_pack_weights_bf16_planar(weight):
     return packed
 
 
-def conv3d_first_bf16(x, weight, bias, *, out_layout, negative_slope=0.2, packed=None):
+def conv3d_first_bf16(x, weight, bias, *, out_layout, negative_slope=0.2, packed=None, out=None):
     """The encoder's first block in the bf16 variant: x float32 (B,Cin,D,W,H), stride 1, output bfloat16
     (B,D,W,H,Cout) in LAYOUT_BF16_NDHWC[_HPS].  Inputs are rounded to bf16 on the way into the MFMA."""
     x = _dev(x, "x")
@@ -310,7 +320,7 @@ def conv3d_first_bf16(x, weight, bias, *, out_layout, negative_slope=0.2, packed
     if packed is None:
         packed = conv3d_pack_weights_bf16_planar(weight)
     b = None if bias is None else _dev(bias.detach(), "bias")
-    y = torch.empty((B, D, W, H, Cout), dtype=torch.bfloat16, device=x.device)
+    y = _conv_out(out, (B, D, W, H, Cout), torch.bfloat16, x.device)
     with _timed(f"conv3d_bf16_c{Cin}x{Cout}_s1_{D}", flops=2.0 * 27 * Cin * Cout * B * D * W * H,
                 bytes=4 * x.numel() + 2 * y.numel(), samples=B, peak_tf=MFMA_BF16_PEAK_TF, bound="hbm"):
         _hip.check(_hip.lib().lr_conv3d_first_bf16(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B, Cin, Cout,

@@ -173,7 +173,29 @@ class SlabShardedRegistration:
         P = net.drr_feature_num
         bf16 = getattr(net, "conv_dtype", "fp32") == "bf16"
         bounds = [slab_bounds(D, comm.world, r) for r in comm.ranks]
-        acts = []
+
+        def layouts(i):
+            blk = net.encoders[i]
+            return net._bf16_layouts[i] if bf16 else (blk.in_layout, blk.out_layout)
+
+        def conv(i, x, out):
+            blk = net.encoders[i]
+            lin, lout = layouts(i)
+            if not bf16:
+                return ops.conv3d_k3_lrelu(x, blk.conv.weight, blk.conv.bias, blk.stride, in_layout=lin, out_layout=lout,
+                                           negative_slope=blk._slope, packed=net._packed_weight(i), out=out)
+            if i == 0:
+                return ops.conv3d_first_bf16(x, blk.conv.weight, blk.conv.bias, out_layout=lout, negative_slope=blk._slope,
+                                             packed=net._packed_weight(0, bf16=True), out=out)
+            return ops.conv3d_k3_lrelu_bf16(x, blk.conv.weight, blk.conv.bias, blk.stride, in_layout=lin, out_layout=lout,
+                                            negative_slope=blk._slope, packed=net._packed_weight(i, bf16=True), out=out)
+
+        # Every channels-last activation of a rank lives, per batch element, in a halo-padded buffer of planes
+        # [0: zeros = the stride-phase filler, 1: the halo plane from the rank below, 2..: the slab]; a block writes its
+        # output straight into the next buffer (its first, misaligned output plane lands on plane 1 and is overwritten
+        # by the halo), so no slab is ever copied or concatenated.
+        act_dt = torch.bfloat16 if bf16 else torch.float32
+        bufs, rows = [], []
         # ---- block 0 (stride 1): both halo planes come from replicated data → no communication
         for inp, (d0, d1) in zip(inputs, bounds):
             moving, proj = inp["source"], inp["target_proj"]
@@ -183,44 +205,61 @@ class SlabShardedRegistration:
                 p = p.detach().cpu().numpy() if isinstance(p, torch.Tensor) else p
                 net._poses = p[0].astype("float32").copy()
             lo, hi = max(d0 - 1, 0), min(d1 + 1, D)
-            B = moving.shape[0]
-            x = torch.empty((B, P + 1, hi - lo, W, H), dtype=torch.float32, device=moving.device)
+            B, n_in = moving.shape[0], hi - lo
+            x = torch.empty((B, P + 1, n_in, W, H), dtype=torch.float32, device=moving.device)
             x[:, 0:1].copy_(moving[:, :, lo:hi])
-            x[:, 1:].copy_(ops.backproject(proj, net._poses, (D, W, H), d0=lo, d1=hi))
-            blk = net.encoders[0]
-            if bf16:   # conv_dtype="bf16" (C4): bf16 activations, and bf16 halo planes on the wire
-                lay_out = net._bf16_layouts[0][1]
-                y = ops.conv3d_first_bf16(x, blk.conv.weight, blk.conv.bias, out_layout=lay_out,
-                                          negative_slope=blk._slope, packed=net._packed_weight(0, bf16=True))
-            else:
-                lay_out = blk.out_layout
-                y = ops.conv3d_k3_lrelu(x, blk.conv.weight, blk.conv.bias, 1, in_layout=blk.in_layout,
-                                        out_layout=lay_out, negative_slope=blk._slope, packed=net._packed_weight(0))
-            ax = self._d_axis(lay_out)
-            acts.append(y.narrow(ax, d0 - lo, d1 - d0).contiguous())
-        # ---- blocks 1..5 (stride 2): one halo plane from the rank below per block
-        for i in range(1, 6):
-            blk = net.encoders[i]
-            lay_in, lay_out = net._bf16_layouts[i] if bf16 else (blk.in_layout, blk.out_layout)
-            ax = self._d_axis(lay_in)
-            tops = [a.narrow(ax, a.shape[ax] - 1, 1).contiguous() for a in acts]
-            halos = comm.shift_up(tops)
-            nxt = []
-            for a, h in zip(acts, halos):
-                plane = torch.zeros_like(a.narrow(ax, 0, 1)) if h is None else h   # rank 0: the conv's zero padding
-                # rows [r0-2, r1): the extra leading plane only aligns the stride phase (its output is dropped)
-                xin = torch.cat([torch.zeros_like(plane), plane, a], dim=ax)
-                if bf16:
-                    y = ops.conv3d_k3_lrelu_bf16(xin, blk.conv.weight, blk.conv.bias, 2, in_layout=lay_in,
-                                                 out_layout=lay_out, negative_slope=blk._slope,
-                                                 packed=net._packed_weight(i, bf16=True))
+            ops.backproject(proj, net._poses, (D, W, H), d0=lo, d1=hi, out=x[:, 1:], out_batch_stride=(P + 1) * n_in * W * H)
+            c0 = net.encoders[0].conv.out_channels
+            lead = d0 - lo                        # 1 except on rank 0: the local output row below the slab is discarded
+            blist = []
+            for b in range(B):
+                buf = torch.empty((1, 2 + (d1 - d0) + 1, W, H, c0), dtype=act_dt, device=moving.device)
+                buf[:, 0].zero_()
+                conv(0, x[b:b + 1], buf[:, 2 - lead:2 - lead + n_in])
+                blist.append(buf)
+            bufs.append(blist)
+            rows.append(d1 - d0)
+        # ---- block 1 (stride 2), the other big one: per batch element again, but INTO one batched padded buffer (a
+        # plane range of one batch element of it is contiguous), so that the small blocks 2..5 can run batched
+        tops = [torch.cat([buf[:, 1 + r:2 + r] for buf in blist], 0) for blist, r in zip(bufs, rows)]
+        halos = comm.shift_up(tops)
+        o = lambda n: (n - 1) // 2 + 1
+        acts_p, nrows = [], []
+        for blist, r, h in zip(bufs, rows, halos):
+            n_out = o(2 + r)                      # planes the block produces from [zero, halo, slab]: 1 filler + r/2
+            b0 = blist[0]
+            nb = torch.empty((len(blist), 1 + n_out, o(b0.shape[2]), o(b0.shape[3]), net.encoders[1].conv.out_channels),
+                             dtype=act_dt, device=b0.device)
+            for b, buf in enumerate(blist):
+                if h is None:
+                    buf[:, 1].zero_()             # rank 0: the conv's own zero padding
                 else:
-                    y = ops.conv3d_k3_lrelu(xin, blk.conv.weight, blk.conv.bias, 2, in_layout=lay_in,
-                                            out_layout=lay_out, negative_slope=blk._slope,
-                                            packed=net._packed_weight(i))
-                axo = self._d_axis(lay_out)
-                nxt.append(y.narrow(axo, 1, y.shape[axo] - 1).contiguous())
-            acts = nxt
+                    buf[:, 1].copy_(h[b])
+                conv(1, buf[:, :2 + r], nb[b:b + 1, 1:1 + n_out])
+            acts_p.append(nb)
+            nrows.append(r // 2)
+        rows = nrows
+        # ---- blocks 2..5: small activations, batched launches; the (small) output is copied behind the two leading planes
+        for i in range(2, 6):
+            tops = [a[:, 1 + r:2 + r].contiguous() for a, r in zip(acts_p, rows)]
+            halos = comm.shift_up(tops)
+            nxt, nrows = [], []
+            for a, r, h in zip(acts_p, rows, halos):
+                a[:, 0].zero_()
+                if h is None:
+                    a[:, 1].zero_()
+                else:
+                    a[:, 1].copy_(h[:, 0])
+                y = conv(i, a, None)              # (B, 1 + r/2, ...) channels-last, or (B, 32, 1 + r/2, ...) for the last block
+                if i == 5:
+                    nxt.append(y[:, :, 1:].contiguous())
+                else:
+                    nb = torch.empty((y.shape[0], 1 + y.shape[1]) + tuple(y.shape[2:]), dtype=y.dtype, device=y.device)
+                    nb[:, 1:].copy_(y)
+                    nxt.append(nb)
+                nrows.append(r // 2)
+            acts_p, rows = nxt, nrows
+        acts = acts_p
         # ---- FC head on the gathered features (replicated), then the slab-local decode
         feats = comm.all_gather_cat(acts, dim=2)     # last block writes NCDHW: (B,32,rows,·,·)
         outs = []

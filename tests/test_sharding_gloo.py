@@ -56,9 +56,14 @@ class OracleOps:
     def conv3d_pack_weights(self, weight, in_layout):
         return None
 
-    def conv3d_k3_lrelu(self, x, weight, bias, stride, *, in_layout=0, out_layout=0, negative_slope=0.2, packed=None):
+    def conv3d_k3_lrelu(self, x, weight, bias, stride, *, in_layout=0, out_layout=0, negative_slope=0.2, packed=None,
+                        out=None):
         y = self.ro.conv_block(self._to_ncdhw(x, in_layout), weight.detach(), bias.detach(), stride, negative_slope)
-        return self._from_ncdhw(y, out_layout)
+        y = self._from_ncdhw(y, out_layout)
+        if out is None:
+            return y
+        out.copy_(y)                       # the sharded forward writes into plane ranges of its halo-padded buffers
+        return out
 
     def linear_lrelu(self, x, weight, bias, negative_slope=1.0):
         y = torch.nn.functional.linear(x, weight.detach(), bias.detach())

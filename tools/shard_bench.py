@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Cost of the z-slab decomposition itself: the slab-sharded forward with N virtual ranks on ONE GPU (LocalComm: the
+halo exchange is a device copy) against the unsharded forward of the same batch.  Development aid.
+
+  python tools/shard_bench.py [--n 256] [--world 4] [--batch 8] [--views 2] [--conv-dtype fp32|bf16]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from liftreg_amd import parallel as par  # noqa: E402
+from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model  # noqa: E402
+from liftreg_amd.utils.sdct_projection_utils import scan_poses  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=256)
+    ap.add_argument("--world", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--views", type=int, default=2)
+    ap.add_argument("--conv-dtype", default="fp32")
+    ap.add_argument("--iters", type=int, default=5)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    n, P, B = a.n, a.views, a.batch
+    torch.manual_seed(1)
+    net = model([n, n, n], {"drr_feature_num": P, "latent_dim": 56, "pca_path": "synthetic:1", "conv_dtype": a.conv_dtype}).to(dev).eval()
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    poses = scan_poses(30, P, n).astype(np.float32)
+    inp = {"source": torch.rand((B, 1, n, n, n), generator=g, device=dev) * 2 - 1,
+           "target": torch.rand((B, 1, n, n, n), generator=g, device=dev) * 2 - 1,
+           "target_proj": torch.rand((B, P, n, n), generator=g, device=dev) * 2 - 1,
+           "target_poses": torch.from_numpy(np.broadcast_to(poses, (B, P, 3)).copy())}
+    sh = par.SlabShardedRegistration(net, par.LocalComm(a.world))
+
+    def timeit(fn):
+        with torch.no_grad():
+            fn()
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(a.iters):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+        return s.elapsed_time(e) / a.iters
+
+    from liftreg_amd import ops
+
+    def table(fn):
+        with torch.no_grad(), ops.kernel_timer() as kt:
+            fn()
+            torch.cuda.synchronize()
+        out = {}
+        for name, rec in kt.summary().items():
+            key = name.split("_s")[0] if name.startswith("conv3d") else name
+            out[key] = round(out.get(key, 0.0) + float(np.sum(rec["ms"])), 3)
+        return out
+
+    if os.environ.get("SHARD_BENCH_TABLE"):
+        print("unsharded", json.dumps(table(lambda: net(inp))))
+        print("sharded  ", json.dumps(table(lambda: sh.forward([inp] * a.world))))
+    t_full = timeit(lambda: net(inp))
+    t_shard = timeit(lambda: sh.forward([inp] * a.world))
+    print(json.dumps({"n": n, "views": P, "batch": B, "world": a.world, "conv_dtype": a.conv_dtype,
+                      "unsharded_ms": round(t_full, 3), "sum_of_slabs_ms": round(t_shard, 3),
+                      "decomposition_overhead": round(t_shard / t_full - 1, 3)}))
+
+
+if __name__ == "__main__":
+    main()
