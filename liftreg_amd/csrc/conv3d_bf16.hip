@@ -23,7 +23,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
-constexpr int MT = 4, TD = 4;
+constexpr int TD = 4;
 
 struct ConvDimsH {
   int B, Cin, Cout, D, W, H, Do, Wo, Ho;
@@ -61,7 +61,7 @@ __device__ __forceinline__ void store_tile_any(const f32x4& acc, void* __restric
 }
 
 // CIN32: Cin == 32 (else 16).  PS: input rows parity-split along H ([parity][H/2][Cin]).
-template <int NT, bool CIN32, bool PS>
+template <int NT, bool CIN32, bool PS, int MT>
 __global__ __launch_bounds__(256) void conv3d_cl_bf16_kernel(const u16* __restrict__ in, const u32x4* __restrict__ wp,
                                                              const float* __restrict__ bias, void* __restrict__ out,
                                                              ConvDimsH d, int out_layout, float slope) {
@@ -643,15 +643,21 @@ extern "C" int lr_conv3d_k3_lrelu_bf16(const void* in, const void* packed_w, con
   if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(packed_w)) & 15u) return LR_EALIGN;
   if (out_layout != LR_LAYOUT_NCDHW && (reinterpret_cast<uintptr_t>(out) & 7u)) return LR_EALIGN;
   if ((int64_t)12 * W * H * Cin * 2 + 4096 >= 0x7fffffffLL) return LR_EINVAL;  // 31-bit offsets inside a window
-  d.nHq = (d.Ho + 15) / 16; d.nWq = (d.Wo + MT - 1) / MT; d.nDq = (d.Do + TD - 1) / TD;
+  // rows per wave: 8 for the big first stride-2 block (fewer weight loads per MFMA), 4 otherwise; LIFTREG_BF16_MT overrides
+  int mtb = (Cin == 16 && d.Wo >= 64) ? 8 : 4;
+  if (const char* e = getenv("LIFTREG_BF16_MT")) mtb = atoi(e) == 8 ? 8 : 4;  // tuning aid
+  d.nHq = (d.Ho + 15) / 16; d.nWq = (d.Wo + mtb - 1) / mtb; d.nDq = (d.Do + TD - 1) / TD;
   const int64_t nblk = (int64_t)B * d.nDq * d.nWq * d.nHq;
   if (nblk > 0x7fffffffLL) return LR_EINVAL;
   const dim3 grid((unsigned)nblk), block(256);
   hipStream_t st = lr_stream(stream);
   const u16* x = reinterpret_cast<const u16*>(in);
   const u32x4* wt = reinterpret_cast<const u32x4*>(packed_w);
-#define LR_BF(NTV, C32, PSV) \
-  hipLaunchKernelGGL((conv3d_cl_bf16_kernel<NTV, C32, PSV>), grid, block, 0, st, x, wt, bias, out, d, out_layout, negative_slope)
+#define LR_BF(NTV, C32, PSV)                                                                                                      \
+  do {                                                                                                                            \
+    if (mtb == 8) hipLaunchKernelGGL((conv3d_cl_bf16_kernel<NTV, C32, PSV, 8>), grid, block, 0, st, x, wt, bias, out, d, out_layout, negative_slope); \
+    else hipLaunchKernelGGL((conv3d_cl_bf16_kernel<NTV, C32, PSV, 4>), grid, block, 0, st, x, wt, bias, out, d, out_layout, negative_slope);          \
+  } while (0)
   const int NT = Cout / 16;
   if (Cin == 32) {
     if (NT == 2) { if (ps) LR_BF(2, true, true); else LR_BF(2, true, false); }
