@@ -408,3 +408,50 @@ def test_preprocessing_drr_cli_matches_reference_files(dev, tmp_path):
     phi = torch.from_numpy(rs.uniform(-1, 1, (2, 3, 4, 5, 6)).astype(np.float32)).to(dev)
     save_deformations(phi, ["x", "y"], str(tmp_path))
     assert np.array_equal(np.load(tmp_path / "y_phi.npy"), ((phi[1].cpu().numpy() + 1.) / 2.).astype(np.float32))
+
+
+def test_register_folder_tool(dev, tmp_path):
+    """liftreg_amd.tools.register_folder over a tiny dataset in the reference's folder layout: the saved {id}_phi.npy
+    equal the model run on inputs prepared the way the reference's dataset does (flip axis 1, clip-range
+    normalisation — restated with numpy), checkpoint loaded through the reference's key names."""
+    from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+    from liftreg_amd.tools import preprocessingDRR, register_folder
+    rs = np.random.RandomState(12)
+    root, out = tmp_path / "data", tmp_path / "out"
+    (root / "preprocessed").mkdir(parents=True)
+    (root / "test").mkdir()
+    shape, ids = (16, 12, 20), ["c1", "c2", "c3"]
+    np.save(root / "test" / "data_id.npy", np.array(ids))
+    vols = {}
+    for c in ids:
+        for kind in ("source", "target"):
+            vols[(c, kind)] = np.clip(rs.normal(-500, 400, shape), -1024, 1000).astype(np.float32)
+            np.save(root / "preprocessed" / f"{c}_{kind}.npy", vols[(c, kind)])
+            np.save(root / "preprocessed" / f"{c}_{kind}_seg.npy", (rs.uniform(0, 1, shape) > 0.4).astype(np.float32))
+    assert preprocessingDRR.main(["-d", str(root), "--drr_folder_name", "t", "--scan_range", "30", "--scan_num", "2",
+                                  "--receptor_w", "20", "--receptor_h", "16", "--phase", "test"]) == 0
+    torch.manual_seed(4)
+    net = model(list(shape), {"drr_feature_num": 2, "latent_dim": 6, "pca_path": "synthetic:3"}).to(dev).eval()
+    torch.save({"state_dict": net.state_dict(), "epoch": 1}, tmp_path / "ck.pth.tar")
+    assert register_folder.main(["-d", str(root), "--drr_folder_name", "t", "--phase", "test", "-o", str(out), "--pca_path",
+                                 "synthetic:3", "--checkpoint", str(tmp_path / "ck.pth.tar"), "--latent_dim", "6",
+                                 "--batch", "2", "--labels"]) == 0
+    drr = root / "drr" / "t" / "drr"
+    poses = np.load(drr / "poses.npy").astype(np.float32)
+    for c in ids:
+        prep = lambda a, lo, hi: torch.from_numpy(ro.normalize_clip(a, lo, hi))
+        flip = lambda a: np.flip(a, axis=1).copy()
+        inp = {"source": prep(flip(vols[(c, "source")]), -1000, 0)[None, None].to(dev),
+               "target": prep(flip(vols[(c, "target")]), -1000, 0)[None, None].to(dev),
+               "target_proj": prep(np.load(drr / f"{c}_target_proj.npy"), 0, 6)[None].to(dev),
+               "source_label": torch.from_numpy(flip(np.load(root / "preprocessed" / f"{c}_source_seg.npy")))[None, None].to(dev),
+               "target_label": torch.from_numpy(flip(np.load(root / "preprocessed" / f"{c}_target_seg.npy")))[None, None].to(dev),
+               "target_poses": torch.from_numpy(poses[None].copy())}
+        with torch.no_grad():
+            want = net(inp)["phi"][0].cpu().numpy()
+        got = np.load(out / f"{c}_phi.npy")
+        assert got.dtype == np.float32 and got.shape == (3,) + shape
+        np.testing.assert_allclose(got, (want + 1.0) / 2.0, rtol=0, atol=1e-6)
+    import json
+    rep = json.load(open(out / "register_folder.json"))
+    assert [r["id"] for r in rep] == ids and all(0.0 <= r["dice"] <= 1.0 for r in rep)
