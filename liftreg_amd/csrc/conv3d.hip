@@ -482,28 +482,35 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(const float* __restrict_
   // PS rows are [channel block of 16][parity][H/2][16 floats]: neighbouring voxels of a half-row are 64 B apart
   const unsigned lvoff = PS ? (unsigned)(col * 64 + kq * 16) : (unsigned)(col * STRIDE * d.Cin * 4 + kq * 16);
   const int half_h = (d.H + 1) >> 1;  // PS: the odd voxels of a row start here
-  unsigned nvmask[MT];  // bit tap CLEAR = that tap of this lane's voxel in tile mt is inside the tensor
+  // Tap validity, split so that the k-loop spends (almost) no vector ALU on it — vector ALU instructions and MFMAs
+  // share the SIMD's issue port, and the former version's ~30 per k-step cost as much as 15 % of the matrix time:
+  //  * x (the lane's own column): three per-lane offsets, one per tx, with bit 31 set when that tap is outside;
+  //  * y, z (wave-uniform): a 9-bit scalar mask per tile; an invalid (tz,ty) switches the load to a zero-length
+  //    resource, for which every lane reads 0 — scalar selects only.
+  unsigned vx[3];
   {
-    // valid(tz,ty,tx) = z[tz] & y[ty] & x[tx]: three 3-bit axis masks spread to the 27 tap bits with shifts
-    // (the taps are bit (tz*3+ty)*3+tx); a dozen ALU ops per tile instead of 27 compares
     const int xi0 = ho * STRIDE - 1;
-    unsigned xm = 0u, zm = 0u;
 #pragma unroll
-    for (int t3 = 0; t3 < 3; ++t3) {
-      if (ho < d.Ho && xi0 + t3 >= 0 && xi0 + t3 < d.H) xm |= 1u << t3;
-      if (zi0 + t3 >= 0 && zi0 + t3 < d.D) zm |= 0x1ffu << (9 * t3);
-    }
-    const unsigned x27 = (xm | (xm << 3) | (xm << 6)) * 0x40201u & zm;  // x pattern in all 9 (tz,ty) triples, gated by z
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int yi0 = (wo0 + mt) * STRIDE - 1;
-      unsigned ym = 0u;
-#pragma unroll
-      for (int t3 = 0; t3 < 3; ++t3)
-        if ((wo0 + mt < d.Wo) && yi0 + t3 >= 0 && yi0 + t3 < d.W) ym |= 0x7u << (3 * t3);
-      nvmask[mt] = ~(x27 & (ym * 0x40201u));
-    }
+    for (int t3 = 0; t3 < 3; ++t3) vx[t3] = lvoff | ((ho < d.Ho && xi0 + t3 >= 0 && xi0 + t3 < d.H) ? 0u : OOR);
   }
+  unsigned zymask[MT];  // bit tz*3+ty SET = valid (wave-uniform)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int yi0 = (wo0 + mt) * STRIDE - 1;
+    unsigned m = 0u;
+#pragma unroll
+    for (int tz = 0; tz < 3; ++tz)
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty)
+        if ((wo0 + mt < d.Wo) && zi0 + tz >= 0 && zi0 + tz < d.D && yi0 + ty >= 0 && yi0 + ty < d.W) m |= 1u << (tz * 3 + ty);
+    zymask[mt] = m;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_null =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wbase), (short)0, 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wp), (short)0, 0x7fffffff, 0x00020000);
+  const unsigned wlane = (unsigned)lane * 16u;
+  const bool ragged_c = (d.Cin & 15) != 0;  // only then can a channel quad of the last 16-block be missing
   const unsigned row_bytes = (unsigned)(STRIDE * d.H * d.Cin * 4);  // next tile (output row) of the wave
 
   // One k-step = (tap, 16-channel block): NT weight fragments + MT activation fragments, 4 MFMAs each.
@@ -518,14 +525,16 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(const float* __restrict_
     const int xs = PS ? (tx == 1 ? 1 : half_h + (tx >> 1)) : tx;
     const unsigned soff = PS ? (unsigned)(((tz * d.W + ty) * d.H * d.Cin + (cb * 2 * half_h + xs) * 16) * 4)
                              : (unsigned)(((tz * d.W + ty) * d.H + xs) * d.Cin * 4 + cb * 64);
-    // branch-free: bit 31 of the offset is set (=> out of range => 0) unless tap and channel are valid
-    const unsigned coor = (cb * 16 + kq * 4 < d.Cin) ? 0u : OOR;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bw[nt] = wp[((int64_t)s * NT + nt) * 64 + lane];
+    for (int nt = 0; nt < NT; ++nt)
+      bw[nt] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wlane, (unsigned)((s * NT + nt) * 1024), 0));
+    unsigned voff = tx == 0 ? vx[0] : (tx == 1 ? vx[1] : vx[2]);
+    if (ragged_c) voff |= (cb * 16 + kq * 4 < d.Cin) ? 0u : OOR;
+    const int zy = tz * 3 + ty;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const unsigned voff = lvoff | coor | ((nvmask[mt] >> tap) << 31);
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + mt * row_bytes, 0);
+      const bool ok = (zymask[mt] >> zy) & 1u;  // scalar
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ok ? rsrc : rsrc_null, voff, soff + mt * row_bytes, 0);
       a[mt] = __builtin_bit_cast(float4, v);
     }
   };
