@@ -157,14 +157,29 @@ __global__ __launch_bounds__(256) void conv3d_cl_bf16_kernel(const u16* __restri
                                                               __builtin_bit_cast(bf16x8, a[mt]), acc[mt][nt], 0, 0, 0);
   };
   u32x4 a0[MT], a1[MT], b0[NT], b1[NT];
-  load_step(0, a0, b0);
-  for (int s = 0; s + 1 < NS; s += 2) {
-    load_step(s + 1, a1, b1);
-    mfma_step(a0, b0);
-    load_step(min(s + 2, NS - 1), a0, b0);
-    mfma_step(a1, b1);
+  if constexpr (MT <= 4) {
+    // loads two steps ahead of the MFMAs (three register sets), as in the fp32 kernel; NS = 27 | 14
+    u32x4 a2[MT], b2[NT];
+    load_step(0, a0, b0);
+    load_step(1, a1, b1);
+    for (int s = 0; s < NS; s += 3) {
+      load_step(min(s + 2, NS - 1), a2, b2);
+      mfma_step(a0, b0);
+      load_step(min(s + 3, NS - 1), a0, b0);
+      if (s + 1 < NS) mfma_step(a1, b1);
+      load_step(min(s + 4, NS - 1), a1, b1);
+      if (s + 2 < NS) mfma_step(a2, b2);
+    }
+  } else {  // 8 rows per wave: a third register set would cost occupancy (measured slower) — one step ahead
+    load_step(0, a0, b0);
+    for (int s = 0; s + 1 < NS; s += 2) {
+      load_step(s + 1, a1, b1);
+      mfma_step(a0, b0);
+      load_step(min(s + 2, NS - 1), a0, b0);
+      mfma_step(a1, b1);
+    }
+    if (NS & 1) mfma_step(a0, b0);
   }
-  if (NS & 1) mfma_step(a0, b0);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
