@@ -1,0 +1,166 @@
+"""GPU: a seeded sweep of RANDOM small shapes through every kernel family against the oracles — the fixed-shape parity
+tests pin known cases, this one looks for the shapes nobody thought of (odd / tiny / non-multiple-of-4 extents, ragged
+tiles, batch and view counts).  Same bars as the parity tests: bit-exact for the gathers, 1e-4 for the fp32 GEMM-like ops."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+from oracle import ref_ops as ro
+
+pytestmark = pytest.mark.gpu
+N_CASES = int(os.environ.get("LIFTREG_FUZZ_CASES", "10"))   # raise for a longer hunt
+SEED = int(os.environ.get("LIFTREG_FUZZ_SEED", "0"))       # shifts every family's seed
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _shape(rs, lo=2, hi=23):
+    return tuple(int(v) for v in rs.randint(lo, hi, 3))
+
+
+def test_fuzz_projector_and_backprojection(dev):
+    from liftreg_amd import ops
+    rs = np.random.RandomState(101 + SEED)
+    for _ in range(N_CASES):
+        D, W, H = _shape(rs, 2, 20)
+        P, B = int(rs.randint(1, 5)), int(rs.randint(1, 4))
+        Rd, Rh = int(rs.randint(2, 26)), int(rs.randint(2, 70))
+        poses = ro.scan_poses(float(rs.uniform(10, 60)), P, W).astype(np.float32)
+        sp = rs.uniform(1.0, 3.0, 3).astype(np.float32)
+        vol = rs.uniform(0, 0.3, (D, W, H)).astype(np.float32)
+        want = co.drr_forward(vol, poses, sp, (Rd, Rh))
+        got = ops.drr_forward(T(vol, dev), poses, (Rd, Rh), sp, nseg=1).cpu().numpy()
+        assert np.array_equal(got, want), ("drr", D, W, H, P, Rd, Rh)            # one run per ray: the oracle's sum order
+        nseg = int(rs.choice([0, 2, 4, 8]))                                       # split rays: partial sums re-associate
+        got = ops.drr_forward(T(vol, dev), poses, (Rd, Rh), sp, nseg=nseg).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6, err_msg=str(("drr nseg", nseg, D, W, H, P, Rd, Rh)))
+        proj = rs.uniform(-1, 1, (B, P, Rd, Rh)).astype(np.float32)
+        bp = ops.backproject(T(proj, dev), poses, (D, W, H)).cpu().numpy()
+        assert np.array_equal(bp, co.backproject(proj, poses, (D, W, H))), ("backproject", D, W, H, P, Rd, Rh, B)
+
+
+def test_fuzz_warp_pca_ncc_reg(dev):
+    from liftreg_amd import ops
+    rs = np.random.RandomState(102 + SEED)
+    for _ in range(N_CASES):
+        shape = _shape(rs, 2, 18)
+        B, C = int(rs.randint(1, 4)), int(rs.randint(1, 3))
+        img = rs.uniform(-1, 1, (B, C) + shape).astype(np.float32)
+        disp = rs.normal(0, 0.3, (B, 3) + shape).astype(np.float32)
+        tabs = ro.identity_axis_tables(shape)
+        zb = bool(rs.randint(0, 2))
+        phi, warped = ops.warp(T(img, dev), T(disp, dev), [T(t, dev) for t in tabs], None, using_scale=True, zero_boundary=zb)
+        want = ro.warp(torch.from_numpy(img), torch.from_numpy(disp) + ro.identity_map(shape), zero_boundary=zb, using_scale=True)
+        np.testing.assert_allclose(warped.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5, err_msg=str(("warp", shape, B, C, zb)))
+        # PCA: M must be a multiple of 4 (the ABI's alignment rule)
+        Lat, M = int(rs.randint(1, 20)), int(rs.randint(1, 300)) * 4
+        basis, mean = rs.normal(0, 0.05, (Lat, M)).astype(np.float32), rs.normal(0, 0.01, M).astype(np.float32)
+        coefs = rs.normal(0, 1, (B, Lat)).astype(np.float32)
+        got = ops.pca_reconstruct(T(coefs, dev), T(basis, dev), T(mean, dev)).cpu().numpy()
+        np.testing.assert_allclose(got, coefs.astype(np.float64) @ basis + mean, rtol=1e-4, atol=1e-5, err_msg=str(("pca", B, Lat, M)))
+        # NCC (both variants) and the regulariser
+        x, y = rs.uniform(-1, 1, (B, C) + shape).astype(np.float32), rs.uniform(-1, 1, (B, C) + shape).astype(np.float32)
+        assert abs(float(ops.ncc_loss(T(x, dev), T(y, dev), 0)) - float(ro.ncc_loss(torch.from_numpy(x), torch.from_numpy(y)))) < 2e-5
+        assert abs(float(ops.ncc_loss(T(x, dev), T(y, dev), 1)) - float(ro.ncc_loss_squared(torch.from_numpy(x), torch.from_numpy(y)))) < 2e-5
+        r = float(ops.disp_reg(T(disp, dev)))
+        rw = float(ro.disp_reg(torch.from_numpy(disp)))
+        assert abs(r - rw) <= 1e-4 * max(1.0, abs(rw)), ("reg", shape, r, rw)
+
+
+def test_fuzz_conv_forward_and_backward(dev):
+    """Random extents for the first block (planar) and the stride-2 blocks (both channels-last layouts), forward and —
+    through the chained backward — weight, bias and data gradients."""
+    from liftreg_amd import ops, ops_bwd
+    rs = np.random.RandomState(103 + SEED)
+
+    def to_layout(t_ncdhw, lay):
+        cl = t_ncdhw.permute(0, 2, 3, 4, 1).contiguous()
+        if lay == ops.LAYOUT_NDHWC_HPS:
+            B, D, W, H, C = cl.shape
+            h = torch.arange(H, device=cl.device)
+            inv = torch.empty(H, dtype=torch.long, device=cl.device)
+            inv[(h & 1) * (H // 2) + (h >> 1)] = h
+            cl = cl.reshape(B, D, W, H, C // 16, 16)[:, :, :, inv].permute(0, 1, 2, 4, 3, 5).reshape(B, D, W, H, C).contiguous()
+        return cl
+
+    for case in range(N_CASES):
+        first = case % 3 == 0
+        shape, B = _shape(rs, 2, 15), int(rs.randint(1, 3))
+        if first:
+            cin, cout, s = int(rs.choice([1, 2, 3, 5, 12])), 16, 1
+            xl = ops.LAYOUT_NCDHW
+        else:
+            cin, cout, s = int(rs.choice([16, 32])), int(rs.choice([16, 32])), 2
+            xl = ops.LAYOUT_NDHWC_HPS if shape[2] % 2 == 0 and rs.randint(0, 2) else ops.LAYOUT_NDHWC
+        ho = (shape[2] - 1) // s + 1
+        yl = ops.LAYOUT_NDHWC_HPS if ho % 2 == 0 and rs.randint(0, 2) else ops.LAYOUT_NDHWC
+        x = rs.uniform(-1, 1, (B, cin) + shape).astype(np.float32)
+        w = (rs.normal(0, 1, (cout, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32)
+        b = rs.uniform(-0.1, 0.1, cout).astype(np.float32)
+        xt, wt, bt = (torch.from_numpy(a).requires_grad_(True) for a in (x, w, b))
+        yref = ro.conv_block(xt, wt, bt, s)
+        gy = rs.normal(0, 1, tuple(yref.shape)).astype(np.float32)
+        yref.backward(torch.from_numpy(gy))
+        xd = T(x, dev) if first else to_layout(T(x, dev), xl)
+        yd = ops.conv3d_k3_lrelu(xd, T(w, dev), T(b, dev), s, in_layout=xl, out_layout=yl)
+        yplain = ops.hps_to_ndhwc(yd) if yl == ops.LAYOUT_NDHWC_HPS else yd
+        tag = str((cin, cout, s, shape, B, xl, yl))
+        np.testing.assert_allclose(yplain.permute(0, 4, 1, 2, 3).cpu().numpy(), yref.detach().numpy(), rtol=1e-4, atol=1e-5,
+                                   err_msg="fwd " + tag)
+        gx, gw, gb = ops_bwd.conv3d_bwd(xd, xl, T(w, dev), yd, yl, to_layout(T(gy, dev), ops.LAYOUT_NDHWC), ops.LAYOUT_NDHWC, s,
+                                        need_gx=not first, nblk=int(rs.choice([1, 8, 64])))
+        np.testing.assert_allclose(gw.cpu().numpy(), wt.grad.numpy(), rtol=3e-4, atol=3e-5, err_msg="gw " + tag)
+        np.testing.assert_allclose(gb.cpu().numpy(), bt.grad.numpy(), rtol=3e-4, atol=3e-5, err_msg="gb " + tag)
+        if not first:
+            gxp = ops.hps_to_ndhwc(gx) if xl == ops.LAYOUT_NDHWC_HPS else gx
+            np.testing.assert_allclose(gxp.permute(0, 4, 1, 2, 3).cpu().numpy(), xt.grad.numpy(), rtol=3e-4, atol=3e-5,
+                                       err_msg="gx " + tag)
+
+
+def test_fuzz_bf16_blocks(dev):
+    from liftreg_amd import ops
+    rs = np.random.RandomState(104 + SEED)
+    for case in range(N_CASES):
+        shape, B = _shape(rs, 2, 15), int(rs.randint(1, 3))
+        if case % 3 == 0:
+            cin, cout = int(rs.choice([1, 3, 4, 12])), int(rs.choice([16, 32]))
+            x = torch.from_numpy(rs.uniform(-1, 1, (B, cin) + shape).astype(np.float32))
+            w = torch.from_numpy((rs.normal(0, 1, (cout, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32))
+            b = torch.from_numpy(rs.uniform(-0.1, 0.1, cout).astype(np.float32))
+            ol = ops.LAYOUT_BF16_NDHWC_HPS if shape[2] % 2 == 0 else ops.LAYOUT_BF16_NDHWC
+            y = ops.conv3d_first_bf16(x.to(dev), w.to(dev), b.to(dev), out_layout=ol)
+            want = ro.conv_block_bf16(x, w, b, 1)
+        else:
+            cin, cout = int(rs.choice([16, 32])), int(rs.choice([16, 32]))
+            x = torch.from_numpy(rs.uniform(-1, 1, (B, cin) + shape).astype(np.float32)).to(torch.bfloat16)
+            w = torch.from_numpy((rs.normal(0, 1, (cout, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32))
+            b = torch.from_numpy(rs.uniform(-0.1, 0.1, cout).astype(np.float32))
+            il = ops.LAYOUT_BF16_NDHWC_HPS if shape[2] % 2 == 0 and rs.randint(0, 2) else ops.LAYOUT_BF16_NDHWC
+            ho = (shape[2] - 1) // 2 + 1
+            ol = ops.LAYOUT_BF16_NDHWC_HPS if ho % 2 == 0 else ops.LAYOUT_BF16_NDHWC
+            xd = x.permute(0, 2, 3, 4, 1).contiguous().to(dev)
+            if il == ops.LAYOUT_BF16_NDHWC_HPS:
+                H = xd.shape[3]
+                h = torch.arange(H, device=dev)
+                inv = torch.empty(H, dtype=torch.long, device=dev)
+                inv[(h & 1) * (H // 2) + (h >> 1)] = h
+                xd = xd[:, :, :, inv].contiguous()
+            y = ops.conv3d_k3_lrelu_bf16(xd, w.to(dev), b.to(dev), 2, in_layout=il, out_layout=ol)
+            want = ro.conv_block_bf16(x.float(), w, b, 2)
+        if ol == ops.LAYOUT_BF16_NDHWC_HPS:
+            y = ops.bf16_hps_to_ndhwc(y)
+        got = y.float().permute(0, 4, 1, 2, 3).cpu().numpy()
+        flips = int((got != want.numpy()).sum())      # fp32 summation order may flip a final bf16 rounding here and there
+        assert flips <= max(2, 0.01 * got.size), (cin, cout, shape, B, flips)
+        np.testing.assert_allclose(got, want.numpy(), rtol=2.0 ** -7, atol=1e-6, err_msg=str((cin, cout, shape, B)))
