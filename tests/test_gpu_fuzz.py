@@ -164,3 +164,49 @@ def test_fuzz_bf16_blocks(dev):
         flips = int((got != want.numpy()).sum())      # fp32 summation order may flip a final bf16 rounding here and there
         assert flips <= max(2, 0.01 * got.size), (cin, cout, shape, B, flips)
         np.testing.assert_allclose(got, want.numpy(), rtol=2.0 ** -7, atol=1e-6, err_msg=str((cin, cout, shape, B)))
+
+
+def test_fuzz_bf16_gradient_backward(dev):
+    """The bf16-gradient backward kernels (transposing LDS reads, shifted window copies) on random extents."""
+    from liftreg_amd import ops, ops_bwd
+    rs = np.random.RandomState(105 + SEED)
+    for case in range(N_CASES):
+        B = int(rs.randint(1, 3))
+        if case % 3 == 0:      # first block: planar fp32 input; the fast path needs H % 4 == 0
+            cin, cout = int(rs.choice([1, 3, 5, 12])), 16
+            shape = (int(rs.randint(2, 10)), int(rs.randint(2, 10)), int(rs.randint(1, 36)) * 4)
+            x = torch.from_numpy(rs.uniform(-1, 1, (B, cin) + shape).astype(np.float32))
+            w = torch.from_numpy((rs.normal(0, 1, (cout, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32))
+            g = torch.from_numpy(rs.normal(0, 1, (B, cout) + shape).astype(np.float32)).to(torch.bfloat16)
+            wr, b0 = w.clone().requires_grad_(True), torch.zeros(cout, requires_grad=True)
+            torch.nn.functional.conv3d(ro._bf16(x), ro._bf16(wr), b0, stride=1, padding=1).backward(g.float())
+            gx, gw, gb = ops_bwd.conv3d_bwd_bf16g(x.to(dev), ops.LAYOUT_NCDHW_RBF16, w.to(dev),
+                                                  g.permute(0, 2, 3, 4, 1).contiguous().to(dev), 1, nblk=int(rs.choice([1, 8, 64])))
+            assert gx is None
+        else:
+            cin, cout = int(rs.choice([16, 32])), 32
+            shape = _shape(rs, 2, 15)
+            xl = ops.LAYOUT_BF16_NDHWC_HPS if shape[2] % 2 == 0 and rs.randint(0, 2) else ops.LAYOUT_BF16_NDHWC
+            x = torch.from_numpy(rs.uniform(-1, 1, (B, cin) + shape).astype(np.float32)).to(torch.bfloat16)
+            w = torch.from_numpy((rs.normal(0, 1, (cout, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32))
+            osz = tuple((n - 1) // 2 + 1 for n in shape)
+            g = torch.from_numpy(rs.normal(0, 1, (B, cout) + osz).astype(np.float32)).to(torch.bfloat16)
+            xr, wr, b0 = x.float().requires_grad_(True), w.clone().requires_grad_(True), torch.zeros(cout, requires_grad=True)
+            torch.nn.functional.conv3d(xr, ro._bf16(wr), b0, stride=2, padding=1).backward(g.float())
+            want_gx = ro._bf16(torch.where(x.float() > 0, xr.grad, 0.25 * xr.grad))
+            xd = x.permute(0, 2, 3, 4, 1).contiguous().to(dev)
+            if xl == ops.LAYOUT_BF16_NDHWC_HPS:
+                H = xd.shape[3]
+                h = torch.arange(H, device=dev)
+                inv = torch.empty(H, dtype=torch.long, device=dev)
+                inv[(h & 1) * (H // 2) + (h >> 1)] = h
+                xd = xd[:, :, :, inv].contiguous()
+            gx, gw, gb = ops_bwd.conv3d_bwd_bf16g(xd, xl, w.to(dev), g.permute(0, 2, 3, 4, 1).contiguous().to(dev), 2,
+                                                  mask_input_slope=0.25, nblk=int(rs.choice([1, 8, 64])))
+            got = gx.float().permute(0, 4, 1, 2, 3).cpu().numpy()
+            flips = int((got != want_gx.numpy()).sum())
+            assert flips <= max(2, 0.01 * got.size), (cin, shape, B, flips)
+            np.testing.assert_allclose(got, want_gx.numpy(), rtol=2.0 ** -7, atol=1e-6, err_msg=str((cin, shape, B)))
+        tag = str((cin, cout, shape, B))
+        np.testing.assert_allclose(gw.cpu().numpy(), wr.grad.numpy(), rtol=3e-4, atol=4e-4, err_msg="gw " + tag)
+        np.testing.assert_allclose(gb.cpu().numpy(), b0.grad.numpy(), rtol=3e-4, atol=4e-4, err_msg="gb " + tag)
