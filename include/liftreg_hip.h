@@ -159,7 +159,8 @@ int lr_linear_lrelu_f32(const float* x, const float* w, const float* bias, float
  * Replaces F.linear(coefs, pca_vectors, pca_mean): …Backproj.py:42-43,102
  *   disp[b,m] = sum_l coefs[b,l]*basis[l*ldb+m] + mean[m],  m in [0,M)
  * basis is the (L,3V) C-contiguous pca_vectors.npy (ldb=3V) or a slab of it.
- * B <= 32.  M%4==0, pointers 16-byte aligned.
+ * B <= 32.  Fast path: M, ldb, stride multiples of 4 and 16-byte aligned pointers (16-byte streaming loads);
+ * anything else (3V is a multiple of 4 only when the voxel count is) runs a one-element-per-thread kernel.
  */
 int lr_pca_reconstruct_f32(const float* coefs, const float* basis, const float* mean, float* disp,
                            int B, int L, int64_t M, int64_t ldb, int64_t disp_batch_stride,

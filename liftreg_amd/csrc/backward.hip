@@ -196,6 +196,50 @@ __global__ __launch_bounds__(256) void pca_bwd_kernel(const float* __restrict__ 
   }
 }
 
+// any M / leading dimension / alignment: one element per thread-iteration, same partial layout
+template <bool BF>
+__global__ __launch_bounds__(256) void pca_bwd_scalar_kernel(const float* __restrict__ g, const float* __restrict__ basis,
+                                                             float* __restrict__ partial, int B, int L, int64_t M,
+                                                             int64_t ldb, int64_t gstride) {
+  const int l0 = blockIdx.y * LG;
+  float acc[LG][8];
+#pragma unroll
+  for (int a = 0; a < LG; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = 0.0f;
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+    float gv[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) gv[b] = b < B ? g[(int64_t)b * gstride + m] : 0.0f;
+#pragma unroll
+    for (int a = 0; a < LG; ++a) {
+      if (l0 + a < L) {
+        float bv;
+        if (BF) bv = __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(basis)[(int64_t)(l0 + a) * ldb + m] << 16);
+        else bv = basis[(int64_t)(l0 + a) * ldb + m];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = fmaf(gv[b], bv, acc[a][b]);
+      }
+    }
+  }
+  __shared__ float red[4][LG * 8];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int a = 0; a < LG; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const float s = lr_wave_sum(acc[a][b]);
+      if (lane == 0) red[wave][a * 8 + b] = s;
+    }
+  __syncthreads();
+  if (threadIdx.x < LG * 8) {
+    const int a = threadIdx.x / 8, b = threadIdx.x % 8;
+    if (l0 + a < L && b < B)
+      partial[((int64_t)blockIdx.x * B + b) * L + l0 + a] =
+          (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
+}
+
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                            int nblk, int n) {
   // out[i] = sum_blk partial[blk][i], fixed order, fp64 accumulate
@@ -300,13 +344,16 @@ static int pca_bwd_impl(bool bf, const float* gdisp, const float* basis, float* 
                                    int L, int64_t M, int64_t ldb, int64_t gdisp_batch_stride, int nblk,
                                    void* stream) {
   if (!gdisp || !basis || !partial || !gcoefs) return LR_ENULL;
-  if (B < 1 || B > 8 || L < 1 || M < 4 || ldb < M || gdisp_batch_stride < M || nblk < 1 || nblk > 65535)
+  if (B < 1 || B > 8 || L < 1 || M < 1 || ldb < M || gdisp_batch_stride < M || nblk < 1 || nblk > 65535)
     return B > 8 ? LR_EUNSUPPORTED : LR_EINVAL;
-  if ((M & 3) || (ldb & 3) || (gdisp_batch_stride & 3)) return LR_EALIGN;
-  if ((reinterpret_cast<uintptr_t>(gdisp) & 15u) || (reinterpret_cast<uintptr_t>(basis) & (bf ? 7u : 15u))) return LR_EALIGN;
   hipStream_t st = lr_stream(stream);
   const dim3 grid((unsigned)nblk, (unsigned)((L + LG - 1) / LG));
-  if (B > 4 && bf) hipLaunchKernelGGL((pca_bwd_kernel<8, true>), grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
+  const bool vec_ok = !((M & 3) || (ldb & 3) || (gdisp_batch_stride & 3)) && !(reinterpret_cast<uintptr_t>(gdisp) & 15u) &&
+                      !(reinterpret_cast<uintptr_t>(basis) & (bf ? 7u : 15u));
+  if (!vec_ok) {  // odd voxel counts (3·D·W·H not a multiple of 4), sliced views
+    if (bf) hipLaunchKernelGGL(pca_bwd_scalar_kernel<true>, grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
+    else hipLaunchKernelGGL(pca_bwd_scalar_kernel<false>, grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
+  } else if (B > 4 && bf) hipLaunchKernelGGL((pca_bwd_kernel<8, true>), grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
   else if (B > 4) hipLaunchKernelGGL((pca_bwd_kernel<8, false>), grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
   else if (bf) hipLaunchKernelGGL((pca_bwd_kernel<4, true>), grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
   else hipLaunchKernelGGL((pca_bwd_kernel<4, false>), grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);

@@ -61,20 +61,61 @@ __global__ __launch_bounds__(256) void pca_kernel(const float* __restrict__ coef
     if (b_lo + b < B) *reinterpret_cast<float4*>(disp + (int64_t)(b_lo + b) * dstride + m) = acc[b];
 }
 
+// Any M / leading dimension / alignment (3·D·W·H is a multiple of 4 only when the voxel count is): one element per
+// thread, 8 batch rows per pass; same fmaf chain per element as the vector kernel.
+template <bool BF>
+__global__ __launch_bounds__(256) void pca_scalar_kernel(const float* __restrict__ coefs, const float* __restrict__ basis,
+                                                         const float* __restrict__ mean, float* __restrict__ disp, int B,
+                                                         int b_lo, int L, int64_t M, int64_t ldb, int64_t dstride) {
+  extern __shared__ float cs[];  // [L][8]
+  for (int t = threadIdx.x; t < L * 8; t += blockDim.x) {
+    const int l = t / 8, b = t % 8;
+    cs[t] = (b_lo + b < B) ? coefs[(int64_t)(b_lo + b) * L + l] : 0.0f;
+  }
+  __syncthreads();
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float acc[8];
+  const float mu = mean[m];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) acc[b] = mu;
+  for (int l = 0; l < L; ++l) {
+    float v;
+    if (BF) v = __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(basis)[(int64_t)l * ldb + m] << 16);
+    else v = basis[(int64_t)l * ldb + m];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[b] = fmaf(cs[l * 8 + b], v, acc[b]);
+  }
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+    if (b_lo + b < B) disp[(int64_t)(b_lo + b) * dstride + m] = acc[b];
+}
+
 }  // namespace
 
 static int pca_impl(const float* coefs, const float* basis, bool bf, const float* mean, float* disp, int B, int L,
                     int64_t M, int64_t ldb, int64_t disp_batch_stride, void* stream) {
   if (!coefs || !basis || !mean || !disp) return LR_ENULL;
-  if (B < 1 || B > 32 || L < 1 || L > 4096 || M < 4 || ldb < M || disp_batch_stride < M)
+  if (B < 1 || B > 32 || L < 1 || L > 4096 || M < 1 || ldb < M || disp_batch_stride < M)
     return LR_EINVAL;
-  if ((M & 3) || (ldb & 3) || (disp_batch_stride & 3)) return LR_EALIGN;
-  if ((reinterpret_cast<uintptr_t>(basis) | reinterpret_cast<uintptr_t>(mean) |
-       reinterpret_cast<uintptr_t>(disp)) & (bf ? 7u : 15u))
-    return LR_EALIGN;
+  hipStream_t st = lr_stream(stream);
+  const bool vec_ok = !((M & 3) || (ldb & 3) || (disp_batch_stride & 3)) &&
+                      !((reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(disp)) & 15u) &&
+                      !(reinterpret_cast<uintptr_t>(basis) & (bf ? 7u : 15u));
+  if (!vec_ok) {  // odd voxel counts, sliced views: the scalar kernel (same results, lower bandwidth)
+    const int64_t nb = (M + 255) / 256;
+    if (nb > 0x7fffffffLL) return LR_EINVAL;
+    for (int b_lo = 0; b_lo < B; b_lo += 8) {
+      if (bf) hipLaunchKernelGGL(pca_scalar_kernel<true>, dim3((unsigned)nb), dim3(256), (size_t)L * 8 * 4, st, coefs, basis,
+                                 mean, disp, B, b_lo, L, M, ldb, disp_batch_stride);
+      else hipLaunchKernelGGL(pca_scalar_kernel<false>, dim3((unsigned)nb), dim3(256), (size_t)L * 8 * 4, st, coefs, basis,
+                              mean, disp, B, b_lo, L, M, ldb, disp_batch_stride);
+      if (int e = lr_launch_status()) return e;
+    }
+    return LR_OK;
+  }
   const int64_t nblk = (M / 4 + 255) / 256;
   if (nblk > 0x7fffffffLL) return LR_EINVAL;
-  hipStream_t st = lr_stream(stream);
   // Batch tiles of 8 (4 for small batches): the basis is re-read once per tile.
   for (int b_lo = 0; b_lo < B;) {
     const int rem = B - b_lo;

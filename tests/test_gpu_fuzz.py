@@ -210,3 +210,49 @@ def test_fuzz_bf16_gradient_backward(dev):
         tag = str((cin, cout, shape, B))
         np.testing.assert_allclose(gw.cpu().numpy(), wr.grad.numpy(), rtol=3e-4, atol=4e-4, err_msg="gw " + tag)
         np.testing.assert_allclose(gb.cpu().numpy(), b0.grad.numpy(), rtol=3e-4, atol=4e-4, err_msg="gb " + tag)
+
+
+def test_fuzz_whole_model(dev):
+    """The plugin model end to end (fp32) on random non-cubic sizes, view counts, latent sizes, batch sizes, with and
+    without label masks, against the CPU oracle — forward outputs and, every other case, all parameter gradients."""
+    from liftreg_amd.losses.SubspaceLoss import loss as SubspaceLoss
+    from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+    rs = np.random.RandomState(106 + SEED)
+    opt = {"initial_reg_factor": 0.01, "min_reg_factor": 0.01, "reg_factor_decay_from": 2}
+    for case in range(max(2, N_CASES // 2)):
+        shape = tuple(int(v) for v in rs.randint(17, 41, 3))
+        P, L, B = int(rs.randint(1, 5)), int(rs.randint(2, 12)), int(rs.randint(1, 3))
+        Rd, Rh = int(rs.randint(8, 40)), int(rs.randint(8, 40))
+        labels = bool(rs.randint(0, 2))
+        torch.manual_seed(1000 + case)
+        net = model(list(shape), {"drr_feature_num": P, "latent_dim": L, "pca_path": f"synthetic:{case}"}).to(dev)
+        poses = ro.scan_poses(float(rs.uniform(15, 45)), P, shape[1]).astype(np.float32)
+        inp = {"source": torch.from_numpy(rs.uniform(-1, 1, (B, 1) + shape).astype(np.float32)),
+               "target": torch.from_numpy(rs.uniform(-1, 1, (B, 1) + shape).astype(np.float32)),
+               "target_proj": torch.from_numpy(rs.uniform(-1, 1, (B, P, Rd, Rh)).astype(np.float32)),
+               "target_poses": torch.from_numpy(np.broadcast_to(poses, (B, P, 3)).copy())}
+        if labels:
+            inp["source_label"] = torch.from_numpy((rs.uniform(0, 1, (B, 1) + shape) > 0.3).astype(np.float32))
+            inp["target_label"] = torch.from_numpy((rs.uniform(0, 1, (B, 1) + shape) > 0.3).astype(np.float32))
+        dinp = {k: v.to(dev) if k != "target_poses" else v for k, v in inp.items()}
+        train = case % 2 == 1
+        tag = str((shape, P, L, B, Rd, Rh, labels, train))
+        if train:
+            net.train()
+            out = net(dinp)
+            out["epoch"] = 0
+            SubspaceLoss(dict(opt))(out)["total_loss"].backward()
+            params = {k: v.detach().cpu().clone().requires_grad_("gaussian" not in k) for k, v in net.state_dict().items()}
+        else:
+            net.eval()
+            with torch.no_grad():
+                out = net(dinp)
+            params = {k: v.cpu() for k, v in net.state_dict().items()}
+        ref = ro.model_forward(params, inp, net.pca_vectors_LxM.cpu(), net.pca_mean.cpu())
+        for k in ("pca_coefs", "params", "phi", "warped", "target"):
+            np.testing.assert_allclose(out[k].detach().cpu().numpy(), ref[k].detach().numpy(), rtol=1e-4, atol=6e-5, err_msg=k + tag)
+        if train:
+            ro.subspace_loss(ref, 0, **opt)["total_loss"].backward()
+            for k, p in net.named_parameters():
+                g, w = p.grad.cpu().numpy(), params[k].grad.numpy()
+                assert np.abs(g - w).max() <= 2e-3 * max(np.abs(w).max(), 1e-12), (k, tag)
