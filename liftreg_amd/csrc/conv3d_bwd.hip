@@ -391,7 +391,9 @@ constexpr int WG_MAXT = 14;  // N-tiles per wave (27 taps * 2 channel blocks / 4
 template <int NTC>
 __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restrict__ xin,
                                                            const float* __restrict__ gpre,
-                                                           float* __restrict__ partial, WgDims d, int64_t ngroups) {
+                                                           float* __restrict__ partial, WgDims d, int64_t ngroups,
+                                                           int round_x /* x rounded to bf16 like the bf16 forward did */,
+                                                           int gbf /* gpre is bf16 storage */) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 15, kq = lane >> 4;
@@ -438,7 +440,11 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
     float a[NTC];
 #pragma unroll
     for (int nt = 0; nt < NTC; ++nt)
-      a[nt] = vok ? gpre[((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + ho) * d.Cout + nt * 16 + col] : 0.0f;
+    {
+      const int64_t go = ((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + ho) * d.Cout + nt * 16 + col;
+      a[nt] = !vok ? 0.0f
+                   : gbf ? __builtin_bit_cast(float, (unsigned)reinterpret_cast<const u16*>(gpre)[go] << 16) : gpre[go];
+    }
     const int zi0 = dz * d.stride - 1, yi0 = wo * d.stride - 1, xi0 = ho * d.stride - 1;
     const int64_t xb = (int64_t)b * d.Cin * V;
 #pragma unroll
@@ -450,7 +456,8 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
       if (d.x_layout == LR_LAYOUT_NCDHW) off = xb + coff[t] + ((int64_t)zi * d.W + yi) * d.H + xi;
       else if (d.x_layout == LR_LAYOUT_NDHWC) off = xb + (((int64_t)zi * d.W + yi) * d.H + xi) * d.Cin + coff[t];
       else off = xb + ((int64_t)zi * d.W + yi) * d.H * d.Cin + coff[t] + (int64_t)((xi & 1) * (d.H >> 1) + (xi >> 1)) * 16;
-      const float xv = ok ? xin[off] : 0.0f;
+      float xv = ok ? xin[off] : 0.0f;
+      if (round_x) xv = round_bf16(xv);
 #pragma unroll
       for (int nt = 0; nt < NTC; ++nt)
         acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nt], xv, acc[t][nt], 0, 0, 0);
@@ -1099,12 +1106,13 @@ __global__ __launch_bounds__(1024) void wgrad_finish_kernel(const float* __restr
 
 // bias gradient on the generic path: per-block channel sums of gpre (B*V, C) -> partial -> sum_partials_kernel
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ gpre, float* __restrict__ partial,
-                                                          int64_t nvox, int C) {
+                                                          int64_t nvox, int C, int gbf) {
   __shared__ float red[256];
   const int c = threadIdx.x % C, lanes = 256 / C;  // C in {16, 32}
   double s = 0.0;
   for (int64_t v = (int64_t)blockIdx.x * lanes + threadIdx.x / C; v < nvox; v += (int64_t)gridDim.x * lanes)
-    s += (double)gpre[v * C + c];
+    s += gbf ? (double)__builtin_bit_cast(float, (unsigned)reinterpret_cast<const u16*>(gpre)[v * C + c] << 16)
+             : (double)gpre[v * C + c];
   red[threadIdx.x] = (float)s;
   __syncthreads();
   if (threadIdx.x < C) {
@@ -1270,9 +1278,9 @@ static int wgrad_impl(const float* x, int x_layout, const float* gpre, int gbf, 
                        ncols, x_layout, planar ? 27 * Cin : d.ntiles * 16);
     return lr_launch_status();
   }
-  if (xbf || xround || gbf) return LR_EUNSUPPORTED;  // the generic kernel reads fp32 activations and gradients only
-  if (Cout == 16) hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, x, gpre, partial, d, ngroups);
-  else hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, x, gpre, partial, d, ngroups);
+  if (xbf) return LR_EUNSUPPORTED;  // the generic kernel reads fp32 activations (bf16 gradients and the rounded first-block input are fine)
+  if (Cout == 16) hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, x, gpre, partial, d, ngroups, (int)xround, gbf);
+  else hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, x, gpre, partial, d, ngroups, (int)xround, gbf);
   if (int e = lr_launch_status()) return e;
   const int n = Cout * d.ntiles * 16;
   hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, partial, gw, (float*)nullptr, nblk,
@@ -1283,7 +1291,7 @@ static int wgrad_impl(const float* x, int x_layout, const float* gpre, int gbf, 
     int64_t cap = (int64_t)nblk * d.ntiles * 16;  // rows of Cout floats the workspace holds
     if (cap > 1024) cap = 1024;
     const int nb = (int)(nvox < cap ? nvox : cap);
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(nb), dim3(256), 0, st, gpre, partial, nvox, Cout);
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(nb), dim3(256), 0, st, gpre, partial, nvox, Cout, gbf);
     if (int e = lr_launch_status()) return e;
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, gb, nb, Cout);
     return lr_launch_status();

@@ -256,3 +256,42 @@ def test_fuzz_whole_model(dev):
             for k, p in net.named_parameters():
                 g, w = p.grad.cpu().numpy(), params[k].grad.numpy()
                 assert np.abs(g - w).max() <= 2e-3 * max(np.abs(w).max(), 1e-12), (k, tag)
+
+
+def test_fuzz_bf16_model_modes(dev):
+    """conv_dtype / grad_dtype / pca_dtype = bf16 on random (odd, non-multiple-of-4) sizes: the forward against the CPU
+    restatement of the bf16 contract, and a training step in every mode runs and yields finite gradients close to the
+    fp32-gradient mode's (the per-kernel contracts are pinned elsewhere; this hunts for unsupported-shape failures)."""
+    from liftreg_amd.losses.SubspaceLoss import loss as SubspaceLoss
+    from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+    rs = np.random.RandomState(107 + SEED)
+    opt = {"initial_reg_factor": 0.01, "min_reg_factor": 0.01, "reg_factor_decay_from": 2}
+    for case in range(max(2, N_CASES // 2)):
+        shape = tuple(int(v) for v in rs.randint(17, 37, 3))
+        P, L, B = int(rs.randint(1, 4)), int(rs.randint(2, 9)), int(rs.randint(1, 3))
+        poses = ro.scan_poses(30.0, P, shape[1]).astype(np.float32)
+        inp = {"source": torch.from_numpy(rs.uniform(-1, 1, (B, 1) + shape).astype(np.float32)).to(dev),
+               "target": torch.from_numpy(rs.uniform(-1, 1, (B, 1) + shape).astype(np.float32)).to(dev),
+               "target_proj": torch.from_numpy(rs.uniform(-1, 1, (B, P, 24, 28)).astype(np.float32)).to(dev),
+               "target_poses": torch.from_numpy(np.broadcast_to(poses, (B, P, 3)).copy())}
+        grads = {}
+        for gd, pd in (("fp32", "fp32"), ("bf16", "fp32"), ("bf16", "bf16")):
+            torch.manual_seed(500 + case)
+            net = model(list(shape), {"drr_feature_num": P, "latent_dim": L, "pca_path": f"synthetic:{case}", "conv_dtype": "bf16",
+                                      "grad_dtype": gd, "pca_dtype": pd}).to(dev).train()
+            out = net(inp)
+            out["epoch"] = 0
+            SubspaceLoss(dict(opt))(out)["total_loss"].backward()
+            g = torch.cat([p.grad.flatten() for p in net.parameters()])
+            assert torch.isfinite(g).all(), (shape, gd, pd)
+            grads[(gd, pd)] = g
+            if (gd, pd) == ("fp32", "fp32"):       # forward against the restatement of the bf16 contract
+                sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+                ref = ro.model_forward(sd, {k: v.cpu() for k, v in inp.items()}, net.pca_vectors_LxM.float().cpu(), net.pca_mean.cpu(),
+                                       conv_dtype="bf16")
+                scale = float(ref["pca_coefs"].abs().max())
+                assert float((out["pca_coefs"].detach().cpu() - ref["pca_coefs"]).abs().max()) <= 5e-3 * scale, shape
+        base = grads[("fp32", "fp32")]
+        for key in (("bf16", "fp32"), ("bf16", "bf16")):
+            cos = float(torch.dot(grads[key], base) / (grads[key].norm() * base.norm()))
+            assert cos > 0.99, (shape, key, cos)
