@@ -295,3 +295,36 @@ def test_fuzz_bf16_model_modes(dev):
         for key in (("bf16", "fp32"), ("bf16", "bf16")):
             cos = float(torch.dot(grads[key], base) / (grads[key].norm() * base.norm()))
             assert cos > 0.99, (shape, key, cos)
+
+
+def test_fuzz_slab_sharded_forward(dev):
+    """z-slab sharded forward == unsharded forward, bit for bit, on random W/H (odd, non-cubic), batch and view counts,
+    fp32 and bf16 activations, with and without label masks (D must stay a multiple of 32·world)."""
+    from liftreg_amd import parallel as par
+    from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+    rs = np.random.RandomState(108 + SEED)
+    for case in range(max(2, N_CASES // 3)):
+        world = int(rs.choice([2, 4]))
+        D = 32 * world * int(rs.randint(1, 3)) if world == 2 else 128
+        W, H = int(rs.randint(17, 40)), int(rs.randint(17, 40))
+        P, L, B = int(rs.randint(1, 4)), int(rs.randint(2, 7)), int(rs.randint(1, 3))
+        cd = str(rs.choice(["fp32", "bf16"]))
+        torch.manual_seed(case)
+        net = model([D, W, H], {"drr_feature_num": P, "latent_dim": L, "pca_path": f"synthetic:{case}", "conv_dtype": cd}).to(dev).eval()
+        poses = ro.scan_poses(30.0, P, W).astype(np.float32)
+        inp = {"source": torch.from_numpy(rs.uniform(-1, 1, (B, 1, D, W, H)).astype(np.float32)).to(dev),
+               "target": torch.from_numpy(rs.uniform(-1, 1, (B, 1, D, W, H)).astype(np.float32)).to(dev),
+               "target_proj": torch.from_numpy(rs.uniform(-1, 1, (B, P, 20, 24)).astype(np.float32)).to(dev),
+               "target_poses": torch.from_numpy(np.broadcast_to(poses, (B, P, 3)).copy())}
+        if rs.randint(0, 2):
+            inp["source_label"] = torch.from_numpy((rs.uniform(0, 1, (B, 1, D, W, H)) > 0.3).astype(np.float32)).to(dev)
+            inp["target_label"] = torch.from_numpy((rs.uniform(0, 1, (B, 1, D, W, H)) > 0.3).astype(np.float32)).to(dev)
+        with torch.no_grad():
+            ref = net(inp)
+            outs = par.SlabShardedRegistration(net, par.LocalComm(world)).forward([inp] * world)
+        tag = str((world, D, W, H, P, L, B, cd, "source_label" in inp))
+        for r, o in enumerate(outs):
+            d0, d1 = par.slab_bounds(D, world, r)
+            assert torch.equal(o["pca_coefs"], ref["pca_coefs"]), "coefs " + tag
+            assert torch.equal(o["params"], ref["params"][:, :, d0:d1]), "params " + tag
+            assert torch.equal(o["warped"], ref["warped"][:, :, d0:d1]), "warped " + tag
