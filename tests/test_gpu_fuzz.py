@@ -328,3 +328,91 @@ def test_fuzz_slab_sharded_forward(dev):
             assert torch.equal(o["pca_coefs"], ref["pca_coefs"]), "coefs " + tag
             assert torch.equal(o["params"], ref["params"][:, :, d0:d1]), "params " + tag
             assert torch.equal(o["warped"], ref["warped"][:, :, d0:d1]), "warped " + tag
+
+
+def test_fuzz_warp_variants_and_slabs(dev):
+    """Warp modes (nearest / border / no scaling / label mask), slab rows [d0,d1) of warp and DRR, on random extents."""
+    from liftreg_amd import ops
+    rs = np.random.RandomState(109 + SEED)
+    for _ in range(N_CASES):
+        shape = _shape(rs, 2, 16)
+        D = shape[0]
+        B, C = int(rs.randint(1, 3)), int(rs.randint(1, 3))
+        img = rs.uniform(-1, 1, (B, C) + shape).astype(np.float32)
+        seg = (rs.uniform(0, 1, (B, C) + shape) > 0.4).astype(np.float32) if rs.randint(0, 2) else None
+        disp = rs.normal(0, 0.35, (B, 3) + shape).astype(np.float32)
+        tabs = ro.identity_axis_tables(shape)
+        flags = (co.USING_SCALE if rs.randint(0, 2) else 0) | (co.BORDER if rs.randint(0, 2) else 0) | (co.NEAREST if rs.randint(0, 3) == 0 else 0)
+        want_phi, want = co.warp(img, disp, tabs, seg, flags=flags)
+        kw = dict(using_scale=bool(flags & co.USING_SCALE), zero_boundary=not (flags & co.BORDER),
+                  mode="nearest" if flags & co.NEAREST else "bilinear")
+        ids = [T(t, dev) for t in tabs]
+        phi, warped = ops.warp(T(img, dev), T(disp, dev), ids, None if seg is None else T(seg, dev), **kw)
+        assert np.array_equal(phi.cpu().numpy(), want_phi) and np.array_equal(warped.cpu().numpy(), want), ("warp", shape, flags)
+        if D >= 3:       # a slab of rows is the same rows of the whole
+            d0 = int(rs.randint(0, D - 1)); d1 = int(rs.randint(d0 + 1, D + 1))
+            ids_s = [T(tabs[0][d0:d1], dev), ids[1], ids[2]]
+            _, ws = ops.warp(T(img, dev), T(disp[:, :, d0:d1], dev), ids_s, None if seg is None else T(seg, dev), d0=d0, d1=d1, **kw)
+            assert np.array_equal(ws.cpu().numpy(), want[:, :, d0:d1]), ("warp slab", shape, d0, d1, flags)
+        # DRR: slab partial images add up to the whole
+        P, Rd, Rh = int(rs.randint(1, 4)), int(rs.randint(3, 20)), int(rs.randint(3, 40))
+        poses = ro.scan_poses(30.0, P, shape[1]).astype(np.float32)
+        sp = np.array((2.2, 2.2, 2.2), np.float32)
+        vol = rs.uniform(0, 0.3, shape).astype(np.float32)
+        full = ops.drr_forward(T(vol, dev), poses, (Rd, Rh), sp, nseg=1)
+        if D >= 2:
+            cut = int(rs.randint(1, D))
+            a = ops.drr_forward(T(vol[:cut], dev), poses, (Rd, Rh), sp, d0=0, d1=cut, full_D=D, nseg=1)
+            b = ops.drr_forward(T(vol[cut:], dev), poses, (Rd, Rh), sp, d0=cut, d1=D, full_D=D, nseg=1)
+            np.testing.assert_allclose((a + b).cpu().numpy(), full.cpu().numpy(), rtol=2e-5, atol=1e-6, err_msg=str(("drr slabs", shape, cut)))
+
+
+def test_fuzz_small_backward_ops(dev):
+    """NCC / warp / PCA / Linear / regulariser gradients on random extents against ATen autograd of the oracle."""
+    from liftreg_amd import ops, ops_bwd
+    rs = np.random.RandomState(110 + SEED)
+    for _ in range(N_CASES):
+        shape = _shape(rs, 2, 14)
+        B, C = int(rs.randint(1, 3)), int(rs.randint(1, 3))
+        # NCC
+        for variant, f in ((0, ro.ncc_loss), (1, ro.ncc_loss_squared)):
+            x = rs.uniform(-1, 1, (B, C) + shape).astype(np.float32)
+            y = (0.5 * x + 0.5 * rs.uniform(-1, 1, x.shape)).astype(np.float32)
+            xt = torch.from_numpy(x).requires_grad_(True)
+            (f(xt, torch.from_numpy(y)) * 1.3).backward()
+            R = B if variant == 0 else B * C
+            m = ops.ncc_moments(T(x, dev), T(y, dev), R)
+            gx = ops_bwd.ncc_bwd(T(x, dev), T(y, dev), m, torch.tensor(1.3, device=dev), x.size // R, variant)
+            np.testing.assert_allclose(gx.cpu().numpy(), xt.grad.numpy(), rtol=3e-4, atol=1e-7, err_msg=str(("ncc", variant, shape)))
+        # warp w.r.t. displacement
+        img = rs.uniform(-1, 1, (B, C) + shape).astype(np.float32)
+        disp = rs.normal(0, 0.25, (B, 3) + shape).astype(np.float32)
+        gw = rs.normal(0, 1, (B, C) + shape).astype(np.float32)
+        zb = bool(rs.randint(0, 2))
+        d = torch.from_numpy(disp).requires_grad_(True)
+        ro.warp(torch.from_numpy(img), d + ro.identity_map(shape), zero_boundary=zb, using_scale=True).backward(torch.from_numpy(gw))
+        got = ops_bwd.warp_bwd_disp(T(img, dev), T(disp, dev), [T(t, dev) for t in ro.identity_axis_tables(shape)], None, T(gw, dev),
+                                    using_scale=True, zero_boundary=zb)
+        np.testing.assert_allclose(got.cpu().numpy(), d.grad.numpy(), rtol=2e-4, atol=3e-5, err_msg=str(("warp_bwd", shape, zb)))
+        # regulariser
+        d2 = torch.from_numpy(disp).requires_grad_(True)
+        (ro.disp_reg(d2) * 0.7).backward()
+        gr = ops_bwd.disp_reg_bwd(T(disp, dev), torch.tensor(0.7, device=dev))
+        np.testing.assert_allclose(gr.cpu().numpy(), d2.grad.numpy(), rtol=2e-4, atol=1e-7, err_msg=str(("reg_bwd", shape)))
+        # PCA coefficients (any M now) and Linear
+        Lat, M = int(rs.randint(1, 15)), int(rs.randint(5, 900))
+        gd, basis = rs.normal(0, 1, (B, M)).astype(np.float32), rs.normal(0, 0.05, (Lat, M)).astype(np.float32)
+        np.testing.assert_allclose(ops_bwd.pca_bwd_coef(T(gd, dev), T(basis, dev)).cpu().numpy(), gd.astype(np.float64) @ basis.T,
+                                   rtol=2e-4, atol=1e-5, err_msg=str(("pca_bwd", B, Lat, M)))
+        K, O = int(rs.randint(3, 300)), int(rs.randint(1, 40))
+        slope = float(rs.choice([0.2, 1.0]))
+        xl = rs.uniform(-1, 1, (B, K)).astype(np.float32)
+        wl = (rs.normal(0, 1, (O, K)) / np.sqrt(K)).astype(np.float32)
+        bl = rs.uniform(-0.1, 0.1, O).astype(np.float32)
+        gyl = rs.normal(0, 1, (B, O)).astype(np.float32)
+        xt, wt, bt = (torch.from_numpy(a).requires_grad_(True) for a in (xl, wl, bl))
+        ro.fc_block(xt, wt, bt, None if slope == 1.0 else slope).backward(torch.from_numpy(gyl))
+        yl = ops.linear_lrelu(T(xl, dev), T(wl, dev), T(bl, dev), slope)
+        gxl, gwl, gbl = ops_bwd.linear_bwd(T(xl, dev), T(wl, dev), yl, T(gyl, dev), slope)
+        for got_, want_, nm in ((gxl, xt.grad, "gx"), (gwl, wt.grad, "gw"), (gbl, bt.grad, "gb")):
+            np.testing.assert_allclose(got_.cpu().numpy(), want_.numpy(), rtol=2e-4, atol=2e-5, err_msg=str(("linear", nm, B, K, O)))
