@@ -25,8 +25,14 @@ def T(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
+LONG_H = int(os.environ.get("LIFTREG_FUZZ_LONG_H", "0"))   # > 0: rows up to this long (crosses the 64/256-voxel tile edges)
+
+
 def _shape(rs, lo=2, hi=23):
-    return tuple(int(v) for v in rs.randint(lo, hi, 3))
+    d, w, h = (int(v) for v in rs.randint(lo, hi, 3))
+    if LONG_H:
+        d, w, h = min(d, 6), min(w, 7), int(rs.randint(40, LONG_H + 1))
+    return d, w, h
 
 
 def test_fuzz_projector_and_backprojection(dev):
@@ -120,8 +126,11 @@ def test_fuzz_conv_forward_and_backward(dev):
                                    err_msg="fwd " + tag)
         gx, gw, gb = ops_bwd.conv3d_bwd(xd, xl, T(w, dev), yd, yl, to_layout(T(gy, dev), ops.LAYOUT_NDHWC), ops.LAYOUT_NDHWC, s,
                                         need_gx=not first, nblk=int(rs.choice([1, 8, 64])))
-        np.testing.assert_allclose(gw.cpu().numpy(), wt.grad.numpy(), rtol=3e-4, atol=3e-5, err_msg="gw " + tag)
-        np.testing.assert_allclose(gb.cpu().numpy(), bt.grad.numpy(), rtol=3e-4, atol=3e-5, err_msg="gb " + tag)
+        # sums over thousands of voxels: the absolute tolerance follows the gradient's own scale
+        np.testing.assert_allclose(gw.cpu().numpy(), wt.grad.numpy(), rtol=3e-4, atol=3e-5 * max(1.0, float(wt.grad.abs().max())),
+                                   err_msg="gw " + tag)
+        np.testing.assert_allclose(gb.cpu().numpy(), bt.grad.numpy(), rtol=3e-4, atol=3e-5 * max(1.0, float(bt.grad.abs().max())),
+                                   err_msg="gb " + tag)
         if not first:
             gxp = ops.hps_to_ndhwc(gx) if xl == ops.LAYOUT_NDHWC_HPS else gx
             np.testing.assert_allclose(gxp.permute(0, 4, 1, 2, 3).cpu().numpy(), xt.grad.numpy(), rtol=3e-4, atol=3e-5,
@@ -208,8 +217,10 @@ def test_fuzz_bf16_gradient_backward(dev):
             assert flips <= max(2, 0.01 * got.size), (cin, shape, B, flips)
             np.testing.assert_allclose(got, want_gx.numpy(), rtol=2.0 ** -7, atol=1e-6, err_msg=str((cin, shape, B)))
         tag = str((cin, cout, shape, B))
-        np.testing.assert_allclose(gw.cpu().numpy(), wr.grad.numpy(), rtol=3e-4, atol=4e-4, err_msg="gw " + tag)
-        np.testing.assert_allclose(gb.cpu().numpy(), b0.grad.numpy(), rtol=3e-4, atol=4e-4, err_msg="gb " + tag)
+        np.testing.assert_allclose(gw.cpu().numpy(), wr.grad.numpy(), rtol=3e-4, atol=4e-4 * max(1.0, float(wr.grad.abs().max()) / 10),
+                                   err_msg="gw " + tag)
+        np.testing.assert_allclose(gb.cpu().numpy(), b0.grad.numpy(), rtol=3e-4, atol=4e-4 * max(1.0, float(b0.grad.abs().max()) / 10),
+                                   err_msg="gb " + tag)
 
 
 def test_fuzz_whole_model(dev):
@@ -393,7 +404,9 @@ def test_fuzz_small_backward_ops(dev):
         ro.warp(torch.from_numpy(img), d + ro.identity_map(shape), zero_boundary=zb, using_scale=True).backward(torch.from_numpy(gw))
         got = ops_bwd.warp_bwd_disp(T(img, dev), T(disp, dev), [T(t, dev) for t in ro.identity_axis_tables(shape)], None, T(gw, dev),
                                     using_scale=True, zero_boundary=zb)
-        np.testing.assert_allclose(got.cpu().numpy(), d.grad.numpy(), rtol=2e-4, atol=3e-5, err_msg=str(("warp_bwd", shape, zb)))
+        # the gradient carries the un-normalisation factor (size-1)/2 of its axis: fp32 cancellation scales with it
+        np.testing.assert_allclose(got.cpu().numpy(), d.grad.numpy(), rtol=2e-4, atol=max(3e-5, 1.5e-6 * max(shape)),
+                                   err_msg=str(("warp_bwd", shape, zb)))
         # regulariser
         d2 = torch.from_numpy(disp).requires_grad_(True)
         (ro.disp_reg(d2) * 0.7).backward()
