@@ -362,6 +362,8 @@ def linear_lrelu(x, weight, bias, negative_slope=1.0):
     O = w.shape[0]
     if w.shape[1] != K:
         raise ValueError(f"weight expects K={w.shape[1]}, input has {K}")
+    if B > 32:     # the kernel holds the whole batch per block (B <= 32): larger batches go in chunks
+        return torch.cat([linear_lrelu(x[i:i + 32], weight, bias, negative_slope) for i in range(0, B, 32)], 0)
     y = torch.empty((B, O), dtype=torch.float32, device=x.device)
     with _timed(f"linear_{K}x{O}", bytes=4 * (w.numel() + x.numel() + y.numel())):
         _hip.check(_hip.lib().lr_linear_lrelu_f32(x.data_ptr(), w.data_ptr(), _ptr(b), y.data_ptr(), B, K, O,
@@ -388,6 +390,10 @@ def pca_reconstruct(coefs, basis_LxM, mean, *, out=None):
         out = torch.empty((B, M), dtype=torch.float32, device=coefs.device)
     else:
         out = _dev(out, "out")
+    if B > 32:     # the entry point tiles up to 32 batch rows: larger batches in chunks (the basis is re-read per chunk)
+        for i in range(0, B, 32):
+            pca_reconstruct(coefs[i:i + 32], basis_LxM, mean, out=out[i:i + 32])
+        return out
     fn = _hip.lib().lr_pca_reconstruct_bf16basis_f32 if bf else _hip.lib().lr_pca_reconstruct_f32
     with _timed("pca_reconstruct" + ("_bf16basis" if bf else ""), bytes=(2 if bf else 4) * L * M + 4 * (M + B * M), samples=B):
         _hip.check(fn(coefs.data_ptr(), basis_LxM.data_ptr(), mean.data_ptr(), out.data_ptr(), B, L, M,

@@ -49,6 +49,8 @@ def pca_bwd_coef(gdisp, basis_LxM, nblk=None):
     L, M = basis_LxM.shape
     if g2.shape[1] != M or basis_LxM.stride(1) != 1:
         raise ValueError("gdisp/basis shape mismatch")
+    if B > 8:      # the kernel keeps 8 batch rows of accumulators per thread: larger batches go in chunks of 8
+        return torch.cat([pca_bwd_coef(g2[i:i + 8], basis_LxM, nblk) for i in range(0, B, 8)], 0)
     if nblk is None:
         nblk = max(1, min(512, M // 4096))
     partial = torch.empty((nblk, B, L), dtype=torch.float32, device=gdisp.device)
@@ -202,6 +204,10 @@ def linear_bwd(x, weight, y, gy, negative_slope=1.0, need_gx=True):
     w = _dev(weight.detach(), "weight")
     B, K = x.shape
     O = w.shape[0]
+    if B > 32:     # chunks of 32 batch rows: gx concatenates, gw / gb add
+        parts = [linear_bwd(x[i:i + 32], weight, y[i:i + 32], gy[i:i + 32], negative_slope, need_gx) for i in range(0, B, 32)]
+        gx = torch.cat([p[0] for p in parts], 0) if need_gx else None
+        return gx, torch.stack([p[1] for p in parts]).sum(0), torch.stack([p[2] for p in parts]).sum(0)
     gx = torch.empty_like(x) if need_gx else None
     gw = torch.empty_like(w)
     gb = torch.empty((O,), dtype=torch.float32, device=x.device)

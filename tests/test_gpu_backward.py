@@ -153,3 +153,30 @@ def test_disp_reg_backward(dev):
         (ro.disp_reg(d) * 0.3).backward()
         got = ops_bwd.disp_reg_bwd(T(disp, dev), torch.tensor(0.3, device=dev))
         np.testing.assert_allclose(got.cpu().numpy(), d.grad.numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_large_batches_are_chunked(dev):
+    """Batch sizes past the kernels' per-block limits (PCA gradient 8, Linear 32) go through in chunks."""
+    from liftreg_amd import ops, ops_bwd
+    rs = np.random.RandomState(8)
+    B, K, O = 70, 96, 24
+    x = rs.uniform(-1, 1, (B, K)).astype(np.float32)
+    w = (rs.normal(0, 1, (O, K)) / np.sqrt(K)).astype(np.float32)
+    b = rs.uniform(-0.1, 0.1, O).astype(np.float32)
+    gy = rs.normal(0, 1, (B, O)).astype(np.float32)
+    xt, wt, bt = (torch.from_numpy(a).requires_grad_(True) for a in (x, w, b))
+    yref = ro.fc_block(xt, wt, bt, 0.2)
+    yref.backward(torch.from_numpy(gy))
+    y = ops.linear_lrelu(T(x, dev), T(w, dev), T(b, dev), 0.2)
+    np.testing.assert_allclose(y.cpu().numpy(), yref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    gx, gw, gb = ops_bwd.linear_bwd(T(x, dev), T(w, dev), y, T(gy, dev), 0.2)
+    np.testing.assert_allclose(gx.cpu().numpy(), xt.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gw.cpu().numpy(), wt.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gb.cpu().numpy(), bt.grad.numpy(), rtol=1e-4, atol=1e-5)
+    Lat, M = 7, 1000
+    g = rs.normal(0, 1, (19, M)).astype(np.float32)
+    basis = rs.normal(0, 0.05, (Lat, M)).astype(np.float32)
+    np.testing.assert_allclose(ops_bwd.pca_bwd_coef(T(g, dev), T(basis, dev)).cpu().numpy(), g.astype(np.float64) @ basis.T, rtol=1e-4, atol=1e-5)
+    coefs = rs.normal(0, 1, (40, Lat)).astype(np.float32)          # forward PCA: the C entry point tiles up to 32 rows
+    got = ops.pca_reconstruct(T(coefs, dev), T(basis, dev), T(np.zeros(M, np.float32), dev))
+    np.testing.assert_allclose(got.cpu().numpy(), coefs.astype(np.float64) @ basis, rtol=1e-4, atol=1e-5)

@@ -232,7 +232,7 @@ def test_fuzz_whole_model(dev):
     opt = {"initial_reg_factor": 0.01, "min_reg_factor": 0.01, "reg_factor_decay_from": 2}
     for case in range(max(2, N_CASES // 2)):
         shape = tuple(int(v) for v in rs.randint(17, 41, 3))
-        P, L, B = int(rs.randint(1, 5)), int(rs.randint(2, 12)), int(rs.randint(1, 3))
+        P, L, B = int(rs.randint(1, 5)), int(rs.randint(2, 12)), int(rs.choice([1, 2, 3, 9, 13]))   # > 8: batch-chunked PCA paths
         Rd, Rh = int(rs.randint(8, 40)), int(rs.randint(8, 40))
         labels = bool(rs.randint(0, 2))
         torch.manual_seed(1000 + case)
