@@ -144,15 +144,21 @@ constexpr int LG = 8;
 template <int BT, bool BF /* bf16-stored basis */>
 __global__ __launch_bounds__(256) void pca_bwd_kernel(const float* __restrict__ g, const float* __restrict__ basis,
                                                       float* __restrict__ partial, int B, int L, int64_t M,
-                                                      int64_t ldb, int64_t gstride) {
-  const int l0 = blockIdx.y * LG;
+                                                      int64_t ldb, int64_t gstride, int nblk) {
+  // 1-D launch order: the l-groups of one m-range are issued together and land on the SAME XCD (ids 8 apart), so the
+  // gradient rows they all read come from HBM once and from that XCD's L2 afterwards (they walk m in near lockstep).
+  const unsigned ng = (unsigned)((L + LG - 1) / LG), per8 = ng * 8u;
+  const unsigned q = blockIdx.x / per8, r = blockIdx.x - q * per8;
+  const unsigned bx = q * 8u + (r & 7u);
+  if (bx >= (unsigned)nblk) return;
+  const int l0 = (int)(r >> 3) * LG;
   float acc[LG][BT];
 #pragma unroll
   for (int a = 0; a < LG; ++a)
 #pragma unroll
     for (int b = 0; b < BT; ++b) acc[a][b] = 0.0f;
-  const int64_t step = (int64_t)gridDim.x * 256 * 4;
-  for (int64_t m = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; m < M; m += step) {
+  const int64_t step = (int64_t)nblk * 256 * 4;
+  for (int64_t m = ((int64_t)bx * 256 + threadIdx.x) * 4; m < M; m += step) {
     f32x4 gv[BT];
 #pragma unroll
     for (int b = 0; b < BT; ++b)
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256) void pca_bwd_kernel(const float* __restrict__ 
   if (threadIdx.x < LG * BT) {
     const int a = threadIdx.x / BT, b = threadIdx.x % BT;
     if (l0 + a < L && b < B)
-      partial[((int64_t)blockIdx.x * B + b) * L + l0 + a] =
+      partial[((int64_t)bx * B + b) * L + l0 + a] =
           (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
   }
 }
@@ -353,10 +359,13 @@ static int pca_bwd_impl(bool bf, const float* gdisp, const float* basis, float* 
   if (!vec_ok) {  // odd voxel counts (3·D·W·H not a multiple of 4), sliced views
     if (bf) hipLaunchKernelGGL(pca_bwd_scalar_kernel<true>, grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
     else hipLaunchKernelGGL(pca_bwd_scalar_kernel<false>, grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
-  } else if (B > 4 && bf) hipLaunchKernelGGL((pca_bwd_kernel<8, true>), grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
-  else if (B > 4) hipLaunchKernelGGL((pca_bwd_kernel<8, false>), grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
-  else if (bf) hipLaunchKernelGGL((pca_bwd_kernel<4, true>), grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
-  else hipLaunchKernelGGL((pca_bwd_kernel<4, false>), grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
+  } else {
+    const dim3 g1((unsigned)((nblk + 7) / 8) * 8u * (unsigned)((L + LG - 1) / LG));
+    if (B > 4 && bf) hipLaunchKernelGGL((pca_bwd_kernel<8, true>), g1, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride, nblk);
+    else if (B > 4) hipLaunchKernelGGL((pca_bwd_kernel<8, false>), g1, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride, nblk);
+    else if (bf) hipLaunchKernelGGL((pca_bwd_kernel<4, true>), g1, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride, nblk);
+    else hipLaunchKernelGGL((pca_bwd_kernel<4, false>), g1, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride, nblk);
+  }
   if (int e = lr_launch_status()) return e;
   const int n = B * L;
   hipLaunchKernelGGL(sum_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partial, gcoefs, nblk, n);

@@ -196,6 +196,131 @@ __global__ __launch_bounds__(256) void warp_kernel(
   }
 }
 
+// ---- the model's case (trilinear, zeros padding, float4 rows, no mask) with a third of the vector-ALU work ------
+// The general kernel above spends its time in the vector ALU, not in memory (64-bit index arithmetic, integer
+// divisions, per-tap range flags and selects: ≈300 instruction slots per voxel).  Same arithmetic, same results:
+//  * taps are fetched with bounds-checked raw buffer loads relative to the (b,c) image: 32-bit offsets built with
+//    full-rate 24-bit multiplies; a tap plane z = -1 or z = D falls outside the resource by itself and reads 0, an
+//    out-of-range y row (or a sample with any axis out of range) is pushed outside with one select on the row term;
+//  * an out-of-range tap is removed through its axis weight (one select per axis side) instead of per-tap flags;
+//    its value never matters because it is the 0 the buffer unit returns (finite whatever the image holds);
+//  * the two x taps are one 8-byte load at x0; only where a wave touches the x faces (x0 = -1 or H-1) a
+//    wave-uniform branch re-bases the pair and zeroes the missing tap;
+//  * (I+1)/2 … ·2-1: halving is exact, so interpolating I+1 and subtracting 1 gives the same bits
+//    (fl(fl(v+1)·w)/2 = fl((fl(v+1)/2)·w), no underflow: weights are ≥ 2^-25 or 0);
+//  * grid = (blocks in a plane, plane, batch element): the only per-thread division is by H/4, done in float.
+// (the 8-byte buffer loads go through HIP's uint2: element access on the builtin's own ext-vector result gets
+//  narrowed to a 4-byte load by this compiler, leaving .y undefined)
+struct AxisF {
+  float w0, w1;  // weights of taps i0 / i0+1, zero where the tap (or the whole axis) is out of range
+  int i0;        // floor(pix), 0 when the axis is out of range
+  bool valid;
+};
+
+__device__ __forceinline__ AxisF axis_fast(float g, int size) {
+  const float pix = lr_unnormalize(g, size);
+  AxisF a;
+  a.valid = pix > -1.0f && pix < (float)size;
+  const float fl = floorf(pix);
+  a.i0 = a.valid ? (int)fl : 0;
+  const float w0 = (fl + 1.0f) - pix, w1 = pix - fl;
+  a.w0 = (a.valid && a.i0 >= 0) ? w0 : 0.0f;
+  a.w1 = (a.valid && a.i0 + 1 < size) ? w1 : 0.0f;
+  return a;
+}
+
+template <bool SCALE>
+__global__ __launch_bounds__(256) void warp_tri_fast_kernel(
+    const float* __restrict__ img, const float* __restrict__ disp, const float* __restrict__ id0,
+    const float* __restrict__ id1, const float* __restrict__ id2, float* __restrict__ phi_out,
+    float* __restrict__ warped, int C, int D, int W, int H, int Dn, float rcp_hv) {
+  const int HV = H >> 2;
+  const int t = blockIdx.x * 256 + threadIdx.x;  // float4 index inside plane i
+  const int i = blockIdx.y, b = blockIdx.z;
+  const int j = (int)(((float)t + 0.5f) * rcp_hv);  // exact: t < 2^20, (t+0.5)/HV is ≥ 0.5/HV away from an integer
+  if (j >= W) return;
+  const int kv = t - __mul24(j, HV);
+  const int sD = W * H;
+  const int64_t slabV = (int64_t)Dn * sD, V = (int64_t)D * sD;
+  const int inplane = __mul24(j, H) + (kv << 2);
+  const int64_t ubase = (int64_t)b * 3 * slabV + (int64_t)i * sD;  // wave-uniform
+
+  const float* dp = disp + ubase + inplane;
+  const float4 da = *reinterpret_cast<const float4*>(dp);
+  const float4 db = *reinterpret_cast<const float4*>(dp + slabV);
+  const float4 dc = *reinterpret_cast<const float4*>(dp + 2 * slabV);
+  float d0v[4] = {da.x, da.y, da.z, da.w}, d1v[4] = {db.x, db.y, db.z, db.w}, d2v[4] = {dc.x, dc.y, dc.z, dc.w};
+  if (id0) {  // deform_field = disp_field + id_transform
+    const float a0 = id0[i], a1 = id1[j];
+    const float4 a2 = *reinterpret_cast<const float4*>(id2 + (kv << 2));
+    const float a2v[4] = {a2.x, a2.y, a2.z, a2.w};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      d0v[v] = d0v[v] + a0;
+      d1v[v] = d1v[v] + a1;
+      d2v[v] = d2v[v] + a2v[v];
+    }
+  }
+  if (phi_out) {
+    float* pp = phi_out + ubase + inplane;
+    *reinterpret_cast<float4*>(pp) = make_float4(d0v[0], d0v[1], d0v[2], d0v[3]);
+    *reinterpret_cast<float4*>(pp + slabV) = make_float4(d1v[0], d1v[1], d1v[2], d1v[3]);
+    *reinterpret_cast<float4*>(pp + 2 * slabV) = make_float4(d2v[0], d2v[1], d2v[2], d2v[3]);
+  }
+
+  constexpr int OUTSIDE = 0x20000000;  // elements; ·4 bytes = 2^31 ≥ any resource length accepted by the launcher
+  for (int c = 0; c < C; ++c) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(img + ((int64_t)b * C + c) * V), (short)0, (int)(V * 4), 0x00020000);
+    float res[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      // grid (x,y,z) = phi channels (2,1,0): x ↔ H, y ↔ W, z ↔ D
+      const AxisF ax = axis_fast(d2v[v], H), ay = axis_fast(d1v[v], W), az = axis_fast(d0v[v], D);
+      const bool all = ax.valid && ay.valid && az.valid;
+      const int y0 = (all && ay.i0 >= 0) ? __mul24(ay.i0, H) : OUTSIDE;
+      const int y1 = (all && ay.i0 + 1 < W) ? __mul24(ay.i0 + 1, H) : OUTSIDE;
+      const int z0 = __mul24(az.i0, sD), z1 = z0 + sD;
+      const int xb = min(max(ax.i0, 0), H - 2);
+      const unsigned xb4 = (unsigned)xb << 2;
+      const unsigned o00 = ((unsigned)(z0 + y0) << 2) + xb4, o01 = ((unsigned)(z0 + y1) << 2) + xb4;
+      const unsigned o10 = ((unsigned)(z1 + y0) << 2) + xb4, o11 = ((unsigned)(z1 + y1) << 2) + xb4;
+      const uint2 q00 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, o00, 0, 0));
+      const uint2 q01 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, o01, 0, 0));
+      const uint2 q10 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, o10, 0, 0));
+      const uint2 q11 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, o11, 0, 0));
+      float tp[8] = {__builtin_bit_cast(float, q00.x), __builtin_bit_cast(float, q00.y),
+                     __builtin_bit_cast(float, q01.x), __builtin_bit_cast(float, q01.y),
+                     __builtin_bit_cast(float, q10.x), __builtin_bit_cast(float, q10.y),
+                     __builtin_bit_cast(float, q11.x), __builtin_bit_cast(float, q11.y)};
+      const int shift = ax.i0 - xb;  // -1: x0 = -1 (tap 0 missing, tap 1 is the pair's first); +1: x0 = H-1
+      if (__builtin_amdgcn_ballot_w64(shift != 0) != 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float px = tp[2 * r], py = tp[2 * r + 1];
+          tp[2 * r] = shift < 0 ? 0.0f : (shift > 0 ? py : px);
+          tp[2 * r + 1] = shift > 0 ? 0.0f : (shift < 0 ? px : py);
+        }
+      }
+      if constexpr (SCALE) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) tp[r] = tp[r] + 1.0f;  // (input1 + 1), the /2 is taken out exactly
+      }
+      float s = tp[0] * ((ax.w0 * ay.w0) * az.w0);
+      s = s + tp[1] * ((ax.w1 * ay.w0) * az.w0);
+      s = s + tp[2] * ((ax.w0 * ay.w1) * az.w0);
+      s = s + tp[3] * ((ax.w1 * ay.w1) * az.w0);
+      s = s + tp[4] * ((ax.w0 * ay.w0) * az.w1);
+      s = s + tp[5] * ((ax.w1 * ay.w0) * az.w1);
+      s = s + tp[6] * ((ax.w0 * ay.w1) * az.w1);
+      s = s + tp[7] * ((ax.w1 * ay.w1) * az.w1);
+      res[v] = SCALE ? s - 1.0f : s;  // (output/2) * 2 - 1
+    }
+    float* wp = warped + ((int64_t)b * C + c) * slabV + (int64_t)i * sD + inplane;
+    *reinterpret_cast<float4*>(wp) = make_float4(res[0], res[1], res[2], res[3]);
+  }
+}
+
 __global__ __launch_bounds__(256) void mask_compose_kernel(const float* __restrict__ img,
                                                            const float* __restrict__ seg,
                                                            float* __restrict__ out, int64_t n) {
@@ -255,6 +380,21 @@ extern "C" int lr_warp_trilinear_f32(const float* img, const float* seg, const f
   const int Dn = d1 - d0;
   const bool vec4 = (H % 4 == 0) && aligned16(disp) && aligned16(warped) &&
                     (!phi_out || aligned16(phi_out));
+  if (vec4 && !seg && !(flags & (LR_WARP_BORDER | LR_WARP_NEAREST)) && (!id2 || aligned16(id2)) &&
+      !getenv("LIFTREG_WARP_GENERAL")) {
+    const int64_t sD = (int64_t)W * H, V = sD * D;
+    if (V * 4 + sD * 4 <= 0x80000000LL && sD < (1 << 23) && sD / 4 <= (1 << 20) && Dn <= 65535 && B <= 65535) {
+      const dim3 grid((unsigned)((sD / 4 + 255) / 256), (unsigned)Dn, (unsigned)B), block(256);
+      const float rcp_hv = 1.0f / (float)(H / 4);
+      if (flags & LR_WARP_USING_SCALE)
+        hipLaunchKernelGGL(warp_tri_fast_kernel<true>, grid, block, 0, lr_stream(stream), img, disp, id0, id1, id2,
+                           phi_out, warped, C, D, W, H, Dn, rcp_hv);
+      else
+        hipLaunchKernelGGL(warp_tri_fast_kernel<false>, grid, block, 0, lr_stream(stream), img, disp, id0, id1, id2,
+                           phi_out, warped, C, D, W, H, Dn, rcp_hv);
+      return lr_launch_status();
+    }
+  }
   if (vec4)
     return dispatch_warp<4>(flags, img, seg, disp, id0, id1, id2, phi_out, warped, B, C, D, W, H,
                             Dn, lr_stream(stream));

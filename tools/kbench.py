@@ -39,7 +39,11 @@ def main():
     ap.add_argument("--config", default="c3")
     ap.add_argument("--only", default="")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--lib", default="", help="load this build of libliftreg_hip.so instead (kernel experiments)")
     a = ap.parse_args()
+    if a.lib:
+        from liftreg_amd import _hip
+        _hip.LIB_PATH = os.path.abspath(a.lib)
     c = CONFIGS[a.config]
     n, P, R, B, L = c["n"], c["P"], c["R"], c["B"], c["L"]
     only = set(a.only.split(",")) if a.only else None
@@ -91,12 +95,18 @@ def main():
             report(f"conv{i} {ci}->{co} s{s} @{size}", timeit(f, a.iters), flops=2.0 * 27 * ci * co * B * so ** 3)
             del x
         size = (size - 1) // s + 1
-    if want("pca"):
+    if want("pca") or want("pca_bwd"):
         basis = torch.empty((L, 3 * V), device=dev).normal_(0, 0.01, generator=g)
         mean = torch.zeros(3 * V, device=dev)
         coefs = rnd(B, L)
         f = lambda: ops.pca_reconstruct(coefs, basis, mean)
         report("pca_reconstruct", timeit(f, a.iters), nbytes=4 * (L * 3 * V + 3 * V + B * 3 * V))
+        if want("pca_bwd"):
+            from liftreg_amd import ops_bwd
+            gd = rnd(B, 3 * V)
+            f = lambda: ops_bwd.pca_bwd_coef(gd, basis)
+            report("pca_bwd_coef", timeit(f, a.iters), nbytes=4 * (L * 3 * V + B * 3 * V))
+            del gd
         del basis
     if want("warp"):
         img = rnd(B, 1, n, n, n)
