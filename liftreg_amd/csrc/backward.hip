@@ -137,6 +137,131 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
   go[2 * per_b] = gx * ax.gmul;  // channel 2 <-> H
 }
 
+// The training step's case (zeros padding, no mask, float4 rows) with a third of the vector-ALU work — the same
+// restructuring as warp.hip's warp_tri_fast_kernel: 4 voxels per thread, taps through bounds-checked raw buffer
+// loads with 32-bit offsets from 24-bit multiplies (no clamping: an out-of-range tap is masked, wherever its address
+// lands), one 8-byte load per x pair (re-based under a wave-uniform branch at the x faces), in-plane index from a
+// float reciprocal.  (v+1)/2 and the factor 2 on the incoming gradient cancel exactly (powers of two), so both are
+// dropped; every other product and sum is written in the general kernel's order — the results are the same bits.
+struct AxisBF {
+  float w0, w1;  // interpolation weights (0 when the axis is out of range)
+  int i0;        // floor(pix), 0 when the axis is out of range
+  bool ok0, ok1;
+};
+
+__device__ __forceinline__ AxisBF axis_bf(float g, int size) {
+  const float pix = ((g + 1.0f) * 0.5f) * (float)(size - 1);
+  const bool valid = pix > -1.0f && pix < (float)size;
+  const float fl = floorf(pix);
+  AxisBF a;
+  a.i0 = valid ? (int)fl : 0;
+  a.w0 = valid ? (fl + 1.0f) - pix : 0.0f;
+  a.w1 = valid ? pix - fl : 0.0f;
+  a.ok0 = valid && a.i0 >= 0;
+  a.ok1 = valid && a.i0 + 1 < size;
+  return a;
+}
+
+template <bool SCALE>
+__global__ __launch_bounds__(256) void warp_bwd_fast_kernel(const float* __restrict__ img, const float* __restrict__ disp,
+                                                            const float* __restrict__ id0, const float* __restrict__ id1,
+                                                            const float* __restrict__ id2, const float* __restrict__ gw,
+                                                            float* __restrict__ gdisp, int C, int D, int W, int H, int Dn,
+                                                            float rcp_hv) {
+  const int HV = H >> 2;
+  const int t = blockIdx.x * 256 + threadIdx.x;  // float4 index inside plane i
+  const int i = blockIdx.y, b = blockIdx.z;
+  const int j = (int)(((float)t + 0.5f) * rcp_hv);
+  if (j >= W) return;
+  const int kv = t - __mul24(j, HV);
+  const int sD = W * H;
+  const int64_t slabV = (int64_t)Dn * sD, V = (int64_t)D * sD;
+  const int inplane = __mul24(j, H) + (kv << 2);
+  const int64_t ubase = (int64_t)b * 3 * slabV + (int64_t)i * sD;  // wave-uniform
+  const float* dp = disp + ubase + inplane;
+  const float4 da = *reinterpret_cast<const float4*>(dp);
+  const float4 db = *reinterpret_cast<const float4*>(dp + slabV);
+  const float4 dc = *reinterpret_cast<const float4*>(dp + 2 * slabV);
+  float p0[4] = {da.x, da.y, da.z, da.w}, p1[4] = {db.x, db.y, db.z, db.w}, p2[4] = {dc.x, dc.y, dc.z, dc.w};
+  if (id0) {
+    const float a0 = id0[i], a1 = id1[j];
+    const float4 a2 = *reinterpret_cast<const float4*>(id2 + (kv << 2));
+    const float a2v[4] = {a2.x, a2.y, a2.z, a2.w};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      p0[v] = p0[v] + a0;
+      p1[v] = p1[v] + a1;
+      p2[v] = p2[v] + a2v[v];
+    }
+  }
+  float gx[4] = {0.f, 0.f, 0.f, 0.f}, gy[4] = {0.f, 0.f, 0.f, 0.f}, gz[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < C; ++c) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(img + ((int64_t)b * C + c) * V), (short)0, (int)(V * 4), 0x00020000);
+    const float4 g4 = *reinterpret_cast<const float4*>(gw + ((int64_t)b * C + c) * slabV + (int64_t)i * sD + inplane);
+    const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const AxisBF ax = axis_bf(p2[v], H), ay = axis_bf(p1[v], W), az = axis_bf(p0[v], D);
+      const int xb = min(max(ax.i0, 0), H - 2), shift = ax.i0 - xb;
+      const int y0 = __mul24(ay.i0, H), z0 = __mul24(az.i0, sD);
+      const unsigned xb4 = (unsigned)xb << 2;
+      unsigned off[2][2];
+      off[0][0] = ((unsigned)(z0 + y0) << 2) + xb4;
+      off[0][1] = ((unsigned)(z0 + y0 + H) << 2) + xb4;
+      off[1][0] = ((unsigned)(z0 + sD + y0) << 2) + xb4;
+      off[1][1] = ((unsigned)(z0 + sD + y0 + H) << 2) + xb4;
+      float val[2][2][2];
+#pragma unroll
+      for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy) {
+          const uint2 q = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off[cz][cy], 0, 0));
+          val[cz][cy][0] = __builtin_bit_cast(float, q.x);
+          val[cz][cy][1] = __builtin_bit_cast(float, q.y);
+        }
+      if (__builtin_amdgcn_ballot_w64(shift != 0) != 0) {  // x0 = -1: tap 1 is the pair's first; x0 = H-1: tap 0 its second
+#pragma unroll
+        for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+          for (int cy = 0; cy < 2; ++cy) {
+            const float px = val[cz][cy][0], py = val[cz][cy][1];
+            val[cz][cy][0] = shift > 0 ? py : px;
+            val[cz][cy][1] = shift < 0 ? px : py;
+          }
+      }
+#pragma unroll
+      for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+          for (int cx = 0; cx < 2; ++cx) {
+            const bool ok = (cz ? az.ok1 : az.ok0) && (cy ? ay.ok1 : ay.ok0) && (cx ? ax.ok1 : ax.ok0);
+            const float tv = SCALE ? val[cz][cy][cx] + 1.0f : val[cz][cy][cx];
+            val[cz][cy][cx] = ok ? tv : 0.0f;
+          }
+      const float wz[2] = {az.w0, az.w1}, wy[2] = {ay.w0, ay.w1}, wx[2] = {ax.w0, ax.w1};
+      float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          dx += wy[a] * wz[q] * (val[q][a][1] - val[q][a][0]);
+          dy += wx[a] * wz[q] * (val[q][1][a] - val[q][0][a]);
+          dz += wx[a] * wy[q] * (val[1][q][a] - val[0][q][a]);
+        }
+      gx[v] += gv[v] * dx;
+      gy[v] += gv[v] * dy;
+      gz[v] += gv[v] * dz;
+    }
+  }
+  const float mz = 0.5f * (float)(D - 1), my = 0.5f * (float)(W - 1), mx = 0.5f * (float)(H - 1);
+  float* go = gdisp + ubase + inplane;
+  *reinterpret_cast<float4*>(go) = make_float4(gz[0] * mz, gz[1] * mz, gz[2] * mz, gz[3] * mz);              // channel 0 <-> D
+  *reinterpret_cast<float4*>(go + slabV) = make_float4(gy[0] * my, gy[1] * my, gy[2] * my, gy[3] * my);      // 1 <-> W
+  *reinterpret_cast<float4*>(go + 2 * slabV) = make_float4(gx[0] * mx, gx[1] * mx, gx[2] * mx, gx[3] * mx);  // 2 <-> H
+}
+
 // ------------------------------------------------------------------------------------------------ PCA
 // gcoefs[b][l] = sum_m g[b][m] * basis[l][m].  grid (m-blocks, l-groups of LG): a block keeps LG x BT
 // accumulators per thread, streams its m-range once per l-group; per-block partials, then a fixed-order reduce.
@@ -329,11 +454,24 @@ extern "C" int lr_warp_bwd_disp_f32(const float* img, const float* seg, const fl
   const bool any_id = id0 || id1 || id2, all_id = id0 && id1 && id2;
   if (any_id && !all_id) return LR_ENULL;
   const int Dn = d1 - d0;
+  hipStream_t st = lr_stream(stream);
+  const bool sc = flags & LR_WARP_USING_SCALE, bo = flags & LR_WARP_BORDER;
+  {
+    const int64_t sD = (int64_t)W * H, V = sD * D;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    if (!seg && !bo && H % 4 == 0 && al16(disp) && al16(gwarped) && al16(gdisp) && (!id2 || al16(id2)) &&
+        V * 4 + sD * 8 <= 0x80000000LL && sD < (1 << 23) && sD / 4 <= (1 << 20) && Dn <= 65535 &&
+        !getenv("LIFTREG_WARP_GENERAL")) {
+      const dim3 g3((unsigned)((sD / 4 + 255) / 256), (unsigned)Dn, (unsigned)B);
+      const float rcp_hv = 1.0f / (float)(H / 4);
+      if (sc) hipLaunchKernelGGL(warp_bwd_fast_kernel<true>, g3, dim3(256), 0, st, img, disp, id0, id1, id2, gwarped, gdisp, C, D, W, H, Dn, rcp_hv);
+      else hipLaunchKernelGGL(warp_bwd_fast_kernel<false>, g3, dim3(256), 0, st, img, disp, id0, id1, id2, gwarped, gdisp, C, D, W, H, Dn, rcp_hv);
+      return lr_launch_status();
+    }
+  }
   const int64_t nblk = ((int64_t)Dn * W * H + 255) / 256;
   if (nblk > 0x7fffffffLL) return LR_EINVAL;
   const dim3 grid((unsigned)nblk, (unsigned)B), block(256);
-  hipStream_t st = lr_stream(stream);
-  const bool sc = flags & LR_WARP_USING_SCALE, bo = flags & LR_WARP_BORDER;
 #define LR_WB(S, Bo, G) hipLaunchKernelGGL((warp_bwd_kernel<S, Bo, G>), grid, block, 0, st, img, seg, disp, id0, id1, id2, gwarped, gdisp, B, C, D, W, H, Dn)
   if (seg) {
     if (sc) { if (bo) LR_WB(true, true, true); else LR_WB(true, false, true); }

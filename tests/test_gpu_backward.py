@@ -54,6 +54,27 @@ def test_warp_backward_wrt_displacement(dev):
         np.testing.assert_allclose(got.cpu().numpy(), d.grad.numpy(), rtol=1e-4, atol=2e-5)
 
 
+def test_warp_backward_fast_kernel_equals_general_kernel(dev, monkeypatch):
+    """float4 rows without a mask take `warp_bwd_fast_kernel`; LIFTREG_WARP_GENERAL=1 forces the general kernel.
+    Same bits, including samples outside every face."""
+    from liftreg_amd import ops_bwd
+    from liftreg_amd.utils import net_utils as N
+    rs = np.random.RandomState(5)
+    for shape, B, C in (((6, 7, 8), 2, 1), ((5, 9, 16), 1, 2), ((10, 6, 260), 1, 1)):
+        img = rs.uniform(-1, 1, (B, C) + shape).astype(np.float32)
+        disp = rs.normal(0, 0.7, (B, 3) + shape).astype(np.float32)
+        gw = rs.normal(0, 1, (B, C) + shape).astype(np.float32)
+        ids = [T(t, dev) for t in N.identity_axis_tables(shape)]
+        for sc in (True, False):
+            monkeypatch.delenv("LIFTREG_WARP_GENERAL", raising=False)
+            fast = ops_bwd.warp_bwd_disp(T(img, dev), T(disp, dev), ids, None, T(gw, dev), using_scale=sc).cpu().numpy()
+            monkeypatch.setenv("LIFTREG_WARP_GENERAL", "1")
+            gen = ops_bwd.warp_bwd_disp(T(img, dev), T(disp, dev), ids, None, T(gw, dev), using_scale=sc).cpu().numpy()
+            monkeypatch.delenv("LIFTREG_WARP_GENERAL", raising=False)
+            assert np.array_equal(fast, gen), (shape, sc)
+            assert np.abs(fast).max() > 0
+
+
 def test_pca_backward_wrt_coefficients(dev):
     from liftreg_amd import ops_bwd
     rs = np.random.RandomState(3)

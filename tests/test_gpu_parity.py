@@ -195,6 +195,39 @@ def test_warp_seg_ragged_and_multichannel(ops, dev):
         assert np.array_equal(mc, co.mask_compose(img, seg))
 
 
+def test_warp_fast_kernel_equals_general_kernel_on_hostile_input(ops, dev, monkeypatch):
+    """The model's case runs `warp_tri_fast_kernel` (buffer-load taps, weights carry the range checks); every
+    other flag combination runs the general kernel.  Same bits on samples outside every face, NaN coordinates, and
+    NaN/Inf voxels sitting where a dropped tap would have been clamped to."""
+    from liftreg_amd.utils import net_utils as N
+    rs = np.random.RandomState(11)
+    for shape, B, C in (((6, 7, 8), 2, 1), ((5, 9, 16), 1, 2), ((12, 10, 260), 1, 1)):
+        img = rs.uniform(-1, 1, (B, C) + shape).astype(np.float32)
+        img[:, :, 0, 0, 0] = np.inf                       # face voxels: reached only through clamped (dropped) taps
+        img[:, :, -1, -1, -1] = np.nan
+        img[:, :, :, :, 1] = rs.choice([np.nan, np.inf, 1.0], size=img[:, :, :, :, 1].shape).astype(np.float32)
+        disp = rs.normal(0, 0.9, (B, 3) + shape).astype(np.float32)   # a third of the samples leave the volume
+        disp[0, 0, 1, 1, 0] = np.nan
+        disp[0, 2, 2, 2, 3] = np.inf
+        disp[0, 1, 0, 0, 1] = -np.inf
+        tabs = N.identity_axis_tables(shape)
+        dt = [T(t, dev) for t in tabs]
+        for sc in (True, False):
+            monkeypatch.delenv("LIFTREG_WARP_GENERAL", raising=False)
+            phi_f, w_f = ops.warp(T(img, dev), T(disp, dev), dt, None, using_scale=sc)
+            monkeypatch.setenv("LIFTREG_WARP_GENERAL", "1")
+            phi_g, w_g = ops.warp(T(img, dev), T(disp, dev), dt, None, using_scale=sc)
+            monkeypatch.delenv("LIFTREG_WARP_GENERAL", raising=False)
+            a, b = w_f.cpu().numpy(), w_g.cpu().numpy()
+            assert np.array_equal(phi_f.cpu().numpy(), phi_g.cpu().numpy(), equal_nan=True)
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (shape, sc)
+            assert np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)]), (shape, sc)
+        clean = np.nan_to_num(img, nan=0.5, posinf=0.25, neginf=-0.25)
+        _, cw = co.warp(clean, np.nan_to_num(disp, nan=0.0, posinf=3.0, neginf=-3.0), ids=tabs, flags=co.USING_SCALE)
+        _, w = ops.warp(T(clean, dev), T(np.nan_to_num(disp, nan=0.0, posinf=3.0, neginf=-3.0), dev), dt, None)
+        assert np.array_equal(w.cpu().numpy(), cw), shape                         # and the C oracle, finite input
+
+
 # ------------------------------------------------------------------------------------- K8 NCC
 def test_ncc_golden_and_sharded(golden, ops, dev):
     from liftreg_amd.layers.losses import NCCLoss
