@@ -209,6 +209,103 @@ __global__ __launch_bounds__(1024) void drr_forward_kernel(
   }
 }
 
+// The projector's usual case (attenuation input, H >= 2, slab under 2 GB) with half the vector-ALU work per sample;
+// the general kernel above is ALU-bound (64-bit addressing, per-tap range flags and selects), not gather-bound.
+//  * sample coordinates: the same code (sample_pix), then clamped to [lo-1, hi] — at the clamp values every tap is
+//    either outside or has weight exactly 0, which is what the general kernel's "nothing in range" branch yields;
+//  * taps: bounds-checked raw buffer loads relative to the slab, 32-bit offsets from 24-bit multiplies; a z tap
+//    outside the slab falls outside the resource by itself, an out-of-range y row is pushed outside with one select;
+//  * the x pair is one 8-byte load; only where a wave touches the x faces a wave-uniform branch re-bases it;
+//  * products and sums in the general kernel's order: same bits.
+template <bool FLIP>
+__global__ __launch_bounds__(1024) void drr_forward_fast_kernel(
+    const float* __restrict__ vol, LrPoses poses, float sp0, float sp1, float sp2,
+    float* __restrict__ out, int D, int W, int H, int d0, int d1, int P, int Rd, int Rh, int nseg) {
+  extern __shared__ float part[];  // [R][64]
+  const int lane = threadIdx.x, row = threadIdx.y, R = blockDim.y;
+  const int a_per_blk = R / nseg;
+  const int nbx = (Rh + 63) >> 6;
+  const unsigned lb = lr_xcd_remap(blockIdx.x, gridDim.x);
+  const int nag = (Rd + a_per_blk - 1) / a_per_blk;
+  const int bx = lb % nbx;
+  const int ag = (lb / nbx) % nag;
+  const int p = lb / nbx / nag;
+  const int a = ag * a_per_blk + row / nseg;
+  const int seg = row % nseg;
+  const int b = bx * 64 + lane;
+  const bool live = (a < Rd) && (b < Rh);
+
+  float acc = 0.0f;
+  float dxv = 0.0f;
+  if (live) {
+    const float ex = poses.e[p][0], ey = poses.e[p][1], ez = poses.e[p][2];
+    const RaySetup rs = ray_setup(a, b, Rd, Rh, ex, ey, ez, sp0, sp1, sp2);
+    dxv = rs.dx;
+    const int per = (W + nseg - 1) / nseg;
+    const int j0 = seg * per, j1 = min(W, j0 + per);
+    const int sD = W * H, Dn = d1 - d0;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vol), (short)0, Dn * sD * 4, 0x00020000);
+    constexpr int OUTSIDE = 0x20000000;  // elements; ·4 bytes = 2^31 ≥ any slab accepted by the launcher
+    const float zlo = (float)(d0 - 1), zhi = (float)d1, yhi = (float)W, xhi = (float)H;
+    for (int j = j0; j < j1; ++j) {
+      float pd, pw, ph;
+      sample_pix(rs, j, ex, ey, ez, D, W, H, pd, pw, ph);
+      pd = __builtin_amdgcn_fmed3f(pd, zlo, zhi);   // NaN -> a bound; both bounds contribute nothing
+      pw = __builtin_amdgcn_fmed3f(pw, -1.0f, yhi);
+      ph = __builtin_amdgcn_fmed3f(ph, -1.0f, xhi);
+      const float fz = floorf(pd), fy = floorf(pw), fx = floorf(ph);
+      const int z0 = (int)fz - d0, y0 = (int)fy, x0 = (int)fx;
+      const float wz0 = (fz + 1.0f) - pd, wz1 = pd - fz;   // (i1 - pix), (pix - i0) — ATen's generic 3D kernel
+      const float wy0 = (fy + 1.0f) - pw, wy1 = pw - fy;
+      const float wx0 = (fx + 1.0f) - ph, wx1 = ph - fx;
+      const int r0 = FLIP ? (W - 1 - y0) : y0, r1 = FLIP ? r0 - 1 : r0 + 1;
+      const int yo0 = ((unsigned)y0 < (unsigned)W) ? __mul24(r0, H) : OUTSIDE;
+      const int yo1 = ((unsigned)(y0 + 1) < (unsigned)W) ? __mul24(r1, H) : OUTSIDE;
+      const int zo0 = __mul24(z0, sD), zo1 = zo0 + sD;
+      const int xb = min(max(x0, 0), H - 2), shift = x0 - xb;
+      const unsigned xb4 = (unsigned)xb << 2;
+      const uint2 q00 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, ((unsigned)(zo0 + yo0) << 2) + xb4, 0, 0));
+      const uint2 q01 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, ((unsigned)(zo0 + yo1) << 2) + xb4, 0, 0));
+      const uint2 q10 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, ((unsigned)(zo1 + yo0) << 2) + xb4, 0, 0));
+      const uint2 q11 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, ((unsigned)(zo1 + yo1) << 2) + xb4, 0, 0));
+      float tp[8] = {__builtin_bit_cast(float, q00.x), __builtin_bit_cast(float, q00.y),
+                     __builtin_bit_cast(float, q01.x), __builtin_bit_cast(float, q01.y),
+                     __builtin_bit_cast(float, q10.x), __builtin_bit_cast(float, q10.y),
+                     __builtin_bit_cast(float, q11.x), __builtin_bit_cast(float, q11.y)};
+      if (__builtin_amdgcn_ballot_w64(shift != 0) != 0) {  // x0 in {-1, H-1, H}: re-base the pair, drop what is outside
+        const bool ok0 = (unsigned)x0 < (unsigned)H, ok1 = (unsigned)(x0 + 1) < (unsigned)H;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float px = tp[2 * r], py = tp[2 * r + 1];
+          tp[2 * r] = ok0 ? (shift > 0 ? py : px) : 0.0f;
+          tp[2 * r + 1] = ok1 ? (shift < 0 ? px : py) : 0.0f;
+        }
+      }
+      float s = tp[0] * ((wx0 * wy0) * wz0);
+      s = s + tp[1] * ((wx1 * wy0) * wz0);
+      s = s + tp[2] * ((wx0 * wy1) * wz0);
+      s = s + tp[3] * ((wx1 * wy1) * wz0);
+      s = s + tp[4] * ((wx0 * wy0) * wz1);
+      s = s + tp[5] * ((wx1 * wy0) * wz1);
+      s = s + tp[6] * ((wx0 * wy1) * wz1);
+      s = s + tp[7] * ((wx1 * wy1) * wz1);
+      acc = acc + s;
+    }
+  }
+  if (nseg == 1) {
+    if (live) out[((int64_t)p * Rd + a) * Rh + b] = (acc * dxv) * 0.1f;
+    return;
+  }
+  part[row * 64 + lane] = acc;
+  __syncthreads();
+  if (live && seg == 0) {
+    float s = part[row * 64 + lane];
+    for (int q = 1; q < nseg; ++q) s = s + part[(row + q) * 64 + lane];
+    out[((int64_t)p * Rd + a) * Rh + b] = (s * dxv) * 0.1f;
+  }
+}
+
 __global__ __launch_bounds__(256) void drr_coords_kernel(LrPoses poses, float sp0, float sp1,
                                                          float sp2, float* __restrict__ pix,
                                                          float* __restrict__ dx, int D, int W,
@@ -280,6 +377,17 @@ extern "C" int lr_drr_forward_f32(const float* vol_slab, const float* poses, con
   hipLaunchKernelGGL((drr_forward_kernel<HUV, FLV>), grid, block, lds, lr_stream(stream),      \
                      vol_slab, lp, spacing[0], spacing[1], spacing[2], out, D, W, H, d0, d1, P, \
                      Rd, Rh, nseg)
+  const int64_t sD64 = (int64_t)W * H;
+  if (!hu && H >= 2 && (int64_t)(d1 - d0) * sD64 * 4 + sD64 * 8 <= 0x80000000LL && sD64 < (1 << 23) &&
+      !getenv("LIFTREG_DRR_GENERAL")) {
+    if (flip)
+      hipLaunchKernelGGL(drr_forward_fast_kernel<true>, grid, block, lds, lr_stream(stream), vol_slab, lp, spacing[0],
+                         spacing[1], spacing[2], out, D, W, H, d0, d1, P, Rd, Rh, nseg);
+    else
+      hipLaunchKernelGGL(drr_forward_fast_kernel<false>, grid, block, lds, lr_stream(stream), vol_slab, lp, spacing[0],
+                         spacing[1], spacing[2], out, D, W, H, d0, d1, P, Rd, Rh, nseg);
+    return lr_launch_status();
+  }
   if (hu && flip) LR_LAUNCH(true, true);
   else if (hu) LR_LAUNCH(true, false);
   else if (flip) LR_LAUNCH(false, true);

@@ -110,6 +110,26 @@ def test_drr_medium_vs_oracles_and_slabs(ops, dev):
     np.testing.assert_allclose(sum(parts).cpu().numpy(), want_t, rtol=1e-5, atol=1e-6)     # z-slab partial sums
 
 
+def test_drr_fast_kernel_equals_general_kernel(ops, dev, monkeypatch):
+    """Attenuation input runs `drr_forward_fast_kernel`; LIFTREG_DRR_GENERAL=1 forces the general kernel.  Same bits:
+    rays leaving through every face (wide detector, close emitter), flipped rows, slabs, explicit segment counts."""
+    rs = np.random.RandomState(9)
+    sp = np.array((2.2, 1.7, 2.0), np.float32)
+    for (D, W, H), R, poses in (((20, 18, 24), (40, 56), np.array([[3.0, 40.0, -2.0], [-9.0, 25.0, 6.0]], np.float32)),
+                                ((33, 21, 70), (24, 130), ro.scan_poses(40, 3, 21).astype(np.float32))):
+        mu = rs.uniform(0, 0.4, (D, W, H)).astype(np.float32)
+        for kw in (dict(nseg=1), dict(nseg=4, flip_w=True), dict(nseg=0),
+                   dict(nseg=2, d0=5, d1=D - 4, full_D=D)):
+            v = mu[kw.get("d0", 0):kw.get("d1", D)]
+            monkeypatch.delenv("LIFTREG_DRR_GENERAL", raising=False)
+            fast = ops.drr_forward(T(v, dev), poses, R, sp, **kw).cpu().numpy()
+            monkeypatch.setenv("LIFTREG_DRR_GENERAL", "1")
+            gen = ops.drr_forward(T(v, dev), poses, R, sp, **kw).cpu().numpy()
+            monkeypatch.delenv("LIFTREG_DRR_GENERAL", raising=False)
+            assert np.array_equal(fast, gen), ((D, W, H), kw)
+            assert fast.max() > 0 and (fast == 0).any()      # some rays cross the volume, some miss it
+
+
 # ------------------------------------------------------------------------------------- K2 backprojection
 @pytest.mark.parametrize("tag", ["bp_a", "bp_b", "bp_c"])
 def test_backproject_golden(golden, ops, dev, tag):
