@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--config", default="c3")
     ap.add_argument("--only", default="")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--bf16", action="store_true", help="conv1..5 in the bf16-storage variant (model layouts)")
     ap.add_argument("--lib", default="", help="load this build of libliftreg_hip.so instead (kernel experiments)")
     a = ap.parse_args()
     if a.lib:
@@ -88,6 +89,17 @@ def main():
                 lay = ops.LAYOUT_NDHWC_HPS if size % 2 == 0 else ops.LAYOUT_NDHWC
             w = rnd(co, ci, 3, 3, 3) / (27 * ci) ** 0.5
             bb = rnd(co) * 0.1
+            if a.bf16 and i > 0:
+                so = (size - 1) // s + 1
+                xb = x.to(torch.bfloat16)
+                li = ops.LAYOUT_BF16_NDHWC_HPS if size % 2 == 0 else ops.LAYOUT_BF16_NDHWC
+                lo = ops.LAYOUT_NCDHW if i == 5 else (ops.LAYOUT_BF16_NDHWC_HPS if so % 2 == 0 else ops.LAYOUT_BF16_NDHWC)
+                pkb = ops.conv3d_pack_weights_bf16(w)
+                f = lambda: ops.conv3d_k3_lrelu_bf16(xb, w, bb, s, in_layout=li, out_layout=lo, packed=pkb)
+                report(f"conv{i}_bf16 {ci}->{co} s{s} @{size}", timeit(f, a.iters), nbytes=2 * B * (ci * size ** 3 + co * so ** 3))
+                del x, xb
+                size = so
+                continue
             pk = ops.conv3d_pack_weights(w, lay)
             so = (size - 1) // s + 1
             lay_out = ops.LAYOUT_NCDHW if i == 5 else (ops.LAYOUT_NDHWC_HPS if so % 2 == 0 else ops.LAYOUT_NDHWC)
