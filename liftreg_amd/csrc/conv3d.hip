@@ -573,6 +573,136 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(const float* __restrict_
       store_tile(acc[mt][nt], out, d, b, dz, wo0 + mt, ho, nt, lane, out_layout, slope);
 }
 
+// ===========================================================================
+// Row-major variant of the parity-split stride-2 kernel for Cin = 16 (the encoder's block 1: 58 of the 118 GFLOP).
+// conv3d_cl_kernel walks TAPS: every (tz,ty,tx) loads its MT rows, so an input row is fetched for (mt,ty=2) and,
+// 24 loads later, again for (mt+1,ty=0) — with a thousand waves per XCD that distance is far beyond the 4 MB L2 and
+// the re-read goes to the fabric: PMC showed 2.6x the input in L2-miss traffic, 6 TB/s = the fabric's rate, next to an
+// 80 %-busy matrix pipe.  This kernel walks INPUT ROWS instead: a row (even half, odd half at tx=0 and tx=2) is
+// loaded ONCE and feeds its one or two (mt,ty) uses immediately; the nine weight fragments of the current tz stay in
+// registers (they cost what the tap-major weight loads cost) and the next tz's arrive while the last rows are on the
+// matrix pipe.  27 rows per tile, loads two rows ahead, everything unrolled (straight-line vmcnt accounting).
+// Every accumulator still sees its taps in (tz,ty,tx) order: the results are bit-identical to conv3d_cl_kernel's.
+// ===========================================================================
+template <int NT>
+__global__ __launch_bounds__(256, 3) void conv3d_cl_rows_kernel(const float* __restrict__ in,
+                                                             const float4* __restrict__ wp,
+                                                             const float* __restrict__ bias,
+                                                             float* __restrict__ out, ConvDims d,
+                                                             int out_layout, float slope) {
+  int b, dq, wq, hq;
+  block_coords(d, b, dq, wq, hq);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int dz = dq * TD + wave;
+  if (dz >= d.Do) return;
+  // the dimensions the loop needs, as scalars of their own (the struct itself may end up in scratch)
+  const int dD = __builtin_amdgcn_readfirstlane(d.D), dW = __builtin_amdgcn_readfirstlane(d.W),
+            dH = __builtin_amdgcn_readfirstlane(d.H), dHo = __builtin_amdgcn_readfirstlane(d.Ho);
+  const int wo0 = wq * MT;
+  const int col = lane & 15, kq = lane >> 4;
+  const int ho = hq * 16 + col;  // this lane's voxel
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const f32x4 bv = bias_init(bias, nt, lane);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = bv;
+  }
+  // window origin (-1,-1,-1) of this wave's tile, as in conv3d_cl_kernel<NT, 2, true> (Cin == 16: one channel block)
+  const int zi0 = dz * 2 - 1, yw0 = wo0 * 2 - 1, xh0 = hq * 16 - 1;
+  const int64_t inb = (int64_t)b * dD * dW * dH * 16;
+  const float* wbase = in + inb + ((int64_t)zi0 * dW + yw0) * dH * 16 + (int64_t)xh0 * 16;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wbase), (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_null =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wbase), (short)0, 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wp), (short)0, 0x7fffffff, 0x00020000);
+  constexpr unsigned OOR = 0x80000000u;
+  const unsigned lvoff = (unsigned)(col * 64 + kq * 16);
+  const int half_h = (dH + 1) >> 1;
+  unsigned vx[3];  // per-lane offset of the lane's own column for tx = 0,1,2; bit 31 set when that tap is outside
+  {
+    const int xi0 = ho * 2 - 1;
+#pragma unroll
+    for (int t3 = 0; t3 < 3; ++t3) vx[t3] = lvoff | ((ho < dHo && xi0 + t3 >= 0 && xi0 + t3 < dH) ? 0u : OOR);
+  }
+  const unsigned wlane = (unsigned)lane * 16u;
+  constexpr int NR = 2 * MT + 1;  // input rows of the tile per plane
+
+  unsigned okmask = 0u;  // bit tz*NR+r SET = input row (zi0+tz, yw0+r) exists (the rest is the conv's zero padding)
+#pragma unroll
+  for (int q = 0; q < 3 * NR; ++q) {
+    const int zi = zi0 + q / NR, yi = yw0 + q % NR;
+    okmask |= ((unsigned)(zi >= 0) & (unsigned)(zi < dD) & (unsigned)(yi >= 0) & (unsigned)(yi < dW)) << q;
+  }
+  float4 w[3][3][NT];  // [ty][tx][nt] of the current tz
+  auto load_w = [&](int tz, int ty) {
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        w[ty][tx][nt] = __builtin_bit_cast(
+            float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wlane, (unsigned)((((tz * 3 + ty) * 3 + tx) * NT + nt) * 1024), 0));
+  };
+  auto load_row = [&](int q, float4 (&a)[3]) {  // q = tz * NR + r
+    const int tz = q / NR, r = q - tz * NR;
+    const bool ok = (okmask >> q) & 1u;  // wave-uniform (scalar select, no branch): outside -> the zero-length resource
+    const unsigned row = (unsigned)((tz * dW + r) * dH * 16);
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) {
+      // tx=1: even half, index ho; tx=0: odd half, index ho-1; tx=2: odd half, index ho (xh0 carries the -1)
+      const int xs = tx == 1 ? 1 : half_h + (tx >> 1);
+      a[tx] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rsrc : rsrc_null, vx[tx],
+                                                                                (row + (unsigned)xs * 16u) * 4u, 0));
+    }
+  };
+  auto use = [&](int mt, int ty, const float4 (&a)[3]) {
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ty][tx][nt].x, a[tx].x, acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ty][tx][nt].y, a[tx].y, acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ty][tx][nt].z, a[tx].z, acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ty][tx][nt].w, a[tx].w, acc[mt][nt], 0, 0, 0);
+      }
+  };
+  float4 rows[3][3];  // three register sets: rows q, q+1, q+2
+  load_w(0, 0);
+  load_w(0, 1);
+  load_w(0, 2);
+  load_row(0, rows[0]);
+  load_row(1, rows[1]);
+#pragma unroll
+  for (int q = 0; q < 3 * NR; ++q) {
+    const int tz = q / NR, r = q % NR;
+    if (q + 2 < 3 * NR) load_row(q + 2, rows[(q + 2) % 3]);
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads two rows ahead: the scheduler otherwise sinks them to their use
+    // row r = 2*mt + ty: the (mt, ty) order below keeps every accumulator's taps in (tz,ty,tx) order
+    if (r & 1) {
+      use(r >> 1, 1, rows[q % 3]);
+    } else {
+      if (r >= 2) use((r >> 1) - 1, 2, rows[q % 3]);
+      if (r < 2 * MT) use(r >> 1, 0, rows[q % 3]);
+    }
+    // a ty's fragments are dead after its last row: fetch the next tz's while the remaining rows compute
+    if (tz < 2) {
+      if (r == 2 * MT - 2) load_w(tz + 1, 0);
+      if (r == 2 * MT - 1) load_w(tz + 1, 1);
+      if (r == 2 * MT) load_w(tz + 1, 2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      store_tile(acc[mt][nt], out, d, b, dz, wo0 + mt, ho, nt, lane, out_layout, slope);
+}
+
 // ---- weight packing -----------------------------------------------------------
 // Both layouts put W[cout = nt*16 + (lane&15)][k of lane group lane>>4] in lane order,
 // i.e. the MFMA A-operand (rows = couts) of one k-step is one coalesced 256-B read.
@@ -673,7 +803,10 @@ extern "C" int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, co
     const dim3 grid((unsigned)nblk);
     const float4* wt = reinterpret_cast<const float4*>(packed_w);
     const size_t occ_lds = getenv("LIFTREG_CONV_LDS") ? (size_t)atoi(getenv("LIFTREG_CONV_LDS")) : 0;  // tuning aid: caps resident blocks
-    if (ps && NT == 1) hipLaunchKernelGGL((conv3d_cl_kernel<1, 2, true>), grid, block, occ_lds, st, in, wt, bias, out, d, out_layout, negative_slope);
+    const bool rows_ok = ps && Cin == 16 && !getenv("LIFTREG_CONV_TAPMAJOR");  // tuning aid: the tap-major kernel
+    if (rows_ok && NT == 1) hipLaunchKernelGGL((conv3d_cl_rows_kernel<1>), grid, block, occ_lds, st, in, wt, bias, out, d, out_layout, negative_slope);
+    else if (rows_ok) hipLaunchKernelGGL((conv3d_cl_rows_kernel<2>), grid, block, occ_lds, st, in, wt, bias, out, d, out_layout, negative_slope);
+    else if (ps && NT == 1) hipLaunchKernelGGL((conv3d_cl_kernel<1, 2, true>), grid, block, occ_lds, st, in, wt, bias, out, d, out_layout, negative_slope);
     else if (ps) hipLaunchKernelGGL((conv3d_cl_kernel<2, 2, true>), grid, block, occ_lds, st, in, wt, bias, out, d, out_layout, negative_slope);
     else if (NT == 1 && stride == 1) hipLaunchKernelGGL((conv3d_cl_kernel<1, 1, false>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope);
     else if (NT == 1) hipLaunchKernelGGL((conv3d_cl_kernel<1, 2, false>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope);

@@ -187,6 +187,140 @@ __global__ __launch_bounds__(256) void conv3d_cl_bf16_kernel(const u16* __restri
 }
 
 // ===========================================================================================================
+// Row-major variant for Cin = 16 on parity-split rows (block 1, the largest stride-2 block).  The tap-major kernel
+// above re-fetches an input row for (mt,ty=2) and later for (mt+1,ty=0); with a thousand waves per XCD that second
+// fetch misses the 4 MB L2, and the kernel ran at the fabric's rate on 1.65x the input in miss traffic (PMC).  Here a
+// row is loaded once (two 16-byte loads per lane: [odd half @tx=0 | even half @tx=1] and [odd half @tx=2 | nothing])
+// and feeds its one or two (mt,ty) uses at once: MFMA 1 = taps (tx0,tx1), MFMA 2 = tap tx2 and 16 zero channels
+// (2 instead of 1.5 MFMAs per use: the bf16 matrix pipe is 14 % busy).  The six weight fragments of a (tz,ty) are
+// picked lane-wise out of the tap-pair packing (tap T, channel half h of cout c sits at fragment T/2, lane
+// ((T&1)*2+h)*16+c); the current tz's stay in registers, the next tz's are fetched under the last rows.
+template <int NT, int MT>
+__global__ __launch_bounds__(256, 3) void conv3d_cl_rows_bf16_kernel(const u16* __restrict__ in, const u32x4* __restrict__ wp,
+                                                                     const float* __restrict__ bias, void* __restrict__ out,
+                                                                     ConvDimsH d, int out_layout, float slope) {
+  constexpr int VB = 32;  // bytes per voxel (16 bf16 channels)
+  const unsigned lb = lr_xcd_remap(blockIdx.x, gridDim.x);
+  const int hq = lb % d.nHq, wq = (lb / d.nHq) % d.nWq, dq = (lb / d.nHq / d.nWq) % d.nDq;
+  const int b = lb / d.nHq / d.nWq / d.nDq;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int dz = dq * TD + wave;
+  if (dz >= d.Do) return;
+  const int dD = __builtin_amdgcn_readfirstlane(d.D), dW = __builtin_amdgcn_readfirstlane(d.W),
+            dH = __builtin_amdgcn_readfirstlane(d.H), dHo = __builtin_amdgcn_readfirstlane(d.Ho);
+  const int wo0 = wq * MT;
+  const int col = lane & 15, kq = lane >> 4;
+  const int ho = hq * 16 + col;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = bias[nt * 16 + kq * 4 + r];
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = bv;
+  }
+  const int zi0 = dz * 2 - 1, yw0 = wo0 * 2 - 1, xh0 = hq * 16 - 1;
+  const int64_t inb = (int64_t)b * dD * dW * dH * 16;
+  const u16* wbase = in + inb + ((int64_t)zi0 * dW + yw0) * dH * 16 + (int64_t)xh0 * 16;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(wbase), (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_null =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(wbase), (short)0, 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(wp), (short)0, 0x7fffffff, 0x00020000);
+  constexpr unsigned OOR = 0x80000000u;
+  const int half_h = (dH + 1) >> 1;
+  // per-lane offsets inside a row: load 1 = tx0 (lanes kq<2: odd half, index ho-1) | tx1 (kq>=2: even half, index ho),
+  // load 2 = tx2 (kq<2: odd half, index ho) | nothing; xh0 carries the -1
+  unsigned v1, v2;
+  {
+    const int xi0 = ho * 2 - 1;
+    const bool in_tile = ho < dHo;
+    const unsigned lv = (unsigned)(col * VB + (kq & 1) * 16);
+    const bool ok0 = in_tile && xi0 >= 0 && xi0 < dH, ok1 = in_tile && xi0 + 1 < dH, ok2 = in_tile && xi0 + 2 < dH;
+    v1 = (kq >> 1) ? (lv + 1u * VB) | (ok1 ? 0u : OOR) : (lv + (unsigned)half_h * VB) | (ok0 ? 0u : OOR);
+    v2 = (kq >> 1) ? OOR : (lv + (unsigned)(half_h + 1) * VB) | (ok2 ? 0u : OOR);
+  }
+  constexpr int NR = 2 * MT + 1;
+  unsigned okmask = 0u;  // bit tz*NR+r SET = input row (zi0+tz, yw0+r) exists; NR*3 <= 51: two words
+  unsigned okmask_hi = 0u;
+#pragma unroll
+  for (int q = 0; q < 3 * NR; ++q) {
+    const int zi = zi0 + q / NR, yi = yw0 + q % NR;
+    const unsigned bit = (unsigned)(zi >= 0) & (unsigned)(zi < dD) & (unsigned)(yi >= 0) & (unsigned)(yi < dW);
+    if (q < 32) okmask |= bit << q;
+    else okmask_hi |= bit << (q - 32);
+  }
+  // weight fragment offsets of this lane: MFMA 1 of (tz,ty) = taps T0 = (tz*3+ty)*3 (lanes kq<2) and T0+1 (kq>=2);
+  // MFMA 2 = tap T0+2 for kq<2 (the other lanes multiply zeros: any fragment)
+  auto woff = [&](int T, int nt) -> unsigned {
+    return (unsigned)(((((T >> 1) * NT + nt) * 64) + (((T & 1) << 1) | (kq & 1)) * 16 + col) * 16);
+  };
+  u32x4 w[3][2][NT];  // [ty][mfma][nt] of the current tz
+  auto load_w = [&](int tz, int ty) {
+    const int T0 = (tz * 3 + ty) * 3;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const unsigned o1 = (kq >> 1) ? woff(T0 + 1, nt) : woff(T0, nt);
+      w[ty][0][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, o1, 0, 0);
+      w[ty][1][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, woff(T0 + 2, nt), 0, 0);
+    }
+  };
+  auto load_row = [&](int q, u32x4 (&a)[2]) {
+    const int tz = q / NR, r = q - tz * NR;
+    const bool ok = ((q < 32 ? okmask >> q : okmask_hi >> (q - 32)) & 1u) != 0u;  // wave-uniform, scalar select
+    const unsigned soff = (unsigned)((tz * dW + r) * dH) * VB;
+    a[0] = __builtin_amdgcn_raw_buffer_load_b128(ok ? rsrc : rsrc_null, v1, soff, 0);
+    a[1] = __builtin_amdgcn_raw_buffer_load_b128(ok ? rsrc : rsrc_null, v2, soff, 0);
+  };
+  auto use = [&](int mt, int ty, const u32x4 (&a)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[ty][j][nt]),
+                                                              __builtin_bit_cast(bf16x8, a[j]), acc[mt][nt], 0, 0, 0);
+  };
+#ifndef LR_BF16_ROWS_AHEAD
+#define LR_BF16_ROWS_AHEAD 5
+#endif
+  constexpr int AH = LR_BF16_ROWS_AHEAD, NSET = AH + 1;
+  u32x4 rows[NSET][2];  // loads run AH rows ahead: a row is only 2-4 MFMAs (64-128 cycles) of work
+  load_w(0, 0);
+  load_w(0, 1);
+  load_w(0, 2);
+#pragma unroll
+  for (int q = 0; q < AH; ++q) load_row(q, rows[q]);
+#pragma unroll
+  for (int q = 0; q < 3 * NR; ++q) {
+    const int tz = q / NR, r = q % NR;
+    if (q + AH < 3 * NR) load_row(q + AH, rows[(q + AH) % NSET]);
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead: the scheduler otherwise sinks them to their use
+    if (r & 1) {
+      use(r >> 1, 1, rows[q % NSET]);
+    } else {
+      if (r >= 2) use((r >> 1) - 1, 2, rows[q % NSET]);
+      if (r < 2 * MT) use(r >> 1, 0, rows[q % NSET]);
+    }
+    if (tz < 2) {
+      if (r == 2 * MT - 2) load_w(tz + 1, 0);
+      if (r == 2 * MT - 1) load_w(tz + 1, 1);
+      if (r == 2 * MT) load_w(tz + 1, 2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) store_tile_any(acc[mt][nt], out, d, b, dz, wo0 + mt, ho, nt, lane, out_layout, slope);
+}
+
+// ===========================================================================================================
 // First block (planar fp32 input, stride 1) on the bf16 MFMA.  Brick = 4 planes (one per wave) x 4 rows x 64
 // voxels.  K order: 27 window rows (channel, tz, ty) x 4 columns (tx = 0..2 and a zero-weight 4th) = 108 -> 128 =
 // four 16x16x32 MFMAs per 16-voxel tile (the fp32 kernel needs 21 16x16x4 MFMAs = 10x the matrix-pipe time): the
@@ -661,6 +795,8 @@ extern "C" int lr_conv3d_k3_lrelu_bf16(const void* in, const void* packed_w, con
   // rows per wave: 8 for the big first stride-2 block (fewer weight loads per MFMA), 4 otherwise; LIFTREG_BF16_MT overrides
   int mtb = (Cin == 16 && d.Wo >= 64) ? 8 : 4;
   if (const char* e = getenv("LIFTREG_BF16_MT")) mtb = atoi(e) == 8 ? 8 : 4;  // tuning aid
+  const bool rows = Cin == 16 && ps && !getenv("LIFTREG_CONV_TAPMAJOR");  // block 1: the row-major kernel (tuning aid: tap-major)
+  if (rows) mtb = 4;  // 4 rows per wave: 8 would not fit three waves per SIMD
   d.nHq = (d.Ho + 15) / 16; d.nWq = (d.Wo + mtb - 1) / mtb; d.nDq = (d.Do + TD - 1) / TD;
   const int64_t nblk = (int64_t)B * d.nDq * d.nWq * d.nHq;
   if (nblk > 0x7fffffffLL) return LR_EINVAL;
@@ -674,6 +810,11 @@ extern "C" int lr_conv3d_k3_lrelu_bf16(const void* in, const void* packed_w, con
     else hipLaunchKernelGGL((conv3d_cl_bf16_kernel<NTV, C32, PSV, 4>), grid, block, 0, st, x, wt, bias, out, d, out_layout, negative_slope);          \
   } while (0)
   const int NT = Cout / 16;
+  if (rows) {
+    if (NT == 2) hipLaunchKernelGGL((conv3d_cl_rows_bf16_kernel<2, 4>), grid, block, 0, st, x, wt, bias, out, d, out_layout, negative_slope);
+    else hipLaunchKernelGGL((conv3d_cl_rows_bf16_kernel<1, 4>), grid, block, 0, st, x, wt, bias, out, d, out_layout, negative_slope);
+    return lr_launch_status();
+  }
   if (Cin == 32) {
     if (NT == 2) { if (ps) LR_BF(2, true, true); else LR_BF(2, true, false); }
     else         { if (ps) LR_BF(1, true, true); else LR_BF(1, true, false); }
