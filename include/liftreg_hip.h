@@ -284,6 +284,21 @@ int lr_pca_reconstruct_bf16basis_f32(const float* coefs, const void* basis_bf16,
 int lr_pca_bwd_coef_bf16basis_f32(const float* gdisp, const void* basis_bf16, float* partial, float* gcoefs, int B,
                                   int L, int64_t M, int64_t ldb, int64_t gdisp_batch_stride, int nblk, void* stream);
 
+/* ---- f1: PCA reconstruction + identity + trilinear warp in ONE pass (the model's decode half in inference).
+ * Replaces the sequence …Backproj.py:102 (F.linear with the PCA basis) → :68 (disp + id) → :69 (Bilinear warp) and
+ * writes all three model outputs: disp = `params` (B,3,D,W,H), phi (B,3,D,W,H), warped (B,C,D,W,H).  Same arithmetic
+ * as lr_pca_reconstruct_f32 followed by lr_warp_trilinear_f32 (bit-identical outputs); the displacement field is
+ * never read back.  basis (L, ldb >= 3·D·W·H) fp32 or bf16 storage; zeros padding, flags = 0 | LR_WARP_USING_SCALE;
+ * B <= 8 per call, H % 4 == 0, 16-byte aligned buffers, volume under 2 GB: otherwise LR_EUNSUPPORTED / LR_EALIGN and
+ * the caller runs the two separate entry points. */
+int lr_pca_warp_f32(const float* coefs, const float* basis, const float* mean, const float* img, const float* id0,
+                    const float* id1, const float* id2, float* disp, float* phi, float* warped, int B, int L, int C,
+                    int D, int W, int H, int64_t ldb, int flags, void* stream);
+int lr_pca_warp_bf16basis_f32(const float* coefs, const void* basis_bf16, const float* mean, const float* img,
+                              const float* id0, const float* id1, const float* id2, float* disp, float* phi,
+                              float* warped, int B, int L, int C, int D, int W, int H, int64_t ldb, int flags,
+                              void* stream);
+
 /* ---- bf16 variant of the stride-2 encoder blocks (Cin, Cout in {16,32}; v_mfma_f32_16x16x32_bf16, fp32
  * accumulate, bias/LeakyReLU in fp32, output rounded to bf16 — or fp32 NCDHW for the last block).
  * in: bf16 LR_LAYOUT_BF16_NDHWC[_HPS]; packed_w: lr_conv3d_packed_bf16_bytes(...) bytes written by

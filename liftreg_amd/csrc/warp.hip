@@ -229,6 +229,53 @@ __device__ __forceinline__ AxisF axis_fast(float g, int size) {
   return a;
 }
 
+// One trilinear sample of the fast path: phi components (g0,g1,g2) <-> (D,W,H) axes, taps from `rsrc` (one image).
+template <bool SCALE>
+__device__ __forceinline__ float tri_sample_fast(const __amdgpu_buffer_rsrc_t rsrc, float g0, float g1, float g2, int D,
+                                                 int W, int H, int sD) {
+  constexpr int OUTSIDE = 0x20000000;  // elements; ·4 bytes = 2^31 ≥ any resource length accepted by the launchers
+  // grid (x,y,z) = phi channels (2,1,0): x ↔ H, y ↔ W, z ↔ D
+  const AxisF ax = axis_fast(g2, H), ay = axis_fast(g1, W), az = axis_fast(g0, D);
+  const bool all = ax.valid && ay.valid && az.valid;
+  const int y0 = (all && ay.i0 >= 0) ? __mul24(ay.i0, H) : OUTSIDE;
+  const int y1 = (all && ay.i0 + 1 < W) ? __mul24(ay.i0 + 1, H) : OUTSIDE;
+  const int z0 = __mul24(az.i0, sD), z1 = z0 + sD;
+  const int xb = min(max(ax.i0, 0), H - 2);
+  const unsigned xb4 = (unsigned)xb << 2;
+  const unsigned o00 = ((unsigned)(z0 + y0) << 2) + xb4, o01 = ((unsigned)(z0 + y1) << 2) + xb4;
+  const unsigned o10 = ((unsigned)(z1 + y0) << 2) + xb4, o11 = ((unsigned)(z1 + y1) << 2) + xb4;
+  const uint2 q00 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, o00, 0, 0));
+  const uint2 q01 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, o01, 0, 0));
+  const uint2 q10 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, o10, 0, 0));
+  const uint2 q11 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, o11, 0, 0));
+  float tp[8] = {__builtin_bit_cast(float, q00.x), __builtin_bit_cast(float, q00.y),
+                 __builtin_bit_cast(float, q01.x), __builtin_bit_cast(float, q01.y),
+                 __builtin_bit_cast(float, q10.x), __builtin_bit_cast(float, q10.y),
+                 __builtin_bit_cast(float, q11.x), __builtin_bit_cast(float, q11.y)};
+  const int shift = ax.i0 - xb;  // -1: x0 = -1 (tap 0 missing, tap 1 is the pair's first); +1: x0 = H-1
+  if (__builtin_amdgcn_ballot_w64(shift != 0) != 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float px = tp[2 * r], py = tp[2 * r + 1];
+      tp[2 * r] = shift < 0 ? 0.0f : (shift > 0 ? py : px);
+      tp[2 * r + 1] = shift > 0 ? 0.0f : (shift < 0 ? px : py);
+    }
+  }
+  if constexpr (SCALE) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) tp[r] = tp[r] + 1.0f;  // (input1 + 1), the /2 is taken out exactly
+  }
+  float s = tp[0] * ((ax.w0 * ay.w0) * az.w0);
+  s = s + tp[1] * ((ax.w1 * ay.w0) * az.w0);
+  s = s + tp[2] * ((ax.w0 * ay.w1) * az.w0);
+  s = s + tp[3] * ((ax.w1 * ay.w1) * az.w0);
+  s = s + tp[4] * ((ax.w0 * ay.w0) * az.w1);
+  s = s + tp[5] * ((ax.w1 * ay.w0) * az.w1);
+  s = s + tp[6] * ((ax.w0 * ay.w1) * az.w1);
+  s = s + tp[7] * ((ax.w1 * ay.w1) * az.w1);
+  return SCALE ? s - 1.0f : s;  // (output/2) * 2 - 1
+}
+
 template <bool SCALE>
 __global__ __launch_bounds__(256) void warp_tri_fast_kernel(
     const float* __restrict__ img, const float* __restrict__ disp, const float* __restrict__ id0,
@@ -268,56 +315,113 @@ __global__ __launch_bounds__(256) void warp_tri_fast_kernel(
     *reinterpret_cast<float4*>(pp + 2 * slabV) = make_float4(d2v[0], d2v[1], d2v[2], d2v[3]);
   }
 
-  constexpr int OUTSIDE = 0x20000000;  // elements; ·4 bytes = 2^31 ≥ any resource length accepted by the launcher
   for (int c = 0; c < C; ++c) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(img + ((int64_t)b * C + c) * V), (short)0, (int)(V * 4), 0x00020000);
     float res[4];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      // grid (x,y,z) = phi channels (2,1,0): x ↔ H, y ↔ W, z ↔ D
-      const AxisF ax = axis_fast(d2v[v], H), ay = axis_fast(d1v[v], W), az = axis_fast(d0v[v], D);
-      const bool all = ax.valid && ay.valid && az.valid;
-      const int y0 = (all && ay.i0 >= 0) ? __mul24(ay.i0, H) : OUTSIDE;
-      const int y1 = (all && ay.i0 + 1 < W) ? __mul24(ay.i0 + 1, H) : OUTSIDE;
-      const int z0 = __mul24(az.i0, sD), z1 = z0 + sD;
-      const int xb = min(max(ax.i0, 0), H - 2);
-      const unsigned xb4 = (unsigned)xb << 2;
-      const unsigned o00 = ((unsigned)(z0 + y0) << 2) + xb4, o01 = ((unsigned)(z0 + y1) << 2) + xb4;
-      const unsigned o10 = ((unsigned)(z1 + y0) << 2) + xb4, o11 = ((unsigned)(z1 + y1) << 2) + xb4;
-      const uint2 q00 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, o00, 0, 0));
-      const uint2 q01 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, o01, 0, 0));
-      const uint2 q10 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, o10, 0, 0));
-      const uint2 q11 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, o11, 0, 0));
-      float tp[8] = {__builtin_bit_cast(float, q00.x), __builtin_bit_cast(float, q00.y),
-                     __builtin_bit_cast(float, q01.x), __builtin_bit_cast(float, q01.y),
-                     __builtin_bit_cast(float, q10.x), __builtin_bit_cast(float, q10.y),
-                     __builtin_bit_cast(float, q11.x), __builtin_bit_cast(float, q11.y)};
-      const int shift = ax.i0 - xb;  // -1: x0 = -1 (tap 0 missing, tap 1 is the pair's first); +1: x0 = H-1
-      if (__builtin_amdgcn_ballot_w64(shift != 0) != 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float px = tp[2 * r], py = tp[2 * r + 1];
-          tp[2 * r] = shift < 0 ? 0.0f : (shift > 0 ? py : px);
-          tp[2 * r + 1] = shift > 0 ? 0.0f : (shift < 0 ? px : py);
-        }
-      }
-      if constexpr (SCALE) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) tp[r] = tp[r] + 1.0f;  // (input1 + 1), the /2 is taken out exactly
-      }
-      float s = tp[0] * ((ax.w0 * ay.w0) * az.w0);
-      s = s + tp[1] * ((ax.w1 * ay.w0) * az.w0);
-      s = s + tp[2] * ((ax.w0 * ay.w1) * az.w0);
-      s = s + tp[3] * ((ax.w1 * ay.w1) * az.w0);
-      s = s + tp[4] * ((ax.w0 * ay.w0) * az.w1);
-      s = s + tp[5] * ((ax.w1 * ay.w0) * az.w1);
-      s = s + tp[6] * ((ax.w0 * ay.w1) * az.w1);
-      s = s + tp[7] * ((ax.w1 * ay.w1) * az.w1);
-      res[v] = SCALE ? s - 1.0f : s;  // (output/2) * 2 - 1
-    }
+    for (int v = 0; v < 4; ++v) res[v] = tri_sample_fast<SCALE>(rsrc, d0v[v], d1v[v], d2v[v], D, W, H, sD);
     float* wp = warped + ((int64_t)b * C + c) * slabV + (int64_t)i * sD + inplane;
     *reinterpret_cast<float4*>(wp) = make_float4(res[0], res[1], res[2], res[3]);
+  }
+}
+
+// ---- f1: PCA reconstruction + identity + warp in one pass -----------------------------------------------------
+// disp = coefs·basis + mean (the arithmetic of pca.hip's pca_kernel: the same fmaf chain per element), phi = disp + id,
+// warped = trilinear(moving, phi) (tri_sample_fast) — the displacement field is written once (`params`, `phi` are
+// model outputs) and never read back: the separate warp kernel re-read 4·3V bytes per sample.  A thread owns 4
+// consecutive voxels of a row and ALL batch rows (the basis is streamed once per batch, as in pca_kernel): 8 x 3
+// float4 accumulators, three basis streams (the rows' D-, W- and H-component thirds).
+template <bool BF, bool SCALE>
+__global__ __launch_bounds__(256) void pca_warp_kernel(const float* __restrict__ coefs, const float* __restrict__ basis,
+                                                       const float* __restrict__ mean, const float* __restrict__ img,
+                                                       const float* __restrict__ id0, const float* __restrict__ id1,
+                                                       const float* __restrict__ id2, float* __restrict__ disp_out,
+                                                       float* __restrict__ phi_out, float* __restrict__ warped, int B,
+                                                       int L, int C, int D, int W, int H, int64_t ldb, float rcp_hv) {
+  constexpr int BT = 8;
+  extern __shared__ float cs[];  // [L][BT]
+  for (int t = threadIdx.x; t < L * BT; t += blockDim.x) {
+    const int l = t / BT, b = t % BT;
+    cs[t] = b < B ? coefs[(int64_t)b * L + l] : 0.0f;
+  }
+  __syncthreads();
+  const int HV = H >> 2;
+  const int t = blockIdx.x * 256 + threadIdx.x;  // float4 index inside plane i
+  const int i = blockIdx.y;
+  const int j = (int)(((float)t + 0.5f) * rcp_hv);
+  if (j >= W) return;
+  const int kv = t - __mul24(j, HV);
+  const int sD = W * H;
+  const int64_t V = (int64_t)D * sD;
+  const int inplane = __mul24(j, H) + (kv << 2);
+  const int64_t m = (int64_t)i * sD + inplane;  // voxel index = column of the D-component third
+
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  f32x4v acc[BT][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const f32x4v mu = *reinterpret_cast<const f32x4v*>(mean + c * V + m);
+#pragma unroll
+    for (int b = 0; b < BT; ++b) acc[b][c] = mu;
+  }
+#pragma unroll 4
+  for (int l = 0; l < L; ++l) {
+    f32x4v v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (BF) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 raw = __builtin_nontemporal_load(
+            reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(basis) + (int64_t)l * ldb + c * V + m));
+        v[c][0] = __builtin_bit_cast(float, raw.x << 16);
+        v[c][1] = __builtin_bit_cast(float, raw.x & 0xffff0000u);
+        v[c][2] = __builtin_bit_cast(float, raw.y << 16);
+        v[c][3] = __builtin_bit_cast(float, raw.y & 0xffff0000u);
+      } else {
+        v[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(basis + (int64_t)l * ldb + c * V + m));
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      const float cf = cs[l * BT + b];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        acc[b][c][0] = fmaf(cf, v[c][0], acc[b][c][0]);
+        acc[b][c][1] = fmaf(cf, v[c][1], acc[b][c][1]);
+        acc[b][c][2] = fmaf(cf, v[c][2], acc[b][c][2]);
+        acc[b][c][3] = fmaf(cf, v[c][3], acc[b][c][3]);
+      }
+    }
+  }
+  const float a0 = id0[i], a1 = id1[j];
+  const f32x4v a2 = *reinterpret_cast<const f32x4v*>(id2 + (kv << 2));
+#pragma unroll
+  for (int b = 0; b < BT; ++b) {
+    if (b >= B) break;
+    float* dp = disp_out + (int64_t)b * 3 * V + m;
+    __builtin_nontemporal_store(acc[b][0], reinterpret_cast<f32x4v*>(dp));
+    __builtin_nontemporal_store(acc[b][1], reinterpret_cast<f32x4v*>(dp + V));
+    __builtin_nontemporal_store(acc[b][2], reinterpret_cast<f32x4v*>(dp + 2 * V));
+    f32x4v p0, p1, p2;  // deform_field = disp_field + id_transform
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      p0[v] = acc[b][0][v] + a0;
+      p1[v] = acc[b][1][v] + a1;
+      p2[v] = acc[b][2][v] + a2[v];
+    }
+    float* pp = phi_out + (int64_t)b * 3 * V + m;
+    __builtin_nontemporal_store(p0, reinterpret_cast<f32x4v*>(pp));
+    __builtin_nontemporal_store(p1, reinterpret_cast<f32x4v*>(pp + V));
+    __builtin_nontemporal_store(p2, reinterpret_cast<f32x4v*>(pp + 2 * V));
+    for (int c = 0; c < C; ++c) {
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(img + ((int64_t)b * C + c) * V), (short)0, (int)(V * 4), 0x00020000);
+      f32x4v res;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) res[v] = tri_sample_fast<SCALE>(rsrc, p0[v], p1[v], p2[v], D, W, H, sD);
+      __builtin_nontemporal_store(res, reinterpret_cast<f32x4v*>(warped + ((int64_t)b * C + c) * V + m));
+    }
   }
 }
 
@@ -400,6 +504,46 @@ extern "C" int lr_warp_trilinear_f32(const float* img, const float* seg, const f
                             Dn, lr_stream(stream));
   return dispatch_warp<1>(flags, img, seg, disp, id0, id1, id2, phi_out, warped, B, C, D, W, H, Dn,
                           lr_stream(stream));
+}
+
+static int pca_warp_impl(bool bf, const float* coefs, const float* basis, const float* mean, const float* img,
+                         const float* id0, const float* id1, const float* id2, float* disp, float* phi, float* warped,
+                         int B, int L, int C, int D, int W, int H, int64_t ldb, int flags, void* stream) {
+  if (!coefs || !basis || !mean || !img || !id0 || !id1 || !id2 || !disp || !phi || !warped) return LR_ENULL;
+  if (B < 1 || L < 1 || C < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
+  if (flags & ~LR_WARP_USING_SCALE) return LR_EUNSUPPORTED;  // zeros padding, trilinear only (the model's case)
+  const int64_t sD = (int64_t)W * H, V = sD * D;
+  if (B > 8 || L > 2048 || (H & 3) || ldb < 3 * V) return LR_EUNSUPPORTED;  // larger batches: chunks of 8 (ops.pca_warp)
+  if (!(V * 4 + sD * 4 <= 0x80000000LL && sD < (1 << 23) && sD / 4 <= (1 << 20) && D <= 65535)) return LR_EUNSUPPORTED;
+  if (((reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(disp) | reinterpret_cast<uintptr_t>(phi) |
+        reinterpret_cast<uintptr_t>(warped) | reinterpret_cast<uintptr_t>(id2)) & 15u) ||
+      (reinterpret_cast<uintptr_t>(basis) & (bf ? 7u : 15u)) || (ldb & 3))
+    return LR_EALIGN;
+  const dim3 grid((unsigned)((sD / 4 + 255) / 256), (unsigned)D), block(256);
+  const size_t lds = (size_t)L * 8 * sizeof(float);
+  const float rcp_hv = 1.0f / (float)(H / 4);
+  hipStream_t st = lr_stream(stream);
+  const bool sc = flags & LR_WARP_USING_SCALE;
+#define LR_PW(BFV, SCV) hipLaunchKernelGGL((pca_warp_kernel<BFV, SCV>), grid, block, lds, st, coefs, basis, mean, img, id0, id1, id2, disp, phi, warped, B, L, C, D, W, H, ldb, rcp_hv)
+  if (bf) { if (sc) LR_PW(true, true); else LR_PW(true, false); }
+  else    { if (sc) LR_PW(false, true); else LR_PW(false, false); }
+#undef LR_PW
+  return lr_launch_status();
+}
+
+extern "C" int lr_pca_warp_f32(const float* coefs, const float* basis, const float* mean, const float* img,
+                               const float* id0, const float* id1, const float* id2, float* disp, float* phi,
+                               float* warped, int B, int L, int C, int D, int W, int H, int64_t ldb, int flags,
+                               void* stream) {
+  return pca_warp_impl(false, coefs, basis, mean, img, id0, id1, id2, disp, phi, warped, B, L, C, D, W, H, ldb, flags, stream);
+}
+
+extern "C" int lr_pca_warp_bf16basis_f32(const float* coefs, const void* basis_bf16, const float* mean, const float* img,
+                                         const float* id0, const float* id1, const float* id2, float* disp, float* phi,
+                                         float* warped, int B, int L, int C, int D, int W, int H, int64_t ldb, int flags,
+                                         void* stream) {
+  return pca_warp_impl(true, coefs, reinterpret_cast<const float*>(basis_bf16), mean, img, id0, id1, id2, disp, phi, warped,
+                       B, L, C, D, W, H, ldb, flags, stream);
 }
 
 extern "C" int lr_mask_compose_f32(const float* img, const float* seg, float* out, int64_t n,

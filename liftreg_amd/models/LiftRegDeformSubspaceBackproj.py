@@ -238,6 +238,10 @@ class model(nn.Module):
     def decode(self, moving, coefs, moving_seg=None):
         """HBM-bound half: PCA reconstruction → identity add + trilinear warp.  Returns (disp, phi, warped)."""
         B, _, D, W, H = moving.shape
+        if (moving_seg is None and not (torch.is_grad_enabled() and coefs.requires_grad) and
+                ops.pca_warp_supported(coefs, self.pca_vectors_LxM, moving)):
+            # inference: one pass writes params, phi and warped (SURVEY §8 f1) — the same bits as the two kernels below
+            return ops.pca_warp(coefs, self.pca_vectors_LxM, self.pca_mean, (self._id0, self._id1, self._id2), moving)
         disp = PCAFn.apply(coefs, self.pca_vectors_LxM, self.pca_mean).view(B, 3, D, W, H)
         # deform_field = disp + id ; warped = Bilinear(moving_cp, deform_field): one kernel; the mask
         # compose of moving ((moving+1)*seg-1, :57) happens on the taps

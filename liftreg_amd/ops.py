@@ -439,6 +439,48 @@ def warp(img, disp, ids=None, seg=None, *, using_scale=True, zero_boundary=True,
     return phi, warped
 
 
+def pca_warp_supported(coefs, basis_LxM, img):
+    """True when the one-pass decode `pca_warp` can run these tensors (else: pca_reconstruct + warp)."""
+    B, C, D, W, H = img.shape
+    V = D * W * H
+    return (H % 4 == 0 and basis_LxM.shape[1] == 3 * V and basis_LxM.stride(1) == 1 and basis_LxM.stride(0) % 4 == 0 and
+            basis_LxM.shape[0] <= 2048 and 4 * V + 4 * W * H <= 2 ** 31 and W * H < 2 ** 22 and D <= 65535 and
+            coefs.shape[0] == B)
+
+
+def pca_warp(coefs, basis_LxM, mean, ids, img, *, using_scale=True):
+    """disp = coefs·basis + mean ; phi = disp + identity ; warped = Bilinear(img, phi) in ONE kernel:
+    the displacement field is written once and never read back.  Returns (disp, phi, warped), bit-identical to
+    `pca_reconstruct` followed by `warp`.  Batches above 8 run in chunks (the basis is re-read per chunk).
+    Replaces …Backproj.py:102 + :68-69 in inference."""
+    coefs, mean, img = _dev(coefs, "coefs"), _dev(mean, "mean"), _dev(img, "img")
+    if not basis_LxM.is_cuda or basis_LxM.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("basis must be a float32 (or bfloat16-stored) GPU tensor")
+    bf = basis_LxM.dtype == torch.bfloat16
+    basis = basis_LxM
+    if coefs.shape[1] != basis.shape[0] or mean.shape[0] != basis.shape[1]:
+        raise ValueError("basis/mean shape mismatch")
+    if not pca_warp_supported(coefs, basis, img):
+        raise ValueError("pca_warp: unsupported shapes (use pca_reconstruct + warp)")
+    B, C, D, W, H = img.shape
+    L = basis.shape[0]
+    i0, i1, i2 = (_dev(t, "id table") for t in ids)
+    disp = torch.empty((B, 3, D, W, H), dtype=torch.float32, device=img.device)
+    phi = torch.empty_like(disp)
+    warped = torch.empty((B, C, D, W, H), dtype=torch.float32, device=img.device)
+    fn = _hip.lib().lr_pca_warp_bf16basis_f32 if bf else _hip.lib().lr_pca_warp_f32
+    V = D * W * H
+    for lo in range(0, B, 8):
+        hi = min(B, lo + 8)
+        nb = (2 if bf else 4) * L * 3 * V + 4 * 3 * V + (hi - lo) * 4 * V * (6 + 2 * C)
+        with _timed("pca_warp" + ("_bf16basis" if bf else ""), bytes=nb, samples=hi - lo):
+            _hip.check(fn(coefs[lo:hi].data_ptr(), basis.data_ptr(), mean.data_ptr(), img[lo:hi].data_ptr(), i0.data_ptr(),
+                          i1.data_ptr(), i2.data_ptr(), disp[lo:hi].data_ptr(), phi[lo:hi].data_ptr(),
+                          warped[lo:hi].data_ptr(), hi - lo, L, C, D, W, H, basis.stride(0),
+                          _hip.WARP_USING_SCALE if using_scale else 0, _stream()), "lr_pca_warp_f32")
+    return disp, phi, warped
+
+
 def mask_compose(img, seg):
     """(img+1)*seg-1  (reference …Backproj.py:57-58)."""
     img = _dev(img, "img")

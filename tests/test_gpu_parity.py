@@ -248,6 +248,32 @@ def test_warp_fast_kernel_equals_general_kernel_on_hostile_input(ops, dev, monke
         assert np.array_equal(w.cpu().numpy(), cw), shape                         # and the C oracle, finite input
 
 
+def test_pca_warp_one_pass_equals_two_kernels(ops, dev):
+    """lr_pca_warp_f32 (PCA reconstruction + identity + warp, displacement never re-read) writes the same
+    bits as lr_pca_reconstruct_f32 followed by lr_warp_trilinear_f32 — fp32 and bf16-stored basis, batches above the
+    kernel's 8 rows (chunked), displacements that leave the volume, with and without the intensity rescale."""
+    from liftreg_amd.utils import net_utils as N
+    rs = np.random.RandomState(21)
+    for shape, B, C, Lat, scale in (((6, 7, 8), 3, 1, 5, 0.4), ((9, 5, 20), 11, 1, 7, 0.15), ((4, 6, 260), 2, 2, 3, 0.05)):
+        V = int(np.prod(shape))
+        img = T(rs.uniform(-1, 1, (B, C) + shape).astype(np.float32), dev)
+        basis = T(rs.normal(0, scale, (Lat, 3 * V)).astype(np.float32), dev)
+        mean = T(rs.normal(0, 0.02, 3 * V).astype(np.float32), dev)
+        coefs = T(rs.normal(0, 1, (B, Lat)).astype(np.float32), dev)
+        ids = [T(t, dev) for t in N.identity_axis_tables(shape)]
+        for bs in (basis, basis.to(torch.bfloat16)):
+            for sc in (True, False):
+                assert ops.pca_warp_supported(coefs, bs, img)
+                d1, p1, w1 = ops.pca_warp(coefs, bs, mean, ids, img, using_scale=sc)
+                d2 = ops.pca_reconstruct(coefs, bs, mean).view(B, 3, *shape)
+                p2, w2 = ops.warp(img, d2, ids, None, using_scale=sc)
+                assert torch.equal(d1, d2) and torch.equal(p1, p2) and torch.equal(w1, w2), (shape, bs.dtype, sc)
+        cw = co.warp(img.cpu().numpy(), d2.cpu().numpy(), ids=N.identity_axis_tables(shape), flags=0)[1]
+        assert np.array_equal(w1.cpu().numpy(), cw)                                 # and the C oracle (last: no rescale)
+    odd = T(rs.uniform(-1, 1, (1, 1, 4, 4, 6)).astype(np.float32), dev)             # H % 4 != 0: the caller falls back
+    assert not ops.pca_warp_supported(T(np.zeros((1, 2), np.float32), dev), T(np.zeros((2, 288), np.float32), dev), odd)
+
+
 # ------------------------------------------------------------------------------------- K8 NCC
 def test_ncc_golden_and_sharded(golden, ops, dev):
     from liftreg_amd.layers.losses import NCCLoss
