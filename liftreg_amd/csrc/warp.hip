@@ -332,14 +332,13 @@ __global__ __launch_bounds__(256) void warp_tri_fast_kernel(
 // model outputs) and never read back: the separate warp kernel re-read 4·3V bytes per sample.  A thread owns 4
 // consecutive voxels of a row and ALL batch rows (the basis is streamed once per batch, as in pca_kernel): 8 x 3
 // float4 accumulators, three basis streams (the rows' D-, W- and H-component thirds).
-template <bool BF, bool SCALE>
+template <bool BF, bool SCALE, int BT /* batch rows per thread: 8, or 4 for small batches (half the accumulators) */>
 __global__ __launch_bounds__(256) void pca_warp_kernel(const float* __restrict__ coefs, const float* __restrict__ basis,
                                                        const float* __restrict__ mean, const float* __restrict__ img,
                                                        const float* __restrict__ id0, const float* __restrict__ id1,
                                                        const float* __restrict__ id2, float* __restrict__ disp_out,
                                                        float* __restrict__ phi_out, float* __restrict__ warped, int B,
                                                        int L, int C, int D, int W, int H, int64_t ldb, float rcp_hv) {
-  constexpr int BT = 8;
   extern __shared__ float cs[];  // [L][BT]
   for (int t = threadIdx.x; t < L * BT; t += blockDim.x) {
     const int l = t / BT, b = t % BT;
@@ -520,14 +519,15 @@ static int pca_warp_impl(bool bf, const float* coefs, const float* basis, const 
       (reinterpret_cast<uintptr_t>(basis) & (bf ? 7u : 15u)) || (ldb & 3))
     return LR_EALIGN;
   const dim3 grid((unsigned)((sD / 4 + 255) / 256), (unsigned)D), block(256);
-  const size_t lds = (size_t)L * 8 * sizeof(float);
   const float rcp_hv = 1.0f / (float)(H / 4);
   hipStream_t st = lr_stream(stream);
   const bool sc = flags & LR_WARP_USING_SCALE;
-#define LR_PW(BFV, SCV) hipLaunchKernelGGL((pca_warp_kernel<BFV, SCV>), grid, block, lds, st, coefs, basis, mean, img, id0, id1, id2, disp, phi, warped, B, L, C, D, W, H, ldb, rcp_hv)
+#define LR_PW1(BFV, SCV, BTV) hipLaunchKernelGGL((pca_warp_kernel<BFV, SCV, BTV>), grid, block, (size_t)L * BTV * sizeof(float), st, coefs, basis, mean, img, id0, id1, id2, disp, phi, warped, B, L, C, D, W, H, ldb, rcp_hv)
+#define LR_PW(BFV, SCV) do { if (B <= 4) LR_PW1(BFV, SCV, 4); else LR_PW1(BFV, SCV, 8); } while (0)
   if (bf) { if (sc) LR_PW(true, true); else LR_PW(true, false); }
   else    { if (sc) LR_PW(false, true); else LR_PW(false, false); }
 #undef LR_PW
+#undef LR_PW1
   return lr_launch_status();
 }
 
