@@ -75,6 +75,20 @@ def test_fuzz_warp_pca_ncc_reg(dev):
         coefs = rs.normal(0, 1, (B, Lat)).astype(np.float32)
         got = ops.pca_reconstruct(T(coefs, dev), T(basis, dev), T(mean, dev)).cpu().numpy()
         np.testing.assert_allclose(got, coefs.astype(np.float64) @ basis + mean, rtol=1e-4, atol=1e-5, err_msg=str(("pca", B, Lat, M)))
+        # one-pass decode (PCA + identity + warp) == the two kernels, wherever it applies (rows of 4k voxels)
+        V3 = 3 * int(np.prod(shape))
+        Lw = int(rs.randint(1, 12))
+        bw = T(rs.normal(0, 0.1, (Lw, V3)).astype(np.float32), dev)
+        if rs.randint(0, 2):
+            bw = bw.to(torch.bfloat16)
+        mw, cw = T(rs.normal(0, 0.02, V3).astype(np.float32), dev), T(rs.normal(0, 1, (B, Lw)).astype(np.float32), dev)
+        if ops.pca_warp_supported(cw, bw, T(img, dev)):
+            d1, p1, w1 = ops.pca_warp(cw, bw, mw, [T(t, dev) for t in tabs], T(img, dev))
+            d2 = ops.pca_reconstruct(cw, bw, mw).view(B, 3, *shape)
+            p2, w2 = ops.warp(T(img, dev), d2, [T(t, dev) for t in tabs], None)
+            assert torch.equal(d1, d2) and torch.equal(p1, p2) and torch.equal(w1, w2), ("pca_warp", shape, B, C, Lw, bw.dtype)
+        else:
+            assert shape[2] % 4 != 0
         # NCC (both variants) and the regulariser
         x, y = rs.uniform(-1, 1, (B, C) + shape).astype(np.float32), rs.uniform(-1, 1, (B, C) + shape).astype(np.float32)
         assert abs(float(ops.ncc_loss(T(x, dev), T(y, dev), 0)) - float(ro.ncc_loss(torch.from_numpy(x), torch.from_numpy(y)))) < 2e-5
