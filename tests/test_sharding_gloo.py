@@ -26,6 +26,10 @@ class OracleOps:
         from oracle import ref_ops as ro
         self.co, self.ro = co, ro
 
+    @staticmethod
+    def pca_warp_supported(*_):
+        return False      # the shim keeps the two-kernel decode (pca_reconstruct + warp)
+
     # ---- layouts (mirror of LR_LAYOUT_*) -------------------------------------------------------
     def _to_ncdhw(self, x, layout):
         if layout == self.LAYOUT_NCDHW:
