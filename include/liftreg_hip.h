@@ -241,6 +241,13 @@ int lr_ncc_bwd_f32(const float* x, const float* y, const double* moments, const 
 int lr_warp_bwd_disp_f32(const float* img, const float* seg, const float* disp, const float* id0,
                          const float* id1, const float* id2, const float* gwarped, float* gdisp, int B,
                          int C, int D, int W, int H, int d0, int d1, int flags, void* stream);
+/* Same, plus gadd (B,3,Dn,W,H): gdisp = (d warped / d disp)·gwarped + gadd.  The displacement field feeds the warp AND
+ * the regulariser (losses/SubspaceLoss.py:63); this folds the sum autograd forms for the two paths into the warp's
+ * gradient kernel (one pass over 3V floats per sample less).  gdisp and gadd are distinct buffers. */
+int lr_warp_bwd_disp_acc_f32(const float* img, const float* seg, const float* disp, const float* id0,
+                             const float* id1, const float* id2, const float* gwarped, const float* gadd,
+                             float* gdisp, int B, int C, int D, int W, int H, int d0, int d1, int flags,
+                             void* stream);
 /* d/d coefs of lr_pca_reconstruct_f32: gcoefs (B,L) = gdisp (B,M) · basis^T.  B <= 8.
  * partial: dev workspace nblk*B*L floats. */
 int lr_pca_bwd_coef_f32(const float* gdisp, const float* basis, float* partial, float* gcoefs, int B,

@@ -148,6 +148,43 @@ class WarpFn(torch.autograd.Function):
         return None, g, None, None, None, None, None, None
 
 
+class DecodeFn(torch.autograd.Function):
+    """The decode half as ONE autograd node: (disp, phi, warped) = warp(img, coefs @ basis + mean).
+
+    Forward: the one-pass kernel (ops.pca_warp) where it applies, else PCA reconstruction + warp — the same bits.
+    Backward: the displacement field receives gradient through `warped` (the similarity), through `disp` itself (the
+    model returns it as `params`, which the regulariser reads) and possibly through `phi`; their sum is formed inside
+    the warp-gradient kernel (`gadd`) instead of by a pass of autograd's own, then projected onto the basis."""
+
+    @staticmethod
+    def forward(ctx, coefs, basis_LxM, mean, img, id0, id1, id2, seg, using_scale):
+        B, _, D, W, H = img.shape
+        if seg is None and ops.pca_warp_supported(coefs, basis_LxM, img):
+            disp, phi, warped = ops.pca_warp(coefs, basis_LxM, mean, (id0, id1, id2), img, using_scale=using_scale)
+        else:
+            disp = ops.pca_reconstruct(coefs, basis_LxM, mean).view(B, 3, D, W, H)
+            phi, warped = ops.warp(img, disp, (id0, id1, id2), seg, using_scale=using_scale, zero_boundary=True)
+        ctx.save_for_backward(basis_LxM, img, disp, id0, id1, id2, seg if seg is not None else img.new_empty(0))
+        ctx.cfg = (using_scale, seg is not None)
+        ctx.set_materialize_grads(False)
+        return disp, phi, warped
+
+    @staticmethod
+    def backward(ctx, gdisp, gphi, gwarped):
+        basis, img, disp, id0, id1, id2, seg = ctx.saved_tensors
+        using_scale, has_seg = ctx.cfg
+        direct = gdisp if gphi is None else (gphi if gdisp is None else gdisp + gphi)   # phi = disp + id
+        if gwarped is not None:
+            g = ops_bwd.warp_bwd_disp(img, disp, (id0, id1, id2), seg if has_seg else None, gwarped.contiguous(),
+                                      using_scale=using_scale, zero_boundary=True,
+                                      gadd=None if direct is None else direct.contiguous())
+        else:
+            g = direct
+        if g is None:
+            return (None,) * 9
+        return (ops_bwd.pca_bwd_coef(g.contiguous(), basis),) + (None,) * 8
+
+
 class NCCFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, variant):

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ disp, const float* __restrict__ id0,
                                                        const float* __restrict__ id1, const float* __restrict__ id2,
                                                        const float* __restrict__ gw, float* __restrict__ gdisp,
-                                                       int B, int C, int D, int W, int H, int Dn) {
+                                                       const float* __restrict__ gadd, int B, int C, int D, int W, int H,
+                                                       int Dn) {
   const int64_t per_b = (int64_t)Dn * W * H;
   const int b = blockIdx.y;
   const int64_t idx = (int64_t)lr_xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
@@ -132,9 +133,16 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
     gz += g * dz;
   }
   float* go = gdisp + (int64_t)b * 3 * per_b + idx;
-  go[0] = gz * az.gmul;          // disp channel 0 <-> D
-  go[per_b] = gy * ay.gmul;      // channel 1 <-> W
-  go[2 * per_b] = gx * ax.gmul;  // channel 2 <-> H
+  float r0 = gz * az.gmul, r1 = gy * ay.gmul, r2 = gx * ax.gmul;  // disp channels 0,1,2 <-> D,W,H
+  if (gadd) {  // + the gradient that reaches the displacement field by another path (e.g. the regulariser)
+    const float* ga = gadd + (int64_t)b * 3 * per_b + idx;
+    r0 = r0 + ga[0];
+    r1 = r1 + ga[per_b];
+    r2 = r2 + ga[2 * per_b];
+  }
+  go[0] = r0;
+  go[per_b] = r1;
+  go[2 * per_b] = r2;
 }
 
 // The training step's case (zeros padding, no mask, float4 rows) with a third of the vector-ALU work — the same
@@ -166,8 +174,8 @@ template <bool SCALE>
 __global__ __launch_bounds__(256) void warp_bwd_fast_kernel(const float* __restrict__ img, const float* __restrict__ disp,
                                                             const float* __restrict__ id0, const float* __restrict__ id1,
                                                             const float* __restrict__ id2, const float* __restrict__ gw,
-                                                            float* __restrict__ gdisp, int C, int D, int W, int H, int Dn,
-                                                            float rcp_hv) {
+                                                            float* __restrict__ gdisp, const float* __restrict__ gadd,
+                                                            int C, int D, int W, int H, int Dn, float rcp_hv) {
   const int HV = H >> 2;
   const int t = blockIdx.x * 256 + threadIdx.x;  // float4 index inside plane i
   const int i = blockIdx.y, b = blockIdx.z;
@@ -257,9 +265,20 @@ __global__ __launch_bounds__(256) void warp_bwd_fast_kernel(const float* __restr
   }
   const float mz = 0.5f * (float)(D - 1), my = 0.5f * (float)(W - 1), mx = 0.5f * (float)(H - 1);
   float* go = gdisp + ubase + inplane;
-  *reinterpret_cast<float4*>(go) = make_float4(gz[0] * mz, gz[1] * mz, gz[2] * mz, gz[3] * mz);              // channel 0 <-> D
-  *reinterpret_cast<float4*>(go + slabV) = make_float4(gy[0] * my, gy[1] * my, gy[2] * my, gy[3] * my);      // 1 <-> W
-  *reinterpret_cast<float4*>(go + 2 * slabV) = make_float4(gx[0] * mx, gx[1] * mx, gx[2] * mx, gx[3] * mx);  // 2 <-> H
+  float4 r0 = make_float4(gz[0] * mz, gz[1] * mz, gz[2] * mz, gz[3] * mz);  // channel 0 <-> D
+  float4 r1 = make_float4(gy[0] * my, gy[1] * my, gy[2] * my, gy[3] * my);  // 1 <-> W
+  float4 r2 = make_float4(gx[0] * mx, gx[1] * mx, gx[2] * mx, gx[3] * mx);  // 2 <-> H
+  if (gadd) {  // + the gradient that reaches the displacement field by another path (e.g. the regulariser)
+    const float* ga = gadd + ubase + inplane;
+    const float4 a0 = *reinterpret_cast<const float4*>(ga), a1 = *reinterpret_cast<const float4*>(ga + slabV),
+                 a2 = *reinterpret_cast<const float4*>(ga + 2 * slabV);
+    r0 = make_float4(r0.x + a0.x, r0.y + a0.y, r0.z + a0.z, r0.w + a0.w);
+    r1 = make_float4(r1.x + a1.x, r1.y + a1.y, r1.z + a1.z, r1.w + a1.w);
+    r2 = make_float4(r2.x + a2.x, r2.y + a2.y, r2.z + a2.z, r2.w + a2.w);
+  }
+  *reinterpret_cast<float4*>(go) = r0;
+  *reinterpret_cast<float4*>(go + slabV) = r1;
+  *reinterpret_cast<float4*>(go + 2 * slabV) = r2;
 }
 
 // ------------------------------------------------------------------------------------------------ PCA
@@ -445,9 +464,9 @@ extern "C" int lr_ncc_bwd_f32(const float* x, const float* y, const double* mome
   return lr_launch_status();
 }
 
-extern "C" int lr_warp_bwd_disp_f32(const float* img, const float* seg, const float* disp, const float* id0,
-                                    const float* id1, const float* id2, const float* gwarped, float* gdisp, int B,
-                                    int C, int D, int W, int H, int d0, int d1, int flags, void* stream) {
+static int warp_bwd_impl(const float* img, const float* seg, const float* disp, const float* id0,
+                         const float* id1, const float* id2, const float* gwarped, float* gdisp, const float* gadd, int B,
+                         int C, int D, int W, int H, int d0, int d1, int flags, void* stream) {
   if (!img || !disp || !gwarped || !gdisp) return LR_ENULL;
   if (B < 1 || B > 65535 || C < 1 || D < 1 || W < 1 || H < 1 || d0 < 0 || d1 > D || d1 <= d0) return LR_EINVAL;
   if (flags & ~(LR_WARP_USING_SCALE | LR_WARP_BORDER)) return LR_EUNSUPPORTED;  // nearest mode has no gradient
@@ -459,20 +478,20 @@ extern "C" int lr_warp_bwd_disp_f32(const float* img, const float* seg, const fl
   {
     const int64_t sD = (int64_t)W * H, V = sD * D;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
-    if (!seg && !bo && H % 4 == 0 && al16(disp) && al16(gwarped) && al16(gdisp) && (!id2 || al16(id2)) &&
+    if (!seg && !bo && H % 4 == 0 && al16(disp) && al16(gwarped) && al16(gdisp) && (!gadd || al16(gadd)) && (!id2 || al16(id2)) &&
         V * 4 + sD * 8 <= 0x80000000LL && sD < (1 << 23) && sD / 4 <= (1 << 20) && Dn <= 65535 &&
         !getenv("LIFTREG_WARP_GENERAL")) {
       const dim3 g3((unsigned)((sD / 4 + 255) / 256), (unsigned)Dn, (unsigned)B);
       const float rcp_hv = 1.0f / (float)(H / 4);
-      if (sc) hipLaunchKernelGGL(warp_bwd_fast_kernel<true>, g3, dim3(256), 0, st, img, disp, id0, id1, id2, gwarped, gdisp, C, D, W, H, Dn, rcp_hv);
-      else hipLaunchKernelGGL(warp_bwd_fast_kernel<false>, g3, dim3(256), 0, st, img, disp, id0, id1, id2, gwarped, gdisp, C, D, W, H, Dn, rcp_hv);
+      if (sc) hipLaunchKernelGGL(warp_bwd_fast_kernel<true>, g3, dim3(256), 0, st, img, disp, id0, id1, id2, gwarped, gdisp, gadd, C, D, W, H, Dn, rcp_hv);
+      else hipLaunchKernelGGL(warp_bwd_fast_kernel<false>, g3, dim3(256), 0, st, img, disp, id0, id1, id2, gwarped, gdisp, gadd, C, D, W, H, Dn, rcp_hv);
       return lr_launch_status();
     }
   }
   const int64_t nblk = ((int64_t)Dn * W * H + 255) / 256;
   if (nblk > 0x7fffffffLL) return LR_EINVAL;
   const dim3 grid((unsigned)nblk, (unsigned)B), block(256);
-#define LR_WB(S, Bo, G) hipLaunchKernelGGL((warp_bwd_kernel<S, Bo, G>), grid, block, 0, st, img, seg, disp, id0, id1, id2, gwarped, gdisp, B, C, D, W, H, Dn)
+#define LR_WB(S, Bo, G) hipLaunchKernelGGL((warp_bwd_kernel<S, Bo, G>), grid, block, 0, st, img, seg, disp, id0, id1, id2, gwarped, gdisp, gadd, B, C, D, W, H, Dn)
   if (seg) {
     if (sc) { if (bo) LR_WB(true, true, true); else LR_WB(true, false, true); }
     else    { if (bo) LR_WB(false, true, true); else LR_WB(false, false, true); }
@@ -482,6 +501,22 @@ extern "C" int lr_warp_bwd_disp_f32(const float* img, const float* seg, const fl
   }
 #undef LR_WB
   return lr_launch_status();
+}
+
+extern "C" int lr_warp_bwd_disp_f32(const float* img, const float* seg, const float* disp, const float* id0,
+                                    const float* id1, const float* id2, const float* gwarped, float* gdisp, int B,
+                                    int C, int D, int W, int H, int d0, int d1, int flags, void* stream) {
+  return warp_bwd_impl(img, seg, disp, id0, id1, id2, gwarped, gdisp, nullptr, B, C, D, W, H, d0, d1, flags, stream);
+}
+
+// Same, plus `gadd` (B,3,Dn,W,H): gdisp = d warped / d disp · gwarped + gadd — the sum autograd would otherwise form
+// in a pass of its own when the displacement field also feeds the regulariser (gdisp and gadd are distinct buffers).
+extern "C" int lr_warp_bwd_disp_acc_f32(const float* img, const float* seg, const float* disp, const float* id0,
+                                        const float* id1, const float* id2, const float* gwarped, const float* gadd,
+                                        float* gdisp, int B, int C, int D, int W, int H, int d0, int d1, int flags,
+                                        void* stream) {
+  if (!gadd) return LR_ENULL;
+  return warp_bwd_impl(img, seg, disp, id0, id1, id2, gwarped, gdisp, gadd, B, C, D, W, H, d0, d1, flags, stream);
 }
 
 static int pca_bwd_impl(bool bf, const float* gdisp, const float* basis, float* partial, float* gcoefs, int B,

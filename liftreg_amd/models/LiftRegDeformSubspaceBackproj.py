@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..autograd import EncoderBf16Fn, PCAFn, WarpFn
+from ..autograd import DecodeFn, EncoderBf16Fn
 from ..layers.layers import convBlock, FullyConnectBlock, GaussianSmoothing
 from ..utils.net_utils import Bilinear, identity_axis_tables
 
@@ -242,11 +242,10 @@ class model(nn.Module):
                 ops.pca_warp_supported(coefs, self.pca_vectors_LxM, moving)):
             # inference: one pass writes params, phi and warped — the same bits as the two kernels below
             return ops.pca_warp(coefs, self.pca_vectors_LxM, self.pca_mean, (self._id0, self._id1, self._id2), moving)
-        disp = PCAFn.apply(coefs, self.pca_vectors_LxM, self.pca_mean).view(B, 3, D, W, H)
-        # deform_field = disp + id ; warped = Bilinear(moving_cp, deform_field): one kernel; the mask
-        # compose of moving ((moving+1)*seg-1, :57) happens on the taps
-        phi, warped = WarpFn.apply(moving, disp, self._id0, self._id1, self._id2, moving_seg, True, True)
-        return disp, phi, warped
+        # training: one autograd node for PCA reconstruction → (+ identity) → warp; the mask compose of moving
+        # ((moving+1)*seg-1, :57) happens on the warp's taps
+        return DecodeFn.apply(coefs, self.pca_vectors_LxM, self.pca_mean, moving, self._id0, self._id1, self._id2,
+                              moving_seg, True)
 
     # ------------------------------------------------------------------ forward
     def forward(self, input):

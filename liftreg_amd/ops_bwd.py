@@ -23,8 +23,9 @@ def ncc_bwd(x, y, moments, gout, n_total, variant=_hip.NCC_CONFIGURED):
     return gx
 
 
-def warp_bwd_disp(img, disp, ids, seg, gwarped, *, using_scale=True, zero_boundary=True, d0=0, d1=None):
-    """d / d disp of ops.warp (bilinear).  Returns (B,3,Dn,W,H)."""
+def warp_bwd_disp(img, disp, ids, seg, gwarped, *, using_scale=True, zero_boundary=True, d0=0, d1=None, gadd=None):
+    """d / d disp of ops.warp (bilinear).  Returns (B,3,Dn,W,H); with `gadd` (same shape: the gradient reaching the
+    displacement field by another path, e.g. the regulariser) the sum of the two, formed in the same pass."""
     img, disp, gwarped = _dev(img, "img"), _dev(disp, "disp"), _dev(gwarped, "gwarped")
     B, C, D, W, H = img.shape
     d1 = D if d1 is None else int(d1)
@@ -34,6 +35,16 @@ def warp_bwd_disp(img, disp, ids, seg, gwarped, *, using_scale=True, zero_bounda
         i0, i1, i2 = (_dev(t, "id table") for t in ids)
     gdisp = torch.empty_like(disp)
     flags = (_hip.WARP_USING_SCALE if using_scale else 0) | (0 if zero_boundary else _hip.WARP_BORDER)
+    if gadd is not None:
+        gadd = _dev(gadd, "gadd")
+        if gadd.shape != disp.shape:
+            raise ValueError("gadd must have the displacement field's shape")
+        with _timed("warp_bwd_disp_acc", bytes=4 * (3 * disp.numel() + gwarped.numel())):
+            _hip.check(_hip.lib().lr_warp_bwd_disp_acc_f32(img.data_ptr(), _ptr(sg), disp.data_ptr(), _ptr(i0), _ptr(i1),
+                                                           _ptr(i2), gwarped.data_ptr(), gadd.data_ptr(), gdisp.data_ptr(),
+                                                           B, C, D, W, H, d0, d1, flags, _stream()),
+                       "lr_warp_bwd_disp_acc_f32")
+        return gdisp
     with _timed("warp_bwd_disp", bytes=4 * (2 * disp.numel() + gwarped.numel())):
         _hip.check(_hip.lib().lr_warp_bwd_disp_f32(img.data_ptr(), _ptr(sg), disp.data_ptr(), _ptr(i0), _ptr(i1),
                                                    _ptr(i2), gwarped.data_ptr(), gdisp.data_ptr(), B, C, D, W, H, d0,

@@ -73,6 +73,14 @@ def test_warp_backward_fast_kernel_equals_general_kernel(dev, monkeypatch):
             monkeypatch.delenv("LIFTREG_WARP_GENERAL", raising=False)
             assert np.array_equal(fast, gen), (shape, sc)
             assert np.abs(fast).max() > 0
+            # the accumulate form (gadd: the regulariser's gradient) == the plain gradient + gadd, both kernels
+            ga = rs.normal(0, 1, disp.shape).astype(np.float32)
+            for env in (None, "1"):
+                if env:
+                    monkeypatch.setenv("LIFTREG_WARP_GENERAL", env)
+                acc = ops_bwd.warp_bwd_disp(T(img, dev), T(disp, dev), ids, None, T(gw, dev), using_scale=sc, gadd=T(ga, dev))
+                monkeypatch.delenv("LIFTREG_WARP_GENERAL", raising=False)
+                assert np.array_equal(acc.cpu().numpy(), fast + ga), (shape, sc, env)
 
 
 def test_pca_backward_wrt_coefficients(dev):

@@ -417,7 +417,7 @@ def test_model_forward_golden(golden, dev, tmp_path):
     assert out["warped_proj"] is out["target_proj"]
     out2 = net(inp)                                  # with grad enabled: same values, graph of HIP Functions only
     assert torch.equal(out2["warped"], out["warped"]) and out2["warped"].grad_fn is not None
-    assert type(out2["warped"].grad_fn).__name__ == "WarpFnBackward"
+    assert type(out2["warped"].grad_fn).__name__ == "DecodeFnBackward"
 
 
 # ------------------------------------------------------------------------------------- error behaviour
