@@ -103,6 +103,28 @@ __device__ __forceinline__ void store_tile(const f32x4& acc, float* __restrict__
   }
 }
 
+// The same tile through an UNCONDITIONAL bounds-checked buffer store (fp32 channels-last layouts): `plane` is the
+// resource of output plane (b, dz) — zero-length when the plane does not exist — and a lane outside the row/column
+// range gets an out-of-range offset; the hardware drops it.  No branch around the store, so the compiler can COUNT the
+// stores in flight (conditional ones force it to wait for all of them before the next dependent load is consumed).
+template <int OUTL>
+__device__ __forceinline__ void store_tile_buf(const f32x4& acc, const __amdgpu_buffer_rsrc_t plane, const ConvDims& d,
+                                               int wo, int ho, int nt, int lane, float slope) {
+  static_assert(OUTL == LR_LAYOUT_NDHWC || OUTL == LR_LAYOUT_NDHWC_HPS, "fp32 channels-last output");
+  const int c0 = nt * 16 + (lane >> 4) * 4;
+  float4 v;
+  v.x = lrelu(acc[0], slope); v.y = lrelu(acc[1], slope); v.z = lrelu(acc[2], slope); v.w = lrelu(acc[3], slope);
+  unsigned off;
+  if (OUTL == LR_LAYOUT_NDHWC) {
+    off = (unsigned)(((wo * d.Ho + ho) * d.Cout + c0) * 4);
+  } else {  // row = [channel block of 16][parity][Ho/2][16 floats]
+    const int hp = (ho & 1) * (d.Ho >> 1) + (ho >> 1);
+    off = (unsigned)((wo * d.Ho * d.Cout + ((c0 >> 4) * d.Ho + hp) * 16 + (c0 & 15)) * 4);
+  }
+  if (wo >= d.Wo || ho >= d.Ho) off = 0x80000000u;
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), plane, off, 0, 0);
+}
+
 __device__ __forceinline__ f32x4 bias_init(const float* __restrict__ bias, int nt, int lane) {
   f32x4 a = {0.f, 0.f, 0.f, 0.f};
   if (bias) {
@@ -207,23 +229,16 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
     const float* org = in + ((int64_t)b * d.Cin + c0) * V + ((int64_t)z0 * d.W + y0) * d.H + x0;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(org), (short)0, 0x7fffffff, 0x00020000);
-    // interior brick (the common case): every row, column and channel of the window exists
-    const bool interior = z0 >= 0 && z0 + G::RD <= d.D && y0 >= 0 && y0 + G::RW <= d.W && x0 >= 0 &&
-                          x0 + G::RSL <= d.H && c0 + CC <= d.Cin;  // wave-uniform
-    if (interior) {
+    // ONE straight run of loads (no interior/edge branch: at a join the compiler can no longer count what is in
+    // flight and drains the queue — prefetch included — at the next wait); the edge test costs ~8 ALU ops per slot
+    const int xi = x0 + lf4 * 4;
+    const bool xok = xi >= 0 && xi + 3 < d.H;  // multiple of 4 and H % 4 == 0: entirely in or out
 #pragma unroll
-      for (int it = 0; it < G::MAXIT; ++it)
-        st[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, srel[it], 0, 0));
-    } else {
-      const int xi = x0 + lf4 * 4;
-      const bool xok = xi >= 0 && xi + 3 < d.H;  // multiple of 4 and H % 4 == 0: entirely in or out
-#pragma unroll
-      for (int it = 0; it < G::MAXIT; ++it) {
-        const int zi = z0 + srz[it], yi = y0 + sry[it];
-        const bool ok = xok && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W && c0 + scc[it] < d.Cin;
-        const unsigned voff = srel[it] | (ok ? 0u : OOR);
-        st[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
-      }
+    for (int it = 0; it < G::MAXIT; ++it) {
+      const int zi = z0 + srz[it], yi = y0 + sry[it];
+      const bool ok = xok & (zi >= 0) & (zi < d.D) & (yi >= 0) & (yi < d.W) & (c0 + scc[it] < d.Cin);
+      const unsigned voff = srel[it] | (ok ? 0u : OOR);
+      st[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
     }
   };
 
@@ -325,6 +340,10 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
         item_coords(unit_item(u), b, dq, wq, hq, pass);
         const int dz = dq * PD + wave;
         const bool zok = dz < d.Do && !(dbg & 1);
+        // output plane (b, dz) of this wave as a buffer resource; zero-length (every store dropped) when it is absent
+        const int64_t plane_elems = (int64_t)d.Wo * d.Ho * d.Cout;
+        const __amdgpu_buffer_rsrc_t oplane = __builtin_amdgcn_make_buffer_rsrc(
+            out + ((int64_t)b * d.Do + (zok ? dz : 0)) * plane_elems, (short)0, zok ? (int)(plane_elems * 4) : 0, 0x00020000);
         constexpr int NS = (PW * 4 / 2) * G::T;  // (tile pair, k-step) sequence, fully unrolled
         float ar[2][2];
         auto rd = [&](int sidx, float (&dst)[2]) {
@@ -362,7 +381,17 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
               __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // … then one LDS read
             }
           }
-          if (t == G::T - 1 && zok) {
+          if constexpr (OUTL == LR_LAYOUT_NDHWC || OUTL == LR_LAYOUT_NDHWC_HPS) {
+            if (t == G::T - 1) {  // unconditional, countable stores (see store_tile_buf)
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const int m = 2 * p + h;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                  store_tile_buf<OUTL>(pacc[h][nt], oplane, d, wq * PW + m / 4, hq * PH + (m % 4) * 16 + col, nt, lane, slope);
+              }
+            }
+          } else if (t == G::T - 1 && zok) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
               const int m = 2 * p + h;
@@ -818,6 +847,7 @@ extern "C" int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, co
     const int npass = (Cin + cc - 1) / cc;
     const int64_t nitems = (int64_t)B * d.nDq * d.nWq * d.nHq * npass;
     if (nitems > 0x7fffffffLL) return LR_EINVAL;
+    if ((int64_t)d.Wo * d.Ho * Cout * 4 >= 0x7fffffffLL) return LR_EINVAL;  // an output plane is one buffer resource
     // 16-byte staging needs aligned rows and a window (cc channels) within 31-bit buffer offsets
     const int vec4 = (stride == 1) && (H % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0) &&
                      ((int64_t)cc * D * W * H * 4 + (int64_t)16 * W * H * 4 < 0x7fffffffLL);
