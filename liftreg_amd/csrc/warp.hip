@@ -395,8 +395,43 @@ __global__ __launch_bounds__(256) void pca_warp_kernel(const float* __restrict__
   }
   const float a0 = id0[i], a1 = id1[j];
   const f32x4v a2 = *reinterpret_cast<const f32x4v*>(id2 + (kv << 2));
+  // Gathers first, for every batch row, stores afterwards: with loads AND stores in flight the wait counter is no
+  // longer in order and every consumed gather would drain the stores issued before it (one store latency per row).
+  if (C == 1) {
+    f32x4v res[BT];
 #pragma unroll
-  for (int b = 0; b < BT; ++b) {
+    for (int b = 0; b < BT; ++b) {
+      if (b >= B) break;
+      const __amdgpu_buffer_rsrc_t rsrc =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img + (int64_t)b * V), (short)0, (int)(V * 4), 0x00020000);
+#pragma unroll
+      for (int v = 0; v < 4; ++v)  // deform_field = disp_field + id_transform
+        res[b][v] = tri_sample_fast<SCALE>(rsrc, acc[b][0][v] + a0, acc[b][1][v] + a1, acc[b][2][v] + a2[v], D, W, H, sD);
+    }
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      if (b >= B) break;
+      float* dp = disp_out + (int64_t)b * 3 * V + m;
+      float* pp = phi_out + (int64_t)b * 3 * V + m;
+      f32x4v p0, p1, p2;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        p0[v] = acc[b][0][v] + a0;
+        p1[v] = acc[b][1][v] + a1;
+        p2[v] = acc[b][2][v] + a2[v];
+      }
+      __builtin_nontemporal_store(acc[b][0], reinterpret_cast<f32x4v*>(dp));
+      __builtin_nontemporal_store(acc[b][1], reinterpret_cast<f32x4v*>(dp + V));
+      __builtin_nontemporal_store(acc[b][2], reinterpret_cast<f32x4v*>(dp + 2 * V));
+      __builtin_nontemporal_store(p0, reinterpret_cast<f32x4v*>(pp));
+      __builtin_nontemporal_store(p1, reinterpret_cast<f32x4v*>(pp + V));
+      __builtin_nontemporal_store(p2, reinterpret_cast<f32x4v*>(pp + 2 * V));
+      __builtin_nontemporal_store(res[b], reinterpret_cast<f32x4v*>(warped + (int64_t)b * V + m));
+    }
+    return;
+  }
+#pragma unroll
+  for (int b = 0; b < BT; ++b) {  // several image channels: row by row
     if (b >= B) break;
     float* dp = disp_out + (int64_t)b * 3 * V + m;
     __builtin_nontemporal_store(acc[b][0], reinterpret_cast<f32x4v*>(dp));
