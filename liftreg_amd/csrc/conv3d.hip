@@ -547,8 +547,10 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(const float* __restrict_
   // runs on the matrix pipe.
   const int NS = 27 * CB;
   auto load_step = [&](int s, float4 (&a)[MT], float4 (&bw)[NT]) {
-    const int tap = s / CB, cb = s - tap * CB;  // wave-uniform
-    const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+    // step order (tz, channel block, ty, tx) — the order in which the row-major kernel below feeds an accumulator, so
+    // the two kernels (and with them the plain and the parity-split layout) give the same bits; wave-uniform
+    const int tz = s / (9 * CB), rem = s - tz * 9 * CB, cb = rem / 9, t9 = rem - cb * 9;
+    const int ty = t9 / 3, tx = t9 - ty * 3, tap = tz * 9 + t9;
     // PS (stride 2): tap tx reads voxel 2*ho+tx-1 — tx=1: even half, index ho; tx=0: odd half, index ho-1;
     // tx=2: odd half, index ho (xh0 already carries the -1)
     const int xs = PS ? (tx == 1 ? 1 : half_h + (tx >> 1)) : tx;
@@ -556,7 +558,7 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(const float* __restrict_
                              : (unsigned)(((tz * d.W + ty) * d.H + xs) * d.Cin * 4 + cb * 64);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-      bw[nt] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wlane, (unsigned)((s * NT + nt) * 1024), 0));
+      bw[nt] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wlane, (unsigned)(((tap * CB + cb) * NT + nt) * 1024), 0));
     unsigned voff = tx == 0 ? vx[0] : (tx == 1 ? vx[1] : vx[2]);
     if (ragged_c) voff |= (cb * 16 + kq * 4 < d.Cin) ? 0u : OOR;
     const int zy = tz * 3 + ty;
@@ -613,7 +615,7 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(const float* __restrict_
 // matrix pipe.  27 rows per tile, loads two rows ahead, everything unrolled (straight-line vmcnt accounting).
 // Every accumulator still sees its taps in (tz,ty,tx) order: the results are bit-identical to conv3d_cl_kernel's.
 // ===========================================================================
-template <int NT>
+template <int NT, int CB /* 16-channel blocks of the input: Cin = 16*CB */>
 __global__ __launch_bounds__(256, 3) void conv3d_cl_rows_kernel(const float* __restrict__ in,
                                                              const float4* __restrict__ wp,
                                                              const float* __restrict__ bias,
@@ -639,10 +641,11 @@ __global__ __launch_bounds__(256, 3) void conv3d_cl_rows_kernel(const float* __r
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = bv;
   }
-  // window origin (-1,-1,-1) of this wave's tile, as in conv3d_cl_kernel<NT, 2, true> (Cin == 16: one channel block)
+  // window origin (-1,-1,-1) of this wave's tile, as in conv3d_cl_kernel<NT, 2, true>
+  constexpr int CIN = 16 * CB;
   const int zi0 = dz * 2 - 1, yw0 = wo0 * 2 - 1, xh0 = hq * 16 - 1;
-  const int64_t inb = (int64_t)b * dD * dW * dH * 16;
-  const float* wbase = in + inb + ((int64_t)zi0 * dW + yw0) * dH * 16 + (int64_t)xh0 * 16;
+  const int64_t inb = (int64_t)b * dD * dW * dH * CIN;
+  const float* wbase = in + inb + ((int64_t)zi0 * dW + yw0) * dH * CIN + (int64_t)xh0 * 16;
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wbase), (short)0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_null =
@@ -667,19 +670,20 @@ __global__ __launch_bounds__(256, 3) void conv3d_cl_rows_kernel(const float* __r
     const int zi = zi0 + q / NR, yi = yw0 + q % NR;
     okmask |= ((unsigned)(zi >= 0) & (unsigned)(zi < dD) & (unsigned)(yi >= 0) & (unsigned)(yi < dW)) << q;
   }
-  float4 w[3][3][NT];  // [ty][tx][nt] of the current tz
-  auto load_w = [&](int tz, int ty) {
+  float4 w[3][3][NT];  // [ty][tx][nt] of the current (tz, channel block)
+  auto load_w = [&](int pl, int ty) {  // pl = tz * CB + cb
+    const int tz = pl / CB, cb = pl - tz * CB;
 #pragma unroll
     for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         w[ty][tx][nt] = __builtin_bit_cast(
-            float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wlane, (unsigned)((((tz * 3 + ty) * 3 + tx) * NT + nt) * 1024), 0));
+            float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wlane, (unsigned)(((((tz * 3 + ty) * 3 + tx) * CB + cb) * NT + nt) * 1024), 0));
   };
-  auto load_row = [&](int q, float4 (&a)[3]) {  // q = tz * NR + r
-    const int tz = q / NR, r = q - tz * NR;
-    const bool ok = (okmask >> q) & 1u;  // wave-uniform (scalar select, no branch): outside -> the zero-length resource
-    const unsigned row = (unsigned)((tz * dW + r) * dH * 16);
+  auto load_row = [&](int q, float4 (&a)[3]) {  // q = (tz * CB + cb) * NR + r
+    const int pl = q / NR, r = q - pl * NR, tz = pl / CB, cb = pl - tz * CB;
+    const bool ok = (okmask >> (tz * NR + r)) & 1u;  // wave-uniform (scalar select, no branch): outside -> the zero-length resource
+    const unsigned row = (unsigned)((tz * dW + r) * dH * CIN + cb * 2 * half_h * 16);
 #pragma unroll
     for (int tx = 0; tx < 3; ++tx) {
       // tx=1: even half, index ho; tx=0: odd half, index ho-1; tx=2: odd half, index ho (xh0 carries the -1)
@@ -706,9 +710,9 @@ __global__ __launch_bounds__(256, 3) void conv3d_cl_rows_kernel(const float* __r
   load_row(0, rows[0]);
   load_row(1, rows[1]);
 #pragma unroll
-  for (int q = 0; q < 3 * NR; ++q) {
-    const int tz = q / NR, r = q % NR;
-    if (q + 2 < 3 * NR) load_row(q + 2, rows[(q + 2) % 3]);
+  for (int q = 0; q < 3 * CB * NR; ++q) {
+    const int pl = q / NR, r = q % NR;
+    if (q + 2 < 3 * CB * NR) load_row(q + 2, rows[(q + 2) % 3]);
     __builtin_amdgcn_sched_barrier(0);  // keep the loads two rows ahead: the scheduler otherwise sinks them to their use
     // row r = 2*mt + ty: the (mt, ty) order below keeps every accumulator's taps in (tz,ty,tx) order
     if (r & 1) {
@@ -718,10 +722,10 @@ __global__ __launch_bounds__(256, 3) void conv3d_cl_rows_kernel(const float* __r
       if (r < 2 * MT) use(r >> 1, 0, rows[q % 3]);
     }
     // a ty's fragments are dead after its last row: fetch the next tz's while the remaining rows compute
-    if (tz < 2) {
-      if (r == 2 * MT - 2) load_w(tz + 1, 0);
-      if (r == 2 * MT - 1) load_w(tz + 1, 1);
-      if (r == 2 * MT) load_w(tz + 1, 2);
+    if (pl + 1 < 3 * CB) {
+      if (r == 2 * MT - 2) load_w(pl + 1, 0);
+      if (r == 2 * MT - 1) load_w(pl + 1, 1);
+      if (r == 2 * MT) load_w(pl + 1, 2);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -832,9 +836,11 @@ extern "C" int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, co
     const dim3 grid((unsigned)nblk);
     const float4* wt = reinterpret_cast<const float4*>(packed_w);
     const size_t occ_lds = getenv("LIFTREG_CONV_LDS") ? (size_t)atoi(getenv("LIFTREG_CONV_LDS")) : 0;  // tuning aid: caps resident blocks
-    const bool rows_ok = ps && Cin == 16 && !getenv("LIFTREG_CONV_TAPMAJOR");  // tuning aid: the tap-major kernel
-    if (rows_ok && NT == 1) hipLaunchKernelGGL((conv3d_cl_rows_kernel<1>), grid, block, occ_lds, st, in, wt, bias, out, d, out_layout, negative_slope);
-    else if (rows_ok) hipLaunchKernelGGL((conv3d_cl_rows_kernel<2>), grid, block, occ_lds, st, in, wt, bias, out, d, out_layout, negative_slope);
+    const bool rows_ok = ps && (Cin == 16 || Cin == 32) && !getenv("LIFTREG_CONV_TAPMAJOR");  // tuning aid: the tap-major kernel
+    if (rows_ok && Cin == 16 && NT == 1) hipLaunchKernelGGL((conv3d_cl_rows_kernel<1, 1>), grid, block, occ_lds, st, in, wt, bias, out, d, out_layout, negative_slope);
+    else if (rows_ok && Cin == 16) hipLaunchKernelGGL((conv3d_cl_rows_kernel<2, 1>), grid, block, occ_lds, st, in, wt, bias, out, d, out_layout, negative_slope);
+    else if (rows_ok && NT == 1) hipLaunchKernelGGL((conv3d_cl_rows_kernel<1, 2>), grid, block, occ_lds, st, in, wt, bias, out, d, out_layout, negative_slope);
+    else if (rows_ok) hipLaunchKernelGGL((conv3d_cl_rows_kernel<2, 2>), grid, block, occ_lds, st, in, wt, bias, out, d, out_layout, negative_slope);
     else if (ps && NT == 1) hipLaunchKernelGGL((conv3d_cl_kernel<1, 2, true>), grid, block, occ_lds, st, in, wt, bias, out, d, out_layout, negative_slope);
     else if (ps) hipLaunchKernelGGL((conv3d_cl_kernel<2, 2, true>), grid, block, occ_lds, st, in, wt, bias, out, d, out_layout, negative_slope);
     else if (NT == 1 && stride == 1) hipLaunchKernelGGL((conv3d_cl_kernel<1, 1, false>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope);
