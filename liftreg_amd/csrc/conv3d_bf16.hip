@@ -195,11 +195,12 @@ __global__ __launch_bounds__(256) void conv3d_cl_bf16_kernel(const u16* __restri
 // (2 instead of 1.5 MFMAs per use: the bf16 matrix pipe is 14 % busy).  The six weight fragments of a (tz,ty) are
 // picked lane-wise out of the tap-pair packing (tap T, channel half h of cout c sits at fragment T/2, lane
 // ((T&1)*2+h)*16+c); the current tz's stay in registers, the next tz's are fetched under the last rows.
-template <int NT, int MT>
+template <int NT, int MT, bool CIN32>
 __global__ __launch_bounds__(256, 3) void conv3d_cl_rows_bf16_kernel(const u16* __restrict__ in, const u32x4* __restrict__ wp,
                                                                      const float* __restrict__ bias, void* __restrict__ out,
                                                                      ConvDimsH d, int out_layout, float slope) {
-  constexpr int VB = 32;  // bytes per voxel (16 bf16 channels)
+  constexpr int CIN = CIN32 ? 32 : 16, VB = CIN * 2;  // bytes per voxel
+  constexpr int NL = CIN32 ? 3 : 2;                    // 16-byte loads per lane and row = MFMAs per (mt, ty) use
   const unsigned lb = lr_xcd_remap(blockIdx.x, gridDim.x);
   const int hq = lb % d.nHq, wq = (lb / d.nHq) % d.nWq, dq = (lb / d.nHq / d.nWq) % d.nDq;
   const int b = lb / d.nHq / d.nWq / d.nDq;
@@ -225,8 +226,8 @@ __global__ __launch_bounds__(256, 3) void conv3d_cl_rows_bf16_kernel(const u16* 
     for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = bv;
   }
   const int zi0 = dz * 2 - 1, yw0 = wo0 * 2 - 1, xh0 = hq * 16 - 1;
-  const int64_t inb = (int64_t)b * dD * dW * dH * 16;
-  const u16* wbase = in + inb + ((int64_t)zi0 * dW + yw0) * dH * 16 + (int64_t)xh0 * 16;
+  const int64_t inb = (int64_t)b * dD * dW * dH * CIN;
+  const u16* wbase = in + inb + ((int64_t)zi0 * dW + yw0) * dH * CIN + (int64_t)xh0 * CIN;
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(wbase), (short)0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_null =
@@ -237,14 +238,22 @@ __global__ __launch_bounds__(256, 3) void conv3d_cl_rows_bf16_kernel(const u16* 
   const int half_h = (dH + 1) >> 1;
   // per-lane offsets inside a row: load 1 = tx0 (lanes kq<2: odd half, index ho-1) | tx1 (kq>=2: even half, index ho),
   // load 2 = tx2 (kq<2: odd half, index ho) | nothing; xh0 carries the -1
-  unsigned v1, v2;
+  // (Cin = 32: one MFMA per tap, a lane holds channels 8kq..8kq+7 of its voxel: three loads tx0, tx1, tx2)
+  unsigned vl[NL];
   {
     const int xi0 = ho * 2 - 1;
     const bool in_tile = ho < dHo;
-    const unsigned lv = (unsigned)(col * VB + (kq & 1) * 16);
     const bool ok0 = in_tile && xi0 >= 0 && xi0 < dH, ok1 = in_tile && xi0 + 1 < dH, ok2 = in_tile && xi0 + 2 < dH;
-    v1 = (kq >> 1) ? (lv + 1u * VB) | (ok1 ? 0u : OOR) : (lv + (unsigned)half_h * VB) | (ok0 ? 0u : OOR);
-    v2 = (kq >> 1) ? OOR : (lv + (unsigned)(half_h + 1) * VB) | (ok2 ? 0u : OOR);
+    if constexpr (CIN32) {
+      const unsigned lv = (unsigned)(col * VB + kq * 16);
+      vl[0] = (lv + (unsigned)half_h * VB) | (ok0 ? 0u : OOR);
+      vl[1] = (lv + 1u * VB) | (ok1 ? 0u : OOR);
+      vl[2] = (lv + (unsigned)(half_h + 1) * VB) | (ok2 ? 0u : OOR);
+    } else {
+      const unsigned lv = (unsigned)(col * VB + (kq & 1) * 16);
+      vl[0] = (kq >> 1) ? (lv + 1u * VB) | (ok1 ? 0u : OOR) : (lv + (unsigned)half_h * VB) | (ok0 ? 0u : OOR);
+      vl[1] = (kq >> 1) ? OOR : (lv + (unsigned)(half_h + 1) * VB) | (ok2 ? 0u : OOR);
+    }
   }
   constexpr int NR = 2 * MT + 1;
   unsigned okmask = 0u;  // bit tz*NR+r SET = input row (zi0+tz, yw0+r) exists; NR*3 <= 51: two words
@@ -261,26 +270,32 @@ __global__ __launch_bounds__(256, 3) void conv3d_cl_rows_bf16_kernel(const u16* 
   auto woff = [&](int T, int nt) -> unsigned {
     return (unsigned)(((((T >> 1) * NT + nt) * 64) + (((T & 1) << 1) | (kq & 1)) * 16 + col) * 16);
   };
-  u32x4 w[3][2][NT];  // [ty][mfma][nt] of the current tz
+  u32x4 w[3][NL][NT];  // [ty][mfma][nt] of the current tz
   auto load_w = [&](int tz, int ty) {
     const int T0 = (tz * 3 + ty) * 3;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const unsigned o1 = (kq >> 1) ? woff(T0 + 1, nt) : woff(T0, nt);
-      w[ty][0][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, o1, 0, 0);
-      w[ty][1][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, woff(T0 + 2, nt), 0, 0);
+      if constexpr (CIN32) {  // fragment of tap T: packed[(T*NT + nt)*64 + lane]
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx)
+          w[ty][tx][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)lane * 16u, (unsigned)(((T0 + tx) * NT + nt) * 1024), 0);
+      } else {
+        const unsigned o1 = (kq >> 1) ? woff(T0 + 1, nt) : woff(T0, nt);
+        w[ty][0][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, o1, 0, 0);
+        w[ty][1][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, woff(T0 + 2, nt), 0, 0);
+      }
     }
   };
-  auto load_row = [&](int q, u32x4 (&a)[2]) {
+  auto load_row = [&](int q, u32x4 (&a)[NL]) {
     const int tz = q / NR, r = q - tz * NR;
     const bool ok = ((q < 32 ? okmask >> q : okmask_hi >> (q - 32)) & 1u) != 0u;  // wave-uniform, scalar select
     const unsigned soff = (unsigned)((tz * dW + r) * dH) * VB;
-    a[0] = __builtin_amdgcn_raw_buffer_load_b128(ok ? rsrc : rsrc_null, v1, soff, 0);
-    a[1] = __builtin_amdgcn_raw_buffer_load_b128(ok ? rsrc : rsrc_null, v2, soff, 0);
-  };
-  auto use = [&](int mt, int ty, const u32x4 (&a)[2]) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NL; ++j) a[j] = __builtin_amdgcn_raw_buffer_load_b128(ok ? rsrc : rsrc_null, vl[j], soff, 0);
+  };
+  auto use = [&](int mt, int ty, const u32x4 (&a)[NL]) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[ty][j][nt]),
@@ -289,8 +304,8 @@ __global__ __launch_bounds__(256, 3) void conv3d_cl_rows_bf16_kernel(const u16* 
 #ifndef LR_BF16_ROWS_AHEAD
 #define LR_BF16_ROWS_AHEAD 5
 #endif
-  constexpr int AH = LR_BF16_ROWS_AHEAD, NSET = AH + 1;
-  u32x4 rows[NSET][2];  // loads run AH rows ahead: a row is only 2-4 MFMAs (64-128 cycles) of work
+  constexpr int AH = CIN32 ? 2 : LR_BF16_ROWS_AHEAD, NSET = AH + 1;
+  u32x4 rows[NSET][NL];  // loads run AH rows ahead: a row is only 2-4 MFMAs (64-128 cycles) of work
   load_w(0, 0);
   load_w(0, 1);
   load_w(0, 2);
@@ -795,7 +810,7 @@ extern "C" int lr_conv3d_k3_lrelu_bf16(const void* in, const void* packed_w, con
   // rows per wave: 8 for the big first stride-2 block (fewer weight loads per MFMA), 4 otherwise; LIFTREG_BF16_MT overrides
   int mtb = (Cin == 16 && d.Wo >= 64) ? 8 : 4;
   if (const char* e = getenv("LIFTREG_BF16_MT")) mtb = atoi(e) == 8 ? 8 : 4;  // tuning aid
-  const bool rows = Cin == 16 && ps && !getenv("LIFTREG_CONV_TAPMAJOR");  // block 1: the row-major kernel (tuning aid: tap-major)
+  const bool rows = ps && !getenv("LIFTREG_CONV_TAPMAJOR");  // parity-split rows: the row-major kernel (tuning aid: tap-major)
   if (rows) mtb = 4;  // 4 rows per wave: 8 would not fit three waves per SIMD
   d.nHq = (d.Ho + 15) / 16; d.nWq = (d.Wo + mtb - 1) / mtb; d.nDq = (d.Do + TD - 1) / TD;
   const int64_t nblk = (int64_t)B * d.nDq * d.nWq * d.nHq;
@@ -811,8 +826,10 @@ extern "C" int lr_conv3d_k3_lrelu_bf16(const void* in, const void* packed_w, con
   } while (0)
   const int NT = Cout / 16;
   if (rows) {
-    if (NT == 2) hipLaunchKernelGGL((conv3d_cl_rows_bf16_kernel<2, 4>), grid, block, 0, st, x, wt, bias, out, d, out_layout, negative_slope);
-    else hipLaunchKernelGGL((conv3d_cl_rows_bf16_kernel<1, 4>), grid, block, 0, st, x, wt, bias, out, d, out_layout, negative_slope);
+#define LR_BR(NTV, C32) hipLaunchKernelGGL((conv3d_cl_rows_bf16_kernel<NTV, 4, C32>), grid, block, 0, st, x, wt, bias, out, d, out_layout, negative_slope)
+    if (Cin == 32) { if (NT == 2) LR_BR(2, true); else LR_BR(1, true); }
+    else           { if (NT == 2) LR_BR(2, false); else LR_BR(1, false); }
+#undef LR_BR
     return lr_launch_status();
   }
   if (Cin == 32) {
