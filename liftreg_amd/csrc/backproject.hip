@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void backproject_tiled_kernel(
           acc = acc + bq * ne;
           acc = acc + c * sw;
           acc = acc + d * se;
-          ob[(((int64_t)p * Ds + i) * W + j) * H + k] = acc;
+          __builtin_nontemporal_store(acc, &ob[(((int64_t)p * Ds + i) * W + j) * H + k]);  // written once, read by block 0 long after it left the L2
         }
       }
     }

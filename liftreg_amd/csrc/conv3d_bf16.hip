@@ -412,7 +412,8 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv0_bf16_kernel(const
       float v[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = lrelu(a[nt][q], slope);
-      *reinterpret_cast<uint2*>(o + nt * 16) = make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+      typedef unsigned u32x2nt __attribute__((ext_vector_type(2)));
+      __builtin_nontemporal_store((u32x2nt){pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])}, reinterpret_cast<u32x2nt*>(o + nt * 16));
     }
   };
   const int npass = (d.Cin + 2) / 3;
