@@ -291,6 +291,14 @@ int lr_pca_reconstruct_bf16basis_f32(const float* coefs, const void* basis_bf16,
 int lr_pca_bwd_coef_bf16basis_f32(const float* gdisp, const void* basis_bf16, float* partial, float* gcoefs, int B,
                                   int L, int64_t M, int64_t ldb, int64_t gdisp_batch_stride, int nblk, void* stream);
 
+/* The encoder's first block on cat([moving, backprojected views], dim=1) (…Backproj.py:95-98) WITHOUT the
+ * concatenation: channel 0 is read from in0 (B,1,D,W,H), channels 1..Cin-1 from in_rest (B,Cin-1,D,W,H), both NCDHW
+ * fp32; packed_w as for lr_conv3d_k3_lrelu_f32 (stride 1).  Same kernel and bits as the concatenated input.
+ * Cin in {2,3}, H % 4 == 0, 16-byte aligned inputs — otherwise LR_EUNSUPPORTED and the caller concatenates. */
+int lr_conv3d_first_split_f32(const float* in0, const float* in_rest, const float* packed_w, const float* bias,
+                              float* out, int B, int Cin, int Cout, int D, int W, int H, int out_layout,
+                              float negative_slope, void* stream);
+
 /* ---- f1: PCA reconstruction + identity + trilinear warp in ONE pass (the model's decode half in inference).
  * Replaces the sequence …Backproj.py:102 (F.linear with the PCA basis) → :68 (disp + id) → :69 (Bilinear warp) and
  * writes all three model outputs: disp = `params` (B,3,D,W,H), phi (B,3,D,W,H), warped (B,C,D,W,H).  Same arithmetic

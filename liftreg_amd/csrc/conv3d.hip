@@ -180,7 +180,10 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
                                                             const float* __restrict__ bias,
                                                             float* __restrict__ out, ConvDims d,
                                                             int out_layout, float slope, int vec4,
-                                                            int nitems, int npass, int dbg) {
+                                                            int nitems, int npass, int dbg,
+                                                            const float* __restrict__ in0 /* or null: see below */) {
+  // in0 != null ("split input", one pass, 16-byte staging only): channel 0 is read from in0 (B,1,D,W,H) and channels
+  // 1.. from `in` (B,Cin-1,D,W,H) — the encoder's cat([moving, backprojected views]) without the copy of `moving`.
   using G = PlanarGeom<S, CC>;
   extern __shared__ __attribute__((aligned(16))) float brick[];  // [CC][RD][RW][RSL]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -210,7 +213,8 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
     const int cc = row / (G::RD * G::RW), rz = (row / G::RW) % G::RD, ry = row % G::RW;
     const bool used = lact && row < G::NROWS;
     scc[it] = (short)cc; srz[it] = (short)rz; sry[it] = (short)ry;
-    srel[it] = used ? (unsigned)(((int64_t)cc * V + ((int64_t)rz * d.W + ry) * d.H + lf4 * 4) * 4) : OOR;
+    const int ccr = (in0 && cc > 0) ? cc - 1 : cc;  // split input: channel index inside its own tensor
+    srel[it] = used ? (unsigned)(((int64_t)ccr * V + ((int64_t)rz * d.W + ry) * d.H + lf4 * 4) * 4) : OOR;
     sdst[it] = used ? cc * G::CS + rz * G::PS + ry * G::RSL + lf4 * 4 : -1;
   }
 
@@ -229,9 +233,12 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
     const int c0 = pass * CC;
     const int z0 = dq * PD * S - 1, y0 = wq * PW * S - 1, x0 = hq * PH * S - 1 - G::XOFF;
     // window origin (may lie before the tensor: never dereferenced there)
-    const float* org = in + ((int64_t)b * d.Cin + c0) * V + ((int64_t)z0 * d.W + y0) * d.H + x0;
+    const int64_t wofs = ((int64_t)z0 * d.W + y0) * d.H + x0;
+    const float* org = in + ((int64_t)b * (in0 ? d.Cin - 1 : d.Cin) + c0) * V + wofs;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(org), (short)0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_c0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(in0 ? in0 + (int64_t)b * V + wofs : org), (short)0, 0x7fffffff, 0x00020000);
     // ONE straight run of loads (no interior/edge branch: at a join the compiler can no longer count what is in
     // flight and drains the queue — prefetch included — at the next wait); the edge test costs ~8 ALU ops per slot
     const int xi = x0 + lf4 * 4;
@@ -241,7 +248,9 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
       const int zi = z0 + srz[it], yi = y0 + sry[it];
       const bool ok = xok & (zi >= 0) & (zi < d.D) & (yi >= 0) & (yi < d.W) & (c0 + scc[it] < d.Cin);
       const unsigned voff = srel[it] | (ok ? 0u : OOR);
-      st[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+      // a slot's rows belong to ONE channel (3 rows per slot, 36 per channel): the resource choice is wave-uniform
+      const bool ch0 = __builtin_amdgcn_readfirstlane((int)scc[it]) == 0;
+      st[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ch0 ? rsrc_c0 : rsrc, voff, 0, 0));
     }
   };
 
@@ -807,10 +816,10 @@ extern "C" int lr_conv3d_pack_weights_f32(const float* weight, float* packed, in
   return lr_launch_status();
 }
 
-extern "C" int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, const float* bias,
-                                      float* out, int B, int Cin, int Cout, int D, int W, int H,
-                                      int stride, int in_layout, int out_layout,
-                                      float negative_slope, void* stream) {
+static int conv_impl(const float* in, const float* in0, const float* packed_w, const float* bias,
+                     float* out, int B, int Cin, int Cout, int D, int W, int H,
+                     int stride, int in_layout, int out_layout,
+                     float negative_slope, void* stream) {
   if (!in || !packed_w || !out) return LR_ENULL;
   if (B < 1 || Cin < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
   if (stride != 1 && stride != 2) return LR_EUNSUPPORTED;
@@ -827,6 +836,7 @@ extern "C" int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, co
   hipStream_t st = lr_stream(stream);
   const int NT = Cout / 16;
   const dim3 block(256);
+  if (in0 && in_layout != LR_LAYOUT_NCDHW) return LR_EUNSUPPORTED;
   if (in_layout == LR_LAYOUT_NDHWC || in_layout == LR_LAYOUT_NDHWC_HPS) {
     const bool ps = in_layout == LR_LAYOUT_NDHWC_HPS;
     if (Cin % 4) return LR_EUNSUPPORTED;
@@ -861,6 +871,8 @@ extern "C" int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, co
     const int vec4 = (stride == 1) && (H % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0) &&
                      ((int64_t)cc * D * W * H * 4 + (int64_t)16 * W * H * 4 < 0x7fffffffLL);
     const bool single = npass == 1;
+    if (in0 && (!vec4 || !single || stride != 1 || Cin < 2 || (reinterpret_cast<uintptr_t>(in0) & 15u)))
+      return LR_EUNSUPPORTED;  // split input: one 3-channel pass with 16-byte staging (the caller concatenates otherwise)
     int64_t resident = 256 * (single ? 3 : 2);  // persistent blocks per CU (registers: <=168 | <=256 per lane)
     if (const char* e = getenv("LIFTREG_CONV0_BLOCKS")) resident = atoi(e);  // tuning aid
     const dim3 grid((unsigned)(nitems < resident ? nitems : resident));
@@ -870,13 +882,13 @@ extern "C" int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, co
     const int dbg = getenv("LIFTREG_CONV0_DBG") ? atoi(getenv("LIFTREG_CONV0_DBG")) : 0;  // timing ablations only
 #define LR_PL(NTV, SV, CCV, SGL, LDSV, V4)                                                                   \
   hipLaunchKernelGGL((conv3d_planar_kernel<NTV, SV, CCV, SGL>), grid, block, LDSV, st, in, packed_w, bias, out, d, \
-                     out_layout, negative_slope, V4, ni, npass, dbg)
+                     out_layout, negative_slope, V4, ni, npass, dbg, in0)
     if (stride == 1 && NT == 1 && single && out_layout == LR_LAYOUT_NDHWC_HPS) {        // the model's first block
       hipLaunchKernelGGL((conv3d_planar_kernel<1, 1, 3, true, LR_LAYOUT_NDHWC_HPS>), grid, block, lds1, st, in, packed_w, bias,
-                         out, d, out_layout, negative_slope, vec4, ni, npass, dbg);
+                         out, d, out_layout, negative_slope, vec4, ni, npass, dbg, in0);
     } else if (stride == 1 && NT == 1 && single && out_layout == LR_LAYOUT_NDHWC) {
       hipLaunchKernelGGL((conv3d_planar_kernel<1, 1, 3, true, LR_LAYOUT_NDHWC>), grid, block, lds1, st, in, packed_w, bias,
-                         out, d, out_layout, negative_slope, vec4, ni, npass, dbg);
+                         out, d, out_layout, negative_slope, vec4, ni, npass, dbg, in0);
     } else if (stride == 1) {
       if (NT == 1 && single) LR_PL(1, 1, 3, true, lds1, vec4);
       else if (NT == 1) LR_PL(1, 1, 3, false, lds1, vec4);
@@ -893,4 +905,23 @@ extern "C" int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, co
     return LR_EINVAL;
   }
   return lr_launch_status();
+}
+
+extern "C" int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, const float* bias,
+                                      float* out, int B, int Cin, int Cout, int D, int W, int H,
+                                      int stride, int in_layout, int out_layout,
+                                      float negative_slope, void* stream) {
+  return conv_impl(in, nullptr, packed_w, bias, out, B, Cin, Cout, D, W, H, stride, in_layout, out_layout, negative_slope,
+                   stream);
+}
+
+// The encoder's first block on cat([moving, views]) WITHOUT the concatenation: channel 0 from `in0` (B,1,D,W,H),
+// channels 1..Cin-1 from `in_rest` (B,Cin-1,D,W,H); same kernel, same results as the concatenated input.
+// Cin in {2,3}, H % 4 == 0, 16-byte aligned inputs; otherwise LR_EUNSUPPORTED (concatenate and call the entry above).
+extern "C" int lr_conv3d_first_split_f32(const float* in0, const float* in_rest, const float* packed_w, const float* bias,
+                                         float* out, int B, int Cin, int Cout, int D, int W, int H, int out_layout,
+                                         float negative_slope, void* stream) {
+  if (!in0) return LR_ENULL;
+  return conv_impl(in_rest, in0, packed_w, bias, out, B, Cin, Cout, D, W, H, 1, LR_LAYOUT_NCDHW, out_layout,
+                   negative_slope, stream);
 }

@@ -207,6 +207,20 @@ class model(nn.Module):
             p = poses.detach().cpu().numpy() if isinstance(poses, torch.Tensor) else np.asarray(poses)
             self._poses = np.ascontiguousarray(p[0], dtype=np.float32)  # poses[0:1] (:87)
         V = D * W * H
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if self.conv_dtype != "bf16" and not needs_grad and P <= 2:
+            # inference, fp32: the first block reads `moving` and the backprojected views from their own buffers —
+            # cat([moving, target_volume], dim=1) (:95-98) is never materialised (no copy of `moving`)
+            tv = torch.empty((B, P, D, W, H), dtype=torch.float32, device=moving.device)
+            mv = moving if moving.is_contiguous() else moving.contiguous()
+            if ops.conv3d_first_split_supported(mv, tv):
+                ops.backproject(target_proj, self._poses, (D, W, H), out=tv, out_batch_stride=P * V)
+                blk = self.encoders[0]
+                x = ops.conv3d_first_split(mv, tv, blk.conv.weight, blk.conv.bias, out_layout=blk.out_layout,
+                                           negative_slope=blk._slope, packed=self._packed_weight(0))
+                for i in range(1, 6):
+                    x = self.encoders[i](x, packed=self._packed_weight(i))
+                return self.encoders[6](x)
         # encoder input = cat([moving, target_volume], dim=1) (:95-98), built in place
         x = torch.empty((B, P + 1, D, W, H), dtype=torch.float32, device=moving.device)
         x[:, 0:1].copy_(moving)

@@ -257,6 +257,37 @@ def conv3d_k3_lrelu(x, weight, bias, stride, *, in_layout=LAYOUT_NCDHW, out_layo
     return y
 
 
+def conv3d_first_split_supported(x0, rest):
+    """True when `conv3d_first_split` can take these tensors (else: concatenate and call conv3d_k3_lrelu)."""
+    return (x0.dim() == 5 and rest.dim() == 5 and x0.shape[1] == 1 and rest.shape[1] in (1, 2) and x0.shape[4] % 4 == 0 and
+            x0.shape[0] == rest.shape[0] and x0.shape[2:] == rest.shape[2:] and x0.is_contiguous() and rest.is_contiguous() and
+            x0.data_ptr() % 16 == 0 and rest.data_ptr() % 16 == 0)
+
+
+def conv3d_first_split(x0, rest, weight, bias, *, out_layout=LAYOUT_NCDHW, negative_slope=0.2, packed=None, out=None):
+    """The encoder's first block on cat([x0, rest], dim=1) WITHOUT the concatenation: x0 (B,1,D,W,H) = the moving image,
+    rest (B,P,D,W,H) = the backprojected views, P in {1,2}.  Same kernel and bits as conv3d_k3_lrelu on the
+    concatenated tensor (reference …Backproj.py:95-98 + layers.py:365-369)."""
+    x0, rest = _dev(x0, "x0"), _dev(rest, "rest")
+    if not conv3d_first_split_supported(x0, rest):
+        raise ValueError("conv3d_first_split: unsupported shapes (concatenate and use conv3d_k3_lrelu)")
+    B, _, D, W, H = x0.shape
+    Cin, Cout = 1 + rest.shape[1], weight.shape[0]
+    if weight.shape[1] != Cin:
+        raise ValueError(f"weight expects Cin={weight.shape[1]}, inputs have {Cin}")
+    if packed is None:
+        packed = conv3d_pack_weights(weight, LAYOUT_NCDHW)
+    b = None if bias is None else _dev(bias.detach(), "bias")
+    shape = (B, Cout, D, W, H) if out_layout == LAYOUT_NCDHW else (B, D, W, H, Cout)
+    y = _conv_out(out, shape, torch.float32, x0.device)
+    with _timed(f"conv3d_c{Cin}x{Cout}_s1_{D}", flops=2.0 * 27 * Cin * Cout * B * D * W * H,
+                bytes=4 * (x0.numel() + rest.numel()) + 4 * y.numel(), samples=B):
+        _hip.check(_hip.lib().lr_conv3d_first_split_f32(x0.data_ptr(), rest.data_ptr(), packed.data_ptr(), _ptr(b),
+                                                        y.data_ptr(), B, Cin, Cout, D, W, H, out_layout,
+                                                        float(negative_slope), _stream()), "lr_conv3d_first_split_f32")
+    return y
+
+
 def conv3d_pack_weights_bf16(weight):
     """(Cout,Cin,3,3,3) fp32 parameter → bf16 MFMA operand order for lr_conv3d_k3_lrelu_bf16 (uint8 buffer)."""
     weight = _dev(weight.detach(), "weight")

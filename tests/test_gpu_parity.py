@@ -341,6 +341,23 @@ def test_conv_parity_split_layout(ops, dev):
         ops.conv3d_k3_lrelu(torch.zeros(1, 4, 4, 5, 16, device=dev), w1, b1, 2, in_layout=ops.LAYOUT_NDHWC_HPS)
 
 
+def test_first_block_split_input_equals_concatenated(ops, dev):
+    """lr_conv3d_first_split_f32 reads channel 0 (the moving image) and the backprojected views from their own buffers:
+    same bits as the block on torch.cat([...], 1), both output layouts, ragged bricks, 2 and 3 channels."""
+    rs = np.random.RandomState(31)
+    for (D, W, H), B, P in (((9, 7, 24), 2, 2), ((4, 5, 68), 1, 1), ((16, 16, 64), 1, 2)):
+        x0 = T(rs.uniform(-1, 1, (B, 1, D, W, H)).astype(np.float32), dev)
+        rest = T(rs.uniform(-1, 1, (B, P, D, W, H)).astype(np.float32), dev)
+        w = T((rs.normal(0, 1, (16, P + 1, 3, 3, 3)) / 9).astype(np.float32), dev)
+        b = T(rs.uniform(-0.1, 0.1, 16).astype(np.float32), dev)
+        assert ops.conv3d_first_split_supported(x0, rest)
+        for lay in (ops.LAYOUT_NDHWC, ops.LAYOUT_NDHWC_HPS, ops.LAYOUT_NCDHW):
+            want = ops.conv3d_k3_lrelu(torch.cat([x0, rest], 1), w, b, 1, out_layout=lay)
+            got = ops.conv3d_first_split(x0, rest, w, b, out_layout=lay)
+            assert torch.equal(got, want), ((D, W, H), P, lay)
+    assert not ops.conv3d_first_split_supported(x0[..., :62].contiguous(), rest[..., :62].contiguous())   # H % 4 != 0
+
+
 def test_conv_medium_vs_oracle(ops, dev):
     rs = np.random.RandomState(11)
     torch.manual_seed(11)

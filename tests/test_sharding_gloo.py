@@ -30,6 +30,10 @@ class OracleOps:
     def pca_warp_supported(*_):
         return False      # the shim keeps the two-kernel decode (pca_reconstruct + warp)
 
+    @staticmethod
+    def conv3d_first_split_supported(*_):
+        return False      # … and the concatenated encoder input
+
     # ---- layouts (mirror of LR_LAYOUT_*) -------------------------------------------------------
     def _to_ncdhw(self, x, layout):
         if layout == self.LAYOUT_NCDHW:
