@@ -136,13 +136,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    # LIFTREG_BENCH_BACKEND=gloo (test hook): lets several ranks share one GPU so the N>1 control path (fence, max over
+    # ranks, single JSON line) can be exercised on a 1-GPU box; the measured configuration is always nccl, one GPU per rank
+    backend = os.environ.get("LIFTREG_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     from liftreg_amd import ops
     from liftreg_amd.layers.losses import NCCLoss
