@@ -199,3 +199,24 @@ def test_reference_native_size_160(dev):
     # as up to a few 1e-5 in a handful of the 4 M warped values
     np.testing.assert_allclose(out["warped"].cpu().numpy(), ref["warped"].numpy(), rtol=1e-4, atol=6e-5)
     assert abs(float(loss) - float(ro.ncc_loss(ref["warped"], ref["target"]))) < 1e-5
+
+
+def test_first_block_full_size_store_paths_agree(dev):
+    """Block 0 at 256^3 (three co-resident persistent blocks per CU): the channels-last outputs go through unconditional
+    bounds-checked buffer stores, the NCDHW output through plain stores — same values; and the split-input entry point
+    equals the concatenated one at this size."""
+    from liftreg_amd import ops
+    n = 256
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    x0 = torch.rand((1, 1, n, n, n), device=dev, generator=g) * 2 - 1
+    rest = torch.rand((1, 2, n, n, n), device=dev, generator=g) * 2 - 1
+    w = torch.randn((16, 3, 3, 3, 3), device=dev, generator=g) / 9
+    b = torch.randn(16, device=dev, generator=g) * 0.1
+    x = torch.cat([x0, rest], 1)
+    y_nc = ops.conv3d_k3_lrelu(x, w, b, 1, out_layout=ops.LAYOUT_NCDHW)
+    y_cl = ops.conv3d_k3_lrelu(x, w, b, 1, out_layout=ops.LAYOUT_NDHWC)
+    assert torch.equal(y_cl.permute(0, 4, 1, 2, 3), y_nc)
+    del y_cl
+    y_hps = ops.conv3d_first_split(x0, rest, w, b, out_layout=ops.LAYOUT_NDHWC_HPS)
+    assert torch.equal(ops.hps_to_ndhwc(y_hps).permute(0, 4, 1, 2, 3), y_nc)
