@@ -112,6 +112,13 @@ int lr_backproject_f32(const float* proj, const float* poses, float* out,
 int lr_backproject_coords_f32(const float* poses, float* pix, int P, int Pw, int Ph,
                               int D, int W, int H, int normalized, void* stream);
 
+/* Parity / API compatibility (backproj_grids, sdct_projection_utils.py:179-202 — the pose-less variant; only the
+ * reference's dead RegNet2D3D calls it): the reference mixes a float64 pose array with float32 linspaces, so the
+ * grid is FLOAT64 and built as scale*g + trans (:194-197).  poses: host (P,3) DOUBLE; grid: dev (P,2,D,W,H) double,
+ * channel 0 = the Ph-axis coordinate, channel 1 = the Pw-axis coordinate (after the reference's flip(1), :201). */
+int lr_backproject_coords_poseless_f64(const double* poses, double* grid, int P, int Pw, int Ph, int D, int W, int H,
+                                       void* stream);
+
 /* ------------------------------------------------------------------------
  * K3  Conv3d(k=3, pad=1, stride 1|2, bias) + LeakyReLU, implicit GEMM on
  * v_mfma_f32_16x16x4_f32.  Replaces convBlock:
@@ -351,6 +358,10 @@ int lr_conv3d_wgrad_bf16g_f32(const float* x, int x_layout, const void* gpre_bf1
  * lr_jacobi_det_stats_f32: out[2] (double, device) = sum of |det J| over voxels with det J < 0, and their count,
  *   for a (B,3,D,W,H) map; sp* = the finite-difference spacing per axis (utils/utils.py:20-55
  *   compute_jacobi_map passes spacing*span).  partial: B*nblk*2 doubles.  Stencil assumed (mermaid): parity unpinned. */
+/* lr_sample_points_f64: landmark sampler of tools/evaluate_dir_lab.py:46-59 (calc_warped_points): trilinear
+ *   F.grid_sample(align_corners=True, zeros padding) of a DOUBLE (C,D,W,H) map at N normalised points (x,y,z) =
+ *   (H,W,D axes); vol, pts (N,3), out (N,C): dev doubles.  The flip and the (dim-1)*phi_spacing scale stay on the host. */
+int lr_sample_points_f64(const double* vol, const double* pts, double* out, int C, int D, int W, int H, int N, void* stream);
 int lr_normalize_clip_f32(const float* in, float* out, int64_t n, float lo, float hi, void* stream);
 int lr_label_overlap_f32(const float* pred, const float* gt, float label, int64_t n, void* partial, int nblk,
                          int64_t* counts, void* stream);

@@ -33,6 +33,8 @@ SIGNATURES = {
     "lr_drr_sample_coords_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "lr_backproject_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _p]),
     "lr_backproject_coords_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "lr_backproject_coords_poseless_f64": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "lr_sample_points_f64": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "lr_conv3d_packed_floats": (_i64, [_i, _i, _i]),
     "lr_conv3d_pack_weights_f32": (_i, [_p, _p, _i, _i, _i, _p]),
     "lr_conv3d_k3_lrelu_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),

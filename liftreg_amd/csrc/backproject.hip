@@ -304,6 +304,40 @@ __global__ __launch_bounds__(256) void backproject_coords_kernel(
   pix[idx * 2 + 1] = normalized ? gv : lr_unnormalize(gv, Ph);
 }
 
+// backproj_grids (sdct_projection_utils.py:179-202), the pose-less variant: the reference mixes a float64 pose array
+// with float32 linspaces, so torch promotes and the whole grid is FLOAT64, built as scale·g + trans (mul, then add),
+// not as (g - e)·s + e like the with-poses variant.  One thread per (p, i, j, k); both channels; channel order after
+// the reference's flip(1): out[p,0] = the Ph-axis (z) coordinate, out[p,1] = the Pw-axis (x) coordinate.
+struct LrPoses64 {
+  double e[LR_MAX_VIEWS][3];
+};
+__global__ __launch_bounds__(256) void backproject_coords_poseless_f64_kernel(LrPoses64 poses, double* __restrict__ grid,
+                                                                              int P, int Pw, int Ph, int D, int W, int H) {
+  const int64_t plane = (int64_t)D * W * H, total = (int64_t)P * plane;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int k = (int)(idx % H);
+  int64_t r = idx / H;
+  const int j = (int)(r % W);
+  r /= W;
+  const int i = (int)(r % D);
+  const int p = (int)(r / D);
+  // torch.linspace(-d/2, d/2-1, d) etc. in float32: exact integers (or half-integers for odd sizes) — step is ±1
+  const double x = (double)((float)i - 0.5f * (float)D), y = (double)(float)(W - 1 - j), z = (double)((float)k - 0.5f * (float)H);
+  const double ex = poses.e[p][0], ey = poses.e[p][1], ez = poses.e[p][2];
+  const double den = ey - y;
+  const double scale = ey / den;              // :194
+  const double ty = (-y) / den;               // :195  poses[:,0::2] * (-y/(e_y - y))
+  const double tx = ex * ty, tz = ez * ty;
+  double gu = __dadd_rn(__dmul_rn(scale, x), tx);   // :197  torch.mul(scale, grids) + trans — two roundings, no FMA
+  double gv = __dadd_rn(__dmul_rn(scale, z), tz);
+  gu = gu / (double)Pw * 2.0;                 // :198-199
+  gv = gv / (double)Ph * 2.0;
+  const int64_t o = (int64_t)p * 2 * plane + (idx - (int64_t)p * plane);
+  grid[o] = gv;                               // flip(1) :201
+  grid[o + plane] = gu;
+}
+
 int fill_poses(LrPoses& lp, const float* poses, int P) {
   if (!poses) return LR_ENULL;
   if (P < 1 || P > LR_MAX_VIEWS) return LR_EINVAL;
@@ -369,5 +403,20 @@ extern "C" int lr_backproject_coords_f32(const float* poses, float* pix, int P, 
   if (nblk > 0x7fffffffLL) return LR_EINVAL;
   hipLaunchKernelGGL(backproject_coords_kernel, dim3((unsigned)nblk), dim3(256), 0,
                      lr_stream(stream), lp, pix, P, Pw, Ph, D, W, H, normalized);
+  return lr_launch_status();
+}
+
+extern "C" int lr_backproject_coords_poseless_f64(const double* poses, double* grid, int P, int Pw, int Ph, int D, int W,
+                                                  int H, void* stream) {
+  if (!poses || !grid) return LR_ENULL;
+  if (P < 1 || P > LR_MAX_VIEWS || Pw < 1 || Ph < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
+  LrPoses64 lp;
+  for (int p = 0; p < P; ++p)
+    for (int c = 0; c < 3; ++c) lp.e[p][c] = poses[p * 3 + c];
+  const int64_t total = (int64_t)P * D * W * H;
+  const int64_t nblk = (total + 255) / 256;
+  if (nblk > 0x7fffffffLL) return LR_EINVAL;
+  hipLaunchKernelGGL(backproject_coords_poseless_f64_kernel, dim3((unsigned)nblk), dim3(256), 0, lr_stream(stream), lp,
+                     grid, P, Pw, Ph, D, W, H);
   return lr_launch_status();
 }

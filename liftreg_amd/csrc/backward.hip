@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void ncc_bwd_kernel(const float* __restrict__ 
   const double* m = moments + (int64_t)r * 5;
   const double n = n_total;
   const double mx = m[0] / n, my = m[1] / n;
-  const double cov = m[2] / n - mx * my, vx = m[3] / n - mx * mx, vy = m[4] / n - my * my;
+  const double cov = m[2] / n - mx * my, vx = fmax(m[3] / n - mx * mx, 0.0), vy = fmax(m[4] / n - my * my, 0.0);  // clamped as in ncc_loss_kernel
   const double g = -(double)(*gout) / (double)R;  // d loss / d ncc_r
   double cy, cx;                                  // gx_i = cy * (y_i - my) + cx * (x_i - mx)
   if (variant == LR_NCC_CONFIGURED) {

@@ -9,7 +9,9 @@
 //        sum of |negative| values and their count                               -> lr_jacobi_det_stats_f32
 //        PARITY UNPINNED: the derivative stencil is mermaid's FD_np (un-vendored); assumed = the regulariser's
 //        (central differences, one-sided at the faces; reg.hip).
-// All three are single streaming passes (HBM-read-bound); reductions are fixed-order (no atomics).
+//   tools/evaluate_dir_lab.py:46-59      calc_warped_points: F.grid_sample(phi (1,C,D,W,H) float64, landmark
+//        positions (1,1,1,N,3) float64, align_corners=True) — trilinear, zeros padding, in DOUBLE  -> lr_sample_points_f64
+// The first three are single streaming passes (HBM-read-bound); reductions are fixed-order (no atomics).
 #include "lr_common.h"
 
 namespace {
@@ -106,7 +108,50 @@ __global__ void jacobi_final_kernel(const double* __restrict__ partial, int n, d
   }
 }
 
+// ATen grid_sampler_3d (CPU, double), restated: unnormalise ((g+1)/2)*(size-1); corner = floor; weight of the
+// "top-north-west" corner = (x_bse - x)(y_bse - y)(z_bse - z) …; out = Σ in corner order tnw,tne,tsw,tse,bnw,bne,bsw,bse,
+// each term added as `out += value * weight` when that corner is inside the volume.  One thread per (point, channel).
+__global__ __launch_bounds__(256) void sample_points_f64_kernel(const double* __restrict__ vol, const double* __restrict__ pts,
+                                                               double* __restrict__ out, int C, int D, int W, int H, int N) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= N * C) return;
+  const int n = t / C, c = t % C;
+  const double gx = pts[n * 3 + 0], gy = pts[n * 3 + 1], gz = pts[n * 3 + 2];  // x <-> H, y <-> W, z <-> D
+  const double ix = ((gx + 1.0) / 2.0) * (double)(H - 1), iy = ((gy + 1.0) / 2.0) * (double)(W - 1),
+               iz = ((gz + 1.0) / 2.0) * (double)(D - 1);
+  const double fx = floor(ix), fy = floor(iy), fz = floor(iz);
+  const double x1 = fx + 1.0, y1 = fy + 1.0, z1 = fz + 1.0;
+  const double wx0 = x1 - ix, wx1 = ix - fx, wy0 = y1 - iy, wy1 = iy - fy, wz0 = z1 - iz, wz1 = iz - fz;
+  // coordinates far outside (|ix| > 2^31) or NaN select no corner
+  const bool finite = fabs(ix) < 2e9 && fabs(iy) < 2e9 && fabs(iz) < 2e9;
+  const int64_t xi = finite ? (int64_t)fx : -2, yi = finite ? (int64_t)fy : -2, zi = finite ? (int64_t)fz : -2;
+  const double* v = vol + (int64_t)c * D * W * H;
+  double acc = 0.0;
+  auto tap = [&](int64_t z, int64_t y, int64_t x, double w) {
+    if (z >= 0 && z < D && y >= 0 && y < W && x >= 0 && x < H) acc = __dadd_rn(acc, __dmul_rn(v[(z * W + y) * H + x], w));
+  };
+  tap(zi, yi, xi, __dmul_rn(__dmul_rn(wx0, wy0), wz0));
+  tap(zi, yi, xi + 1, __dmul_rn(__dmul_rn(wx1, wy0), wz0));
+  tap(zi, yi + 1, xi, __dmul_rn(__dmul_rn(wx0, wy1), wz0));
+  tap(zi, yi + 1, xi + 1, __dmul_rn(__dmul_rn(wx1, wy1), wz0));
+  tap(zi + 1, yi, xi, __dmul_rn(__dmul_rn(wx0, wy0), wz1));
+  tap(zi + 1, yi, xi + 1, __dmul_rn(__dmul_rn(wx1, wy0), wz1));
+  tap(zi + 1, yi + 1, xi, __dmul_rn(__dmul_rn(wx0, wy1), wz1));
+  tap(zi + 1, yi + 1, xi + 1, __dmul_rn(__dmul_rn(wx1, wy1), wz1));
+  out[(int64_t)n * C + c] = acc;
+}
+
 }  // namespace
+
+extern "C" int lr_sample_points_f64(const double* vol, const double* pts, double* out, int C, int D, int W, int H, int N,
+                                    void* stream) {
+  if (!vol || !pts || !out) return LR_ENULL;
+  if (C < 1 || D < 1 || W < 1 || H < 1 || N < 0 || (int64_t)N * C > 0x7fffffffLL) return LR_EINVAL;
+  if (N == 0) return LR_OK;
+  hipLaunchKernelGGL(sample_points_f64_kernel, dim3((unsigned)(((int64_t)N * C + 255) / 256)), dim3(256), 0,
+                     lr_stream(stream), vol, pts, out, C, D, W, H, N);
+  return lr_launch_status();
+}
 
 extern "C" int lr_normalize_clip_f32(const float* in, float* out, int64_t n, float lo, float hi, void* stream) {
   if (!in || !out) return LR_ENULL;

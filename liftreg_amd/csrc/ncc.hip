@@ -93,8 +93,10 @@ __global__ __launch_bounds__(64) void ncc_loss_kernel(const double* __restrict__
     const double* m = moments + (int64_t)r * 5;
     const double mx = m[0] / n, my = m[1] / n;
     const double cov = m[2] / n - mx * my;
-    const double vx = m[3] / n - mx * mx;
-    const double vy = m[4] / n - my * my;
+    // raw-moment variances cancel to ~1e-17 on a constant volume: clamp, or (vx+e2)(vy+e2) can go negative → NaN
+    // (the reference's centred form stays finite there, layers/losses.py:18-26)
+    const double vx = fmax(m[3] / n - mx * mx, 0.0);
+    const double vy = fmax(m[4] / n - my * my, 0.0);
     double v;
     if (variant == LR_NCC_CONFIGURED) {
       // a = x - mean(x) + 1e-10 ; mean(ab) = cov + 1e-20 (mean(x-mean) = 0)

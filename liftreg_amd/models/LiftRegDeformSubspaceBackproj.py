@@ -178,11 +178,29 @@ class model(nn.Module):
     def _basis_storage(self, vec):
         return vec.to(torch.bfloat16) if self.pca_dtype == "bf16" else vec.to(torch.float32)
 
+    def invalidate_packed(self):
+        """Drop the cached MFMA-ordered weight copies.  The cache is keyed on (data_ptr, tensor version, device): an
+        optimizer step, `load_state_dict` and `.to()` are seen by themselves (and are hooked below anyway); an in-place
+        update THROUGH `.data` (`w.data.mul_()`, EMA / clipping code, an external library) changes neither — call this
+        after such an update.  In training mode the weights are re-packed on every forward (the pack kernel is
+        microseconds next to a step), so only inference after an out-of-band update needs it."""
+        self._packed.clear()
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.get("_packed", {}).clear()
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.__dict__.get("_packed", {}).clear()
+        return super().load_state_dict(*args, **kwargs)
+
     def _packed_weight(self, i, bf16=False):
         blk = self.encoders[i]
         w = blk.conv.weight
         key = (w.data_ptr(), w._version, str(w.device))
         hit = self._packed.get((i, bf16))
+        if self.training and w.requires_grad:
+            hit = None                       # training: never trust the cache (see invalidate_packed)
         if hit is None or hit[0] != key:
             if bf16:
                 pk = ops.conv3d_pack_weights_bf16_planar(w) if i == 0 else ops.conv3d_pack_weights_bf16(w)

@@ -30,6 +30,17 @@ def _dev(t, name, dtype=torch.float32):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _out_arg(out, shape, name="out", dtype=torch.float32):
+    """A caller-supplied output buffer: it is written in place, so it is never copied — a non-contiguous, wrongly
+    shaped or wrongly typed `out` raises instead of silently writing into a temporary."""
+    if not isinstance(out, torch.Tensor) or not out.is_cuda:
+        raise _hip.LiftRegHipError(f"{name}: must be a GPU tensor (no CPU fallback)")
+    if out.dtype != dtype or tuple(out.shape) != tuple(shape) or not out.is_contiguous():
+        raise ValueError(f"{name}: must be a contiguous {dtype} tensor of shape {tuple(shape)}, got "
+                         f"{out.dtype} {tuple(out.shape)} (contiguous={out.is_contiguous()})")
+    return out
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -124,7 +135,7 @@ def drr_forward(vol, poses, resolution, spacing=(2.2, 2.2, 2.2), *, d0=0, d1=Non
     if out is None:
         out = torch.empty((P, Rd, Rh), dtype=torch.float32, device=vol.device)
     else:
-        out = _dev(out, "out")
+        out = _out_arg(out, (P, Rd, Rh))
     flags = (_hip.DRR_HU_INPUT if hu_input else 0) | (_hip.DRR_FLIP_W if flip_w else 0)
     with _timed("drr_forward", bytes=4 * (Ds * W * H + P * Rd * Rh)):
         _hip.check(_hip.lib().lr_drr_forward_f32(vol.data_ptr(), poses.ctypes.data, sp.ctypes.data,
@@ -170,11 +181,18 @@ def backproject(proj, poses, img_shape, *, d0=0, d1=None, out=None, out_batch_st
         out_batch_stride = P * Ds * W * H
         optr = out.data_ptr()
     else:
-        if not out.is_cuda or out.dtype != torch.float32:
-            raise TypeError("out must be a float32 GPU tensor")
         if out_batch_stride is None:
-            out = _dev(out, "out")
+            out = _out_arg(out, (B, P, Ds, W, H))
             out_batch_stride = P * Ds * W * H
+        else:
+            # a view into a larger buffer (channels 1..P of the encoder input): each batch element's (P,Ds,W,H)
+            # block must itself be dense, the batch stride is the caller's
+            if not out.is_cuda or out.dtype != torch.float32:
+                raise TypeError("out must be a float32 GPU tensor")
+            if tuple(out.shape) != (B, P, Ds, W, H) or (B > 1 and out.stride(0) != int(out_batch_stride)) or \
+                    tuple(out.stride()[1:]) != (Ds * W * H, W * H, H, 1):
+                raise ValueError(f"out must be a {(B, P, Ds, W, H)} view with dense (P,Ds,W,H) blocks and batch stride "
+                                 f"{out_batch_stride}, got shape {tuple(out.shape)} strides {tuple(out.stride())}")
         optr = out.data_ptr()
     with _timed("backproject", bytes=4 * (B * P * Ds * W * H + B * P * Pw * Ph), samples=B):
         _hip.check(_hip.lib().lr_backproject_f32(proj.data_ptr(), poses.ctypes.data, optr, B, P, Pw, Ph, D, W,
@@ -194,6 +212,20 @@ def backproject_coords(poses, img_shape, proj_shape, device, normalized=False):
     _hip.check(_hip.lib().lr_backproject_coords_f32(poses.ctypes.data, pix.data_ptr(), P, Pw, Ph, D, W, H,
                                                     int(normalized), _stream()), "lr_backproject_coords_f32")
     return pix
+
+
+def backproject_coords_poseless_f64(poses64, img_shape, proj_shape, device):
+    """(P,2,D,W,H) float64 grid of the pose-less backproj_grids (reference sdct_projection_utils.py:179-202)."""
+    D, W, H = (int(v) for v in img_shape)
+    Pw, Ph = int(proj_shape[0]), int(proj_shape[1])
+    poses = np.ascontiguousarray(np.asarray(poses64, dtype=np.float64).reshape(-1, 3))
+    P = poses.shape[0]
+    grid = torch.empty((P, 2, D, W, H), dtype=torch.float64, device=device)
+    if not grid.is_cuda:
+        raise _hip.LiftRegHipError("backproject_coords_poseless_f64 runs on the GPU only (no CPU fallback)")
+    _hip.check(_hip.lib().lr_backproject_coords_poseless_f64(poses.ctypes.data, grid.data_ptr(), P, Pw, Ph, D, W, H,
+                                                             _stream()), "lr_backproject_coords_poseless_f64")
+    return grid
 
 
 # ----------------------------------------------------------------------------- K3 conv
@@ -420,7 +452,7 @@ def pca_reconstruct(coefs, basis_LxM, mean, *, out=None):
     if out is None:
         out = torch.empty((B, M), dtype=torch.float32, device=coefs.device)
     else:
-        out = _dev(out, "out")
+        out = _out_arg(out, (B, M))
     if B > 32:     # the entry point tiles up to 32 batch rows: larger batches in chunks (the basis is re-read per chunk)
         for i in range(0, B, 32):
             pca_reconstruct(coefs[i:i + 32], basis_LxM, mean, out=out[i:i + 32])
@@ -593,6 +625,22 @@ def normalize_clip(img, lo, hi, out=None):
     with _timed("normalize_clip", bytes=8 * img.numel()):
         _hip.check(_hip.lib().lr_normalize_clip_f32(img.data_ptr(), out.data_ptr(), img.numel(), float(lo), float(hi),
                                                     _stream()), "lr_normalize_clip_f32")
+    return out
+
+
+def sample_points_f64(vol, pts):
+    """Trilinear samples (zeros padding, align_corners=True) of a float64 (C,D,W,H) map at N normalised points
+    (N,3) ordered (x,y,z) = (H,W,D axes) → (N,C) float64.  The landmark sampler of the reference's
+    tools/evaluate_dir_lab.py:46-59 (F.grid_sample on doubles)."""
+    vol = _dev(vol, "vol", torch.float64)
+    pts = _dev(pts, "pts", torch.float64)
+    if vol.dim() != 4 or pts.dim() != 2 or pts.shape[1] != 3:
+        raise ValueError("vol must be (C,D,W,H), pts (N,3)")
+    C, D, W, H = vol.shape
+    N = pts.shape[0]
+    out = torch.empty((N, C), dtype=torch.float64, device=vol.device)
+    _hip.check(_hip.lib().lr_sample_points_f64(vol.data_ptr(), pts.data_ptr(), out.data_ptr(), C, D, W, H, N, _stream()),
+               "lr_sample_points_f64")
     return out
 
 

@@ -273,6 +273,9 @@ class SlabShardedRegistration:
             out = {"warped": warped, "phi": phi, "params": disp, "pca_coefs": coefs}
             if "target" in inp:
                 tgt = inp["target"][:, :, d0:d1].contiguous()
+                if "source_label" in inp and "target_label" in inp:   # (target+1)*target_seg-1 (…Backproj.py:57-58)
+                    tgt = ops.mask_compose(tgt, inp["target_label"][:, :, d0:d1].contiguous())
+                out["target"] = tgt
                 rows = warped.shape[0] if self.variant == NCC_CONFIGURED else warped.shape[0] * warped.shape[1]
                 moms.append(ops.ncc_moments(warped, tgt, rows))
             outs.append(out)

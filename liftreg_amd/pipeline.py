@@ -28,6 +28,14 @@ class TwoStreamRegistrar:
         cur = torch.cuda.current_stream()
         self.enc.wait_stream(cur)  # inputs produced on the caller's stream
         self.dec.wait_stream(cur)
+        # the batch's tensors were allocated on the caller's stream but are read by kernels on enc/dec: tell the
+        # caching allocator, or a serving loop that drops the batch after submit() gets its blocks re-used (and
+        # overwritten on the caller's stream) while the previous batch's warp / first conv block still reads them
+        for k in ("source", "target", "target_proj", "source_label", "target_label"):
+            t = batch.get(k) if isinstance(batch, dict) else None
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(self.enc)
+                t.record_stream(self.dec)
         with torch.cuda.stream(self.enc):
             coefs = net.encode(moving, batch["target_proj"], batch["target_poses"])
             done = torch.cuda.Event()
@@ -41,7 +49,11 @@ class TwoStreamRegistrar:
             loss = self.sim(warped, target_cp) if self.sim is not None else None
         out = {"warped": warped, "phi": phi, "params": disp, "target": target_cp, "pca_coefs": coefs,
                "target_proj": batch["target_proj"], "warped_proj": batch["target_proj"]}
-        self._hold = [self._hold[-1] if self._hold else None, (out, loss)][-2:]
+        # outputs were allocated on enc/dec and are handed to code running on the caller's stream
+        for t in (warped, phi, disp, coefs, target_cp, loss):
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(cur)
+        self._hold = [self._hold[-1] if self._hold else None, (batch, out, loss)][-2:]
         return out, loss
 
     def synchronize(self):

@@ -91,9 +91,12 @@ def backproj_grids_with_poses(poses, img_shape, proj_shape, device=None):
 
 
 def backproj_grids(scan_range, proj_num, img_shape, proj_shape, device=None):
-    """Pose-less variant (sdct_projection_utils.py:179-202): emitter at y = 3.0·W."""
-    poses = scan_poses(scan_range, proj_num, img_shape[1], y_scale=3.).astype(np.float32)[None]
-    return backproj_grids_with_poses(poses, img_shape, proj_shape, device)[0]
+    """Pose-less variant (sdct_projection_utils.py:179-202): emitter at y = 3.0·W.  The reference's float64 pose
+    array promotes the whole computation, so this returns a FLOAT64 (P,2,D,W,H) grid built as scale·g + trans
+    (:194-197) — its own kernel, not the fp32 with-poses one (different type and op order)."""
+    device = _gpu(device)
+    poses = scan_poses(scan_range, proj_num, img_shape[1], y_scale=3.)   # float64, as poses_scale*w at :193
+    return ops.backproject_coords_poseless_f64(poses, img_shape, proj_shape, device)
 
 
 def forward_grids_with_poses(poses, spacing, img_shape, device=None, receptor_size=None):

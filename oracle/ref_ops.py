@@ -111,6 +111,75 @@ def backproj_grid(poses, img_shape, proj_shape):
     return grids.flip(2)                                                      # :250
 
 
+def backproj_grid_poseless(scan_range, proj_num, img_shape, proj_shape):
+    """backproj_grids (sdct_projection_utils.py:179-202), the pose-less variant: emitter at y = 3.0·W, and — because
+    `poses` is a float64 array meeting float32 linspaces — a FLOAT64 grid built as scale·g + trans (:194-197).
+    Returns (P,2,D,W,H) float64 after the reference's flip(1)."""
+    d, w, h = img_shape
+    proj_w, proj_h = proj_shape
+    x = torch.linspace(-d / 2, d / 2 - 1, d)
+    y = torch.linspace(w - 1, 0, w)
+    z = torch.linspace(-h / 2, h / 2 - 1, h)
+    gx, _gy, gz = torch.meshgrid(x, y, z, indexing="ij")
+    poses = torch.from_numpy(scan_poses(scan_range, proj_num, w, y_scale=3.))            # float64 (:193)
+    scale = poses[:, 1:2] / (poses[:, 1:2] - y)                                          # (P,W) :194
+    trans = poses[:, 0::2, None] * (-y / (poses[:, 1:2] - y)).reshape(proj_num, 1, w)    # (P,2,W) :195
+    grids = torch.cat((gx[None, :], gz[None, :]), dim=0).unsqueeze(0)                    # (1,2,D,W,H) :196
+    grids = torch.mul(scale.reshape(proj_num, 1, 1, w, 1), grids) + trans.reshape(proj_num, 2, 1, w, 1)   # :197
+    grids[:, 0] = grids[:, 0] / proj_w * 2.0
+    grids[:, 1] = grids[:, 1] / proj_h * 2.0
+    return grids.flip(1)
+
+
+# --------------------------------------------------------------------------- a5
+def _default_resolution(img_shape, receptor_size):
+    if receptor_size is not None:
+        return list(receptor_size)
+    return [int(img_shape[0] * 1.5), int(img_shape[2] * 1.5)]
+
+
+def forward_grids_with_poses(poses, spacing, img_shape, receptor_size=None):
+    """sdct_projection_utils.py:252-265 → (grids (P,Rd,Rh,W,3) flipped to (z,y,x), dx)."""
+    grid, dx = project_grid(poses, _default_resolution(img_shape, receptor_size), img_shape,
+                            torch.tensor(spacing).float(), torch.float32)
+    return torch.flip(grid, [4]), dx
+
+
+def forward_grids(scan_range, proj_num, spacing, img_shape, receptor_size=None):
+    """sdct_projection_utils.py:204-225: as above with the emitter at y = 3.0·W (:208), not 3.5."""
+    return forward_grids_with_poses(scan_poses(scan_range, proj_num, img_shape[1], y_scale=3.), spacing, img_shape,
+                                    receptor_size)
+
+
+def csv_geometry_poses(geo_rows_mm, img_spacing):
+    """calculate_projection_wraper_with_geo_csv_file (sdct_projection_utils.py:161-163): emitter positions of the CSV
+    (header row already dropped) in mm → voxel units, float64."""
+    return np.asarray(geo_rows_mm, dtype=np.float64) / np.asarray(img_spacing)
+
+
+# --------------------------------------------------------------------------- f4 (tools/evaluate_dir_lab.py)
+def calc_warped_points(source_list_t, phi_t, dim, phi_spacing):
+    """tools/evaluate_dir_lab.py:46-59: grid_sample of the float64 map at the normalised landmarks, channel flip,
+    × (dim-1) × phi_spacing."""
+    warped = F.grid_sample(phi_t, source_list_t, align_corners=True)
+    warped = torch.flip(warped.permute(0, 2, 3, 4, 1), [4])[0, 0, 0]
+    return torch.mul(torch.mul(warped, torch.from_numpy(np.asarray(dim) - 1.)), torch.from_numpy(np.asarray(phi_spacing)))
+
+
+def landmark_tre(source_list, target_list, phi, dim, spacing, origin, phi_spacing):
+    """eval_with_data (tools/evaluate_dir_lab.py:81-138) → (mean TRE, [|dx|,|dy|,|dz|] means, warped (N,3))."""
+    dim, spacing, phi_spacing = (np.asarray(v, dtype=np.float64) for v in (dim, spacing, phi_spacing))
+    origin_list = np.repeat([origin, ], target_list.shape[0], axis=0)
+    t = torch.from_numpy((target_list - 1.) * spacing) - torch.from_numpy(origin_list * phi_spacing)
+    s = torch.from_numpy((source_list - 1.) * spacing) - torch.from_numpy(origin_list * phi_spacing)
+    t[:, 1] = (dim[1] - 1) * phi_spacing[1] - t[:, 1]
+    s[:, 1] = (dim[1] - 1) * phi_spacing[1] - s[:, 1]
+    s_norm = (s / torch.from_numpy(phi_spacing) / torch.from_numpy(dim - 1.) * 2.0 - 1.0)[None, None, None]
+    w = calc_warped_points(s_norm, torch.from_numpy(np.asarray(phi)).double(), dim, phi_spacing)
+    dist = torch.nn.PairwiseDistance(p=2)(t, w)
+    return (torch.mean(dist).item(), [torch.mean(torch.abs(t[:, i] - w[:, i])).item() for i in range(3)], w, s_norm)
+
+
 # --------------------------------------------------------------------------- a7
 def backproject(target_proj, poses, img_shape):
     """Backprojection of model._estimate_flow (LiftRegDeformSubspaceBackproj.py:85-93).

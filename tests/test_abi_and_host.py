@@ -99,3 +99,52 @@ def test_model_state_dict_matches_reference_keys(golden, tmp_path):
         with torch.no_grad():                                         # CPU tensors: no fallback
             net({"source": torch.zeros(1, 1, 32, 32, 32), "target": torch.zeros(1, 1, 32, 32, 32),
                  "target_proj": torch.zeros(1, 2, 32, 32), "target_poses": torch.zeros(1, 2, 3)})
+
+
+REF_ROOT = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF_ROOT, "src", "liftreg")),
+                    reason="build container only: needs the reference checkout (it never travels to the GPU box)")
+def test_plugins_construct_through_the_references_own_parameterdict_and_get_class(tmp_path):
+    """The drop-in claim of INTEGRATION.md, exercised with the REFERENCE's machinery: its shipped cur_task_setting.json
+    is loaded through its own `ParameterDict`, the three dotted class paths are patched, and the classes are resolved by
+    its own `get_class` and constructed with the sub-dicts exactly as RegistrationNet.__init__ does
+    (networks/RegistrationNet.py:95,99; losses/SubspaceLoss.py:22-30).  CPU only: construction needs no GPU."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(REF_ROOT, "src"))
+    try:
+        import liftreg.utils.module_parameters as pars
+        from liftreg.utils.general import get_class as ref_get_class
+    finally:
+        sys.path.remove(os.path.join(REF_ROOT, "src"))
+    with open(os.path.join(REF_ROOT, "cur_task_setting.json")) as fh:
+        cfg = json.load(fh)
+    assert cfg["train"]["model_class"] == "liftreg.models.LiftRegDeformSubspaceBackproj.model"   # what we replace
+    cfg["train"]["model_class"] = "liftreg_amd.models.LiftRegDeformSubspaceBackproj.model"
+    cfg["train"]["loss_class"] = "liftreg_amd.losses.SubspaceLoss.loss"
+    cfg["train"]["loss"]["sim_class"] = "liftreg_amd.layers.losses.NCCLoss"
+    n, L = 32, int(cfg["train"]["model"]["latent_dim"])
+    np.save(tmp_path / "pca_vectors.npy", np.zeros((L, 3 * n ** 3), np.float32))
+    np.save(tmp_path / "pca_mean.npy", np.zeros((3 * n ** 3,), np.float32))
+    cfg["train"]["model"]["pca_path"] = str(tmp_path)
+    patched = tmp_path / "cur_task_setting.json"
+    patched.write_text(json.dumps(cfg))
+
+    setting = pars.ParameterDict()
+    setting.print_settings_off()
+    setting.load_JSON(str(patched))
+    train_setting = setting["train"]
+    net = ref_get_class(train_setting["model_class"])([n, n, n], setting["train"]["model"])
+    loss = ref_get_class(train_setting["loss_class"])(setting["train"]["loss"])
+    assert type(net).__module__ == "liftreg_amd.models.LiftRegDeformSubspaceBackproj" and isinstance(net, torch.nn.Module)
+    assert net.drr_feature_num == int(cfg["train"]["model"]["drr_feature_num"]) and net.latent_dim == L
+    assert net.encoders[0].conv.in_channels == net.drr_feature_num + 1
+    assert len(net.state_dict()) == 19
+    assert type(loss).__module__ == "liftreg_amd.losses.SubspaceLoss"
+    assert type(loss.sim).__module__ == "liftreg_amd.layers.losses" and type(loss.sim).__name__ == "NCCLoss"
+    assert loss.get_reg_factor(0) == 0.01 and loss.get_reg_factor(100) == 0.01            # shipped config: constant factor
+    # the harness-facing surface RegistrationNet touches (networks/RegistrationNet.py:179,394,410)
+    assert net.get_extra_to_plot() == (None, None) and net.get_disp() == (None, "")
+    assert callable(getattr(net, "train")) and callable(getattr(net, "eval")) and len(list(net.parameters())) == 18

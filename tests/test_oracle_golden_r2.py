@@ -1,0 +1,51 @@
+"""CPU: pin the oracle restatements of the rows closed in round 2 against golden vectors produced by importing the
+reference (tests/golden/make_golden_r2.py): forward_grids / forward_grids_with_poses (a5), the pose-less float64
+backproj_grids (a6'), the CSV geometry wrapper (a2') and the DirLab landmark sampler / TRE (f4)."""
+import numpy as np
+import torch
+
+from oracle import ref_ops as ro
+
+
+def test_forward_grids_bit_exact(golden):
+    g = golden("fwd_grids")
+    shape, spacing = tuple(int(v) for v in g["shape"]), tuple(float(v) for v in g["spacing"])
+    g1, dx1 = ro.forward_grids(30, 3, spacing, shape, receptor_size=(7, 9))
+    assert np.array_equal(g1.numpy(), g["g1"]) and np.array_equal(dx1.numpy(), g["dx1"])
+    g2, dx2 = ro.forward_grids(24, 2, spacing, shape)                       # default receptor [int(1.5 D), int(1.5 H)]
+    assert g2.shape == (2, 15, 12, shape[1], 3)
+    assert np.array_equal(g2.numpy(), g["g2"]) and np.array_equal(dx2.numpy(), g["dx2"])
+    g3, dx3 = ro.forward_grids_with_poses(g["poses"], spacing, shape, receptor_size=(6, 11))
+    assert np.array_equal(g3.numpy(), g["g3"]) and np.array_equal(dx3.numpy(), g["dx3"])
+
+
+def test_backproj_grids_poseless_float64_bit_exact(golden):
+    g = golden("bp_poseless")
+    for tag in ("a", "b"):
+        shp, pshape = tuple(int(v) for v in g[f"{tag}_shape"]), tuple(int(v) for v in g[f"{tag}_pshape"])
+        got = ro.backproj_grid_poseless(int(g[f"{tag}_range"]), int(g[f"{tag}_P"]), shp, pshape)
+        assert got.dtype == torch.float64 and got.shape == (int(g[f"{tag}_P"]), 2) + shp
+        assert np.array_equal(got.numpy(), g[f"{tag}_grid"])
+
+
+def test_csv_geometry(golden):
+    g = golden("csv_geo")
+    sp = tuple(float(v) for v in g["img_spacing"])      # a tuple of Python floats, as the reference's call sites pass it
+    poses = ro.csv_geometry_poses(g["geo_mm"], sp)
+    assert poses.dtype == np.float64 and np.array_equal(poses, g["poses"])
+    assert np.array_equal(ro.calc_relative_atten_coef(g["hu"]), g["mu"])
+    got = ro.drr_forward(g["mu"], poses, (9, 13), sp)
+    assert np.array_equal(got, g["proj"])
+    D, _, H = g["hu"].shape
+    got = ro.drr_forward(g["mu"], poses, (int(D * 1.5), int(H * 1.5)), sp)
+    assert np.array_equal(got, g["proj_default"])
+
+
+def test_landmark_tre(golden):
+    g = golden("tre")
+    tre, xyz, warped, s_norm = ro.landmark_tre(g["source"], g["target"], g["phi"][None], g["dim"], g["spacing"], g["origin"],
+                                               g["phi_spacing"])
+    assert np.array_equal(s_norm.numpy(), g["source_norm"])
+    assert np.array_equal(warped.numpy(), g["warped"])
+    assert tre == float(g["tre"]) and np.array_equal(np.array(xyz), g["tre_xyz"])
+    assert (g["warped"][:4] == 0).any()          # the fixture does hold landmarks outside the map (zeros padding)
