@@ -78,15 +78,48 @@ def synth_inputs(cfg, dev, seed=2021):
             "target_poses": torch.from_numpy(np.broadcast_to(p32, (B, P, 3)).copy())}
 
 
+def _cpu_forward_sample0(net, inp):
+    """oracle/ref_ops.model_forward (the reference's ATen op sequence, CPU) on sample 0 of `inp`."""
+    from oracle import ref_ops as ro
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    one = {k: v[:1].cpu().contiguous() for k, v in inp.items()}
+    with torch.no_grad():
+        ref = ro.model_forward(sd, one, net.pca_vectors_LxM.cpu(), net.pca_mean.cpu())
+        ref["ncc"] = float(ro.ncc_loss(ref["warped"], ref["target"]))
+    return ref
+
+
+def parity_vs_cpu(net, inp, out, ref=None):
+    """The timed workload checked at its own size: sample 0 of the GPU output `out` (= net(inp)) against the CPU
+    restatement of the reference's forward on the same input.  `ref` = an already computed CPU forward (the
+    cpu_baseline leg has paid for one).  Checker only — runs after the timed region."""
+    from liftreg_amd.layers.losses import NCCLoss
+    if ref is None:
+        ref = _cpu_forward_sample0(net, inp)
+    with torch.no_grad():
+        ncc_gpu = float(NCCLoss(check_nan=False)(out["warped"][:1].contiguous(), out["target"][:1].contiguous()))
+    g = {k: out[k][:1].detach().cpu() for k in ("params", "pca_coefs", "warped", "phi")}
+    coef_scale = float(ref["pca_coefs"].abs().max())
+    return {"sample": "sample 0 of the timed batch vs oracle/ref_ops.model_forward (torch CPU, the reference's op sequence)",
+            "max_abs_disp": float((g["params"] - ref["params"]).abs().max()),
+            "max_abs_phi": float((g["phi"] - ref["phi"]).abs().max()),
+            "max_rel_coefs": float((g["pca_coefs"] - ref["pca_coefs"]).abs().max()) / max(coef_scale, 1e-30),
+            "max_abs_warped": float((g["warped"] - ref["warped"]).abs().max()),
+            "mean_abs_warped": float((g["warped"] - ref["warped"]).abs().mean()),
+            "ncc_gpu": ncc_gpu, "ncc_cpu": ref["ncc"], "ncc_abs": abs(ncc_gpu - ref["ncc"]),
+            "bar": "displacement field within 1e-4 of the reference (BASELINE.json north_star)"}
+
+
 def cpu_baseline(cfg, net, inp, budget_s=30.0):
-    """Torch-CPU oracle (the reference's ATen op sequence) on ONE registration of the same workload."""
+    """Torch-CPU oracle (the reference's ATen op sequence) on ONE registration of the same workload.
+    Returns (the cpu_baseline record, the CPU forward's outputs for sample 0 — kept for parity_vs_cpu)."""
     import psutil
     from oracle import ref_ops as ro
     n, L = cfg["n"], cfg["L"]
     need = 4 * (L * 3 * n ** 3) * 1.3 + 4 * 40 * n ** 3
     if psutil.virtual_memory().available < need:
         return {"value": None, "unit": "registrations/s", "cores": os.cpu_count(), "kind": "port",
-                "sample": f"skipped: host has < {need / 2**30:.0f} GiB free for the PCA basis"}
+                "sample": f"skipped: host has < {need / 2**30:.0f} GiB free for the PCA basis"}, None
     cores = os.cpu_count()
     torch.set_num_threads(cores)
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
@@ -104,9 +137,10 @@ def cpu_baseline(cfg, net, inp, budget_s=30.0):
             ro.ncc_loss(out["warped"], out["target"])
             times.append(time.perf_counter() - t0)
     best = float(np.median(times[1:])) if len(times) > 1 else first
+    out["ncc"] = float(ro.ncc_loss(out["warped"], out["target"]))
     return {"value": 1.0 / best, "unit": "registrations/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} x 1 registration (B=1) of the same {n}^3/{cfg['P']}-view workload, "
-                      f"torch {torch.__version__} CPU ops, median of runs after the first; s/reg={best:.3f}"}
+                      f"torch {torch.__version__} CPU ops, median of runs after the first; s/reg={best:.3f}"}, out
 
 
 def main():
@@ -116,6 +150,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-drr", action="store_true", help="skip the projector-only legs after the timed region (profiling runs)")
     ap.add_argument("--streams", type=int, default=1, choices=(1, 2),
                     help="2: batch i's HBM-bound decode half overlaps batch i+1's MFMA-bound encode half on two HIP "
                          "streams (measured +1.3 %% at C3: every kernel already fills the chip; per-kernel timings "
@@ -227,22 +262,35 @@ def main():
         k["frac"] = k["achieved"] / k["peak"]
         k["traffic"] = None
         kernels[name] = k
-    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes per launch, if profiled
+    # PMC-derived HBM bytes per launch (tools/pmc_bench.sh over this very command).  Every entry is stamped with the
+    # kernel instance it was measured on and the sha256 of that kernel's source file: an entry whose source has changed
+    # since is dropped (traffic: null) — a profile never outlives the kernel it describes.
+    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+    stale = []
     if os.path.exists(traffic_file):
+        import hashlib
         with open(traffic_file) as fh:
-            for name, tb in json.load(fh).get(args.config, {}).items():
-                if name in kernels:
-                    kernels[name]["traffic"] = tb
+            for name, ent in json.load(fh).get(args.config, {}).items():
+                if name not in kernels or not isinstance(ent, dict):
+                    continue
+                src = os.path.join(ROOT, "liftreg_amd", "csrc", str(ent.get("source")))
+                ok = os.path.exists(src) and hashlib.sha256(open(src, "rb").read()).hexdigest() == ent.get("source_sha256")
+                if ok:
+                    kernels[name]["traffic"] = ent["bytes"]
+                    kernels[name]["traffic_kernel"] = ent.get("kernel")
+                else:
+                    stale.append(name)
     dominant = max(kernels, key=lambda kname: kernels[kname]["avg_ms"] * kernels[kname]["launches_per_step"])
 
     def roof(name):
         k = kernels[name]
         return {"kernel": name, "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
-                "unit": k["unit"], "frac": k["frac"], "traffic": k["traffic"], "avg_ms": k["avg_ms"]}
+                "unit": k["unit"], "frac": k["frac"], "traffic": k["traffic"], "avg_ms": k["avg_ms"],
+                "traffic_measured_on": k.get("traffic_kernel")}
 
     # the projector on its own and the simulate+register rate — outside the timed region
     drr = None
-    if rank == 0:
+    if rank == 0 and not args.no_drr:
         from liftreg_amd.utils.sdct_projection_utils import scan_poses
         p32 = scan_poses(30, P, n).astype(np.float32)
         vols = (inp["target"][:, 0] + 1) * 500 - 1000                   # back to HU: the projector folds HU→μ
@@ -285,12 +333,17 @@ def main():
         "roofline_backproject": roof("backproject"),
         "backproj_hbm_GBps": kernels["backproject"]["achieved"],
         "kernels": {k: {"ms": round(v["avg_ms"], 4), "n": v["launches_per_step"], "frac": round(v["frac"], 4),
-                        "bound": v["bound"]} for k, v in kernels.items()},
+                        "bound": v["bound"], "traffic": v["traffic"]} for k, v in kernels.items()},
+        "traffic_stale": stale,
         "ncc_loss": float(loss),
         "drr_forward": drr,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(cfg, net, inp)
+        result["cpu_baseline"], ref = cpu_baseline(cfg, net, inp)
+        if ref is not None:       # the CPU forward is paid for: compare the GPU output of the SAME input with it
+            with torch.no_grad():
+                gpu_out = net(inp)
+            result["parity_vs_cpu"] = parity_vs_cpu(net, inp, gpu_out, ref)
     elif rank == 0:
         result["cpu_baseline"] = None
     if rank == 0:

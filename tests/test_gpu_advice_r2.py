@@ -1,0 +1,159 @@
+"""GPU: regression tests for the round-1 advisor findings.
+
+  * NCC of a constant volume stays finite (raw-moment variances are clamped at 0 before the 1e-20 epsilon), forward and
+    backward, and equals the reference's centred formulation (layers/losses.py:18-26) on the oracle;
+  * `out=` arguments are written in place or rejected — never silently copied;
+  * the MFMA-ordered weight cache follows `load_state_dict`, `.to()` and explicit invalidation;
+  * the two-stream registrar keeps a batch's inputs alive across streams (serving loop that drops its batches);
+  * the slab-sharded forward masks the target with its label like the unsharded model (…Backproj.py:57-58).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops as ro
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def test_ncc_constant_volume_is_finite_and_matches_reference_form(dev):
+    from liftreg_amd import ops, ops_bwd
+    from liftreg_amd.layers.losses import NCCLoss
+    rs = np.random.RandomState(5)
+    y = torch.from_numpy(rs.uniform(-1, 1, (2, 1, 16, 16, 16)).astype(np.float32))
+    for cval in (0.3, -1.0, 0.1234567):            # 0.1234567²·n is not exactly representable: cancellation error ≠ 0
+        x = torch.full((2, 1, 16, 16, 16), cval)
+        want = float(ro.ncc_loss(x, y))
+        got = float(NCCLoss()(x.to(dev), y.to(dev)))   # asserts not-NaN itself (layers/losses.py:27)
+        assert np.isfinite(got) and abs(got - want) < 1e-5, (cval, got, want)
+        both = float(NCCLoss()(x.to(dev), x.to(dev)))  # constant vs constant: the reference gives ncc = 1 → loss 0
+        assert np.isfinite(both) and abs(both - float(ro.ncc_loss(x, x))) < 1e-5
+        # backward: finite gradient
+        m = ops.ncc_moments(x.to(dev), y.to(dev), 2)
+        g = ops_bwd.ncc_bwd(x.to(dev), y.to(dev), m, torch.ones((), device=dev), 16 ** 3)
+        assert torch.isfinite(g).all()
+
+
+def test_out_arguments_are_written_in_place_or_rejected(dev):
+    from liftreg_amd import ops
+    from liftreg_amd.utils.sdct_projection_utils import scan_poses
+    n, P, B = 16, 2, 2
+    poses = scan_poses(30, P, n).astype(np.float32)
+    proj = torch.rand((B, P, n, n), device=dev)
+    vol = torch.rand((n, n, n), device=dev)
+    # non-contiguous out: rejected, not copied
+    bad = torch.empty((B, P, n, n, 2 * n), device=dev)[..., ::2]
+    with pytest.raises(ValueError):
+        ops.backproject(proj, poses, (n, n, n), out=bad)
+    with pytest.raises(ValueError):
+        ops.drr_forward(vol, poses, (n, n), out=torch.empty((P, n, 2 * n), device=dev)[..., ::2])
+    with pytest.raises(ValueError):
+        ops.drr_forward(vol, poses, (n, n), out=torch.empty((P, n, n + 1), device=dev))           # wrong shape
+    coefs, basis, mean = torch.rand((B, 3), device=dev), torch.rand((3, 64), device=dev), torch.rand((64,), device=dev)
+    with pytest.raises(ValueError):
+        ops.pca_reconstruct(coefs, basis, mean, out=torch.empty((B, 128), device=dev)[:, ::2])
+    # a strided view with a wrong batch stride or non-dense blocks: rejected
+    buf = torch.empty((B, P + 1, n, n, n), device=dev)
+    with pytest.raises(ValueError):
+        ops.backproject(proj, poses, (n, n, n), out=buf[:, 1:], out_batch_stride=P * n ** 3)
+    # the supported forms write into the caller's memory
+    want = ops.backproject(proj, poses, (n, n, n))
+    buf.fill_(-7.0)
+    ops.backproject(proj, poses, (n, n, n), out=buf[:, 1:], out_batch_stride=(P + 1) * n ** 3)
+    assert torch.equal(buf[:, 1:], want) and float(buf[:, 0].max()) == -7.0
+    o = torch.full((B, P, n, n, n), -7.0, device=dev)
+    assert ops.backproject(proj, poses, (n, n, n), out=o) is o and torch.equal(o, want)
+    d = torch.full((P, n, n), -7.0, device=dev)
+    assert ops.drr_forward(vol, poses, (n, n), out=d) is d and torch.equal(d, ops.drr_forward(vol, poses, (n, n)))
+
+
+def _net(dev, n=32, P=2, L=6):
+    from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+    torch.manual_seed(11)
+    return model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:3"}).to(dev).eval()
+
+
+def _batch(dev, n=32, P=2, B=2, seed=0, labels=False):
+    from liftreg_amd.utils.sdct_projection_utils import scan_poses
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    poses = scan_poses(30, P, n).astype(np.float32)
+    b = {"source": torch.rand((B, 1, n, n, n), generator=g, device=dev) * 2 - 1,
+         "target": torch.rand((B, 1, n, n, n), generator=g, device=dev) * 2 - 1,
+         "target_proj": torch.rand((B, P, n, n), generator=g, device=dev) * 2 - 1,
+         "target_poses": torch.from_numpy(np.broadcast_to(poses, (B, P, 3)).copy())}
+    if labels:
+        b["source_label"] = (torch.rand((B, 1, n, n, n), generator=g, device=dev) > 0.3).float()
+        b["target_label"] = (torch.rand((B, 1, n, n, n), generator=g, device=dev) > 0.3).float()
+    return b
+
+
+def test_packed_weight_cache_follows_state_dict_and_explicit_invalidation(dev):
+    net = _net(dev)
+    inp = _batch(dev)
+    with torch.no_grad():
+        a = net(inp)["pca_coefs"].clone()
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        sd["encoders.1.conv.weight"] = sd["encoders.1.conv.weight"] * 1.5
+        net.load_state_dict(sd)
+        b = net(inp)["pca_coefs"].clone()
+        assert not torch.equal(a, b)                     # the new weights are in use
+        # an update THROUGH .data bumps neither data_ptr nor the version counter …
+        net.encoders[1].conv.weight.data.mul_(1 / 1.5)
+        net.invalidate_packed()                          # … so the documented call is needed
+        c = net(inp)["pca_coefs"]
+        np.testing.assert_allclose(c.cpu().numpy(), a.cpu().numpy(), rtol=2e-5, atol=1e-6)
+        # the same through-.data update is picked up without the call in training mode (re-packed every forward)
+    net.train()
+    net.encoders[1].conv.weight.data.mul_(1.5)
+    d = net(inp)["pca_coefs"].detach()
+    np.testing.assert_allclose(d.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=1e-6)
+
+
+def test_two_stream_registrar_serving_loop_that_drops_its_batches(dev):
+    """Each batch is created, submitted and dropped; the next batch's allocation may reuse its blocks on the caller's
+    stream.  With the inputs recorded on the encode/decode streams the results equal the plain forward's."""
+    from liftreg_amd.layers.losses import NCCLoss
+    from liftreg_amd.pipeline import TwoStreamRegistrar
+    net = _net(dev)
+    sim = NCCLoss(check_nan=False)
+    reg = TwoStreamRegistrar(net, sim)
+    want = []
+    with torch.no_grad():
+        for i in range(6):
+            b = _batch(dev, seed=i)
+            o = net(b)
+            want.append((o["warped"].clone(), float(sim(o["warped"], o["target"]))))
+        torch.cuda.synchronize()
+        got = []
+        for i in range(6):
+            b = _batch(dev, seed=i)
+            out, loss = reg.submit(b)
+            got.append((out["warped"], loss))
+            del b, out                                    # the caller drops the batch right after submit()
+            junk = torch.full((2, 1, 32, 32, 32), float(i), device=dev)   # and allocates again on its own stream
+            del junk
+        reg.synchronize()
+    for (w, l), (gw, gl) in zip(want, got):
+        assert torch.equal(w, gw) and abs(l - float(gl)) < 1e-6
+
+
+def test_slab_sharded_forward_masks_the_target_like_the_unsharded_model(dev):
+    from liftreg_amd import parallel as par
+    from liftreg_amd.layers.losses import NCCLoss
+    net = _net(dev, n=64)
+    inp = _batch(dev, n=64, labels=True)
+    with torch.no_grad():
+        ref = net(inp)
+        ref_loss = float(NCCLoss()(ref["warped"], ref["target"]))
+        outs = par.SlabShardedRegistration(net, par.LocalComm(2)).forward([inp, inp])
+    for r, out in enumerate(outs):
+        d0, d1 = par.slab_bounds(64, 2, r)
+        assert torch.equal(out["warped"], ref["warped"][:, :, d0:d1])
+        assert torch.equal(out["target"], ref["target"][:, :, d0:d1])          # (target+1)*target_label-1, sliced
+        assert abs(float(out["sim_loss"]) - ref_loss) < 1e-6
