@@ -143,6 +143,42 @@ def cpu_baseline(cfg, net, inp, budget_s=30.0):
                       f"torch {torch.__version__} CPU ops, median of runs after the first; s/reg={best:.3f}"}, out
 
 
+def dry_run(args, rank, world):
+    """The N-rank control path without a GPU: what the driver's `torch.distributed.run … bench.py --gpus N` exercises
+    around the measurement — rendezvous, warm-up, barrier-fenced timed region, MAX over ranks, one JSON line from
+    rank 0 — with a sleep standing in for the step (rank r sleeps (r+1) x 5 ms, so the max-over-ranks is checkable)."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.005 * (rank + 1))
+    fence()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "registrations/sec (256^3 CT, 2-view DRR)", "value": None, "unit": "registrations/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "strong" if args.shard == "slab" else "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "none", "dry_run": True,
+                          "config": {"workload": "control-path self-test: no GPU work, a sleep as the step",
+                                     "parallelism": f"{args.shard} x{world}"}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,6 +196,14 @@ def main():
     ap.add_argument("--conv-dtype", default="fp32", choices=("fp32", "bf16"),
                     help='bf16: activations between the conv blocks stored as bfloat16, blocks 1..5 on the bf16 MFMA '
                          '(configs C4/C5); NOT the headline configuration — the JSON line says so in "dtype"')
+    ap.add_argument("--shard", default="replicas", choices=("replicas", "slab"),
+                    help="replicas (default, the registrations/s metric): one independent batch per GPU, weak scaling, no "
+                         "data-path collective.  slab: ONE batch sharded by z-slab (axis D) over the N ranks — halo planes "
+                         "point-to-point, encoder features all-gathered, partial NCC moments all-reduced over RCCL/xGMI "
+                         "(BASELINE.json north_star / SURVEY 8e); strong scaling: value = B*steps/time")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="control-path self-test WITHOUT a GPU (CPU tests): rendezvous over gloo, fences, max-over-ranks "
+                         "timing and the single JSON line with a sleep as the step; the line says dry_run and carries no value")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from one captured HIP graph (launch-bound small configs c1/c2); the "
                          "per-kernel table then comes from one extra eager step outside the timed region")
@@ -174,6 +218,8 @@ def main():
     # LIFTREG_BENCH_BACKEND=gloo (test hook): lets several ranks share one GPU so the N>1 control path (fence, max over
     # ranks, single JSON line) can be exercised on a 1-GPU box; the measured configuration is always nccl, one GPU per rank
     backend = os.environ.get("LIFTREG_BENCH_BACKEND", "nccl")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if backend != "nccl":
         local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
@@ -195,10 +241,22 @@ def main():
     n, P, B, L = cfg["n"], cfg["P"], cfg["B"], cfg["L"]
     net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:2021",
                             "conv_dtype": args.conv_dtype, "pca_dtype": args.pca_dtype}).to(dev).eval()
-    inp = synth_inputs(cfg, dev, seed=2021 + rank)
+    slab = args.shard == "slab"
+    inp = synth_inputs(cfg, dev, seed=2021 if slab else 2021 + rank)   # slab: every rank holds the SAME batch
     sim = NCCLoss(check_nan=False)
 
-    if args.streams == 2:
+    if slab:
+        from liftreg_amd import parallel as par
+        if args.streams != 1 or args.graph:
+            sys.exit("--shard slab runs eagerly on one stream")
+        sharded = par.SlabShardedRegistration(net, par.DistComm())
+        d0, d1 = par.slab_bounds(n, world, rank)
+        # a rank needs the whole moving volume and the views (replicated), and only its slab of the target
+        my = dict(inp)
+
+        def step():
+            return sharded.forward([my])[0]["sim_loss"]
+    elif args.streams == 2:
         from liftreg_amd.pipeline import TwoStreamRegistrar
         reg = TwoStreamRegistrar(net, sim)
 
@@ -245,7 +303,7 @@ def main():
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    value = world * B * args.steps / elapsed
+    value = (B if slab else world * B) * args.steps / elapsed
 
     # per-kernel roofline numbers from the live HIP-event timings
     kernels = {}
@@ -320,14 +378,16 @@ def main():
     result = {
         "metric": "registrations/sec (256^3 CT, 2-view DRR)" if args.config == "c3" else f"registrations/sec ({args.config})",
         "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if slab else "weak",
         "vs_baseline": None,
         "dtype": "f32" if (args.conv_dtype, args.pca_dtype) == ("fp32", "fp32") else
                  f"conv blocks {args.conv_dtype}, PCA basis storage {args.pca_dtype}, f32 elsewhere",
         "data": "synthetic",
         "config": {"workload": f"{args.config}: {n}^3 CT, {P}x{cfg['R']}^2 DRR, batch {B}/GPU, latent {L}, "
-                               "backproject+conv6(MFMA f32)+FC3+PCA+warp+NCC", "global_batch": world * B,
-                   "parallelism": f"replicas x{world} (independent registrations, no data-path collective)",
+                               "backproject+conv6(MFMA f32)+FC3+PCA+warp+NCC", "global_batch": B if slab else world * B,
+                   "parallelism": (f"z-slab x{world}: ONE batch of {B} registrations sharded along D (rows {d0}:{d1} on rank 0); "
+                                   "halo planes p2p, encoder features all-gather, NCC moments all-reduce over RCCL" if slab else
+                                   f"replicas x{world} (independent registrations, no data-path collective)"),
                    "streams": args.streams, "hip_graph": bool(args.graph)},
         "roofline": roof(dominant),
         "roofline_backproject": roof("backproject"),
@@ -338,7 +398,7 @@ def main():
         "ncc_loss": float(loss),
         "drr_forward": drr,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not slab:
         result["cpu_baseline"], ref = cpu_baseline(cfg, net, inp)
         if ref is not None:       # the CPU forward is paid for: compare the GPU output of the SAME input with it
             with torch.no_grad():

@@ -321,6 +321,23 @@ int lr_pca_warp_bf16basis_f32(const float* coefs, const void* basis_bf16, const 
                               float* warped, int B, int L, int C, int D, int W, int H, int64_t ldb, int flags,
                               void* stream);
 
+/* Slab form of the one-pass decode, with the similarity's moments in its epilogue:
+ *  - rows [d0,d1) of D: outputs are (B,3,Dn,W,H) / (B,C,Dn,W,H) slabs (Dn = d1-d0); `img` is the WHOLE moving volume
+ *    (taps cross slabs); `basis` / `mean` point at the column of (component 0, row d0) and their three component
+ *    thirds are `basis_comp_stride` columns apart: D*W*H for a view into the full (L,3V) basis (ldb = its row stride),
+ *    Dn*W*H for a rank's compact (L,3*Dn*W*H) slab of it (11.3 GB -> 1.4 GB per GPU at 8 ranks); id0 = the D-axis
+ *    identity table from row d0 on.  basis_is_bf16: the basis is stored as bfloat16 (ldb and stride in elements).
+ *  - target != NULL (C == 1): (B,1,Dn,W,H) target slab; the five fp64 raw moments of (warped, target) per batch row
+ *    (layers/losses.py:18-29, the sums lr_ncc_moments_f32 produces) are accumulated while `warped` is still in
+ *    registers: ncc_partial = B * gridblocks * 5 doubles of scratch (gridblocks = ceil(W*H/1024) * Dn),
+ *    ncc_moments = (B,5) doubles.  Slab moments add (all-reduce), lr_ncc_loss_from_moments turns them into the loss.
+ * Same bits as lr_pca_warp_f32 for params / phi / warped. */
+int lr_pca_warp_slab_f32(const float* coefs, const void* basis, int basis_is_bf16, const float* mean, const float* img,
+                         const float* id0, const float* id1, const float* id2, float* disp, float* phi, float* warped,
+                         int B, int L, int C, int D, int W, int H, int d0, int d1, int64_t ldb,
+                         int64_t basis_comp_stride, int flags, const float* target, double* ncc_partial,
+                         double* ncc_moments, void* stream);
+
 /* ---- bf16 variant of the stride-2 encoder blocks (Cin, Cout in {16,32}; v_mfma_f32_16x16x32_bf16, fp32
  * accumulate, bias/LeakyReLU in fp32, output rounded to bf16 — or fp32 NCDHW for the last block).
  * in: bf16 LR_LAYOUT_BF16_NDHWC[_HPS]; packed_w: lr_conv3d_packed_bf16_bytes(...) bytes written by

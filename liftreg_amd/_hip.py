@@ -45,6 +45,8 @@ SIGNATURES = {
     "lr_conv3d_first_split_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "lr_pca_warp_f32": (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _i, _i64, _i, _p]),
     "lr_pca_warp_bf16basis_f32": (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _i, _i64, _i, _p]),
+    "lr_pca_warp_slab_f32": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i,
+                                  _p, _p, _p, _p]),
     "lr_warp_trilinear_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "lr_mask_compose_f32": (_i, [_p, _p, _p, _i64, _p]),
     "lr_ncc_moments_f32": (_i, [_p, _p, _p, _p, _i, _i64, _i, _p]),

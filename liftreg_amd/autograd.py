@@ -190,7 +190,9 @@ class NCCFn(torch.autograd.Function):
     def forward(ctx, x, y, variant):
         n_batch = x.shape[0]
         rows = n_batch if variant == _hip.NCC_CONFIGURED else n_batch * x.shape[1]
-        m = ops.ncc_moments(x, y, rows)
+        m = ops.cached_ncc_moments(x, y, rows)      # left by the one-pass decode's epilogue for these very tensors
+        if m is None:
+            m = ops.ncc_moments(x, y, rows)
         loss, _ = ops.ncc_loss_from_moments(m, x.numel() // rows, n_batch, variant)
         ctx.save_for_backward(x, y, m)
         ctx.cfg = (variant, x.numel() // rows)

@@ -55,3 +55,6 @@ __device__ __forceinline__ double lr_wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   return v;
 }
+
+// ncc.hip: fixed-order sum of per-block moment partials [R][nblk][5] -> moments [R][5] (one block per row)
+int lr_internal_ncc_reduce(const double* partial, double* moments, int R, int nblk, hipStream_t st);

@@ -118,6 +118,12 @@ __global__ __launch_bounds__(64) void ncc_loss_kernel(const double* __restrict__
 
 }  // namespace
 
+// shared with warp.hip's one-pass decode, whose epilogue leaves per-block partials in the same [row][block][5] layout
+int lr_internal_ncc_reduce(const double* partial, double* moments, int R, int nblk, hipStream_t st) {
+  hipLaunchKernelGGL(ncc_reduce_kernel, dim3((unsigned)R), dim3(256), 0, st, partial, moments, nblk);
+  return lr_launch_status();
+}
+
 extern "C" int lr_ncc_moments_f32(const float* x, const float* y, double* partial, double* moments,
                                   int R, int64_t N, int nblk, void* stream) {
   if (!x || !y || !partial || !moments) return LR_ENULL;

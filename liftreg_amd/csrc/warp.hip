@@ -332,13 +332,23 @@ __global__ __launch_bounds__(256) void warp_tri_fast_kernel(
 // model outputs) and never read back: the separate warp kernel re-read 4·3V bytes per sample.  A thread owns 4
 // consecutive voxels of a row and ALL batch rows (the basis is streamed once per batch, as in pca_kernel): 8 x 3
 // float4 accumulators, three basis streams (the rows' D-, W- and H-component thirds).
-template <bool BF, bool SCALE, int BT /* batch rows per thread: 8, or 4 for small batches (half the accumulators) */>
+// Slab form (z-slab sharding): the launch covers output rows [d0,d1) = Dn rows; `basis`/`mean` point at the
+// column of (component 0, row d0) and their three component thirds are `bcs` columns apart (V for the full (L,3V)
+// basis, Dn·W·H for a rank's compact slab of it); outputs are (B,3,Dn,W,H) / (B,C,Dn,W,H) slabs; the moving image is
+// whole (taps cross slabs).  id0 = the D-axis identity table from row d0 on.
+// NCC (f1, "NCC moments in the warp epilogue"): with a target slab (B,1,Dn,W,H) the five fp64 raw moments of
+// (warped, target) per batch row are reduced here — the similarity never re-reads `warped` (layers/losses.py:18-29
+// made ~8 passes, ncc_moments_kernel one): per-block partials [b][block][5], fixed order, no atomics; the caller's
+// ncc_reduce pass (ncc.hip) sums the blocks.  C == 1 only.
+template <bool BF, bool SCALE, int BT /* batch rows per thread: 8, or 4 for small batches (half the accumulators) */, bool NCC>
 __global__ __launch_bounds__(256) void pca_warp_kernel(const float* __restrict__ coefs, const float* __restrict__ basis,
                                                        const float* __restrict__ mean, const float* __restrict__ img,
                                                        const float* __restrict__ id0, const float* __restrict__ id1,
                                                        const float* __restrict__ id2, float* __restrict__ disp_out,
                                                        float* __restrict__ phi_out, float* __restrict__ warped, int B,
-                                                       int L, int C, int D, int W, int H, int64_t ldb, float rcp_hv) {
+                                                       int L, int C, int D, int W, int H, int64_t ldb, float rcp_hv,
+                                                       int64_t bcs, const float* __restrict__ target,
+                                                       double* __restrict__ ncc_partial) {
   extern __shared__ float cs[];  // [L][BT]
   for (int t = threadIdx.x; t < L * BT; t += blockDim.x) {
     const int l = t / BT, b = t % BT;
@@ -347,20 +357,24 @@ __global__ __launch_bounds__(256) void pca_warp_kernel(const float* __restrict__
   __syncthreads();
   const int HV = H >> 2;
   const int t = blockIdx.x * 256 + threadIdx.x;  // float4 index inside plane i
-  const int i = blockIdx.y;
-  const int j = (int)(((float)t + 0.5f) * rcp_hv);
-  if (j >= W) return;
-  const int kv = t - __mul24(j, HV);
+  const int i = blockIdx.y;                       // slab row (global row d0 + i)
+  const int Dn = gridDim.y;
+  const int jj = (int)(((float)t + 0.5f) * rcp_hv);
+  const bool active = jj < W;
+  if (!NCC && !active) return;
+  const int j = active ? jj : 0;
+  const int kv = active ? t - __mul24(j, HV) : 0;
   const int sD = W * H;
-  const int64_t V = (int64_t)D * sD;
+  const int64_t V = (int64_t)D * sD;        // the moving image: whole volume
+  const int64_t Vs = (int64_t)Dn * sD;      // output slabs
   const int inplane = __mul24(j, H) + (kv << 2);
-  const int64_t m = (int64_t)i * sD + inplane;  // voxel index = column of the D-component third
+  const int64_t m = (int64_t)i * sD + inplane;  // voxel index inside the slab = column of the D-component third
 
   typedef float f32x4v __attribute__((ext_vector_type(4)));
   f32x4v acc[BT][3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const f32x4v mu = *reinterpret_cast<const f32x4v*>(mean + c * V + m);
+    const f32x4v mu = *reinterpret_cast<const f32x4v*>(mean + c * bcs + m);
 #pragma unroll
     for (int b = 0; b < BT; ++b) acc[b][c] = mu;
   }
@@ -372,13 +386,13 @@ __global__ __launch_bounds__(256) void pca_warp_kernel(const float* __restrict__
       if (BF) {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         const u32x2 raw = __builtin_nontemporal_load(
-            reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(basis) + (int64_t)l * ldb + c * V + m));
+            reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(basis) + (int64_t)l * ldb + c * bcs + m));
         v[c][0] = __builtin_bit_cast(float, raw.x << 16);
         v[c][1] = __builtin_bit_cast(float, raw.x & 0xffff0000u);
         v[c][2] = __builtin_bit_cast(float, raw.y << 16);
         v[c][3] = __builtin_bit_cast(float, raw.y & 0xffff0000u);
       } else {
-        v[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(basis + (int64_t)l * ldb + c * V + m));
+        v[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(basis + (int64_t)l * ldb + c * bcs + m));
       }
     }
 #pragma unroll
@@ -399,6 +413,7 @@ __global__ __launch_bounds__(256) void pca_warp_kernel(const float* __restrict__
   // longer in order and every consumed gather would drain the stores issued before it (one store latency per row).
   if (C == 1) {
     f32x4v res[BT];
+    f32x4v tg[NCC ? BT : 1];
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
       if (b >= B) break;
@@ -407,36 +422,95 @@ __global__ __launch_bounds__(256) void pca_warp_kernel(const float* __restrict__
 #pragma unroll
       for (int v = 0; v < 4; ++v)  // deform_field = disp_field + id_transform
         res[b][v] = tri_sample_fast<SCALE>(rsrc, acc[b][0][v] + a0, acc[b][1][v] + a1, acc[b][2][v] + a2[v], D, W, H, sD);
+      if constexpr (NCC) tg[b] = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(target + (int64_t)b * Vs + m));
     }
+    if (active) {
 #pragma unroll
-    for (int b = 0; b < BT; ++b) {
-      if (b >= B) break;
-      float* dp = disp_out + (int64_t)b * 3 * V + m;
-      float* pp = phi_out + (int64_t)b * 3 * V + m;
-      f32x4v p0, p1, p2;
+      for (int b = 0; b < BT; ++b) {
+        if (b >= B) break;
+        float* dp = disp_out + (int64_t)b * 3 * Vs + m;
+        float* pp = phi_out + (int64_t)b * 3 * Vs + m;
+        f32x4v p0, p1, p2;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        p0[v] = acc[b][0][v] + a0;
-        p1[v] = acc[b][1][v] + a1;
-        p2[v] = acc[b][2][v] + a2[v];
+        for (int v = 0; v < 4; ++v) {
+          p0[v] = acc[b][0][v] + a0;
+          p1[v] = acc[b][1][v] + a1;
+          p2[v] = acc[b][2][v] + a2[v];
+        }
+        __builtin_nontemporal_store(acc[b][0], reinterpret_cast<f32x4v*>(dp));
+        __builtin_nontemporal_store(acc[b][1], reinterpret_cast<f32x4v*>(dp + Vs));
+        __builtin_nontemporal_store(acc[b][2], reinterpret_cast<f32x4v*>(dp + 2 * Vs));
+        __builtin_nontemporal_store(p0, reinterpret_cast<f32x4v*>(pp));
+        __builtin_nontemporal_store(p1, reinterpret_cast<f32x4v*>(pp + Vs));
+        __builtin_nontemporal_store(p2, reinterpret_cast<f32x4v*>(pp + 2 * Vs));
+        __builtin_nontemporal_store(res[b], reinterpret_cast<f32x4v*>(warped + (int64_t)b * Vs + m));
       }
-      __builtin_nontemporal_store(acc[b][0], reinterpret_cast<f32x4v*>(dp));
-      __builtin_nontemporal_store(acc[b][1], reinterpret_cast<f32x4v*>(dp + V));
-      __builtin_nontemporal_store(acc[b][2], reinterpret_cast<f32x4v*>(dp + 2 * V));
-      __builtin_nontemporal_store(p0, reinterpret_cast<f32x4v*>(pp));
-      __builtin_nontemporal_store(p1, reinterpret_cast<f32x4v*>(pp + V));
-      __builtin_nontemporal_store(p2, reinterpret_cast<f32x4v*>(pp + 2 * V));
-      __builtin_nontemporal_store(res[b], reinterpret_cast<f32x4v*>(warped + (int64_t)b * V + m));
+    }
+    if constexpr (NCC) {
+      // five fp64 moments per batch row over this thread's 4 voxels (products of two fp32 are exact in fp64) …
+      double s[BT][5];
+#pragma unroll
+      for (int b = 0; b < BT; ++b) {
+        if (b < B && active) {
+          const double x0 = res[b][0], x1 = res[b][1], x2 = res[b][2], x3 = res[b][3];
+          const double y0 = tg[b][0], y1 = tg[b][1], y2 = tg[b][2], y3 = tg[b][3];
+          s[b][0] = (x0 + x1) + (x2 + x3);
+          s[b][1] = (y0 + y1) + (y2 + y3);
+          s[b][2] = (x0 * y0 + x1 * y1) + (x2 * y2 + x3 * y3);
+          s[b][3] = (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3);
+          s[b][4] = (y0 * y0 + y1 * y1) + (y2 * y2 + y3 * y3);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 5; ++q) s[b][q] = 0.0;
+        }
+      }
+      // … reduced over the wave by a halving butterfly: at step k a lane keeps the half of its rows that bit k of its
+      // lane id selects and receives its partner's sums for them, so BT·5 sums cost ≈ BT·5 shuffles instead of
+      // BT·5·6; after log2(BT) steps a lane holds ONE row, b = bitreverse(lane & (BT-1)), summed over BT lanes
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+      for (int half = BT / 2, bit = 1; half >= 1; half >>= 1, bit <<= 1) {
+        const bool up = lane & bit;
+#pragma unroll
+        for (int b = 0; b < half; ++b)
+#pragma unroll
+          for (int q = 0; q < 5; ++q) {
+            const double lo = s[b][q], hi = s[b + half][q];
+            const double got = __shfl_xor(up ? lo : hi, bit, 64);
+            s[b][q] = (up ? hi : lo) + got;
+          }
+      }
+#pragma unroll
+      for (int q = 0; q < 5; ++q)
+#pragma unroll
+        for (int o = BT; o < 64; o <<= 1) s[0][q] += __shfl_xor(s[0][q], o, 64);
+      __shared__ double red[4][BT][5];
+      if (lane < BT) {
+        int brow = 0;  // bit-reverse of the lane's low log2(BT) bits
+#pragma unroll
+        for (int bit = 1, w = BT / 2; w >= 1; bit <<= 1, w >>= 1) brow |= (lane & bit) ? w : 0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) red[wave][brow][q] = s[0][q];
+      }
+      __syncthreads();
+      if (threadIdx.x < BT * 5) {
+        const int b = threadIdx.x / 5, q = threadIdx.x % 5;
+        if (b < B) {
+          const int64_t nblk = (int64_t)gridDim.x * gridDim.y, blk = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+          ncc_partial[((int64_t)b * nblk + blk) * 5 + q] = (red[0][b][q] + red[1][b][q]) + (red[2][b][q] + red[3][b][q]);
+        }
+      }
     }
     return;
   }
+  if (!active) return;
 #pragma unroll
   for (int b = 0; b < BT; ++b) {  // several image channels: row by row
     if (b >= B) break;
-    float* dp = disp_out + (int64_t)b * 3 * V + m;
+    float* dp = disp_out + (int64_t)b * 3 * Vs + m;
     __builtin_nontemporal_store(acc[b][0], reinterpret_cast<f32x4v*>(dp));
-    __builtin_nontemporal_store(acc[b][1], reinterpret_cast<f32x4v*>(dp + V));
-    __builtin_nontemporal_store(acc[b][2], reinterpret_cast<f32x4v*>(dp + 2 * V));
+    __builtin_nontemporal_store(acc[b][1], reinterpret_cast<f32x4v*>(dp + Vs));
+    __builtin_nontemporal_store(acc[b][2], reinterpret_cast<f32x4v*>(dp + 2 * Vs));
     f32x4v p0, p1, p2;  // deform_field = disp_field + id_transform
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -444,17 +518,17 @@ __global__ __launch_bounds__(256) void pca_warp_kernel(const float* __restrict__
       p1[v] = acc[b][1][v] + a1;
       p2[v] = acc[b][2][v] + a2[v];
     }
-    float* pp = phi_out + (int64_t)b * 3 * V + m;
+    float* pp = phi_out + (int64_t)b * 3 * Vs + m;
     __builtin_nontemporal_store(p0, reinterpret_cast<f32x4v*>(pp));
-    __builtin_nontemporal_store(p1, reinterpret_cast<f32x4v*>(pp + V));
-    __builtin_nontemporal_store(p2, reinterpret_cast<f32x4v*>(pp + 2 * V));
+    __builtin_nontemporal_store(p1, reinterpret_cast<f32x4v*>(pp + Vs));
+    __builtin_nontemporal_store(p2, reinterpret_cast<f32x4v*>(pp + 2 * Vs));
     for (int c = 0; c < C; ++c) {
       const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(img + ((int64_t)b * C + c) * V), (short)0, (int)(V * 4), 0x00020000);
       f32x4v res;
 #pragma unroll
       for (int v = 0; v < 4; ++v) res[v] = tri_sample_fast<SCALE>(rsrc, p0[v], p1[v], p2[v], D, W, H, sD);
-      __builtin_nontemporal_store(res, reinterpret_cast<f32x4v*>(warped + ((int64_t)b * C + c) * V + m));
+      __builtin_nontemporal_store(res, reinterpret_cast<f32x4v*>(warped + ((int64_t)b * C + c) * Vs + m));
     }
   }
 }
@@ -542,35 +616,46 @@ extern "C" int lr_warp_trilinear_f32(const float* img, const float* seg, const f
 
 static int pca_warp_impl(bool bf, const float* coefs, const float* basis, const float* mean, const float* img,
                          const float* id0, const float* id1, const float* id2, float* disp, float* phi, float* warped,
-                         int B, int L, int C, int D, int W, int H, int64_t ldb, int flags, void* stream) {
+                         int B, int L, int C, int D, int W, int H, int d0, int d1, int64_t ldb, int64_t bcs, int flags,
+                         const float* target, double* ncc_partial, double* ncc_moments, void* stream) {
   if (!coefs || !basis || !mean || !img || !id0 || !id1 || !id2 || !disp || !phi || !warped) return LR_ENULL;
   if (B < 1 || L < 1 || C < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
+  if (d0 < 0 || d1 > D || d1 <= d0) return LR_EINVAL;
   if (flags & ~LR_WARP_USING_SCALE) return LR_EUNSUPPORTED;  // zeros padding, trilinear only (the model's case)
-  const int64_t sD = (int64_t)W * H, V = sD * D;
-  if (B > 8 || L > 2048 || (H & 3) || ldb < 3 * V) return LR_EUNSUPPORTED;  // larger batches: chunks of 8 (ops.pca_warp)
+  const bool ncc = target != nullptr;
+  if (ncc && (!ncc_partial || !ncc_moments)) return LR_ENULL;
+  if (ncc && C != 1) return LR_EUNSUPPORTED;
+  const int Dn = d1 - d0;
+  const int64_t sD = (int64_t)W * H, V = sD * D, Vs = sD * Dn;
+  if (B > 8 || L > 2048 || (H & 3) || bcs < Vs || ldb < 2 * bcs + Vs) return LR_EUNSUPPORTED;  // larger batches: chunks of 8 (ops.pca_warp)
   if (!(V * 4 + sD * 4 <= 0x80000000LL && sD < (1 << 23) && sD / 4 <= (1 << 20) && D <= 65535)) return LR_EUNSUPPORTED;
   if (((reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(disp) | reinterpret_cast<uintptr_t>(phi) |
-        reinterpret_cast<uintptr_t>(warped) | reinterpret_cast<uintptr_t>(id2)) & 15u) ||
-      (reinterpret_cast<uintptr_t>(basis) & (bf ? 7u : 15u)) || (ldb & 3))
+        reinterpret_cast<uintptr_t>(warped) | reinterpret_cast<uintptr_t>(id2) | reinterpret_cast<uintptr_t>(target)) & 15u) ||
+      (reinterpret_cast<uintptr_t>(basis) & (bf ? 7u : 15u)) || (ldb & 3) || (bcs & 3))
     return LR_EALIGN;
-  const dim3 grid((unsigned)((sD / 4 + 255) / 256), (unsigned)D), block(256);
+  const dim3 grid((unsigned)((sD / 4 + 255) / 256), (unsigned)Dn), block(256);
   const float rcp_hv = 1.0f / (float)(H / 4);
   hipStream_t st = lr_stream(stream);
   const bool sc = flags & LR_WARP_USING_SCALE;
-#define LR_PW1(BFV, SCV, BTV) hipLaunchKernelGGL((pca_warp_kernel<BFV, SCV, BTV>), grid, block, (size_t)L * BTV * sizeof(float), st, coefs, basis, mean, img, id0, id1, id2, disp, phi, warped, B, L, C, D, W, H, ldb, rcp_hv)
+#define LR_PW2(BFV, SCV, BTV, NCV) hipLaunchKernelGGL((pca_warp_kernel<BFV, SCV, BTV, NCV>), grid, block, (size_t)L * BTV * sizeof(float), st, coefs, basis, mean, img, id0, id1, id2, disp, phi, warped, B, L, C, D, W, H, ldb, rcp_hv, bcs, target, ncc_partial)
+#define LR_PW1(BFV, SCV, BTV) do { if (ncc) LR_PW2(BFV, SCV, BTV, true); else LR_PW2(BFV, SCV, BTV, false); } while (0)
 #define LR_PW(BFV, SCV) do { if (B <= 4) LR_PW1(BFV, SCV, 4); else LR_PW1(BFV, SCV, 8); } while (0)
   if (bf) { if (sc) LR_PW(true, true); else LR_PW(true, false); }
   else    { if (sc) LR_PW(false, true); else LR_PW(false, false); }
 #undef LR_PW
 #undef LR_PW1
-  return lr_launch_status();
+#undef LR_PW2
+  if (int e = lr_launch_status()) return e;
+  if (ncc) return lr_internal_ncc_reduce(ncc_partial, ncc_moments, B, (int)(grid.x * grid.y), st);
+  return LR_OK;
 }
 
 extern "C" int lr_pca_warp_f32(const float* coefs, const float* basis, const float* mean, const float* img,
                                const float* id0, const float* id1, const float* id2, float* disp, float* phi,
                                float* warped, int B, int L, int C, int D, int W, int H, int64_t ldb, int flags,
                                void* stream) {
-  return pca_warp_impl(false, coefs, basis, mean, img, id0, id1, id2, disp, phi, warped, B, L, C, D, W, H, ldb, flags, stream);
+  return pca_warp_impl(false, coefs, basis, mean, img, id0, id1, id2, disp, phi, warped, B, L, C, D, W, H, 0, D, ldb,
+                       (int64_t)D * W * H, flags, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int lr_pca_warp_bf16basis_f32(const float* coefs, const void* basis_bf16, const float* mean, const float* img,
@@ -578,7 +663,17 @@ extern "C" int lr_pca_warp_bf16basis_f32(const float* coefs, const void* basis_b
                                          float* warped, int B, int L, int C, int D, int W, int H, int64_t ldb, int flags,
                                          void* stream) {
   return pca_warp_impl(true, coefs, reinterpret_cast<const float*>(basis_bf16), mean, img, id0, id1, id2, disp, phi, warped,
-                       B, L, C, D, W, H, ldb, flags, stream);
+                       B, L, C, D, W, H, 0, D, ldb, (int64_t)D * W * H, flags, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int lr_pca_warp_slab_f32(const float* coefs, const void* basis, int basis_is_bf16, const float* mean,
+                                    const float* img, const float* id0, const float* id1, const float* id2, float* disp,
+                                    float* phi, float* warped, int B, int L, int C, int D, int W, int H, int d0, int d1,
+                                    int64_t ldb, int64_t basis_comp_stride, int flags, const float* target,
+                                    double* ncc_partial, double* ncc_moments, void* stream) {
+  return pca_warp_impl(basis_is_bf16 != 0, coefs, reinterpret_cast<const float*>(basis), mean, img, id0, id1, id2, disp, phi,
+                       warped, B, L, C, D, W, H, d0, d1, ldb, basis_comp_stride, flags, target, ncc_partial, ncc_moments,
+                       stream);
 }
 
 extern "C" int lr_mask_compose_f32(const float* img, const float* seg, float* out, int64_t n,

@@ -129,8 +129,12 @@ class model(nn.Module):
         self.register_buffer("_id0", torch.from_numpy(t0), persistent=False)
         self.register_buffer("_id1", torch.from_numpy(t1), persistent=False)
         self.register_buffer("_id2", torch.from_numpy(t2), persistent=False)
+        # optional (non-reference) key "fuse_ncc": in inference the one-pass decode also accumulates the similarity's
+        # moments against `target` (they cost one extra read of the target there instead of a pass over both volumes)
+        self.fuse_ncc = bool(_opt(opt, "fuse_ncc", True))
         self._poses = None         # geometry of the first batch's element 0, cached like :85-87
         self._packed = {}          # conv weights in MFMA operand order, keyed by parameter version
+        self._pca_slabs = {}       # compact per-rank column slabs of the basis (pca_slab)
 
     # ------------------------------------------------------------------ reference-compatible surface
     @property
@@ -157,6 +161,7 @@ class model(nn.Module):
             raise ValueError("basis must be (latent_dim, 3*D*W*H)")
         self.pca_vectors_LxM = self._basis_storage(vectors_LxM.contiguous())
         self.pca_mean = mean.contiguous()
+        self._pca_slabs.clear()
 
     # ------------------------------------------------------------------ internals
     def _ensure_pca(self, device):
@@ -174,6 +179,38 @@ class model(nn.Module):
             self.pca_mean = torch.zeros((M,), dtype=torch.float32, device=device)
         elif self.pca_dtype == "bf16" and self.pca_vectors_LxM.dtype != torch.bfloat16:
             self.pca_vectors_LxM = self._basis_storage(self.pca_vectors_LxM)     # a basis loaded from pca_path
+
+    def pca_slab(self, d0, d1, device):
+        """(basis (L, 3·Dn·W·H), mean (3·Dn·W·H,)): the COMPACT column slab of rows [d0,d1) of D — what one rank of a
+        z-slab sharded registration keeps ("shard basis rows by slab, 11.3 GB → 1.4 GB/GPU at G=8").
+        Built once per (d0,d1): sliced out of the full basis when that is resident, else (synthetic basis) generated row
+        by row through a (3V,) scratch row, so the full (L,3V) array never exists on a sharded rank.  Same values as
+        the corresponding columns of the full basis."""
+        D, W, H = self.img_sz
+        key = (int(d0), int(d1), str(device))
+        hit = self._pca_slabs.get(key)
+        if hit is not None:
+            return hit
+        plane, Dn = W * H, d1 - d0
+        cols = torch.cat([torch.arange((c * D + d0) * plane, (c * D + d1) * plane, device=device) for c in range(3)])
+        if self.pca_vectors_LxM.numel() > 0:
+            vec = self.pca_vectors_LxM.to(device)
+            basis = self._basis_storage(vec[:, cols].contiguous())
+            mean = self.pca_mean.to(device)[cols].contiguous()
+        else:
+            if self._synthetic_seed is None:
+                raise RuntimeError("PCA basis missing")
+            g = torch.Generator(device=device)
+            g.manual_seed(self._synthetic_seed)
+            row = torch.empty((3 * D * plane,), dtype=torch.float32, device=device)
+            basis = torch.empty((self.latent_dim, 3 * Dn * plane), dtype=torch.float32, device=device)
+            for l in range(self.latent_dim):      # the same stream of normals as _ensure_pca's full basis
+                row.normal_(0.0, 0.02 / float(np.sqrt(self.latent_dim)), generator=g)
+                basis[l] = row[cols]
+            basis = self._basis_storage(basis)
+            mean = torch.zeros((3 * Dn * plane,), dtype=torch.float32, device=device)
+        self._pca_slabs[key] = (basis, mean)
+        return basis, mean
 
     def _basis_storage(self, vec):
         return vec.to(torch.bfloat16) if self.pca_dtype == "bf16" else vec.to(torch.float32)
@@ -267,12 +304,18 @@ class model(nn.Module):
             x = self.encoders[i](x, packed=self._packed_weight(i))
         return self.encoders[6](x)
 
-    def decode(self, moving, coefs, moving_seg=None):
-        """HBM-bound half: PCA reconstruction → identity add + trilinear warp.  Returns (disp, phi, warped)."""
-        B, _, D, W, H = moving.shape
+    def decode(self, moving, coefs, moving_seg=None, target=None):
+        """HBM-bound half: PCA reconstruction → identity add + trilinear warp.  Returns (disp, phi, warped).
+        `target` (inference, single-channel): the similarity's five moments of (warped, target) are accumulated in the
+        same pass and left for `NCCLoss(out["warped"], out["target"])` (ops.cached_ncc_moments) — SURVEY §8 f1."""
+        B, C, D, W, H = moving.shape
         if (moving_seg is None and not (torch.is_grad_enabled() and coefs.requires_grad) and
                 ops.pca_warp_supported(coefs, self.pca_vectors_LxM, moving)):
             # inference: one pass writes params, phi and warped (SURVEY §8 f1) — the same bits as the two kernels below
+            if target is not None and C == 1 and target.is_cuda and target.dtype == torch.float32 and \
+                    target.is_contiguous() and target.shape == moving.shape and self.fuse_ncc:
+                return ops.pca_warp(coefs, self.pca_vectors_LxM, self.pca_mean, (self._id0, self._id1, self._id2), moving,
+                                    target=target)[:3]
             return ops.pca_warp(coefs, self.pca_vectors_LxM, self.pca_mean, (self._id0, self._id1, self._id2), moving)
         # training: one autograd node for PCA reconstruction → (+ identity) → warp; the mask compose of moving
         # ((moving+1)*seg-1, :57) happens on the warp's taps
@@ -295,7 +338,7 @@ class model(nn.Module):
             target_cp = target
 
         coefs = self.encode(moving, target_proj, input['target_poses'])
-        disp_field, deform_field, warped_source = self.decode(moving, coefs, moving_seg)
+        disp_field, deform_field, warped_source = self.decode(moving, coefs, moving_seg, target=target_cp)
         return {"warped": warped_source,
                 "phi": deform_field,
                 "params": disp_field,

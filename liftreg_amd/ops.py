@@ -502,20 +502,46 @@ def warp(img, disp, ids=None, seg=None, *, using_scale=True, zero_boundary=True,
     return phi, warped
 
 
-def pca_warp_supported(coefs, basis_LxM, img):
-    """True when the one-pass decode `pca_warp` can run these tensors (else: pca_reconstruct + warp)."""
+def pca_warp_supported(coefs, basis_LxM, img, d0=0, d1=None):
+    """True when the one-pass decode `pca_warp` can run these tensors (else: pca_reconstruct + warp).  The basis is
+    the full (L,3V) array, or — for rows [d0,d1) — a rank's compact (L,3·Dn·W·H) slab of it."""
     B, C, D, W, H = img.shape
     V = D * W * H
-    return (H % 4 == 0 and basis_LxM.shape[1] == 3 * V and basis_LxM.stride(1) == 1 and basis_LxM.stride(0) % 4 == 0 and
+    Dn = (D if d1 is None else d1) - d0
+    cols = basis_LxM.shape[1]
+    return (H % 4 == 0 and cols in (3 * V, 3 * Dn * W * H) and basis_LxM.stride(1) == 1 and basis_LxM.stride(0) % 4 == 0 and
             basis_LxM.shape[0] <= 2048 and 4 * V + 4 * W * H <= 2 ** 31 and W * H < 2 ** 22 and D <= 65535 and
             coefs.shape[0] == B)
 
 
-def pca_warp(coefs, basis_LxM, mean, ids, img, *, using_scale=True):
+# moments the one-pass decode left behind for the similarity: (weakref warped, weakref target, versions, moments)
+_ncc_cache = None
+
+
+def cached_ncc_moments(x, y, rows):
+    """The (rows,5) fp64 moments of (x, y) if the one-pass decode just produced them for exactly these two tensor
+    objects (same objects, unmodified since) — else None.  Lets `NCCLoss(out["warped"], out["target"])` skip its pass
+    over the two volumes ("NCC moments in the warp epilogue")."""
+    c = _ncc_cache
+    if c is None:
+        return None
+    xr, yr, ver, m = c
+    if xr() is x and yr() is y and ver == (x._version, y._version) and m.shape[0] == rows:
+        return m
+    return None
+
+
+def pca_warp(coefs, basis_LxM, mean, ids, img, *, using_scale=True, d0=0, d1=None, target=None):
     """disp = coefs·basis + mean ; phi = disp + identity ; warped = Bilinear(img, phi) in ONE kernel:
     the displacement field is written once and never read back.  Returns (disp, phi, warped), bit-identical to
     `pca_reconstruct` followed by `warp`.  Batches above 8 run in chunks (the basis is re-read per chunk).
-    Replaces …Backproj.py:102 + :68-69 in inference."""
+    Replaces …Backproj.py:102 + :68-69 in inference.
+
+    Rows [d0,d1) (z-slab sharding): outputs are slabs; `basis_LxM`/`mean` are the full (L,3V)/(3V,) arrays or a rank's
+    compact (L,3·Dn·W·H)/(3·Dn·W·H,) slabs; ids[0] = the D-axis identity table of the slab's rows (Dn entries) or the
+    whole table.  `target` (B,1,Dn,W,H), single-channel images only: the five fp64 NCC moments per batch row are
+    accumulated in the kernel's epilogue and returned as a 4th value (also left for `cached_ncc_moments`)."""
+    global _ncc_cache
     coefs, mean, img = _dev(coefs, "coefs"), _dev(mean, "mean"), _dev(img, "img")
     if not basis_LxM.is_cuda or basis_LxM.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError("basis must be a float32 (or bfloat16-stored) GPU tensor")
@@ -523,24 +549,51 @@ def pca_warp(coefs, basis_LxM, mean, ids, img, *, using_scale=True):
     basis = basis_LxM
     if coefs.shape[1] != basis.shape[0] or mean.shape[0] != basis.shape[1]:
         raise ValueError("basis/mean shape mismatch")
-    if not pca_warp_supported(coefs, basis, img):
-        raise ValueError("pca_warp: unsupported shapes (use pca_reconstruct + warp)")
     B, C, D, W, H = img.shape
+    d1 = D if d1 is None else int(d1)
+    Dn = d1 - d0
+    if not pca_warp_supported(coefs, basis, img, d0, d1):
+        raise ValueError("pca_warp: unsupported shapes (use pca_reconstruct + warp)")
     L = basis.shape[0]
+    V, Vs = D * W * H, Dn * W * H
+    compact = basis.shape[1] == 3 * Vs and Dn != D
+    bcs = Vs if compact else V                       # columns between the three component thirds
+    col0 = 0 if compact else d0 * W * H              # column of (component 0, row d0)
+    esz = 2 if bf else 4
     i0, i1, i2 = (_dev(t, "id table") for t in ids)
-    disp = torch.empty((B, 3, D, W, H), dtype=torch.float32, device=img.device)
+    if i0.numel() == D and Dn != D:
+        i0 = i0[d0:d1].contiguous()
+    if i0.numel() != Dn or i1.numel() != W or i2.numel() != H:
+        raise ValueError("identity tables must have (Dn, W, H) entries")
+    disp = torch.empty((B, 3, Dn, W, H), dtype=torch.float32, device=img.device)
     phi = torch.empty_like(disp)
-    warped = torch.empty((B, C, D, W, H), dtype=torch.float32, device=img.device)
-    fn = _hip.lib().lr_pca_warp_bf16basis_f32 if bf else _hip.lib().lr_pca_warp_f32
-    V = D * W * H
+    warped = torch.empty((B, C, Dn, W, H), dtype=torch.float32, device=img.device)
+    moments = None
+    if target is not None:
+        if C != 1:
+            raise ValueError("pca_warp(target=…): single-channel images only")
+        target = _dev(target, "target")
+        if tuple(target.shape) != (B, 1, Dn, W, H):
+            raise ValueError(f"target must be {(B, 1, Dn, W, H)}, got {tuple(target.shape)}")
+        nblk = ((W * H // 4 + 255) // 256) * Dn
+        partial = torch.empty((min(B, 8), nblk, 5), dtype=torch.float64, device=img.device)
+        moments = torch.empty((B, 5), dtype=torch.float64, device=img.device)
     for lo in range(0, B, 8):
         hi = min(B, lo + 8)
-        nb = (2 if bf else 4) * L * 3 * V + 4 * 3 * V + (hi - lo) * 4 * V * (6 + 2 * C)
-        with _timed("pca_warp" + ("_bf16basis" if bf else ""), bytes=nb, samples=hi - lo):
-            _hip.check(fn(coefs[lo:hi].data_ptr(), basis.data_ptr(), mean.data_ptr(), img[lo:hi].data_ptr(), i0.data_ptr(),
-                          i1.data_ptr(), i2.data_ptr(), disp[lo:hi].data_ptr(), phi[lo:hi].data_ptr(),
-                          warped[lo:hi].data_ptr(), hi - lo, L, C, D, W, H, basis.stride(0),
-                          _hip.WARP_USING_SCALE if using_scale else 0, _stream()), "lr_pca_warp_f32")
+        nb = esz * L * 3 * Vs + 4 * 3 * Vs + (hi - lo) * 4 * Vs * (6 + 2 * C) + (4 * (hi - lo) * Vs if target is not None else 0)
+        name = "pca_warp" + ("_ncc" if target is not None else "") + ("_bf16basis" if bf else "")
+        with _timed(name, bytes=nb, samples=hi - lo):
+            _hip.check(_hip.lib().lr_pca_warp_slab_f32(
+                coefs[lo:hi].data_ptr(), basis.data_ptr() + col0 * esz, int(bf), mean.data_ptr() + col0 * 4,
+                img[lo:hi].data_ptr(), i0.data_ptr(), i1.data_ptr(), i2.data_ptr(), disp[lo:hi].data_ptr(),
+                phi[lo:hi].data_ptr(), warped[lo:hi].data_ptr(), hi - lo, L, C, D, W, H, d0, d1, basis.stride(0), bcs,
+                _hip.WARP_USING_SCALE if using_scale else 0,
+                None if target is None else target[lo:hi].data_ptr(), None if target is None else partial.data_ptr(),
+                None if target is None else moments[lo:hi].data_ptr(), _stream()), "lr_pca_warp_slab_f32")
+    if target is not None:
+        import weakref
+        _ncc_cache = (weakref.ref(warped), weakref.ref(target), (warped._version, target._version), moments)
+        return disp, phi, warped, moments
     return disp, phi, warped
 
 

@@ -96,33 +96,62 @@ def ncc_loss_sharded(x_slab, y_slab, n_total, group=None, variant=NCC_CONFIGURED
 # z-slab sharded forward of the whole model ("a8 convs: 1-voxel halo exchange per layer")
 # ======================================================================================================
 class DistComm:
-    """Communication of ONE local rank over torch.distributed (nccl = RCCL over xGMI, or gloo)."""
+    """Communication of ONE local rank over torch.distributed (nccl = RCCL over xGMI, or gloo).
+
+    Under gloo (CPU tests; several ranks sharing one GPU on a 1-GPU box) GPU tensors are staged through the host:
+    gloo has no GPU point-to-point or all-gather.  The measured configuration is nccl, one GPU per rank, where the
+    tensors go over xGMI as they are."""
 
     def __init__(self, group=None):
         self.group = group
         self.rank, self.world = world(group)
         self.ranks = [self.rank]
+        self.host_stage = self.world > 1 and dist.get_backend(group) == "gloo"
+
+    def _peer(self, group_rank):
+        """P2POp takes GLOBAL ranks: translate a rank of `self.group`."""
+        return group_rank if self.group is None else dist.get_global_rank(self.group, group_rank)
 
     def shift_up(self, planes):
         """planes[0] = this rank's top plane → returns [the plane of rank-1] ([None] on rank 0).
-        Neighbour point-to-point: on xGMI each pair has its own link, so all exchanges run concurrently."""
-        recv = torch.empty_like(planes[0]) if self.rank > 0 else None
-        reqs = []
+        Neighbour point-to-point: on xGMI each pair has its own link, so all exchanges run concurrently.  The send and
+        the receive of a rank go out as ONE batch (`batch_isend_irecv` = a grouped RCCL call): un-grouped isend/irecv
+        would lazily create one communicator per peer pair and serialise the two operations of an interior rank."""
+        if self.world == 1:
+            return [None]
+        src = planes[0].contiguous()
+        send = src.cpu() if (self.host_stage and src.is_cuda) else src
+        recv = torch.empty_like(send) if self.rank > 0 else None
+        ops_ = []
         if self.rank + 1 < self.world:
-            reqs.append(dist.isend(planes[0], self.rank + 1, group=self.group))
+            ops_.append(dist.P2POp(dist.isend, send, self._peer(self.rank + 1), group=self.group))
         if self.rank > 0:
-            reqs.append(dist.irecv(recv, self.rank - 1, group=self.group))
-        for r in reqs:
-            r.wait()
+            ops_.append(dist.P2POp(dist.irecv, recv, self._peer(self.rank - 1), group=self.group))
+        if ops_:
+            for r in dist.batch_isend_irecv(ops_):
+                r.wait()
+        if recv is not None and recv.device != src.device:
+            recv = recv.to(src.device)
         return [recv]
 
     def all_gather_cat(self, pieces, dim):
-        parts = [torch.empty_like(pieces[0]) for _ in range(self.world)]
-        dist.all_gather(parts, pieces[0].contiguous(), group=self.group)
-        return [torch.cat(parts, dim=dim)]
+        if self.world == 1:
+            return [pieces[0]]
+        src = pieces[0].contiguous()
+        mine = src.cpu() if (self.host_stage and src.is_cuda) else src
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine, group=self.group)
+        return [torch.cat(parts, dim=dim).to(src.device)]
 
     def all_reduce_sum(self, ts):
-        dist.all_reduce(ts[0], op=dist.ReduceOp.SUM, group=self.group)
+        if self.world == 1:
+            return ts
+        if self.host_stage and ts[0].is_cuda:
+            h = ts[0].cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            ts[0].copy_(h)
+        else:
+            dist.all_reduce(ts[0], op=dist.ReduceOp.SUM, group=self.group)
         return ts
 
 
@@ -199,7 +228,6 @@ class SlabShardedRegistration:
         # ---- block 0 (stride 1): both halo planes come from replicated data → no communication
         for inp, (d0, d1) in zip(inputs, bounds):
             moving, proj = inp["source"], inp["target_proj"]
-            net._ensure_pca(moving.device)
             if net._poses is None:
                 p = inp["target_poses"]
                 p = p.detach().cpu().numpy() if isinstance(p, torch.Tensor) else p
@@ -267,17 +295,29 @@ class SlabShardedRegistration:
         for inp, f, (d0, d1) in zip(inputs, feats, bounds):
             coefs = net.encoders[6](f.contiguous())
             moving = inp["source"]
-            disp = pca_reconstruct_slab(coefs, net.pca_vectors_LxM, net.pca_mean, (D, W, H), d0, d1)
-            phi, warped = warp_slab(moving, disp.contiguous(), (net._id0, net._id1, net._id2), d0, d1,
-                                    seg=inp.get("source_label"))
-            out = {"warped": warped, "phi": phi, "params": disp, "pca_coefs": coefs}
+            tgt = None
             if "target" in inp:
                 tgt = inp["target"][:, :, d0:d1].contiguous()
                 if "source_label" in inp and "target_label" in inp:   # (target+1)*target_seg-1 (…Backproj.py:57-58)
                     tgt = ops.mask_compose(tgt, inp["target_label"][:, :, d0:d1].contiguous())
+            # the rank's COMPACT column slab of the basis (L, 3·Dn·W·H): 11.3 GB → 1.4 GB per GPU at 8 ranks (C3)
+            basis_s, mean_s = net.pca_slab(d0, d1, moving.device)
+            ids = (net._id0[d0:d1].contiguous(), net._id1, net._id2)
+            mom = None
+            if "source_label" not in inp and ops.pca_warp_supported(coefs, basis_s, moving, d0, d1):
+                # ONE launch: PCA reconstruction of the slab + identity + warp (+ the NCC moments of the slab)
+                if tgt is not None and moving.shape[1] == 1:
+                    disp, phi, warped, mom = ops.pca_warp(coefs, basis_s, mean_s, ids, moving, d0=d0, d1=d1, target=tgt)
+                else:
+                    disp, phi, warped = ops.pca_warp(coefs, basis_s, mean_s, ids, moving, d0=d0, d1=d1)
+            else:
+                disp = pca_reconstruct_slab(coefs, basis_s, mean_s, (D, W, H), d0, d1)
+                phi, warped = ops.warp(moving, disp.contiguous(), ids, inp.get("source_label"), d0=d0, d1=d1)
+            out = {"warped": warped, "phi": phi, "params": disp, "pca_coefs": coefs}
+            if tgt is not None:
                 out["target"] = tgt
                 rows = warped.shape[0] if self.variant == NCC_CONFIGURED else warped.shape[0] * warped.shape[1]
-                moms.append(ops.ncc_moments(warped, tgt, rows))
+                moms.append(mom if (mom is not None and mom.shape[0] == rows) else ops.ncc_moments(warped, tgt, rows))
             outs.append(out)
         if moms:
             moms = comm.all_reduce_sum(moms)

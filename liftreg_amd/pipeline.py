@@ -43,9 +43,9 @@ class TwoStreamRegistrar:
         coefs.record_stream(self.dec)
         with torch.cuda.stream(self.dec):
             self.dec.wait_event(done)
-            disp, phi, warped = net.decode(moving, coefs, seg)
             from . import ops
             target_cp = ops.mask_compose(target, batch["target_label"]) if seg is not None else target
+            disp, phi, warped = net.decode(moving, coefs, seg, target=target_cp if self.sim is not None else None)
             loss = self.sim(warped, target_cp) if self.sim is not None else None
         out = {"warped": warped, "phi": phi, "params": disp, "target": target_cp, "pca_coefs": coefs,
                "target_proj": batch["target_proj"], "warped_proj": batch["target_proj"]}

@@ -102,3 +102,29 @@ def test_c3_one_registration_of_the_timed_workload_vs_cpu_forward(dev):
     assert par["max_rel_coefs"] <= 1e-4, par
     assert par["max_abs_warped"] <= 1e-3, par
     assert abs(par["ncc_gpu"] - float(loss)) < 1e-6 and par["ncc_abs"] <= 1e-5, par
+
+
+def test_c3_ncc_moments_in_the_decode_epilogue(decode_case):
+    """the one-pass decode with a target accumulates the similarity's five fp64 moments while `warped` is
+    still in registers.  At the headline size: params/phi/warped keep their bits, the moments equal the separate
+    one-pass NCC kernel's (fp64 sums in another order: ≤1e-12 relative), and NCCLoss picks them up (no second pass)."""
+    from liftreg_amd import ops
+    from liftreg_amd.layers.losses import NCCLoss
+    basis, mean, img, coefs, ids = decode_case
+    g = torch.Generator(device=img.device)
+    g.manual_seed(5)
+    target = torch.rand(img.shape, generator=g, device=img.device) * 2 - 1
+    d0, p0, w0 = ops.pca_warp(coefs, basis, mean, ids, img)
+    d1, p1, w1, m = ops.pca_warp(coefs, basis, mean, ids, img, target=target)
+    assert torch.equal(d0, d1) and torch.equal(p0, p1) and torch.equal(w0, w1)
+    want = ops.ncc_moments(w0, target, B)
+    rel = ((m - want).abs() / want.abs().clamp_min(1e-300)).max()
+    assert float(rel) < 1e-12, float(rel)
+    assert ops.cached_ncc_moments(w1, target, B) is m and ops.cached_ncc_moments(w0, target, B) is None
+    with ops.kernel_timer() as kt:
+        fused = NCCLoss(check_nan=False)(w1, target)
+        names = set(kt.summary())
+    assert "ncc_moments" not in names                      # the cached moments were used
+    assert abs(float(fused) - float(NCCLoss(check_nan=False)(w0, target))) < 1e-7
+    w1.add_(0.0)                                           # any in-place touch invalidates the cache (version counter)
+    assert ops.cached_ncc_moments(w1, target, B) is None

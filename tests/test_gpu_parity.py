@@ -551,3 +551,41 @@ def test_register_folder_tool(dev, tmp_path):
     import json
     rep = json.load(open(out / "register_folder.json"))
     assert [r["id"] for r in rep] == ids and all(0.0 <= r["dice"] <= 1.0 for r in rep)
+
+
+def test_pca_warp_slab_and_ncc_epilogue(ops, dev):
+    """lr_pca_warp_slab_f32: rows [d0,d1) from a view into the full basis and from a rank's compact column slab give the
+    rows of the unsharded decode bit for bit; the epilogue's NCC moments of the slabs add up to the whole volume's
+    (≤1e-12 relative, fp64) — ragged planes (W·H/4 not a multiple of the block), batches of 1..9, both basis dtypes."""
+    from liftreg_amd.utils import net_utils as N
+    rs = np.random.RandomState(33)
+    for shape, B, Lat in (((8, 6, 12), 3, 5), ((6, 5, 20), 9, 4), ((5, 36, 32), 1, 3), ((12, 8, 8), 5, 6)):
+        D, W, H = shape
+        V = int(np.prod(shape))
+        img = T(rs.uniform(-1, 1, (B, 1) + shape).astype(np.float32), dev)
+        tgt = T(rs.uniform(-1, 1, (B, 1) + shape).astype(np.float32), dev)
+        basis32 = T(rs.normal(0, 0.2, (Lat, 3 * V)).astype(np.float32), dev)
+        mean = T(rs.normal(0, 0.02, 3 * V).astype(np.float32), dev)
+        coefs = T(rs.normal(0, 1, (B, Lat)).astype(np.float32), dev)
+        ids = [T(t, dev) for t in N.identity_axis_tables(shape)]
+        for basis in (basis32, basis32.to(torch.bfloat16)):
+            d_ref, p_ref, w_ref = ops.pca_warp(coefs, basis, mean, ids, img)
+            d_f, p_f, w_f, m_full = ops.pca_warp(coefs, basis, mean, ids, img, target=tgt)
+            assert torch.equal(d_f, d_ref) and torch.equal(p_f, p_ref) and torch.equal(w_f, w_ref)
+            m_want = ops.ncc_moments(w_ref, tgt, B)
+            np.testing.assert_allclose(m_full.cpu().numpy(), m_want.cpu().numpy(), rtol=1e-12, atol=1e-300)
+            cuts = [0, D // 3, D // 3 + 1, D]
+            m_sum = torch.zeros_like(m_full)
+            for d0, d1 in zip(cuts[:-1], cuts[1:]):
+                if d1 == d0:
+                    continue
+                plane = W * H
+                cols = torch.cat([torch.arange((c * D + d0) * plane, (c * D + d1) * plane, device=dev) for c in range(3)])
+                compact, cmean = basis[:, cols].contiguous(), mean[cols].contiguous()
+                ts = tgt[:, :, d0:d1].contiguous()
+                for bs, ms in ((basis, mean), (compact, cmean)):
+                    d_s, p_s, w_s, m_s = ops.pca_warp(coefs, bs, ms, ids, img, d0=d0, d1=d1, target=ts)
+                    assert torch.equal(d_s, d_ref[:, :, d0:d1]) and torch.equal(p_s, p_ref[:, :, d0:d1])
+                    assert torch.equal(w_s, w_ref[:, :, d0:d1]), (shape, d0, d1, bs.shape)
+                m_sum += m_s
+            np.testing.assert_allclose(m_sum.cpu().numpy(), m_want.cpu().numpy(), rtol=1e-12, atol=1e-300)

@@ -89,6 +89,9 @@ class OracleOps:
             return out
         return res
 
+    def pca_warp_supported(self, *a, **k):
+        return False           # the shim has no one-pass decode: the sharded forward takes its two-op path
+
     def pca_reconstruct(self, coefs, basis, mean):
         return torch.from_numpy(self.co.pca_reconstruct(coefs.numpy(), basis.numpy(), mean.numpy()))
 
