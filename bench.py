@@ -204,6 +204,8 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="control-path self-test WITHOUT a GPU (CPU tests): rendezvous over gloo, fences, max-over-ranks "
                          "timing and the single JSON line with a sleep as the step; the line says dry_run and carries no value")
+    ap.add_argument("--no-fuse-ncc", action="store_true", help="A/B aid: the similarity's moments by their own kernel instead of "
+                                                               "the decode's epilogue (opt key fuse_ncc)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from one captured HIP graph (launch-bound small configs c1/c2); the "
                          "per-kernel table then comes from one extra eager step outside the timed region")
@@ -240,7 +242,8 @@ def main():
     torch.manual_seed(2021)
     n, P, B, L = cfg["n"], cfg["P"], cfg["B"], cfg["L"]
     net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:2021",
-                            "conv_dtype": args.conv_dtype, "pca_dtype": args.pca_dtype}).to(dev).eval()
+                            "conv_dtype": args.conv_dtype, "pca_dtype": args.pca_dtype,
+                            "fuse_ncc": not args.no_fuse_ncc}).to(dev).eval()
     slab = args.shard == "slab"
     inp = synth_inputs(cfg, dev, seed=2021 if slab else 2021 + rank)   # slab: every rank holds the SAME batch
     sim = NCCLoss(check_nan=False)

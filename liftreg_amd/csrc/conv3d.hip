@@ -179,9 +179,15 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
                                                             const float* __restrict__ wp,
                                                             const float* __restrict__ bias,
                                                             float* __restrict__ out, ConvDims d,
-                                                            int out_layout, float slope, int vec4,
-                                                            int nitems, int npass, int dbg,
+                                                            int out_layout, float slope, int vec4_rt,
+                                                            int nitems, int npass, int dbg_rt,
                                                             const float* __restrict__ in0 /* or null: see below */) {
+#ifdef LR_C0_STATIC   /* experiment: compile-time staging mode and no ablation switches (clean control flow) */
+  constexpr int vec4 = 1, dbg = 0;
+  (void)vec4_rt; (void)dbg_rt;
+#else
+  const int vec4 = vec4_rt, dbg = dbg_rt;
+#endif
   // in0 != null ("split input", one pass, 16-byte staging only): channel 0 is read from in0 (B,1,D,W,H) and channels
   // 1.. from `in` (B,Cin-1,D,W,H) — the encoder's cat([moving, backprojected views]) without the copy of `moving`.
   using G = PlanarGeom<S, CC>;
@@ -437,6 +443,9 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
     }
     }
     LR_STAMP(0);  // sweep
+#ifdef LR_C0_PRIO
+    __builtin_amdgcn_s_setprio(3);  // experiment: hurry through the non-matrix phases
+#endif
     __syncthreads();  // every wave is done reading the brick
     LR_STAMP(1);  // barrier A
     if (!(dbg & 2)) stage(min(u + 1, my_units - 1));
@@ -464,6 +473,9 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
     __syncthreads();  // next brick visible in LDS
     LR_STAMP(5);  // barrier B
     if (vec4 && !(dbg & 2)) prefetch(unit_item(min(u + 2, my_units - 1)));
+#ifdef LR_C0_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     LR_STAMP(6);  // prefetch issue
   }
 #ifdef LR_CONV0_STAMPS
