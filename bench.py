@@ -204,6 +204,8 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="control-path self-test WITHOUT a GPU (CPU tests): rendezvous over gloo, fences, max-over-ranks "
                          "timing and the single JSON line with a sleep as the step; the line says dry_run and carries no value")
+    ap.add_argument("--fuse-bp", action="store_true", help="A/B aid: backprojection computed inside block 0 (opt key "
+                                                           "fuse_backproject; measured slower at C3, off by default)")
     ap.add_argument("--no-fuse-ncc", action="store_true", help="A/B aid: the similarity's moments by their own kernel instead of "
                                                                "the decode's epilogue (opt key fuse_ncc)")
     ap.add_argument("--graph", action="store_true",
@@ -243,7 +245,7 @@ def main():
     n, P, B, L = cfg["n"], cfg["P"], cfg["B"], cfg["L"]
     net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:2021",
                             "conv_dtype": args.conv_dtype, "pca_dtype": args.pca_dtype,
-                            "fuse_ncc": not args.no_fuse_ncc}).to(dev).eval()
+                            "fuse_ncc": not args.no_fuse_ncc, "fuse_backproject": args.fuse_bp}).to(dev).eval()
     slab = args.shard == "slab"
     inp = synth_inputs(cfg, dev, seed=2021 if slab else 2021 + rank)   # slab: every rank holds the SAME batch
     sim = NCCLoss(check_nan=False)
@@ -308,12 +310,29 @@ def main():
     elapsed = float(t.item())
     value = (B if slab else world * B) * args.steps / elapsed
 
+    # the kernel BASELINE.json's metric names ("backproj HBM GB/s"): when the step computes the backprojection inside
+    # block 0's staging (f1) no stand-alone backprojection runs in the timed region — time lr_backproject_f32 on the
+    # same views right after it (every rank: the table below is rank 0's)
+    bp_standalone = "backproject" not in ksum
+    if bp_standalone:
+        from liftreg_amd.utils.sdct_projection_utils import scan_poses as _sp
+        _p32 = _sp(30, P, n).astype(np.float32)
+        with torch.no_grad():
+            ops.backproject(inp["target_proj"], _p32, (n, n, n))
+            torch.cuda.synchronize()
+            with ops.kernel_timer() as kt_bp:
+                for _ in range(5):
+                    ops.backproject(inp["target_proj"], _p32, (n, n, n))
+            bp_rec = kt_bp.summary()["backproject"]
+        ksum = dict(ksum)
+        ksum["backproject"] = {"ms": bp_rec["ms"], "info": bp_rec["info"], "outside_step": True}
+
     # per-kernel roofline numbers from the live HIP-event timings
     kernels = {}
     for name, rec in ksum.items():
         ms = float(np.mean(rec["ms"]))
         info = rec["info"]
-        launches = len(rec["ms"]) / args.steps
+        launches = 0.0 if rec.get("outside_step") else len(rec["ms"]) / args.steps
         k = {"avg_ms": ms, "launches_per_step": launches}
         if "flops" in info and info.get("bound", "mfma") == "mfma":
             k.update(bound="mfma", achieved=info["flops"] / (ms * 1e-3) / 1e12,
@@ -395,6 +414,9 @@ def main():
         "roofline": roof(dominant),
         "roofline_backproject": roof("backproject"),
         "backproj_hbm_GBps": kernels["backproject"]["achieved"],
+        "backproject_note": ("stand-alone lr_backproject_f32 timed right after the step (n = 0 launches per step): the step "
+                             "computes the backprojection inside block 0's staging, SURVEY 8 f1") if bp_standalone else
+                            "lr_backproject_f32 as launched inside the timed step",
         "kernels": {k: {"ms": round(v["avg_ms"], 4), "n": v["launches_per_step"], "frac": round(v["frac"], 4),
                         "bound": v["bound"], "traffic": v["traffic"]} for k, v in kernels.items()},
         "traffic_stale": stale,

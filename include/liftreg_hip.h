@@ -306,6 +306,17 @@ int lr_conv3d_first_split_f32(const float* in0, const float* in_rest, const floa
                               float* out, int B, int Cin, int Cout, int D, int W, int H, int out_layout,
                               float negative_slope, void* stream);
 
+/* f1 ("backproject -> conv0: never write the P*V volume"): the same first block with the backprojection
+ * computed INSIDE its staging.  Channel 0 = in0 (B,1,D,W,H), channels 1..P = the backprojection of proj (B,P,Pw,Ph)
+ * for `poses` (host, P x 3 fp32, ONE geometry for the batch, …Backproj.py:85-87) — sample for sample the arithmetic
+ * of lr_backproject_f32 (sdct_projection_utils.py:227-250 + F.grid_sample 2-D, …Backproj.py:89-93), gathered from the
+ * views (L2-resident).  Output bits = lr_backproject_f32 followed by lr_conv3d_first_split_f32; the (B,P,D,W,H)
+ * feature volume is never written or read.  P in {1,2}, H % 4 == 0, in0 16-byte aligned, Cout = 16 — otherwise
+ * LR_EUNSUPPORTED and the caller runs the two kernels. */
+int lr_conv3d_first_fused_bp_f32(const float* in0, const float* proj, const float* poses, const float* packed_w,
+                                 const float* bias, float* out, int B, int P, int Pw, int Ph, int Cout, int D, int W, int H,
+                                 int out_layout, float negative_slope, void* stream);
+
 /* ---- f1: PCA reconstruction + identity + trilinear warp in ONE pass (the model's decode half in inference).
  * Replaces the sequence …Backproj.py:102 (F.linear with the PCA basis) → :68 (disp + id) → :69 (Bilinear warp) and
  * writes all three model outputs: disp = `params` (B,3,D,W,H), phi (B,3,D,W,H), warped (B,C,D,W,H).  Same arithmetic

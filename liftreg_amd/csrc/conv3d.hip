@@ -828,10 +828,17 @@ extern "C" int lr_conv3d_pack_weights_f32(const float* weight, float* packed, in
   return lr_launch_status();
 }
 
+struct FusedBp {  // host-side description of the views for the fused first block (conv0_pc.hip)
+  const float* proj;
+  const float* poses;  // host, P x 3
+  int P, Pw, Ph;
+};
+
 static int conv_impl(const float* in, const float* in0, const float* packed_w, const float* bias,
                      float* out, int B, int Cin, int Cout, int D, int W, int H,
                      int stride, int in_layout, int out_layout,
-                     float negative_slope, void* stream) {
+                     float negative_slope, void* stream, const FusedBp* bpa = nullptr) {
+  if (bpa) in = in0;   // no channel-1.. tensor exists: the staging never dereferences `in` for them
   if (!in || !packed_w || !out) return LR_ENULL;
   if (B < 1 || Cin < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
   if (stride != 1 && stride != 2) return LR_EUNSUPPORTED;
@@ -895,6 +902,26 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
 #define LR_PL(NTV, SV, CCV, SGL, LDSV, V4)                                                                   \
   hipLaunchKernelGGL((conv3d_planar_kernel<NTV, SV, CCV, SGL>), grid, block, LDSV, st, in, packed_w, bias, out, d, \
                      out_layout, negative_slope, V4, ni, npass, dbg, in0)
+    // conv0_pc.hip: the same block as a producer/consumer kernel with a double-buffered brick.  It carries the fused
+    // backprojection (f1); for plain inputs it measured equal to the single-buffer kernel below (3.31-3.34 vs 3.29-3.30 ms
+    // at C3, same bits), which therefore stays the default — LIFTREG_CONV0_PC=1 selects it (A/B aid).
+    const bool pc_on = bpa || (getenv("LIFTREG_CONV0_PC") && atoi(getenv("LIFTREG_CONV0_PC")) != 0);
+    if (pc_on && stride == 1 && NT == 1 && single && vec4 &&
+        (out_layout == LR_LAYOUT_NDHWC || out_layout == LR_LAYOUT_NDHWC_HPS)) {
+      const int64_t V = (int64_t)D * W * H;
+      int rc;
+      if (bpa)
+        rc = lr_internal_conv0_pc(in0, V, nullptr, 0, packed_w, bias, out, B, Cin, D, W, H, out_layout, negative_slope, bpa->proj,
+                                  bpa->poses, bpa->P, bpa->Pw, bpa->Ph, st);
+      else if (in0)
+        rc = lr_internal_conv0_pc(in0, V, in, (int64_t)(Cin - 1) * V, packed_w, bias, out, B, Cin, D, W, H, out_layout,
+                                  negative_slope, nullptr, nullptr, 0, 0, 0, st);
+      else
+        rc = lr_internal_conv0_pc(in, (int64_t)Cin * V, in + V, (int64_t)Cin * V, packed_w, bias, out, B, Cin, D, W, H, out_layout,
+                                  negative_slope, nullptr, nullptr, 0, 0, 0, st);
+      if (rc != LR_EUNSUPPORTED || bpa) return rc;
+    }
+    if (bpa) return LR_EUNSUPPORTED;
     if (stride == 1 && NT == 1 && single && out_layout == LR_LAYOUT_NDHWC_HPS) {        // the model's first block
       hipLaunchKernelGGL((conv3d_planar_kernel<1, 1, 3, true, LR_LAYOUT_NDHWC_HPS>), grid, block, lds1, st, in, packed_w, bias,
                          out, d, out_layout, negative_slope, vec4, ni, npass, dbg, in0);
@@ -936,4 +963,20 @@ extern "C" int lr_conv3d_first_split_f32(const float* in0, const float* in_rest,
   if (!in0) return LR_ENULL;
   return conv_impl(in_rest, in0, packed_w, bias, out, B, Cin, Cout, D, W, H, 1, LR_LAYOUT_NCDHW, out_layout,
                    negative_slope, stream);
+}
+
+// f1: the encoder's first block with the backprojection computed inside its staging — the
+// (B,P,D,W,H) feature volume of …Backproj.py:85-93 is never written: channel 0 = in0 (the moving image), channels
+// 1..P = the backprojection of `proj` (B,P,Pw,Ph) for the emitter poses (host, P x 3 floats), sample for sample the
+// arithmetic of lr_backproject_f32.  Same bits as lr_backproject_f32 + lr_conv3d_first_split_f32.  P in {1,2},
+// H % 4 == 0, 16-byte aligned in0; otherwise LR_EUNSUPPORTED (the caller runs the two kernels).
+extern "C" int lr_conv3d_first_fused_bp_f32(const float* in0, const float* proj, const float* poses, const float* packed_w,
+                                            const float* bias, float* out, int B, int P, int Pw, int Ph, int Cout, int D,
+                                            int W, int H, int out_layout, float negative_slope, void* stream) {
+  if (!in0 || !proj || !poses) return LR_ENULL;
+  if (P < 1 || P > 2 || Pw < 2 || Ph < 2 || (int64_t)Pw * Ph * 4 >= 0x7fffffffLL || Pw >= (1 << 23) / Ph) return LR_EUNSUPPORTED;
+  FusedBp a;
+  a.proj = proj; a.poses = poses; a.P = P; a.Pw = Pw; a.Ph = Ph;
+  return conv_impl(nullptr, in0, packed_w, bias, out, B, P + 1, Cout, D, W, H, 1, LR_LAYOUT_NCDHW, out_layout, negative_slope,
+                   stream, &a);
 }

@@ -132,6 +132,13 @@ class model(nn.Module):
         # optional (non-reference) key "fuse_ncc": in inference the one-pass decode also accumulates the similarity's
         # moments against `target` (they cost one extra read of the target there instead of a pass over both volumes)
         self.fuse_ncc = bool(_opt(opt, "fuse_ncc", True))
+        # optional (non-reference) key "fuse_backproject" (default False): in fp32 inference with P <= 2 views the
+        # backprojection is computed inside the first conv block (conv0_pc.hip producers; the (B,P,D,W,H) feature volume
+        # is never materialised; same bits).  Off by default because it MEASURED SLOWER at C3: the block is bound by the
+        # matrix pipe, its 4x4x64 bricks recompute every sample 2.5x (window halo), and the vector-ALU work of those
+        # samples takes issue slots from the MFMAs — 4.05 ms fused vs 3.31 + 0.27 ms as two kernels.
+        # Worth it where HBM capacity/traffic matters more than the 4 % (the volume is 1.08 GB per batch of 8).
+        self.fuse_backproject = bool(_opt(opt, "fuse_backproject", False))
         self._poses = None         # geometry of the first batch's element 0, cached like :85-87
         self._packed = {}          # conv weights in MFMA operand order, keyed by parameter version
         self._pca_slabs = {}       # compact per-rank column slabs of the basis (pca_slab)
@@ -266,8 +273,19 @@ class model(nn.Module):
         if self.conv_dtype != "bf16" and not needs_grad and P <= 2:
             # inference, fp32: the first block reads `moving` and the backprojected views from their own buffers —
             # cat([moving, target_volume], dim=1) (:95-98) is never materialised (no copy of `moving`)
-            tv = torch.empty((B, P, D, W, H), dtype=torch.float32, device=moving.device)
             mv = moving if moving.is_contiguous() else moving.contiguous()
+            blk = self.encoders[0]
+            if self.fuse_backproject and blk.conv.out_channels == 16 and blk.out_layout != ops.LAYOUT_NCDHW and \
+                    ops.conv3d_first_fused_bp_supported(mv, target_proj):
+                # f1: the backprojection is computed inside the first block's staging — target_volume (:89-93) is
+                # never written or read
+                x = ops.conv3d_first_fused_bp(mv, target_proj, self._poses, blk.conv.weight, blk.conv.bias,
+                                              out_layout=blk.out_layout, negative_slope=blk._slope,
+                                              packed=self._packed_weight(0))
+                for i in range(1, 6):
+                    x = self.encoders[i](x, packed=self._packed_weight(i))
+                return self.encoders[6](x)
+            tv = torch.empty((B, P, D, W, H), dtype=torch.float32, device=moving.device)
             if ops.conv3d_first_split_supported(mv, tv):
                 ops.backproject(target_proj, self._poses, (D, W, H), out=tv, out_batch_stride=P * V)
                 blk = self.encoders[0]

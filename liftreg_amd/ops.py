@@ -320,6 +320,41 @@ def conv3d_first_split(x0, rest, weight, bias, *, out_layout=LAYOUT_NCDHW, negat
     return y
 
 
+def conv3d_first_fused_bp_supported(x0, proj):
+    """True when `conv3d_first_fused_bp` can take these tensors (else: backproject + conv3d_first_split)."""
+    return (x0.dim() == 5 and proj.dim() == 4 and x0.shape[1] == 1 and proj.shape[1] in (1, 2) and x0.shape[4] % 4 == 0 and
+            x0.shape[0] == proj.shape[0] and x0.is_contiguous() and x0.data_ptr() % 16 == 0 and proj.shape[2] >= 2 and
+            proj.shape[3] >= 2 and x0.shape[2] * x0.shape[3] * x0.shape[4] * 4 * 3 < 2 ** 31 - 2 ** 26)
+
+
+def conv3d_first_fused_bp(x0, proj, poses, weight, bias, *, out_layout=LAYOUT_NCDHW, negative_slope=0.2, packed=None, out=None):
+    """The encoder's first block with the backprojection computed inside its staging: x0 (B,1,D,W,H) =
+    the moving image, proj (B,P,Pw,Ph) = the views, poses (P,3) = ONE emitter geometry.  The (B,P,D,W,H) feature volume
+    of …Backproj.py:85-98 is never written; output bits = backproject + conv3d_first_split."""
+    x0, proj = _dev(x0, "x0"), _dev(proj, "proj")
+    if not conv3d_first_fused_bp_supported(x0, proj):
+        raise ValueError("conv3d_first_fused_bp: unsupported shapes (use backproject + conv3d_first_split)")
+    B, _, D, W, H = x0.shape
+    P, Pw, Ph = proj.shape[1], proj.shape[2], proj.shape[3]
+    poses = _host_f32(poses, (3,), "poses").reshape(-1, 3)
+    if poses.shape[0] != P:
+        raise ValueError(f"poses has {poses.shape[0]} views, proj has {P}")
+    Cin, Cout = P + 1, weight.shape[0]
+    if weight.shape[1] != Cin:
+        raise ValueError(f"weight expects Cin={weight.shape[1]}, inputs have {Cin}")
+    if packed is None:
+        packed = conv3d_pack_weights(weight, LAYOUT_NCDHW)
+    b = None if bias is None else _dev(bias.detach(), "bias")
+    shape = (B, Cout, D, W, H) if out_layout == LAYOUT_NCDHW else (B, D, W, H, Cout)
+    y = _conv_out(out, shape, torch.float32, x0.device)
+    with _timed(f"conv3d_bp_c{Cin}x{Cout}_s1_{D}", flops=2.0 * 27 * Cin * Cout * B * D * W * H,
+                bytes=4 * (x0.numel() + proj.numel()) + 4 * y.numel(), samples=B):
+        _hip.check(_hip.lib().lr_conv3d_first_fused_bp_f32(x0.data_ptr(), proj.data_ptr(), poses.ctypes.data, packed.data_ptr(),
+                                                           _ptr(b), y.data_ptr(), B, P, Pw, Ph, Cout, D, W, H, out_layout,
+                                                           float(negative_slope), _stream()), "lr_conv3d_first_fused_bp_f32")
+    return y
+
+
 def conv3d_pack_weights_bf16(weight):
     """(Cout,Cin,3,3,3) fp32 parameter → bf16 MFMA operand order for lr_conv3d_k3_lrelu_bf16 (uint8 buffer)."""
     weight = _dev(weight.detach(), "weight")

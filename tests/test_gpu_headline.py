@@ -128,3 +128,21 @@ def test_c3_ncc_moments_in_the_decode_epilogue(decode_case):
     assert abs(float(fused) - float(NCCLoss(check_nan=False)(w0, target))) < 1e-7
     w1.add_(0.0)                                           # any in-place touch invalidates the cache (version counter)
     assert ops.cached_ncc_moments(w1, target, B) is None
+
+
+def test_c3_first_block_with_fused_backprojection_every_bit(dev):
+    """The headline size: block 0 with the backprojection computed in its staging == backproject + block 0, all
+    8·256³·16 outputs, on bench.py's own views and moving volumes."""
+    import bench
+    from liftreg_amd import ops
+    from liftreg_amd.utils.sdct_projection_utils import scan_poses
+    inp = bench.synth_inputs(bench.CONFIGS["c3"], dev, seed=2021)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    w = torch.randn((16, P + 1, 3, 3, 3), generator=g, device=dev) / 9
+    b = torch.randn((16,), generator=g, device=dev) * 0.1
+    poses = scan_poses(30, P, N).astype(np.float32)
+    tv = ops.backproject(inp["target_proj"], poses, (N, N, N))
+    want = ops.conv3d_first_split(inp["source"], tv, w, b, out_layout=ops.LAYOUT_NDHWC_HPS)
+    got = ops.conv3d_first_fused_bp(inp["source"], inp["target_proj"], poses, w, b, out_layout=ops.LAYOUT_NDHWC_HPS)
+    assert torch.equal(got, want), float((got - want).abs().max())

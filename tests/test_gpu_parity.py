@@ -589,3 +589,32 @@ def test_pca_warp_slab_and_ncc_epilogue(ops, dev):
                     assert torch.equal(w_s, w_ref[:, :, d0:d1]), (shape, d0, d1, bs.shape)
                 m_sum += m_s
             np.testing.assert_allclose(m_sum.cpu().numpy(), m_want.cpu().numpy(), rtol=1e-12, atol=1e-300)
+
+
+def test_first_block_with_fused_backprojection_equals_two_kernels(ops, dev):
+    """lr_conv3d_first_fused_bp_f32 (backprojection computed inside block 0's staging; the (B,P,D,W,H)
+    feature volume of …Backproj.py:89-93 never materialised) gives the bits of lr_backproject_f32 followed by
+    lr_conv3d_first_split_f32 — detectors smaller / larger than the volume (shadows falling off every edge), oblique
+    emitters, one and two views, ragged bricks, both channels-last output layouts."""
+    rs = np.random.RandomState(41)
+    cases = [((8, 8, 64), (8, 64), 2, 2), ((10, 6, 68), (14, 40), 2, 1), ((5, 9, 132), (6, 200), 1, 3),
+             ((12, 12, 16), (30, 30), 2, 2), ((64, 64, 64), (64, 64), 2, 1)]
+    for shape, pshape, P, B in cases:
+        D, W, H = shape
+        moving = T(rs.uniform(-1, 1, (B, 1) + shape).astype(np.float32), dev)
+        proj = T(rs.uniform(-1, 1, (B, P) + pshape).astype(np.float32), dev)
+        for pose_kind in ("scan", "oblique"):
+            if pose_kind == "scan":
+                poses = np.stack([np.tan(np.linspace(-15, 15, P) / 180. * np.pi) * 3., np.full(P, 3.5),
+                                  np.linspace(-0.2, 0.2, P)], 1).astype(np.float32) * W
+            else:
+                poses = (np.array([[1.7, 1.3, -0.9], [-2.2, 1.15, 1.4]], np.float32)[:P] * W)
+            w = T(rs.normal(0, 0.2, (16, P + 1, 3, 3, 3)).astype(np.float32), dev)
+            b = T(rs.normal(0, 0.1, 16).astype(np.float32), dev)
+            tv = ops.backproject(proj, poses, shape)
+            for lay in (ops.LAYOUT_NDHWC_HPS, ops.LAYOUT_NDHWC):
+                assert ops.conv3d_first_fused_bp_supported(moving, proj)
+                want = ops.conv3d_first_split(moving, tv, w, b, out_layout=lay)
+                got = ops.conv3d_first_fused_bp(moving, proj, poses, w, b, out_layout=lay)
+                assert torch.equal(got, want), (shape, pshape, P, pose_kind, lay, float((got - want).abs().max()))
+    assert not ops.conv3d_first_fused_bp_supported(T(np.zeros((1, 1, 4, 4, 6), np.float32), dev), proj[:1])   # H % 4
