@@ -340,7 +340,7 @@ int lr_pca_warp_bf16basis_f32(const float* coefs, const void* basis_bf16, const 
  *    identity table from row d0 on.  basis_is_bf16: the basis is stored as bfloat16 (ldb and stride in elements).
  *  - target != NULL (C == 1): (B,1,Dn,W,H) target slab; the five fp64 raw moments of (warped, target) per batch row
  *    (layers/losses.py:18-29, the sums lr_ncc_moments_f32 produces) are accumulated while `warped` is still in
- *    registers: ncc_partial = B * gridblocks * 5 doubles of scratch (gridblocks = ceil(W*H/1024) * Dn),
+ *    registers: ncc_partial = B * 4 * gridblocks * 5 doubles of scratch (gridblocks = ceil(W*H/1024) * Dn, one partial per wave),
  *    ncc_moments = (B,5) doubles.  Slab moments add (all-reduce), lr_ncc_loss_from_moments turns them into the loss.
  * Same bits as lr_pca_warp_f32 for params / phi / warped. */
 int lr_pca_warp_slab_f32(const float* coefs, const void* basis, int basis_is_bf16, const float* mean, const float* img,

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void warp_tri_fast_kernel(
 // whole (taps cross slabs).  id0 = the D-axis identity table from row d0 on.
 // NCC (f1, "NCC moments in the warp epilogue"): with a target slab (B,1,Dn,W,H) the five fp64 raw moments of
 // (warped, target) per batch row are reduced here — the similarity never re-reads `warped` (layers/losses.py:18-29
-// made ~8 passes, ncc_moments_kernel one): per-block partials [b][block][5], fixed order, no atomics; the caller's
+// made ~8 passes, ncc_moments_kernel one): per-wave partials [b][4*block+wave][5], fixed order, no atomics; the caller's
 // ncc_reduce pass (ncc.hip) sums the blocks.  C == 1 only.
 template <bool BF, bool SCALE, int BT /* batch rows per thread: 8, or 4 for small batches (half the accumulators) */, bool NCC>
 __global__ __launch_bounds__(256) void pca_warp_kernel(const float* __restrict__ coefs, const float* __restrict__ basis,
@@ -484,20 +484,17 @@ __global__ __launch_bounds__(256) void pca_warp_kernel(const float* __restrict__
       for (int q = 0; q < 5; ++q)
 #pragma unroll
         for (int o = BT; o < 64; o <<= 1) s[0][q] += __shfl_xor(s[0][q], o, 64);
-      __shared__ double red[4][BT][5];
+      // one partial per WAVE (no LDS round, no block barrier in the epilogue): [b][4*block + wave][5]
       if (lane < BT) {
         int brow = 0;  // bit-reverse of the lane's low log2(BT) bits
 #pragma unroll
         for (int bit = 1, w = BT / 2; w >= 1; bit <<= 1, w >>= 1) brow |= (lane & bit) ? w : 0;
+        if (brow < B) {
+          const int64_t nprt = (int64_t)gridDim.x * gridDim.y * 4;
+          const int64_t prt = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+          double* dst = ncc_partial + ((int64_t)brow * nprt + prt) * 5;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) red[wave][brow][q] = s[0][q];
-      }
-      __syncthreads();
-      if (threadIdx.x < BT * 5) {
-        const int b = threadIdx.x / 5, q = threadIdx.x % 5;
-        if (b < B) {
-          const int64_t nblk = (int64_t)gridDim.x * gridDim.y, blk = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-          ncc_partial[((int64_t)b * nblk + blk) * 5 + q] = (red[0][b][q] + red[1][b][q]) + (red[2][b][q] + red[3][b][q]);
+          for (int q = 0; q < 5; ++q) dst[q] = s[0][q];
         }
       }
     }
@@ -646,7 +643,7 @@ static int pca_warp_impl(bool bf, const float* coefs, const float* basis, const 
 #undef LR_PW1
 #undef LR_PW2
   if (int e = lr_launch_status()) return e;
-  if (ncc) return lr_internal_ncc_reduce(ncc_partial, ncc_moments, B, (int)(grid.x * grid.y), st);
+  if (ncc) return lr_internal_ncc_reduce(ncc_partial, ncc_moments, B, (int)(grid.x * grid.y * 4), st);
   return LR_OK;
 }
 

@@ -129,9 +129,12 @@ class model(nn.Module):
         self.register_buffer("_id0", torch.from_numpy(t0), persistent=False)
         self.register_buffer("_id1", torch.from_numpy(t1), persistent=False)
         self.register_buffer("_id2", torch.from_numpy(t2), persistent=False)
-        # optional (non-reference) key "fuse_ncc": in inference the one-pass decode also accumulates the similarity's
-        # moments against `target` (they cost one extra read of the target there instead of a pass over both volumes)
-        self.fuse_ncc = bool(_opt(opt, "fuse_ncc", True))
+        # optional (non-reference) key "fuse_ncc" (default False): in inference the one-pass decode also accumulates the
+        # similarity's five fp64 moments against `target` in its epilogue (one extra read of the target there instead of
+        # a pass over both volumes; moments equal to 1e-12).  Off by default: interleaved A/B at C3 measured it 0.04 ms
+        # SLOWER than decode + the 0.19 ms moments kernel — the decode runs at 2 waves per SIMD and is HBM-latency-bound,
+        # so the epilogue's extra stream and fp64 reduction lengthen every wave's tail by what the saved pass costs.
+        self.fuse_ncc = bool(_opt(opt, "fuse_ncc", False))
         # optional (non-reference) key "fuse_backproject" (default False): in fp32 inference with P <= 2 views the
         # backprojection is computed inside the first conv block (conv0_pc.hip producers; the (B,P,D,W,H) feature volume
         # is never materialised; same bits).  Off by default because it MEASURED SLOWER at C3: the block is bound by the

@@ -610,7 +610,7 @@ def pca_warp(coefs, basis_LxM, mean, ids, img, *, using_scale=True, d0=0, d1=Non
         target = _dev(target, "target")
         if tuple(target.shape) != (B, 1, Dn, W, H):
             raise ValueError(f"target must be {(B, 1, Dn, W, H)}, got {tuple(target.shape)}")
-        nblk = ((W * H // 4 + 255) // 256) * Dn
+        nblk = ((W * H // 4 + 255) // 256) * Dn * 4        # one partial per wave
         partial = torch.empty((min(B, 8), nblk, 5), dtype=torch.float64, device=img.device)
         moments = torch.empty((B, 5), dtype=torch.float64, device=img.device)
     for lo in range(0, B, 8):

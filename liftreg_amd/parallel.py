@@ -306,7 +306,7 @@ class SlabShardedRegistration:
             mom = None
             if "source_label" not in inp and ops.pca_warp_supported(coefs, basis_s, moving, d0, d1):
                 # ONE launch: PCA reconstruction of the slab + identity + warp (+ the NCC moments of the slab)
-                if tgt is not None and moving.shape[1] == 1:
+                if tgt is not None and moving.shape[1] == 1 and getattr(net, "fuse_ncc", False):
                     disp, phi, warped, mom = ops.pca_warp(coefs, basis_s, mean_s, ids, moving, d0=d0, d1=d1, target=tgt)
                 else:
                     disp, phi, warped = ops.pca_warp(coefs, basis_s, mean_s, ids, moving, d0=d0, d1=d1)

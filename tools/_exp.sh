@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-L=liftreg_amd/csrc
-LIFTREG_CONV0_PC=1 python3 tools/abconv.py --block 0 --split --libs $L/libliftreg_hip.so,$L/libx_ah2.so,$L/libx_ah3.so,$L/libx_ah4.so 2>&1 | tail -n 8
-LIFTREG_CONV0_DBG=2 python3 tools/abconv.py --block 0 --split --libs $L/libliftreg_hip.so,$L/libx_ah2.so,$L/libx_ah3.so,$L/libx_ah4.so 2>&1 | tail -n 4
+python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_headline.py tests/test_gpu_sharded_model.py -m gpu -q -x -k "ncc or slab or sharded" 2>&1 | tail -n 3
+python3 tools/abdecode.py 2>&1 | tail -n 2
