@@ -146,6 +146,13 @@ int lr_backproject_coords_poseless_f64(const double* poses, double* grid, int P,
 /* fp32 NCDHW whose values the forward rounded to bf16 on the way into the MFMA (the saved input of
  * lr_conv3d_first_bf16): accepted as x_layout by lr_conv3d_wgrad_f32, which rounds the same way while staging. */
 #define LR_LAYOUT_NCDHW_RBF16 5
+/* Not an activation layout: the LeakyReLU SIGN MASK of a block output, (B,D,W,H,C/4) uint8, bit r of byte q = "channel
+ * 4q+r > 0" — written by lr_conv3d_k3_lrelu_mask_f32 and accepted as x_layout by lr_conv3d_dgrad_f32 (x_saved then points
+ * to the mask): the data gradient needs only the signs of the producer's output, C/4 bytes per voxel instead of 4*C. */
+#define LR_LAYOUT_SIGN4 6
+int lr_conv3d_k3_lrelu_mask_f32(const float* in, const float* packed_w, const float* bias, float* out, uint8_t* mask_out,
+                                int B, int Cin, int Cout, int D, int W, int H, int stride, int in_layout, int out_layout,
+                                float negative_slope, void* stream);
 int64_t lr_conv3d_packed_floats(int Cin, int Cout, int in_layout);
 int lr_conv3d_pack_weights_f32(const float* weight, float* packed, int Cin, int Cout,
                                int in_layout, void* stream);
@@ -270,7 +277,8 @@ int lr_linear_bwd_f32(const float* x, const float* w, const float* y, const floa
  *  2. lr_conv3d_dgrad_f32 (stride-2 blocks): gx (B,D,W,H,Cx) NDHWC from gpre (B,Do,Wo,Ho,Cg) NDHWC and
  *     packed_wT = lr_conv3d_pack_weights_f32 of the weight TRANSPOSED to (Cin,Cout,3,3,3), layout NDHWC.
  *     D,W,H = the block's INPUT size; Cx = Cin in {16,32}.  x_saved (nullable): the block's saved input,
- *     i.e. the PRODUCER block's LeakyReLU output, in x_layout (NDHWC | NDHWC_HPS); when given, the result
+ *     i.e. the PRODUCER block's LeakyReLU output, in x_layout (NDHWC | NDHWC_HPS, or LR_LAYOUT_SIGN4: its sign mask
+ *     from lr_conv3d_k3_lrelu_mask_f32 — one byte per channel quad instead of 16); when given, the result
  *     is multiplied by (x_saved > 0 ? 1 : negative_slope) in the epilogue — it is then the producer's gpre
  *     and step 1 is skipped for the producer (write it as plain NDHWC: gx_layout = LR_LAYOUT_NDHWC).
  *  3. lr_conv3d_wgrad_f32: gw (Cout,Cin,3,3,3) from the block's saved input x (any layout) and gpre;

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(CSRC, "libliftreg_hip.so")
 LR_OK = 0
 LAYOUT_NCDHW, LAYOUT_NDHWC, LAYOUT_NDHWC_HPS = 0, 1, 2
 LAYOUT_BF16_NDHWC, LAYOUT_BF16_NDHWC_HPS, LAYOUT_NCDHW_RBF16 = 3, 4, 5
+LAYOUT_SIGN4 = 6   # (B,D,W,H,C/4) uint8 LeakyReLU sign mask of a block output (see the header)
 DRR_HU_INPUT, DRR_FLIP_W = 1, 2
 WARP_USING_SCALE, WARP_BORDER, WARP_NEAREST = 1, 2, 4
 NCC_CONFIGURED, NCC_SQUARED = 0, 1
@@ -38,6 +39,7 @@ SIGNATURES = {
     "lr_conv3d_packed_floats": (_i64, [_i, _i, _i]),
     "lr_conv3d_pack_weights_f32": (_i, [_p, _p, _i, _i, _i, _p]),
     "lr_conv3d_k3_lrelu_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "lr_conv3d_k3_lrelu_mask_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "lr_linear_lrelu_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _p]),
     "lr_pca_reconstruct_f32": (_i, [_p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _p]),
     "lr_pca_reconstruct_bf16basis_f32": (_i, [_p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _p]),

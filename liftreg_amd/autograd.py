@@ -20,10 +20,14 @@ class ConvBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, in_layout, out_layout, slope, packed, premasked_grad=False,
-                mask_input_slope=None):
+                mask_input_slope=None, mask_out=None, x_sign4=None):
+        # mask_out: a uint8 (B,D,W,H,C/4) tensor this block's forward fills with its LeakyReLU sign mask (the encoder's
+        # first block in training); x_sign4: the producer's such mask for THIS block's input — the data gradient then
+        # takes the producer's mask from one byte per channel quad instead of re-reading 16 bytes
         y = ops.conv3d_k3_lrelu(x, weight, bias, stride, in_layout=in_layout, out_layout=out_layout,
-                                negative_slope=slope, packed=packed)
+                                negative_slope=slope, packed=packed, mask_out=mask_out)
         ctx.save_for_backward(x, weight, y)
+        ctx.x_sign4 = x_sign4
         ctx.cfg = (stride, in_layout, out_layout, slope, bias is not None, premasked_grad, mask_input_slope)
         return y
 
@@ -37,8 +41,9 @@ class ConvBlockFn(torch.autograd.Function):
                                       "(the encoder's first block receives data, not activations)")
         gx, gw, gb = ops_bwd.conv3d_bwd(x, in_layout, weight, y, out_layout, gy.contiguous(), out_layout, stride,
                                         slope, need_gx=need_gx, gy_is_gpre=premasked,
-                                        mask_input_slope=in_slope if need_gx else None)
-        return gx, gw, (gb if has_bias else None), None, None, None, None, None, None, None
+                                        mask_input_slope=in_slope if need_gx else None,
+                                        x_sign4=ctx.x_sign4 if need_gx else None)
+        return gx, gw, (gb if has_bias else None), None, None, None, None, None, None, None, None, None
 
 
 class EncoderBf16Fn(torch.autograd.Function):

@@ -174,14 +174,20 @@ struct PlanarGeom {
 // PAIR of tiles: 2 live accumulators instead of 16, and each pair is stored the moment its CC*7 k-steps
 // are done, so the 64 KB a block writes per brick drains under the MFMAs of the following pairs instead of
 // stalling the wave in one 16-store burst (stamped build: that burst cost as much as the whole sweep).
-template <int NT, int S, int CC, bool SINGLE, int OUTL = -1>
+template <int NT, int S, int CC, bool SINGLE, int OUTL = -1, bool MASK = false>
 __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(const float* __restrict__ in,
                                                             const float* __restrict__ wp,
                                                             const float* __restrict__ bias,
                                                             float* __restrict__ out, ConvDims d,
                                                             int out_layout, float slope, int vec4_rt,
                                                             int nitems, int npass, int dbg_rt,
-                                                            const float* __restrict__ in0 /* or null: see below */) {
+                                                            const float* __restrict__ in0 /* or null: see below */,
+                                                            unsigned char* __restrict__ mask_out = nullptr) {
+  // MASK (training forward, 16 couts): besides the activation, one byte per (output voxel, channel quad) whose bit r
+  // says "channel 4q+r's output is > 0" (LR_LAYOUT_SIGN4) — the LeakyReLU mask the NEXT block's data gradient
+  // multiplies by.  That gradient kernel used to re-read this block's whole fp32 output (8.6 GB per batch at C3) for
+  // nothing but these signs.  A lane's four accumulators ARE one such quad: no cross-lane work, one unconditional
+  // bounds-checked byte store per tile (a wave's 64 bytes are contiguous).
 #ifdef LR_C0_STATIC   /* experiment: compile-time staging mode and no ablation switches (clean control flow) */
   constexpr int vec4 = 1, dbg = 0;
   (void)vec4_rt; (void)dbg_rt;
@@ -362,6 +368,10 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
         const int64_t plane_elems = (int64_t)d.Wo * d.Ho * d.Cout;
         const __amdgpu_buffer_rsrc_t oplane = __builtin_amdgcn_make_buffer_rsrc(
             out + ((int64_t)b * d.Do + (zok ? dz : 0)) * plane_elems, (short)0, zok ? (int)(plane_elems * 4) : 0, 0x00020000);
+        // the sign-mask plane (b, dz) of this wave (MASK): zero-length when the plane does not exist
+        const __amdgpu_buffer_rsrc_t mplane = __builtin_amdgcn_make_buffer_rsrc(
+            MASK ? mask_out + ((int64_t)b * d.Do + (zok ? dz : 0)) * d.Wo * d.Ho * 4 : reinterpret_cast<unsigned char*>(out),
+            (short)0, (MASK && zok) ? d.Wo * d.Ho * 4 : 0, 0x00020000);
         constexpr int NS = (PW * 4 / 2) * G::T;  // (tile pair, k-step) sequence, fully unrolled
         float ar[2][2];
         auto rd = [&](int sidx, float (&dst)[2]) {
@@ -407,6 +417,13 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                   store_tile_buf<OUTL>(pacc[h][nt], oplane, d, wq * PW + m / 4, hq * PH + (m % 4) * 16 + col, nt, lane, slope);
+                if constexpr (MASK && NT == 1) {
+                  const f32x4 a4 = pacc[h][0];
+                  const unsigned mm = (a4[0] > 0.0f ? 1u : 0u) | (a4[1] > 0.0f ? 2u : 0u) | (a4[2] > 0.0f ? 4u : 0u) | (a4[3] > 0.0f ? 8u : 0u);
+                  const int wo = wq * PW + m / 4, ho = hq * PH + (m % 4) * 16 + col;
+                  const unsigned moff = (wo < d.Wo && ho < d.Ho) ? (unsigned)((wo * d.Ho + ho) * 4 + kq) : 0x80000000u;
+                  __builtin_amdgcn_raw_buffer_store_b8((unsigned char)mm, mplane, moff, 0, 0);
+                }
               }
             }
           } else if (t == G::T - 1 && zok) {
@@ -837,7 +854,7 @@ struct FusedBp {  // host-side description of the views for the fused first bloc
 static int conv_impl(const float* in, const float* in0, const float* packed_w, const float* bias,
                      float* out, int B, int Cin, int Cout, int D, int W, int H,
                      int stride, int in_layout, int out_layout,
-                     float negative_slope, void* stream, const FusedBp* bpa = nullptr) {
+                     float negative_slope, void* stream, const FusedBp* bpa = nullptr, unsigned char* mask_out = nullptr) {
   if (bpa) in = in0;   // no channel-1.. tensor exists: the staging never dereferences `in` for them
   if (!in || !packed_w || !out) return LR_ENULL;
   if (B < 1 || Cin < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
@@ -922,6 +939,18 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
       if (rc != LR_EUNSUPPORTED || bpa) return rc;
     }
     if (bpa) return LR_EUNSUPPORTED;
+    if (mask_out) {  // training forward of the first block: activation + LeakyReLU sign mask (uint16 per voxel)
+      if (!(stride == 1 && NT == 1 && single && vec4)) return LR_EUNSUPPORTED;
+      if (out_layout == LR_LAYOUT_NDHWC_HPS)
+        hipLaunchKernelGGL((conv3d_planar_kernel<1, 1, 3, true, LR_LAYOUT_NDHWC_HPS, true>), grid, block, lds1, st, in, packed_w, bias,
+                           out, d, out_layout, negative_slope, vec4, ni, npass, 0, in0, mask_out);
+      else if (out_layout == LR_LAYOUT_NDHWC)
+        hipLaunchKernelGGL((conv3d_planar_kernel<1, 1, 3, true, LR_LAYOUT_NDHWC, true>), grid, block, lds1, st, in, packed_w, bias,
+                           out, d, out_layout, negative_slope, vec4, ni, npass, 0, in0, mask_out);
+      else
+        return LR_EUNSUPPORTED;
+      return lr_launch_status();
+    }
     if (stride == 1 && NT == 1 && single && out_layout == LR_LAYOUT_NDHWC_HPS) {        // the model's first block
       hipLaunchKernelGGL((conv3d_planar_kernel<1, 1, 3, true, LR_LAYOUT_NDHWC_HPS>), grid, block, lds1, st, in, packed_w, bias,
                          out, d, out_layout, negative_slope, vec4, ni, npass, dbg, in0);
@@ -944,6 +973,19 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
     return LR_EINVAL;
   }
   return lr_launch_status();
+}
+
+// Training forward of the encoder's first block: lr_conv3d_k3_lrelu_f32 (NCDHW in, stride 1, 16 couts, channels-last
+// out, H % 4 == 0) that ALSO writes mask_out (B,D,W,H,4) uint8 (LR_LAYOUT_SIGN4): bit r of byte q = "output channel
+// 4q+r > 0".  The next block's data gradient takes it as x_saved with x_layout = LR_LAYOUT_SIGN4 instead of re-reading
+// the fp32 activation.
+extern "C" int lr_conv3d_k3_lrelu_mask_f32(const float* in, const float* packed_w, const float* bias, float* out,
+                                           uint8_t* mask_out, int B, int Cin, int Cout, int D, int W, int H, int stride,
+                                           int in_layout, int out_layout, float negative_slope, void* stream) {
+  if (!mask_out) return LR_ENULL;
+  if (in_layout != LR_LAYOUT_NCDHW || Cout != 16 || stride != 1 || Cin > 3) return LR_EUNSUPPORTED;
+  return conv_impl(in, nullptr, packed_w, bias, out, B, Cin, Cout, D, W, H, stride, in_layout, out_layout, negative_slope,
+                   stream, nullptr, mask_out);
 }
 
 extern "C" int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, const float* bias,

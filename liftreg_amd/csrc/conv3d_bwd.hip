@@ -106,6 +106,12 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 __device__ __forceinline__ f32x4 load_mask_src(const float* xsave, int layout, int64_t row, int x, int hp, int nt, int kq,
                                                int H, int Cx) {
   const int c = nt * 16 + kq * 4;
+  if (layout == LR_LAYOUT_SIGN4) {  // (B,D,W,H,Cx/4) uint8 written by the producer's forward: bit r = channel 4q+r > 0
+    // row = voxel-row index * H * Cx, Cx in {16,32}: the divisions are shifts
+    const int64_t vox = (Cx == 16 ? row >> 4 : row >> 5) + x;
+    const unsigned m = reinterpret_cast<const unsigned char*>(xsave)[vox * (Cx >> 2) + nt * 4 + kq];
+    return (f32x4){(float)(m & 1u), (float)((m >> 1) & 1u), (float)((m >> 2) & 1u), (float)((m >> 3) & 1u)};
+  }
   if (layout == LR_LAYOUT_NDHWC) return *reinterpret_cast<const f32x4*>(xsave + row + (int64_t)x * Cx + c);
   if (layout == LR_LAYOUT_NDHWC_HPS) return *reinterpret_cast<const f32x4*>(xsave + row + ((int64_t)nt * H + hp) * 16 + kq * 4);
   const u16* xb = reinterpret_cast<const u16*>(xsave);  // bf16: rows [H][C] or [parity][H/2][C]
@@ -376,6 +382,177 @@ __global__ __launch_bounds__(256, 2) void conv3d_dgrad_lds_kernel(const float* _
   }
 }
 
+// Weights-in-LDS variant for the 16-channel data gradient (NT = 1: the encoder's block 1, 464 of the step's GFLOP).
+// conv3d_dgrad_lds_kernel fetches its weight fragments from global memory inside the k-loop, one step ahead: a step is
+// 16 MFMAs (512 cycles), an L2 hit under load is longer, the loop restarts for each of the 8 parity classes (2..16 steps
+// each), and with 61 KB of LDS per block only two waves share a SIMD — the matrix pipe idled half the time (43 % of the
+// fp32 MFMA peak).  Here ALL packed weights of the layer live in LDS for the life of a PERSISTENT block (27*CB KiB,
+// loaded once), a block is 8 wavefronts = 8 quotient planes of one 8 x 2 x 16 tile (two waves per SIMD around ONE tile
+// and ONE weight copy: 54 + 66 KB), the k-loop touches LDS only (three ds_read_b128 per 8 MFMAs), and the next tile's
+// gpre voxels are already in flight (bounds-checked buffer loads into registers) while the current one is computed.
+// Same parity-class scheme, same tap/channel order per accumulator as conv3d_dgrad_lds_kernel -> same bits.
+// MK = how the producer's LeakyReLU mask arrives (compile time: a runtime switch around the mask loads makes hipcc drain
+// the memory queue at every join — each load then costs a full latency with the matrix pipe idle): 0 none, 1 the fp32
+// activation in plain NDHWC, 2 in NDHWC_HPS, 3 the LR_LAYOUT_SIGN4 byte mask (kept RAW until the epilogue).
+constexpr int WMT = 2;  // quotient rows per wave
+template <int CB, int MK>
+__global__ __launch_bounds__(512, 2) void conv3d_dgrad_wlds_kernel(const float* __restrict__ gpre,
+                                                                   const float4* __restrict__ wp,
+                                                                   float* __restrict__ gx,
+                                                                   const float* __restrict__ xsave, DgDims d, int ntiles, int dbg) {
+  constexpr int CG = CB * 16, VS = CG + 4, C4 = CG / 4, NVOX = 9 * (WMT + 1) * 17, NCH = NVOX * C4;
+  constexpr int NIT = (NCH + 511) / 512;
+  constexpr int NWF = 27 * CB * 64;  // float4 weight fragments
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  float4* wl = reinterpret_cast<float4*>(dsm);           // [27][CB][64 lanes]
+  float* ts = dsm + NWF * 4;                              // [9][WMT+1][17][VS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < NWF; i += 512) wl[i] = wp[i];
+  const int nWq = (d.Wo + WMT - 1) / WMT, nDq = (d.Do + 7) / 8;
+  auto tile_coords = [&](int t, int& b, int& zq0, int& yq0, int& xq0) {
+    const int hq = t % d.nHq; t /= d.nHq;
+    const int wq = t % nWq; t /= nWq;
+    const int dq = t % nDq;
+    b = t / nDq;
+    zq0 = dq * 8; yq0 = wq * WMT; xq0 = hq * 16;
+  };
+  float4 st[NIT];
+  auto prefetch = [&](int t) {
+    int b, zq0, yq0, xq0;
+    tile_coords(t, b, zq0, yq0, xq0);
+    // resource = the tile's own origin: offsets stay inside nine planes whatever the volume size
+    const float* base = gpre + ((((int64_t)b * d.Do + zq0) * d.Wo + yq0) * d.Ho + xq0) * CG;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = it * 512 + tid;
+      const int vox = q / C4, c4 = q % C4;
+      const int xx = vox % 17, r = vox / 17, yy = r % (WMT + 1), zz = r / (WMT + 1);
+      const bool ok = q < NCH && zq0 + zz < d.Do && yq0 + yy < d.Wo && xq0 + xx < d.Ho;
+      const unsigned voff = ok ? (unsigned)(((((zz * d.Wo) + yy) * d.Ho + xx) * CG + c4 * 4) * 4) : OOR;
+      st[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+    }
+  };
+  const int col = lane & 15, kq = lane >> 4;
+  const float* lts = ts + col * VS + kq * 4;
+  int t = (int)blockIdx.x;
+  if (t < ntiles) prefetch(t);
+  for (; t < ntiles; t += (int)gridDim.x) {
+    __syncthreads();  // every wave is done with the previous tile (first pass: the weights are in LDS after the next one)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = it * 512 + tid;
+      if (q < NCH) *reinterpret_cast<float4*>(ts + (q / C4) * VS + (q % C4) * 4) = st[it];
+    }
+    __syncthreads();
+    int b, zq0, yq0, xq0;
+    tile_coords(t, b, zq0, yq0, xq0);
+    if (t + (int)gridDim.x < ntiles) prefetch(t + (int)gridDim.x);  // lands while this tile runs on the matrix pipe
+    const int zq = zq0 + wave, xq = xq0 + col;
+    float4 a0[WMT], a1[WMT], b0, b1;
+    for (int pp = 3; pp >= 0; --pp) {
+      const int py = pp & 1, pz = pp >> 1;
+      const int z = 2 * zq + pz;
+      if (z >= d.D) continue;  // wave-uniform; no barrier inside the class loop
+      f32x4 accp[2][WMT];
+      f32x4 xv[2][WMT];        // MK 1|2: the producer's activation at this lane's voxel (4 channels)
+      unsigned mraw[2][WMT];   // MK 3: its sign byte
+      // all mask loads of the class pair first, unconditionally (clamped addresses), a whole pair ahead of their use
+      if constexpr (MK != 0) {
+#pragma unroll
+        for (int px = 1; px >= 0; --px)
+#pragma unroll
+          for (int mt = 0; mt < WMT; ++mt) {
+            const int x = 2 * xq + px, y = 2 * (yq0 + mt) + py;
+            const bool ok = x < d.H && y < d.W;
+            const int64_t rowv = (((int64_t)b * d.D + z) * d.W + (ok ? y : 0)) * d.H;  // voxel index of the row's start
+            if constexpr (MK == 1) xv[px][mt] = *reinterpret_cast<const f32x4*>(xsave + (rowv + (ok ? x : 0)) * 16 + kq * 4);
+            if constexpr (MK == 2) xv[px][mt] = *reinterpret_cast<const f32x4*>(xsave + (rowv + (ok ? px * (d.H >> 1) + xq : 0)) * 16 + kq * 4);
+            if constexpr (MK == 3) mraw[px][mt] = reinterpret_cast<const unsigned char*>(xsave)[(rowv + (ok ? x : 0)) * 4 + kq];
+          }
+        __builtin_amdgcn_sched_barrier(0);  // the scheduler otherwise sinks these loads to the store epilogue
+      }
+#pragma unroll
+      for (int px = 1; px >= 0; --px) {
+        const int x = 2 * xq + px;
+        (void)x;
+#pragma unroll
+        for (int mt = 0; mt < WMT; ++mt) accp[px][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int NS = (1 << (px + py + pz)) * CB;
+        auto load_step = [&](int s, float4 (&a)[WMT], float4& bw) {
+          const int tapi = s / CB, cb = s - tapi * CB;
+          const int ix = tapi & px, r1 = tapi >> px, iy = r1 & py, iz = (r1 >> py) & pz;
+          const int tx = px ? 2 * ix : 1, ox = px ? 1 - ix : 0;
+          const int ty = py ? 2 * iy : 1, oy = py ? 1 - iy : 0;
+          const int tz = pz ? 2 * iz : 1, oz = pz ? 1 - iz : 0;
+          const int sfull = ((tz * 3 + ty) * 3 + tx) * CB + cb;
+          bw = wl[sfull * 64 + lane];
+          const float* src = lts + (((wave + oz) * (WMT + 1) + oy) * 17 + ox) * VS + cb * 16;
+#pragma unroll
+          for (int mt = 0; mt < WMT; ++mt) a[mt] = *reinterpret_cast<const float4*>(src + mt * 17 * VS);
+        };
+        auto mfma_step = [&](const float4 (&a)[WMT], const float4& bw) {
+#pragma unroll
+          for (int mt = 0; mt < WMT; ++mt) {
+            f32x4 c = accp[px][mt];
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(bw.x, a[mt].x, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(bw.y, a[mt].y, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(bw.z, a[mt].z, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(bw.w, a[mt].w, c, 0, 0, 0);
+            accp[px][mt] = c;
+          }
+        };
+        load_step(0, a0, b0);
+        for (int s2 = 0; s2 + 1 < NS; s2 += 2) {
+          load_step(s2 + 1, a1, b1);
+          mfma_step(a0, b0);
+          load_step(min(s2 + 2, NS - 1), a0, b0);
+          mfma_step(a1, b1);
+        }
+        if (NS & 1) mfma_step(a0, b0);
+      }
+      // Mask first, for all four tiles of the pair, THEN the stores: with a mask load still pending when a store is issued,
+      // hipcc (loads and stores share one wait counter, which it treats as unordered) makes every later use of a mask
+      // wait for the just-issued stores as well — one store latency per class pair with the matrix pipe idle.
+#pragma unroll
+      for (int mt = 0; mt < WMT; ++mt)
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          f32x4 v = accp[px][mt];
+          if constexpr (MK == 1 || MK == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = xv[px][mt][r] > 0.0f ? v[r] : v[r] * d.slope;
+          }
+          if constexpr (MK == 3) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = ((mraw[px][mt] >> r) & 1u) ? v[r] : v[r] * d.slope;
+          }
+          accp[px][mt] = v;
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      // store both px classes of this (pz, py) together
+#pragma unroll
+      for (int mt = 0; mt < WMT; ++mt) {
+        const int y = 2 * (yq0 + mt) + py;
+        if (y < d.W) {
+          const int64_t row = (((int64_t)b * d.D + z) * d.W + y) * d.H * d.Cx;
+#pragma unroll
+          for (int px = 0; px < 2; ++px) {
+            const int x = 2 * xq + px;
+            if (x < d.H && !(dbg & 2)) {
+              const int64_t o = d.gx_layout == LR_LAYOUT_NDHWC ? row + (int64_t)x * d.Cx + kq * 4
+                                                               : row + (int64_t)(px * (d.H >> 1) + xq) * 16 + kq * 4;
+              *reinterpret_cast<f32x4*>(gx + o) = accp[px][mt];
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ wgrad
 // gw[co][ci][tap] = sum_{b, o} gpre[b, o, co] * X[b, ci, s*o + tap - 1]
 // MFMA: rows = co (NTC tiles of 16), cols = 16 "columns" n of an N-tile, k = 4 consecutive output voxels
@@ -485,46 +662,56 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
 // gradient segment, and the window of brick i+1 is in flight while brick i is on the matrix pipe.
 // LDS window layout [pz*3+py][cb][pos][16] with the columns parity-split (even window columns first): the 4
 // voxels of a k-step are then 16 floats apart for every tap — bank-conflict-free 256-byte wavefront reads.
-template <int CB, int NTC>
+template <int CB, int NTC, int ROWS>
 struct WclGeom {
-  static constexpr int HB = 32 / CB;             // output voxels per brick
+  static constexpr int HB = 32 / CB;             // output voxels per brick row
   static constexpr int NCP = 2 * HB + 1;         // window columns
-  static constexpr int XF4 = 9 * CB * NCP * 4;   // float4 chunks of the window
+  static constexpr int NR = 2 * ROWS + 1;        // window rows (y) of ROWS consecutive output rows
+  static constexpr int ROWF = CB * NCP * 16;     // floats of one window row (all channel blocks)
+  static constexpr int XF4 = 3 * NR * CB * NCP * 4;  // float4 chunks of the window
   static constexpr int NW = 4 * CB;              // waves per block: 27*CB N-tiles, 7 per wave
   static constexpr int NTH = NW * 64;
   static constexpr int XIT = (XF4 + NTH - 1) / NTH;
-  static constexpr int GF4 = HB * NTC * 4;       // float4 chunks of the gradient segment (<= 256)
+  static constexpr int GF4 = HB * NTC * 4;       // float4 chunks of ONE row's gradient segment (<= 256)
   static constexpr int T = (27 * CB + NW - 1) / NW;  // N-tiles per wave
+  static constexpr int XS_FLOATS = XF4 * 4 + HB * 16;  // + a tile of ones (bias gradient)
+  static constexpr int GS_FLOATS = ROWS * HB * NTC * 16;
+  static constexpr size_t LDS_BYTES = (size_t)(XS_FLOATS + GS_FLOATS) * sizeof(float);
 };
 
 // XB: the saved input is bf16 storage (rows [H][C] or, HPS, [parity][H/2][C]) — 8-byte loads expanded to fp32 on the
 // way into the same LDS image (the bf16-forward training variant: fp32 gradient math on the bf16-rounded activations)
-template <int CB, int NTC, bool HPS, bool XB>
+// ROWS: output rows (along Wo) per brick.  Two rows share the middle window row (15 staged rows instead of 18) and halve
+// the barriers and staging instructions per MFMA: with one row a brick is 112 MFMAs per wave against 10 loads, 10 LDS
+// stores and two barriers (57 % of the fp32 MFMA peak on block 1's 464 GFLOP).
+template <int CB, int NTC, bool HPS, bool XB, int ROWS>
 __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_kernel(const float* __restrict__ xin,
                                                                  const float* __restrict__ gpre,
                                                                  float* __restrict__ partial, WgDims d, int nbricks,
                                                                  int gbf /* gpre is bf16 storage */) {
-  using G = WclGeom<CB, NTC>;
-  constexpr int Cin = CB * 16, Cout = NTC * 16, HB = G::HB;
-  __shared__ __attribute__((aligned(16))) float xs[G::XF4 * 4 + HB * 16];  // + a tile of ones (bias gradient)
-  __shared__ __attribute__((aligned(16))) float gs[HB * NTC * 16];
+  using G = WclGeom<CB, NTC, ROWS>;
+  constexpr int Cin = CB * 16, Cout = NTC * 16, HB = G::HB, NR = G::NR;
+  extern __shared__ __attribute__((aligned(16))) float wsm[];
+  float* xs = wsm;                    // [pz*NR+py][cb][pos][16] + a tile of ones
+  float* gs = wsm + G::XS_FLOATS;     // [row][nt][HB][16]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nseg = (d.Ho + HB - 1) / HB;
+  const int nwo = (d.Wo + ROWS - 1) / ROWS;
   for (int i = tid; i < HB * 16; i += G::NTH) xs[G::XF4 * 4 + i] = 1.0f;
 
-  // staging slots: chunk q = it*256 + tid of the window, decoded once (brick-independent)
+  // staging slots: chunk q = it*NTH + tid of the window, decoded once (brick-independent)
   unsigned xrel[G::XIT];
-  int xdec[G::XIT];  // pz | py<<2 | pc<<4 | used<<12
+  int xdec[G::XIT];  // pz | py<<2 | pc<<5 | used<<13
 #pragma unroll
   for (int it = 0; it < G::XIT; ++it) {
     const int q = it * G::NTH + tid;
     const bool used = q < G::XF4;
     const int c4 = q & 3, pos = (q >> 2) % G::NCP, rc = (q >> 2) / G::NCP;
-    const int cb = rc % CB, row9 = used ? rc / CB : 0;
-    const int pz = row9 / 3, py = row9 % 3;
+    const int cb = rc % CB, rowi = used ? rc / CB : 0;
+    const int pz = rowi / NR, py = rowi % NR;
     const int pc = pos <= HB ? 2 * pos : 2 * (pos - HB - 1) + 1;
-    xdec[it] = pz | (py << 2) | (pc << 4) | (used ? 1 << 12 : 0);
+    xdec[it] = pz | (py << 2) | (pc << 5) | (used ? 1 << 13 : 0);
     const int hprel = (pc & 1) ? (pc - 1) / 2 : (d.H >> 1) - 1 + pc / 2;  // parity-split position relative to ho0
     if (XB)
       xrel[it] = (unsigned)(((((pz * d.W + py) * d.H + (HPS ? hprel : pc)) * Cin) + cb * 16 + c4 * 4) * 2);
@@ -533,16 +720,18 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
     else
       xrel[it] = (unsigned)(((((pz * d.W + py) * d.H + pc) * Cin) + cb * 16 + c4 * 4) * 4);
   }
-  // N-tiles of this wave: j = wave + NW*t -> (tap, cb); LDS float offset of the tile's first voxel
+  // N-tiles of this wave: j = wave + NW*t -> (tap, cb); LDS float offset of the tile's first voxel (output row 0)
   int boff[G::T];
+  bool bones[G::T];
 #pragma unroll
   for (int t = 0; t < G::T; ++t) {
     const int jr = wave + G::NW * t;  // tile 27*CB (one spare slot exists) multiplies by ones: sum of gpre = gb
     const int j = min(jr, 27 * CB - 1);
     const int tap = j / CB, cb = j % CB;
     const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
-    boff[t] = (jr == 27 * CB ? G::XF4 * 4
-                             : (((tz * 3 + ty) * CB + cb) * G::NCP + (tx == 1 ? HB + 1 : (tx >> 1))) * 16) + lane;
+    bones[t] = jr == 27 * CB;
+    boff[t] = (bones[t] ? G::XF4 * 4
+                        : (((tz * NR + ty) * CB + cb) * G::NCP + (tx == 1 ? HB + 1 : (tx >> 1))) * 16) + lane;
   }
   f32x4 acc[G::T][NTC];
 #pragma unroll
@@ -550,12 +739,12 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
 #pragma unroll
     for (int nt = 0; nt < NTC; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float4 xst[G::XIT], gst;
+  float4 xst[G::XIT], gst[ROWS];
   auto prefetch = [&](int brick) {
     const bool live = brick < nbricks;
     int r = live ? brick : 0;
     const int hseg = r % nseg; r /= nseg;
-    const int wo = r % d.Wo; r /= d.Wo;
+    const int wo = (r % nwo) * ROWS; r /= nwo;
     const int dz = r % d.Do;
     const int b = r / d.Do;
     const int ho0 = hseg * HB;
@@ -571,8 +760,8 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(xb), (short)0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int it = 0; it < G::XIT; ++it) {
-      const int zi = zi0 + (xdec[it] & 3), yi = yi0 + ((xdec[it] >> 2) & 3), xi = xi0 + ((xdec[it] >> 4) & 255);
-      const bool ok = live && (xdec[it] >> 12) && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W && xi >= 0 && xi < d.H;
+      const int zi = zi0 + (xdec[it] & 3), yi = yi0 + ((xdec[it] >> 2) & 7), xi = xi0 + ((xdec[it] >> 5) & 255);
+      const bool ok = live && (xdec[it] >> 13) && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W && xi >= 0 && xi < d.H;
       const unsigned voff = ok ? xrel[it] : OOR;
       if (XB) {
         const f32x4 v = bf16x4_to_f32(__builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rx, voff, 0, 0)));
@@ -581,16 +770,19 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
         xst[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, 0));
       }
     }
-    const int64_t gorg = ((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + ho0) * Cout;
-    const void* gb = gbf ? (const void*)(reinterpret_cast<const u16*>(gpre) + gorg) : (const void*)(gpre + gorg);
-    const __amdgpu_buffer_rsrc_t rg =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(gb), (short)0, 0x7fffffff, 0x00020000);
-    const bool gok = live && tid < G::GF4 && ho0 + tid / (NTC * 4) < d.Ho;
-    if (gbf) {
-      const f32x4 v = bf16x4_to_f32(__builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rg, gok ? (unsigned)tid * 8u : OOR, 0, 0)));
-      gst = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-      gst = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rg, gok ? (unsigned)tid * 16u : OOR, 0, 0));
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+      const int64_t gorg = ((((int64_t)b * d.Do + dz) * d.Wo + min(wo + rr, d.Wo - 1)) * d.Ho + ho0) * Cout;
+      const void* gb = gbf ? (const void*)(reinterpret_cast<const u16*>(gpre) + gorg) : (const void*)(gpre + gorg);
+      const __amdgpu_buffer_rsrc_t rg =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(gb), (short)0, 0x7fffffff, 0x00020000);
+      const bool gok = live && tid < G::GF4 && ho0 + tid / (NTC * 4) < d.Ho && wo + rr < d.Wo;
+      if (gbf) {
+        const f32x4 v = bf16x4_to_f32(__builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rg, gok ? (unsigned)tid * 8u : OOR, 0, 0)));
+        gst[rr] = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        gst[rr] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rg, gok ? (unsigned)tid * 16u : OOR, 0, 0));
+      }
     }
   };
 
@@ -600,24 +792,29 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
     __syncthreads();  // the previous brick's reads are done
 #pragma unroll
     for (int it = 0; it < G::XIT; ++it)
-      if ((xdec[it] >> 12) & 1) *reinterpret_cast<float4*>(xs + (it * G::NTH + tid) * 4) = xst[it];
+      if ((xdec[it] >> 13) & 1) *reinterpret_cast<float4*>(xs + (it * G::NTH + tid) * 4) = xst[it];
     if (tid < G::GF4) {
       const int i = tid / (NTC * 4), c4 = tid % (NTC * 4);
-      *reinterpret_cast<float4*>(gs + ((c4 >> 2) * HB + i) * 16 + (c4 & 3) * 4) = gst;
+#pragma unroll
+      for (int rr = 0; rr < ROWS; ++rr)
+        *reinterpret_cast<float4*>(gs + rr * HB * NTC * 16 + ((c4 >> 2) * HB + i) * 16 + (c4 & 3) * 4) = gst[rr];
     }
     __syncthreads();
     prefetch(brick + (int)gridDim.x);
 #pragma unroll
-    for (int ks = 0; ks < HB / 4; ++ks) {
-      float a[NTC];
+    for (int rr = 0; rr < ROWS; ++rr) {
 #pragma unroll
-      for (int nt = 0; nt < NTC; ++nt) a[nt] = gs[nt * HB * 16 + ks * 64 + lane];
+      for (int ks = 0; ks < HB / 4; ++ks) {
+        float a[NTC];
 #pragma unroll
-      for (int t = 0; t < G::T; ++t) {
-        const float bv = xs[boff[t] + ks * 64];
+        for (int nt = 0; nt < NTC; ++nt) a[nt] = gs[rr * HB * NTC * 16 + nt * HB * 16 + ks * 64 + lane];
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt)
-          acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nt], bv, acc[t][nt], 0, 0, 0);
+        for (int t = 0; t < G::T; ++t) {
+          const float bv = xs[boff[t] + (bones[t] ? 0 : rr * 2 * G::ROWF) + ks * 64];
+#pragma unroll
+          for (int nt = 0; nt < NTC; ++nt)
+            acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nt], bv, acc[t][nt], 0, 0, 0);
+        }
       }
     }
   }
@@ -1161,16 +1358,49 @@ extern "C" int lr_conv3d_dgrad_f32(const float* gpre, const float* packed_wT, fl
   d.nHq = ((H + 1) / 2 + 15) / 16; d.nWq = ((W + 1) / 2 + DMT - 1) / DMT; d.nDq = ((D + 1) / 2 + 3) / 4;
   d.gx_layout = gx_layout;
   if (x_saved && x_layout != LR_LAYOUT_NDHWC && x_layout != LR_LAYOUT_NDHWC_HPS && x_layout != LR_LAYOUT_BF16_NDHWC &&
-      x_layout != LR_LAYOUT_BF16_NDHWC_HPS)
+      x_layout != LR_LAYOUT_BF16_NDHWC_HPS && x_layout != LR_LAYOUT_SIGN4)
     return LR_EINVAL;
   if (x_saved && (x_layout == LR_LAYOUT_NDHWC_HPS || x_layout == LR_LAYOUT_BF16_NDHWC_HPS) && (H & 1)) return LR_EUNSUPPORTED;
-  if (x_saved && (reinterpret_cast<uintptr_t>(x_saved) & 15u)) return LR_EALIGN;
+  if (x_saved && (reinterpret_cast<uintptr_t>(x_saved) & (x_layout == LR_LAYOUT_SIGN4 ? 0u : 15u))) return LR_EALIGN;
   d.xs_layout = x_layout; d.slope = negative_slope;
   const int64_t nblk = (int64_t)B * d.nDq * d.nWq * d.nHq;  // tiles of 4 x 4 x 16 voxels per parity class
   if (nblk > 0x7fffffffLL) return LR_EINVAL;
   const float4* wt = reinterpret_cast<const float4*>(packed_wT);
   hipStream_t st = lr_stream(stream);
   const dim3 grid((unsigned)nblk), blk(256);
+  const int dbgv = getenv("LIFTREG_DGRAD_DBG") ? atoi(getenv("LIFTREG_DGRAD_DBG")) : 0;  // timing ablations only
+  const float* xs_eff = (dbgv & 1) ? nullptr : x_saved;
+  const int mk = !xs_eff ? 0 : x_layout == LR_LAYOUT_NDHWC ? 1 : x_layout == LR_LAYOUT_NDHWC_HPS ? 2 : x_layout == LR_LAYOUT_SIGN4 ? 3 : -1;
+  if (Cx == 16 && (Cg == 32 || Cg == 16) && mk >= 0 && !getenv("LIFTREG_DGRAD_OLD")) {
+    // 16-channel gx (the encoder's block 1): persistent 8-wave blocks, all weights in LDS (conv3d_dgrad_wlds_kernel)
+    const int CBv = Cg / 16;
+    const int nWq2 = (d.Wo + WMT - 1) / WMT, nDq2 = (d.Do + 7) / 8;
+    const int64_t nt = (int64_t)B * nDq2 * nWq2 * d.nHq;
+    if (nt <= 0x7fffffffLL && (int64_t)10 * d.Wo * d.Ho * Cg * 4 < 0x7fffffffLL) {
+      const size_t ldsb = ((size_t)27 * CBv * 64 * 4 + (size_t)9 * (WMT + 1) * 17 * (Cg + 4)) * sizeof(float);
+      int resident = 256;  // one 8-wave block per CU
+      if (const char* e = getenv("LIFTREG_DGRAD_BLOCKS")) resident = atoi(e);  // tuning aid
+      const dim3 g2((unsigned)(nt < resident ? nt : resident)), b2(512);
+#define LR_DGW(CBV, MKV)                                                                                                  \
+  do {                                                                                                                    \
+    static bool attr_done = false;                                                                                        \
+    if (!attr_done) {                                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_dgrad_wlds_kernel<CBV, MKV>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);                                   \
+      attr_done = true;                                                                                                   \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((conv3d_dgrad_wlds_kernel<CBV, MKV>), g2, b2, ldsb, st, gpre, wt, gx, xs_eff, d, (int)nt, dbgv);   \
+  } while (0)
+#define LR_DGW_MK(CBV)                                                                                                    \
+  do {                                                                                                                    \
+    if (mk == 0) LR_DGW(CBV, 0); else if (mk == 1) LR_DGW(CBV, 1); else if (mk == 2) LR_DGW(CBV, 2); else LR_DGW(CBV, 3);  \
+  } while (0)
+      if (CBv == 2) LR_DGW_MK(2); else LR_DGW_MK(1);
+#undef LR_DGW_MK
+#undef LR_DGW
+      return lr_launch_status();
+    }
+  }
   if (Cg == 32 && Cx == 16) hipLaunchKernelGGL((conv3d_dgrad_lds_kernel<1, 2>), grid, blk, 0, st, gpre, wt, gx, x_saved, d);
   else if (Cg == 32) hipLaunchKernelGGL((conv3d_dgrad_lds_kernel<2, 2>), grid, blk, 0, st, gpre, wt, gx, x_saved, d);
   else if (Cg == 16 && Cx == 16) hipLaunchKernelGGL((conv3d_dgrad_lds_kernel<1, 1>), grid, blk, 0, st, gpre, wt, gx, x_saved, d);
@@ -1236,10 +1466,26 @@ static int wgrad_impl(const float* x, int x_layout, const float* gpre, int gbf, 
         nparts = (int)grid;
       }
     } else if (nbricks < 0x7fffffffLL) {
-      const unsigned grid = (unsigned)(nbricks < nblk ? nbricks : nblk);
+      // two output rows per brick (15 staged window rows instead of 18, half the barriers per MFMA); LIFTREG_WGRAD_ROWS=1
+      // selects the one-row bricks (A/B aid; partial sums then add in another order: equal to rounding)
+      const int rows = (getenv("LIFTREG_WGRAD_ROWS") && atoi(getenv("LIFTREG_WGRAD_ROWS")) == 1) ? 1 : 2;
+      const int64_t nbr = rows == 1 ? nbricks : (int64_t)B * d.Do * ((d.Wo + 1) / 2) * ((d.Ho + hb - 1) / hb);
+      const unsigned grid = (unsigned)(nbr < nblk ? nbr : nblk);
       const bool hps = x_layout == LR_LAYOUT_NDHWC_HPS;
+#define LR_WCL2(CBV, NTCV, HP, XBV, RV)                                                                                  \
+  do {                                                                                                                   \
+    constexpr size_t ldsb = WclGeom<CBV, NTCV, RV>::LDS_BYTES;                                                          \
+    static bool attr_done = false;                                                                                       \
+    if (!attr_done) {                                                                                                    \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_cl_kernel<CBV, NTCV, HP, XBV, RV>),          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);                                  \
+      attr_done = true;                                                                                                  \
+    }                                                                                                                    \
+    hipLaunchKernelGGL((conv3d_wgrad_cl_kernel<CBV, NTCV, HP, XBV, RV>), dim3(grid), dim3(256 * CBV), ldsb, st, x, gpre, \
+                       partial, d, (int)nbr, gbf);                                                                       \
+  } while (0)
 #define LR_WCL1(CBV, NTCV, HP, XBV) \
-  hipLaunchKernelGGL((conv3d_wgrad_cl_kernel<CBV, NTCV, HP, XBV>), dim3(grid), dim3(256 * CBV), 0, st, x, gpre, partial, d, (int)nbricks, gbf)
+  do { if (rows == 1) LR_WCL2(CBV, NTCV, HP, XBV, 1); else LR_WCL2(CBV, NTCV, HP, XBV, 2); } while (0)
 #define LR_WCL(CBV, NTCV)                                                       \
   do {                                                                          \
     if (hps) { if (xbf) LR_WCL1(CBV, NTCV, true, true); else LR_WCL1(CBV, NTCV, true, false); }     \
@@ -1251,6 +1497,7 @@ static int wgrad_impl(const float* x, int x_layout, const float* gpre, int gbf, 
       else LR_WCL(2, 2);
 #undef LR_WCL
 #undef LR_WCL1
+#undef LR_WCL2
       nparts = (int)grid;
     }
   } else if (x_layout == LR_LAYOUT_NCDHW && stride == 1 && Cout == 16 && Cin <= 12 && H % 4 == 0 && al16 &&

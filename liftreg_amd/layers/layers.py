@@ -43,8 +43,20 @@ class convBlock(nn.Module):
             raise NotImplementedError("fused epilogue supports LeakyReLU or None")
 
     def forward(self, x, packed=None):
-        return ConvBlockFn.apply(x, self.conv.weight, self.conv.bias, self.stride, self.in_layout, self.out_layout,
-                                 self._slope, packed, self.premasked_grad, self.mask_input_slope)
+        # Training, chained blocks: a 16-channel block whose consumer applies this block's LeakyReLU mask in its data
+        # gradient (premasked_grad) also writes that mask as one byte per channel quad; it travels to the consumer as an
+        # attribute of the activation tensor (`_lr_sign4`) and replaces the consumer's re-read of the activation.
+        mask_out = None
+        x_sign4 = getattr(x, "_lr_sign4", None) if self.mask_input_slope is not None else None
+        if (self.premasked_grad and torch.is_grad_enabled() and self.conv.weight.requires_grad and
+                ops.conv3d_mask_supported(x, self.conv.weight, self.stride, self.in_layout, self.out_layout)):
+            B, _, D, W, H = x.shape
+            mask_out = torch.empty((B, D, W, H, self.conv.out_channels // 4), dtype=torch.uint8, device=x.device)
+        y = ConvBlockFn.apply(x, self.conv.weight, self.conv.bias, self.stride, self.in_layout, self.out_layout,
+                              self._slope, packed, self.premasked_grad, self.mask_input_slope, mask_out, x_sign4)
+        if mask_out is not None:
+            y._lr_sign4 = mask_out
+        return y
 
 
 class FullyConnectBlock(nn.Module):

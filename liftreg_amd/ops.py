@@ -254,8 +254,14 @@ def _conv_out(out, shape, dtype, device):
     return out
 
 
+def conv3d_mask_supported(x, weight, stride, in_layout, out_layout):
+    """True when conv3d_k3_lrelu can also emit the LeakyReLU sign mask (LAYOUT_SIGN4; the encoder's first block in training)."""
+    return (in_layout == LAYOUT_NCDHW and out_layout in (LAYOUT_NDHWC, LAYOUT_NDHWC_HPS) and stride == 1 and
+            weight.shape[0] == 16 and weight.shape[1] <= 3 and x.dim() == 5 and x.shape[4] % 4 == 0 and x.data_ptr() % 16 == 0)
+
+
 def conv3d_k3_lrelu(x, weight, bias, stride, *, in_layout=LAYOUT_NCDHW, out_layout=LAYOUT_NCDHW,
-                    negative_slope=0.2, packed=None, out=None):
+                    negative_slope=0.2, packed=None, out=None, mask_out=None):
     """LeakyReLU(Conv3d(k3,p1,stride)(x)+b).  x is (B,Cin,D,W,H) for NCDHW, (B,D,W,H,Cin) for NDHWC.
     LAYOUT_NDHWC_HPS is NDHWC with every H row parity-split (even voxels, then odd): the private layout
     between a block and a following stride-2 block (see `hps_to_ndhwc`).
@@ -283,9 +289,19 @@ def conv3d_k3_lrelu(x, weight, bias, stride, *, in_layout=LAYOUT_NCDHW, out_layo
     flops = 2.0 * 27 * Cin * Cout * B * Do * Wo * Ho
     with _timed(f"conv3d_c{Cin}x{Cout}_s{stride}_{D}" + ("_bf16out" if bf16_out else ""), flops=flops,
                 bytes=4 * x.numel() + y.numel() * y.element_size(), samples=B):
-        _hip.check(_hip.lib().lr_conv3d_k3_lrelu_f32(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B,
-                                                     Cin, Cout, D, W, H, stride, in_layout, out_layout,
-                                                     float(negative_slope), _stream()), "lr_conv3d_k3_lrelu_f32")
+        if mask_out is not None:
+            # training forward of the first block: also the (B,D,W,H,C/4) uint8 sign mask for the next block's data gradient
+            if not mask_out.is_cuda or mask_out.dtype != torch.uint8 or tuple(mask_out.shape) != (B, Do, Wo, Ho, Cout // 4) or \
+                    not mask_out.is_contiguous():
+                raise ValueError(f"mask_out must be a contiguous uint8 GPU tensor of shape {(B, Do, Wo, Ho, Cout // 4)}")
+            _hip.check(_hip.lib().lr_conv3d_k3_lrelu_mask_f32(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(),
+                                                              mask_out.data_ptr(), B, Cin, Cout, D, W, H, stride, in_layout,
+                                                              out_layout, float(negative_slope), _stream()),
+                       "lr_conv3d_k3_lrelu_mask_f32")
+        else:
+            _hip.check(_hip.lib().lr_conv3d_k3_lrelu_f32(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B,
+                                                         Cin, Cout, D, W, H, stride, in_layout, out_layout,
+                                                         float(negative_slope), _stream()), "lr_conv3d_k3_lrelu_f32")
     return y
 
 

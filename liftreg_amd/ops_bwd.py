@@ -84,7 +84,7 @@ def _act_dims(t, layout):
 
 
 def conv3d_bwd(x, x_layout, weight, y, y_layout, gy, gy_layout, stride, negative_slope=0.2, need_gx=True,
-               nblk=1024, gy_is_gpre=False, mask_input_slope=None, round_weights=False):
+               nblk=1024, gy_is_gpre=False, mask_input_slope=None, round_weights=False, x_sign4=None):
     """Backward of ops.conv3d_k3_lrelu.  x / y: the block's saved input / output (any layout), gy: gradient of
     the output.  Returns (gx, gw (Cout,Cin,3,3,3), gb (Cout)); gx is (B,D,W,H,Cin) in x's own channels-last
     layout, or None.
@@ -93,6 +93,9 @@ def conv3d_bwd(x, x_layout, weight, y, y_layout, gy, gy_layout, stride, negative
     the data-gradient epilogue also applies the producer's mask (its output is this block's saved input), so the
     returned gx is the producer's pre-activation gradient in plain NDHWC; the producer then passes it with
     `gy_is_gpre=True` and skips its own mask pass.  The bias gradient comes out of the weight-gradient kernel.
+
+    `x_sign4` (with `mask_input_slope`): the producer's (B,D,W,H,C/4) uint8 sign mask (ops.conv3d_k3_lrelu(mask_out=…))
+    — the data gradient then reads one byte per channel quad for the producer's LeakyReLU mask instead of 16.
 
     bf16-forward training (conv_dtype="bf16"): x / y may be bfloat16 tensors in LAYOUT_BF16_NDHWC[_HPS] (the first
     block: its fp32 input with x_layout=LAYOUT_NCDHW_RBF16); gradients stay fp32; `round_weights` makes the data
@@ -139,9 +142,15 @@ def conv3d_bwd(x, x_layout, weight, y, y_layout, gy, gy_layout, stride, negative
             raise ValueError("a bf16 saved input needs the chained form (mask_input_slope)")
         gxl = _hip.LAYOUT_NDHWC if (fuse or x_layout == _hip.LAYOUT_NCDHW) else x_layout
         with _timed(f"conv3d_dgrad_c{Cout}x{Cin}_{D}", flops=2.0 * 27 * Cin * Cout * B * Do * Wo * Ho,
-                    bytes=4 * (gpre.numel() + gx.numel() * (2 if fuse else 1))):
+                    bytes=4 * (gpre.numel() + gx.numel() * (2 if (fuse and x_sign4 is None) else 1))):
+            use_s4 = fuse and x_sign4 is not None
+            if use_s4 and (x_sign4.dtype != torch.uint8 or tuple(x_sign4.shape) != (B, D, W, H, Cin // 4) or not x_sign4.is_cuda or
+                            not x_sign4.is_contiguous()):
+                raise ValueError(f"x_sign4 must be a contiguous uint8 GPU tensor of shape {(B, D, W, H, Cin // 4)}")
             _hip.check(lib.lr_conv3d_dgrad_f32(gpre.data_ptr(), packed_t.data_ptr(), gx.data_ptr(), B, Cout, Cin, D, W,
-                                               H, stride, gxl, x.data_ptr() if fuse else None, x_layout,
+                                               H, stride, gxl,
+                                               (x_sign4.data_ptr() if use_s4 else x.data_ptr()) if fuse else None,
+                                               _hip.LAYOUT_SIGN4 if use_s4 else x_layout,
                                                float(mask_input_slope) if fuse else 1.0, _stream()),
                        "lr_conv3d_dgrad_f32")
     # 3. weight gradient (+ bias gradient)

@@ -209,3 +209,40 @@ def test_large_batches_are_chunked(dev):
     coefs = rs.normal(0, 1, (40, Lat)).astype(np.float32)          # forward PCA: the C entry point tiles up to 32 rows
     got = ops.pca_reconstruct(T(coefs, dev), T(basis, dev), T(np.zeros(M, np.float32), dev))
     np.testing.assert_allclose(got.cpu().numpy(), coefs.astype(np.float64) @ basis, rtol=1e-4, atol=1e-5)
+
+
+def test_sign_mask_from_the_first_block_replaces_the_activation_re_read(dev, monkeypatch):
+    """Training chain block 0 -> block 1: block 0's forward also writes one byte per channel quad (bit r = channel 4q+r > 0) and
+    block 1's data gradient takes the producer's LeakyReLU mask from it instead of re-reading the 64-byte activation.
+    The mask has exactly the signs of the activation, and the masked data gradient has the same bits either way — through
+    the weights-in-LDS kernel and the older per-tile kernel (LIFTREG_DGRAD_OLD), plain and parity-split layouts, ragged sizes."""
+    from liftreg_amd import ops, ops_bwd
+    rs = np.random.RandomState(8)
+    for shape, B in (((8, 8, 64), 2), ((6, 10, 36), 1), ((16, 4, 32), 1)):
+        D, W, H = shape
+        x0 = T(rs.uniform(-1, 1, (B, 3) + shape).astype(np.float32), dev)
+        w0 = T(rs.normal(0, 0.3, (16, 3, 3, 3, 3)).astype(np.float32), dev)
+        b0 = T(rs.normal(0, 0.1, 16).astype(np.float32), dev)
+        w1 = T(rs.normal(0, 0.2, (32, 16, 3, 3, 3)).astype(np.float32), dev)
+        for lay in (ops.LAYOUT_NDHWC_HPS, ops.LAYOUT_NDHWC):
+            mask = torch.empty((B, D, W, H, 4), dtype=torch.uint8, device=dev)
+            assert ops.conv3d_mask_supported(x0, w0, 1, ops.LAYOUT_NCDHW, lay)
+            y0 = ops.conv3d_k3_lrelu(x0, w0, b0, 1, in_layout=ops.LAYOUT_NCDHW, out_layout=lay, mask_out=mask)
+            assert torch.equal(y0, ops.conv3d_k3_lrelu(x0, w0, b0, 1, in_layout=ops.LAYOUT_NCDHW, out_layout=lay))
+            plain = ops.hps_to_ndhwc(y0) if lay == ops.LAYOUT_NDHWC_HPS else y0           # (B,D,W,H,16)
+            want_bits = ((plain > 0).to(torch.int32).reshape(B, D, W, H, 4, 4) << torch.arange(4, device=dev, dtype=torch.int32)).sum(-1)
+            assert torch.equal(mask.to(torch.int32), want_bits)
+            y1 = ops.conv3d_k3_lrelu(y0, w1, None, 2, in_layout=lay, out_layout=ops.LAYOUT_NDHWC)
+            gpre = T(rs.normal(0, 1, tuple(y1.shape)).astype(np.float32), dev)
+            for old in (False, True):
+                if old:
+                    monkeypatch.setenv("LIFTREG_DGRAD_OLD", "1")
+                else:
+                    monkeypatch.delenv("LIFTREG_DGRAD_OLD", raising=False)
+                g_act, gw_a, _ = ops_bwd.conv3d_bwd(y0, lay, w1, y1, ops.LAYOUT_NDHWC, gpre, ops.LAYOUT_NDHWC, 2, gy_is_gpre=True,
+                                                    mask_input_slope=0.2)
+                g_bit, gw_b, _ = ops_bwd.conv3d_bwd(y0, lay, w1, y1, ops.LAYOUT_NDHWC, gpre, ops.LAYOUT_NDHWC, 2, gy_is_gpre=True,
+                                                    mask_input_slope=0.2, x_sign4=mask)
+                assert torch.equal(g_act, g_bit), (shape, lay, old)
+                assert torch.equal(gw_a, gw_b)
+            monkeypatch.delenv("LIFTREG_DGRAD_OLD", raising=False)
