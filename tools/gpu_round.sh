@@ -23,3 +23,14 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/fwd" -- 
 find "$O" -name "*kernel_trace.csv" -delete
 find "$O" -name "*agent_info.csv" -delete
 find "$O" -name "*kernel_stats.csv" | head -n 2
+cd "$R"
+: > "$O/train_modes.jsonl"
+for m in "--config c3" "--config c3 --conv-dtype bf16 --grad-dtype bf16" "--config c5 --conv-dtype bf16 --grad-dtype bf16"; do
+  timeout 600 python3 tools/train_bench.py $m 2>/dev/null | head -n 1 >> "$O/train_modes.jsonl"
+done
+timeout 600 python3 tools/train_bench.py --config c3 2>/dev/null > "$O/train_c3_kernels.jsonl"
+timeout 300 python3 bench.py --no-cpu-baseline --no-drr --conv-dtype bf16 2>/dev/null | tail -n 1 > "$O/bench_bf16.json"
+timeout 300 python3 bench.py --no-cpu-baseline --no-drr --config c4 --conv-dtype bf16 2>/dev/null | tail -n 1 > "$O/bench_c4_bf16.json"
+timeout 300 python3 bench.py --no-cpu-baseline --no-drr --shard slab 2>/dev/null | tail -n 1 > "$O/bench_slab_x1.json"
+timeout 300 python3 bench.py --no-cpu-baseline --no-drr --fuse-bp --fuse-ncc 2>/dev/null | tail -n 1 > "$O/bench_f1_fusions_on.json"
+cat "$O/train_modes.jsonl"

@@ -30,8 +30,8 @@ def short_name(k):
 
 def source_of(kernel):
     base = re.match(r"[A-Za-z0-9_]+", kernel).group(0)
-    for f in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
-        if re.search(r"\b" + re.escape(base) + r"\b", open(f).read()):
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):      # the file that DEFINES the kernel, not one that mentions it
+        if re.search(r"\bvoid\s+" + re.escape(base) + r"\s*\(", open(f).read()):
             return os.path.basename(f)
     return None
 
@@ -43,9 +43,9 @@ def sha256(path):
 def op_table(cfg, P, bf16):
     """(bench op name, kernel regex, rank among same-regex groups by descending grid size)."""
     n = CONFIG_N[cfg]
-    ops = [("backproject", r"^backproject_(tiled_)?kernel", 0), ("pca_warp", r"^pca_warp_kernel", 0),
-           ("pca_warp_ncc", r"^pca_warp_kernel", 0), ("ncc_moments", r"^ncc_moments_kernel", 0),
-           (f"conv3d_c{P + 1}x16_s1_{n}", r"^conv3d_(planar|fused_bp)_kernel", 0),
+    ops = [("backproject", r"^backproject_(tiled_)?kernel", 0), ("pca_warp", r"^pca_warp_kernel<.*, false>$", 0),
+           ("pca_warp_ncc", r"^pca_warp_kernel<.*, true>$", 0), ("ncc_moments", r"^ncc_moments_kernel", 0),
+           (f"conv3d_c{P + 1}x16_s1_{n}", r"^conv3d_planar_kernel", 0), (f"conv3d_bp_c{P + 1}x16_s1_{n}", r"^conv0_pc_kernel<.*, true>$", 0),
            (f"conv3d_c16x32_s2_{n}", r"^conv3d_cl_rows_kernel<2, 1>", 0)]
     size, rank = n // 2, 0
     while size >= 16:
