@@ -148,3 +148,29 @@ def test_plugins_construct_through_the_references_own_parameterdict_and_get_clas
     # the harness-facing surface RegistrationNet touches (networks/RegistrationNet.py:179,394,410)
     assert net.get_extra_to_plot() == (None, None) and net.get_disp() == (None, "")
     assert callable(getattr(net, "train")) and callable(getattr(net, "eval")) and len(list(net.parameters())) == 18
+
+
+def test_save_deformations_writes_npy_and_nifti(tmp_path):
+    """utils/utils.py:57-68: `{id}_phi.npy` and `{id}_phi.nii.gz` = (phi+1)/2.  The NIfTI-1 file follows the published
+    layout (348-byte header, magic n+1, dim / datatype / vox_offset, sform = identity, Fortran-ordered float32 voxels)
+    and round-trips through the package's own reader (nibabel is absent: no byte comparison with its files)."""
+    import gzip
+    import struct
+    from liftreg_amd.utils.utils import read_nifti1_gz, save_deformations
+    rs = np.random.RandomState(3)
+    phi = rs.uniform(-1, 1, (2, 3, 4, 5, 6)).astype(np.float32)
+    save_deformations(torch.from_numpy(phi), ["a", "b"], str(tmp_path))
+    for i, name in enumerate(("a", "b")):
+        want = ((phi[i] + 1.) / 2.).astype(np.float32)
+        assert np.array_equal(np.load(tmp_path / f"{name}_phi.npy"), want)
+        arr, aff = read_nifti1_gz(str(tmp_path / f"{name}_phi.nii.gz"))
+        assert arr.dtype == np.float32 and np.array_equal(arr, want) and np.array_equal(aff, np.eye(4))
+        raw = gzip.open(tmp_path / f"{name}_phi.nii.gz").read()
+        assert len(raw) == 352 + want.nbytes
+        assert struct.unpack_from("<i", raw, 0)[0] == 348 and raw[344:348] == b"n+1\x00"
+        assert struct.unpack_from("<8h", raw, 40) == (4, 3, 4, 5, 6, 1, 1, 1)
+        assert struct.unpack_from("<hh", raw, 70) == (16, 32) and struct.unpack_from("<f", raw, 108)[0] == 352.0
+        assert struct.unpack_from("<hh", raw, 252) == (0, 2)
+        # Fortran order: the FIRST array index is the fastest on disk
+        first = np.frombuffer(raw, np.float32, count=3, offset=352)
+        assert np.array_equal(first, want[:, 0, 0, 0])
