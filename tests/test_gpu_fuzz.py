@@ -459,3 +459,84 @@ def test_fuzz_small_backward_ops(dev):
         gxl, gwl, gbl = ops_bwd.linear_bwd(T(xl, dev), T(wl, dev), yl, T(gyl, dev), slope)
         for got_, want_, nm in ((gxl, xt.grad, "gx"), (gwl, wt.grad, "gw"), (gbl, bt.grad, "gb")):
             np.testing.assert_allclose(got_.cpu().numpy(), want_.numpy(), rtol=2e-4, atol=2e-5, err_msg=str(("linear", nm, B, K, O)))
+
+
+def test_fuzz_round2_kernels(dev, monkeypatch):
+    """Random shapes through the kernels added in round 2, each against the kernel pair / kernel it must equal bit for
+    bit: the first block with the backprojection fused into it (conv0_pc.hip), the producer/consumer first block on plain
+    inputs, the slab form of the one-pass decode with the NCC moments in its epilogue, and the sign-mask data gradient."""
+    from liftreg_amd import ops, ops_bwd
+    from liftreg_amd.utils import net_utils as N
+    rs = np.random.RandomState(909 + SEED)
+    for case in range(N_CASES):
+        # ---- first block: fused backprojection == backproject + first_split; PC kernel == single-buffer kernel
+        D, W = int(rs.randint(2, 14)), int(rs.randint(2, 14))
+        H = 4 * int(rs.randint(1, 36 if not LONG_H else LONG_H // 4 + 1))
+        B, P = int(rs.randint(1, 4)), int(rs.randint(1, 3))
+        Pw, Ph = int(rs.randint(2, 40)), int(rs.randint(2, 90))
+        moving = T(rs.uniform(-1, 1, (B, 1, D, W, H)).astype(np.float32), dev)
+        proj = T(rs.uniform(-1, 1, (B, P, Pw, Ph)).astype(np.float32), dev)
+        if rs.rand() < 0.5:
+            poses = ro.scan_poses(float(rs.uniform(10, 60)), P, W).astype(np.float32)
+        else:
+            poses = (rs.uniform(-2.5, 2.5, (P, 3)) * np.array([1, 0, 1]) + np.array([0, rs.uniform(1.1, 4.0), 0])).astype(np.float32) * W
+        w0 = T(rs.normal(0, 0.3, (16, P + 1, 3, 3, 3)).astype(np.float32), dev)
+        b0 = T(rs.normal(0, 0.1, 16).astype(np.float32), dev)
+        lay = ops.LAYOUT_NDHWC_HPS if (H % 2 == 0 and rs.rand() < 0.7) else ops.LAYOUT_NDHWC
+        tv = ops.backproject(proj, poses, (D, W, H))
+        want = ops.conv3d_first_split(moving, tv, w0, b0, out_layout=lay)
+        got = ops.conv3d_first_fused_bp(moving, proj, poses, w0, b0, out_layout=lay)
+        assert torch.equal(got, want), ("fused bp", case, D, W, H, B, P, Pw, Ph, lay)
+        monkeypatch.setenv("LIFTREG_CONV0_PC", "1")
+        got_pc = ops.conv3d_first_split(moving, tv, w0, b0, out_layout=lay)
+        got_cat = ops.conv3d_k3_lrelu(torch.cat([moving, tv], 1), w0, b0, 1, in_layout=ops.LAYOUT_NCDHW, out_layout=lay)
+        monkeypatch.delenv("LIFTREG_CONV0_PC")
+        assert torch.equal(got_pc, want) and torch.equal(got_cat, want), ("pc kernel", case, D, W, H, B, P, lay)
+        # ---- sign mask of block 0 -> data gradient of block 1
+        mask = torch.empty((B, D, W, H, 4), dtype=torch.uint8, device=dev)
+        y0 = ops.conv3d_k3_lrelu(torch.cat([moving, tv], 1), w0, b0, 1, in_layout=ops.LAYOUT_NCDHW, out_layout=lay, mask_out=mask)
+        assert torch.equal(y0, want)
+        Cout1 = int(rs.choice([16, 32]))
+        w1 = T(rs.normal(0, 0.2, (Cout1, 16, 3, 3, 3)).astype(np.float32), dev)
+        y1 = ops.conv3d_k3_lrelu(y0, w1, None, 2, in_layout=lay, out_layout=ops.LAYOUT_NDHWC)
+        gpre = T(rs.normal(0, 1, tuple(y1.shape)).astype(np.float32), dev)
+        g_act, gw_a, gb_a = ops_bwd.conv3d_bwd(y0, lay, w1, y1, ops.LAYOUT_NDHWC, gpre, ops.LAYOUT_NDHWC, 2, gy_is_gpre=True, mask_input_slope=0.2)
+        g_bit, gw_b, gb_b = ops_bwd.conv3d_bwd(y0, lay, w1, y1, ops.LAYOUT_NDHWC, gpre, ops.LAYOUT_NDHWC, 2, gy_is_gpre=True, mask_input_slope=0.2,
+                                               x_sign4=mask)
+        assert torch.equal(g_act, g_bit) and torch.equal(gw_a, gw_b) and torch.equal(gb_a, gb_b), ("sign mask", case, D, W, H, Cout1, lay)
+        monkeypatch.setenv("LIFTREG_DGRAD_OLD", "1")
+        g_old, _, _ = ops_bwd.conv3d_bwd(y0, lay, w1, y1, ops.LAYOUT_NDHWC, gpre, ops.LAYOUT_NDHWC, 2, gy_is_gpre=True, mask_input_slope=0.2)
+        monkeypatch.delenv("LIFTREG_DGRAD_OLD")
+        assert torch.equal(g_old, g_act), ("weights-in-LDS data gradient vs per-tile kernel", case, D, W, H, Cout1, lay)
+        monkeypatch.setenv("LIFTREG_WGRAD_ROWS", "1")
+        _, gw_1, gb_1 = ops_bwd.conv3d_bwd(y0, lay, w1, y1, ops.LAYOUT_NDHWC, gpre, ops.LAYOUT_NDHWC, 2, gy_is_gpre=True, need_gx=False)
+        monkeypatch.delenv("LIFTREG_WGRAD_ROWS")
+        scale = float(gw_1.abs().max()) + 1e-20
+        assert float((gw_1 - gw_a).abs().max()) <= 2e-5 * scale and float((gb_1 - gb_a).abs().max()) <= 2e-5 * (float(gb_1.abs().max()) + 1e-20)
+        # ---- slab decode with the NCC epilogue
+        Bd, Lat = int(rs.randint(1, 10)), int(rs.randint(1, 9))
+        V = D * W * H
+        img = T(rs.uniform(-1, 1, (Bd, 1, D, W, H)).astype(np.float32), dev)
+        tgt = T(rs.uniform(-1, 1, (Bd, 1, D, W, H)).astype(np.float32), dev)
+        basis = T(rs.normal(0, 0.2, (Lat, 3 * V)).astype(np.float32), dev)
+        if rs.rand() < 0.4:
+            basis = basis.to(torch.bfloat16)
+        mean = T(rs.normal(0, 0.02, 3 * V).astype(np.float32), dev)
+        coefs = T(rs.normal(0, 1, (Bd, Lat)).astype(np.float32), dev)
+        ids = [T(t, dev) for t in N.identity_axis_tables((D, W, H))]
+        d_ref, p_ref, w_ref = ops.pca_warp(coefs, basis, mean, ids, img)
+        m_want = ops.ncc_moments(w_ref, tgt, Bd).cpu().numpy()
+        d0 = int(rs.randint(0, D))
+        d1 = int(rs.randint(d0 + 1, D + 1))
+        m_sum = np.zeros_like(m_want)
+        for lo, hi in ((0, d0), (d0, d1), (d1, D)):
+            if hi == lo:
+                continue
+            plane = W * H
+            cols = torch.cat([torch.arange((c * D + lo) * plane, (c * D + hi) * plane, device=dev) for c in range(3)])
+            bs, ms = (basis, mean) if rs.rand() < 0.5 else (basis[:, cols].contiguous(), mean[cols].contiguous())
+            d_s, p_s, w_s, m_s = ops.pca_warp(coefs, bs, ms, ids, img, d0=lo, d1=hi, target=tgt[:, :, lo:hi].contiguous())
+            assert torch.equal(d_s, d_ref[:, :, lo:hi]) and torch.equal(p_s, p_ref[:, :, lo:hi]) and torch.equal(w_s, w_ref[:, :, lo:hi]), \
+                ("slab decode", case, D, W, H, Bd, Lat, lo, hi, bs.shape)
+            m_sum += m_s.cpu().numpy()
+        np.testing.assert_allclose(m_sum, m_want, rtol=1e-11, atol=1e-9, err_msg=str(("slab moments", case, D, W, H, Bd)))
