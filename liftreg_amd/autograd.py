@@ -24,8 +24,9 @@ class ConvBlockFn(torch.autograd.Function):
         # mask_out: a uint8 (B,D,W,H,C/4) tensor this block's forward fills with its LeakyReLU sign mask (the encoder's
         # first block in training); x_sign4: the producer's such mask for THIS block's input — the data gradient then
         # takes the producer's mask from one byte per channel quad instead of re-reading 16 bytes
+        extra = {} if mask_out is None else {"mask_out": mask_out}
         y = ops.conv3d_k3_lrelu(x, weight, bias, stride, in_layout=in_layout, out_layout=out_layout,
-                                negative_slope=slope, packed=packed, mask_out=mask_out)
+                                negative_slope=slope, packed=packed, **extra)
         ctx.save_for_backward(x, weight, y)
         ctx.x_sign4 = x_sign4
         ctx.cfg = (stride, in_layout, out_layout, slope, bias is not None, premasked_grad, mask_input_slope)

@@ -64,6 +64,9 @@ class OracleOps:
     def conv3d_pack_weights(self, weight, in_layout):
         return None
 
+    def conv3d_mask_supported(self, *a, **k):
+        return False           # the shim writes no LeakyReLU sign masks
+
     def conv3d_k3_lrelu(self, x, weight, bias, stride, *, in_layout=0, out_layout=0, negative_slope=0.2, packed=None,
                         out=None):
         y = self.ro.conv_block(self._to_ncdhw(x, in_layout), weight.detach(), bias.detach(), stride, negative_slope)
