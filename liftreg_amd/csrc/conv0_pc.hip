@@ -3,9 +3,9 @@
 // computed by the producers, so the (B,P,D,W,H) feature volume of …Backproj.py:89-93 is never written or read.
 //
 //   block = 6 wavefronts, 2 blocks per CU, persistent over 4x4x64 output bricks:
-//     waves 0..3  consumers: one output plane each, the output-stationary MFMA sweep of conv3d_planar_kernel
-//                 (v_mfma_f32_16x16x4_f32, operands by immediate-offset ds_read_b32, weights in registers, tile pairs
-//                 stored as they finish) — and NOTHING else: no staging, no address arithmetic, one barrier per brick;
+//     waves 0..3  consumers: one output plane each, the Winograd F(2,3)-along-H MFMA sweep of conv3d_planar_kernel
+//                 (v_mfma_f32_16x16x4_f32, operands by immediate-offset LDS reads, transformed weights in registers,
+//                 pairs of tiles stored as they finish) — and NOTHING else: no staging, one barrier per brick;
 //     waves 4,5   producers: build brick u+1 in the OTHER LDS buffer while brick u is swept: channel 0 (the moving
 //                 image) by 16-byte bounds-checked buffer loads (out of volume -> 0 = the conv's padding), channels
 //                 1..P either loaded the same way (plain 3-channel input) or COMPUTED: each window voxel's value is
@@ -35,7 +35,6 @@ constexpr int RSL = 72, F4 = RSL / 4;            // window row: 72 floats = 18 f
 constexpr int PS = RW * RSL, CS = RD * PS;       // plane / channel stride (floats)
 constexpr int CC = 3;                            // channels of the brick (Cin <= 3; unused ones are zero)
 constexpr int BRICK = CC * CS;                   // 7776 floats = 31104 bytes per buffer
-constexpr int T = CC * 7;                        // k-steps: channel c, 7 quads of taps (27 padded to 28)
 constexpr int NPROD = RW * F4;                   // 108 producer lanes: one per (window row ry, float4 lf4)
 constexpr unsigned OOR = 0x80000000u;
 #ifndef LR_STORE_AUX
@@ -225,24 +224,30 @@ __global__ __launch_bounds__(384, 3) void conv0_pc_kernel(const float* __restric
   }
 
   // ============================================================= consumers ===================================
+  // The Winograd F(2,3)-along-H sweep of conv3d_planar_kernel<…, WINO> (conv3d.hip), instruction for instruction: columns
+  // of an MFMA = 16 output PAIRS of a row; a lane reads the four inputs d0..d3 under a pair's taps once, forms the four
+  // differences and feeds four MFMAs (positions r = 0..3) with the transformed weights U_r that lr_conv3d_pack_weights_f32
+  // leaves behind the direct ones; 28 MFMAs per 32 outputs instead of 42.
   const int col = lane & 15, kq = lane >> 4;
-  int qoff[7];  // per-lane LDS offsets of the 7 tap quads (tap 27 is padding: weight 0, address of tap 26)
+  int woff[7];   // LDS offset of d0 for this lane's k = (c, tz, ty) of quad q (k = 27 is padding: U = 0, address of k = 26)
+  float uw[4][7];
 #pragma unroll
   for (int q = 0; q < 7; ++q) {
-    const int tap = min(q * 4 + kq, 26);
-    const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
-    qoff[q] = (wave + tz) * PS + ty * RSL + XOFF + tx + col;
-  }
-  float w[T];  // MFMA A operand (rows = couts): the pack_planar order of lr_conv3d_pack_weights_f32
+    const int k = min(q * 4 + kq, 26);
+    const int c = k / 9, tz = (k / 3) % 3, ty = k % 3;
+    woff[q] = c * CS + (wave + tz) * PS + ty * RSL + XOFF + 2 * col;
 #pragma unroll
-  for (int t = 0; t < T; ++t) w[t] = (t / 7 < d.Cin) ? wp[((t / 7) * 7 + t % 7) * 64 + lane] : 0.0f;
+    for (int r = 0; r < 4; ++r) uw[r][q] = wp[d.Cin * 7 * 64 + (r * 7 + q) * 64 + lane];
+  }
   f32x4 bvec = {0.f, 0.f, 0.f, 0.f};
   if (bias) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) bvec[r] = bias[(lane >> 4) * 4 + r];
   }
 #pragma unroll
-  for (int t = 0; t < T; ++t) asm volatile("" : "+v"(w[t]));  // the loads' wait stays here, not inside the sweep
+  for (int q = 0; q < 7; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(uw[r][q]));  // the loads' wait stays here, not inside the sweep
   __syncthreads();  // brick 0 is in LDS
   const int64_t plane_elems = (int64_t)d.W * d.H * 16;
   for (int u = 0; u < my_bricks; ++u) {
@@ -254,64 +259,61 @@ __global__ __launch_bounds__(384, 3) void conv0_pc_kernel(const float* __restric
     // output plane (b, dz) as a buffer resource; zero-length (every store dropped) when the plane does not exist
     const __amdgpu_buffer_rsrc_t oplane = __builtin_amdgcn_make_buffer_rsrc(
         out + ((int64_t)b * d.D + (zok ? dz : 0)) * plane_elems, (short)0, zok ? (int)(plane_elems * 4) : 0, 0x00020000);
-    constexpr int NS = (PW * 4 / 2) * T;  // (tile pair, k-step) sequence, fully unrolled
-#ifndef LR_PC_AHEAD
-#define LR_PC_AHEAD 1   /* k-steps the LDS reads run ahead of the MFMAs */
-#endif
-    constexpr int AH = LR_PC_AHEAD, NB = AH + 1;
-    float ar[NB][2];
-    auto rd = [&](int sidx, float (&dst)[2]) {
-      const int p = sidx / T, t = sidx % T;
-      const float* base = brick + (t / 7) * CS + qoff[t % 7];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int m = 2 * p + h;
-        dst[h] = base[(m / 4) * RSL + (m % 4) * 16];
-      }
+    constexpr int NU = PW * 2, NSW = NU * 7;   // units = (row y, half g of the 64-wide row), 7 k-quads each
+    auto rd4 = [&](int sidx, float (&dst)[4]) {
+      const int un = sidx / 7, q = sidx % 7;
+      const float* dp = brick + woff[q] + (un >> 1) * RSL + (un & 1) * 32;
+      dst[0] = dp[0]; dst[1] = dp[1]; dst[2] = dp[2]; dst[3] = dp[3];
     };
-#pragma unroll
-    for (int a = 0; a < AH; ++a) rd(a, ar[a % NB]);
-    f32x4 pacc[2];
+    float dv[2][4];
+    rd4(0, dv[0]);
+    f32x4 dacc[4];
     if (!(dbg & 1))
 #pragma clang loop unroll(full)
-    for (int p = 0; p < PW * 4 / 2; ++p)
-#pragma clang loop unroll(full)
-      for (int t = 0; t < T; ++t) {
-        const int sidx = p * T + t;
-        if (t == 0) {
-          pacc[0] = bvec;
-          pacc[1] = bvec;
+    for (int sidx = 0; sidx < NSW; ++sidx) {
+      const int un = sidx / 7, q = sidx % 7;
+      if (q == 0) {
+        dacc[0] = bvec;  // y0 = D0 + D1 + D2 carries the bias; y1 gets it in the epilogue
+#pragma unroll
+        for (int r = 1; r < 4; ++r) dacc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      if (sidx + 1 < NSW) rd4(sidx + 1, dv[(sidx + 1) & 1]);
+      const float* dc = dv[sidx & 1];
+      const float v0 = dc[0] - dc[2], v1 = dc[1] + dc[2], v2 = dc[2] - dc[1], v3 = dc[1] - dc[3];
+      dacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uw[0][q], v0, dacc[0], 0, 0, 0);
+      dacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uw[1][q], v1, dacc[1], 0, 0, 0);
+      dacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(uw[2][q], v2, dacc[2], 0, 0, 0);
+      dacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(uw[3][q], v3, dacc[3], 0, 0, 0);
+      if (sidx + 1 < NSW) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
+      if (q == 6) {  // unconditional, countable stores: 16 bytes per lane, 1 KiB contiguous per tile in the parity-split row
+        f32x4 yo[2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          yo[0][e] = (dacc[0][e] + dacc[1][e]) + dacc[2][e];
+          yo[1][e] = ((dacc[1][e] - dacc[2][e]) - dacc[3][e]) + bvec[e];
         }
-        if (sidx + AH < NS) rd(sidx + AH, ar[(sidx + AH) % NB]);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) pacc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t], ar[sidx % NB][h], pacc[h], 0, 0, 0);
-        if (sidx + AH < NS) {
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA …
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // … then one LDS read
+        for (int o = 0; o < 2; ++o) {
+          const int wo = wq * PW + (un >> 1), ho = hq * PH + (un & 1) * 32 + 2 * col + o;
+          const int c0 = (lane >> 4) * 4;
+          float4 v;
+          v.x = lrelu(yo[o][0], slope); v.y = lrelu(yo[o][1], slope); v.z = lrelu(yo[o][2], slope); v.w = lrelu(yo[o][3], slope);
+          unsigned off;
+          if (OUTL == LR_LAYOUT_NDHWC) {
+            off = (unsigned)(((wo * d.H + ho) * 16 + c0) * 4);
+          } else {  // row = [parity][H/2][16 floats]
+            const int hp = (ho & 1) * (d.H >> 1) + (ho >> 1);
+            off = (unsigned)((wo * d.H * 16 + hp * 16 + c0) * 4);
           }
-        }
-        if (t == T - 1) {  // unconditional, countable stores: 16 bytes per lane, 1 KiB contiguous per tile
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int m = 2 * p + h;
-            const int wo = wq * PW + m / 4, ho = hq * PH + (m % 4) * 16 + col;
-            const int c0 = (lane >> 4) * 4;
-            float4 v;
-            v.x = lrelu(pacc[h][0], slope); v.y = lrelu(pacc[h][1], slope); v.z = lrelu(pacc[h][2], slope); v.w = lrelu(pacc[h][3], slope);
-            unsigned off;
-            if (OUTL == LR_LAYOUT_NDHWC) {
-              off = (unsigned)(((wo * d.H + ho) * 16 + c0) * 4);
-            } else {  // row = [parity][H/2][16 floats]
-              const int hp = (ho & 1) * (d.H >> 1) + (ho >> 1);
-              off = (unsigned)((wo * d.H * 16 + hp * 16 + c0) * 4);
-            }
-            if (wo >= d.W || ho >= d.H) off = OOR;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), oplane, off, 0, LR_STORE_AUX);
-          }
+          if (wo >= d.W || ho >= d.H) off = OOR;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), oplane, off, 0, LR_STORE_AUX);
         }
       }
+    }
     __syncthreads();  // every consumer is done with this buffer; the producers have filled the other one
   }
 }

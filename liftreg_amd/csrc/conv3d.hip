@@ -174,7 +174,19 @@ struct PlanarGeom {
 // PAIR of tiles: 2 live accumulators instead of 16, and each pair is stored the moment its CC*7 k-steps
 // are done, so the 64 KB a block writes per brick drains under the MFMAs of the following pairs instead of
 // stalling the wave in one 16-store burst (stamped build: that burst cost as much as the whole sweep).
-template <int NT, int S, int CC, bool SINGLE, int OUTL = -1, bool MASK = false>
+// WINO (the model's first block: stride 1, Cin <= 3, 16 couts, channels-last output): the sweep runs the Winograd F(2,3)
+// minimal-filtering algorithm ALONG H — two neighbouring outputs of a row share the four inputs d0..d3 under their taps,
+//   m0 = (d0-d2) g0,  m1 = (d1+d2) (g0+g1+g2)/2,  m2 = (d2-d1) (g0-g1+g2)/2,  m3 = (d1-d3) g2,
+//   y0 = m0+m1+m2,    y1 = m1-m2-m3                (g = the three taps along H of one (channel, tz, ty))
+// i.e. 4 multiplications for 2 outputs instead of 6: the contraction index shrinks from 81 (c, 27 taps) to 4 x 27
+// (position r, (c,tz,ty)) per PAIR of outputs = 28 MFMAs per 32 outputs instead of 42 — one third fewer of the
+// instructions that bound this block (fp32 MFMA runs at 1/16 of the bf16 rate on gfx950; at the clock the chip holds the
+// direct sweep alone is 2.74 of the block's 3.3 ms).  Columns of an MFMA = 16 output PAIRS of a row; a lane reads d0..d3
+// once (two ds_read2_b32), forms the four differences on the vector ALU and feeds four MFMAs (r = 0..3) with the
+// transformed weights U_r (packed by lr_conv3d_pack_weights_f32 behind the direct ones); the output transform is four
+// adds per accumulator.  fp32 throughout; results differ from the direct sum by rounding (~1e-7 relative: the data-side
+// transform has coefficients +-1 only).  The parity-split output row makes both stores of a pair contiguous KiBs.
+template <int NT, int S, int CC, bool SINGLE, int OUTL = -1, bool MASK = false, bool WINO = false>
 __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(const float* __restrict__ in,
                                                             const float* __restrict__ wp,
                                                             const float* __restrict__ bias,
@@ -277,6 +289,23 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
   f32x4 acc[PW * 4][NT];
   float w[G::T][NT];
   float a[2][PW * 4];
+  float uw[WINO ? 4 : 1][WINO ? 7 : 1];  // WINO: transformed weights U_r of k-quad q (lane: cout = lane&15, k = 4q + kq)
+  int woff[WINO ? 7 : 1];                 // WINO: LDS offset of d0 for this lane's k of quad q (output pair `col`)
+  if constexpr (WINO) {
+    static_assert(NT == 1 && S == 1 && CC == 3 && SINGLE, "Winograd sweep: the model's first block");
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const int k = min(q * 4 + kq, 26);   // k = (c, tz, ty); k = 27 is padding (U = 0), address of k = 26
+      const int c = k / 9, tz = (k / 3) % 3, ty = k % 3;
+      woff[q] = c * G::CS + (wave + tz) * G::PS + ty * G::RSL + G::XOFF + 2 * col;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) uw[r][q] = wp[d.Cin * 7 * 64 + (r * 7 + q) * 64 + lane];
+    }
+#pragma unroll
+    for (int q = 0; q < 7; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(uw[r][q]));
+  }
 
   // brick of unit u -> LDS (from the prefetched registers, or scalar loads when !vec4)
   auto stage = [&](int u) {
@@ -310,7 +339,7 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
   for (int nt = 0; nt < NT; ++nt) bvec[nt] = bias_init(bias, nt, lane);
   auto setup = [&](int u) {
     const int pass = u % npass, c0 = pass * CC;
-    if (npass > 1 || u == 0) {
+    if (!WINO && (npass > 1 || u == 0)) {   // (the Winograd sweep has its own transformed weights, loaded once above)
 #pragma unroll
       for (int t = 0; t < G::T; ++t)
 #pragma unroll
@@ -372,6 +401,63 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
         const __amdgpu_buffer_rsrc_t mplane = __builtin_amdgcn_make_buffer_rsrc(
             MASK ? mask_out + ((int64_t)b * d.Do + (zok ? dz : 0)) * d.Wo * d.Ho * 4 : reinterpret_cast<unsigned char*>(out),
             (short)0, (MASK && zok) ? d.Wo * d.Ho * 4 : 0, 0x00020000);
+        if constexpr (WINO) {
+          // units = (row y, half g of the 64-wide row): 16 output pairs each; ONE unit at a time (its four accumulators are
+          // four independent MFMA chains, 128 cycles apart: no dependency stall), the (unit, k-quad) sequence fully unrolled
+          // with the four LDS values of the next step loaded while the current step's MFMAs run
+          constexpr int NU = PW * 2, NSW = NU * 7;
+          auto rd4 = [&](int sidx, float (&dst)[4]) {
+            const int un = sidx / 7, q = sidx % 7;
+            const float* dp = brick + woff[q] + (un >> 1) * G::RSL + (un & 1) * 32;
+            dst[0] = dp[0]; dst[1] = dp[1]; dst[2] = dp[2]; dst[3] = dp[3];
+          };
+          float dv[2][4];
+          rd4(0, dv[0]);
+          f32x4 dacc[4];
+#pragma clang loop unroll(full)
+          for (int sidx = 0; sidx < NSW; ++sidx) {
+            const int un = sidx / 7, q = sidx % 7;
+            if (q == 0) {
+              dacc[0] = bvec[0];  // y0 = D0 + D1 + D2 carries the bias; y1 gets it in the epilogue
+#pragma unroll
+              for (int r = 1; r < 4; ++r) dacc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            if (sidx + 1 < NSW) rd4(sidx + 1, dv[(sidx + 1) & 1]);
+            const float* dc = dv[sidx & 1];
+            const float v0 = dc[0] - dc[2], v1 = dc[1] + dc[2], v2 = dc[2] - dc[1], v3 = dc[1] - dc[3];
+            dacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uw[0][q], v0, dacc[0], 0, 0, 0);
+            dacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uw[1][q], v1, dacc[1], 0, 0, 0);
+            dacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(uw[2][q], v2, dacc[2], 0, 0, 0);
+            dacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(uw[3][q], v3, dacc[3], 0, 0, 0);
+            if (sidx + 1 < NSW) {   // per step: the two LDS reads of the next step, then the 4 differences + 4 MFMAs
+              __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+            if (q == 6) {
+              f32x4 y0, y1;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                y0[e] = (dacc[0][e] + dacc[1][e]) + dacc[2][e];
+                y1[e] = ((dacc[1][e] - dacc[2][e]) - dacc[3][e]) + bvec[0][e];
+              }
+              const int wo = wq * PW + (un >> 1), ho = hq * PH + (un & 1) * 32 + 2 * col;
+              if constexpr (OUTL == LR_LAYOUT_NDHWC || OUTL == LR_LAYOUT_NDHWC_HPS) {
+                store_tile_buf<OUTL>(y0, oplane, d, wo, ho, 0, lane, slope);
+                store_tile_buf<OUTL>(y1, oplane, d, wo, ho + 1, 0, lane, slope);
+                if constexpr (MASK) {
+#pragma unroll
+                  for (int o = 0; o < 2; ++o) {
+                    const f32x4 a4 = o ? y1 : y0;
+                    const unsigned mm = (a4[0] > 0.0f ? 1u : 0u) | (a4[1] > 0.0f ? 2u : 0u) | (a4[2] > 0.0f ? 4u : 0u) | (a4[3] > 0.0f ? 8u : 0u);
+                    const unsigned moff = (wo < d.Wo && ho + o < d.Ho) ? (unsigned)((wo * d.Ho + ho + o) * 4 + kq) : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)mm, mplane, moff, 0, 0);
+                  }
+                }
+              }
+            }
+          }
+        } else {
         constexpr int NS = (PW * 4 / 2) * G::T;  // (tile pair, k-step) sequence, fully unrolled
         float ar[2][2];
         auto rd = [&](int sidx, float (&dst)[2]) {
@@ -437,6 +523,7 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
             }
           }
         }
+        }  // direct sweep
       }
     } else {
     if (!(dbg & 4)) {
@@ -799,6 +886,24 @@ __global__ void pack_cl_kernel(const float* __restrict__ w, float4* __restrict__
   packed[idx] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// Winograd F(2,3)-along-H weights of the first block (Cin <= 3, 16 couts), packed BEHIND the direct ones:
+// [r 0..3][q 0..6][lane] with lane = (cout = lane&15, kq = lane>>4), k = 4q + kq = (c, tz, ty), U = G g:
+// U0 = g0, U1 = (g0+g1+g2)/2, U2 = (g0-g1+g2)/2, U3 = g2 over the three taps along H.
+__global__ void pack_planar_wino_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cin, int Cout) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 4 * 7 * 64) return;
+  const int lane = idx & 63, q = (idx >> 6) % 7, r = (idx >> 6) / 7;
+  const int co = lane & 15, k = q * 4 + (lane >> 4);
+  float u = 0.0f;
+  const int c = k / 9;
+  if (k < 27 && c < Cin && co < Cout) {
+    const float* g = w + ((int64_t)co * Cin + c) * 27 + (k % 9) * 3;   // taps (tz, ty, tx = 0..2): k % 9 = tz*3 + ty
+    const float g0 = g[0], g1 = g[1], g2 = g[2];
+    u = r == 0 ? g0 : r == 1 ? ((g0 + g1) + g2) * 0.5f : r == 2 ? ((g0 - g1) + g2) * 0.5f : g2;
+  }
+  packed[idx] = u;
+}
+
 __global__ void pack_planar_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cin,
                                    int Cout, int NT) {
   const int total = Cin * 7 * NT * 64;
@@ -819,7 +924,7 @@ extern "C" int64_t lr_conv3d_packed_floats(int Cin, int Cout, int in_layout) {
   if (Cin < 1 || (Cout != 16 && Cout != 32)) return LR_EUNSUPPORTED;
   const int NT = Cout / 16;
   if (in_layout == LR_LAYOUT_NDHWC || in_layout == LR_LAYOUT_NDHWC_HPS) return (int64_t)27 * ((Cin + 15) / 16) * NT * 64 * 4;
-  if (in_layout == LR_LAYOUT_NCDHW) return (int64_t)Cin * 7 * NT * 64;
+  if (in_layout == LR_LAYOUT_NCDHW) return (int64_t)Cin * 7 * NT * 64 + ((Cin <= 3 && NT == 1) ? 4 * 7 * 64 : 0);
   return LR_EINVAL;
 }
 
@@ -839,6 +944,8 @@ extern "C" int lr_conv3d_pack_weights_f32(const float* weight, float* packed, in
     const int total = Cin * 7 * NT * 64;
     hipLaunchKernelGGL(pack_planar_kernel, dim3((total + 255) / 256), dim3(256), 0,
                        lr_stream(stream), weight, packed, Cin, Cout, NT);
+    if (Cin <= 3 && NT == 1)
+      hipLaunchKernelGGL(pack_planar_wino_kernel, dim3(7), dim3(256), 0, lr_stream(stream), weight, packed + total, Cin, Cout);
   } else {
     return LR_EINVAL;
   }
@@ -939,9 +1046,18 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
       if (rc != LR_EUNSUPPORTED || bpa) return rc;
     }
     if (bpa) return LR_EUNSUPPORTED;
-    if (mask_out) {  // training forward of the first block: activation + LeakyReLU sign mask (uint16 per voxel)
+    // the Winograd F(2,3)-along-H sweep (default for the model's first block); LIFTREG_CONV0_DIRECT=1 selects the direct
+    // sweep (the exact fmaf chain of the oracle; A/B aid)
+    const bool wino = !getenv("LIFTREG_CONV0_DIRECT") && Cin <= 3 && vec4;
+    if (mask_out) {  // training forward of the first block: activation + LeakyReLU sign mask (one byte per channel quad)
       if (!(stride == 1 && NT == 1 && single && vec4)) return LR_EUNSUPPORTED;
-      if (out_layout == LR_LAYOUT_NDHWC_HPS)
+      if (out_layout == LR_LAYOUT_NDHWC_HPS && wino)
+        hipLaunchKernelGGL((conv3d_planar_kernel<1, 1, 3, true, LR_LAYOUT_NDHWC_HPS, true, true>), grid, block, lds1, st, in, packed_w, bias,
+                           out, d, out_layout, negative_slope, vec4, ni, npass, 0, in0, mask_out);
+      else if (out_layout == LR_LAYOUT_NDHWC && wino)
+        hipLaunchKernelGGL((conv3d_planar_kernel<1, 1, 3, true, LR_LAYOUT_NDHWC, true, true>), grid, block, lds1, st, in, packed_w, bias,
+                           out, d, out_layout, negative_slope, vec4, ni, npass, 0, in0, mask_out);
+      else if (out_layout == LR_LAYOUT_NDHWC_HPS)
         hipLaunchKernelGGL((conv3d_planar_kernel<1, 1, 3, true, LR_LAYOUT_NDHWC_HPS, true>), grid, block, lds1, st, in, packed_w, bias,
                            out, d, out_layout, negative_slope, vec4, ni, npass, 0, in0, mask_out);
       else if (out_layout == LR_LAYOUT_NDHWC)
@@ -951,7 +1067,13 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
         return LR_EUNSUPPORTED;
       return lr_launch_status();
     }
-    if (stride == 1 && NT == 1 && single && out_layout == LR_LAYOUT_NDHWC_HPS) {        // the model's first block
+    if (stride == 1 && NT == 1 && single && out_layout == LR_LAYOUT_NDHWC_HPS && wino) {        // the model's first block
+      hipLaunchKernelGGL((conv3d_planar_kernel<1, 1, 3, true, LR_LAYOUT_NDHWC_HPS, false, true>), grid, block, lds1, st, in, packed_w, bias,
+                         out, d, out_layout, negative_slope, vec4, ni, npass, dbg, in0, nullptr);
+    } else if (stride == 1 && NT == 1 && single && out_layout == LR_LAYOUT_NDHWC && wino) {
+      hipLaunchKernelGGL((conv3d_planar_kernel<1, 1, 3, true, LR_LAYOUT_NDHWC, false, true>), grid, block, lds1, st, in, packed_w, bias,
+                         out, d, out_layout, negative_slope, vec4, ni, npass, dbg, in0, nullptr);
+    } else if (stride == 1 && NT == 1 && single && out_layout == LR_LAYOUT_NDHWC_HPS) {
       hipLaunchKernelGGL((conv3d_planar_kernel<1, 1, 3, true, LR_LAYOUT_NDHWC_HPS>), grid, block, lds1, st, in, packed_w, bias,
                          out, d, out_layout, negative_slope, vec4, ni, npass, dbg, in0);
     } else if (stride == 1 && NT == 1 && single && out_layout == LR_LAYOUT_NDHWC) {

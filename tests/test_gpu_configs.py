@@ -201,10 +201,12 @@ def test_reference_native_size_160(dev):
     assert abs(float(loss) - float(ro.ncc_loss(ref["warped"], ref["target"]))) < 1e-5
 
 
-def test_first_block_full_size_store_paths_agree(dev):
-    """Block 0 at 256^3 (three co-resident persistent blocks per CU): the channels-last outputs go through unconditional
-    bounds-checked buffer stores, the NCDHW output through plain stores — same values; and the split-input entry point
-    equals the concatenated one at this size."""
+def test_first_block_full_size_store_paths_agree(dev, monkeypatch):
+    """Block 0 at 256^3 (three co-resident persistent blocks per CU).  With the DIRECT sweep (LIFTREG_CONV0_DIRECT=1) the
+    channels-last outputs (unconditional bounds-checked buffer stores) and the NCDHW output (plain stores) hold the same
+    bits, and the split-input entry point equals the concatenated one.  The default Winograd F(2,3)-along-H sweep of the
+    channels-last paths gives the same bits on both of its layouts and entry points, and differs from the direct sum by
+    rounding only (every one of the 256^3 x 16 outputs within 4e-6 absolute at |y| <= 4)."""
     from liftreg_amd import ops
     n = 256
     g = torch.Generator(device=dev)
@@ -214,12 +216,21 @@ def test_first_block_full_size_store_paths_agree(dev):
     w = torch.randn((16, 3, 3, 3, 3), device=dev, generator=g) / 9
     b = torch.randn(16, device=dev, generator=g) * 0.1
     x = torch.cat([x0, rest], 1)
-    y_nc = ops.conv3d_k3_lrelu(x, w, b, 1, out_layout=ops.LAYOUT_NCDHW)
+    y_nc = ops.conv3d_k3_lrelu(x, w, b, 1, out_layout=ops.LAYOUT_NCDHW)          # always the direct sweep
+    monkeypatch.setenv("LIFTREG_CONV0_DIRECT", "1")
     y_cl = ops.conv3d_k3_lrelu(x, w, b, 1, out_layout=ops.LAYOUT_NDHWC)
     assert torch.equal(y_cl.permute(0, 4, 1, 2, 3), y_nc)
     del y_cl
     y_hps = ops.conv3d_first_split(x0, rest, w, b, out_layout=ops.LAYOUT_NDHWC_HPS)
     assert torch.equal(ops.hps_to_ndhwc(y_hps).permute(0, 4, 1, 2, 3), y_nc)
+    del y_hps
+    monkeypatch.delenv("LIFTREG_CONV0_DIRECT")
+    w_cl = ops.conv3d_k3_lrelu(x, w, b, 1, out_layout=ops.LAYOUT_NDHWC)          # Winograd sweep
+    w_hps = ops.conv3d_first_split(x0, rest, w, b, out_layout=ops.LAYOUT_NDHWC_HPS)
+    assert torch.equal(ops.hps_to_ndhwc(w_hps), w_cl)
+    del w_hps
+    err = float((w_cl.permute(0, 4, 1, 2, 3) - y_nc).abs().max())
+    assert err <= 4e-6 and float(y_nc.abs().max()) <= 4.0, err
 
 
 @pytest.mark.parametrize("grad_dtype", ["fp32", "bf16"])

@@ -160,7 +160,15 @@ def test_conv_full_size_all_layers_vs_independent_gpu_conv(ops, dev):
             xin = cur_ncdhw.permute(0, 2, 3, 4, 1).contiguous()
             y_nc = ops.conv3d_k3_lrelu(xin, w, b, s, in_layout=ops.LAYOUT_NDHWC, out_layout=ops.LAYOUT_NCDHW)
             y_cl = ops.conv3d_k3_lrelu(xin, w, b, s, in_layout=ops.LAYOUT_NDHWC, out_layout=ops.LAYOUT_NDHWC)
-        assert torch.equal(y_cl.permute(0, 4, 1, 2, 3), y_nc), f"layer {i}: layouts disagree"
+        if i == 0:
+            # block 0: the channels-last output runs the Winograd F(2,3)-along-H sweep, the NCDHW output the direct one —
+            # equal to rounding (and BOTH are held to the independent conv below)
+            assert float((y_cl.permute(0, 4, 1, 2, 3) - y_nc).abs().max()) <= 4e-6, "layer 0: layouts disagree"
+            errw = (y_cl.permute(0, 4, 1, 2, 3) - ref).abs()
+            assert int((errw > 1e-4 * ref.abs() + 2e-5).sum()) <= 256, f"layer 0 (Winograd sweep): max err {float(errw.max()):.3e}"
+            del errw
+        else:
+            assert torch.equal(y_cl.permute(0, 4, 1, 2, 3), y_nc), f"layer {i}: layouts disagree"
         err = (y_nc - ref).abs()
         tol = 1e-4 * ref.abs() + 2e-5
         bad = (err > tol).nonzero()
