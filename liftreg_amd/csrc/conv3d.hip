@@ -411,8 +411,13 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
             const float* dp = brick + woff[q] + (un >> 1) * G::RSL + (un & 1) * 32;
             dst[0] = dp[0]; dst[1] = dp[1]; dst[2] = dp[2]; dst[3] = dp[3];
           };
-          float dv[2][4];
-          rd4(0, dv[0]);
+#ifndef LR_WINO_AHEAD
+#define LR_WINO_AHEAD 1
+#endif
+          constexpr int WA = LR_WINO_AHEAD, WNB = WA + 1;
+          float dv[WNB][4];
+#pragma unroll
+          for (int a0 = 0; a0 < WA; ++a0) rd4(a0, dv[a0 % WNB]);
           f32x4 dacc[4];
 #pragma clang loop unroll(full)
           for (int sidx = 0; sidx < NSW; ++sidx) {
@@ -422,14 +427,14 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
 #pragma unroll
               for (int r = 1; r < 4; ++r) dacc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            if (sidx + 1 < NSW) rd4(sidx + 1, dv[(sidx + 1) & 1]);
-            const float* dc = dv[sidx & 1];
+            if (sidx + WA < NSW) rd4(sidx + WA, dv[(sidx + WA) % WNB]);
+            const float* dc = dv[sidx % WNB];
             const float v0 = dc[0] - dc[2], v1 = dc[1] + dc[2], v2 = dc[2] - dc[1], v3 = dc[1] - dc[3];
             dacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uw[0][q], v0, dacc[0], 0, 0, 0);
             dacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uw[1][q], v1, dacc[1], 0, 0, 0);
             dacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(uw[2][q], v2, dacc[2], 0, 0, 0);
             dacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(uw[3][q], v3, dacc[3], 0, 0, 0);
-            if (sidx + 1 < NSW) {   // per step: the two LDS reads of the next step, then the 4 differences + 4 MFMAs
+            if (sidx + WA < NSW) {   // per step: the two LDS reads of a later step, then the 4 differences + 4 MFMAs
               __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
               __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
               __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
