@@ -125,7 +125,8 @@ int lr_backproject_coords_poseless_f64(const double* poses, double* grid, int P,
  *   src/liftreg/layers/layers.py:335-372 as wired at …Backproj.py:29-33,95-100
  *
  * lr_conv3d_pack_weights_f32: weight (Cout,Cin,3,3,3) -> MFMA B-operand order.
- *   packed needs lr_conv3d_packed_floats(Cin,Cout) floats.
+ *   packed needs lr_conv3d_packed_floats(Cin,Cout,in_layout) floats (channels-last: the 27 taps + 9 Winograd sums
+ *   w(ty=0)+w(ty=2) per (tz,tx); NCDHW with Cin<=3: the direct fragments + the F(2,3) ones).
  * lr_conv3d_k3_lrelu_f32:
  *   in  : dev; LR_LAYOUT_NCDHW (B,Cin,D,W,H) or LR_LAYOUT_NDHWC (B,D,W,H,Cin)
  *   out : dev; (B,Cout,Do,Wo,Ho) or (B,Do,Wo,Ho,Cout); Xo = (X-1)/stride+1
@@ -159,6 +160,19 @@ int lr_conv3d_pack_weights_f32(const float* weight, float* packed, int Cin, int 
 int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, const float* bias, float* out,
                            int B, int Cin, int Cout, int D, int W, int H, int stride,
                            int in_layout, int out_layout, float negative_slope, void* stream);
+/* Arithmetic of the stride-2 blocks on a parity-split input (in_layout LR_LAYOUT_NDHWC_HPS, Cin in {16,32}; blocks 1..5
+ * of the encoder): Winograd F(2,2) along W in fp32 on the same MFMA (conv3d_rows.hip) — 10 row products per 4 output rows
+ * instead of 12, coefficients +-1; results agree with the direct fmaf chain (the CPU oracle) to ~3e-6 of the activation
+ * scale and are NOT bit-identical to it.  The first block (NCDHW input, Cin <= 3, H % 4 == 0) likewise uses F(2,3) along
+ * H.  Environment LIFTREG_CONV_DIRECT=1 / LIFTREG_CONV0_DIRECT=1 select the direct kernels (the oracle's bits).
+ *
+ * lr_conv3d_k3_lrelu_zphase_f32 = lr_conv3d_k3_lrelu_f32 for a z-SLAB of a larger volume (the sharded model,
+ * liftreg_amd/parallel.py): z_phase in {0,1} = parity of the GLOBAL output plane that local output plane 0 is.  The
+ * Winograd rows kernel orders a plane's three input planes by that parity, so a slab gets, plane for plane, the bits of
+ * the unsharded launch.  Kernels without such an order ignore it. */
+int lr_conv3d_k3_lrelu_zphase_f32(const float* in, const float* packed_w, const float* bias, float* out,
+                                  int B, int Cin, int Cout, int D, int W, int H, int stride,
+                                  int in_layout, int out_layout, float negative_slope, int z_phase, void* stream);
 
 /* ------------------------------------------------------------------------
  * K4  Linear (+ optional LeakyReLU) for the small-batch FC head.

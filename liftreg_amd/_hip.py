@@ -39,6 +39,7 @@ SIGNATURES = {
     "lr_conv3d_packed_floats": (_i64, [_i, _i, _i]),
     "lr_conv3d_pack_weights_f32": (_i, [_p, _p, _i, _i, _i, _p]),
     "lr_conv3d_k3_lrelu_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "lr_conv3d_k3_lrelu_zphase_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "lr_conv3d_k3_lrelu_mask_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "lr_linear_lrelu_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _p]),
     "lr_pca_reconstruct_f32": (_i, [_p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _p]),

@@ -874,7 +874,9 @@ __global__ __launch_bounds__(256, 3) void conv3d_cl_rows_kernel(const float* __r
 // i.e. the MFMA A-operand (rows = couts) of one k-step is one coalesced 256-B read.
 __global__ void pack_cl_kernel(const float* __restrict__ w, float4* __restrict__ packed, int Cin,
                                int Cout, int CB, int NT) {
-  const int total = 27 * CB * NT * 64;
+  // taps 27..35 = (tz, tx): w(tz, ty=0, tx) + w(tz, ty=2, tx), the M2 fragments of the Winograd-along-W rows kernel
+  // (conv3d_rows.hip); every other kernel reads the first 27 taps only
+  const int total = 36 * CB * NT * 64;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int lane = idx & 63;
@@ -886,7 +888,10 @@ __global__ void pack_cl_kernel(const float* __restrict__ w, float4* __restrict__
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int ci = cb * 16 + (lane >> 4) * 4 + m;
-    v[m] = (co < Cout && ci < Cin) ? w[((int64_t)co * Cin + ci) * 27 + tap] : 0.0f;
+    const float* g = w + ((int64_t)co * Cin + ci) * 27;
+    if (!(co < Cout && ci < Cin)) v[m] = 0.0f;
+    else if (tap < 27) v[m] = g[tap];
+    else v[m] = g[((tap - 27) / 3) * 9 + (tap - 27) % 3] + g[((tap - 27) / 3) * 9 + 6 + (tap - 27) % 3];
   }
   packed[idx] = make_float4(v[0], v[1], v[2], v[3]);
 }
@@ -928,7 +933,7 @@ __global__ void pack_planar_kernel(const float* __restrict__ w, float* __restric
 extern "C" int64_t lr_conv3d_packed_floats(int Cin, int Cout, int in_layout) {
   if (Cin < 1 || (Cout != 16 && Cout != 32)) return LR_EUNSUPPORTED;
   const int NT = Cout / 16;
-  if (in_layout == LR_LAYOUT_NDHWC || in_layout == LR_LAYOUT_NDHWC_HPS) return (int64_t)27 * ((Cin + 15) / 16) * NT * 64 * 4;
+  if (in_layout == LR_LAYOUT_NDHWC || in_layout == LR_LAYOUT_NDHWC_HPS) return (int64_t)36 * ((Cin + 15) / 16) * NT * 64 * 4;
   if (in_layout == LR_LAYOUT_NCDHW) return (int64_t)Cin * 7 * NT * 64 + ((Cin <= 3 && NT == 1) ? 4 * 7 * 64 : 0);
   return LR_EINVAL;
 }
@@ -942,7 +947,7 @@ extern "C" int lr_conv3d_pack_weights_f32(const float* weight, float* packed, in
   if (in_layout == LR_LAYOUT_NDHWC || in_layout == LR_LAYOUT_NDHWC_HPS) {
     if (Cin % 4) return LR_EUNSUPPORTED;
     const int CB = (Cin + 15) / 16;
-    const int total = 27 * CB * NT * 64;
+    const int total = 36 * CB * NT * 64;
     hipLaunchKernelGGL(pack_cl_kernel, dim3((total + 255) / 256), dim3(256), 0, lr_stream(stream),
                        weight, reinterpret_cast<float4*>(packed), Cin, Cout, CB, NT);
   } else if (in_layout == LR_LAYOUT_NCDHW) {
@@ -966,7 +971,8 @@ struct FusedBp {  // host-side description of the views for the fused first bloc
 static int conv_impl(const float* in, const float* in0, const float* packed_w, const float* bias,
                      float* out, int B, int Cin, int Cout, int D, int W, int H,
                      int stride, int in_layout, int out_layout,
-                     float negative_slope, void* stream, const FusedBp* bpa = nullptr, unsigned char* mask_out = nullptr) {
+                     float negative_slope, void* stream, const FusedBp* bpa = nullptr, unsigned char* mask_out = nullptr,
+                     int z_phase = 0) {
   if (bpa) in = in0;   // no channel-1.. tensor exists: the staging never dereferences `in` for them
   if (!in || !packed_w || !out) return LR_ENULL;
   if (B < 1 || Cin < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
@@ -998,6 +1004,13 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
     const float4* wt = reinterpret_cast<const float4*>(packed_w);
     const size_t occ_lds = getenv("LIFTREG_CONV_LDS") ? (size_t)atoi(getenv("LIFTREG_CONV_LDS")) : 0;  // tuning aid: caps resident blocks
     const bool rows_ok = ps && (Cin == 16 || Cin == 32) && !getenv("LIFTREG_CONV_TAPMAJOR");  // tuning aid: the tap-major kernel
+    // default for the parity-split stride-2 blocks: conv3d_rows.hip (persistent, Winograd F(2,2) along W, fragments in
+    // LDS); LIFTREG_CONV_DIRECT=1 selects the direct walk below — the oracle's fmaf chain, bit for bit (A/B aid, tests)
+    if (rows_ok && !getenv("LIFTREG_CONV_DIRECT")) {
+      const int rc = lr_internal_conv_rows_wlds(in, packed_w, bias, out, B, Cin, Cout, D, W, H, out_layout, negative_slope,
+                                                z_phase, st);
+      if (rc != LR_EUNSUPPORTED) return rc;
+    }
     if (rows_ok && Cin == 16 && NT == 1) hipLaunchKernelGGL((conv3d_cl_rows_kernel<1, 1>), grid, block, occ_lds, st, in, wt, bias, out, d, out_layout, negative_slope);
     else if (rows_ok && Cin == 16) hipLaunchKernelGGL((conv3d_cl_rows_kernel<2, 1>), grid, block, occ_lds, st, in, wt, bias, out, d, out_layout, negative_slope);
     else if (rows_ok && NT == 1) hipLaunchKernelGGL((conv3d_cl_rows_kernel<1, 2>), grid, block, occ_lds, st, in, wt, bias, out, d, out_layout, negative_slope);
@@ -1121,6 +1134,18 @@ extern "C" int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, co
                                       float negative_slope, void* stream) {
   return conv_impl(in, nullptr, packed_w, bias, out, B, Cin, Cout, D, W, H, stride, in_layout, out_layout, negative_slope,
                    stream);
+}
+
+// lr_conv3d_k3_lrelu_f32 for a z-SLAB of a larger volume: z_phase = (global output plane of local output plane 0) & 1.
+// The Winograd rows kernel (conv3d_rows.hip) alternates the order in which neighbouring output planes walk their three
+// input planes by the plane's parity; a slab whose local plane 0 is an odd global plane passes z_phase = 1 and gets, plane
+// for plane, the bits of the unsharded launch.  Every other kernel ignores it.
+extern "C" int lr_conv3d_k3_lrelu_zphase_f32(const float* in, const float* packed_w, const float* bias, float* out, int B,
+                                             int Cin, int Cout, int D, int W, int H, int stride, int in_layout,
+                                             int out_layout, float negative_slope, int z_phase, void* stream) {
+  if (z_phase != 0 && z_phase != 1) return LR_EINVAL;
+  return conv_impl(in, nullptr, packed_w, bias, out, B, Cin, Cout, D, W, H, stride, in_layout, out_layout, negative_slope,
+                   stream, nullptr, nullptr, z_phase);
 }
 
 // The encoder's first block on cat([moving, views]) WITHOUT the concatenation: channel 0 from `in0` (B,1,D,W,H),

@@ -59,6 +59,12 @@ __device__ __forceinline__ double lr_wave_sum(double v) {
 // ncc.hip: fixed-order sum of per-block moment partials [R][nblk][5] -> moments [R][5] (one block per row)
 int lr_internal_ncc_reduce(const double* partial, double* moments, int R, int nblk, hipStream_t st);
 
+// conv3d_rows.hip: a stride-2 block (parity-split channels-last input, Cin = 16 | 32) as the persistent Winograd-along-W
+// rows kernel with its weight fragments in LDS (z_phase: parity of the global output plane of local plane 0).
+// LR_EUNSUPPORTED -> use conv3d.hip's kernels.
+int lr_internal_conv_rows_wlds(const float* in, const float* packed_w, const float* bias, float* out, int B, int Cin,
+                               int Cout, int D, int W, int H, int out_layout, float slope, int z_phase, hipStream_t st);
+
 // conv0_pc.hip: the first block as a producer/consumer kernel (double-buffered LDS brick; proj != NULL: channels 1..P
 // are the backprojection of the views, computed by the producers).  LR_EUNSUPPORTED -> use the single-buffer kernel.
 int lr_internal_conv0_pc(const float* in0, int64_t bs0, const float* in_rest, int64_t bsr, const float* packed_w,

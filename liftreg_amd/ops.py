@@ -261,10 +261,12 @@ def conv3d_mask_supported(x, weight, stride, in_layout, out_layout):
 
 
 def conv3d_k3_lrelu(x, weight, bias, stride, *, in_layout=LAYOUT_NCDHW, out_layout=LAYOUT_NCDHW,
-                    negative_slope=0.2, packed=None, out=None, mask_out=None):
+                    negative_slope=0.2, packed=None, out=None, mask_out=None, z_phase=0):
     """LeakyReLU(Conv3d(k3,p1,stride)(x)+b).  x is (B,Cin,D,W,H) for NCDHW, (B,D,W,H,Cin) for NDHWC.
     LAYOUT_NDHWC_HPS is NDHWC with every H row parity-split (even voxels, then odd): the private layout
     between a block and a following stride-2 block (see `hps_to_ndhwc`).
+    z_phase (0|1): x is a z-slab of a larger volume and local output plane 0 is an odd (1) / even (0) GLOBAL output
+    plane — the stride-2 Winograd kernel then reproduces the unsharded launch bit for bit (lr_conv3d_k3_lrelu_zphase_f32).
 
     Replaces convBlock (reference layers/layers.py:335-372).
     """
@@ -298,6 +300,11 @@ def conv3d_k3_lrelu(x, weight, bias, stride, *, in_layout=LAYOUT_NCDHW, out_layo
                                                               mask_out.data_ptr(), B, Cin, Cout, D, W, H, stride, in_layout,
                                                               out_layout, float(negative_slope), _stream()),
                        "lr_conv3d_k3_lrelu_mask_f32")
+        elif z_phase:
+            _hip.check(_hip.lib().lr_conv3d_k3_lrelu_zphase_f32(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B,
+                                                                Cin, Cout, D, W, H, stride, in_layout, out_layout,
+                                                                float(negative_slope), int(z_phase), _stream()),
+                       "lr_conv3d_k3_lrelu_zphase_f32")
         else:
             _hip.check(_hip.lib().lr_conv3d_k3_lrelu_f32(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B,
                                                          Cin, Cout, D, W, H, stride, in_layout, out_layout,

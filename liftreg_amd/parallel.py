@@ -207,12 +207,15 @@ class SlabShardedRegistration:
             blk = net.encoders[i]
             return net._bf16_layouts[i] if bf16 else (blk.in_layout, blk.out_layout)
 
-        def conv(i, x, out):
+        def conv(i, x, out, d0=0):
             blk = net.encoders[i]
             lin, lout = layouts(i)
             if not bf16:
+                # stride-2 blocks see [zero, halo, slab]: local output plane 1 is global plane (d0 of the block's input
+                # level) / 2, so local plane 0 has the parity of d0/2 - 1 (the Winograd kernel orders by global parity)
+                zp = ((d0 >> (i - 1) >> 1) - 1) & 1 if i >= 1 else 0
                 return ops.conv3d_k3_lrelu(x, blk.conv.weight, blk.conv.bias, blk.stride, in_layout=lin, out_layout=lout,
-                                           negative_slope=blk._slope, packed=net._packed_weight(i), out=out)
+                                           negative_slope=blk._slope, packed=net._packed_weight(i), out=out, z_phase=zp)
             if i == 0:
                 return ops.conv3d_first_bf16(x, blk.conv.weight, blk.conv.bias, out_layout=lout, negative_slope=blk._slope,
                                              packed=net._packed_weight(0, bf16=True), out=out)
@@ -253,7 +256,7 @@ class SlabShardedRegistration:
         halos = comm.shift_up(tops)
         o = lambda n: (n - 1) // 2 + 1
         acts_p, nrows = [], []
-        for blist, r, h in zip(bufs, rows, halos):
+        for blist, r, h, (d0, _) in zip(bufs, rows, halos, bounds):
             n_out = o(2 + r)                      # planes the block produces from [zero, halo, slab]: 1 filler + r/2
             b0 = blist[0]
             nb = torch.empty((len(blist), 1 + n_out, o(b0.shape[2]), o(b0.shape[3]), net.encoders[1].conv.out_channels),
@@ -263,7 +266,7 @@ class SlabShardedRegistration:
                     buf[:, 1].zero_()             # rank 0: the conv's own zero padding
                 else:
                     buf[:, 1].copy_(h[b])
-                conv(1, buf[:, :2 + r], nb[b:b + 1, 1:1 + n_out])
+                conv(1, buf[:, :2 + r], nb[b:b + 1, 1:1 + n_out], d0)
             acts_p.append(nb)
             nrows.append(r // 2)
         rows = nrows
@@ -272,13 +275,13 @@ class SlabShardedRegistration:
             tops = [a[:, 1 + r:2 + r].contiguous() for a, r in zip(acts_p, rows)]
             halos = comm.shift_up(tops)
             nxt, nrows = [], []
-            for a, r, h in zip(acts_p, rows, halos):
+            for a, r, h, (d0, _) in zip(acts_p, rows, halos, bounds):
                 a[:, 0].zero_()
                 if h is None:
                     a[:, 1].zero_()
                 else:
                     a[:, 1].copy_(h[:, 0])
-                y = conv(i, a, None)              # (B, 1 + r/2, ...) channels-last, or (B, 32, 1 + r/2, ...) for the last block
+                y = conv(i, a, None, d0)          # (B, 1 + r/2, ...) channels-last, or (B, 32, 1 + r/2, ...) for the last block
                 if i == 5:
                     nxt.append(y[:, :, 1:].contiguous())
                 else:

@@ -38,7 +38,8 @@ def test_argument_validation_without_gpu(hip):
     assert lib.lr_backproject_f32(None, None, None, 1, 1, 4, 4, 4, 4, 4, 0, 4, 64, None) == -2
     # first block: direct fragments (3·7·64) followed by the Winograd U fragments (4 r × 7 q × 64 lanes)
     assert lib.lr_conv3d_packed_floats(3, 16, 0) == 3 * 7 * 64 + 4 * 7 * 64
-    assert lib.lr_conv3d_packed_floats(16, 32, 1) == 27 * 1 * 2 * 64 * 4
+    # channels-last: 27 taps + the 9 Winograd sums w(ty=0)+w(ty=2) per (tz,tx), each (CB x NT) fragments of 64 float4
+    assert lib.lr_conv3d_packed_floats(16, 32, 1) == (27 + 9) * 1 * 2 * 64 * 4
     assert lib.lr_conv3d_packed_floats(3, 8, 0) == -3
     assert lib.lr_strerror(0) == b"ok" and lib.lr_strerror(-5).startswith(b"pointer")
     one = ctypes.c_float(0)

@@ -313,9 +313,11 @@ def test_conv_golden_all_layouts(golden, ops, dev, tag):
         assert np.array_equal(y3.cpu().numpy(), y2.permute(0, 4, 1, 2, 3).cpu().numpy())
 
 
-def test_conv_parity_split_layout(ops, dev):
+def test_conv_parity_split_layout(ops, dev, monkeypatch):
     """LAYOUT_NDHWC_HPS (even voxels of a row, then odd) as a block's output and as a stride-2 block's input
-    gives bit-identical results to plain NDHWC."""
+    gives bit-identical results to plain NDHWC — with the direct stride-2 walk (LIFTREG_CONV_DIRECT=1: the oracle's
+    fmaf chain; the default Winograd rows kernel has its own test, test_winograd_rows_kernel_matches_direct)."""
+    monkeypatch.setenv("LIFTREG_CONV_DIRECT", "1")
     rs = np.random.RandomState(21)
     for (D, W, H), B in (((10, 9, 20), 2), ((7, 8, 34), 1), ((16, 16, 64), 1)):
         x = T(rs.uniform(-1, 1, (B, 3, D, W, H)).astype(np.float32), dev)
@@ -339,6 +341,54 @@ def test_conv_parity_split_layout(ops, dev):
     from liftreg_amd import _hip
     with pytest.raises(_hip.LiftRegHipError):                                     # odd H cannot be parity-split
         ops.conv3d_k3_lrelu(torch.zeros(1, 4, 4, 5, 16, device=dev), w1, b1, 2, in_layout=ops.LAYOUT_NDHWC_HPS)
+
+
+def _to_hps(x):
+    """(B,D,W,H,C) channels-last -> LAYOUT_NDHWC_HPS rows [C/16][parity of h][H/2][16] (H even, C % 16 == 0)."""
+    B, D, W, H, C = x.shape
+    h = torch.arange(H, device=x.device)
+    inv = torch.empty(H, dtype=torch.long, device=x.device)
+    inv[(h & 1) * (H // 2) + (h >> 1)] = h
+    return x.reshape(B, D, W, H, C // 16, 16)[:, :, :, inv].permute(0, 1, 2, 4, 3, 5).reshape(B, D, W, H, C).contiguous()
+
+
+def test_winograd_rows_kernel_matches_direct(ops, dev, monkeypatch):
+    """The default stride-2 kernel on parity-split input (conv3d_rows.hip: persistent, Winograd F(2,2) along W, fragments in
+    LDS) against the direct walk (the oracle's fmaf chain) and against the C oracle itself: same fp32 arithmetic, another
+    summation tree -> within 2e-5 of the activation scale (north_star: 1e-4 rel for fp32 convs).  Ragged shapes (odd D/W,
+    W and Ho not multiples of the tile), every Cin/Cout combination, every output layout, few and many tiles (both work
+    orders), and z_phase = 1 on a slab == the matching planes of the whole volume, bit for bit."""
+    import oracle.c_oracle as co
+    rs = np.random.RandomState(77)
+    cases = [((9, 7, 12), 2, 16, 32), ((12, 18, 64), 1, 16, 32), ((5, 9, 34), 1, 32, 32), ((16, 16, 32), 2, 32, 16),
+             ((7, 6, 20), 1, 16, 16), ((40, 72, 96), 1, 16, 32), ((24, 40, 64), 2, 32, 32)]
+    for (D, W, H), B, ci, cout in cases:
+        x = T(rs.uniform(-1, 1, (B, D, W, H, ci)).astype(np.float32), dev)
+        w = T((rs.normal(0, 1, (cout, ci, 3, 3, 3)) / (27 * ci) ** 0.5).astype(np.float32), dev)
+        b = T(rs.uniform(-0.1, 0.1, cout).astype(np.float32), dev)
+        x_ps = _to_hps(x)
+        monkeypatch.setenv("LIFTREG_CONV_DIRECT", "1")
+        want = ops.conv3d_k3_lrelu(x_ps, w, b, 2, in_layout=ops.LAYOUT_NDHWC_HPS, out_layout=ops.LAYOUT_NDHWC)
+        monkeypatch.delenv("LIFTREG_CONV_DIRECT")
+        scale = float(want.abs().max())
+        got = ops.conv3d_k3_lrelu(x_ps, w, b, 2, in_layout=ops.LAYOUT_NDHWC_HPS, out_layout=ops.LAYOUT_NDHWC)
+        assert float((got - want).abs().max()) <= 2e-5 * scale, ((D, W, H), ci, cout)
+        assert not torch.equal(got, want) or D * W * H < 64          # it IS the other kernel
+        g2 = ops.conv3d_k3_lrelu(x_ps, w, b, 2, in_layout=ops.LAYOUT_NDHWC_HPS, out_layout=ops.LAYOUT_NCDHW)
+        assert torch.equal(g2, got.permute(0, 4, 1, 2, 3).contiguous())
+        if got.shape[3] % 2 == 0:
+            g3 = ops.conv3d_k3_lrelu(x_ps, w, b, 2, in_layout=ops.LAYOUT_NDHWC_HPS, out_layout=ops.LAYOUT_NDHWC_HPS)
+            assert torch.equal(ops.hps_to_ndhwc(g3), got)
+        if D * W * H * ci <= 200000:                                  # the C oracle (scalar loops) on the small cases
+            ref = co.conv3d_k3_lrelu(x.permute(0, 4, 1, 2, 3).contiguous().cpu().numpy(), w.cpu().numpy(), b.cpu().numpy(), 2, 0.2)
+            assert np.abs(got.permute(0, 4, 1, 2, 3).cpu().numpy() - ref).max() <= 2e-5 * scale
+        # a z-slab starting at global input plane 2: local output plane k = global plane k + 1, so local plane 0 is an
+        # ODD global plane -> z_phase = 1 reproduces the whole-volume bits (what the sharded model relies on)
+        if D >= 7:
+            sl = _to_hps(x[:, 2:].contiguous())
+            got_sl = ops.conv3d_k3_lrelu(sl, w, b, 2, in_layout=ops.LAYOUT_NDHWC_HPS, out_layout=ops.LAYOUT_NDHWC, z_phase=1)
+            # interior planes (local k >= 1: no zero padding below) equal global planes k + 1 bit for bit
+            assert torch.equal(got_sl[:, 1:], got[:, 2:]), ((D, W, H), ci, cout)
 
 
 def test_first_block_split_input_equals_concatenated(ops, dev):

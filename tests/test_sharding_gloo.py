@@ -68,7 +68,7 @@ class OracleOps:
         return False           # the shim writes no LeakyReLU sign masks
 
     def conv3d_k3_lrelu(self, x, weight, bias, stride, *, in_layout=0, out_layout=0, negative_slope=0.2, packed=None,
-                        out=None):
+                        out=None, z_phase=0):
         y = self.ro.conv_block(self._to_ncdhw(x, in_layout), weight.detach(), bias.detach(), stride, negative_slope)
         y = self._from_ncdhw(y, out_layout)
         if out is None:

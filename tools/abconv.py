@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--n", type=int, default=256)
+    ap.add_argument("--env-b", default="", help="NAME=VALUE: time the FIRST library a second time with this variable set (kernels read their A/B switches per launch)")
     ap.add_argument("--split", action="store_true", help="block 0 through lr_conv3d_first_split_f32 (the model's inference path)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -55,6 +56,10 @@ def main():
     bias = rnd(co) * 0.1
     stream = torch.cuda.current_stream().cuda_stream
     libs = [(os.path.basename(p), load(p)) for p in a.libs.split(",")]
+    envb = None
+    if a.env_b:
+        envb = a.env_b.split("=", 1)
+        libs.append((libs[0][0] + " " + a.env_b, libs[0][1]))
     outs, packs = [], []
     for name, h in libs:
         npk = h.lr_conv3d_packed_floats(ci, co, lin)
@@ -67,6 +72,11 @@ def main():
 
     def run(i):
         name, h = libs[i]
+        if envb:
+            if i == len(libs) - 1:
+                os.environ[envb[0]] = envb[1]
+            else:
+                os.environ.pop(envb[0], None)
         if a.split:
             rc = h.lr_conv3d_first_split_f32(x0.data_ptr(), xr.data_ptr(), packs[i].data_ptr(), bias.data_ptr(), outs[i].data_ptr(),
                                              B, ci, co, size, size, size, lout, 0.2, stream)
