@@ -83,7 +83,17 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void conv3d_rows_wlds_kernel(const f
                                                                           int ntiles, int xmap, int z_phase) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wl[];
   constexpr int NF4 = 36 * CB * NT * 64;  // float4s = the packed buffer, same order
-  for (int i = threadIdx.x; i < NF4; i += NWAVE * 64) reinterpret_cast<float4*>(wl)[i] = wp[i];
+  {
+    // all of a thread's fragment loads in flight at once (a copy loop would pay one memory round trip per iteration:
+    // 12 in a row for the 144 KB of a 32 -> 32 block, which is most of a small layer's run time)
+    constexpr int K = NF4 / (NWAVE * 64);
+    static_assert(K * NWAVE * 64 == NF4, "whole fragments per thread");
+    float4 t[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) t[k] = wp[threadIdx.x + k * NWAVE * 64];
+#pragma unroll
+    for (int k = 0; k < K; ++k) reinterpret_cast<float4*>(wl)[threadIdx.x + k * NWAVE * 64] = t[k];
+  }
   __syncthreads();  // the only barrier: from here on the waves are independent
 
   const int lane = threadIdx.x & 63;
@@ -378,6 +388,11 @@ int launch(const float* in, const float* packed_w, const float* bias, float* out
 int lr_internal_conv_rows_wlds(const float* in, const float* packed_w, const float* bias, float* out, int B, int Cin,
                                int Cout, int D, int W, int H, int out_layout, float slope, int z_phase, hipStream_t st) {
   if ((Cin != 16 && Cin != 32) || (Cout != 16 && Cout != 32) || (H & 1)) return LR_EUNSUPPORTED;
+  // Small planes (blocks 3..5 of the encoder: 32^2 outputs per plane and less) stay with conv3d.hip's direct kernels: a few
+  // hundred tiles cannot amortise the per-block fragment staging and the serial 27/54-row walk (measured at C3: 0.14 /
+  // 0.07 / 0.07 ms here against 0.12 / 0.03 / 0.03 ms).  The rule looks at the PLANE only, so a z-slab of a volume takes
+  // the same kernel as the whole volume (the sharded model is bit-identical to the unsharded one).
+  if ((int64_t)((W - 1) / 2 + 1) * ((H - 1) / 2 + 1) < 4096 && !getenv("LIFTREG_CONV_ROWS_ALWAYS")) return LR_EUNSUPPORTED;
   if (out_layout != LR_LAYOUT_NDHWC && out_layout != LR_LAYOUT_NDHWC_HPS && out_layout != LR_LAYOUT_NCDHW)
     return LR_EUNSUPPORTED;
   RowsDims d;

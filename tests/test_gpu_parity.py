@@ -361,8 +361,13 @@ def test_winograd_rows_kernel_matches_direct(ops, dev, monkeypatch):
     import oracle.c_oracle as co
     rs = np.random.RandomState(77)
     cases = [((9, 7, 12), 2, 16, 32), ((12, 18, 64), 1, 16, 32), ((5, 9, 34), 1, 32, 32), ((16, 16, 32), 2, 32, 16),
-             ((7, 6, 20), 1, 16, 16), ((40, 72, 96), 1, 16, 32), ((24, 40, 64), 2, 32, 32)]
+             ((7, 6, 20), 1, 16, 16), ((40, 72, 96), 1, 16, 32), ((24, 40, 64), 2, 32, 32), ((9, 128, 130), 1, 16, 32)]
     for (D, W, H), B, ci, cout in cases:
+        # the dispatcher keeps planes under 64 x 64 outputs on the direct kernels; the small cases force the rows kernel
+        if ((W - 1) // 2 + 1) * ((H - 1) // 2 + 1) < 4096:
+            monkeypatch.setenv("LIFTREG_CONV_ROWS_ALWAYS", "1")
+        else:
+            monkeypatch.delenv("LIFTREG_CONV_ROWS_ALWAYS", raising=False)
         x = T(rs.uniform(-1, 1, (B, D, W, H, ci)).astype(np.float32), dev)
         w = T((rs.normal(0, 1, (cout, ci, 3, 3, 3)) / (27 * ci) ** 0.5).astype(np.float32), dev)
         b = T(rs.uniform(-0.1, 0.1, cout).astype(np.float32), dev)
