@@ -18,6 +18,7 @@ HIP events on the launch stream inside the timed region.  `cpu_baseline` times t
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -341,6 +342,16 @@ def main():
             k.update(bound="hbm", achieved=info["bytes"] / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
         k["frac"] = k["achieved"] / k["peak"]
         k["traffic"] = None
+        # `achieved` counts ALGORITHMIC flops (2*27*Cin*Cout per output voxel).  The fp32 Winograd kernels issue fewer:
+        # 28 of 42 MFMAs in the first block (F(2,3) along H), 10 of 12 row products in the stride-2 blocks with planes of
+        # >= 64 x 64 outputs (F(2,2) along W) — `issued_share` x frac = the share of the fp32 MFMA peak the pipe really ran at.
+        m = re.match(r"conv3d_c(\d+)x(\d+)_s(\d)_(\d+)$", name)
+        if m and k["bound"] == "mfma":
+            ci, _, st_, dd = (int(g) for g in m.groups())
+            if st_ == 1 and ci <= 3 and not os.environ.get("LIFTREG_CONV0_DIRECT"):
+                k["issued_share"] = 28.0 / 42.0
+            elif st_ == 2 and ((dd - 1) // 2 + 1) ** 2 >= 4096 and not os.environ.get("LIFTREG_CONV_DIRECT"):
+                k["issued_share"] = 10.0 / 12.0
         kernels[name] = k
     # PMC-derived HBM bytes per launch (tools/pmc_bench.sh over this very command).  Every entry is stamped with the
     # kernel instance it was measured on and the sha256 of that kernel's source file: an entry whose source has changed
@@ -366,7 +377,9 @@ def main():
         k = kernels[name]
         return {"kernel": name, "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
                 "unit": k["unit"], "frac": k["frac"], "traffic": k["traffic"], "avg_ms": k["avg_ms"],
-                "traffic_measured_on": k.get("traffic_kernel")}
+                "traffic_measured_on": k.get("traffic_kernel"),
+                **({"flops": "algorithmic (direct conv); fp32 Winograd kernel", "mfma_issued_share": k["issued_share"],
+                    "frac_mfma_issued": k["frac"] * k["issued_share"]} if "issued_share" in k else {})}
 
     # the projector on its own and the simulate+register rate — outside the timed region
     drr = None

@@ -46,12 +46,18 @@ def op_table(cfg, P, bf16):
     ops = [("backproject", r"^backproject_(tiled_)?kernel", 0), ("pca_warp", r"^pca_warp_kernel<.*, false>$", 0),
            ("pca_warp_ncc", r"^pca_warp_kernel<.*, true>$", 0), ("ncc_moments", r"^ncc_moments_kernel", 0),
            (f"conv3d_c{P + 1}x16_s1_{n}", r"^conv3d_planar_kernel", 0), (f"conv3d_bp_c{P + 1}x16_s1_{n}", r"^conv0_pc_kernel<.*, true>$", 0),
-           (f"conv3d_c16x32_s2_{n}", r"^conv3d_cl_rows_kernel<2, 1>", 0)]
-    size, rank = n // 2, 0
+           (f"conv3d_c16x32_s2_{n}", r"^conv3d_rows_wlds_kernel<2, 1,", 0)]
+    # stride-2 blocks: planes of >= 64 x 64 outputs run the persistent Winograd rows kernel (one grid size for all of them:
+    # told apart by rank only if there are several), smaller ones the direct rows kernel
+    size, rank_w, rank_d = n // 2, 0, 0
     while size >= 16:
-        ops.append((f"conv3d_c32x32_s2_{size}", r"^conv3d_cl_rows_kernel<2, 2>", rank))
+        if (size // 2) ** 2 >= 4096:
+            ops.append((f"conv3d_c32x32_s2_{size}", r"^conv3d_rows_wlds_kernel<2, 2,", rank_w))
+            rank_w += 1
+        else:
+            ops.append((f"conv3d_c32x32_s2_{size}", r"^conv3d_cl_rows_kernel<2, 2>", rank_d))
+            rank_d += 1
         size //= 2
-        rank += 1
     return ops
 
 
