@@ -174,6 +174,20 @@ int lr_conv3d_k3_lrelu_zphase_f32(const float* in, const float* packed_w, const 
                                   int B, int Cin, int Cout, int D, int W, int H, int stride,
                                   int in_layout, int out_layout, float negative_slope, int z_phase, void* stream);
 
+/* Training backward of the encoder's first two blocks in ONE kernel (conv3d_bwd_fused.hip): the data gradient of block 1
+ * (16 <- 32 channels, stride 2), the LeakyReLU mask of block 0 and the weight / bias gradient of block 0 — the (B,D,W,H,16)
+ * pre-activation gradient of block 0 (8.6 GB at 256^3 x 8) is never written: nothing but block 0's weight gradient reads it.
+ *   gpre1 (B,Do,Wo,Ho,32) fp32 plain channels-last = pre-activation gradient of block 1; packed_w1T =
+ *   lr_conv3d_pack_weights_f32 of block 1's weight transposed to (16,32,3,3,3), layout NDHWC (as lr_conv3d_dgrad_f32 takes);
+ *   mask0 (B,D,W,H,4) uint8 = block 0's LR_LAYOUT_SIGN4 mask (4-byte aligned); x0 (B,Cin0,D,W,H) fp32 = block 0's input,
+ *   Cin0 in {2,3}; H % 4 == 0; partial: lr_conv3d_dgrad_wgrad0_partial_floats(Cin0) floats of scratch.
+ * Results: gw0 (16,Cin0,3,3,3), gb0 (16) = lr_conv3d_dgrad_f32(x_layout SIGN4) + lr_conv3d_wgrad_f32 up to fp32 summation
+ * order.  Replaces autograd of layers.py:365-369 for blocks 0/1 (RegistrationNet.py:401). */
+int64_t lr_conv3d_dgrad_wgrad0_partial_floats(int Cin0);
+int lr_conv3d_dgrad_wgrad0_f32(const float* gpre1, const float* packed_w1T, const uint8_t* mask0, float slope0,
+                               const float* x0, float* partial, float* gw0, float* gb0, int B, int Cin0, int D, int W,
+                               int H, void* stream);
+
 /* ------------------------------------------------------------------------
  * K4  Linear (+ optional LeakyReLU) for the small-batch FC head.
  * Replaces FullyConnectBlock: src/liftreg/layers/layers.py:413-439

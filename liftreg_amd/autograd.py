@@ -47,6 +47,39 @@ class ConvBlockFn(torch.autograd.Function):
         return gx, gw, (gb if has_bias else None), None, None, None, None, None, None, None, None, None
 
 
+class ConvPair01Fn(torch.autograd.Function):
+    """The encoder's first two blocks (3 -> 16 stride 1, 16 -> 32 stride 2) as ONE autograd node (fp32 training).
+
+    Forward: the two block kernels, the first also writing its LeakyReLU sign mask.  Backward: block 1's weight gradient,
+    then ops_bwd.conv3d_dgrad_wgrad0 — block 1's data gradient, block 0's mask and block 0's weight / bias gradient in one
+    kernel.  As two nodes (ConvBlockFn twice) the (B,D,W,H,16) gradient between the blocks is written by one kernel and read
+    back by the next (8.6 GB each way at 256^3 x 8) although nothing else uses it: the encoder input is data.
+    `premasked_grad`: as in ConvBlockFn, for block 1's output (block 2's data gradient applied block 1's mask already)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, slope0, slope1, mid_layout, out_layout, packed0, packed1, premasked_grad):
+        B, _, D, W, H = x.shape
+        mask0 = torch.empty((B, D, W, H, w0.shape[0] // 4), dtype=torch.uint8, device=x.device)
+        y0 = ops.conv3d_k3_lrelu(x, w0, b0, 1, in_layout=_hip.LAYOUT_NCDHW, out_layout=mid_layout, negative_slope=slope0,
+                                 packed=packed0, mask_out=mask0)
+        y1 = ops.conv3d_k3_lrelu(y0, w1, b1, 2, in_layout=mid_layout, out_layout=out_layout, negative_slope=slope1,
+                                 packed=packed1)
+        ctx.save_for_backward(x, w0, w1, y0, y1, mask0)
+        ctx.cfg = (slope0, slope1, mid_layout, out_layout, b0 is not None, b1 is not None, premasked_grad)
+        return y1
+
+    @staticmethod
+    def backward(ctx, gy1):
+        x, w0, w1, y0, y1, mask0 = ctx.saved_tensors
+        slope0, slope1, mid_layout, out_layout, has_b0, has_b1, premasked = ctx.cfg
+        gy1 = gy1.contiguous()
+        gpre1 = gy1 if premasked else ops_bwd.lrelu_bwd(gy1, out_layout, y1, out_layout, slope1)
+        _, gw1, gb1 = ops_bwd.conv3d_bwd(y0, mid_layout, w1, y1, out_layout, gpre1, _hip.LAYOUT_NDHWC, 2, slope1,
+                                         need_gx=False, gy_is_gpre=True)
+        gw0, gb0 = ops_bwd.conv3d_dgrad_wgrad0(gpre1, w1, mask0, slope0, x)
+        return (None, gw0, gb0 if has_b0 else None, gw1, gb1 if has_b1 else None, None, None, None, None, None, None, None)
+
+
 class EncoderBf16Fn(torch.autograd.Function):
     """The six conv blocks of the bf16 variant (conv_dtype="bf16") as ONE autograd node: the activations between the
     blocks are bfloat16 tensors in private layouts, which autograd could not carry gradients for (a gradient must

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..autograd import DecodeFn, EncoderBf16Fn
+from ..autograd import ConvPair01Fn, DecodeFn, EncoderBf16Fn
 from ..layers.layers import convBlock, FullyConnectBlock, GaussianSmoothing
 from ..utils.net_utils import Bilinear, identity_axis_tables
 
@@ -142,6 +142,10 @@ class model(nn.Module):
         # samples takes issue slots from the MFMAs — 4.05 ms fused vs 3.31 + 0.27 ms as two kernels.
         # Worth it where HBM capacity/traffic matters more than the 4 % (the volume is 1.08 GB per batch of 8).
         self.fuse_backproject = bool(_opt(opt, "fuse_backproject", False))
+        # optional (non-reference) key "fuse_first_backward" (default True): in fp32 training the first two encoder blocks
+        # are one autograd node whose backward computes block 1's data gradient and block 0's weight gradient in one kernel
+        # (autograd.ConvPair01Fn); False = one node per block (the gradient between them goes through memory)
+        self.fuse_first_backward = bool(_opt(opt, "fuse_first_backward", True))
         self._poses = None         # geometry of the first batch's element 0, cached like :85-87
         self._packed = {}          # conv weights in MFMA operand order, keyed by parameter version
         self._pca_slabs = {}       # compact per-rank column slabs of the basis (pca_slab)
@@ -321,7 +325,17 @@ class model(nn.Module):
                                                  out_layout=lout, negative_slope=blk._slope,
                                                  packed=self._packed_weight(i, bf16=True))
             return self.encoders[6](x)
-        for i in range(6):
+        first = 0
+        b0, b1 = self.encoders[0], self.encoders[1]
+        if (self.fuse_first_backward and needs_grad and b0.conv.weight.requires_grad and b1.conv.weight.requires_grad and
+                b0.premasked_grad and b1.stride == 2 and b0.out_layout == b1.in_layout and
+                ops.conv3d_mask_supported(x, b0.conv.weight, b0.stride, b0.in_layout, b0.out_layout) and
+                tuple(b1.conv.weight.shape[:2]) == (32, 16) and x.shape[1] in (2, 3) and x[0].numel() * 4 < 2 ** 31 - 1):
+            # training, fp32: blocks 0 and 1 as one autograd node — the gradient between them never reaches memory
+            x = ConvPair01Fn.apply(x, b0.conv.weight, b0.conv.bias, b1.conv.weight, b1.conv.bias, b0._slope, b1._slope,
+                                   b0.out_layout, b1.out_layout, self._packed_weight(0), self._packed_weight(1), b1.premasked_grad)
+            first = 2
+        for i in range(first, 6):
             x = self.encoders[i](x, packed=self._packed_weight(i))
         return self.encoders[6](x)
 

@@ -246,3 +246,41 @@ def test_sign_mask_from_the_first_block_replaces_the_activation_re_read(dev, mon
                 assert torch.equal(g_act, g_bit), (shape, lay, old)
                 assert torch.equal(gw_a, gw_b)
             monkeypatch.delenv("LIFTREG_DGRAD_OLD", raising=False)
+
+
+@pytest.mark.gpu
+def test_fused_first_blocks_backward_matches_two_kernels(dev):
+    """lr_conv3d_dgrad_wgrad0_f32 (block 1's data gradient + block 0's LeakyReLU mask + block 0's weight / bias gradient in one
+    kernel, the 16-channel gradient between them never written) against the two-kernel path it replaces
+    (conv3d_bwd of block 1 with the sign mask -> gpre0, conv3d_bwd of block 0 on it) and against float64 torch autograd of the
+    same two blocks: ragged sizes (odd D / W, H not a multiple of 32, several tiles per axis), 2 and 3 input channels."""
+    from liftreg_amd import ops, ops_bwd
+    rs = np.random.RandomState(18)
+    for shape, B, cin0 in (((8, 8, 64), 2, 3), ((7, 9, 36), 1, 3), ((18, 6, 40), 1, 2), ((34, 10, 68), 1, 3)):
+        D, W, H = shape
+        x0 = T(rs.uniform(-1, 1, (B, cin0) + shape).astype(np.float32), dev)
+        w0 = T(rs.normal(0, 0.3, (16, cin0, 3, 3, 3)).astype(np.float32), dev)
+        b0 = T(rs.normal(0, 0.1, 16).astype(np.float32), dev)
+        w1 = T(rs.normal(0, 0.2, (32, 16, 3, 3, 3)).astype(np.float32), dev)
+        lay = ops.LAYOUT_NDHWC_HPS
+        mask = torch.empty((B, D, W, H, 4), dtype=torch.uint8, device=dev)
+        y0 = ops.conv3d_k3_lrelu(x0, w0, b0, 1, in_layout=ops.LAYOUT_NCDHW, out_layout=lay, mask_out=mask)
+        y1 = ops.conv3d_k3_lrelu(y0, w1, None, 2, in_layout=lay, out_layout=ops.LAYOUT_NDHWC)
+        gpre1 = T(rs.normal(0, 1, tuple(y1.shape)).astype(np.float32), dev)
+        assert ops_bwd.conv3d_dgrad_wgrad0_supported(x0, mask, w1)
+        gw0, gb0 = ops_bwd.conv3d_dgrad_wgrad0(gpre1, w1, mask, 0.2, x0)
+        gpre0, _, _ = ops_bwd.conv3d_bwd(y0, lay, w1, y1, ops.LAYOUT_NDHWC, gpre1, ops.LAYOUT_NDHWC, 2, gy_is_gpre=True,
+                                         mask_input_slope=0.2, x_sign4=mask)
+        _, gw_ref, gb_ref = ops_bwd.conv3d_bwd(x0, ops.LAYOUT_NCDHW, w0, y0, lay, gpre0, ops.LAYOUT_NDHWC, 1, need_gx=False,
+                                               gy_is_gpre=True)
+        sw, sb = float(gw_ref.abs().max()), float(gb_ref.abs().max())
+        assert float((gw0 - gw_ref).abs().max()) <= 2e-5 * sw, (shape, cin0, float((gw0 - gw_ref).abs().max()), sw)
+        assert float((gb0 - gb_ref).abs().max()) <= 2e-5 * sb, (shape, cin0)
+        # float64 autograd of the two blocks (CPU): d/dw0, d/db0 of <conv1(lrelu(conv0(x0))), gpre1>
+        xd = x0.double().cpu()
+        w0d, b0d = w0.double().cpu().requires_grad_(True), b0.double().cpu().requires_grad_(True)
+        y0d = torch.nn.functional.leaky_relu(torch.nn.functional.conv3d(xd, w0d, b0d, padding=1), 0.2)
+        y1d = torch.nn.functional.conv3d(y0d, w1.double().cpu(), None, stride=2, padding=1)
+        (y1d * gpre1.permute(0, 4, 1, 2, 3).double().cpu()).sum().backward()
+        assert float((gw0.cpu().double() - w0d.grad).abs().max()) <= 1e-4 * float(w0d.grad.abs().max()), (shape, cin0)
+        assert float((gb0.cpu().double() - b0d.grad).abs().max()) <= 1e-4 * float(b0d.grad.abs().max()), (shape, cin0)
