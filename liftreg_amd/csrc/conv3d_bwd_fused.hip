@@ -192,18 +192,21 @@ __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __res
       unsigned mw[2][WMT][4];
       // the mask dwords of the class pair first, a whole pair ahead of their use: one resource per batch element, the
       // row as the scalar offset, the voxel (2*(xq0 + 4kq + r) + px) as one per-lane offset + immediates; a row outside
-      // the volume reads through the zero-length resource, a voxel past its row reads a neighbour (masked below)
+      // the volume reads through the zero-length resource, a voxel past its row reads a neighbour or, past the tensor, zeros (masked below)
 #pragma unroll
       for (int mt = 0; mt < WMT; ++mt) {
         const int y = 2 * (yq0 + mt) + py;
         const __amdgpu_buffer_rsrc_t rsm = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<unsigned*>(mask0 + (int64_t)b * d.D * d.W * d.H), (short)0, y < d.W ? (int)((int64_t)d.D * d.W * d.H * 4) : 0, 0x00020000);
         const unsigned rowb = (unsigned)((z * d.W + y) * d.H * 4);
+        // this lane's 8 voxels 2*(4kq + r) + px of the row are 8 consecutive dwords: two 16-byte loads
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rsm, mvoff, rowb, 0);
+        const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rsm, mvoff + 16u, rowb, 0);
 #pragma unroll
-        for (int px = 1; px >= 0; --px)
+        for (int px = 0; px < 2; ++px)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            mw[px][mt][r] = __builtin_amdgcn_raw_buffer_load_b32(rsm, mvoff + (unsigned)((2 * r + px) * 4), rowb, 0);
+          for (int r = 0; r < 4; ++r) mw[px][mt][r] = r < 2 ? lo[2 * r + px] : hi[2 * (r - 2) + px];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
