@@ -553,6 +553,159 @@ __global__ __launch_bounds__(512, 2) void conv3d_dgrad_wlds_kernel(const float* 
   }
 }
 
+// The same persistent weights-in-LDS scheme for the 32 -> 32 blocks (gx has 32 channels: blocks 2..5, 116 GFLOP at block 2):
+// 27 taps x 2 channel blocks x 2 gx tiles of fragments = 108 KB of LDS, which leaves room for a window of ONE quotient row
+// (9 x 2 x 17 voxels x 36 floats = 43 KB): a tile is 8 x 1 x 16 quotient voxels, a wave again one quotient plane; per step
+// one window read feeds the two gx tiles (8 MFMAs per 3 LDS reads, as above), the two tiles alternate on the matrix pipe.
+// conv3d_dgrad_lds_kernel<2,2> (fragments from global memory inside the k-loop, 2 x 16 KB of LDS per block) ran block 2 at
+// 43 % of the fp32 MFMA peak.  MK: 0 no mask, 1 the producer's fp32 activation in NDHWC, 2 in NDHWC_HPS.
+template <int MK>
+__global__ __launch_bounds__(512, 1) void conv3d_dgrad_wlds32_kernel(const float* __restrict__ gpre,
+                                                                     const float4* __restrict__ wp, float* __restrict__ gx,
+                                                                     const float* __restrict__ xsave, DgDims d, int ntiles) {
+  constexpr int CBv = 2, NT = 2, CG = 32, VS = CG + 4, C4 = CG / 4, NVOX = 9 * 2 * 17, NCH = NVOX * C4;
+  constexpr int NIT = (NCH + 511) / 512;
+  constexpr int NWF = 27 * CBv * NT * 64;  // float4 weight fragments
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  float4* wl = reinterpret_cast<float4*>(dsm);  // [27][CB][NT][64 lanes]
+  float* ts = dsm + NWF * 4;                     // [9][2][17][VS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    constexpr int K = (NWF + 511) / 512;  // all of a thread's fragment loads in flight at once
+    float4 t4[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) t4[k] = wp[min(tid + k * 512, NWF - 1)];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (tid + k * 512 < NWF) wl[tid + k * 512] = t4[k];
+  }
+  const int nDq = (d.Do + 7) / 8;
+  auto tile_coords = [&](int t, int& b, int& zq0, int& yq, int& xq0) {
+    const int hq = t % d.nHq; t /= d.nHq;
+    yq = t % d.Wo; t /= d.Wo;
+    const int dq = t % nDq;
+    b = t / nDq;
+    zq0 = dq * 8; xq0 = hq * 16;
+  };
+  float4 st[NIT];
+  auto prefetch = [&](int t) {
+    int b, zq0, yq, xq0;
+    tile_coords(t, b, zq0, yq, xq0);
+    const float* base = gpre + ((((int64_t)b * d.Do + zq0) * d.Wo + yq) * d.Ho + xq0) * CG;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = it * 512 + tid;
+      const int vox = q / C4, c4 = q % C4;
+      const int xx = vox % 17, r = vox / 17, yy = r % 2, zz = r / 2;
+      const bool ok = q < NCH && zq0 + zz < d.Do && yq + yy < d.Wo && xq0 + xx < d.Ho;
+      const unsigned voff = ok ? (unsigned)(((((zz * d.Wo) + yy) * d.Ho + xx) * CG + c4 * 4) * 4) : OOR;
+      st[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+    }
+  };
+  const int col = lane & 15, kq = lane >> 4;
+  const float* lts = ts + col * VS + kq * 4;
+  int t = (int)blockIdx.x;
+  if (t < ntiles) prefetch(t);
+  for (; t < ntiles; t += (int)gridDim.x) {
+    __syncthreads();  // every wave is done with the previous tile (first pass: the weights are in LDS after the next one)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = it * 512 + tid;
+      if (q < NCH) *reinterpret_cast<float4*>(ts + (q / C4) * VS + (q % C4) * 4) = st[it];
+    }
+    __syncthreads();
+    int b, zq0, yq, xq0;
+    tile_coords(t, b, zq0, yq, xq0);
+    if (t + (int)gridDim.x < ntiles) prefetch(t + (int)gridDim.x);  // lands while this tile runs on the matrix pipe
+    const int zq = zq0 + wave, xq = xq0 + col;
+    float4 a0, a1, b0[NT], b1[NT];
+    for (int pp = 3; pp >= 0; --pp) {
+      const int py = pp & 1, pz = pp >> 1;
+      const int z = 2 * zq + pz, y = 2 * yq + py;
+      if (z >= d.D || y >= d.W) continue;  // wave-uniform; no barrier inside the class loop
+      f32x4 accp[2][NT];
+      f32x4 xv[2][NT];  // the producer's activation at this lane's voxel (4 channels per gx tile)
+      const int64_t rowv = (((int64_t)b * d.D + z) * d.W + y) * d.H;  // voxel index of the row's start
+      if constexpr (MK != 0) {
+#pragma unroll
+        for (int px = 1; px >= 0; --px)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int x = 2 * xq + px;
+            const bool ok = x < d.H;
+            if constexpr (MK == 1) xv[px][nt] = *reinterpret_cast<const f32x4*>(xsave + (rowv + (ok ? x : 0)) * 32 + nt * 16 + kq * 4);
+            if constexpr (MK == 2)
+              xv[px][nt] = *reinterpret_cast<const f32x4*>(xsave + rowv * 32 + ((int64_t)nt * d.H + (ok ? px * (d.H >> 1) + xq : 0)) * 16 + kq * 4);
+          }
+        __builtin_amdgcn_sched_barrier(0);  // the scheduler otherwise sinks these loads to the store epilogue
+      }
+#pragma unroll
+      for (int px = 1; px >= 0; --px) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) accp[px][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int NS = (1 << (px + py + pz)) * CBv;
+        auto load_step = [&](int s, float4& a, float4 (&bw)[NT]) {
+          const int tapi = s / CBv, cb = s - tapi * CBv;
+          const int ix = tapi & px, r1 = tapi >> px, iy = r1 & py, iz = (r1 >> py) & pz;
+          const int tx = px ? 2 * ix : 1, ox = px ? 1 - ix : 0;
+          const int ty = py ? 2 * iy : 1, oy = py ? 1 - iy : 0;
+          const int tz = pz ? 2 * iz : 1, oz = pz ? 1 - iz : 0;
+          const int sfull = ((tz * 3 + ty) * 3 + tx) * CBv + cb;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bw[nt] = wl[(sfull * NT + nt) * 64 + lane];
+          a = *reinterpret_cast<const float4*>(lts + (((wave + oz) * 2 + oy) * 17 + ox) * VS + cb * 16);
+        };
+        auto mfma_step = [&](const float4& a, const float4 (&bw)[NT]) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) accp[px][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[nt].x, a.x, accp[px][nt], 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) accp[px][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[nt].y, a.y, accp[px][nt], 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) accp[px][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[nt].z, a.z, accp[px][nt], 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) accp[px][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[nt].w, a.w, accp[px][nt], 0, 0, 0);
+        };
+        load_step(0, a0, b0);
+        for (int s2 = 0; s2 + 1 < NS; s2 += 2) {
+          load_step(s2 + 1, a1, b1);
+          mfma_step(a0, b0);
+          load_step(min(s2 + 2, NS - 1), a0, b0);
+          mfma_step(a1, b1);
+        }
+      }
+      // mask first, for all four tiles of the pair, THEN the stores (see conv3d_dgrad_wlds_kernel)
+      if constexpr (MK != 0) {
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            f32x4 v = accp[px][nt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = xv[px][nt][r] > 0.0f ? v[r] : v[r] * d.slope;
+            accp[px][nt] = v;
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int64_t row = rowv * 32;
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        const int x = 2 * xq + px;
+        if (x < d.H) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int64_t o = d.gx_layout == LR_LAYOUT_NDHWC ? row + (int64_t)x * 32 + nt * 16 + kq * 4
+                                                             : row + ((int64_t)nt * d.H + (px * (d.H >> 1) + xq)) * 16 + kq * 4;
+            *reinterpret_cast<f32x4*>(gx + o) = accp[px][nt];
+          }
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ wgrad
 // gw[co][ci][tap] = sum_{b, o} gpre[b, o, co] * X[b, ci, s*o + tap - 1]
 // MFMA: rows = co (NTC tiles of 16), cols = 16 "columns" n of an N-tile, k = 4 consecutive output voxels
@@ -1398,6 +1551,30 @@ extern "C" int lr_conv3d_dgrad_f32(const float* gpre, const float* packed_wT, fl
       if (CBv == 2) LR_DGW_MK(2); else LR_DGW_MK(1);
 #undef LR_DGW_MK
 #undef LR_DGW
+      return lr_launch_status();
+    }
+  }
+  if (Cx == 32 && Cg == 32 && mk >= 0 && mk <= 2 && !getenv("LIFTREG_DGRAD_OLD")) {
+    // 32-channel gx (blocks 2..5): persistent 8-wave blocks, all fragments in LDS (conv3d_dgrad_wlds32_kernel)
+    const int nDq2 = (d.Do + 7) / 8;
+    const int64_t nt = (int64_t)B * nDq2 * d.Wo * d.nHq;
+    if (nt <= 0x7fffffffLL && (int64_t)10 * d.Wo * d.Ho * Cg * 4 < 0x7fffffffLL) {
+      const size_t ldsb = ((size_t)27 * 2 * 2 * 64 * 4 + (size_t)9 * 2 * 17 * (Cg + 4)) * sizeof(float);
+      int resident = 256;  // one 8-wave block per CU
+      if (const char* e = getenv("LIFTREG_DGRAD_BLOCKS")) resident = atoi(e);  // tuning aid
+      const dim3 g2((unsigned)(nt < resident ? nt : resident)), b2(512);
+#define LR_DGW32(MKV)                                                                                                      \
+  do {                                                                                                                    \
+    static bool attr_done = false;                                                                                        \
+    if (!attr_done) {                                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_dgrad_wlds32_kernel<MKV>),                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);                                   \
+      attr_done = true;                                                                                                   \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((conv3d_dgrad_wlds32_kernel<MKV>), g2, b2, ldsb, st, gpre, wt, gx, xs_eff, d, (int)nt);            \
+  } while (0)
+      if (mk == 0) LR_DGW32(0); else if (mk == 1) LR_DGW32(1); else LR_DGW32(2);
+#undef LR_DGW32
       return lr_launch_status();
     }
   }
