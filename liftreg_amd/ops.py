@@ -717,7 +717,7 @@ def disp_reg(disp, nblk=None):
     if C3 != 3:
         raise ValueError("disp must be (B,3,D,W,H)")
     if nblk is None:
-        nblk = max(1, min(2048 // B if B < 2048 else 1, (D * W * H + 1023) // 1024))
+        nblk = max(1, min(4096, (D * W * H + 1023) // 1024))   # partial sums per batch element (the marching kernel: 3 x row blocks x plane chunks)
     partial = torch.empty((B, nblk), dtype=torch.float64, device=disp.device)
     out = torch.empty((), dtype=torch.float32, device=disp.device)
     with _timed("disp_reg", bytes=4 * disp.numel()):

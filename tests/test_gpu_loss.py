@@ -43,3 +43,22 @@ def test_subspace_loss_plugin_vs_restatement():
     ramp = torch.zeros((1, 3, n, n, n), device=dev)
     ramp[:, 0] = torch.linspace(-1, 1, n, device=dev)[:, None, None] * 0.05    # 0.05·x along D in normalised units
     assert abs(float(ops.disp_reg(ramp)) - 0.05 ** 2) < 1e-7
+
+
+def test_disp_reg_marching_kernel_equals_vector_kernel(monkeypatch):
+    """The z-marching regulariser (rows with H >= 64: a block walks plane chunks, in-plane neighbours from an LDS tile) against the
+    vectorised kernel it replaces (LIFTREG_REG_NOMARCH=1) and the torch oracle: ragged D / W (rows and planes that do not fill
+    the last block / chunk), several H, few and many partials per batch element."""
+    from liftreg_amd import ops
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(31)
+    for shape, B, nblk in (((5, 9, 64), 2, None), ((37, 10, 128), 1, 7), ((33, 7, 96), 2, 64), ((20, 33, 256), 1, None), ((3, 2, 64), 1, 3)):
+        disp = rs.normal(0, 0.05, (B, 3) + shape).astype(np.float32)
+        d = torch.from_numpy(disp).to(dev)
+        got = float(ops.disp_reg(d, nblk=nblk))
+        monkeypatch.setenv("LIFTREG_REG_NOMARCH", "1")
+        old = float(ops.disp_reg(d, nblk=nblk))
+        monkeypatch.delenv("LIFTREG_REG_NOMARCH")
+        want = float(ro.disp_reg(torch.from_numpy(disp)))
+        assert abs(got - old) <= 2e-6 * abs(old), (shape, got, old)
+        assert abs(got - want) <= 1e-5 * abs(want), (shape, got, want)
