@@ -137,6 +137,22 @@ def test_fuzz_conv_forward_and_backward(dev):
         tag = str((cin, cout, s, shape, B, xl, yl))
         ygpu = yplain.permute(0, 4, 1, 2, 3).cpu()
         np.testing.assert_allclose(ygpu.numpy(), yref.detach().numpy(), rtol=1e-4, atol=1e-5, err_msg="fwd " + tag)
+        if not first and xl == ops.LAYOUT_NDHWC_HPS:
+            # the persistent Winograd rows kernel (default only for planes of >= 64 x 64 outputs) forced onto this small case,
+            # every output layout it has, and as a z-slab with the other plane parity
+            os.environ["LIFTREG_CONV_ROWS_ALWAYS"] = "1"
+            try:
+                for lay2 in (ops.LAYOUT_NDHWC, ops.LAYOUT_NCDHW) + ((ops.LAYOUT_NDHWC_HPS,) if ho % 2 == 0 else ()):
+                    y2 = ops.conv3d_k3_lrelu(xd, T(w, dev), T(b, dev), s, in_layout=xl, out_layout=lay2)
+                    y2 = y2 if lay2 == ops.LAYOUT_NCDHW else (ops.hps_to_ndhwc(y2) if lay2 == ops.LAYOUT_NDHWC_HPS else y2).permute(0, 4, 1, 2, 3)
+                    np.testing.assert_allclose(y2.cpu().numpy(), yref.detach().numpy(), rtol=1e-4, atol=1e-5, err_msg="rows " + tag)
+                if shape[0] >= 5:
+                    full = ops.conv3d_k3_lrelu(xd, T(w, dev), T(b, dev), s, in_layout=xl, out_layout=ops.LAYOUT_NDHWC)
+                    slab = ops.conv3d_k3_lrelu(xd[:, 2:].contiguous(), T(w, dev), T(b, dev), s, in_layout=xl,
+                                               out_layout=ops.LAYOUT_NDHWC, z_phase=1)
+                    assert torch.equal(slab[:, 1:], full[:, 2:]), "z_phase " + tag
+            finally:
+                del os.environ["LIFTREG_CONV_ROWS_ALWAYS"]
         # reference gradients through the LeakyReLU mask of the GPU's own output: a pre-activation within rounding
         # distance of 0 may sit on the other side on the CPU, and ONE flipped mask element moves the 27*Cin weight
         # gradients of its output channel by O(1) — that is a property of the comparison, not of the kernels
@@ -540,3 +556,30 @@ def test_fuzz_round2_kernels(dev, monkeypatch):
                 ("slab decode", case, D, W, H, Bd, Lat, lo, hi, bs.shape)
             m_sum += m_s.cpu().numpy()
         np.testing.assert_allclose(m_sum, m_want, rtol=1e-11, atol=1e-9, err_msg=str(("slab moments", case, D, W, H, Bd)))
+
+
+def test_fuzz_fused_first_blocks_backward(dev):
+    """lr_conv3d_dgrad_wgrad0_f32 on random extents (odd D / W, H a multiple of 4 up to several tiles, 2 or 3 input channels,
+    batch 1-2) against the two kernels it replaces."""
+    from liftreg_amd import ops, ops_bwd
+    rs = np.random.RandomState(733 + SEED)
+    for case in range(max(6, N_CASES // 4)):
+        D, W, H = int(rs.randint(2, 22)), int(rs.randint(2, 14)), 4 * int(rs.randint(2, 20))
+        B, cin0 = int(rs.randint(1, 3)), int(rs.choice([2, 3]))
+        x0 = T(rs.uniform(-1, 1, (B, cin0, D, W, H)).astype(np.float32), dev)
+        w0 = T(rs.normal(0, 0.3, (16, cin0, 3, 3, 3)).astype(np.float32), dev)
+        b0 = T(rs.normal(0, 0.1, 16).astype(np.float32), dev)
+        w1 = T(rs.normal(0, 0.2, (32, 16, 3, 3, 3)).astype(np.float32), dev)
+        lay = ops.LAYOUT_NDHWC_HPS
+        mask = torch.empty((B, D, W, H, 4), dtype=torch.uint8, device=dev)
+        y0 = ops.conv3d_k3_lrelu(x0, w0, b0, 1, in_layout=ops.LAYOUT_NCDHW, out_layout=lay, mask_out=mask)
+        y1 = ops.conv3d_k3_lrelu(y0, w1, None, 2, in_layout=lay, out_layout=ops.LAYOUT_NDHWC)
+        gpre1 = T(rs.normal(0, 1, tuple(y1.shape)).astype(np.float32), dev)
+        gw0, gb0 = ops_bwd.conv3d_dgrad_wgrad0(gpre1, w1, mask, 0.2, x0)
+        gpre0, _, _ = ops_bwd.conv3d_bwd(y0, lay, w1, y1, ops.LAYOUT_NDHWC, gpre1, ops.LAYOUT_NDHWC, 2, gy_is_gpre=True,
+                                         mask_input_slope=0.2, x_sign4=mask)
+        _, gw_ref, gb_ref = ops_bwd.conv3d_bwd(x0, ops.LAYOUT_NCDHW, w0, y0, lay, gpre0, ops.LAYOUT_NDHWC, 1, need_gx=False,
+                                               gy_is_gpre=True)
+        tag = str((D, W, H, B, cin0))
+        assert float((gw0 - gw_ref).abs().max()) <= 3e-5 * max(1e-3, float(gw_ref.abs().max())), tag
+        assert float((gb0 - gb_ref).abs().max()) <= 3e-5 * max(1e-3, float(gb_ref.abs().max())), tag
