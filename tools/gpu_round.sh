@@ -19,7 +19,7 @@ cat "$O/conv0_stamps.txt"
 bash tools/pmc_bench.sh $TAG/pmc > /dev/null 2>&1
 tail -n 3 "$O/pmc/summary.txt"
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/fwd" -- python3 "$R/bench.py" --no-cpu-baseline --no-drr --steps 10 --warmup 3 > "$O/fwd.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/fwd" -- python3 "$R/bench.py" --no-cpu-baseline --no-drr --ramp-seconds 0 --steps 10 --warmup 3 > "$O/fwd.log" 2>&1
 find "$O" -name "*kernel_trace.csv" -delete
 find "$O" -name "*agent_info.csv" -delete
 find "$O" -name "*kernel_stats.csv" | head -n 2

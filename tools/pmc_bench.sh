@@ -9,7 +9,7 @@ TAG=$1; shift
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-drr --steps 3 --warmup 1 $*"
+ARGS="--no-cpu-baseline --no-drr --ramp-seconds 0 --steps 3 --warmup 1 $*"
 i=0
 for G in \
   "FETCH_SIZE" \
