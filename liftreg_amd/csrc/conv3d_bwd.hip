@@ -851,11 +851,14 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nseg = (d.Ho + HB - 1) / HB;
   const int nwo = (d.Wo + ROWS - 1) / ROWS;
-  for (int i = tid; i < HB * 16; i += G::NTH) xs[G::XF4 * 4 + i] = 1.0f;
 
   // staging slots: chunk q = it*NTH + tid of the window, decoded once (brick-independent)
+  // xdec: pc | py << 8 | pz << 16 in 7-bit fields with a guard bit each, bits 24..26 = "pc / py / pz is 0", bit 27 = the slot
+  // is past the window.  Per brick one add of a bias vector makes every field that is past the volume overflow into its guard
+  // bit, so a chunk's validity is add + and + compare (the chain of short-circuit range tests it replaces compiled into ~20
+  // instructions and two exec-mask branches per chunk, issued by all waves at once right after the barrier).
   unsigned xrel[G::XIT];
-  int xdec[G::XIT];  // pz | py<<2 | pc<<5 | used<<13
+  unsigned xdec[G::XIT];
 #pragma unroll
   for (int it = 0; it < G::XIT; ++it) {
     const int q = it * G::NTH + tid;
@@ -864,7 +867,7 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
     const int cb = rc % CB, rowi = used ? rc / CB : 0;
     const int pz = rowi / NR, py = rowi % NR;
     const int pc = pos <= HB ? 2 * pos : 2 * (pos - HB - 1) + 1;
-    xdec[it] = pz | (py << 2) | (pc << 5) | (used ? 1 << 13 : 0);
+    xdec[it] = used ? (unsigned)(pc | (py << 8) | (pz << 16) | ((pc == 0) << 24) | ((py == 0) << 25) | ((pz == 0) << 26)) : 0x08000000u;
     const int hprel = (pc & 1) ? (pc - 1) / 2 : (d.H >> 1) - 1 + pc / 2;  // parity-split position relative to ho0
     if (XB)
       xrel[it] = (unsigned)(((((pz * d.W + py) * d.H + (HPS ? hprel : pc)) * Cin) + cb * 16 + c4 * 4) * 2);
@@ -874,18 +877,20 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
       xrel[it] = (unsigned)(((((pz * d.W + py) * d.H + pc) * Cin) + cb * 16 + c4 * 4) * 4);
   }
   // N-tiles of this wave: j = wave + NW*t -> (tap, cb); LDS float offset of the tile's first voxel (output row 0)
+  // (the bias gradient = column sums of gpre used to be a 28th tile multiplying by ones: a wave-uniform select per LDS read
+  // of every tile — 1.4 scalar instructions per MFMA by PMC — and 1/28 of the MFMAs; it is two vector adds per k-step now)
   int boff[G::T];
-  bool bones[G::T];
+  // (a wave whose last slot is past the 27*CB tiles recomputes its previous tile there and does not write it: no branch in the k-loop)
 #pragma unroll
   for (int t = 0; t < G::T; ++t) {
-    const int jr = wave + G::NW * t;  // tile 27*CB (one spare slot exists) multiplies by ones: sum of gpre = gb
-    const int j = min(jr, 27 * CB - 1);
+    const int j = min(wave + G::NW * t, 27 * CB - 1);
     const int tap = j / CB, cb = j % CB;
     const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
-    bones[t] = jr == 27 * CB;
-    boff[t] = (bones[t] ? G::XF4 * 4
-                        : (((tz * NR + ty) * CB + cb) * G::NCP + (tx == 1 ? HB + 1 : (tx >> 1))) * 16) + lane;
+    boff[t] = (((tz * NR + ty) * CB + cb) * G::NCP + (tx == 1 ? HB + 1 : (tx >> 1))) * 16 + lane;
   }
+  float bsum[NTC];
+#pragma unroll
+  for (int nt = 0; nt < NTC; ++nt) bsum[nt] = 0.0f;
   f32x4 acc[G::T][NTC];
 #pragma unroll
   for (int t = 0; t < G::T; ++t)
@@ -911,10 +916,12 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
     const void* xb = XB ? (const void*)(reinterpret_cast<const u16*>(xin) + xorg) : (const void*)(xin + xorg);
     const __amdgpu_buffer_rsrc_t rx =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(xb), (short)0, 0x7fffffff, 0x00020000);
+    auto bias7 = [](int rem) { return (unsigned)(128 - (rem < 0 ? 0 : rem > 128 ? 128 : rem)); };  // field >= rem -> guard bit
+    const unsigned vbias = bias7(d.H - xi0) | bias7(d.W - yi0) << 8 | bias7(d.D - zi0) << 16 | (live ? 0u : 0x08000000u);
+    const unsigned vmask = 0x18808080u | (unsigned)(xi0 < 0) << 24 | (unsigned)(yi0 < 0) << 25 | (unsigned)(zi0 < 0) << 26;
 #pragma unroll
     for (int it = 0; it < G::XIT; ++it) {
-      const int zi = zi0 + (xdec[it] & 3), yi = yi0 + ((xdec[it] >> 2) & 7), xi = xi0 + ((xdec[it] >> 5) & 255);
-      const bool ok = live && (xdec[it] >> 13) && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W && xi >= 0 && xi < d.H;
+      const bool ok = ((xdec[it] + vbias) & vmask) == 0u;
       const unsigned voff = ok ? xrel[it] : OOR;
       if (XB) {
         const f32x4 v = bf16x4_to_f32(__builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rx, voff, 0, 0)));
@@ -929,7 +936,7 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
       const void* gb = gbf ? (const void*)(reinterpret_cast<const u16*>(gpre) + gorg) : (const void*)(gpre + gorg);
       const __amdgpu_buffer_rsrc_t rg =
           __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(gb), (short)0, 0x7fffffff, 0x00020000);
-      const bool gok = live && tid < G::GF4 && ho0 + tid / (NTC * 4) < d.Ho && wo + rr < d.Wo;
+      const bool gok = (int)live & (int)(tid < G::GF4) & (int)(ho0 + tid / (NTC * 4) < d.Ho) & (int)(wo + rr < d.Wo);
       if (gbf) {
         const f32x4 v = bf16x4_to_f32(__builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rg, gok ? (unsigned)tid * 8u : OOR, 0, 0)));
         gst[rr] = make_float4(v[0], v[1], v[2], v[3]);
@@ -945,7 +952,7 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
     __syncthreads();  // the previous brick's reads are done
 #pragma unroll
     for (int it = 0; it < G::XIT; ++it)
-      if ((xdec[it] >> 13) & 1) *reinterpret_cast<float4*>(xs + (it * G::NTH + tid) * 4) = xst[it];
+      if (it * G::NTH + tid < G::XF4) *reinterpret_cast<float4*>(xs + (it * G::NTH + tid) * 4) = xst[it];  // compile-time true but for the last slot
     if (tid < G::GF4) {
       const int i = tid / (NTC * 4), c4 = tid % (NTC * 4);
 #pragma unroll
@@ -960,10 +967,13 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
       for (int ks = 0; ks < HB / 4; ++ks) {
         float a[NTC];
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) a[nt] = gs[rr * HB * NTC * 16 + nt * HB * 16 + ks * 64 + lane];
+        for (int nt = 0; nt < NTC; ++nt) {
+          a[nt] = gs[rr * HB * NTC * 16 + nt * HB * 16 + ks * 64 + lane];
+          bsum[nt] += a[nt];  // lane = (co, voxel 4ks + kq): the bias gradient's share of this lane
+        }
 #pragma unroll
         for (int t = 0; t < G::T; ++t) {
-          const float bv = xs[boff[t] + (bones[t] ? 0 : rr * 2 * G::ROWF) + ks * 64];
+          const float bv = xs[boff[t] + rr * 2 * G::ROWF + ks * 64];
 #pragma unroll
           for (int nt = 0; nt < NTC; ++nt)
             acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nt], bv, acc[t][nt], 0, 0, 0);
@@ -976,13 +986,22 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
 #pragma unroll
   for (int t = 0; t < G::T; ++t) {
     const int j = wave + G::NW * t;
-    if (j <= 27 * CB) {
+    if (j < 27 * CB) {
 #pragma unroll
       for (int nt = 0; nt < NTC; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           partial[((int64_t)blockIdx.x * Cout + nt * 16 + kq * 4 + r) * ncols + j * 16 + col] = acc[t][nt][r];
     }
+  }
+  // bias gradient: every wave summed the same gradient values (co = lane & 15 of tile nt, its own voxels kq): fold the four
+  // lane groups, wave 0 writes column 27*CB*16 (= gb_col of wgrad_finish_kernel)
+#pragma unroll
+  for (int nt = 0; nt < NTC; ++nt) {
+    float v = bsum[nt];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (wave == 0 && kq == 0) partial[((int64_t)blockIdx.x * Cout + nt * 16 + col) * ncols + 27 * CB * 16] = v;
   }
 }
 
