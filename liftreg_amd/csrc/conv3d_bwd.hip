@@ -430,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_dgrad_wlds_kernel(const float* 
       const int q = it * 512 + tid;
       const int vox = q / C4, c4 = q % C4;
       const int xx = vox % 17, r = vox / 17, yy = r % (WMT + 1), zz = r / (WMT + 1);
-      const bool ok = q < NCH && zq0 + zz < d.Do && yq0 + yy < d.Wo && xq0 + xx < d.Ho;
+      const bool ok = (int)(q < NCH) & (int)(zq0 + zz < d.Do) & (int)(yq0 + yy < d.Wo) & (int)(xq0 + xx < d.Ho);  // bitwise: no exec-mask branches
       const unsigned voff = ok ? (unsigned)(((((zz * d.Wo) + yy) * d.Ho + xx) * CG + c4 * 4) * 4) : OOR;
       st[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
     }
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_dgrad_wlds32_kernel(const float
       const int q = it * 512 + tid;
       const int vox = q / C4, c4 = q % C4;
       const int xx = vox % 17, r = vox / 17, yy = r % 2, zz = r / 2;
-      const bool ok = q < NCH && zq0 + zz < d.Do && yq + yy < d.Wo && xq0 + xx < d.Ho;
+      const bool ok = (int)(q < NCH) & (int)(zq0 + zz < d.Do) & (int)(yq + yy < d.Wo) & (int)(xq0 + xx < d.Ho);  // bitwise: no exec-mask branches
       const unsigned voff = ok ? (unsigned)(((((zz * d.Wo) + yy) * d.Ho + xx) * CG + c4 * 4) * 4) : OOR;
       st[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
     }
