@@ -145,6 +145,9 @@ __device__ __forceinline__ f32x4 bias_init(const float* __restrict__ bias, int n
 // owns tap 4q+kq, so one ds_read_b32 per lane feeds one MFMA.
 // ===========================================================================
 constexpr int PD = 4, PW = 4, PH = 64;
+#ifndef LR_C0_WINO_BLOCKS
+#define LR_C0_WINO_BLOCKS 3   // resident blocks per CU of the Winograd first-block kernel (138 registers; 4 = a 128-register build: 8 spills, 3.18 vs 3.07 ms)
+#endif
 
 // CC = channels staged per pass: 3 for stride 1 (P=2 views -> Cin=3: a single pass, 31 KB of LDS),
 // 1 for stride 2 (its brick is 4.4x larger; off the model's path).
@@ -187,7 +190,7 @@ struct PlanarGeom {
 // adds per accumulator.  fp32 throughout; results differ from the direct sum by rounding (~1e-7 relative: the data-side
 // transform has coefficients +-1 only).  The parity-split output row makes both stores of a pair contiguous KiBs.
 template <int NT, int S, int CC, bool SINGLE, int OUTL = -1, bool MASK = false, bool WINO = false>
-__global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(const float* __restrict__ in,
+__global__ __launch_bounds__(256, (SINGLE ? (WINO ? LR_C0_WINO_BLOCKS : 3) : 2)) void conv3d_planar_kernel(const float* __restrict__ in,
                                                             const float* __restrict__ wp,
                                                             const float* __restrict__ bias,
                                                             float* __restrict__ out, ConvDims d,
@@ -228,19 +231,16 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
   // Row decode and the offset relative to the window origin do not depend on the brick.
   const int lrow = lane / G::F4, lf4 = lane - lrow * G::F4;
   const bool lact = lane < G::RPI * G::F4;
-  unsigned srel[G::MAXIT];   // byte offset from the window origin (or OOR for an unused slot)
-  int sdst[G::MAXIT];        // LDS float index (or -1)
-  short srz[G::MAXIT], sry[G::MAXIT], scc[G::MAXIT];
-#pragma unroll
-  for (int it = 0; it < G::MAXIT; ++it) {
-    const int row = (it * 4 + wave) * G::RPI + lrow;
-    const int cc = row / (G::RD * G::RW), rz = (row / G::RW) % G::RD, ry = row % G::RW;
-    const bool used = lact && row < G::NROWS;
-    scc[it] = (short)cc; srz[it] = (short)rz; sry[it] = (short)ry;
-    const int ccr = (in0 && cc > 0) ? cc - 1 : cc;  // split input: channel index inside its own tensor
-    srel[it] = used ? (unsigned)(((int64_t)ccr * V + ((int64_t)rz * d.W + ry) * d.H + lf4 * 4) * 4) : OOR;
-    sdst[it] = used ? cc * G::CS + rz * G::PS + ry * G::RSL + lf4 * 4 : -1;
-  }
+  // The RPI rows of one wavefront load lie in ONE window plane of ONE channel (RW % RPI == 0): which channel / plane / first
+  // row a slot covers depends on (it, wave) only — scalars — and a lane adds its own row and float4.  (Per-slot VGPR
+  // descriptors — five arrays of MAXIT — cost this kernel 35 registers and its fourth resident block per CU.)
+  static_assert(G::RW % G::RPI == 0 && G::NROWS % G::RPI == 0, "a load instruction stays inside one window plane");
+  const unsigned lane_rel = (unsigned)((lrow * d.H + lf4 * 4) * 4);   // byte offset of the lane inside its slot's first row
+  const int lane_dst = lrow * G::RSL + lf4 * 4;                        // LDS float index, likewise
+  auto slot_cc = [&](int it) { return ((it * 4 + wave) * G::RPI) / (G::RD * G::RW); };
+  auto slot_rz = [&](int it) { return (((it * 4 + wave) * G::RPI) / G::RW) % G::RD; };
+  auto slot_ry = [&](int it) { return ((it * 4 + wave) * G::RPI) % G::RW; };
+  auto slot_used = [&](int it) { return (it * 4 + wave) * G::RPI < G::NROWS; };
 
   auto item_coords = [&](int item, int& b, int& dq, int& wq, int& hq, int& pass) {
     pass = item % npass;
@@ -267,14 +267,18 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
     // flight and drains the queue — prefetch included — at the next wait); the edge test costs ~8 ALU ops per slot
     const int xi = x0 + lf4 * 4;
     const bool xok = xi >= 0 && xi + 3 < d.H;  // multiple of 4 and H % 4 == 0: entirely in or out
+    const __amdgpu_buffer_rsrc_t rsrc_null = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(org), (short)0, 0, 0x00020000);
 #pragma unroll
     for (int it = 0; it < G::MAXIT; ++it) {
-      const int zi = z0 + srz[it], yi = y0 + sry[it];
-      const bool ok = xok & (zi >= 0) & (zi < d.D) & (yi >= 0) & (yi < d.W) & (c0 + scc[it] < d.Cin);
-      const unsigned voff = srel[it] | (ok ? 0u : OOR);
-      // a slot's rows belong to ONE channel (3 rows per slot, 36 per channel): the resource choice is wave-uniform
-      const bool ch0 = __builtin_amdgcn_readfirstlane((int)scc[it]) == 0;
-      st[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ch0 ? rsrc_c0 : rsrc, voff, 0, 0));
+      const int cc = slot_cc(it), rz = slot_rz(it), ry0 = slot_ry(it);   // wave-uniform
+      const int zi = z0 + rz, yi = y0 + ry0 + lrow;
+      const bool sok = slot_used(it) & (zi >= 0) & (zi < d.D) & (c0 + cc < d.Cin);   // scalar: else the zero-length resource
+      const bool ok = lact & xok & (yi >= 0) & (yi < d.W);
+      const int ccr = (in0 && cc > 0) ? cc - 1 : cc;  // split input: channel index inside its own tensor
+      const unsigned soff = (unsigned)(((int64_t)ccr * V + ((int64_t)rz * d.W + ry0) * d.H) * 4);
+      // a slot's rows belong to ONE channel: the resource choice is wave-uniform
+      st[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(!sok ? rsrc_null : cc == 0 ? rsrc_c0 : rsrc,
+                                                                                 ok ? lane_rel : OOR, soff, 0));
     }
   };
 
@@ -312,7 +316,8 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv3d_planar_kernel(co
     if (vec4) {
 #pragma unroll
       for (int it = 0; it < G::MAXIT; ++it)
-        if (sdst[it] >= 0) *reinterpret_cast<float4*>(brick + sdst[it]) = st[it];
+        if (slot_used(it) && lact)
+          *reinterpret_cast<float4*>(brick + slot_cc(it) * G::CS + slot_rz(it) * G::PS + slot_ry(it) * G::RSL + lane_dst) = st[it];
     } else {  // H % 4 != 0 or unaligned base: scalar staging of the same window, no prefetch
       int b, dq, wq, hq, pass;
       item_coords(unit_item(u), b, dq, wq, hq, pass);
@@ -1052,6 +1057,8 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
     if (in0 && (!vec4 || !single || stride != 1 || Cin < 2 || (reinterpret_cast<uintptr_t>(in0) & 15u)))
       return LR_EUNSUPPORTED;  // split input: one 3-channel pass with 16-byte staging (the caller concatenates otherwise)
     int64_t resident = 256 * (single ? 3 : 2);  // persistent blocks per CU (registers: <=168 | <=256 per lane)
+    if (single && !getenv("LIFTREG_CONV0_DIRECT") && Cin <= 3 && stride == 1 && NT == 1 && (out_layout == LR_LAYOUT_NDHWC || out_layout == LR_LAYOUT_NDHWC_HPS))
+      resident = 256 * LR_C0_WINO_BLOCKS;  // the Winograd instance (<=128 registers)
     if (const char* e = getenv("LIFTREG_CONV0_BLOCKS")) resident = atoi(e);  // tuning aid
     const dim3 grid((unsigned)(nitems < resident ? nitems : resident));
     const size_t lds1 = (size_t)3 * PlanarGeom<1, 3>::CS * sizeof(float);
