@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv0_bf16_kernel(const
         const int row = q / 18, f4 = q - row * 18;
         const int cc = row / 36, rz = (row / 6) % 6, ry = row % 6;
         const int zi = z0 - 1 + rz, yi = y0 - 1 + ry, xi = x0 - 4 + f4 * 4;
-        const bool ok = q < WROWS * 18 && c0 + cc < d.Cin && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W && xi >= 0 && xi < d.H;
+        const bool ok = (int)(q < WROWS * 18) & (int)(c0 + cc < d.Cin) & (int)(zi >= 0) & (int)(zi < d.D) & (int)(yi >= 0) & (int)(yi < d.W) & (int)(xi >= 0) & (int)(xi < d.H);  // bitwise: no exec-mask branches around the loads' address math
         const unsigned voff = ok ? (unsigned)(((int64_t)cc * V + ((int64_t)zi * d.W + yi) * d.H + xi) * 4) : 0x80000000u;
         st[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
       }
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_dgrad_bf16_kernel(const u16* __
       const int q = it * 256 + tid;
       const int vox = q >> 2, c8 = q & 3;
       const int xx = vox % 17, r = vox / 17, yy = r % 5, zz = r / 5;
-      const bool ok = q < NCH && zq0 + zz < d.Do && yq0 + yy < d.Wo && xq0 + xx < d.Ho;
+      const bool ok = (int)(q < NCH) & (int)(zq0 + zz < d.Do) & (int)(yq0 + yy < d.Wo) & (int)(xq0 + xx < d.Ho);  // bitwise: no exec-mask branches around the loads' address math
       const unsigned voff = ok ? (unsigned)(((((zz * d.Wo) + yy) * d.Ho + xx) * CG + c8 * 8) * 2) : 0x80000000u;
       st[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
     }

@@ -1085,7 +1085,7 @@ __global__ __launch_bounds__(256 * CB, 2) void conv3d_wgrad_cl_bf16_kernel(const
 #pragma unroll
     for (int it = 0; it < XIT; ++it) {
       const int zi = zi0 + (xdec[it] & 3), yi = yi0 + ((xdec[it] >> 2) & 3), xi = xi0 + ((xdec[it] >> 4) & 255);
-      const bool ok = live && (xdec[it] >> 12) && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W && xi >= 0 && xi < d.H;
+      const bool ok = (int)(live) & (int)(((xdec[it] >> 12) & 1)) & (int)(zi >= 0) & (int)(zi < d.D) & (int)(yi >= 0) & (int)(yi < d.W) & (int)(xi >= 0) & (int)(xi < d.H);  // bitwise: no exec-mask branches around the loads' address math
       xst[it] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xrel[it] : OOR, 0, 0);
     }
     const u16* gb = gpre + ((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + ho0) * Cout;
@@ -1222,7 +1222,7 @@ __global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_ke
 #pragma unroll
     for (int it = 0; it < G::XIT; ++it) {
       const int zi = z - 1 + (xdec[it] & 3), yi = y0 - 1 + ((xdec[it] >> 2) & 7), xi = h0 - 4 + ((xdec[it] >> 9) & 31) * 4;
-      const bool ok = live && (xdec[it] >> 14) && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W && xi >= 0 && xi < d.H;
+      const bool ok = (int)(live) & (int)(((xdec[it] >> 14) & 1)) & (int)(zi >= 0) & (int)(zi < d.D) & (int)(yi >= 0) & (int)(yi < d.W) & (int)(xi >= 0) & (int)(xi < d.H);  // bitwise: no exec-mask branches around the loads' address math
       xst[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? org + xrel[it] : OOR, 0, 0));
     }
     const int64_t gorg = ((((int64_t)b * d.D + z) * d.W + y0) * d.H + h0) * 16;
@@ -1357,7 +1357,7 @@ __global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_bf
 #pragma unroll
     for (int it = 0; it < XIT; ++it) {
       const int zi = z - 1 + (xdec[it] & 3), yi = y0 - 1 + ((xdec[it] >> 2) & 7), xi = h0 - 4 + ((xdec[it] >> 9) & 31) * 4;
-      const bool ok = live && (xdec[it] >> 14) && zi >= 0 && zi < d.D && yi >= 0 && yi < d.W && xi >= 0 && xi < d.H;
+      const bool ok = (int)(live) & (int)(((xdec[it] >> 14) & 1)) & (int)(zi >= 0) & (int)(zi < d.D) & (int)(yi >= 0) & (int)(yi < d.W) & (int)(xi >= 0) & (int)(xi < d.H);  // bitwise: no exec-mask branches around the loads' address math
       xst[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? org + xrel[it] : OOR, 0, 0));
     }
     // gradient rows: 4 rows x 64 voxels x 16 co bf16 = 512 chunks of 16 bytes, 2 per thread
