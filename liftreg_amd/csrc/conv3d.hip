@@ -770,7 +770,9 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(const float* __restrict_
 // matrix pipe.  27 rows per tile, loads two rows ahead, everything unrolled (straight-line vmcnt accounting).
 // Every accumulator still sees its taps in (tz,ty,tx) order: the results are bit-identical to conv3d_cl_kernel's.
 // ===========================================================================
-template <int NT, int CB /* 16-channel blocks of the input: Cin = 16*CB */>
+// MTV: output rows of a wave's tile.  4 for the big blocks; 1 for the last, tiny blocks of the encoder (16^3 and 8^3 outputs: a
+// few dozen tiles — with 4 rows a wave walks 54 input rows in sequence while most of the chip idles).
+template <int NT, int CB /* 16-channel blocks of the input: Cin = 16*CB */, int MTV = MT>
 __global__ __launch_bounds__(256, 3) void conv3d_cl_rows_kernel(const float* __restrict__ in,
                                                              const float4* __restrict__ wp,
                                                              const float* __restrict__ bias,
@@ -785,16 +787,16 @@ __global__ __launch_bounds__(256, 3) void conv3d_cl_rows_kernel(const float* __r
   // the dimensions the loop needs, as scalars of their own (the struct itself may end up in scratch)
   const int dD = __builtin_amdgcn_readfirstlane(d.D), dW = __builtin_amdgcn_readfirstlane(d.W),
             dH = __builtin_amdgcn_readfirstlane(d.H), dHo = __builtin_amdgcn_readfirstlane(d.Ho);
-  const int wo0 = wq * MT;
+  const int wo0 = wq * MTV;
   const int col = lane & 15, kq = lane >> 4;
   const int ho = hq * 16 + col;  // this lane's voxel
 
-  f32x4 acc[MT][NT];
+  f32x4 acc[MTV][NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const f32x4 bv = bias_init(bias, nt, lane);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = bv;
+    for (int mt = 0; mt < MTV; ++mt) acc[mt][nt] = bv;
   }
   // window origin (-1,-1,-1) of this wave's tile, as in conv3d_cl_kernel<NT, 2, true>
   constexpr int CIN = 16 * CB;
@@ -817,7 +819,7 @@ __global__ __launch_bounds__(256, 3) void conv3d_cl_rows_kernel(const float* __r
     for (int t3 = 0; t3 < 3; ++t3) vx[t3] = lvoff | ((ho < dHo && xi0 + t3 >= 0 && xi0 + t3 < dH) ? 0u : OOR);
   }
   const unsigned wlane = (unsigned)lane * 16u;
-  constexpr int NR = 2 * MT + 1;  // input rows of the tile per plane
+  constexpr int NR = 2 * MTV + 1;  // input rows of the tile per plane
 
   unsigned okmask = 0u;  // bit tz*NR+r SET = input row (zi0+tz, yw0+r) exists (the rest is the conv's zero padding)
 #pragma unroll
@@ -874,18 +876,18 @@ __global__ __launch_bounds__(256, 3) void conv3d_cl_rows_kernel(const float* __r
       use(r >> 1, 1, rows[q % 3]);
     } else {
       if (r >= 2) use((r >> 1) - 1, 2, rows[q % 3]);
-      if (r < 2 * MT) use(r >> 1, 0, rows[q % 3]);
+      if (r < 2 * MTV) use(r >> 1, 0, rows[q % 3]);
     }
     // a ty's fragments are dead after its last row: fetch the next tz's while the remaining rows compute
     if (pl + 1 < 3 * CB) {
-      if (r == 2 * MT - 2) load_w(pl + 1, 0);
-      if (r == 2 * MT - 1) load_w(pl + 1, 1);
-      if (r == 2 * MT) load_w(pl + 1, 2);
+      if (r == 2 * MTV - 2) load_w(pl + 1, 0);
+      if (r == 2 * MTV - 1) load_w(pl + 1, 1);
+      if (r == 2 * MTV) load_w(pl + 1, 2);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+  for (int mt = 0; mt < MTV; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
       store_tile(acc[mt][nt], out, d, b, dz, wo0 + mt, ho, nt, lane, out_layout, slope);
@@ -1032,6 +1034,13 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
       const int rc = lr_internal_conv_rows_wlds(in, packed_w, bias, out, B, Cin, Cout, D, W, H, out_layout, negative_slope,
                                                 z_phase, st);
       if (rc != LR_EUNSUPPORTED) return rc;
+    }
+    if (rows_ok && Cin == 32 && NT == 2 && nblk < (getenv("LIFTREG_CONV_ROWS_MT1_BELOW") ? atoi(getenv("LIFTREG_CONV_ROWS_MT1_BELOW")) : 512)) {  // env: tuning aid
+      // the last tiny blocks (32 -> 32): one output row per wave, four times the waves, a quarter of the serial walk; same bits
+      d.nWq = d.Wo;
+      const dim3 g1((unsigned)((int64_t)B * d.nDq * d.nWq * d.nHq));
+      hipLaunchKernelGGL((conv3d_cl_rows_kernel<2, 2, 1>), g1, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope);
+      return lr_launch_status();
     }
     if (rows_ok && Cin == 16 && NT == 1) hipLaunchKernelGGL((conv3d_cl_rows_kernel<1, 1>), grid, block, occ_lds, st, in, wt, bias, out, d, out_layout, negative_slope);
     else if (rows_ok && Cin == 16) hipLaunchKernelGGL((conv3d_cl_rows_kernel<2, 1>), grid, block, occ_lds, st, in, wt, bias, out, d, out_layout, negative_slope);
