@@ -10,9 +10,11 @@
 
 namespace {
 
-constexpr int OT = 4;
+constexpr int OT4 = 4;
 
-template <int BT>
+// OT output neurons per block: 4 (the activations are re-read 4x less), or 1 when 4 would leave CUs idle (FC1: 800 neurons =
+// 200 blocks of 4 on a 256-CU chip; the 52 MB weight read ran at 1.4 TB/s).  Same accumulation order per neuron either way.
+template <int BT, int OT>
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x,
                                                      const float* __restrict__ w,
                                                      const float* __restrict__ bias,
@@ -35,7 +37,8 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
   int k_done = 0;
   if (vec_ok) {
     const int K4 = K >> 2;
-    for (int k4 = threadIdx.x; k4 < K4; k4 += 256) {
+#pragma unroll 4
+    for (int k4 = threadIdx.x; k4 < K4; k4 += 256) {  // several weight loads in flight per thread
       float4 wv[OT];
 #pragma unroll
       for (int o = 0; o < OT; ++o) wv[o] = reinterpret_cast<const float4*>(wr[o])[k4];
@@ -93,24 +96,21 @@ extern "C" int lr_linear_lrelu_f32(const float* x, const float* w, const float* 
   if (B < 1 || B > 32 || K < 1 || O < 1) return LR_EINVAL;
   const int vec_ok = ((K & 3) == 0) &&
                      (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0);
-  const unsigned nblk = (unsigned)((O + OT - 1) / OT);
+  const bool wide = (O + OT4 - 1) / OT4 < 512;  // few neurons: one per block
+  const unsigned nblk = wide ? (unsigned)O : (unsigned)((O + OT4 - 1) / OT4);
   hipStream_t st = lr_stream(stream);
+#define LR_LIN(BTV)                                                                                                          \
+  do {                                                                                                                      \
+    if (wide) hipLaunchKernelGGL((linear_kernel<BTV, 1>), dim3(nblk), dim3(256), 0, st, x, w, bias, y, B, b_lo, K, O, negative_slope, vec_ok); \
+    else hipLaunchKernelGGL((linear_kernel<BTV, OT4>), dim3(nblk), dim3(256), 0, st, x, w, bias, y, B, b_lo, K, O, negative_slope, vec_ok);    \
+  } while (0)
   for (int b_lo = 0; b_lo < B;) {
     const int rem = B - b_lo;
-    if (rem > 4) {
-      hipLaunchKernelGGL(linear_kernel<8>, dim3(nblk), dim3(256), 0, st, x, w, bias, y, B, b_lo, K,
-                         O, negative_slope, vec_ok);
-      b_lo += 8;
-    } else if (rem > 1) {
-      hipLaunchKernelGGL(linear_kernel<4>, dim3(nblk), dim3(256), 0, st, x, w, bias, y, B, b_lo, K,
-                         O, negative_slope, vec_ok);
-      b_lo += 4;
-    } else {
-      hipLaunchKernelGGL(linear_kernel<1>, dim3(nblk), dim3(256), 0, st, x, w, bias, y, B, b_lo, K,
-                         O, negative_slope, vec_ok);
-      b_lo += 1;
-    }
+    if (rem > 4) { LR_LIN(8); b_lo += 8; }
+    else if (rem > 1) { LR_LIN(4); b_lo += 4; }
+    else { LR_LIN(1); b_lo += 1; }
     if (int e = lr_launch_status()) return e;
   }
+#undef LR_LIN
   return LR_OK;
 }
