@@ -199,9 +199,9 @@ __global__ __launch_bounds__(256) void disp_reg_bwd_vec_kernel(const float* __re
 // of algorithmic traffic).  Here a block owns R full rows of ONE channel and walks a chunk of planes: a thread keeps its own
 // column (3 planes) in registers, so the z neighbours cost nothing, and the plane it has just loaded goes into an LDS tile
 // (R rows + halo rows) from which the in-plane neighbours are read a step later.  Every value is requested from L2 once
-// (+ the halo rows); same arithmetic per element as above.  0.61 -> 0.37 ms (4.4 TB/s).  The same scheme for the gradient
-// (5 planes in registers, 3 LDS tiles) measured equal to disp_reg_bwd_vec_kernel (1.12 vs 1.10 ms: that kernel is bound by its
-// ~180 vector-ALU operations per quad and its store, not by L2) and was not kept.
+// (+ the halo rows); same arithmetic per element as above.  0.61 -> 0.37 ms (4.4 TB/s).  The gradient: disp_reg_bwd_march_kernel
+// below — marching alone (1.03 vs 1.04 ms) and cheaper index logic alone (1.10 vs 1.10 ms) each changed nothing, the vector
+// kernel sits on two bounds at once (L2 requests and ~290 vector-ALU operations per quad); both together: 0.94 ms.
 template <int HALO>
 __device__ __forceinline__ void march_store_plane(float* tile, const float* __restrict__ pl /* plane base of the channel */,
                                                   const f32x4& own /* this thread's quad of that plane */, int H, int W, int R,
@@ -272,6 +272,86 @@ __global__ __launch_bounds__(1024) void disp_reg_march_kernel(const float* __res
   }
 }
 
+// axis_g5 with the index-dependent part factored out: along z and y a thread's four voxels share the index, so the six
+// comparisons and selects of axis_g5 are done once per thread and step (G5c) and each voxel costs two selects and eight flops
+// (same terms, (h*h)*x instead of h*(h*x): results agree to an ulp).
+struct G5c {
+  float a, b, c, e;   // weights of (f0 - FM), (FP - f0), (f0 - fm1), (fp1 - f0)
+  bool m1, p1;        // FM = fm1 (else fm2), FP = fp1 (else fp2)
+};
+__device__ __forceinline__ G5c g5_coefs(int i, int n, float ih) {
+  const float h = 0.5f * ih, hh = h * h, ii = ih * ih;
+  G5c k;
+  k.m1 = i == 1; k.p1 = i == n - 2;
+  k.a = i >= 1 ? (i == 1 ? ii : hh) : 0.0f;
+  k.b = i <= n - 2 ? (i == n - 2 ? ii : hh) : 0.0f;
+  k.c = i == n - 1 ? ii : 0.0f;
+  k.e = i == 0 ? ii : 0.0f;
+  return k;
+}
+__device__ __forceinline__ float axis_g5c(const G5c& k, float fm2, float fm1, float f0, float fp1, float fp2) {
+  const float FM = k.m1 ? fm1 : fm2, FP = k.p1 ? fp1 : fp2;
+  return (k.a * (f0 - FM) - k.b * (FP - f0)) + (k.c * (f0 - fm1) - k.e * (fp1 - f0));
+}
+
+// The gradient as a z-marching kernel: five planes of the thread's own column in registers, the in-plane +-1 / +-2 neighbours
+// from LDS tiles of (R + 4) rows.  FOUR tiles in a ring (planes i .. i+3 fit while plane i is read and plane i+2 is written), so
+// one barrier per plane suffices.  The vectorised kernel above requests every value ~11 times from L2 (17.6 GB of L2 traffic
+// for a 1.6 GB field: it runs at the L2's rate, 1.03-1.10 ms at C3 whatever its grid or its arithmetic); here it is
+// requested once (+ halo rows).
+__global__ __launch_bounds__(1024) void disp_reg_bwd_march_kernel(const float* __restrict__ disp, const float* __restrict__ gout,
+                                                                  float* __restrict__ gdisp, int B, int D, int W, int H, int R,
+                                                                  int ZC, float ihd, float ihw, float ihh) {
+  extern __shared__ __attribute__((aligned(16))) float mt[];  // 4 tiles of (R + 4) x H
+  const int H4 = H >> 2;
+  const int k4 = threadIdx.x % H4, r = threadIdx.x / H4;
+  const int j0 = blockIdx.x * R, i0 = blockIdx.y * ZC, i1 = min(D, i0 + ZC);
+  const int64_t V = (int64_t)D * W * H;
+  const float* base = disp + (int64_t)blockIdx.z * V;
+  float* gb = gdisp + (int64_t)blockIdx.z * V;
+  const float scale = (*gout) * 2.0f / (float)((double)B * (double)V);
+  const int j = j0 + r, k = k4 * 4;
+  const bool active = j < W;
+  const size_t tsz = (size_t)(R + 4) * H;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  auto ldp = [&](int i) -> f32x4 {  // this thread's quad of plane i (zero outside the volume: never selected by axis_g5)
+    return (active && i >= 0 && i < D) ? *reinterpret_cast<const f32x4*>(base + (int64_t)i * W * H + (int64_t)j * H + k) : zero;
+  };
+  const G5c ky = g5_coefs(j, W, ihw);
+  G5c kx[4];  // the x index of a thread's four voxels never changes along the march
+#pragma unroll
+  for (int t = 0; t < 4; ++t) kx[t] = g5_coefs(k + t, H, ihh);
+  f32x4 fm2 = ldp(i0 - 2), fm1 = ldp(i0 - 1), f0 = ldp(i0), fp1 = ldp(i0 + 1), fp2;
+  march_store_plane<2>(mt + (i0 & 3) * tsz, base + (int64_t)i0 * W * H, f0, H, W, R, j0, r, k4, active);
+  if (i0 + 1 < D) march_store_plane<2>(mt + ((i0 + 1) & 3) * tsz, base + (int64_t)(i0 + 1) * W * H, fp1, H, W, R, j0, r, k4, active);
+  for (int i = i0; i < i1; ++i) {
+    fp2 = ldp(i + 2);
+    if (i + 2 < D) march_store_plane<2>(mt + ((i + 2) & 3) * tsz, base + (int64_t)(i + 2) * W * H, fp2, H, W, R, j0, r, k4, active);
+    __syncthreads();  // plane i's tile is complete (filled two steps ago / before the loop); the tile written now (plane i+2) was
+                      // last read as plane i-2, two barriers ago
+    if (active) {
+      const float* tl = mt + (i & 3) * tsz + (size_t)(2 + r) * H + k;
+      const bool yb = j < 2 || j > W - 3;
+      const f32x4 ym2 = j >= 2 ? *reinterpret_cast<const f32x4*>(tl - 2 * H) : zero;
+      const f32x4 yp2 = j <= W - 3 ? *reinterpret_cast<const f32x4*>(tl + 2 * H) : zero;
+      const f32x4 ym1 = (yb && j >= 1) ? *reinterpret_cast<const f32x4*>(tl - H) : zero;
+      const f32x4 yp1 = (yb && j <= W - 2) ? *reinterpret_cast<const f32x4*>(tl + H) : zero;
+      const f32x4 l = k >= 4 ? *reinterpret_cast<const f32x4*>(tl - 4) : zero;
+      const f32x4 rr = k + 4 < H ? *reinterpret_cast<const f32x4*>(tl + 4) : zero;
+      const float e[12] = {l[0], l[1], l[2], l[3], f0[0], f0[1], f0[2], f0[3], rr[0], rr[1], rr[2], rr[3]};
+      const G5c kz = g5_coefs(i, D, ihd);  // (ky: per thread, before the loop)
+      f32x4 g;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        g[t] = axis_g5c(kz, fm2[t], fm1[t], f0[t], fp1[t], fp2[t]) + axis_g5c(ky, ym2[t], ym1[t], f0[t], yp1[t], yp2[t]) +
+               axis_g5c(kx[t], e[2 + t], e[3 + t], e[4 + t], e[5 + t], e[6 + t]);
+      }
+      __builtin_nontemporal_store(g * scale, reinterpret_cast<f32x4*>(gb + (int64_t)i * W * H + (int64_t)j * H + k));
+    }
+    fm2 = fm1; fm1 = f0; f0 = fp1; fp1 = fp2;
+  }
+}
+
 }  // namespace
 
 extern "C" int lr_disp_reg_bwd_f32(const float* disp, const float* gout, float* gdisp, int B, int D, int W, int H,
@@ -282,10 +362,24 @@ extern "C" int lr_disp_reg_bwd_f32(const float* disp, const float* gout, float* 
   const float ihw = W > 1 ? 0.5f * (float)(W - 1) : 0.0f;
   const float ihh = H > 1 ? 0.5f * (float)(H - 1) : 0.0f;
   const int64_t total = (int64_t)B * 3 * D * W * H;
+  if (H % 4 == 0 && H >= 64 && H <= 1024 && W >= 4 && !getenv("LIFTREG_REG_NOMARCH") &&
+      ((reinterpret_cast<uintptr_t>(disp) | reinterpret_cast<uintptr_t>(gdisp)) & 15u) == 0 && (int64_t)B * 3 <= 65535) {
+    // z-marching kernel: R full rows per block (>= 4: two halo rows each side are fetched by the first four thread rows)
+    const int H4 = H / 4;
+    int R = 512 / H4; if (R < 4) R = 4; if (R > 16) R = 16;
+    const size_t lds = (size_t)4 * (R + 4) * H * sizeof(float);
+    if (R * H4 <= 1024 && lds <= 64 * 1024) {
+      const int ZC = D >= 64 ? 32 : D;
+      const dim3 grid((unsigned)((W + R - 1) / R), (unsigned)((D + ZC - 1) / ZC), (unsigned)(B * 3));
+      hipLaunchKernelGGL(disp_reg_bwd_march_kernel, grid, dim3((unsigned)(R * H4)), lds, lr_stream(stream), disp, gout, gdisp, B, D, W,
+                         H, R, ZC, ihd, ihw, ihh);
+      return lr_launch_status();
+    }
+  }
   if (H % 4 == 0 && H >= 8 && total / 4 < 0xffffffffLL &&
       ((reinterpret_cast<uintptr_t>(disp) | reinterpret_cast<uintptr_t>(gdisp)) & 15u) == 0) {
     int64_t nb = (total / 4 + 255) / 256;
-    if (nb > 16384) nb = 16384;
+    if (const char* e = getenv("LIFTREG_REG_BWD_BLOCKS")) { if (nb > atoi(e)) nb = atoi(e); } else if (nb > 16384) nb = 16384;  // env: tuning aid
     hipLaunchKernelGGL(disp_reg_bwd_vec_kernel, dim3((unsigned)nb), dim3(256), 0, lr_stream(stream), disp, gout, gdisp,
                        B, D, W, H, ihd, ihw, ihh);
     return lr_launch_status();

@@ -62,3 +62,24 @@ def test_disp_reg_marching_kernel_equals_vector_kernel(monkeypatch):
         want = float(ro.disp_reg(torch.from_numpy(disp)))
         assert abs(got - old) <= 2e-6 * abs(old), (shape, got, old)
         assert abs(got - want) <= 1e-5 * abs(want), (shape, got, want)
+
+
+def test_disp_reg_gradient_marching_kernel_equals_vector_kernel(monkeypatch):
+    """The z-marching gradient of the regulariser (H >= 64) against the vectorised kernel (LIFTREG_REG_NOMARCH=1) and torch
+    autograd of the oracle: ragged D / W / plane chunks, faces in every axis (the +-1 / +-2 stencil changes there)."""
+    from liftreg_amd import ops_bwd
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(37)
+    for shape, B in (((5, 9, 64), 2), ((37, 10, 128), 1), ((33, 7, 96), 1), ((70, 6, 64), 1), ((3, 4, 64), 1)):
+        disp = rs.normal(0, 0.05, (B, 3) + shape).astype(np.float32)
+        d = torch.from_numpy(disp).to(dev)
+        gout = torch.tensor(0.7, device=dev)
+        got = ops_bwd.disp_reg_bwd(d, gout)
+        monkeypatch.setenv("LIFTREG_REG_NOMARCH", "1")
+        old = ops_bwd.disp_reg_bwd(d, gout)
+        monkeypatch.delenv("LIFTREG_REG_NOMARCH")
+        scale = float(old.abs().max())
+        assert float((got - old).abs().max()) <= 2e-6 * scale, shape
+        dt = torch.from_numpy(disp).requires_grad_(True)
+        (ro.disp_reg(dt) * 0.7).backward()
+        assert float((got.cpu() - dt.grad).abs().max()) <= 2e-5 * float(dt.grad.abs().max()), shape
