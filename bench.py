@@ -33,8 +33,9 @@ CONFIGS = {  # BASELINE.json configs (single-GPU ones)
     "c1": dict(n=64, P=2, R=64, B=1, L=56),
     "c2": dict(n=128, P=2, R=128, B=4, L=56),
     "c3": dict(n=256, P=2, R=256, B=8, L=56),
-    "c4": dict(n=256, P=11, R=256, B=4, L=56),   # C4 per GPU (batch 16 over 4 GPUs), unsharded here; use --conv-dtype bf16
+    "c4": dict(n=256, P=11, R=256, B=4, L=56),   # C4 per GPU in replica mode (batch 16 over 4 GPUs); use --conv-dtype bf16
 }
+SLAB_GLOBAL_BATCH = {"c4": 16}   # --shard slab: C4 is ONE batch of 16 sharded by z-slab over the ranks (BASELINE configs[3])
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* fp32-input matrix peak
 
@@ -80,12 +81,14 @@ def synth_inputs(cfg, dev, seed=2021):
 
 
 def _cpu_forward_sample0(net, inp):
-    """oracle/ref_ops.model_forward (the reference's ATen op sequence, CPU) on sample 0 of `inp`."""
+    """oracle/ref_ops.model_forward (the reference's ATen op sequence, CPU) on sample 0 of `inp` — in the model's own
+    conv_dtype: a bf16 line is compared with the bf16 restatement (oracle/ref_ops.encoder_bf16), not the fp32 one."""
     from oracle import ref_ops as ro
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     one = {k: v[:1].cpu().contiguous() for k, v in inp.items()}
     with torch.no_grad():
-        ref = ro.model_forward(sd, one, net.pca_vectors_LxM.cpu(), net.pca_mean.cpu())
+        ref = ro.model_forward(sd, one, net.pca_vectors_LxM.float().cpu(), net.pca_mean.cpu(),
+                               conv_dtype=getattr(net, "conv_dtype", "fp32"))
         ref["ncc"] = float(ro.ncc_loss(ref["warped"], ref["target"]))
     return ref
 
@@ -101,14 +104,18 @@ def parity_vs_cpu(net, inp, out, ref=None):
         ncc_gpu = float(NCCLoss(check_nan=False)(out["warped"][:1].contiguous(), out["target"][:1].contiguous()))
     g = {k: out[k][:1].detach().cpu() for k in ("params", "pca_coefs", "warped", "phi")}
     coef_scale = float(ref["pca_coefs"].abs().max())
-    return {"sample": "sample 0 of the timed batch vs oracle/ref_ops.model_forward (torch CPU, the reference's op sequence)",
+    cd = getattr(net, "conv_dtype", "fp32")
+    return {"sample": "sample 0 of the timed batch vs oracle/ref_ops.model_forward (torch CPU, the reference's op sequence"
+                      + (")" if cd == "fp32" else f"; conv_dtype={cd}: the bf16-storage restatement ref_ops.encoder_bf16)"),
             "max_abs_disp": float((g["params"] - ref["params"]).abs().max()),
             "max_abs_phi": float((g["phi"] - ref["phi"]).abs().max()),
             "max_rel_coefs": float((g["pca_coefs"] - ref["pca_coefs"]).abs().max()) / max(coef_scale, 1e-30),
             "max_abs_warped": float((g["warped"] - ref["warped"]).abs().max()),
             "mean_abs_warped": float((g["warped"] - ref["warped"]).abs().mean()),
             "ncc_gpu": ncc_gpu, "ncc_cpu": ref["ncc"], "ncc_abs": abs(ncc_gpu - ref["ncc"]),
-            "bar": "displacement field within 1e-4 of the reference (BASELINE.json north_star)"}
+            "bar": "displacement field within 1e-4 of the reference (BASELINE.json north_star)" if cd == "fp32" else
+                   "bf16 storage: rare one-ulp bf16 rounding flips of activations vs the CPU restatement move the coefficients "
+                   "by ~1e-3 relative (tests/test_gpu_bf16.py); the 1e-4 bar applies to the fp32 path"}
 
 
 def cpu_baseline(cfg, net, inp, budget_s=30.0):
@@ -125,16 +132,17 @@ def cpu_baseline(cfg, net, inp, budget_s=30.0):
     torch.set_num_threads(cores)
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     one = {k: v[:1].cpu().contiguous() for k, v in inp.items()}
-    vec, mean = net.pca_vectors_LxM.cpu(), net.pca_mean.cpu()
+    vec, mean = net.pca_vectors_LxM.float().cpu(), net.pca_mean.cpu()
+    cd = getattr(net, "conv_dtype", "fp32")
     with torch.no_grad():
         t0 = time.perf_counter()
-        out = ro.model_forward(sd, one, vec, mean)
+        out = ro.model_forward(sd, one, vec, mean, conv_dtype=cd)
         ro.ncc_loss(out["warped"], out["target"])
         first = time.perf_counter() - t0
         times = [first]
         while sum(times) < budget_s and len(times) < 5:
             t0 = time.perf_counter()
-            out = ro.model_forward(sd, one, vec, mean)
+            out = ro.model_forward(sd, one, vec, mean, conv_dtype=cd)
             ro.ncc_loss(out["warped"], out["target"])
             times.append(time.perf_counter() - t0)
     best = float(np.median(times[1:])) if len(times) > 1 else first
@@ -215,7 +223,9 @@ def main():
                     help="replay the step from one captured HIP graph (launch-bound small configs c1/c2); the "
                          "per-kernel table then comes from one extra eager step outside the timed region")
     args = ap.parse_args()
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    if args.shard == "slab" and args.config in SLAB_GLOBAL_BATCH:
+        cfg["B"] = SLAB_GLOBAL_BATCH[args.config]
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -280,7 +290,7 @@ def main():
     else:
         def step():
             out = net(inp)
-            return sim(out["warped"], out["target"])
+            return sim(out["warped"], out["target"], moments=out.get("ncc_moments"))   # moments: only with --fuse-ncc
 
     def fence():
         torch.cuda.synchronize()
@@ -294,8 +304,10 @@ def main():
         # second.  W steps of 11 ms do not cover that, so the step runs untimed for --ramp-seconds first; the W warm-up steps
         # and the K timed steps follow exactly as the contract says.
         t_r = time.perf_counter()
+        ramp_steps = 0
         while args.ramp_seconds > 0:
             loss = step()
+            ramp_steps += 1
             torch.cuda.synchronize()
             go = torch.tensor([1.0 if time.perf_counter() - t_r < args.ramp_seconds else 0.0], dtype=torch.float32, device=dev)
             if dist is not None:     # every rank leaves the ramp after the same step (the sharded step has collectives inside)
@@ -398,7 +410,7 @@ def main():
 
     # the projector on its own and the simulate+register rate — outside the timed region
     drr = None
-    if rank == 0 and not args.no_drr:
+    if rank == 0 and not args.no_drr and not slab:    # (slab mode: step() has collectives inside — rank 0 must not run it alone)
         from liftreg_amd.utils.sdct_projection_utils import scan_poses
         p32 = scan_poses(30, P, n).astype(np.float32)
         vols = (inp["target"][:, 0] + 1) * 500 - 1000                   # back to HU: the projector folds HU→μ
@@ -425,9 +437,48 @@ def main():
                "simulate_plus_register_per_s": B / t_both,
                "note": f"{P} views of {R}x{R} per {n}^3 volume, HU->mu as a one-pass prologue (lr_hu_to_mu_f32), the axis-1 flip folded into the projector"}
 
+    # slab mode: the sharded projector leg of the north star ("RCCL all-reduce of slab-boundary partial sums"): every rank
+    # integrates the taps of its rows [d0,d1) of each target volume, the partial (P,Rd,Rh) images sum over the ranks
+    # (one all-reduce of B·P·Rd·Rh floats per batch) — outside the timed region, every rank takes part
+    drr_sharded = None
+    if slab and not args.no_drr:
+        from liftreg_amd.utils.sdct_projection_utils import scan_poses
+        p32 = scan_poses(30, P, n).astype(np.float32)
+        R = cfg["R"]
+        mu_slab = ops.hu_to_mu(((inp["target"][:, 0, d0:d1] + 1) * 500 - 1000).contiguous())   # this rank's rows, HU→μ once
+        part = torch.empty((B, P, R, R), dtype=torch.float32, device=dev)
+
+        def project_sharded():
+            for b in range(B):
+                ops.drr_forward(mu_slab[b], p32, (R, R), (2.2, 2.2, 2.2), d0=d0, d1=d1, full_D=n, flip_w=True, out=part[b])
+            if dist is not None:
+                dist.all_reduce(part, op=dist.ReduceOp.SUM)
+            return part
+
+        with torch.no_grad():
+            project_sharded()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                project_sharded()
+            fence()
+            t_sh = torch.tensor([(time.perf_counter() - t0) / 5], dtype=torch.float64, device=dev)
+            if dist is not None:
+                dist.all_reduce(t_sh, op=dist.ReduceOp.MAX)
+            full = torch.stack([ops.drr_forward(((inp["target"][b, 0] + 1) * 500 - 1000).contiguous(), p32, (R, R),
+                                                (2.2, 2.2, 2.2), hu_input=True, flip_w=True) for b in range(B)])
+            err = float((project_sharded() - full).abs().max() / full.abs().max())
+        drr_sharded = {"volumes_per_s": B / float(t_sh.item()), "ms_per_batch": float(t_sh.item()) * 1e3,
+                       "allreduce_bytes": 4 * B * P * R * R, "max_rel_vs_unsharded": err,
+                       "note": f"rows {d0}:{d1} of each of the {B} volumes on rank 0; partial DRRs summed over {world} rank(s) "
+                               "(fp32 sums in another order than the single-GPU ray walk: ~1e-7 relative)"}
+
     result = {
         "metric": "registrations/sec (256^3 CT, 2-view DRR)" if args.config == "c3" else f"registrations/sec ({args.config})",
         "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        # untimed clock ramp BEFORE the W warm-up steps (the same step, run for --ramp-seconds): the line measures the
+        # steady state of a GPU that is already busy, and says so
+        "ramp_seconds": args.ramp_seconds, "ramp_steps": ramp_steps,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if slab else "weak",
         "vs_baseline": None,
         "dtype": "f32" if (args.conv_dtype, args.pca_dtype) == ("fp32", "fp32") else
@@ -438,7 +489,8 @@ def main():
                    "parallelism": (f"z-slab x{world}: ONE batch of {B} registrations sharded along D (rows {d0}:{d1} on rank 0); "
                                    "halo planes p2p, encoder features all-gather, NCC moments all-reduce over RCCL" if slab else
                                    f"replicas x{world} (independent registrations, no data-path collective)"),
-                   "streams": args.streams, "hip_graph": bool(args.graph)},
+                   "streams": args.streams, "hip_graph": bool(args.graph),
+                   "untimed_before_warmup": f"{ramp_steps} steps ({args.ramp_seconds:g} s clock ramp), then {args.warmup} warm-up steps"},
         "roofline": roof(dominant),
         "roofline_backproject": roof("backproject"),
         "backproj_hbm_GBps": kernels["backproject"]["achieved"],
@@ -450,6 +502,7 @@ def main():
         "traffic_stale": stale,
         "ncc_loss": float(loss),
         "drr_forward": drr,
+        **({"drr_forward_sharded": drr_sharded} if drr_sharded is not None else {}),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not slab:
         result["cpu_baseline"], ref = cpu_baseline(cfg, net, inp)

@@ -226,12 +226,16 @@ class DecodeFn(torch.autograd.Function):
 
 class NCCFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, y, variant):
+    def forward(ctx, x, y, variant, moments=None):
         n_batch = x.shape[0]
         rows = n_batch if variant == _hip.NCC_CONFIGURED else n_batch * x.shape[1]
-        m = ops.cached_ncc_moments(x, y, rows)      # left by the one-pass decode's epilogue for these very tensors
+        # `moments`: the (rows,5) fp64 moments of exactly (x, y) that the one-pass decode's epilogue produced (model output
+        # key "ncc_moments") — handed over explicitly by the caller, never looked up by tensor identity
+        m = moments
         if m is None:
             m = ops.ncc_moments(x, y, rows)
+        elif tuple(m.shape) != (rows, 5) or m.dtype != torch.float64 or m.device != x.device:
+            raise ValueError(f"moments must be a float64 ({rows},5) tensor on {x.device}")
         loss, _ = ops.ncc_loss_from_moments(m, x.numel() // rows, n_batch, variant)
         ctx.save_for_backward(x, y, m)
         ctx.cfg = (variant, x.numel() // rows)
@@ -241,7 +245,7 @@ class NCCFn(torch.autograd.Function):
     def backward(ctx, gout):
         x, y, m = ctx.saved_tensors
         variant, n = ctx.cfg
-        return ops_bwd.ncc_bwd(x.contiguous(), y.contiguous(), m, gout, n, variant).view_as(x), None, None
+        return ops_bwd.ncc_bwd(x.contiguous(), y.contiguous(), m, gout, n, variant).view_as(x), None, None, None
 
 
 class DispRegFn(torch.autograd.Function):

@@ -1555,12 +1555,8 @@ extern "C" int lr_conv3d_dgrad_f32(const float* gpre, const float* packed_wT, fl
       const dim3 g2((unsigned)(nt < resident ? nt : resident)), b2(512);
 #define LR_DGW(CBV, MKV)                                                                                                  \
   do {                                                                                                                    \
-    static bool attr_done = false;                                                                                        \
-    if (!attr_done) {                                                                                                     \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_dgrad_wlds_kernel<CBV, MKV>),                       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);                                   \
-      attr_done = true;                                                                                                   \
-    }                                                                                                                     \
+    static std::atomic<uint64_t> attr_done{0}; /* one bit per device */                                                 \
+    if (lr_raise_dyn_lds(reinterpret_cast<const void*>(&conv3d_dgrad_wlds_kernel<CBV, MKV>), ldsb, attr_done) != LR_OK) return LR_ELAUNCH;\
     hipLaunchKernelGGL((conv3d_dgrad_wlds_kernel<CBV, MKV>), g2, b2, ldsb, st, gpre, wt, gx, xs_eff, d, (int)nt, dbgv);   \
   } while (0)
 #define LR_DGW_MK(CBV)                                                                                                    \
@@ -1584,12 +1580,8 @@ extern "C" int lr_conv3d_dgrad_f32(const float* gpre, const float* packed_wT, fl
       const dim3 g2((unsigned)(nt < resident ? nt : resident)), b2(512);
 #define LR_DGW32(MKV)                                                                                                      \
   do {                                                                                                                    \
-    static bool attr_done = false;                                                                                        \
-    if (!attr_done) {                                                                                                     \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_dgrad_wlds32_kernel<MKV>),                          \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);                                   \
-      attr_done = true;                                                                                                   \
-    }                                                                                                                     \
+    static std::atomic<uint64_t> attr_done{0}; /* one bit per device */                                                 \
+    if (lr_raise_dyn_lds(reinterpret_cast<const void*>(&conv3d_dgrad_wlds32_kernel<MKV>), ldsb, attr_done) != LR_OK) return LR_ELAUNCH;\
     hipLaunchKernelGGL((conv3d_dgrad_wlds32_kernel<MKV>), g2, b2, ldsb, st, gpre, wt, gx, xs_eff, d, (int)nt);            \
   } while (0)
       if (mk == 0) LR_DGW32(0); else if (mk == 1) LR_DGW32(1); else LR_DGW32(2);
@@ -1671,12 +1663,8 @@ static int wgrad_impl(const float* x, int x_layout, const float* gpre, int gbf, 
 #define LR_WCL2(CBV, NTCV, HP, XBV, RV)                                                                                  \
   do {                                                                                                                   \
     constexpr size_t ldsb = WclGeom<CBV, NTCV, RV>::LDS_BYTES;                                                          \
-    static bool attr_done = false;                                                                                       \
-    if (!attr_done) {                                                                                                    \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_cl_kernel<CBV, NTCV, HP, XBV, RV>),          \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);                                  \
-      attr_done = true;                                                                                                  \
-    }                                                                                                                    \
+    static std::atomic<uint64_t> attr_done{0}; /* one bit per device */                                                 \
+    if (lr_raise_dyn_lds(reinterpret_cast<const void*>(&conv3d_wgrad_cl_kernel<CBV, NTCV, HP, XBV, RV>), ldsb, attr_done) != LR_OK) return LR_ELAUNCH;\
     hipLaunchKernelGGL((conv3d_wgrad_cl_kernel<CBV, NTCV, HP, XBV, RV>), dim3(grid), dim3(256 * CBV), ldsb, st, x, gpre, \
                        partial, d, (int)nbr, gbf);                                                                       \
   } while (0)

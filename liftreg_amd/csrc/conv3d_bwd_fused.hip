@@ -344,13 +344,8 @@ int launch(const float* gpre1, const float* packed_w1T, const unsigned char* mas
            float* gb0, const FzDims& d, int ntiles, int blocks, hipStream_t st) {
   constexpr int NTP = (27 * CIN0 + 1 + 15) / 16;
   const size_t ldsb = ((size_t)27 * CB * 64 * 4 + (size_t)9 * (WMT + 1) * 17 * 32 + (size_t)CIN0 * XZ * XY * XX) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_wgrad0_kernel<CIN0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)ldsb) != hipSuccess)
-      return LR_ELAUNCH;
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};  // per instantiation, one bit per device
+  if (lr_raise_dyn_lds(reinterpret_cast<const void*>(&dgrad_wgrad0_kernel<CIN0>), ldsb, attr_done) != LR_OK) return LR_ELAUNCH;
   hipLaunchKernelGGL((dgrad_wgrad0_kernel<CIN0>), dim3((unsigned)blocks), dim3(512), ldsb, st, gpre1,
                      reinterpret_cast<const float4*>(packed_w1T), reinterpret_cast<const unsigned*>(mask0), x0, partial, d, ntiles);
   const int ncols = NTP * 16;

@@ -353,13 +353,8 @@ template <int NT, int CB, int OUTL>
 int launch_l(const float* in, const float* packed_w, const float* bias, float* out, const RowsDims& d, float slope, int ntiles,
              int z_phase, hipStream_t st) {
   const size_t lds = (size_t)36 * CB * NT * 1024;
-  static bool attr_done = false;  // per instantiation
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_rows_wlds_kernel<NT, CB, OUTL>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return LR_ELAUNCH;
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};  // per instantiation, one bit per device
+  if (lr_raise_dyn_lds(reinterpret_cast<const void*>(conv3d_rows_wlds_kernel<NT, CB, OUTL>), lds, attr_done) != LR_OK) return LR_ELAUNCH;
   const int ntrip = (ntiles + 2) / 3;
   int blocks = cu_count();
   if (const char* e = getenv("LIFTREG_CONV_ROWS_BLOCKS")) blocks = atoi(e);  // tuning aid

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/liftreg_hip.h"
 
 #define LR_WAVE 64
@@ -22,6 +23,19 @@ static inline int lr_launch_status() {
 static inline hipStream_t lr_stream(void* s) {
   (void)hipGetLastError();
   return reinterpret_cast<hipStream_t>(s);
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: `done` (one static per kernel
+// instantiation at the launch site) remembers the devices it was raised on, so a process that drives several GPUs — or
+// several threads launching at once — raises it on each of them.  Returns LR_OK or LR_ELAUNCH (checked by every caller).
+static inline int lr_raise_dyn_lds(const void* kernel, size_t bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return LR_ELAUNCH;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return LR_OK;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return LR_ELAUNCH;
+  done.fetch_or(bit, std::memory_order_release);
+  return LR_OK;
 }
 
 // Emitter poses travel by value (kernel-argument segment → SGPR loads).

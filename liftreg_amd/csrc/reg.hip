@@ -227,7 +227,9 @@ __global__ __launch_bounds__(1024) void disp_reg_march_kernel(const float* __res
   const int64_t V = (int64_t)D * W * H;
   const float* base = disp + (int64_t)bc * V;
   const int j = j0 + r;
-  const bool active = j < W;
+  // the block is R x H/4 threads rounded UP to whole wavefronts (lr_wave_sum below shuffles across all 64 lanes): the
+  // padding threads (r >= R) load nothing, store nothing and contribute acc = 0
+  const bool active = j < W && r < R;
   const size_t tsz = (size_t)(R + 2) * H;
   const int k = k4 * 4;
   const float cw = (j == 0 || j == W - 1) ? ihw : 0.5f * ihw;
@@ -413,7 +415,7 @@ extern "C" int lr_disp_reg_f32(const float* disp, double* partial, float* out, i
       const int ZC = (D + nzc - 1) / nzc;
       nzc = (D + ZC - 1) / ZC;
       const dim3 grid((unsigned)nrb, (unsigned)nzc, (unsigned)(B * 3));
-      hipLaunchKernelGGL(disp_reg_march_kernel, grid, dim3((unsigned)(R * H4)), lds, st, disp, partial, D, W, H, R, ZC, ihd, ihw, ihh);
+      hipLaunchKernelGGL(disp_reg_march_kernel, grid, dim3((unsigned)((R * H4 + 63) & ~63)), lds, st, disp, partial, D, W, H, R, ZC, ihd, ihw, ihh);
       if (int e = lr_launch_status()) return e;
       hipLaunchKernelGGL(disp_reg_final_kernel, dim3(1), dim3(256), 0, st, partial, out, B * 3 * nrb * nzc, (double)B * D * W * H);
       return lr_launch_status();

@@ -18,8 +18,10 @@ class NCCLoss(nn.Module):
         super().__init__()
         self.check_nan = check_nan
 
-    def forward(self, input, target):
-        loss = NCCFn.apply(input, target, NCC_CONFIGURED)
+    def forward(self, input, target, moments=None):
+        """`moments` (optional, non-reference): the (B,5) fp64 moments of exactly (input, target) when the model's one-pass
+        decode already accumulated them (output key "ncc_moments", opt key fuse_ncc) — the pass over both volumes is skipped."""
+        loss = NCCFn.apply(input, target, NCC_CONFIGURED, moments)
         if self.check_nan:
             assert not torch.isnan(loss), 'NCC loss is Nan.'
         return loss

@@ -58,7 +58,11 @@ class loss(nn.Module):
         return DispRegFn.apply(disp)
 
     def forward(self, input):
-        similarity = self.sim(input["warped"], input["target"])
+        moments = input.get("ncc_moments") if hasattr(input, "get") else None
+        if moments is not None:          # the decode's epilogue already accumulated them (model opt key fuse_ncc)
+            similarity = self.sim(input["warped"], input["target"], moments=moments)
+        else:
+            similarity = self.sim(input["warped"], input["target"])
         smoothness = self.compute_reg_loss(input["params"])
         total = self.sim_factor * similarity + self.get_reg_factor(input["epoch"]) * smoothness
         return {"total_loss": total, "sim_loss": similarity.item(), "reg_loss": smoothness.item()}

@@ -206,11 +206,18 @@ class model(nn.Module):
         if hit is not None:
             return hit
         plane, Dn = W * H, d1 - d0
-        cols = torch.cat([torch.arange((c * D + d0) * plane, (c * D + d1) * plane, device=device) for c in range(3)])
+        runs = [((c * D + d0) * plane, (c * D + d1) * plane) for c in range(3)]     # three contiguous column runs
         if self.pca_vectors_LxM.numel() > 0:
-            vec = self.pca_vectors_LxM.to(device)
-            basis = self._basis_storage(vec[:, cols].contiguous())
-            mean = self.pca_mean.to(device)[cols].contiguous()
+            # a loaded basis: copy ONLY the three column runs to the device, from wherever the full array lives (after
+            # `offload_full_basis()` that is host memory, so a sharded rank holds 1/world of the basis and nothing else);
+            # no index tensor, no device copy of the full array
+            vec, mu = self.pca_vectors_LxM, self.pca_mean
+            basis = torch.empty((self.latent_dim, 3 * Dn * plane), dtype=vec.dtype, device=device)
+            mean = torch.empty((3 * Dn * plane,), dtype=torch.float32, device=device)
+            for c, (lo, hi) in enumerate(runs):
+                basis[:, c * Dn * plane:(c + 1) * Dn * plane].copy_(vec[:, lo:hi])
+                mean[c * Dn * plane:(c + 1) * Dn * plane].copy_(mu[lo:hi])
+            basis = self._basis_storage(basis)
         else:
             if self._synthetic_seed is None:
                 raise RuntimeError("PCA basis missing")
@@ -220,11 +227,20 @@ class model(nn.Module):
             basis = torch.empty((self.latent_dim, 3 * Dn * plane), dtype=torch.float32, device=device)
             for l in range(self.latent_dim):      # the same stream of normals as _ensure_pca's full basis
                 row.normal_(0.0, 0.02 / float(np.sqrt(self.latent_dim)), generator=g)
-                basis[l] = row[cols]
+                for c, (lo, hi) in enumerate(runs):
+                    basis[l, c * Dn * plane:(c + 1) * Dn * plane].copy_(row[lo:hi])
             basis = self._basis_storage(basis)
             mean = torch.zeros((3 * Dn * plane,), dtype=torch.float32, device=device)
         self._pca_slabs[key] = (basis, mean)
         return basis, mean
+
+    def offload_full_basis(self):
+        """Sharded ranks: move the full (L,3V) basis and mean (loaded from `pca_path`) to host memory, keeping only the
+        per-rank column slabs `pca_slab` builds on the device (11.3 GB -> 1.4 GB per GPU at 8 ranks, C3).  The unsharded
+        `forward` needs the full basis on the device again (`net.to(device)` brings it back)."""
+        if self.pca_vectors_LxM.numel() > 0:
+            self.pca_vectors_LxM = self.pca_vectors_LxM.cpu()
+            self.pca_mean = self.pca_mean.cpu()
 
     def _basis_storage(self, vec):
         return vec.to(torch.bfloat16) if self.pca_dtype == "bf16" else vec.to(torch.float32)
@@ -341,8 +357,8 @@ class model(nn.Module):
 
     def decode(self, moving, coefs, moving_seg=None, target=None):
         """HBM-bound half: PCA reconstruction → identity add + trilinear warp.  Returns (disp, phi, warped).
-        `target` (inference, single-channel): the similarity's five moments of (warped, target) are accumulated in the
-        same pass and left for `NCCLoss(out["warped"], out["target"])` (ops.cached_ncc_moments) — SURVEY §8 f1."""
+        `target` (inference, single-channel, opt key fuse_ncc): the similarity's five moments of (warped, target) are
+        accumulated in the same pass and returned as a 4th value → output key "ncc_moments" (SURVEY §8 f1)."""
         B, C, D, W, H = moving.shape
         if (moving_seg is None and not (torch.is_grad_enabled() and coefs.requires_grad) and
                 ops.pca_warp_supported(coefs, self.pca_vectors_LxM, moving)):
@@ -350,7 +366,7 @@ class model(nn.Module):
             if target is not None and C == 1 and target.is_cuda and target.dtype == torch.float32 and \
                     target.is_contiguous() and target.shape == moving.shape and self.fuse_ncc:
                 return ops.pca_warp(coefs, self.pca_vectors_LxM, self.pca_mean, (self._id0, self._id1, self._id2), moving,
-                                    target=target)[:3]
+                                    target=target)
             return ops.pca_warp(coefs, self.pca_vectors_LxM, self.pca_mean, (self._id0, self._id1, self._id2), moving)
         # training: one autograd node for PCA reconstruction → (+ identity) → warp; the mask compose of moving
         # ((moving+1)*seg-1, :57) happens on the warp's taps
@@ -373,8 +389,9 @@ class model(nn.Module):
             target_cp = target
 
         coefs = self.encode(moving, target_proj, input['target_poses'])
-        disp_field, deform_field, warped_source = self.decode(moving, coefs, moving_seg, target=target_cp)
-        return {"warped": warped_source,
+        disp_field, deform_field, warped_source, *mom = self.decode(moving, coefs, moving_seg, target=target_cp)
+        return {**({"ncc_moments": mom[0]} if mom else {}),      # only with the non-reference opt key fuse_ncc
+                "warped": warped_source,
                 "phi": deform_field,
                 "params": disp_field,
                 "target": target_cp,

@@ -572,23 +572,6 @@ def pca_warp_supported(coefs, basis_LxM, img, d0=0, d1=None):
             coefs.shape[0] == B)
 
 
-# moments the one-pass decode left behind for the similarity: (weakref warped, weakref target, versions, moments)
-_ncc_cache = None
-
-
-def cached_ncc_moments(x, y, rows):
-    """The (rows,5) fp64 moments of (x, y) if the one-pass decode just produced them for exactly these two tensor
-    objects (same objects, unmodified since) — else None.  Lets `NCCLoss(out["warped"], out["target"])` skip its pass
-    over the two volumes ("NCC moments in the warp epilogue")."""
-    c = _ncc_cache
-    if c is None:
-        return None
-    xr, yr, ver, m = c
-    if xr() is x and yr() is y and ver == (x._version, y._version) and m.shape[0] == rows:
-        return m
-    return None
-
-
 def pca_warp(coefs, basis_LxM, mean, ids, img, *, using_scale=True, d0=0, d1=None, target=None):
     """disp = coefs·basis + mean ; phi = disp + identity ; warped = Bilinear(img, phi) in ONE kernel:
     the displacement field is written once and never read back.  Returns (disp, phi, warped), bit-identical to
@@ -598,8 +581,9 @@ def pca_warp(coefs, basis_LxM, mean, ids, img, *, using_scale=True, d0=0, d1=Non
     Rows [d0,d1) (z-slab sharding): outputs are slabs; `basis_LxM`/`mean` are the full (L,3V)/(3V,) arrays or a rank's
     compact (L,3·Dn·W·H)/(3·Dn·W·H,) slabs; ids[0] = the D-axis identity table of the slab's rows (Dn entries) or the
     whole table.  `target` (B,1,Dn,W,H), single-channel images only: the five fp64 NCC moments per batch row are
-    accumulated in the kernel's epilogue and returned as a 4th value (also left for `cached_ncc_moments`)."""
-    global _ncc_cache
+    accumulated in the kernel's epilogue and returned as a 4th value — the caller hands them to the similarity
+    explicitly (`NCCLoss(warped, target, moments=…)`, model output key "ncc_moments"); nothing is cached behind the
+    caller's back, so a later in-place change of `warped`/`target` cannot meet stale moments."""
     coefs, mean, img = _dev(coefs, "coefs"), _dev(mean, "mean"), _dev(img, "img")
     if not basis_LxM.is_cuda or basis_LxM.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError("basis must be a float32 (or bfloat16-stored) GPU tensor")
@@ -649,8 +633,6 @@ def pca_warp(coefs, basis_LxM, mean, ids, img, *, using_scale=True, d0=0, d1=Non
                 None if target is None else target[lo:hi].data_ptr(), None if target is None else partial.data_ptr(),
                 None if target is None else moments[lo:hi].data_ptr(), _stream()), "lr_pca_warp_slab_f32")
     if target is not None:
-        import weakref
-        _ncc_cache = (weakref.ref(warped), weakref.ref(target), (warped._version, target._version), moments)
         return disp, phi, warped, moments
     return disp, phi, warped
 

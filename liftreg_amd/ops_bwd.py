@@ -68,7 +68,9 @@ def pca_bwd_coef(gdisp, basis_LxM, nblk=None):
     gcoefs = torch.empty((B, L), dtype=torch.float32, device=gdisp.device)
     bf = basis_LxM.dtype == torch.bfloat16
     fn = _hip.lib().lr_pca_bwd_coef_bf16basis_f32 if bf else _hip.lib().lr_pca_bwd_coef_f32
-    with _timed("pca_bwd_coef" + ("_bf16basis" if bf else ""), bytes=(2 if bf else 4) * L * M + 4 * ((L + 7) // 8) * B * M):
+    # compulsory HBM bytes: the basis once + the gradient ONCE (the ceil(L/8) l-groups that share a range of the gradient
+    # run together on one XCD and take their re-reads from that L2 — they are not HBM traffic and are not counted)
+    with _timed("pca_bwd_coef" + ("_bf16basis" if bf else ""), bytes=(2 if bf else 4) * L * M + 4 * B * M):
         _hip.check(fn(g2.data_ptr(), basis_LxM.data_ptr(), partial.data_ptr(), gcoefs.data_ptr(), B, L, M,
                       basis_LxM.stride(0), M, nblk, _stream()), "lr_pca_bwd_coef_f32")
     return gcoefs

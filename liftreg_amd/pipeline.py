@@ -45,8 +45,11 @@ class TwoStreamRegistrar:
             self.dec.wait_event(done)
             from . import ops
             target_cp = ops.mask_compose(target, batch["target_label"]) if seg is not None else target
-            disp, phi, warped = net.decode(moving, coefs, seg, target=target_cp if self.sim is not None else None)
-            loss = self.sim(warped, target_cp) if self.sim is not None else None
+            disp, phi, warped, *mom = net.decode(moving, coefs, seg, target=target_cp if self.sim is not None else None)
+            if self.sim is None:
+                loss = None
+            else:                       # moments from the decode's epilogue (opt key fuse_ncc) go to the similarity explicitly
+                loss = self.sim(warped, target_cp, moments=mom[0]) if mom else self.sim(warped, target_cp)
         out = {"warped": warped, "phi": phi, "params": disp, "target": target_cp, "pca_coefs": coefs,
                "target_proj": batch["target_proj"], "warped_proj": batch["target_proj"]}
         # outputs were allocated on enc/dec and are handed to code running on the caller's stream
@@ -95,8 +98,10 @@ class GraphedRegistrar:
 
     def _run(self):
         out = self.net(self.static_in)
-        loss = self.sim(out["warped"], out["target"]) if self.sim is not None else None
-        return out, loss
+        if self.sim is None:
+            return out, None
+        mom = out.get("ncc_moments")
+        return out, (self.sim(out["warped"], out["target"], moments=mom) if mom is not None else self.sim(out["warped"], out["target"]))
 
     def __call__(self, batch):
         for k, t in self.static_in.items():

@@ -22,15 +22,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(nproc, extra, env=None, timeout=600):
+def _launch(nproc, extra, env=None, timeout=600, script="bench.py"):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + extra
+           "--master-port", str(_free_port()), os.path.join(ROOT, script), "--gpus", str(nproc)] + extra
     e = dict(os.environ)
     e.update(env or {})
     e["OMP_NUM_THREADS"] = "2"
     r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
     assert len(lines) == 1, f"exactly one JSON line expected from rank 0, got {len(lines)}:\n{r.stdout[-2000:]}"
     return json.loads(lines[0])
 
@@ -42,6 +42,21 @@ def test_two_rank_control_path_dry_run():
     assert d["ms_per_step"] >= 10.0 * 0.95          # rank 1 sleeps 10 ms per step: the line carries the MAX over ranks
     d = _launch(2, ["--steps", "2", "--warmup", "0", "--dry-run", "--shard", "slab"])
     assert d["scaling"] == "strong" and "slab" in d["config"]["parallelism"]
+
+
+def test_training_two_rank_control_path_dry_run():
+    """tools/train_bench.py as the driver would launch C5's data-parallel training step: rendezvous, the flat-bucket
+    gradient all-reduce fired from the autograd hooks (parallel.GradientAllReduce), fences, MAX over ranks, one line.
+    With the SAME batch on both ranks the averaged gradient is one rank's gradient: the Adam trajectory must equal the
+    single-process one; with different batches it must not."""
+    tb = os.path.join("tools", "train_bench.py")
+    one = _launch(1, ["--dry-run", "--config", "c2", "--steps", "3", "--warmup", "1"], script=tb)
+    same = _launch(2, ["--dry-run", "--config", "c2", "--steps", "3", "--warmup", "1", "--same-data"], script=tb)
+    diff = _launch(2, ["--dry-run", "--config", "c2", "--steps", "3", "--warmup", "1"], script=tb)
+    assert same["n_gpus"] == 2 and same["global_batch"] == 2 * one["global_batch"] and same["scaling"] == "weak"
+    assert "data parallel x2" in same["parallelism"] and "2 flat buckets" in same["parallelism"]
+    assert same["losses"] == pytest.approx(one["losses"], rel=1e-6)
+    assert diff["losses"][-1] != pytest.approx(one["losses"][-1], rel=1e-6)
 
 
 def test_wrong_world_size_is_refused():
@@ -62,3 +77,27 @@ def test_two_ranks_on_one_gpu_replicas_and_slab():
     assert "z-slab x2" in slab["config"]["parallelism"] and slab["value"] > 0
     # the same batch (seed 2021), sharded over two ranks: the NCC from all-reduced slab moments = the unsharded NCC
     assert abs(slab["ncc_loss"] - one["ncc_loss"]) < 1e-6, (slab["ncc_loss"], one["ncc_loss"])
+
+
+@pytest.mark.gpu
+def test_slab_mode_reports_the_sharded_projector_leg():
+    """`--shard slab` without --no-drr: the partial DRRs of the two ranks' slabs, summed by the all-reduce, equal the
+    single-GPU projector's images (north star: "all-reduce of slab-boundary partial sums")."""
+    env = {"LIFTREG_BENCH_BACKEND": "gloo"}
+    slab = _launch(2, ["--config", "c1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--shard", "slab", "--ramp-seconds", "0"], env)
+    leg = slab["drr_forward_sharded"]
+    assert leg["max_rel_vs_unsharded"] < 1e-5 and leg["volumes_per_s"] > 0 and leg["allreduce_bytes"] == 4 * 1 * 2 * 64 * 64
+    assert slab["ramp_seconds"] == 0 and slab["ramp_steps"] == 0
+
+
+@pytest.mark.gpu
+def test_training_two_ranks_on_one_gpu_same_data_equals_single_process():
+    """The data-parallel training step on the HIP kernels (C1 shape, two gloo ranks sharing the GPU): same batch on both
+    ranks -> bucketed, averaged gradients == one rank's -> the loss trajectory of the single-process run."""
+    env = {"LIFTREG_BENCH_BACKEND": "gloo"}
+    tb = os.path.join("tools", "train_bench.py")
+    args = ["--config", "c1", "--steps", "3", "--warmup", "1", "--no-kernel-table"]
+    one = _launch(1, args, env, script=tb)
+    two = _launch(2, args + ["--same-data"], env, script=tb)
+    assert two["n_gpus"] == 2 and two["global_batch"] == 2 and "data parallel x2" in two["parallelism"]
+    assert two["losses"] == pytest.approx(one["losses"], rel=2e-4, abs=1e-6), (one["losses"], two["losses"])

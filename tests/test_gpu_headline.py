@@ -85,7 +85,8 @@ def test_c3_decode_slab_crops_equal_c_oracle(decode_case):
 def test_c3_one_registration_of_the_timed_workload_vs_cpu_forward(dev):
     """bench.py's own C3 input and model (seed 2021), B=8 on the GPU; sample 0 through the torch-CPU restatement of
     model.forward (…Backproj.py:49-104, net_utils.py:26-52).  Bars: displacement ≤ 1e-4 (north star), coefficients
-    1e-4 relative, warped ≤ 1e-3 absolute (a 1e-5 coordinate difference times the phantom's HU edges), NCC ≤ 1e-5."""
+    1e-4 relative, warped ≤ 1e-4 absolute (the north star's bar for fp32 warps; measured 3e-5: a ~1e-9 coordinate
+    difference times the phantom's edges), NCC ≤ 1e-5."""
     import bench
     from liftreg_amd.layers.losses import NCCLoss
     from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
@@ -100,14 +101,14 @@ def test_c3_one_registration_of_the_timed_workload_vs_cpu_forward(dev):
     print("C3 parity vs CPU forward:", par)
     assert par["max_abs_disp"] <= 1e-4, par
     assert par["max_rel_coefs"] <= 1e-4, par
-    assert par["max_abs_warped"] <= 1e-3, par
+    assert par["max_abs_warped"] <= 1e-4, par
     assert abs(par["ncc_gpu"] - float(loss)) < 1e-6 and par["ncc_abs"] <= 1e-5, par
 
 
 def test_c3_ncc_moments_in_the_decode_epilogue(decode_case):
     """the one-pass decode with a target accumulates the similarity's five fp64 moments while `warped` is
     still in registers.  At the headline size: params/phi/warped keep their bits, the moments equal the separate
-    one-pass NCC kernel's (fp64 sums in another order: ≤1e-12 relative), and NCCLoss picks them up (no second pass)."""
+    one-pass NCC kernel's (fp64 sums in another order: ≤1e-12 relative), and NCCLoss takes them (no second pass)."""
     from liftreg_amd import ops
     from liftreg_amd.layers.losses import NCCLoss
     basis, mean, img, coefs, ids = decode_case
@@ -120,14 +121,13 @@ def test_c3_ncc_moments_in_the_decode_epilogue(decode_case):
     want = ops.ncc_moments(w0, target, B)
     rel = ((m - want).abs() / want.abs().clamp_min(1e-300)).max()
     assert float(rel) < 1e-12, float(rel)
-    assert ops.cached_ncc_moments(w1, target, B) is m and ops.cached_ncc_moments(w0, target, B) is None
     with ops.kernel_timer() as kt:
-        fused = NCCLoss(check_nan=False)(w1, target)
+        fused = NCCLoss(check_nan=False)(w1, target, moments=m)     # handed over explicitly: no identity-keyed cache
         names = set(kt.summary())
-    assert "ncc_moments" not in names                      # the cached moments were used
+    assert "ncc_moments" not in names                      # the epilogue's moments were used
     assert abs(float(fused) - float(NCCLoss(check_nan=False)(w0, target))) < 1e-7
-    w1.add_(0.0)                                           # any in-place touch invalidates the cache (version counter)
-    assert ops.cached_ncc_moments(w1, target, B) is None
+    with pytest.raises(ValueError):
+        NCCLoss(check_nan=False)(w1, target, moments=m[:3])
 
 
 def test_c3_first_block_with_fused_backprojection_every_bit(dev):

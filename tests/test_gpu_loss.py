@@ -52,7 +52,9 @@ def test_disp_reg_marching_kernel_equals_vector_kernel(monkeypatch):
     from liftreg_amd import ops
     dev = torch.device("cuda:0")
     rs = np.random.RandomState(31)
-    for shape, B, nblk in (((5, 9, 64), 2, None), ((37, 10, 128), 1, 7), ((33, 7, 96), 2, 64), ((20, 33, 256), 1, None), ((3, 2, 64), 1, 3)):
+    # H = 160 and 68: R x H/4 = 480 / 272 threads — not whole wavefronts (the block is padded with inactive threads)
+    for shape, B, nblk in (((5, 9, 64), 2, None), ((37, 10, 128), 1, 7), ((33, 7, 96), 2, 64), ((20, 33, 256), 1, None), ((3, 2, 64), 1, 3),
+                           ((9, 13, 160), 1, None), ((7, 35, 68), 2, None), ((4, 5, 68), 1, 9)):
         disp = rs.normal(0, 0.05, (B, 3) + shape).astype(np.float32)
         d = torch.from_numpy(disp).to(dev)
         got = float(ops.disp_reg(d, nblk=nblk))
@@ -70,7 +72,7 @@ def test_disp_reg_gradient_marching_kernel_equals_vector_kernel(monkeypatch):
     from liftreg_amd import ops_bwd
     dev = torch.device("cuda:0")
     rs = np.random.RandomState(37)
-    for shape, B in (((5, 9, 64), 2), ((37, 10, 128), 1), ((33, 7, 96), 1), ((70, 6, 64), 1), ((3, 4, 64), 1)):
+    for shape, B in (((5, 9, 64), 2), ((37, 10, 128), 1), ((33, 7, 96), 1), ((70, 6, 64), 1), ((3, 4, 64), 1), ((9, 13, 160), 1), ((7, 35, 68), 1)):
         disp = rs.normal(0, 0.05, (B, 3) + shape).astype(np.float32)
         d = torch.from_numpy(disp).to(dev)
         gout = torch.tensor(0.7, device=dev)

@@ -164,9 +164,25 @@ def test_conv_full_size_all_layers_vs_independent_gpu_conv(ops, dev):
             # block 0: the channels-last output runs the Winograd F(2,3)-along-H sweep, the NCDHW output the direct one —
             # equal to rounding (and BOTH are held to the independent conv below)
             assert float((y_cl.permute(0, 4, 1, 2, 3) - y_nc).abs().max()) <= 4e-6, "layer 0: layouts disagree"
-            errw = (y_cl.permute(0, 4, 1, 2, 3) - ref).abs()
-            assert int((errw > 1e-4 * ref.abs() + 2e-5).sum()) <= 256, f"layer 0 (Winograd sweep): max err {float(errw.max()):.3e}"
-            del errw
+            # the Winograd output is held to the same bar as the direct one: every element within the mixed tolerance of
+            # the independent conv, the few that are not (MIOpen's own wrong voxels, below) arbitrated on the CPU — no
+            # element may exceed the tolerance unexamined
+            y_w = y_cl.permute(0, 4, 1, 2, 3)
+            errw = (y_w - ref).abs()
+            badw = (errw > 1e-4 * ref.abs() + 2e-5).nonzero()
+            assert badw.shape[0] <= 256, f"layer 0 (Winograd sweep): {badw.shape[0]} disagreements, max err {float(errw.max()):.3e}"
+            for bi, _, z, yy, xx in {(r[0], 0, r[2], r[3], r[4]) for r in badw.tolist()}:
+                crop = torch.zeros((1, ci, 3, 3, 3))
+                for dz in range(3):
+                    for dy in range(3):
+                        for dx in range(3):
+                            a, bb, c = z + dz - 1, yy + dy - 1, xx + dx - 1
+                            if 0 <= a < N and 0 <= bb < N and 0 <= c < N:
+                                crop[0, :, dz, dy, dx] = cur_ncdhw[bi, :, a, bb, c].cpu()
+                want = F.leaky_relu(F.conv3d(crop, w.cpu(), b.cpu()), 0.2).flatten()
+                np.testing.assert_allclose(y_w[bi, :, z, yy, xx].cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5,
+                                           err_msg=f"layer 0 (Winograd sweep) voxel {(bi, z, yy, xx)}: CPU arbitration says OUR kernel is wrong")
+            del errw, y_w
         else:
             assert torch.equal(y_cl.permute(0, 4, 1, 2, 3), y_nc), f"layer {i}: layouts disagree"
         err = (y_nc - ref).abs()

@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
-"""Training-step timing at a BASELINE configuration (development aid; bench.py is the inference contract).
+"""Training-step timing at a BASELINE configuration — single GPU, or data-parallel over N GPUs of one node
+(BASELINE configs[4] = C5: 384^3 CT, 2x512^2 DRR, batch 32 over 8 GPUs, bf16 convs + fp32 warp, NCC loss backward).
 
   python tools/train_bench.py [--config c3] [--steps 5]
-One step = model(input) → SubspaceLoss → backward → Adam.step (RegistrationNet.py:389-406).
-Prints ms/step and the per-kernel table (HIP events around every launch, forward and backward).
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         tools/train_bench.py --gpus N --config c5 --conv-dtype bf16 --grad-dtype bf16
+
+One step = model(input) -> SubspaceLoss -> backward -> [gradient all-reduce] -> Adam.step (the reference's single-GPU
+`step()`, RegistrationNet.py:389-406 / main.py:108-111, with the one collective data parallelism needs: SURVEY 8e).
+N > 1: one process per GPU, B registrations per rank (weak scaling), gradients averaged by parallel.GradientAllReduce
+(flat buckets; the 52 MB FC-head bucket goes out from an autograd hook underneath the conv backward kernels).
+Rank 0 prints ONE JSON line {"metric": "training samples/s", "value": world*B*steps/time, ...} (time = MAX over ranks
+between barrier+synchronize fences) followed by the per-kernel table of its own step (HIP events, one line per kernel).
+`--dry-run`: the same control path on CPU over gloo with a stand-in module (no HIP kernel runs): rendezvous, bucket
+all-reduce from the hooks, fences, max-over-ranks, the single line.
 """
 import argparse
 import json
 import os
 import sys
+import time
 
 import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from liftreg_amd import ops  # noqa: E402
-from liftreg_amd.losses.SubspaceLoss import loss as SubspaceLoss  # noqa: E402
-from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model  # noqa: E402
-from liftreg_amd.utils.sdct_projection_utils import scan_poses  # noqa: E402
 
 CONFIGS = {"c1": dict(n=64, P=2, R=64, B=1, L=56), "c2": dict(n=128, P=2, R=128, B=4, L=56),
            "c3": dict(n=256, P=2, R=256, B=8, L=56),
@@ -28,6 +35,7 @@ CONFIGS = {"c1": dict(n=64, P=2, R=64, B=1, L=56), "c2": dict(n=128, P=2, R=128,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="c3")
+    ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pca-dtype", default="fp32", choices=("fp32", "bf16"),
@@ -36,61 +44,147 @@ def main():
                     help="bf16: bf16 forward of the conv blocks, fp32 gradients of that arithmetic (config C5)")
     ap.add_argument("--grad-dtype", default="fp32", choices=("fp32", "bf16"),
                     help="bf16 (with --conv-dtype bf16): pre-activation gradients between the blocks stored as bf16")
+    ap.add_argument("--ddp", action="store_true", help="use the flat gradient buckets at world size 1 too (A/B aid)")
+    ap.add_argument("--same-data", action="store_true",
+                    help="every rank trains on the SAME batch (test hook: the averaged gradient then equals one rank's, "
+                         "so the loss trajectory must equal the single-process run's)")
+    ap.add_argument("--no-kernel-table", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="CPU/gloo control-path self-test with a stand-in module")
     a = ap.parse_args()
     c = CONFIGS[a.config]
     n, P, R, B, L = c["n"], c["P"], c["R"], c["B"], c["L"]
-    dev = torch.device("cuda:0")
-    torch.manual_seed(2021)
-    net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:2021",
-                            "conv_dtype": a.conv_dtype, "grad_dtype": a.grad_dtype,
-                            "pca_dtype": a.pca_dtype}).to(dev).train()
-    crit = SubspaceLoss({"initial_reg_factor": 0.01, "min_reg_factor": 0.01, "reg_factor_decay_from": 2})
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4, eps=1e-5)
-    g = torch.Generator(device=dev)
-    g.manual_seed(2021)
-    rnd = lambda *s: torch.rand(*s, generator=g, device=dev) * 2 - 1
-    poses = scan_poses(30, P, n).astype(np.float32)
-    inp = {"source": rnd(B, 1, n, n, n), "target": rnd(B, 1, n, n, n), "target_proj": rnd(B, P, R, R),
-           "target_poses": torch.from_numpy(np.broadcast_to(poses, (B, P, 3)).copy())}
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        sys.exit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    backend = "gloo" if a.dry_run else os.environ.get("LIFTREG_BENCH_BACKEND", "nccl")   # nccl == RCCL on ROCm
+    dist = None
+    if a.dry_run:
+        dev = torch.device("cpu")
+    else:
+        if backend != "nccl":       # test hook: several gloo ranks share one GPU on a 1-GPU box
+            local %= max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    from liftreg_amd.parallel import GradientAllReduce
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+
+    def fence():
+        sync()
+        if dist is not None:
+            dist.barrier()
+        sync()
+
+    torch.manual_seed(2021)                     # identical initial weights on every rank (as DDP's broadcast would give)
+    if a.dry_run:
+        net = torch.nn.Sequential()
+        net.add_module("encoders", torch.nn.ModuleList([torch.nn.Linear(16, 16) for _ in range(6)] +
+                                                       [torch.nn.Sequential(torch.nn.Linear(16, 4))]))
+        g = torch.Generator().manual_seed(2021 if a.same_data else 2021 + rank)
+        xin = torch.randn(B, 16, generator=g)
+
+        def loss_of(ep):
+            h = xin
+            for m in net.encoders:
+                h = torch.tanh(m(h))
+            return (h ** 2).mean()
+    else:
+        from liftreg_amd import ops
+        from liftreg_amd.losses.SubspaceLoss import loss as SubspaceLoss
+        from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+        from liftreg_amd.utils.sdct_projection_utils import scan_poses
+        net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:2021",
+                                "conv_dtype": a.conv_dtype, "grad_dtype": a.grad_dtype,
+                                "pca_dtype": a.pca_dtype}).to(dev).train()
+        crit = SubspaceLoss({"initial_reg_factor": 0.01, "min_reg_factor": 0.01, "reg_factor_decay_from": 2})
+        crit.sim.check_nan = False
+        g = torch.Generator(device=dev)
+        g.manual_seed(2021 if a.same_data else 2021 + rank)
+        rnd = lambda *s: torch.rand(*s, generator=g, device=dev) * 2 - 1
+        poses = scan_poses(30, P, n).astype(np.float32)
+        inp = {"source": rnd(B, 1, n, n, n), "target": rnd(B, 1, n, n, n), "target_proj": rnd(B, P, R, R),
+               "target_poses": torch.from_numpy(np.broadcast_to(poses, (B, P, 3)).copy())}
+
+        def loss_of(ep):
+            out = net(inp)
+            out["epoch"] = ep
+            return crit(out)["total_loss"]
+
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, eps=1e-5)     # RegistrationNet.py:245
+    ddp = GradientAllReduce(net) if (world > 1 or a.ddp) else None
 
     def step(ep):
-        opt.zero_grad(set_to_none=True)
-        out = net(inp)
-        out["epoch"] = ep
-        crit.sim.check_nan = False
-        l = crit(out)["total_loss"]
+        if ddp is not None:
+            ddp.zero_grad()                      # one memset per bucket; .grad stays a view into its bucket
+        else:
+            opt.zero_grad(set_to_none=True)
+        l = loss_of(ep)
         l.backward()
+        if ddp is not None:
+            ddp.finish()                         # wait for the bucket all-reduces (launched from hooks), average
         opt.step()
-        return l
+        return l.detach()
 
+    losses = []
     for i in range(a.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
+        losses.append(step(i))
+    fence()
+    t0 = time.perf_counter()
     for i in range(a.steps):
-        step(i)
-    e.record()
-    torch.cuda.synchronize()
-    ms = s.elapsed_time(e) / a.steps
-    with ops.kernel_timer() as t:
-        step(0)
-        torch.cuda.synchronize()
+        losses.append(step(a.warmup + i))
+    fence()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms = elapsed / a.steps * 1e3
+    losses = [float(l) for l in losses]
+    assert all(np.isfinite(losses)), losses
+
     rows = []
-    for name, rec in t.summary().items():
-        avg = float(np.mean(rec["ms"]))
-        info = rec.get("info", {})
-        row = {"kernel": name, "ms": round(avg, 4), "launches": len(rec["ms"])}
-        if info.get("flops"):
-            row["TFLOP/s"] = round(info["flops"] / avg / 1e9, 1)
-        if info.get("bytes"):
-            row["GB/s"] = round(info["bytes"] / avg / 1e6, 0)
-        rows.append(row)
-    rows.sort(key=lambda r: -r["ms"] * r["launches"])
-    print(json.dumps({"config": a.config, "conv_dtype": a.conv_dtype, "grad_dtype": a.grad_dtype, "pca_dtype": a.pca_dtype, "ms_per_train_step": round(ms, 3), "samples_per_s": round(B / ms * 1e3, 1),
-                      "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
-    for r in rows:
-        print(json.dumps(r))
+    if not a.dry_run and not a.no_kernel_table:
+        with ops.kernel_timer() as kt:
+            step(a.warmup + a.steps)
+            torch.cuda.synchronize()
+        for name, rec in kt.summary().items():
+            avg = float(np.mean(rec["ms"]))
+            info = rec.get("info", {})
+            row = {"kernel": name, "ms": round(avg, 4), "launches": len(rec["ms"])}
+            if info.get("flops"):
+                row["TFLOP/s"] = round(info["flops"] / avg / 1e9, 1)
+            if info.get("bytes"):
+                row["GB/s"] = round(info["bytes"] / avg / 1e6, 0)
+            rows.append(row)
+        rows.sort(key=lambda r: -r["ms"] * r["launches"])
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training samples/s", "value": round(world * B / ms * 1e3, 2), "unit": "samples/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_train_step": round(ms, 3), "samples_per_s": round(world * B / ms * 1e3, 1),
+            "higher_is_better": True, "scaling": "weak", "dry_run": bool(a.dry_run),
+            "config": a.config, "conv_dtype": a.conv_dtype, "grad_dtype": a.grad_dtype, "pca_dtype": a.pca_dtype,
+            "global_batch": world * B,
+            "parallelism": (f"data parallel x{world}: {B} registrations per rank, gradient all-reduce of "
+                            f"{ddp.nbytes() / 2**20:.1f} MiB in {len(ddp.buckets)} flat buckets ({backend})" if ddp is not None
+                            else "single process"),
+            "losses": [round(l, 6) for l in losses],
+            "peak_mem_GB": None if a.dry_run else round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
+        for r in rows:
+            print(json.dumps(r))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
