@@ -215,7 +215,8 @@ class model(nn.Module):
             basis = torch.empty((self.latent_dim, 3 * Dn * plane), dtype=vec.dtype, device=device)
             mean = torch.empty((3 * Dn * plane,), dtype=torch.float32, device=device)
             for c, (lo, hi) in enumerate(runs):
-                basis[:, c * Dn * plane:(c + 1) * Dn * plane].copy_(vec[:, lo:hi])
+                for l in range(self.latent_dim):     # row by row: both sides contiguous -> direct copies, no staging temporaries
+                    basis[l, c * Dn * plane:(c + 1) * Dn * plane].copy_(vec[l, lo:hi])
                 mean[c * Dn * plane:(c + 1) * Dn * plane].copy_(mu[lo:hi])
             basis = self._basis_storage(basis)
         else:

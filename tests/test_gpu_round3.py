@@ -1,0 +1,114 @@
+"""GPU: round-3 additions outside the big-size files — the model's non-reference option keys end to end, the sharded
+basis slab built from a LOADED basis (column runs only), the compulsory-bytes model of the PCA gradient."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(n, P, B, dev, seed):
+    from liftreg_amd.utils.sdct_projection_utils import scan_poses
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    poses = scan_poses(30, P, n).astype(np.float32)
+    return {"source": torch.rand((B, 1, n, n, n), generator=g, device=dev) * 2 - 1,
+            "target": torch.rand((B, 1, n, n, n), generator=g, device=dev) * 2 - 1,
+            "target_proj": torch.rand((B, P, n, n), generator=g, device=dev) * 2 - 1,
+            "target_poses": torch.from_numpy(np.broadcast_to(poses, (B, P, 3)).copy())}
+
+
+def test_fuse_ncc_key_hands_the_moments_over_explicitly():
+    """opt key fuse_ncc: the output dict carries "ncc_moments" (an 8th, non-reference key), NCCLoss / SubspaceLoss take them
+    explicitly (no pass over the volumes, same value); without the key the output has exactly the reference's 7 keys.
+    A later in-place change of `warped` cannot meet stale moments: nothing is cached by tensor identity any more."""
+    from liftreg_amd import ops
+    from liftreg_amd.layers.losses import NCCLoss
+    from liftreg_amd.losses.SubspaceLoss import loss as SubspaceLoss
+    from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+    dev = torch.device("cuda:0")
+    n, P, L, B = 64, 2, 8, 2
+    torch.manual_seed(11)
+    plain = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:3"}).to(dev).eval()
+    fused = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:3", "fuse_ncc": True}).to(dev).eval()
+    fused.load_state_dict(plain.state_dict())
+    inp = _inputs(n, P, B, dev, 11)
+    sim = NCCLoss(check_nan=False)
+    with torch.no_grad():
+        o0, o1 = plain(inp), fused(inp)
+        assert sorted(o0) == sorted(["warped", "phi", "params", "target", "pca_coefs", "target_proj", "warped_proj"])
+        assert sorted(o1) == sorted(list(o0) + ["ncc_moments"])
+        for k in ("warped", "phi", "params", "pca_coefs"):
+            assert torch.equal(o0[k], o1[k]), k
+        want = float(sim(o0["warped"], o0["target"]))
+        with ops.kernel_timer() as kt:
+            got = float(sim(o1["warped"], o1["target"], moments=o1["ncc_moments"]))
+            crit = SubspaceLoss({"initial_reg_factor": 0.01, "min_reg_factor": 0.01, "reg_factor_decay_from": 2})
+            crit.sim.check_nan = False
+            tot = crit({**o1, "epoch": 0})
+            names = set(kt.summary())
+        assert "ncc_moments" not in names, names
+        assert abs(got - want) < 1e-7 and abs(tot["sim_loss"] - want) < 1e-7
+        # after an in-place change the caller simply does not pass the (now stale) moments: the loss is recomputed
+        o1["warped"].mul_(0.5)
+        assert abs(float(sim(o1["warped"], o1["target"])) - float(sim(o0["warped"] * 0.5, o0["target"]))) < 1e-7
+
+
+def test_pca_slab_of_a_loaded_basis_copies_column_runs_only(tmp_path):
+    """A basis loaded from pca_path, offloaded to the host on a sharded rank: pca_slab copies the three column runs of the
+    rank's rows to the device — equal to the columns of the full basis, the full array never reaches the device again, and
+    the sharded forward built on those slabs equals the unsharded one."""
+    from liftreg_amd import parallel as par
+    from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+    dev = torch.device("cuda:0")
+    n, P, L, B = 64, 2, 6, 1
+    rs = np.random.RandomState(5)
+    vec = (rs.standard_normal((L, 3 * n ** 3)) * 0.01).astype(np.float32)
+    mean = (rs.standard_normal((3 * n ** 3,)) * 0.001).astype(np.float32)
+    np.save(os.path.join(tmp_path, "pca_vectors.npy"), vec)
+    np.save(os.path.join(tmp_path, "pca_mean.npy"), mean)
+    torch.manual_seed(5)
+    net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": str(tmp_path)}).to(dev).eval()
+    inp = _inputs(n, P, B, dev, 5)
+    with torch.no_grad():
+        ref = net(inp)
+    net.offload_full_basis()
+    assert not net.pca_vectors_LxM.is_cuda
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    before = torch.cuda.memory_allocated()
+    plane = n * n
+    for world in (2,):
+        for r in range(world):
+            d0, d1 = par.slab_bounds(n, world, r)
+            bs, ms = net.pca_slab(d0, d1, dev)
+            cols = np.concatenate([np.arange((c * n + d0) * plane, (c * n + d1) * plane) for c in range(3)])
+            assert bs.is_cuda and tuple(bs.shape) == (L, 3 * (d1 - d0) * plane)
+            assert np.array_equal(bs.cpu().numpy(), vec[:, cols]) and np.array_equal(ms.cpu().numpy(), mean[cols])
+    # both slabs together are one basis worth of bytes; a full device copy or an int64 index would show in the peak
+    assert torch.cuda.max_memory_allocated() - before < 1.2 * (vec.nbytes + mean.nbytes), (torch.cuda.max_memory_allocated() - before, vec.nbytes)
+    with torch.no_grad():
+        outs = par.SlabShardedRegistration(net, par.LocalComm(2)).forward([inp] * 2)
+    for r, o in enumerate(outs):
+        d0, d1 = par.slab_bounds(n, 2, r)
+        assert torch.equal(o["params"], ref["params"][:, :, d0:d1]) and torch.equal(o["warped"], ref["warped"][:, :, d0:d1])
+
+
+def test_pca_gradient_byte_model_is_compulsory_traffic():
+    """ops_bwd.pca_bwd_coef reports basis + ONE read of the gradient (the l-groups' re-reads come from L2): no table entry
+    can exceed what HBM delivers."""
+    from liftreg_amd import ops, ops_bwd
+    dev = torch.device("cuda:0")
+    B, L, M = 4, 56, 3 * 32 ** 3
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    basis = torch.randn((L, M), generator=g, device=dev)
+    gd = torch.randn((B, M), generator=g, device=dev)
+    with ops.kernel_timer() as kt:
+        gc = ops_bwd.pca_bwd_coef(gd, basis)
+        rec = kt.summary()["pca_bwd_coef"]
+    assert rec["info"]["bytes"] == 4 * L * M + 4 * B * M
+    want = gd.double() @ basis.double().T
+    assert float((gc.double() - want).abs().max() / want.abs().max()) < 1e-5
