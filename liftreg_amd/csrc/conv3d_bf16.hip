@@ -703,7 +703,8 @@ extern "C" int lr_conv3d_pack_weights_bf16(const float* weight, void* packed, in
 
 extern "C" int64_t lr_conv3d_packed_bf16_planar_bytes(int Cin, int Cout) {
   if (Cin < 1 || (Cout != 16 && Cout != 32)) return LR_EUNSUPPORTED;
-  return (int64_t)((Cin + 2) / 3) * 4 * (Cout / 16) * 64 * 16;
+  // [channel-pass packing | packing of the all-channels kernel (conv0_cl_bf16.hip), present for 4 < Cin <= 16]
+  return (int64_t)((Cin + 2) / 3) * 4 * (Cout / 16) * 64 * 16 + lr_internal_conv0_cl_bf16_packed_bytes(Cin, Cout);
 }
 
 extern "C" int lr_conv3d_pack_weights_bf16_planar(const float* weight, void* packed, int Cin, int Cout, void* stream) {
@@ -711,9 +712,11 @@ extern "C" int lr_conv3d_pack_weights_bf16_planar(const float* weight, void* pac
   if (Cin < 1 || (Cout != 16 && Cout != 32)) return LR_EUNSUPPORTED;
   if (reinterpret_cast<uintptr_t>(packed) & 15u) return LR_EALIGN;
   const int total = ((Cin + 2) / 3) * 4 * (Cout / 16) * 64;
-  hipLaunchKernelGGL(pack_bf16_planar_kernel, dim3((total + 255) / 256), dim3(256), 0, lr_stream(stream), weight,
+  hipStream_t st = lr_stream(stream);
+  hipLaunchKernelGGL(pack_bf16_planar_kernel, dim3((total + 255) / 256), dim3(256), 0, st, weight,
                      reinterpret_cast<u32x4*>(packed), Cin, Cout, Cout / 16);
-  return lr_launch_status();
+  if (int e = lr_launch_status()) return e;
+  return lr_internal_conv0_cl_bf16_pack(weight, reinterpret_cast<unsigned char*>(packed) + (size_t)total * 16, Cin, Cout, st);
 }
 
 // The encoder's first block in the bf16 variant: fp32 NCDHW input (rounded to bf16 on the way into the MFMA),
@@ -737,6 +740,11 @@ extern "C" int lr_conv3d_first_bf16(const float* in, const void* packed_w, const
   const dim3 grid((unsigned)nblk), block(256);
   hipStream_t st = lr_stream(stream);
   const u32x4* wt = reinterpret_cast<const u32x4*>(packed_w);
+  if (Cin > 3 && !getenv("LIFTREG_CONV0_BF16_PASSES")) {   // many channels (C4): all of them staged once, channels-last in LDS
+    const int e = lr_internal_conv0_cl_bf16(in, wt + (size_t)((Cin + 2) / 3) * 4 * (Cout / 16) * 64, bias, out, B, Cin, Cout, D, W, H,
+                                            out_layout, negative_slope, st);
+    if (e != LR_EUNSUPPORTED) return e;
+  }
 #define LR_C0(NTV, SG)                                                                                                   \
   do {                                                                                                                    \
     if (out_layout == LR_LAYOUT_BF16_NDHWC_HPS)                                                                           \

@@ -84,3 +84,11 @@ int lr_internal_conv_rows_wlds(const float* in, const float* packed_w, const flo
 int lr_internal_conv0_pc(const float* in0, int64_t bs0, const float* in_rest, int64_t bsr, const float* packed_w,
                          const float* bias, float* out, int B, int Cin, int D, int W, int H, int out_layout, float slope,
                          const float* proj, const float* poses, int P, int Pw, int Ph, hipStream_t st);
+
+// conv0_cl_bf16.hip: the first block with 4 < Cin <= 16 input channels on the bf16 MFMA (all channels of a brick staged once,
+// channels-last in LDS).  Its operand packing is appended to the channel-pass packing of lr_conv3d_pack_weights_bf16_planar.
+// LR_EUNSUPPORTED -> use conv0_bf16_kernel's channel passes.
+int64_t lr_internal_conv0_cl_bf16_packed_bytes(int Cin, int Cout);
+int lr_internal_conv0_cl_bf16_pack(const float* weight, void* packed, int Cin, int Cout, hipStream_t st);
+int lr_internal_conv0_cl_bf16(const float* in, const void* packed, const float* bias, void* out, int B, int Cin, int Cout, int D,
+                              int W, int H, int out_layout, float slope, hipStream_t st);
