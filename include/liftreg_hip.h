@@ -173,6 +173,15 @@ int lr_conv3d_k3_lrelu_f32(const float* in, const float* packed_w, const float* 
 int lr_conv3d_k3_lrelu_zphase_f32(const float* in, const float* packed_w, const float* bias, float* out,
                                   int B, int Cin, int Cout, int D, int W, int H, int stride,
                                   int in_layout, int out_layout, float negative_slope, int z_phase, void* stream);
+/* ... writing into a STRIDED batch: output element (b, ...) lives at out + b*out_batch_stride + its dense offset inside one
+ * batch element; out_batch_stride >= Cout*Do*Wo*Ho in elements of the output type (0 = dense).  The sharded model
+ * (liftreg_amd/parallel.py; replaces the per-layer call of src/liftreg/layers/layers.py:365-369 under z-slab sharding,
+ * SURVEY 8e) keeps every activation in per-sample halo-padded buffers [filler | halo | slab]: with the stride ONE launch
+ * covers the whole batch instead of one launch per sample.  Same kernels, same bits as the dense entry points. */
+int lr_conv3d_k3_lrelu_obs_f32(const float* in, const float* packed_w, const float* bias, float* out,
+                               int B, int Cin, int Cout, int D, int W, int H, int stride,
+                               int in_layout, int out_layout, float negative_slope, int z_phase,
+                               int64_t out_batch_stride, void* stream);
 
 /* Training backward of the encoder's first two blocks in ONE kernel (conv3d_bwd_fused.hip): the data gradient of block 1
  * (16 <- 32 channels, stride 2), the LeakyReLU mask of block 0 and the weight / bias gradient of block 0 — the (B,D,W,H,16)
@@ -395,6 +404,10 @@ int lr_conv3d_pack_weights_bf16(const float* weight, void* packed, int Cin, int 
 int lr_conv3d_k3_lrelu_bf16(const void* in, const void* packed_w, const float* bias, void* out, int B, int Cin,
                             int Cout, int D, int W, int H, int stride, int in_layout, int out_layout,
                             float negative_slope, void* stream);
+/* lr_conv3d_k3_lrelu_bf16 into a strided batch (see lr_conv3d_k3_lrelu_obs_f32; stride in elements of the output type). */
+int lr_conv3d_k3_lrelu_obs_bf16(const void* in, const void* packed_w, const float* bias, void* out, int B, int Cin,
+                                int Cout, int D, int W, int H, int stride, int in_layout, int out_layout,
+                                float negative_slope, int64_t out_batch_stride, void* stream);
 int lr_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 /* The first block of the bf16 variant: fp32 NCDHW input (CT + backprojection; rounded to bf16 on the way into
  * the MFMA), stride 1, any Cin (passes of 3 channels), bf16 channels-last output (out_layout 3|4).
@@ -403,6 +416,10 @@ int64_t lr_conv3d_packed_bf16_planar_bytes(int Cin, int Cout);
 int lr_conv3d_pack_weights_bf16_planar(const float* weight, void* packed, int Cin, int Cout, void* stream);
 int lr_conv3d_first_bf16(const float* in, const void* packed_w, const float* bias, void* out, int B, int Cin,
                          int Cout, int D, int W, int H, int out_layout, float negative_slope, void* stream);
+/* ... into a strided batch (see lr_conv3d_k3_lrelu_obs_f32; stride in bf16 elements, 0 = dense). */
+int lr_conv3d_first_obs_bf16(const float* in, const void* packed_w, const float* bias, void* out, int B, int Cin, int Cout,
+                             int D, int W, int H, int out_layout, float negative_slope, int64_t out_batch_stride,
+                             void* stream);
 
 /* bf16-gradient training variant: the pre-activation gradients between the blocks are stored as bf16 plain
  * channels-last (what bf16 mixed precision does).  lr_conv3d_dgrad_bf16: gx (B,D,W,H,Cx) bf16 = the PRODUCER's

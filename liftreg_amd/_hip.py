@@ -40,6 +40,7 @@ SIGNATURES = {
     "lr_conv3d_pack_weights_f32": (_i, [_p, _p, _i, _i, _i, _p]),
     "lr_conv3d_k3_lrelu_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "lr_conv3d_k3_lrelu_zphase_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "lr_conv3d_k3_lrelu_obs_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i64, _p]),
     "lr_conv3d_k3_lrelu_mask_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "lr_conv3d_dgrad_wgrad0_partial_floats": (_i64, [_i]),
     "lr_conv3d_dgrad_wgrad0_f32": (_i, [_p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
@@ -69,10 +70,12 @@ SIGNATURES = {
     "lr_conv3d_packed_bf16_bytes": (_i64, [_i, _i]),
     "lr_conv3d_pack_weights_bf16": (_i, [_p, _p, _i, _i, _p]),
     "lr_conv3d_k3_lrelu_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "lr_conv3d_k3_lrelu_obs_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i64, _p]),
     "lr_cast_f32_to_bf16": (_i, [_p, _p, _i64, _p]),
     "lr_conv3d_packed_bf16_planar_bytes": (_i64, [_i, _i]),
     "lr_conv3d_pack_weights_bf16_planar": (_i, [_p, _p, _i, _i, _p]),
     "lr_conv3d_first_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "lr_conv3d_first_obs_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i64, _p]),
     "lr_conv3d_dgrad_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _f, _p]),
     "lr_conv3d_wgrad_bf16g_f32": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "lr_normalize_clip_f32": (_i, [_p, _p, _i64, _f, _f, _p]),

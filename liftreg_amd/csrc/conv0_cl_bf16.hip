@@ -54,6 +54,7 @@ struct C0Dims {
   int B, Cin, D, W, H;
   int nHq, nWq, nch, ZC;   // column grid (x, y), z chunks per column and planes per chunk (a multiple of SZ)
   int nunits;             // B * nch * nWq * nHq
+  long long out_bs;       // output elements between batch elements (dense: 16*D*W*H)
   float slope;
   int abl;   // timing-only ablation bits (LIFTREG_C0CL_ABL, wrong results): 1 no global loads, 2 no stores, 4 no sweep, 8 no LDS writes
 };
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void conv0_cl_bf16_kernel(const float* __re
     s2 -= s2 >= NRING ? NRING : 0;
     // this lane's voxel of tile (r, t): row y0 + 2 rh + r, x = x0 + 16 t + col; channels kq*4 .. kq*4+3
     const int hp_lane = HPSOUT ? (col & 1) * (dH >> 1) + (u.x0 >> 1) + (col >> 1) : u.x0 + col;
-    u16* const out_lane = out + ((((int64_t)u.b * dD + dz) * dW + (u.y0 + 2 * rh)) * dH + hp_lane) * 16 + kq * 4;
+    u16* const out_lane = out + (int64_t)u.b * d.out_bs + (((int64_t)dz * dW + (u.y0 + 2 * rh)) * dH + hp_lane) * 16 + kq * 4;
     const unsigned char* const pl0 = lds + (unsigned)s0 * PLB;
     const unsigned char* const pl2 = lds + (unsigned)s2 * PLB;
     const unsigned char* const cls[6] = {pl0 + offA[0], pl0 + offA[1], pl0 + offA[2], pl2 + offB, pl2 + offC, pl2 + offD};
@@ -398,7 +399,7 @@ int lr_internal_conv0_cl_bf16_pack(const float* weight, void* packed, int Cin, i
 
 // LR_EUNSUPPORTED -> the caller falls back to the channel-pass kernel
 int lr_internal_conv0_cl_bf16(const float* in, const void* packed, const float* bias, void* out, int B, int Cin, int Cout, int D,
-                              int W, int H, int out_layout, float slope, hipStream_t st) {
+                              int W, int H, int out_layout, float slope, long long out_bs, hipStream_t st) {
   if (Cin <= 3 || Cin > 16 || Cout != 16 || (H & 3) || (reinterpret_cast<uintptr_t>(in) & 15u)) return LR_EUNSUPPORTED;
   const int64_t V = (int64_t)D * W * H;
   if ((int64_t)Cin * V * 4 + (int64_t)8 * W * H * 4 >= 0x7fffffffLL) return LR_EUNSUPPORTED;   // 31-bit byte offsets inside one batch element
@@ -425,6 +426,7 @@ int lr_internal_conv0_cl_bf16(const float* in, const void* packed, const float* 
   const int64_t nu = cols * d.nch;
   if (nu > 0x7fffffffLL) return LR_EINVAL;
   d.nunits = (int)nu; d.slope = slope;
+  d.out_bs = out_bs ? out_bs : (long long)16 * D * W * H;
   d.abl = 0;
   if (const char* e = getenv("LIFTREG_C0CL_ABL")) d.abl = atoi(e);
   if (blocks > d.nunits) blocks = d.nunits;

@@ -56,6 +56,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct ConvDims {
   int B, Cin, Cout, D, W, H, Do, Wo, Ho;
   int nHq, nWq, nDq;
+  long long out_bs;   // output elements between two batch elements (dense: Cout*Do*Wo*Ho; larger: `out` is a plane range of a
+                      // bigger per-sample buffer, parallel.SlabShardedRegistration)
 };
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.0f ? v : v * slope; }
@@ -82,13 +84,13 @@ __device__ __forceinline__ void store_tile(const f32x4& acc, float* __restrict__
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] = lrelu(acc[r], slope);
   if (out_layout == LR_LAYOUT_NDHWC) {
-    float* o = out + ((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + ho) * d.Cout + c0;
+    float* o = out + (int64_t)b * d.out_bs + (((int64_t)dz * d.Wo + wo) * d.Ho + ho) * d.Cout + c0;
     *reinterpret_cast<f32x4*>(o) = v;
   } else if (out_layout == LR_LAYOUT_BF16_NDHWC || out_layout == LR_LAYOUT_BF16_NDHWC_HPS) {
     // bf16 storage (C4/C5): 4 couts of one voxel = one 8-byte store; rows plain or [parity][Ho/2][Cout]
     const int hp = out_layout == LR_LAYOUT_BF16_NDHWC_HPS ? (ho & 1) * (d.Ho >> 1) + (ho >> 1) : ho;
     unsigned short* o = reinterpret_cast<unsigned short*>(out) +
-                        ((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + hp) * d.Cout + c0;
+                        (int64_t)b * d.out_bs + (((int64_t)dz * d.Wo + wo) * d.Ho + hp) * d.Cout + c0;
     unsigned short h[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) h[r] = __builtin_bit_cast(unsigned short, (__bf16)v[r]);  // round to nearest even
@@ -96,11 +98,11 @@ __device__ __forceinline__ void store_tile(const f32x4& acc, float* __restrict__
   } else if (out_layout == LR_LAYOUT_NDHWC_HPS) {  // even voxels of the row first, then the odd ones
     // row = [channel block of 16][parity][Ho/2][16 floats]
     const int hp = (ho & 1) * (d.Ho >> 1) + (ho >> 1);
-    float* o = out + (((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho * d.Cout + ((c0 >> 4) * d.Ho + hp) * 16 + (c0 & 15);
+    float* o = out + (int64_t)b * d.out_bs + ((int64_t)dz * d.Wo + wo) * d.Ho * d.Cout + ((c0 >> 4) * d.Ho + hp) * 16 + (c0 & 15);
     *reinterpret_cast<f32x4*>(o) = v;
   } else {
     const int64_t vo = (int64_t)d.Do * d.Wo * d.Ho;
-    float* o = out + ((int64_t)b * d.Cout + c0) * vo + ((int64_t)dz * d.Wo + wo) * d.Ho + ho;
+    float* o = out + (int64_t)b * d.out_bs + (int64_t)c0 * vo + ((int64_t)dz * d.Wo + wo) * d.Ho + ho;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r * vo] = v[r];
   }
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(256, (SINGLE ? (WINO ? LR_C0_WINO_BLOCKS : 3) : 2))
         // output plane (b, dz) of this wave as a buffer resource; zero-length (every store dropped) when it is absent
         const int64_t plane_elems = (int64_t)d.Wo * d.Ho * d.Cout;
         const __amdgpu_buffer_rsrc_t oplane = __builtin_amdgcn_make_buffer_rsrc(
-            out + ((int64_t)b * d.Do + (zok ? dz : 0)) * plane_elems, (short)0, zok ? (int)(plane_elems * 4) : 0, 0x00020000);
+            out + (int64_t)b * d.out_bs + (int64_t)(zok ? dz : 0) * plane_elems, (short)0, zok ? (int)(plane_elems * 4) : 0, 0x00020000);
         // the sign-mask plane (b, dz) of this wave (MASK): zero-length when the plane does not exist
         const __amdgpu_buffer_rsrc_t mplane = __builtin_amdgcn_make_buffer_rsrc(
             MASK ? mask_out + ((int64_t)b * d.Do + (zok ? dz : 0)) * d.Wo * d.Ho * 4 : reinterpret_cast<unsigned char*>(out),
@@ -996,7 +998,7 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
                      float* out, int B, int Cin, int Cout, int D, int W, int H,
                      int stride, int in_layout, int out_layout,
                      float negative_slope, void* stream, const FusedBp* bpa = nullptr, unsigned char* mask_out = nullptr,
-                     int z_phase = 0) {
+                     int z_phase = 0, long long out_bs = 0) {
   if (bpa) in = in0;   // no channel-1.. tensor exists: the staging never dereferences `in` for them
   if (!in || !packed_w || !out) return LR_ENULL;
   if (B < 1 || Cin < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
@@ -1011,6 +1013,10 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
   ConvDims d;
   d.B = B; d.Cin = Cin; d.Cout = Cout; d.D = D; d.W = W; d.H = H;
   d.Do = (D - 1) / stride + 1; d.Wo = (W - 1) / stride + 1; d.Ho = (H - 1) / stride + 1;
+  const long long dense_bs = (long long)Cout * d.Do * d.Wo * d.Ho;
+  if (out_bs != 0 && out_bs < dense_bs) return LR_EINVAL;
+  if (out_bs != 0 && out_bs != dense_bs && (bpa || mask_out)) return LR_EUNSUPPORTED;   // the fused / mask forms write dense outputs
+  d.out_bs = out_bs ? out_bs : dense_bs;
   hipStream_t st = lr_stream(stream);
   const int NT = Cout / 16;
   const dim3 block(256);
@@ -1032,7 +1038,7 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
     // LDS); LIFTREG_CONV_DIRECT=1 selects the direct walk below — the oracle's fmaf chain, bit for bit (A/B aid, tests)
     if (rows_ok && !getenv("LIFTREG_CONV_DIRECT")) {
       const int rc = lr_internal_conv_rows_wlds(in, packed_w, bias, out, B, Cin, Cout, D, W, H, out_layout, negative_slope,
-                                                z_phase, st);
+                                                z_phase, d.out_bs, st);
       if (rc != LR_EUNSUPPORTED) return rc;
     }
     if (rows_ok && Cin == 32 && NT == 2 && nblk < (getenv("LIFTREG_CONV_ROWS_MT1_BELOW") ? atoi(getenv("LIFTREG_CONV_ROWS_MT1_BELOW")) : 512)) {  // env: tuning aid
@@ -1081,7 +1087,7 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
     // backprojection (f1); for plain inputs it measured equal to the single-buffer kernel below (3.31-3.34 vs 3.29-3.30 ms
     // at C3, same bits), which therefore stays the default — LIFTREG_CONV0_PC=1 selects it (A/B aid).
     const bool pc_on = bpa || (getenv("LIFTREG_CONV0_PC") && atoi(getenv("LIFTREG_CONV0_PC")) != 0);
-    if (pc_on && stride == 1 && NT == 1 && single && vec4 &&
+    if (pc_on && d.out_bs == dense_bs && stride == 1 && NT == 1 && single && vec4 &&
         (out_layout == LR_LAYOUT_NDHWC || out_layout == LR_LAYOUT_NDHWC_HPS)) {
       const int64_t V = (int64_t)D * W * H;
       int rc;
@@ -1179,6 +1185,19 @@ extern "C" int lr_conv3d_k3_lrelu_zphase_f32(const float* in, const float* packe
   if (z_phase != 0 && z_phase != 1) return LR_EINVAL;
   return conv_impl(in, nullptr, packed_w, bias, out, B, Cin, Cout, D, W, H, stride, in_layout, out_layout, negative_slope,
                    stream, nullptr, nullptr, z_phase);
+}
+
+// lr_conv3d_k3_lrelu_zphase_f32 writing into a STRIDED batch: output element (b, ...) lives at out + b*out_batch_stride + the
+// dense offset inside one batch element (out_batch_stride >= Cout*Do*Wo*Ho, in elements of the output type).  The sharded
+// model's activations live in per-sample halo-padded buffers; with the stride one launch covers the whole batch.
+extern "C" int lr_conv3d_k3_lrelu_obs_f32(const float* in, const float* packed_w, const float* bias, float* out, int B,
+                                          int Cin, int Cout, int D, int W, int H, int stride, int in_layout,
+                                          int out_layout, float negative_slope, int z_phase, int64_t out_batch_stride,
+                                          void* stream) {
+  if (z_phase != 0 && z_phase != 1) return LR_EINVAL;
+  if (out_batch_stride < 0) return LR_EINVAL;
+  return conv_impl(in, nullptr, packed_w, bias, out, B, Cin, Cout, D, W, H, stride, in_layout, out_layout, negative_slope,
+                   stream, nullptr, nullptr, z_phase, (long long)out_batch_stride);
 }
 
 // The encoder's first block on cat([moving, views]) WITHOUT the concatenation: channel 0 from `in0` (B,1,D,W,H),

@@ -28,6 +28,7 @@ constexpr int TD = 4;
 struct ConvDimsH {
   int B, Cin, Cout, D, W, H, Do, Wo, Ho;
   int nHq, nWq, nDq;
+  long long out_bs;   // output elements between batch elements (dense: Cout*Do*Wo*Ho)
 };
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.0f ? v : v * slope; }
@@ -48,13 +49,13 @@ __device__ __forceinline__ void store_tile_any(const f32x4& acc, void* __restric
   for (int r = 0; r < 4; ++r) v[r] = lrelu(acc[r], slope);
   if (out_layout == LR_LAYOUT_NCDHW) {  // fp32, the reference's layout (last block -> Flatten)
     const int64_t vo = (int64_t)d.Do * d.Wo * d.Ho;
-    float* o = reinterpret_cast<float*>(out) + ((int64_t)b * d.Cout + c0) * vo + ((int64_t)dz * d.Wo + wo) * d.Ho + ho;
+    float* o = reinterpret_cast<float*>(out) + (int64_t)b * d.out_bs + (int64_t)c0 * vo + ((int64_t)dz * d.Wo + wo) * d.Ho + ho;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r * vo] = v[r];
     return;
   }
   const int hp = out_layout == LR_LAYOUT_BF16_NDHWC_HPS ? (ho & 1) * (d.Ho >> 1) + (ho >> 1) : ho;
-  u16* o = reinterpret_cast<u16*>(out) + ((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + hp) * d.Cout + c0;
+  u16* o = reinterpret_cast<u16*>(out) + (int64_t)b * d.out_bs + (((int64_t)dz * d.Wo + wo) * d.Ho + hp) * d.Cout + c0;
   const unsigned lo = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
   const unsigned hi = (unsigned)to_bf16(v[2]) | ((unsigned)to_bf16(v[3]) << 16);
   *reinterpret_cast<uint2*>(o) = make_uint2(lo, hi);
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv0_bf16_kernel(const
   // store of tile (r, t): bf16 rows of Cout channels; this lane's voxel is x0 + 16t + col.  x0 is a multiple of 64,
   // so in a parity-split row the lane sits at (col&1)*(H/2) + x0/2 + col/2 and a tile advances 8 positions.
   const int hp_lane = HPSOUT ? (col & 1) * (d.H >> 1) + (x0 >> 1) + (col >> 1) : x0 + col;
-  u16* const out_lane = reinterpret_cast<u16*>(out) + ((((int64_t)b * d.D + dz) * d.W + y0) * d.H + hp_lane) * d.Cout + kq * 4;
+  u16* const out_lane = reinterpret_cast<u16*>(out) + (int64_t)b * d.out_bs + (((int64_t)dz * d.W + y0) * d.H + hp_lane) * d.Cout + kq * 4;
   const int64_t row_el = (int64_t)d.H * d.Cout;
   auto store_tile = [&](const f32x4 (&a)[NT], int r, int t) {
     if (dz >= d.D || y0 + r >= d.W || x0 + t * 16 + col >= d.H) return;
@@ -721,9 +722,9 @@ extern "C" int lr_conv3d_pack_weights_bf16_planar(const float* weight, void* pac
 
 // The encoder's first block in the bf16 variant: fp32 NCDHW input (rounded to bf16 on the way into the MFMA),
 // stride 1, bf16 channels-last output.
-extern "C" int lr_conv3d_first_bf16(const float* in, const void* packed_w, const float* bias, void* out, int B, int Cin,
-                                    int Cout, int D, int W, int H, int out_layout, float negative_slope,
-                                    void* stream) {
+static int first_bf16_impl(const float* in, const void* packed_w, const float* bias, void* out, int B, int Cin,
+                           int Cout, int D, int W, int H, int out_layout, float negative_slope, long long out_bs,
+                           void* stream) {
   if (!in || !packed_w || !out) return LR_ENULL;
   if (B < 1 || Cin < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
   if (Cout != 16 && Cout != 32) return LR_EUNSUPPORTED;
@@ -732,6 +733,8 @@ extern "C" int lr_conv3d_first_bf16(const float* in, const void* packed_w, const
   if ((reinterpret_cast<uintptr_t>(packed_w) & 15u) || (reinterpret_cast<uintptr_t>(out) & 7u)) return LR_EALIGN;
   ConvDimsH d;
   d.B = B; d.Cin = Cin; d.Cout = Cout; d.D = D; d.W = W; d.H = H; d.Do = D; d.Wo = W; d.Ho = H;
+  if (out_bs != 0 && out_bs < (long long)Cout * D * W * H) return LR_EINVAL;
+  d.out_bs = out_bs ? out_bs : (long long)Cout * D * W * H;
   d.nHq = (H + PH - 1) / PH; d.nWq = (W + PW - 1) / PW; d.nDq = (D + PD - 1) / PD;
   const int64_t nblk = (int64_t)B * d.nDq * d.nWq * d.nHq;
   if (nblk > 0x7fffffffLL) return LR_EINVAL;
@@ -742,7 +745,7 @@ extern "C" int lr_conv3d_first_bf16(const float* in, const void* packed_w, const
   const u32x4* wt = reinterpret_cast<const u32x4*>(packed_w);
   if (Cin > 3 && !getenv("LIFTREG_CONV0_BF16_PASSES")) {   // many channels (C4): all of them staged once, channels-last in LDS
     const int e = lr_internal_conv0_cl_bf16(in, wt + (size_t)((Cin + 2) / 3) * 4 * (Cout / 16) * 64, bias, out, B, Cin, Cout, D, W, H,
-                                            out_layout, negative_slope, st);
+                                            out_layout, negative_slope, d.out_bs, st);
     if (e != LR_EUNSUPPORTED) return e;
   }
 #define LR_C0(NTV, SG)                                                                                                   \
@@ -798,9 +801,9 @@ extern "C" int lr_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* 
   return lr_launch_status();
 }
 
-extern "C" int lr_conv3d_k3_lrelu_bf16(const void* in, const void* packed_w, const float* bias, void* out, int B,
-                                       int Cin, int Cout, int D, int W, int H, int stride, int in_layout,
-                                       int out_layout, float negative_slope, void* stream) {
+static int conv_bf16_impl(const void* in, const void* packed_w, const float* bias, void* out, int B,
+                          int Cin, int Cout, int D, int W, int H, int stride, int in_layout,
+                          int out_layout, float negative_slope, long long out_bs, void* stream) {
   if (!in || !packed_w || !out) return LR_ENULL;
   if (B < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
   if (stride != 2 || (Cin != 16 && Cin != 32) || (Cout != 16 && Cout != 32)) return LR_EUNSUPPORTED;
@@ -812,6 +815,11 @@ extern "C" int lr_conv3d_k3_lrelu_bf16(const void* in, const void* packed_w, con
   ConvDimsH d;
   d.B = B; d.Cin = Cin; d.Cout = Cout; d.D = D; d.W = W; d.H = H;
   d.Do = (D - 1) / 2 + 1; d.Wo = (W - 1) / 2 + 1; d.Ho = (H - 1) / 2 + 1;
+  {
+    const long long dense_bs = (long long)Cout * d.Do * d.Wo * d.Ho;
+    if (out_bs != 0 && out_bs < dense_bs) return LR_EINVAL;
+    d.out_bs = out_bs ? out_bs : dense_bs;
+  }
   if (out_layout == LR_LAYOUT_BF16_NDHWC_HPS && (d.Ho & 1)) return LR_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(packed_w)) & 15u) return LR_EALIGN;
   if (out_layout != LR_LAYOUT_NCDHW && (reinterpret_cast<uintptr_t>(out) & 7u)) return LR_EALIGN;
@@ -850,4 +858,34 @@ extern "C" int lr_conv3d_k3_lrelu_bf16(const void* in, const void* packed_w, con
   }
 #undef LR_BF
   return lr_launch_status();
+}
+
+extern "C" int lr_conv3d_k3_lrelu_bf16(const void* in, const void* packed_w, const float* bias, void* out, int B,
+                                       int Cin, int Cout, int D, int W, int H, int stride, int in_layout,
+                                       int out_layout, float negative_slope, void* stream) {
+  return conv_bf16_impl(in, packed_w, bias, out, B, Cin, Cout, D, W, H, stride, in_layout, out_layout, negative_slope, 0, stream);
+}
+
+// lr_conv3d_k3_lrelu_bf16 writing into a strided batch (see lr_conv3d_k3_lrelu_obs_f32): out_batch_stride in elements of
+// the output type (bf16 for the channels-last layouts, fp32 for NCDHW).
+extern "C" int lr_conv3d_k3_lrelu_obs_bf16(const void* in, const void* packed_w, const float* bias, void* out, int B,
+                                           int Cin, int Cout, int D, int W, int H, int stride, int in_layout,
+                                           int out_layout, float negative_slope, int64_t out_batch_stride, void* stream) {
+  if (out_batch_stride < 0) return LR_EINVAL;
+  return conv_bf16_impl(in, packed_w, bias, out, B, Cin, Cout, D, W, H, stride, in_layout, out_layout, negative_slope,
+                        (long long)out_batch_stride, stream);
+}
+
+extern "C" int lr_conv3d_first_bf16(const float* in, const void* packed_w, const float* bias, void* out, int B, int Cin,
+                                    int Cout, int D, int W, int H, int out_layout, float negative_slope,
+                                    void* stream) {
+  return first_bf16_impl(in, packed_w, bias, out, B, Cin, Cout, D, W, H, out_layout, negative_slope, 0, stream);
+}
+
+// lr_conv3d_first_bf16 writing into a strided batch (see lr_conv3d_k3_lrelu_obs_f32; stride in bf16 elements).
+extern "C" int lr_conv3d_first_obs_bf16(const float* in, const void* packed_w, const float* bias, void* out, int B, int Cin,
+                                        int Cout, int D, int W, int H, int out_layout, float negative_slope,
+                                        int64_t out_batch_stride, void* stream) {
+  if (out_batch_stride < 0) return LR_EINVAL;
+  return first_bf16_impl(in, packed_w, bias, out, B, Cin, Cout, D, W, H, out_layout, negative_slope, (long long)out_batch_stride, stream);
 }

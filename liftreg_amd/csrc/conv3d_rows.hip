@@ -27,6 +27,7 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.0f 
 struct RowsDims {
   int B, D, W, H, Do, Wo, Ho, Cout;
   int nHq, nWq, nDq;
+  long long out_bs;   // output elements between batch elements (>= Cout*Do*Wo*Ho)
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void conv3d_rows_wlds_kernel(const f
     const int ho = t.hq * 16 + col;
     constexpr bool cl = OUTL != LR_LAYOUT_NCDHW;
     const int64_t pstride = cl ? (int64_t)d.Wo * d.Ho * d.Cout : 0;
-    float* pbase = out + (cl ? ((int64_t)t.b * d.Do + t.dz) * pstride : (int64_t)t.b * d.Cout * d.Do * d.Wo * d.Ho);
+    float* pbase = out + (int64_t)t.b * d.out_bs + (cl ? (int64_t)t.dz * pstride : 0);
     const unsigned bytes = !t.valid ? 0u : cl ? (unsigned)(pstride * 4) : (unsigned)((int64_t)d.Cout * d.Do * d.Wo * d.Ho * 4);
     const __amdgpu_buffer_rsrc_t res = __builtin_amdgcn_make_buffer_rsrc(pbase, (short)0, (int)bytes, 0x00020000);
 #pragma unroll
@@ -381,7 +382,8 @@ int launch(const float* in, const float* packed_w, const float* bias, float* out
 // Stride-2 block on a parity-split channels-last input (B,D,W,H,Cin) with Cin = 16 | 32, Cout = 16 | 32, fp32 output in
 // NDHWC / NDHWC_HPS / NCDHW.  LR_EUNSUPPORTED for anything else (the caller falls back to conv3d.hip's kernels).
 int lr_internal_conv_rows_wlds(const float* in, const float* packed_w, const float* bias, float* out, int B, int Cin,
-                               int Cout, int D, int W, int H, int out_layout, float slope, int z_phase, hipStream_t st) {
+                               int Cout, int D, int W, int H, int out_layout, float slope, int z_phase, long long out_bs,
+                               hipStream_t st) {
   if ((Cin != 16 && Cin != 32) || (Cout != 16 && Cout != 32) || (H & 1)) return LR_EUNSUPPORTED;
   // Small planes (blocks 3..5 of the encoder: 32^2 outputs per plane and less) stay with conv3d.hip's direct kernels: a few
   // hundred tiles cannot amortise the per-block fragment staging and the serial 27/54-row walk (measured at C3: 0.14 /
@@ -393,6 +395,7 @@ int lr_internal_conv_rows_wlds(const float* in, const float* packed_w, const flo
   RowsDims d;
   d.B = B; d.D = D; d.W = W; d.H = H; d.Cout = Cout;
   d.Do = (D - 1) / 2 + 1; d.Wo = (W - 1) / 2 + 1; d.Ho = (H - 1) / 2 + 1;
+  d.out_bs = out_bs ? out_bs : (long long)Cout * d.Do * d.Wo * d.Ho;
   d.nHq = (d.Ho + 15) / 16; d.nWq = (d.Wo + MT - 1) / MT; d.nDq = (d.Do + 3) / 4;
   const int64_t nt64 = (int64_t)B * d.nDq * d.nWq * d.nHq;
   if (nt64 > 0x3fffffffLL) return LR_EINVAL;

@@ -77,7 +77,8 @@ int lr_internal_ncc_reduce(const double* partial, double* moments, int R, int nb
 // rows kernel with its weight fragments in LDS (z_phase: parity of the global output plane of local plane 0).
 // LR_EUNSUPPORTED -> use conv3d.hip's kernels.
 int lr_internal_conv_rows_wlds(const float* in, const float* packed_w, const float* bias, float* out, int B, int Cin,
-                               int Cout, int D, int W, int H, int out_layout, float slope, int z_phase, hipStream_t st);
+                               int Cout, int D, int W, int H, int out_layout, float slope, int z_phase, long long out_bs,
+                               hipStream_t st);
 
 // conv0_pc.hip: the first block as a producer/consumer kernel (double-buffered LDS brick; proj != NULL: channels 1..P
 // are the backprojection of the views, computed by the producers).  LR_EUNSUPPORTED -> use the single-buffer kernel.
@@ -91,4 +92,4 @@ int lr_internal_conv0_pc(const float* in0, int64_t bs0, const float* in_rest, in
 int64_t lr_internal_conv0_cl_bf16_packed_bytes(int Cin, int Cout);
 int lr_internal_conv0_cl_bf16_pack(const float* weight, void* packed, int Cin, int Cout, hipStream_t st);
 int lr_internal_conv0_cl_bf16(const float* in, const void* packed, const float* bias, void* out, int B, int Cin, int Cout, int D,
-                              int W, int H, int out_layout, float slope, hipStream_t st);
+                              int W, int H, int out_layout, float slope, long long out_bs, hipStream_t st);

@@ -244,14 +244,25 @@ def conv3d_pack_weights(weight, in_layout):
     return packed
 
 
-def _conv_out(out, shape, dtype, device):
-    """The output tensor of a conv wrapper: freshly allocated, or the caller's contiguous `out` (e.g. a plane range
-    of a larger halo-padded buffer, see parallel.SlabShardedRegistration)."""
+def _conv_out(out, shape, dtype, device, strided_batch=False):
+    """The output tensor of a conv wrapper: freshly allocated, or the caller's `out` — contiguous, or (strided_batch) a
+    batch of dense per-sample blocks whose batch stride is larger than a block (a plane range of per-sample
+    halo-padded buffers, see parallel.SlabShardedRegistration: ONE launch for the whole batch)."""
     if out is None:
         return torch.empty(shape, dtype=dtype, device=device)
-    if tuple(out.shape) != tuple(shape) or out.dtype != dtype or not out.is_contiguous() or not out.is_cuda:
-        raise ValueError(f"out must be a contiguous {dtype} GPU tensor of shape {tuple(shape)}")
+    if tuple(out.shape) != tuple(shape) or out.dtype != dtype or not out.is_cuda:
+        raise ValueError(f"out must be a {dtype} GPU tensor of shape {tuple(shape)}")
+    if not out.is_contiguous():
+        dense = int(np.prod(shape[1:]))
+        if not (strided_batch and out[0].is_contiguous() and (out.shape[0] == 1 or out.stride(0) >= dense)):
+            raise ValueError(f"out must be contiguous (or, for the stride-2 blocks, dense per batch element with a larger "
+                             f"batch stride); got strides {tuple(out.stride())}")
     return out
+
+
+def _batch_stride(y):
+    """Elements between two batch elements of a conv output (dense blocks; see _conv_out)."""
+    return int(y.stride(0)) if (y.shape[0] > 1 and not y.is_contiguous()) else 0
 
 
 def conv3d_mask_supported(x, weight, stride, in_layout, out_layout):
@@ -287,7 +298,8 @@ def conv3d_k3_lrelu(x, weight, bias, stride, *, in_layout=LAYOUT_NCDHW, out_layo
     Do, Wo, Ho = o(D), o(W), o(H)
     shape = (B, Cout, Do, Wo, Ho) if out_layout == LAYOUT_NCDHW else (B, Do, Wo, Ho, Cout)
     bf16_out = out_layout in (_hip.LAYOUT_BF16_NDHWC, _hip.LAYOUT_BF16_NDHWC_HPS)   # fp32 compute, bf16 storage
-    y = _conv_out(out, shape, torch.bfloat16 if bf16_out else torch.float32, x.device)
+    y = _conv_out(out, shape, torch.bfloat16 if bf16_out else torch.float32, x.device, strided_batch=mask_out is None)
+    obs = _batch_stride(y)
     flops = 2.0 * 27 * Cin * Cout * B * Do * Wo * Ho
     with _timed(f"conv3d_c{Cin}x{Cout}_s{stride}_{D}" + ("_bf16out" if bf16_out else ""), flops=flops,
                 bytes=4 * x.numel() + y.numel() * y.element_size(), samples=B):
@@ -300,6 +312,11 @@ def conv3d_k3_lrelu(x, weight, bias, stride, *, in_layout=LAYOUT_NCDHW, out_layo
                                                               mask_out.data_ptr(), B, Cin, Cout, D, W, H, stride, in_layout,
                                                               out_layout, float(negative_slope), _stream()),
                        "lr_conv3d_k3_lrelu_mask_f32")
+        elif obs:
+            _hip.check(_hip.lib().lr_conv3d_k3_lrelu_obs_f32(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B,
+                                                             Cin, Cout, D, W, H, stride, in_layout, out_layout,
+                                                             float(negative_slope), int(z_phase), obs, _stream()),
+                       "lr_conv3d_k3_lrelu_obs_f32")
         elif z_phase:
             _hip.check(_hip.lib().lr_conv3d_k3_lrelu_zphase_f32(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B,
                                                                 Cin, Cout, D, W, H, stride, in_layout, out_layout,
@@ -406,14 +423,20 @@ def conv3d_k3_lrelu_bf16(x, weight, bias, stride, *, in_layout, out_layout, nega
     o = lambda n: (n - 1) // stride + 1
     Do, Wo, Ho = o(D), o(W), o(H)
     if out_layout == LAYOUT_NCDHW:
-        y = _conv_out(out, (B, Cout, Do, Wo, Ho), torch.float32, x.device)
+        y = _conv_out(out, (B, Cout, Do, Wo, Ho), torch.float32, x.device, strided_batch=True)
     else:
-        y = _conv_out(out, (B, Do, Wo, Ho, Cout), torch.bfloat16, x.device)
+        y = _conv_out(out, (B, Do, Wo, Ho, Cout), torch.bfloat16, x.device, strided_batch=True)
+    obs = _batch_stride(y)
     with _timed(f"conv3d_bf16_c{Cin}x{Cout}_s{stride}_{D}", flops=2.0 * 27 * Cin * Cout * B * Do * Wo * Ho,
                 bytes=2 * x.numel() + y.numel() * y.element_size(), samples=B, peak_tf=MFMA_BF16_PEAK_TF, bound="hbm"):
-        _hip.check(_hip.lib().lr_conv3d_k3_lrelu_bf16(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B, Cin,
-                                                      Cout, D, W, H, stride, in_layout, out_layout,
-                                                      float(negative_slope), _stream()), "lr_conv3d_k3_lrelu_bf16")
+        if obs:
+            _hip.check(_hip.lib().lr_conv3d_k3_lrelu_obs_bf16(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B, Cin,
+                                                              Cout, D, W, H, stride, in_layout, out_layout,
+                                                              float(negative_slope), obs, _stream()), "lr_conv3d_k3_lrelu_obs_bf16")
+        else:
+            _hip.check(_hip.lib().lr_conv3d_k3_lrelu_bf16(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B, Cin,
+                                                          Cout, D, W, H, stride, in_layout, out_layout,
+                                                          float(negative_slope), _stream()), "lr_conv3d_k3_lrelu_bf16")
     return y
 
 
@@ -441,12 +464,18 @@ def conv3d_first_bf16(x, weight, bias, *, out_layout, negative_slope=0.2, packed
     if packed is None:
         packed = conv3d_pack_weights_bf16_planar(weight)
     b = None if bias is None else _dev(bias.detach(), "bias")
-    y = _conv_out(out, (B, D, W, H, Cout), torch.bfloat16, x.device)
+    y = _conv_out(out, (B, D, W, H, Cout), torch.bfloat16, x.device, strided_batch=True)
+    obs = _batch_stride(y)
     with _timed(f"conv3d_bf16_c{Cin}x{Cout}_s1_{D}", flops=2.0 * 27 * Cin * Cout * B * D * W * H,
                 bytes=4 * x.numel() + 2 * y.numel(), samples=B, peak_tf=MFMA_BF16_PEAK_TF, bound="hbm"):
-        _hip.check(_hip.lib().lr_conv3d_first_bf16(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B, Cin, Cout,
-                                                   D, W, H, out_layout, float(negative_slope), _stream()),
-                   "lr_conv3d_first_bf16")
+        if obs:
+            _hip.check(_hip.lib().lr_conv3d_first_obs_bf16(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B, Cin, Cout,
+                                                           D, W, H, out_layout, float(negative_slope), obs, _stream()),
+                       "lr_conv3d_first_obs_bf16")
+        else:
+            _hip.check(_hip.lib().lr_conv3d_first_bf16(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B, Cin, Cout,
+                                                       D, W, H, out_layout, float(negative_slope), _stream()),
+                       "lr_conv3d_first_bf16")
     return y
 
 

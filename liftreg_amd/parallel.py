@@ -134,6 +134,24 @@ class DistComm:
             recv = recv.to(src.device)
         return [recv]
 
+    def shift_up_start(self, planes):
+        """Post `shift_up` without waiting: returns a handle whose `.wait()` gives [the plane of rank-1].  Over nccl (RCCL)
+        the grouped send/recv runs on the communicator's own stream, so kernels launched between start and wait overlap the
+        transfer (the sharded forward posts group A's halo, runs block 0 of group B, then waits)."""
+        if self.world == 1:
+            return _Done([None])
+        if self.host_stage:                      # gloo has no GPU point-to-point: staged through the host, synchronously
+            return _Done(self.shift_up(planes))
+        src = planes[0].contiguous()
+        recv = torch.empty_like(src) if self.rank > 0 else None
+        ops_ = []
+        if self.rank + 1 < self.world:
+            ops_.append(dist.P2POp(dist.isend, src, self._peer(self.rank + 1), group=self.group))
+        if self.rank > 0:
+            ops_.append(dist.P2POp(dist.irecv, recv, self._peer(self.rank - 1), group=self.group))
+        reqs = dist.batch_isend_irecv(ops_) if ops_ else []
+        return _Pending(reqs, [recv], keep=src)
+
     def all_gather_cat(self, pieces, dim):
         if self.world == 1:
             return [pieces[0]]
@@ -155,6 +173,29 @@ class DistComm:
         return ts
 
 
+class _Done:
+    """A finished exchange (world 1, host-staged gloo, virtual ranks)."""
+
+    def __init__(self, result):
+        self.result = result
+
+    def wait(self):
+        return self.result
+
+
+class _Pending:
+    """A posted grouped send/recv: wait() blocks the current stream on it and returns the received planes."""
+
+    def __init__(self, reqs, result, keep=None):
+        self.reqs, self.result, self.keep = reqs, result, keep     # `keep`: the send buffer stays alive until the wait
+
+    def wait(self):
+        for r in self.reqs:
+            r.wait()
+        self.keep = None
+        return self.result
+
+
 class LocalComm:
     """All `world` ranks simulated in one process (tests: N virtual ranks on one GPU)."""
 
@@ -164,6 +205,9 @@ class LocalComm:
 
     def shift_up(self, planes):
         return [None] + [p.clone() for p in planes[:-1]]
+
+    def shift_up_start(self, planes):
+        return _Done(self.shift_up(planes))
 
     def all_gather_cat(self, pieces, dim):
         full = torch.cat(pieces, dim=dim)
@@ -222,54 +266,70 @@ class SlabShardedRegistration:
             return ops.conv3d_k3_lrelu_bf16(x, blk.conv.weight, blk.conv.bias, blk.stride, in_layout=lin, out_layout=lout,
                                             negative_slope=blk._slope, packed=net._packed_weight(i, bf16=True), out=out)
 
-        # Every channels-last activation of a rank lives, per batch element, in a halo-padded buffer of planes
-        # [0: zeros = the stride-phase filler, 1: the halo plane from the rank below, 2..: the slab]; a block writes its
-        # output straight into the next buffer (its first, misaligned output plane lands on plane 1 and is overwritten
-        # by the halo), so no slab is ever copied or concatenated.
+        # Every channels-last activation of a rank lives, per batch element, in a halo-padded run of planes
+        # [filler (stride phase: its content never reaches a kept output) | halo plane from the rank below | slab].
+        # Blocks 0 and 1 — the two big ones — run as ONE launch per group of samples (round 2: one launch per sample, +7 % at
+        # world 1 and the largest part of the decomposition's overhead):
+        #   * block 0 (stride 1; both halo planes come from replicated inputs, no communication) writes its rows+2 output
+        #     planes [d0-1 | slab | d1] of sample b into planes 1 + b*(rows+2) .. of ONE buffer (strided-batch output for the
+        #     edge ranks, whose input has one plane less).  Seen one plane EARLIER, the same memory is the dense batch
+        #     (B, rows+2, W, H, C) of block 1's inputs [filler = the unused last plane of the sample before | halo slot |
+        #     slab]: no copy, no per-sample launch;
+        #   * block 1 (stride 2) writes planes 1.. of the (B, 1 + n_out, ...) buffer the small blocks continue from
+        #     (strided-batch output, lr_conv3d_k3_lrelu_obs_*).
+        # The batch goes in (up to) two groups so that the halo exchange of group A (posted right after its block 0) travels
+        # while block 0 of group B computes: the only wait is in front of block 1 of group A.
         act_dt = torch.bfloat16 if bf16 else torch.float32
-        bufs, rows = [], []
-        # ---- block 0 (stride 1): both halo planes come from replicated data → no communication
+        o = lambda n: (n - 1) // 2 + 1
+        B = inputs[0]["source"].shape[0]
+        ngroups = 2 if (B >= 2 and comm.world > 1) else 1
+        gb = [(g * B // ngroups, (g + 1) * B // ngroups) for g in range(ngroups)]
+        c0, c1 = net.encoders[0].conv.out_channels, net.encoders[1].conv.out_channels
+        st = []                                     # per local rank: buffers and views
         for inp, (d0, d1) in zip(inputs, bounds):
-            moving, proj = inp["source"], inp["target_proj"]
+            moving = inp["source"]
             if net._poses is None:
                 p = inp["target_poses"]
                 p = p.detach().cpu().numpy() if isinstance(p, torch.Tensor) else p
                 net._poses = p[0].astype("float32").copy()
+            r = d1 - d0
+            n_in = r + 2
             lo, hi = max(d0 - 1, 0), min(d1 + 1, D)
-            B, n_in = moving.shape[0], hi - lo
-            x = torch.empty((B, P + 1, n_in, W, H), dtype=torch.float32, device=moving.device)
-            x[:, 0:1].copy_(moving[:, :, lo:hi])
-            ops.backproject(proj, net._poses, (D, W, H), d0=lo, d1=hi, out=x[:, 1:], out_batch_stride=(P + 1) * n_in * W * H)
-            c0 = net.encoders[0].conv.out_channels
-            lead = d0 - lo                        # 1 except on rank 0: the local output row below the slab is discarded
-            blist = []
-            for b in range(B):
-                buf = torch.empty((1, 2 + (d1 - d0) + 1, W, H, c0), dtype=act_dt, device=moving.device)
-                buf[:, 0].zero_()
-                conv(0, x[b:b + 1], buf[:, 2 - lead:2 - lead + n_in])
-                blist.append(buf)
-            bufs.append(blist)
-            rows.append(d1 - d0)
-        # ---- block 1 (stride 2), the other big one: per batch element again, but INTO one batched padded buffer (a
-        # plane range of one batch element of it is contiguous), so that the small blocks 2..5 can run batched
-        tops = [torch.cat([buf[:, 1 + r:2 + r] for buf in blist], 0) for blist, r in zip(bufs, rows)]
-        halos = comm.shift_up(tops)
-        o = lambda n: (n - 1) // 2 + 1
-        acts_p, nrows = [], []
-        for blist, r, h, (d0, _) in zip(bufs, rows, halos, bounds):
-            n_out = o(2 + r)                      # planes the block produces from [zero, halo, slab]: 1 filler + r/2
-            b0 = blist[0]
-            nb = torch.empty((len(blist), 1 + n_out, o(b0.shape[2]), o(b0.shape[3]), net.encoders[1].conv.out_channels),
-                             dtype=act_dt, device=b0.device)
-            for b, buf in enumerate(blist):
-                if h is None:
-                    buf[:, 1].zero_()             # rank 0: the conv's own zero padding
+            a0 = lo - (d0 - 1)                      # first output plane block 0 really computes (1 on rank 0)
+            buf0 = torch.empty((1 + B * n_in, W, H, c0), dtype=act_dt, device=moving.device)
+            y0 = buf0[1:].view(B, n_in, W, H, c0)   # block 0's outputs [d0-1 | slab | d1] per sample
+            in1 = buf0[:B * n_in].view(B, n_in, W, H, c0)   # block 1's inputs [filler | halo | slab] per sample: one plane earlier
+            if hi - lo < n_in:                      # edge ranks: the planes block 0 does not write (halo slot / last filler)
+                if a0:
+                    y0[:, 0].zero_()
+                if hi - lo + a0 < n_in:
+                    y0[:, n_in - 1].zero_()
+            n_out = o(n_in)                         # planes block 1 produces from [filler, halo, slab]: 1 junk + r/2
+            nb = torch.empty((B, 1 + n_out, o(W), o(H), c1), dtype=act_dt, device=moving.device)
+            st.append(dict(r=r, n_in=n_in, lo=lo, hi=hi, a0=a0, y0=y0, in1=in1, nb=nb, n_out=n_out))
+        pend = []
+        for g0, g1 in gb:                           # ---- block 0 of every group, its halo posted at once
+            tops = []
+            for inp, (d0, d1), t in zip(inputs, bounds, st):
+                moving, proj = inp["source"], inp["target_proj"]
+                lo, hi, n_real = t["lo"], t["hi"], t["hi"] - t["lo"]
+                x = torch.empty((g1 - g0, P + 1, n_real, W, H), dtype=torch.float32, device=moving.device)
+                x[:, 0:1].copy_(moving[g0:g1, :, lo:hi])
+                ops.backproject(proj[g0:g1].contiguous(), net._poses, (D, W, H), d0=lo, d1=hi, out=x[:, 1:],
+                                out_batch_stride=(P + 1) * n_real * W * H)
+                conv(0, x, t["y0"][g0:g1, t["a0"]:t["a0"] + n_real])
+                tops.append(t["y0"][g0:g1, t["r"]:t["r"] + 1])       # the slab's top plane (d1 - 1) -> the rank above
+            pend.append(comm.shift_up_start(tops))
+        for (g0, g1), h in zip(gb, pend):           # ---- block 1 of every group, behind its halo
+            halos = h.wait()
+            for (d0, _), t, hl in zip(bounds, st, halos):
+                if hl is None:
+                    t["y0"][g0:g1, 0].zero_()       # rank 0: the conv's own zero padding
                 else:
-                    buf[:, 1].copy_(h[b])
-                conv(1, buf[:, :2 + r], nb[b:b + 1, 1:1 + n_out], d0)
-            acts_p.append(nb)
-            nrows.append(r // 2)
-        rows = nrows
+                    t["y0"][g0:g1, 0].copy_(hl[:, 0])
+                conv(1, t["in1"][g0:g1], t["nb"][g0:g1, 1:1 + t["n_out"]], d0)
+        acts_p = [t["nb"] for t in st]
+        rows = [t["r"] // 2 for t in st]
         # ---- blocks 2..5: small activations, batched launches; the (small) output is copied behind the two leading planes
         for i in range(2, 6):
             tops = [a[:, 1 + r:2 + r].contiguous() for a, r in zip(acts_p, rows)]

@@ -18,7 +18,7 @@ for G in \
   "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
   "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum TA_BUSY_avr GRBM_GUI_ACTIVE" ; do
   i=$((i+1))
-  timeout 900 rocprofv3 --pmc $G --output-format csv -d "$OUT/p$i" -- python3 "$R/bench.py" $ARGS > "$OUT/p$i.log" 2>&1
+  timeout 240 rocprofv3 --pmc $G --output-format csv -d "$OUT/p$i" -- python3 "$R/bench.py" $ARGS > "$OUT/p$i.log" 2>&1
   echo "pass $i ($G): exit $?" >> "$OUT/passes.log"
 done
 python3 "$R/tools/traffic_from_pmc.py" "$OUT" --bench-args "$ARGS" | tee "$OUT/summary.txt"

@@ -65,10 +65,17 @@ def main():
             out[key] = round(out.get(key, 0.0) + float(np.sum(rec["ms"])), 3)
         return out
 
+    from liftreg_amd.layers.losses import NCCLoss
+    sim = NCCLoss(check_nan=False)
+
+    def full():          # the unsharded step INCLUDING the similarity (the sharded forward computes it from all-reduced moments)
+        out = net(inp)
+        return sim(out["warped"], out["target"])
+
     if os.environ.get("SHARD_BENCH_TABLE"):
-        print("unsharded", json.dumps(table(lambda: net(inp))))
+        print("unsharded", json.dumps(table(full)))
         print("sharded  ", json.dumps(table(lambda: sh.forward([inp] * a.world))))
-    t_full = timeit(lambda: net(inp))
+    t_full = timeit(full)
     t_shard = timeit(lambda: sh.forward([inp] * a.world))
     print(json.dumps({"n": n, "views": P, "batch": B, "world": a.world, "conv_dtype": a.conv_dtype,
                       "unsharded_ms": round(t_full, 3), "sum_of_slabs_ms": round(t_shard, 3),

@@ -49,6 +49,15 @@ def op_table(cfg, P, bf16):
            (f"conv3d_c16x32_s2_{n}", r"^conv3d_rows_wlds_kernel<2, 1,", 0)]
     # stride-2 blocks: planes of >= 64 x 64 outputs run the persistent Winograd rows kernel (one grid size for all of them:
     # told apart by rank only if there are several), smaller ones the direct rows kernel
+    if bf16:   # --conv-dtype bf16: the first block (all channels at once for > 3 of them, else the channel-pass kernel), then the row kernels
+        ops = ops[:4] + [(f"conv3d_bf16_c{P + 1}x16_s1_{n}", r"^conv0_cl_bf16_kernel" if P + 1 > 3 else r"^conv0_bf16_kernel", 0),
+                         (f"conv3d_bf16_c16x32_s2_{n}", r"^conv3d_cl_rows_bf16_kernel<2, 4, false>", 0)]
+        size, rank = n // 2, 0
+        while size >= 16:
+            ops.append((f"conv3d_bf16_c32x32_s2_{size}", r"^conv3d_cl_rows_bf16_kernel<(1|2), 4, true>", rank))
+            rank += 1
+            size //= 2
+        return ops
     size, rank_w, rank_d = n // 2, 0, 0
     while size >= 16:
         if (size // 2) ** 2 >= 4096:
@@ -98,7 +107,7 @@ def main():
         if "SQ_INSTS_LDS" in avg and avg["SQ_INSTS_LDS"] > 0 and "SQ_LDS_BANK_CONFLICT" in avg:
             print(f"   {'LDS conflict cycles per LDS inst':32s} {avg['SQ_LDS_BANK_CONFLICT'] / avg['SQ_INSTS_LDS']:18.3f}")
     traffic = {}
-    for op, rx, rank in op_table(cfg, P, False):
+    for op, rx, rank in op_table(cfg, P, "--conv-dtype bf16" in a.bench_args):
         cands = sorted((k for k in groups if re.search(rx, k[0])), key=lambda k: -k[1])
         if len(cands) <= rank:
             continue
