@@ -416,6 +416,17 @@ int64_t lr_conv3d_packed_bf16_planar_bytes(int Cin, int Cout);
 int lr_conv3d_pack_weights_bf16_planar(const float* weight, void* packed, int Cin, int Cout, void* stream);
 int lr_conv3d_first_bf16(const float* in, const void* packed_w, const float* bias, void* out, int B, int Cin,
                          int Cout, int D, int W, int H, int out_layout, float negative_slope, void* stream);
+/* The bf16 variant's encoder input for MANY views (C4: 11) without the fp32 feature volume: lr_backproject_encin_bf16 writes
+ * rows [d0,d1) of cat([moving, backprojected views], dim=1) (src/liftreg/models/LiftRegDeformSubspaceBackproj.py:85-98) as
+ * bf16 channels-last records (B, d1-d0, W, H, 16): channel 0 = moving (B,1,D,W,H) fp32, 1..P = the samples of
+ * lr_backproject_f32, the rest 0, each rounded to nearest-even bf16 — the rounding lr_conv3d_first_bf16 applies to its input
+ * anyway.  lr_conv3d_first_clin_bf16 is lr_conv3d_first_bf16 on that tensor (same packed weights, same results).
+ * 1 <= P <= 15; out_batch_stride in bf16 elements (0 = dense). */
+int lr_backproject_encin_bf16(const float* proj, const float* moving, const float* poses, void* out, int B, int P, int Pw,
+                              int Ph, int D, int W, int H, int d0, int d1, int64_t out_batch_stride, void* stream);
+int lr_conv3d_first_clin_bf16(const void* in, const void* packed_w, const float* bias, void* out, int B, int Cin, int Cout,
+                              int D, int W, int H, int out_layout, float negative_slope, int64_t out_batch_stride,
+                              void* stream);
 /* ... into a strided batch (see lr_conv3d_k3_lrelu_obs_f32; stride in bf16 elements, 0 = dense). */
 int lr_conv3d_first_obs_bf16(const float* in, const void* packed_w, const float* bias, void* out, int B, int Cin, int Cout,
                              int D, int W, int H, int out_layout, float negative_slope, int64_t out_batch_stride,

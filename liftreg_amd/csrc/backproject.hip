@@ -338,6 +338,217 @@ __global__ __launch_bounds__(256) void backproject_coords_poseless_f64_kernel(Lr
   grid[o + plane] = gu;
 }
 
+// ---- The encoder input of the bf16 variant with MANY views (BASELINE config C4: 11) written directly in the layout its
+// first block stages: (B, Ds, W, H, 16) bf16 channels-last records [moving | view 0 .. view NV-1 | zeros] — what
+// cat([moving, target_volume], dim=1) (…Backproj.py:95-98) holds, rounded to nearest-even bf16 (the rounding the first
+// block applies to its input anyway: the conv's results keep their bits).  The fp32 (B,P,D,W,H) feature volume — 2.95 GB
+// written and 1.6x that read back at C4 — is never materialised: 32 bytes per voxel instead of 48 + 48.
+// Structure of backproject_tiled_kernel (same arithmetic, same 4-term order: bit-identical samples), turned inside out: a
+// block owns a 4 x 4 (D x W) bundle of H-rows and ALL views — the <= 8 detector rows each view's shadows touch are staged
+// together in zero-padded LDS (one barrier pair per batch element, not per view; 93 KB for 11 views of 256 columns), a
+// thread owns the column k of half the bundle (two of its four planes), walks the NV views of a voxel with LDS taps,
+// assembles the 32-byte record in registers and stores it: lanes run along H, a wave's records are one contiguous 2 KiB
+// store.  (Measured on the way: global-memory taps — 176 scattered dword loads per thread — 3.5 ms for C4's 0.45 ms of
+// writes; a 2 x 2 bundle — one staged float per sample — 1.7 ms: the bundle must amortise its tile like
+// backproject_tiled_kernel's 8 x 4 one does.)
+typedef unsigned bp_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned bp_bf16(float v) {
+  const __bf16 h = (__bf16)v;
+  return (unsigned)__builtin_bit_cast(unsigned short, h);
+}
+#ifndef LR_BE_SHAPE
+#define LR_BE_SHAPE 0
+#endif
+#if LR_BE_SHAPE == 0   // 4 x 4 bundle, one 512-thread block per CU (105 KB of tiles), next element's tiles prefetched into registers
+constexpr int BE_TI = 4, BE_TJ = 4, BE_RCAP = 9, BE_THREADS = 512, BE_NPF = 13;
+constexpr bool BE_PREFETCH = true;
+#else                  // 2 x 4 bundle, two 256-thread blocks per CU (70 KB each): one stages while the other computes
+constexpr int BE_TI = 2, BE_TJ = 4, BE_RCAP = 6, BE_THREADS = 256, BE_NPF = 1;
+constexpr bool BE_PREFETCH = false;
+#endif
+template <int NV>
+__global__ __launch_bounds__(BE_THREADS) void backproject_encin_bf16_kernel(
+    const float* __restrict__ proj, const float* __restrict__ moving, LrPoses poses, unsigned short* __restrict__ out,
+    int B, int Pw, int Ph, int D, int W, int H, int d0, int Ds, int64_t out_bs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int RS = Ph + 2 * BT_PAD;                  // padded row length (floats)
+  float* tile = smem;                              // [NV][BE_RCAP][RS]
+  float4* tyt = reinterpret_cast<float4*>(smem + NV * BE_RCAP * RS);   // [NV][TJ*TI] {row offset, e, w, -}
+  __shared__ int s_lo[NV], s_hi[NV];
+  const int tid = threadIdx.x;
+  const int nJ = (W + BE_TJ - 1) / BE_TJ;
+  const int jt = blockIdx.x % nJ, it = blockIdx.x / nJ;
+  const int i_base = it * BE_TI, j_base = jt * BE_TJ;
+  if (tid < NV) { s_lo[tid] = 0x7fffffff; s_hi[tid] = -0x7fffffff; }
+  __syncthreads();
+  TapU myty;
+  myty.i0 = BT_SENTINEL; myty.e = myty.w = 0.0f;
+  const int tv = tid / (BE_TI * BE_TJ), tpos = tid % (BE_TI * BE_TJ);   // threads 0 .. 4 NV - 1: (view, position of the bundle)
+  if (tv < NV) {
+    const int ii = tpos % BE_TI, jj = tpos / BE_TI;
+    const int i = i_base + ii, j = j_base + jj;
+    if (i < Ds && j < W) {
+      const float ex = poses.e[tv][0], ey = poses.e[tv][1];
+      const float x = (float)(d0 + i) - 0.5f * (float)D;
+      const float y = (float)(W - 1 - j);
+      const float scale = ey / (ey - y);
+      myty = make_tap_u(shadow_pix(x, ex, scale, (float)Pw, Pw), Pw);
+      if (myty.i0 != BT_SENTINEL) {
+        atomicMin(&s_lo[tv], myty.i0);
+        atomicMax(&s_hi[tv], myty.i0 + 1);
+      }
+    }
+  }
+  __syncthreads();
+  if (tv < NV) {
+    const int rel = (myty.i0 == BT_SENTINEL) ? 0 : (myty.i0 - s_lo[tv]) * RS;
+    tyt[tid] = make_float4(__int_as_float(rel), myty.e, myty.w, 0.0f);
+  }
+  // a view whose shadows span more detector rows than the tile holds (oblique geometry): the whole block takes the
+  // slow path below — per-sample taps straight from the views, 2-byte stores; block-uniform, never on the model's path
+  __shared__ int s_oblique;
+  if (tid == 0) {
+    int ob = 0;
+    for (int v = 0; v < NV; ++v) ob |= (s_hi[v] >= s_lo[v] && s_hi[v] - s_lo[v] + 1 > BE_RCAP) ? 1 : 0;
+    s_oblique = ob;
+  }
+  __syncthreads();
+  if (s_oblique) {
+    if (tid >= H || tid >= 256) return;   // (only the first 256 threads: one per column)
+    for (int b = 0; b < B; ++b)
+      for (int pos = 0; pos < BE_TI * BE_TJ; ++pos) {
+        const int i = i_base + pos % BE_TI, j = j_base + pos / BE_TI;
+        if (i >= Ds || j >= W) continue;
+        unsigned short* rec = out + (int64_t)b * out_bs + (((int64_t)i * W + j) * H + tid) * 16;
+        rec[0] = (unsigned short)bp_bf16(moving[(int64_t)b * D * W * H + ((int64_t)(d0 + i) * W + j) * H + tid]);
+        for (int c = NV + 1; c < 16; ++c) rec[c] = 0;
+        const float x = (float)(d0 + i) - 0.5f * (float)D, y = (float)(W - 1 - j), zz = (float)tid - 0.5f * (float)H;
+        for (int v = 0; v < NV; ++v) {
+          const float ex = poses.e[v][0], ey = poses.e[v][1], ez = poses.e[v][2];
+          const float scale = ey / (ey - y);
+          const Tap ty = make_tap(shadow_pix(x, ex, scale, (float)Pw, Pw), Pw);
+          const Tap tx = make_tap(shadow_pix(zz, ez, scale, (float)Ph, Ph), Ph);
+          const float nw = ty.w0 * tx.w0, ne = ty.w0 * tx.w1, sw = ty.w1 * tx.w0, se = ty.w1 * tx.w1;
+          const float* r0 = proj + ((int64_t)b * NV + v) * Pw * Ph + (int64_t)ty.i0 * Ph;
+          const float* r1 = proj + ((int64_t)b * NV + v) * Pw * Ph + (int64_t)ty.i1 * Ph;
+          float acc = r0[tx.i0] * nw;
+          acc = acc + r0[tx.i1] * ne;
+          acc = acc + r1[tx.i0] * sw;
+          acc = acc + r1[tx.i1] * se;
+          rec[v + 1] = (unsigned short)bp_bf16(acc);
+        }
+      }
+    return;
+  }
+  const int k = tid & 255, jh = tid >> 8;   // column of this thread (H <= 256: checked by the launcher), half of the planes
+  constexpr int TJH = BE_TJ / (BE_THREADS / 256);
+  const float z = (float)k - 0.5f * (float)H;
+  // column taps of this thread per (plane jj of its half, view): the same for all four rows and every batch element
+  TapU txs[TJH][NV];
+#pragma unroll
+  for (int jj = 0; jj < TJH; ++jj) {
+    const float y = (float)(W - 1 - (j_base + jh * TJH + jj));
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const float ey = poses.e[v][1], ez = poses.e[v][2];
+      const float scale = ey / (ey - y);
+      txs[jj][v] = make_tap_u(shadow_pix(z, ez, scale, (float)Ph, Ph), Ph);
+      if (txs[jj][v].i0 == BT_SENTINEL) txs[jj][v].i0 = -1;  // weights are 0; any padded column
+    }
+  }
+  __syncthreads();
+  const int64_t view_sz = (int64_t)Pw * Ph, V = (int64_t)D * W * H;
+  const int RS4 = RS >> 2;
+  // The detector rows of every view for batch element b+1 travel into registers while element b is computed (one block of
+  // 8 waves per CU holds the LDS: without the look-ahead every element paid the views' L2 latency in the open).
+  // (Ph % 4 == 0 and 16-byte aligned views: checked by the launcher.)
+  constexpr int NPF_MAX = (15 * BE_RCAP * ((1024 + 2 * BT_PAD) / 4) + BE_THREADS - 1) / BE_THREADS;
+  const int total4 = NV * BE_RCAP * RS4;
+  const int npf = (total4 + BE_THREADS - 1) / BE_THREADS;
+  float4 pre[BE_NPF];   // npf <= BE_NPF is checked by the launcher
+  (void)NPF_MAX;
+  auto fetch = [&](int b) __attribute__((always_inline)) {
+    const float* pbn = proj + (int64_t)b * NV * view_sz;
+#pragma unroll
+    for (int t = 0; t < BE_NPF; ++t) {
+      const int idx = tid + t * BE_THREADS;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < npf && idx < total4) {
+        const int v = idx / (BE_RCAP * RS4), rem = idx - v * (BE_RCAP * RS4);
+        const int row = rem / RS4, c4 = rem - row * RS4;
+        const int lo = s_lo[v], nr = s_hi[v] >= lo ? s_hi[v] - lo + 1 : 0;
+        const int grow = lo + row, col = c4 * 4 - BT_PAD;
+        if (row < nr && grow >= 0 && grow < Pw && col >= 0 && col < Ph)
+          val = *reinterpret_cast<const float4*>(pbn + (int64_t)v * view_sz + (int64_t)grow * Ph + col);
+      }
+      pre[t] = val;
+    }
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < BE_NPF; ++t) {
+      const int idx = tid + t * BE_THREADS;
+      if (t < npf && idx < total4) reinterpret_cast<float4*>(tile)[idx] = pre[t];   // tile is [v][row][RS]: idx is its float4 index
+    }
+  };
+  auto stage_direct = [&](int b) __attribute__((always_inline)) {   // without the register look-ahead: global -> LDS in a loop
+    const float* pbn = proj + (int64_t)b * NV * view_sz;
+    for (int idx = tid; idx < total4; idx += BE_THREADS) {
+      const int v = idx / (BE_RCAP * RS4), rem = idx - v * (BE_RCAP * RS4);
+      const int row = rem / RS4, c4 = rem - row * RS4;
+      const int lo = s_lo[v], nr = s_hi[v] >= lo ? s_hi[v] - lo + 1 : 0;
+      const int grow = lo + row, col = c4 * 4 - BT_PAD;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < nr && grow >= 0 && grow < Pw && col >= 0 && col < Ph)
+        val = *reinterpret_cast<const float4*>(pbn + (int64_t)v * view_sz + (int64_t)grow * Ph + col);
+      reinterpret_cast<float4*>(tile)[idx] = val;
+    }
+  };
+  if constexpr (BE_PREFETCH) { fetch(0); commit(); } else { stage_direct(0); }
+  __syncthreads();
+  for (int b = 0; b < B; ++b) {
+    if (BE_PREFETCH && b + 1 < B) fetch(b + 1);
+    if (k < H) {
+#pragma unroll
+      for (int jj = 0; jj < TJH; ++jj) {
+        const int jl = jh * TJH + jj, j = j_base + jl;
+        if (j >= W) break;
+#pragma unroll 1
+        for (int ii = 0; ii < BE_TI; ++ii) {   // (not unrolled: all sample bodies at once cost 219 registers and 146 scalar spills)
+          const int i = i_base + ii;
+          if (i >= Ds) break;
+          unsigned rec[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) rec[q] = 0u;
+          rec[0] = bp_bf16(moving[(int64_t)b * V + ((int64_t)(d0 + i) * W + j) * H + k]);
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            // a view the bundle's shadows miss entirely has zero weights and a zero-filled tile: acc = 0, no branch
+            const TapU tx = txs[jj][v];
+            const float4 ty = tyt[v * (BE_TI * BE_TJ) + jl * BE_TI + ii];
+            const float nw = ty.y * tx.e, ne = ty.y * tx.w, sw = ty.z * tx.e, se = ty.z * tx.w;
+            const float* r0 = tile + v * BE_RCAP * RS + __float_as_int(ty.x) + tx.i0 + BT_PAD;
+            const float a = r0[0], bq = r0[1], c = r0[RS], dd = r0[RS + 1];
+            float acc = a * nw;
+            acc = acc + bq * ne;
+            acc = acc + c * sw;
+            acc = acc + dd * se;
+            rec[(v + 1) >> 1] |= bp_bf16(acc) << (16 * ((v + 1) & 1));
+          }
+          bp_u32x4* dst = reinterpret_cast<bp_u32x4*>(out + (int64_t)b * out_bs + (((int64_t)i * W + j) * H + k) * 16);
+          __builtin_nontemporal_store((bp_u32x4){rec[0], rec[1], rec[2], rec[3]}, dst);
+          __builtin_nontemporal_store((bp_u32x4){rec[4], rec[5], rec[6], rec[7]}, dst + 1);
+        }
+      }
+    }
+    __syncthreads();  // everyone is done with element b's tile
+    if (b + 1 < B) {
+      if constexpr (BE_PREFETCH) commit(); else stage_direct(b + 1);
+      __syncthreads();
+    }
+  }
+}
+
 int fill_poses(LrPoses& lp, const float* poses, int P) {
   if (!poses) return LR_ENULL;
   if (P < 1 || P > LR_MAX_VIEWS) return LR_EINVAL;
@@ -389,6 +600,42 @@ extern "C" int lr_backproject_f32(const float* proj, const float* poses, float* 
   else
     hipLaunchKernelGGL(backproject_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, lr_stream(stream),
                        proj, lp, out, B, P, Pw, Ph, D, W, H, d0, Ds, out_batch_stride);
+  return lr_launch_status();
+}
+
+// (B,P,Pw,Ph) views + (B,1,D,W,H) moving image -> rows [d0,d1) of the bf16 channels-last encoder input (B,Ds,W,H,16):
+// channel 0 = moving, 1..P = the backprojected views, P+1..15 = 0.  1 <= P <= 15; out 16-byte aligned; out_batch_stride
+// in bf16 elements (>= 16*Ds*W*H).  Values = lr_backproject_f32's (and moving), rounded to nearest-even bf16.
+extern "C" int lr_backproject_encin_bf16(const float* proj, const float* moving, const float* poses, void* out, int B, int P,
+                                         int Pw, int Ph, int D, int W, int H, int d0, int d1, int64_t out_batch_stride,
+                                         void* stream) {
+  if (!proj || !moving || !out) return LR_ENULL;
+  if (B < 1 || Pw < 1 || Ph < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
+  if (d0 < 0 || d1 > D || d1 <= d0) return LR_EINVAL;
+  if (P < 1 || P > 15 || H > 256 || (Ph & 3) || (reinterpret_cast<uintptr_t>(proj) & 15u)) return LR_EUNSUPPORTED;
+  if (reinterpret_cast<uintptr_t>(out) & 15u) return LR_EALIGN;
+  LrPoses lp;
+  if (int e = fill_poses(lp, poses, P)) return e;
+  const int Ds = d1 - d0;
+  if (out_batch_stride < (int64_t)16 * Ds * W * H || (out_batch_stride & 7)) return LR_EINVAL;
+  const int64_t nblk = (int64_t)((Ds + BE_TI - 1) / BE_TI) * ((W + BE_TJ - 1) / BE_TJ);
+  if (nblk > 0x7fffffffLL) return LR_EINVAL;
+  const size_t lds = ((size_t)P * BE_RCAP * (Ph + 2 * BT_PAD) + 4 * (size_t)P * BE_TI * BE_TJ) * sizeof(float);
+  if (lds > 150 * 1024 || (BE_PREFETCH && (int64_t)P * BE_RCAP * ((Ph + 2 * BT_PAD) / 4) > (int64_t)BE_NPF * BE_THREADS)) return LR_EUNSUPPORTED;
+  unsigned short* o = reinterpret_cast<unsigned short*>(out);
+  hipStream_t st = lr_stream(stream);
+#define LR_BE(NVV)                                                                                                         \
+  case NVV: {                                                                                                              \
+    static std::atomic<uint64_t> attr_done{0};                                                                             \
+    if (lr_raise_dyn_lds(reinterpret_cast<const void*>(&backproject_encin_bf16_kernel<NVV>), lds, attr_done) != LR_OK) return LR_ELAUNCH; \
+    hipLaunchKernelGGL(backproject_encin_bf16_kernel<NVV>, dim3((unsigned)nblk), dim3(BE_THREADS), lds, st, proj, moving, lp, o, B, Pw, Ph, D, \
+                       W, H, d0, Ds, out_batch_stride);                                                                    \
+  } break
+  switch (P) {
+    LR_BE(1); LR_BE(2); LR_BE(3); LR_BE(4); LR_BE(5); LR_BE(6); LR_BE(7); LR_BE(8); LR_BE(9); LR_BE(10); LR_BE(11); LR_BE(12);
+    LR_BE(13); LR_BE(14); LR_BE(15);
+  }
+#undef LR_BE
   return lr_launch_status();
 }
 

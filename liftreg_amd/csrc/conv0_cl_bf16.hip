@@ -101,7 +101,10 @@ __device__ __forceinline__ void brick_range(int bid, int nblk, int nbricks, int&
 // f+1 | ONE barrier.  The slots group f+1 overwrites were last read in iteration f-1's sweep, which every wave left before
 // the previous barrier; the step of iteration f reads other slots.  Every input plane is fetched once per column (+ 2 per
 // chunk) instead of 1.5 times.
-template <int CQ, bool HPSOUT, int SZ, int BY>
+// CLIN: `in` is already the bf16 channels-last encoder input (B, D, W, H, 16) that lr_backproject_encin_bf16 writes — the
+// staging is then a plain copy of 16-byte record halves (no rounding, no transposition, no swizzle: consecutive lanes write
+// consecutive 16 bytes, the natural record order is conflict-free on both sides) and the window starts exactly at x0 - 1.
+template <int CQ, bool HPSOUT, int SZ, int BY, bool CLIN = false>
 __global__ __launch_bounds__(512, 2) void conv0_cl_bf16_kernel(const float* __restrict__ in, const u32x4* __restrict__ wp,
                                                                const float* __restrict__ bias, u16* __restrict__ out, C0Dims d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -111,7 +114,8 @@ __global__ __launch_bounds__(512, 2) void conv0_cl_bf16_kernel(const float* __re
   constexpr int NRING = 2 * SZ + 2;
   constexpr int NPRE = (2 + SZ - 1) / SZ;           // groups of a unit before its first step (the two planes above it)
   constexpr int LDSB = NRING * PLB + SLOT;
-  constexpr int NITEMS = CQ * SZ * WR * NQ;         // one item = 4 channels x one x-quad of one row of one plane of a group
+  constexpr int NCHK = 132;                         // CLIN: 16-byte chunks of a window row (66 records)
+  constexpr int NITEMS = CLIN ? SZ * WR * NCHK : CQ * SZ * WR * NQ;   // planar: one item = 4 channels x one x-quad of a row
   constexpr int NIT = (NITEMS + 511) / 512;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,24 +133,32 @@ __global__ __launch_bounds__(512, 2) void conv0_cl_bf16_kernel(const float* __re
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int item = it * 512 + tid;
+    const bool live = item < NITEMS;
+    if constexpr (CLIN) {   // item = (plane j, row, 16-byte chunk c of the row's 66 records); q holds the chunk index
+      const int c = item % NCHK, row = (item / NCHK) % WR, j = item / NCHK / WR;
+      g_rel[it] = (unsigned)(((j * dW + row) * dH) * SLOT + c * 16);
+      l_rec[it] = (unsigned)(row * RB + (3 + (c >> 1)) * SLOT + (c & 1) * 16);
+      it_pk[it] = (unsigned)(live ? j : 0) | ((unsigned)row << 3) | ((unsigned)(c >> 1) << 8) | (live ? 1u << 15 : 0u);
+      continue;
+    }
     const int cq = item % CQ, rest = item / CQ;
     const int q = rest % NQ, row = (rest / NQ) % WR, j = rest / NQ / WR;
-    const bool live = item < NITEMS;
     g_rel[it] = (unsigned)cq * 4u * V4 + (unsigned)((j * dW + row) * dH + 4 * q) * 4u;
     l_rec[it] = (unsigned)(row * RB + 4 * q * SLOT + cq * 8);
-    static_assert(SZ <= 8 && WR <= 32 && NQ <= 32 && CQ <= 4, "it_pk field widths");
+    static_assert(SZ <= 8 && WR <= 32 && NQ <= 32 && CQ <= 4, "it_pk field widths");   // (CLIN: the voxel index c>>1 <= 65 takes bits 8..14)
     it_pk[it] = (unsigned)(live ? j : 0) | ((unsigned)row << 3) | ((unsigned)q << 8) | ((unsigned)cq << 13) | (live ? 1u << 15 : 0u);
   }
 
   // ---- B-operand offsets of this lane inside a ring plane: see the header for the four tap-pair classes
   const int zw = wave % SZ, rh = wave / SZ;
   const int hb = (kq & 1) * 16;
+  auto prec = [](int p) __attribute__((always_inline)) -> int { return CLIN ? p : phys_rec(p); };
   unsigned offA[3], offB, offC, offD;
 #pragma unroll
-  for (int tx = 0; tx < 3; ++tx) offA[tx] = (unsigned)(2 * rh * RB + phys_rec(col + tx + 3) * SLOT + hb);
-  offB = (unsigned)(2 * rh * RB + phys_rec(col + up + 3) * SLOT + hb);
-  offC = (unsigned)((2 * rh + up) * RB + phys_rec(col + 5) * SLOT + hb);
-  offD = (unsigned)(2 * rh * RB + phys_rec(col + 5) * SLOT + hb);
+  for (int tx = 0; tx < 3; ++tx) offA[tx] = (unsigned)(2 * rh * RB + prec(col + tx + 3) * SLOT + hb);
+  offB = (unsigned)(2 * rh * RB + prec(col + up + 3) * SLOT + hb);
+  offC = (unsigned)((2 * rh + up) * RB + prec(col + 5) * SLOT + hb);
+  offD = (unsigned)(2 * rh * RB + prec(col + 5) * SLOT + hb);
 
   u32x4 w[NSTEP];
 #pragma unroll
@@ -160,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void conv0_cl_bf16_kernel(const float* __re
   int first, stride, end;
   brick_range((int)blockIdx.x, (int)gridDim.x, d.nunits, first, stride, end);
 
-  f32x4 ld[LR_C0CL_DEPTH][NIT][4];   // DEPTH groups in flight: register set = flat group index % DEPTH
+  f32x4 ld[LR_C0CL_DEPTH][NIT][CLIN ? 1 : 4];   // DEPTH groups in flight: register set = flat group index % DEPTH
   struct Unit { int b, zc0, zc1, y0, x0; };
   auto decode = [&](int u) __attribute__((always_inline)) -> Unit {
     const int hq = u % d.nHq, wq = (u / d.nHq) % d.nWq, ch = (u / d.nHq / d.nWq) % d.nch;
@@ -188,18 +200,29 @@ __global__ __launch_bounds__(512, 2) void conv0_cl_bf16_kernel(const float* __re
     // the resource ends with the batch element (Cin volumes): any offset outside it reads 0, never faults.  Base and size
     // go through readfirstlane: left to its own analysis hipcc kept the descriptor in vector registers and wrapped every
     // load in a waterfall loop
-    const uint64_t xa = reinterpret_cast<uint64_t>(in + (int64_t)u.b * d.Cin * ((int64_t)dD * dW * dH));
+    const uint64_t xa = CLIN ? reinterpret_cast<uint64_t>(reinterpret_cast<const u16*>(in) + (int64_t)u.b * 16 * ((int64_t)dD * dW * dH))
+                             : reinterpret_cast<uint64_t>(in + (int64_t)u.b * d.Cin * ((int64_t)dD * dW * dH));
     const uint64_t xs = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(xa >> 32)) << 32) |
                         (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xa);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(xs), (short)0,
-                                                                          __builtin_amdgcn_readfirstlane((int)((unsigned)d.Cin * V4)), 0x00020000);
+                                                                          __builtin_amdgcn_readfirstlane((int)(CLIN ? 8u * V4 : (unsigned)d.Cin * V4)), 0x00020000);
     const int zg = u.zc0 - NPRE * SZ + 1 + SZ * g;
-    const int org = ((zg * dW + (u.y0 - 1)) * dH + (u.x0 - 4)) * 4;   // may be negative: only used where the element exists
+    const int org = CLIN ? ((zg * dW + (u.y0 - 1)) * dH + (u.x0 - 1)) * SLOT
+                         : ((zg * dW + (u.y0 - 1)) * dH + (u.x0 - 4)) * 4;   // may be negative: only used where the element exists
     const int jmin = g == 0 ? NPRE * SZ - 2 : 0;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const unsigned pk = it_pk[it];
       const int j = (int)(pk & 7u);
+      if constexpr (CLIN) {
+        const int zi = zg + j, yi = u.y0 - 1 + (int)((pk >> 3) & 31u), xi = u.x0 - 1 + (int)((pk >> 8) & 127u);
+        const int ok = (int)valid & (int)((pk >> 15) & 1u) & (int)(j >= jmin) & (int)(zi >= 0) & (int)(zi < dD) & (int)(yi >= 0) & (int)(yi < dW) &
+                       (int)(xi >= 0) & (int)(xi < dH);
+        unsigned voff = ((unsigned)org + g_rel[it]) | (((unsigned)ok - 1u) & OOR);
+        if (d.abl & 1) voff = OOR;
+        ld[SET][it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+        continue;
+      }
       const int zi = zg + j, yi = u.y0 - 1 + (int)((pk >> 3) & 31u), xi = u.x0 - 4 + 4 * (int)((pk >> 8) & 31u);
       // bitwise, no short circuits: hipcc turns `a && b ? x : y` around a load into exec-mask branches with a full vmcnt drain
       const int ok = (int)valid & (int)((pk >> 15) & 1u) & (int)(j >= jmin) & (int)(zi >= 0) & (int)(zi < dD) & (int)(yi >= 0) & (int)(yi < dW) &
@@ -224,6 +247,10 @@ __global__ __launch_bounds__(512, 2) void conv0_cl_bf16_kernel(const float* __re
       if ((it + 1) * 512 <= NITEMS || it * 512 + tid < NITEMS) {
         int sl = wpos + (int)(it_pk[it] & 7u);
         sl -= sl >= NRING ? NRING : 0;
+        if constexpr (CLIN) {
+          *reinterpret_cast<f32x4*>(lds + (unsigned)sl * PLB + l_rec[it]) = ld[SET][it][0];
+          continue;
+        }
         const unsigned xo = (it_pk[it] >> 2) & 64u;   // q odd (bit 8 of the pack): the quad's voxel pairs are swapped (64 bytes = two records)
         const unsigned base = (unsigned)sl * PLB + l_rec[it];
         const unsigned la = base + xo, lb2 = base + (64u - xo);
@@ -388,7 +415,7 @@ __global__ void pack_c0cl_kernel(const float* __restrict__ w, u32x4* __restrict_
 
 // ---- internal entry points (conv3d_bf16.hip dispatches to them; declared in lr_common.h)
 int64_t lr_internal_conv0_cl_bf16_packed_bytes(int Cin, int Cout) {
-  return (Cin > 3 && Cin <= 16 && Cout == 16) ? (int64_t)NSTEP * 64 * 16 : 0;
+  return (Cin >= 1 && Cin <= 16 && Cout == 16) ? (int64_t)NSTEP * 64 * 16 : 0;
 }
 
 int lr_internal_conv0_cl_bf16_pack(const float* weight, void* packed, int Cin, int Cout, hipStream_t st) {
@@ -398,11 +425,13 @@ int lr_internal_conv0_cl_bf16_pack(const float* weight, void* packed, int Cin, i
 }
 
 // LR_EUNSUPPORTED -> the caller falls back to the channel-pass kernel
+// clin: `in` is the (B,D,W,H,16) bf16 channels-last encoder input of lr_backproject_encin_bf16 instead of fp32 NCDHW
 int lr_internal_conv0_cl_bf16(const float* in, const void* packed, const float* bias, void* out, int B, int Cin, int Cout, int D,
-                              int W, int H, int out_layout, float slope, long long out_bs, hipStream_t st) {
-  if (Cin <= 3 || Cin > 16 || Cout != 16 || (H & 3) || (reinterpret_cast<uintptr_t>(in) & 15u)) return LR_EUNSUPPORTED;
+                              int W, int H, int out_layout, float slope, long long out_bs, int clin, hipStream_t st) {
+  if (Cin < 1 || Cin > 16 || Cout != 16 || (reinterpret_cast<uintptr_t>(in) & 15u)) return LR_EUNSUPPORTED;
+  if (!clin && (H & 3)) return LR_EUNSUPPORTED;
   const int64_t V = (int64_t)D * W * H;
-  if ((int64_t)Cin * V * 4 + (int64_t)8 * W * H * 4 >= 0x7fffffffLL) return LR_EUNSUPPORTED;   // 31-bit byte offsets inside one batch element
+  if ((int64_t)(clin ? 8 : Cin) * V * 4 + (int64_t)8 * W * H * 32 >= 0x7fffffffLL) return LR_EUNSUPPORTED;   // 31-bit byte offsets inside one batch element
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   int blocks = cus;
@@ -442,8 +471,21 @@ int lr_internal_conv0_cl_bf16(const float* in, const void* packed, const float* 
     if (lr_raise_dyn_lds(reinterpret_cast<const void*>(&conv0_cl_bf16_kernel<CQV, HP, SZV, BYV>), ldsb, attr_done) != LR_OK) return LR_ELAUNCH; \
     hipLaunchKernelGGL((conv0_cl_bf16_kernel<CQV, HP, SZV, BYV>), dim3((unsigned)blocks), dim3(512), ldsb, st, in, wt, bias, o, d);  \
   } while (0)
+  if (clin) {   // staged from the channels-last bf16 encoder input: one instance per output layout (1 x 16 steps)
+    if (shape != 116) return LR_EUNSUPPORTED;
+#define LR_C0CLIN(HP)                                                                                                      \
+  do {                                                                                                                     \
+    static std::atomic<uint64_t> attr_done{0};                                                                             \
+    if (lr_raise_dyn_lds(reinterpret_cast<const void*>(&conv0_cl_bf16_kernel<4, HP, 1, 16, true>), ldsb, attr_done) != LR_OK) return LR_ELAUNCH; \
+    hipLaunchKernelGGL((conv0_cl_bf16_kernel<4, HP, 1, 16, true>), dim3((unsigned)blocks), dim3(512), ldsb, st, in, wt, bias, o, d);  \
+  } while (0)
+    if (hps) LR_C0CLIN(true); else LR_C0CLIN(false);
+#undef LR_C0CLIN
+    return lr_launch_status();
+  }
 #define LR_C0CL(CQV, HP) do { if (shape == 44) LR_C0CL3(CQV, HP, 4, 4); else if (shape == 28) LR_C0CL3(CQV, HP, 2, 8); else LR_C0CL3(CQV, HP, 1, 16); } while (0)
-  if (CQ == 2) { if (hps) LR_C0CL(2, true); else LR_C0CL(2, false); }
+  if (CQ == 1) { if (hps) LR_C0CL(1, true); else LR_C0CL(1, false); }
+  else if (CQ == 2) { if (hps) LR_C0CL(2, true); else LR_C0CL(2, false); }
   else if (CQ == 3) { if (hps) LR_C0CL(3, true); else LR_C0CL(3, false); }
   else { if (hps) LR_C0CL(4, true); else LR_C0CL(4, false); }
 #undef LR_C0CL3

@@ -743,9 +743,11 @@ static int first_bf16_impl(const float* in, const void* packed_w, const float* b
   const dim3 grid((unsigned)nblk), block(256);
   hipStream_t st = lr_stream(stream);
   const u32x4* wt = reinterpret_cast<const u32x4*>(packed_w);
-  if (Cin > 3 && !getenv("LIFTREG_CONV0_BF16_PASSES")) {   // many channels (C4): all of them staged once, channels-last in LDS
+  // many channels (C4): all of them staged once, channels-last in LDS (conv0_cl_bf16.hip); LIFTREG_CONV0_BF16_CL=1 sends the
+  // 3-channel case there too (A/B aid), LIFTREG_CONV0_BF16_PASSES=1 keeps everything on the channel-pass kernel
+  if ((Cin > 3 || getenv("LIFTREG_CONV0_BF16_CL")) && !getenv("LIFTREG_CONV0_BF16_PASSES")) {
     const int e = lr_internal_conv0_cl_bf16(in, wt + (size_t)((Cin + 2) / 3) * 4 * (Cout / 16) * 64, bias, out, B, Cin, Cout, D, W, H,
-                                            out_layout, negative_slope, d.out_bs, st);
+                                            out_layout, negative_slope, d.out_bs, 0, st);
     if (e != LR_EUNSUPPORTED) return e;
   }
 #define LR_C0(NTV, SG)                                                                                                   \
@@ -888,4 +890,23 @@ extern "C" int lr_conv3d_first_obs_bf16(const float* in, const void* packed_w, c
                                         int64_t out_batch_stride, void* stream) {
   if (out_batch_stride < 0) return LR_EINVAL;
   return first_bf16_impl(in, packed_w, bias, out, B, Cin, Cout, D, W, H, out_layout, negative_slope, (long long)out_batch_stride, stream);
+}
+
+// The first block of the bf16 variant on the CHANNELS-LAST bf16 encoder input (B,D,W,H,16) written by
+// lr_backproject_encin_bf16 (channel 0 = moving, 1..Cin-1 = the backprojected views, the rest 0): same weights
+// (lr_conv3d_pack_weights_bf16_planar), same products, same results as lr_conv3d_first_bf16 on the fp32 NCDHW
+// cat([moving, views]) — the rounding to bf16 merely happened one kernel earlier.  Cout = 16, 1 <= Cin <= 16.
+extern "C" int lr_conv3d_first_clin_bf16(const void* in, const void* packed_w, const float* bias, void* out, int B, int Cin,
+                                         int Cout, int D, int W, int H, int out_layout, float negative_slope,
+                                         int64_t out_batch_stride, void* stream) {
+  if (!in || !packed_w || !out) return LR_ENULL;
+  if (B < 1 || Cin < 1 || D < 1 || W < 1 || H < 1 || out_batch_stride < 0) return LR_EINVAL;
+  if (Cout != 16 || Cin > 16) return LR_EUNSUPPORTED;
+  if (out_layout != LR_LAYOUT_BF16_NDHWC && out_layout != LR_LAYOUT_BF16_NDHWC_HPS) return LR_EINVAL;
+  if (out_layout == LR_LAYOUT_BF16_NDHWC_HPS && (H & 1)) return LR_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(packed_w) & 15u) || (reinterpret_cast<uintptr_t>(out) & 7u) || (reinterpret_cast<uintptr_t>(in) & 15u)) return LR_EALIGN;
+  if (out_batch_stride != 0 && out_batch_stride < (int64_t)Cout * D * W * H) return LR_EINVAL;
+  const u32x4* wt = reinterpret_cast<const u32x4*>(packed_w);
+  return lr_internal_conv0_cl_bf16(reinterpret_cast<const float*>(in), wt + (size_t)((Cin + 2) / 3) * 4 * (Cout / 16) * 64, bias, out, B,
+                                   Cin, Cout, D, W, H, out_layout, negative_slope, (long long)out_batch_stride, 1, lr_stream(stream));
 }

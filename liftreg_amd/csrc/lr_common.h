@@ -92,4 +92,4 @@ int lr_internal_conv0_pc(const float* in0, int64_t bs0, const float* in_rest, in
 int64_t lr_internal_conv0_cl_bf16_packed_bytes(int Cin, int Cout);
 int lr_internal_conv0_cl_bf16_pack(const float* weight, void* packed, int Cin, int Cout, hipStream_t st);
 int lr_internal_conv0_cl_bf16(const float* in, const void* packed, const float* bias, void* out, int B, int Cin, int Cout, int D,
-                              int W, int H, int out_layout, float slope, long long out_bs, hipStream_t st);
+                              int W, int H, int out_layout, float slope, long long out_bs, int clin, hipStream_t st);

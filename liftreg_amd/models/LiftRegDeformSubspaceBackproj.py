@@ -46,6 +46,9 @@ class model(nn.Module):
     :param img_sz: voxel shape [D, W, H]
     :param opt: mapping with "drr_feature_num" (P), "latent_dim" (L), "pca_path"
     """
+    # bf16 inference: from this many views on, the encoder input is written as 32-byte channels-last bf16 records
+    # (ops.backproject_encoder_input_bf16) instead of the fp32 planar feature volume (4 (P + 1) bytes per voxel)
+    ENCIN_MIN_VIEWS = 8
 
     def __init__(self, img_sz, opt=None):
         super().__init__()
@@ -318,6 +321,23 @@ class model(nn.Module):
                 for i in range(1, 6):
                     x = self.encoders[i](x, packed=self._packed_weight(i))
                 return self.encoders[6](x)
+        if (self.conv_dtype == "bf16" and not needs_grad and P >= self.ENCIN_MIN_VIEWS and self.encoders[0].conv.out_channels == 16 and
+                ops.encoder_input_bf16_supported(moving, target_proj)):
+            # inference, bf16 variant, many views (C4: 11): cat([moving, target_volume]) (:89-98) is written ONCE, as the bf16
+            # channels-last records the first block stages (32 bytes per voxel) — the fp32 (B,P,D,W,H) feature volume
+            # (2.95 GB written, 1.6x that read back at C4) never exists; the first block's results keep their bits (its
+            # inputs were rounded to bf16 anyway, now one kernel earlier)
+            mv = moving if moving.is_contiguous() else moving.contiguous()
+            x = ops.backproject_encoder_input_bf16(mv, target_proj, self._poses)
+            blk = self.encoders[0]
+            x = ops.conv3d_first_clin_bf16(x, blk.conv.weight, blk.conv.bias, out_layout=self._bf16_layouts[0][1],
+                                           negative_slope=blk._slope, packed=self._packed_weight(0, bf16=True))
+            for i in range(1, 6):
+                blk = self.encoders[i]
+                lin, lout = self._bf16_layouts[i]
+                x = ops.conv3d_k3_lrelu_bf16(x, blk.conv.weight, blk.conv.bias, blk.stride, in_layout=lin, out_layout=lout,
+                                             negative_slope=blk._slope, packed=self._packed_weight(i, bf16=True))
+            return self.encoders[6](x)
         # encoder input = cat([moving, target_volume], dim=1) (:95-98), built in place
         x = torch.empty((B, P + 1, D, W, H), dtype=torch.float32, device=moving.device)
         x[:, 0:1].copy_(moving)

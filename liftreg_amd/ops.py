@@ -479,6 +479,57 @@ def conv3d_first_bf16(x, weight, bias, *, out_layout, negative_slope=0.2, packed
     return y
 
 
+def encoder_input_bf16_supported(moving, proj):
+    """True when `backproject_encoder_input_bf16` + `conv3d_first_clin_bf16` can replace backproject + cat + the first block
+    (bf16 variant, 1..15 views, single-channel moving image)."""
+    return (moving.dim() == 5 and proj.dim() == 4 and moving.shape[1] == 1 and 1 <= proj.shape[1] <= 15 and
+            moving.shape[0] == proj.shape[0] and moving.shape[2] * moving.shape[3] * moving.shape[4] * 32 < 2 ** 31 - 2 ** 24 and
+            moving.shape[4] <= 256 and proj.shape[3] % 4 == 0 and proj.data_ptr() % 16 == 0 and
+            proj.shape[1] * 9 * (proj.shape[3] + 8) * 4 <= 140 * 1024 and proj.shape[1] * 9 * ((proj.shape[3] + 8) // 4) <= 13 * 512)
+
+
+def backproject_encoder_input_bf16(moving, proj, poses, *, d0=0, d1=None, out=None):
+    """Rows [d0,d1) of cat([moving, backprojection of proj], dim=1) as bfloat16 channels-last records (B, d1-d0, W, H, 16):
+    channel 0 = moving, 1..P = the views' backprojection (lr_backproject_f32's values), the rest 0, rounded to nearest-even
+    bf16.  The fp32 (B,P,D,W,H) feature volume of …Backproj.py:89-93 is never written (C4: 2.95 GB).  Feeds
+    `conv3d_first_clin_bf16`."""
+    moving, proj = _dev(moving, "moving"), _dev(proj, "proj")
+    if not encoder_input_bf16_supported(moving, proj):
+        raise ValueError("backproject_encoder_input_bf16: unsupported shapes")
+    B, _, D, W, H = moving.shape
+    P, Pw, Ph = proj.shape[1], proj.shape[2], proj.shape[3]
+    d1 = D if d1 is None else int(d1)
+    poses = _host_f32(poses, (3,), "poses").reshape(-1, 3)
+    if poses.shape[0] != P:
+        raise ValueError(f"poses has {poses.shape[0]} views, proj has {P}")
+    y = _conv_out(out, (B, d1 - d0, W, H, 16), torch.bfloat16, moving.device, strided_batch=True)
+    obs = _batch_stride(y) or 16 * (d1 - d0) * W * H
+    with _timed("backproject_encin_bf16", bytes=4 * B * (d1 - d0) * W * H + 32 * B * (d1 - d0) * W * H + 4 * proj.numel(), samples=B):
+        _hip.check(_hip.lib().lr_backproject_encin_bf16(proj.data_ptr(), moving.data_ptr(), poses.ctypes.data, y.data_ptr(), B, P, Pw,
+                                                        Ph, D, W, H, int(d0), d1, obs, _stream()), "lr_backproject_encin_bf16")
+    return y
+
+
+def conv3d_first_clin_bf16(x_cl, weight, bias, *, out_layout, negative_slope=0.2, packed=None, out=None):
+    """The bf16 variant's first block on the channels-last bf16 encoder input (B,D,W,H,16) of
+    `backproject_encoder_input_bf16`: same weights and results as `conv3d_first_bf16` on the fp32 NCDHW concatenation."""
+    x_cl = _dev(x_cl, "x_cl", torch.bfloat16)
+    B, D, W, H, C16 = x_cl.shape
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    if C16 != 16 or Cin > 16:
+        raise ValueError("x_cl must be (B,D,W,H,16) and the weight have at most 16 input channels")
+    if packed is None:
+        packed = conv3d_pack_weights_bf16_planar(weight)
+    b = None if bias is None else _dev(bias.detach(), "bias")
+    y = _conv_out(out, (B, D, W, H, Cout), torch.bfloat16, x_cl.device, strided_batch=True)
+    with _timed(f"conv3d_bf16_c{Cin}x{Cout}_s1_{D}_clin", flops=2.0 * 27 * Cin * Cout * B * D * W * H,
+                bytes=2 * x_cl.numel() + 2 * y.numel(), samples=B, peak_tf=MFMA_BF16_PEAK_TF, bound="hbm"):
+        _hip.check(_hip.lib().lr_conv3d_first_clin_bf16(x_cl.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B, Cin, Cout, D, W,
+                                                        H, out_layout, float(negative_slope), _batch_stride(y), _stream()),
+                   "lr_conv3d_first_clin_bf16")
+    return y
+
+
 def cast_bf16(x):
     """fp32 → bfloat16 (round to nearest even), same shape/order."""
     x = _dev(x, "x")

@@ -313,6 +313,17 @@ class SlabShardedRegistration:
             for inp, (d0, d1), t in zip(inputs, bounds, st):
                 moving, proj = inp["source"], inp["target_proj"]
                 lo, hi, n_real = t["lo"], t["hi"], t["hi"] - t["lo"]
+                if (bf16 and P >= getattr(net, "ENCIN_MIN_VIEWS", 99) and c0 == 16 and
+                        ops.encoder_input_bf16_supported(moving, proj)):
+                    # many views (C4): the slab's encoder input as bf16 channels-last records straight from the views and the
+                    # replicated moving volume — the same kernels, and bits, as the unsharded model's first block
+                    mvg = moving[g0:g1] if moving[g0:g1].is_contiguous() else moving[g0:g1].contiguous()
+                    e = ops.backproject_encoder_input_bf16(mvg, proj[g0:g1].contiguous(), net._poses, d0=lo, d1=hi)
+                    blk = net.encoders[0]
+                    ops.conv3d_first_clin_bf16(e, blk.conv.weight, blk.conv.bias, out_layout=layouts(0)[1], negative_slope=blk._slope,
+                                               packed=net._packed_weight(0, bf16=True), out=t["y0"][g0:g1, t["a0"]:t["a0"] + n_real])
+                    tops.append(t["y0"][g0:g1, t["r"]:t["r"] + 1])
+                    continue
                 x = torch.empty((g1 - g0, P + 1, n_real, W, H), dtype=torch.float32, device=moving.device)
                 x[:, 0:1].copy_(moving[g0:g1, :, lo:hi])
                 ops.backproject(proj[g0:g1].contiguous(), net._poses, (D, W, H), d0=lo, d1=hi, out=x[:, 1:],

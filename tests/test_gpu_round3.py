@@ -112,3 +112,41 @@ def test_pca_gradient_byte_model_is_compulsory_traffic():
     assert rec["info"]["bytes"] == 4 * L * M + 4 * B * M
     want = gd.double() @ basis.double().T
     assert float((gc.double() - want).abs().max() / want.abs().max()) < 1e-5
+
+
+def test_encoder_input_bf16_records_equal_feature_volume_path():
+    """Many views (C4's 11), bf16 variant: the channels-last bf16 encoder input (lr_backproject_encin_bf16) holds
+    bf16(moving) | bf16(lr_backproject_f32's samples) | zeros, for the whole volume and for a z-slab written into a strided
+    batch; the first block on it (lr_conv3d_first_clin_bf16) equals lr_conv3d_first_bf16 on the fp32 concatenation bit for
+    bit — ragged sizes (D, W not multiples of the bundle / step) and an oblique geometry (the slow path) included."""
+    from liftreg_amd import ops
+    from liftreg_amd.utils.sdct_projection_utils import scan_poses
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(21)
+    for (D, W, H), P, B, Pw, Ph, oblique in (((22, 18, 64), 11, 3, 40, 64, False), ((9, 7, 128), 8, 1, 64, 128, False),
+                                             ((16, 16, 64), 9, 2, 24, 64, True), ((40, 36, 256), 11, 2, 64, 256, False), ((12, 10, 32), 15, 1, 32, 32, False)):
+        mv = torch.rand((B, 1, D, W, H), generator=g, device=dev) * 2 - 1
+        proj = torch.rand((B, P, Pw, Ph), generator=g, device=dev) * 2 - 1
+        poses = scan_poses(30, P, W).astype(np.float32)
+        if oblique:
+            poses[:, 1] = W * 0.55          # emitter almost inside the volume: shadows fan out over many detector rows
+        assert ops.encoder_input_bf16_supported(mv, proj)
+        e = ops.backproject_encoder_input_bf16(mv, proj, poses)
+        tv = ops.backproject(proj, poses, (D, W, H))
+        assert torch.equal(e[..., 0], mv[:, 0].to(torch.bfloat16))
+        assert torch.equal(e[..., 1:P + 1], tv.permute(0, 2, 3, 4, 1).to(torch.bfloat16)), (D, W, H, P, oblique)
+        assert bool((e[..., P + 1:] == 0).all())
+        # a z-slab into a strided batch (the sharded model's buffers)
+        d0, d1 = 3, D - 2
+        big = torch.zeros((B, D + 3, W, H, 16), dtype=torch.bfloat16, device=dev)
+        ops.backproject_encoder_input_bf16(mv, proj, poses, d0=d0, d1=d1, out=big[:, 2:2 + d1 - d0])
+        assert torch.equal(big[:, 2:2 + d1 - d0], e[:, d0:d1]) and bool((big[:, :2] == 0).all()) and bool((big[:, 2 + d1 - d0:] == 0).all())
+        if H % 4 == 0:
+            w = torch.randn((16, P + 1, 3, 3, 3), generator=g, device=dev) * 0.05
+            bias = torch.randn((16,), generator=g, device=dev) * 0.1
+            x = torch.cat([mv, tv], 1)
+            for lay in (ops.LAYOUT_BF16_NDHWC, ops.LAYOUT_BF16_NDHWC_HPS):
+                want = ops.conv3d_first_bf16(x, w, bias, out_layout=lay)
+                got = ops.conv3d_first_clin_bf16(e, w, bias, out_layout=lay)
+                assert torch.equal(got, want), (D, W, H, P, lay)

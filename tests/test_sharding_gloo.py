@@ -34,6 +34,10 @@ class OracleOps:
     def conv3d_first_split_supported(*_):
         return False      # … and the concatenated encoder input
 
+    @staticmethod
+    def encoder_input_bf16_supported(*_):
+        return False      # … and the fp32 feature volume
+
     # ---- layouts (mirror of LR_LAYOUT_*) -------------------------------------------------------
     def _to_ncdhw(self, x, layout):
         if layout == self.LAYOUT_NCDHW:
