@@ -494,8 +494,11 @@ def main():
         "roofline": roof(dominant),
         "roofline_backproject": roof("backproject"),
         "backproj_hbm_GBps": kernels["backproject"]["achieved"],
-        "backproject_note": ("stand-alone lr_backproject_f32 timed right after the step (n = 0 launches per step): the step "
-                             "computes the backprojection inside block 0's staging, SURVEY 8 f1") if bp_standalone else
+        "backproject_note": (("stand-alone lr_backproject_f32 timed right after the step (n = 0 launches per step): the step "
+                              "writes the backprojected views straight into the first block's bf16 channels-last input "
+                              "(backproject_encin_bf16 in `kernels`), the fp32 feature volume never exists") if "backproject_encin_bf16" in ksum else
+                             ("stand-alone lr_backproject_f32 timed right after the step (n = 0 launches per step): the step "
+                              "computes the backprojection inside block 0's staging, SURVEY 8 f1")) if bp_standalone else
                             "lr_backproject_f32 as launched inside the timed step",
         "kernels": {k: {"ms": round(v["avg_ms"], 4), "n": v["launches_per_step"], "frac": round(v["frac"], 4),
                         "bound": v["bound"], "traffic": v["traffic"]} for k, v in kernels.items()},

@@ -150,3 +150,67 @@ def test_encoder_input_bf16_records_equal_feature_volume_path():
                 want = ops.conv3d_first_bf16(x, w, bias, out_layout=lay)
                 got = ops.conv3d_first_clin_bf16(e, w, bias, out_layout=lay)
                 assert torch.equal(got, want), (D, W, H, P, lay)
+
+
+def test_first_block_winograd_sweep_vs_c_oracle_and_direct(monkeypatch):
+    """The DEFAULT first block (conv3d_planar_kernel, Winograd F(2,3) along H, channels-last output) against the scalar C
+    oracle (the reference's fmaf chain) and against the direct sweep (LIFTREG_CONV0_DIRECT=1): same fp32 arithmetic, another
+    summation tree -> within 2e-5 of the activation scale, EVERY element (no outlier allowance).  Ragged sizes (D, W, H not
+    multiples of the 4 x 4 x 64 brick), 1-3 input channels, both channels-last layouts, the strided-batch output."""
+    import oracle.c_oracle as co
+    from liftreg_amd import ops
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(5)
+    for (D, W, H), B, ci in (((6, 9, 64), 2, 3), ((5, 4, 132), 1, 2), ((9, 11, 72), 1, 3), ((4, 4, 256), 1, 1), ((13, 6, 68), 2, 3)):
+        x = torch.from_numpy(rs.uniform(-1, 1, (B, ci, D, W, H)).astype(np.float32)).to(dev)
+        w = torch.from_numpy((rs.normal(0, 1, (16, ci, 3, 3, 3)) / (27 * ci) ** 0.5).astype(np.float32)).to(dev)
+        b = torch.from_numpy(rs.uniform(-0.1, 0.1, 16).astype(np.float32)).to(dev)
+        ref = co.conv3d_k3_lrelu(x.cpu().numpy(), w.cpu().numpy(), b.cpu().numpy(), 1, 0.2)          # (B,16,D,W,H)
+        scale = float(np.abs(ref).max())
+        got = ops.conv3d_k3_lrelu(x, w, b, 1, out_layout=ops.LAYOUT_NDHWC)                            # Winograd sweep
+        err = np.abs(got.permute(0, 4, 1, 2, 3).cpu().numpy() - ref).max()
+        assert err <= 2e-5 * scale, ((D, W, H), ci, err, scale)
+        monkeypatch.setenv("LIFTREG_CONV0_DIRECT", "1")
+        direct = ops.conv3d_k3_lrelu(x, w, b, 1, out_layout=ops.LAYOUT_NDHWC)
+        monkeypatch.delenv("LIFTREG_CONV0_DIRECT")
+        assert np.array_equal(direct.permute(0, 4, 1, 2, 3).cpu().numpy(), ref), "the direct sweep IS the oracle's chain"
+        assert not torch.equal(direct, got)                                                          # … and the default is the other kernel
+        if H % 2 == 0:
+            hps = ops.conv3d_k3_lrelu(x, w, b, 1, out_layout=ops.LAYOUT_NDHWC_HPS)
+            assert torch.equal(ops.hps_to_ndhwc(hps), got)
+        # strided-batch output (the sharded model's halo-padded buffers): same bits, the padding planes untouched
+        big = torch.full((B, D + 3, W, H, 16), 7.0, dtype=torch.float32, device=dev)
+        ops.conv3d_k3_lrelu(x, w, b, 1, out_layout=ops.LAYOUT_NDHWC, out=big[:, 2:2 + D])
+        assert torch.equal(big[:, 2:2 + D], got) and bool((big[:, :2] == 7.0).all()) and bool((big[:, 2 + D:] == 7.0).all())
+
+
+def test_stride2_blocks_strided_batch_output_equals_dense(monkeypatch):
+    """lr_conv3d_k3_lrelu_obs_f32 / _obs_bf16: the stride-2 blocks writing into a plane range of per-sample padded buffers (one
+    launch for the whole batch) give the bits of the dense launch — Winograd rows kernel, direct rows kernel and the bf16 rows
+    kernel, with z_phase, every output layout; the planes around the range stay untouched."""
+    from liftreg_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    for (D, W, H), B, ci, co_, force_rows in (((10, 12, 32), 3, 16, 32, False), ((6, 128, 128), 2, 16, 32, False), ((8, 10, 16), 2, 32, 32, True)):
+        if force_rows:
+            monkeypatch.setenv("LIFTREG_CONV_ROWS_ALWAYS", "1")
+        else:
+            monkeypatch.delenv("LIFTREG_CONV_ROWS_ALWAYS", raising=False)
+        x = torch.rand((B, D, W, H, ci), generator=g, device=dev) * 2 - 1
+        w = torch.randn((co_, ci, 3, 3, 3), generator=g, device=dev) / (27 * ci) ** 0.5
+        b = torch.randn((co_,), generator=g, device=dev) * 0.1
+        Do, Wo, Ho = (D - 1) // 2 + 1, (W - 1) // 2 + 1, (H - 1) // 2 + 1
+        for zp in (0, 1):
+            for lay in (ops.LAYOUT_NDHWC, ops.LAYOUT_NDHWC_HPS):
+                want = ops.conv3d_k3_lrelu(x, w, b, 2, in_layout=ops.LAYOUT_NDHWC_HPS, out_layout=lay, z_phase=zp)
+                big = torch.full((B, Do + 2, Wo, Ho, co_), 3.0, dtype=torch.float32, device=dev)
+                ops.conv3d_k3_lrelu(x, w, b, 2, in_layout=ops.LAYOUT_NDHWC_HPS, out_layout=lay, z_phase=zp, out=big[:, 1:1 + Do])
+                assert torch.equal(big[:, 1:1 + Do], want) and bool((big[:, 0] == 3.0).all()) and bool((big[:, 1 + Do] == 3.0).all())
+        xb = x.to(torch.bfloat16)
+        for lay in (ops.LAYOUT_BF16_NDHWC, ops.LAYOUT_BF16_NDHWC_HPS):
+            want = ops.conv3d_k3_lrelu_bf16(xb, w, b, 2, in_layout=ops.LAYOUT_BF16_NDHWC_HPS, out_layout=lay)
+            big = torch.full((B, Do + 2, Wo, Ho, co_), 3.0, dtype=torch.bfloat16, device=dev)
+            ops.conv3d_k3_lrelu_bf16(xb, w, b, 2, in_layout=ops.LAYOUT_BF16_NDHWC_HPS, out_layout=lay, out=big[:, 1:1 + Do])
+            assert torch.equal(big[:, 1:1 + Do], want) and bool((big[:, 0] == 3.0).all()) and bool((big[:, 1 + Do] == 3.0).all())
+    monkeypatch.delenv("LIFTREG_CONV_ROWS_ALWAYS", raising=False)

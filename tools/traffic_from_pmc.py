@@ -50,7 +50,9 @@ def op_table(cfg, P, bf16):
     # stride-2 blocks: planes of >= 64 x 64 outputs run the persistent Winograd rows kernel (one grid size for all of them:
     # told apart by rank only if there are several), smaller ones the direct rows kernel
     if bf16:   # --conv-dtype bf16: the first block (all channels at once for > 3 of them, else the channel-pass kernel), then the row kernels
-        ops = ops[:4] + [(f"conv3d_bf16_c{P + 1}x16_s1_{n}", r"^conv0_cl_bf16_kernel" if P + 1 > 3 else r"^conv0_bf16_kernel", 0),
+        ops = ops[:4] + [(f"conv3d_bf16_c{P + 1}x16_s1_{n}", r"^conv0_cl_bf16_kernel<.*, false>$" if P + 1 > 3 else r"^conv0_bf16_kernel", 0),
+                         (f"conv3d_bf16_c{P + 1}x16_s1_{n}_clin", r"^conv0_cl_bf16_kernel<.*, true>$", 0),
+                         ("backproject_encin_bf16", r"^backproject_encin_bf16_kernel", 0),
                          (f"conv3d_bf16_c16x32_s2_{n}", r"^conv3d_cl_rows_bf16_kernel<2, 4, false>", 0)]
         size, rank = n // 2, 0
         while size >= 16:
