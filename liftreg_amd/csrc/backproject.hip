@@ -373,7 +373,8 @@ __global__ __launch_bounds__(BE_THREADS) void backproject_encin_bf16_kernel(
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int RS = Ph + 2 * BT_PAD;                  // padded row length (floats)
   float* tile = smem;                              // [NV][BE_RCAP][RS]
-  float4* tyt = reinterpret_cast<float4*>(smem + NV * BE_RCAP * RS);   // [NV][TJ*TI] {row offset, e, w, -}
+  const int tile_floats = BE_PREFETCH ? ((NV * BE_RCAP * (RS >> 2) + BE_THREADS - 1) / BE_THREADS) * BE_THREADS * 4 : NV * BE_RCAP * RS;
+  float4* tyt = reinterpret_cast<float4*>(smem + tile_floats);   // [NV][TJ*TI] {row offset, e, w, -}
   __shared__ int s_lo[NV], s_hi[NV];
   const int tid = threadIdx.x;
   const int nJ = (W + BE_TJ - 1) / BE_TJ;
@@ -462,34 +463,36 @@ __global__ __launch_bounds__(BE_THREADS) void backproject_encin_bf16_kernel(
   // The detector rows of every view for batch element b+1 travel into registers while element b is computed (one block of
   // 8 waves per CU holds the LDS: without the look-ahead every element paid the views' L2 latency in the open).
   // (Ph % 4 == 0 and 16-byte aligned views: checked by the launcher.)
-  constexpr int NPF_MAX = (15 * BE_RCAP * ((1024 + 2 * BT_PAD) / 4) + BE_THREADS - 1) / BE_THREADS;
   const int total4 = NV * BE_RCAP * RS4;
-  const int npf = (total4 + BE_THREADS - 1) / BE_THREADS;
-  float4 pre[BE_NPF];   // npf <= BE_NPF is checked by the launcher
-  (void)NPF_MAX;
-  auto fetch = [&](int b) __attribute__((always_inline)) {
-    const float* pbn = proj + (int64_t)b * NV * view_sz;
+  const int npf = (total4 + BE_THREADS - 1) / BE_THREADS;   // slots in use (<= BE_NPF: checked by the launcher)
+  float4 pre[BE_NPF];
+  // which view element every prefetch slot of this thread holds does not depend on the batch element: byte offsets (or
+  // "outside": the load then returns the tile's zero padding) are computed once; the look-ahead itself is BE_NPF
+  // unconditional bounds-checked buffer loads and as many unconditional LDS stores (the tile is sized in whole slots)
+  unsigned poff[BE_NPF];
 #pragma unroll
-    for (int t = 0; t < BE_NPF; ++t) {
-      const int idx = tid + t * BE_THREADS;
-      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t < npf && idx < total4) {
-        const int v = idx / (BE_RCAP * RS4), rem = idx - v * (BE_RCAP * RS4);
-        const int row = rem / RS4, c4 = rem - row * RS4;
-        const int lo = s_lo[v], nr = s_hi[v] >= lo ? s_hi[v] - lo + 1 : 0;
-        const int grow = lo + row, col = c4 * 4 - BT_PAD;
-        if (row < nr && grow >= 0 && grow < Pw && col >= 0 && col < Ph)
-          val = *reinterpret_cast<const float4*>(pbn + (int64_t)v * view_sz + (int64_t)grow * Ph + col);
-      }
-      pre[t] = val;
+  for (int t = 0; t < BE_NPF; ++t) {
+    const int idx = tid + t * BE_THREADS;
+    unsigned off = 0x80000000u;
+    if (BE_PREFETCH && idx < total4) {
+      const int v = idx / (BE_RCAP * RS4), rem = idx - v * (BE_RCAP * RS4);
+      const int row = rem / RS4, c4 = rem - row * RS4;
+      const int lo = s_lo[v], nr = s_hi[v] >= lo ? s_hi[v] - lo + 1 : 0;
+      const int grow = lo + row, col = c4 * 4 - BT_PAD;
+      if (row < nr && grow >= 0 && grow < Pw && col >= 0 && col < Ph) off = (unsigned)((((int64_t)v * Pw + grow) * Ph + col) * 4);
     }
+    poff[t] = off;
+  }
+  auto fetch = [&](int b) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(proj + (int64_t)b * NV * view_sz), (short)0,
+                                                                        (int)(NV * view_sz * 4), 0x00020000);
+#pragma unroll
+    for (int t = 0; t < BE_NPF; ++t) pre[t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[t], 0, 0));
   };
   auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int t = 0; t < BE_NPF; ++t) {
-      const int idx = tid + t * BE_THREADS;
-      if (t < npf && idx < total4) reinterpret_cast<float4*>(tile)[idx] = pre[t];   // tile is [v][row][RS]: idx is its float4 index
-    }
+    for (int t = 0; t < BE_NPF; ++t)
+      if (t < npf) reinterpret_cast<float4*>(tile)[tid + t * BE_THREADS] = pre[t];   // block-uniform bound; tile is [v][row][RS] in float4s, sized in whole slots
   };
   auto stage_direct = [&](int b) __attribute__((always_inline)) {   // without the register look-ahead: global -> LDS in a loop
     const float* pbn = proj + (int64_t)b * NV * view_sz;
@@ -620,7 +623,9 @@ extern "C" int lr_backproject_encin_bf16(const float* proj, const float* moving,
   if (out_batch_stride < (int64_t)16 * Ds * W * H || (out_batch_stride & 7)) return LR_EINVAL;
   const int64_t nblk = (int64_t)((Ds + BE_TI - 1) / BE_TI) * ((W + BE_TJ - 1) / BE_TJ);
   if (nblk > 0x7fffffffLL) return LR_EINVAL;
-  const size_t lds = ((size_t)P * BE_RCAP * (Ph + 2 * BT_PAD) + 4 * (size_t)P * BE_TI * BE_TJ) * sizeof(float);
+  const size_t tile4 = (size_t)P * BE_RCAP * ((Ph + 2 * BT_PAD) / 4);
+  const size_t lds = ((BE_PREFETCH ? (tile4 + BE_THREADS - 1) / BE_THREADS * BE_THREADS : tile4) * 4 + 4 * (size_t)P * BE_TI * BE_TJ) * sizeof(float);
+  if ((int64_t)P * Pw * Ph * 4 >= 0x7fffffffLL) return LR_EUNSUPPORTED;
   if (lds > 150 * 1024 || (BE_PREFETCH && (int64_t)P * BE_RCAP * ((Ph + 2 * BT_PAD) / 4) > (int64_t)BE_NPF * BE_THREADS)) return LR_EUNSUPPORTED;
   unsigned short* o = reinterpret_cast<unsigned short*>(out);
   hipStream_t st = lr_stream(stream);
