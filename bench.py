@@ -435,7 +435,7 @@ def main():
             t_both = (time.perf_counter() - t0) / 5
         drr = {"volumes_per_s": B / t_drr, "projections_per_s": B * P / t_drr, "ms_per_volume": t_drr / B * 1e3,
                "simulate_plus_register_per_s": B / t_both,
-               "note": f"{P} views of {R}x{R} per {n}^3 volume, HU->mu as a one-pass prologue (lr_hu_to_mu_f32), the axis-1 flip folded into the projector"}
+               "note": f"{P} views of {R}x{R} per {n}^3 volume, HU->mu and the axis-1 flip folded into the projector's tap loads (no prologue pass, no temporary volume)"}
 
     # slab mode: the sharded projector leg of the north star ("RCCL all-reduce of slab-boundary partial sums"): every rank
     # integrates the taps of its rows [d0,d1) of each target volume, the partial (P,Rd,Rh) images sum over the ranks

@@ -111,6 +111,22 @@ __device__ __forceinline__ float mu_of(float v) {
   }
   return v;
 }
+// calc_relative_atten_coef with the division by 1000 as a multiplication and ONE Markstein correction step:
+//   q = x r,  e = fma(-q, 1000, x),  q' = fma(e, r, q)   with r = RN(1/1000)
+// q' equals the IEEE quotient x / 1000 for EVERY finite x >= 2^-100 (checked exhaustively over all 2.1e9 non-negative floats on
+// the CPU: the only mismatches are quotients in the denormal range, x < 1e-34) — and x = max(HU, -1000) + 1000 is 0 or at
+// least one ulp of 1000 (6e-5).  Six vector-ALU operations per tap instead of the ~14 of the IEEE divide sequence: cheap
+// enough to fold HU -> mu into the projector's tap loads, same bits as hu_to_mu_kernel.
+__device__ __forceinline__ float mu_of_fast(float v) {
+  v = (v < -1000.0f) ? -1000.0f : v;
+  const float x = v + 1000.0f;
+  const float r = 1.0f / 1000.0f;        // RN(1/1000), a compile-time constant
+  const float q = x * r;
+  const float e = fmaf(-q, 1000.0f, x);
+  const float qc = fmaf(e, r, q);
+  return qc * 0.2f;
+}
+
 template <bool HU>
 __device__ __forceinline__ void load_mu_pair(const float* p, int shift, bool ok0, bool ok1, float& v0,
                                              float& v1) {
@@ -217,7 +233,7 @@ __global__ __launch_bounds__(1024) void drr_forward_kernel(
 //    outside the slab falls outside the resource by itself, an out-of-range y row is pushed outside with one select;
 //  * the x pair is one 8-byte load; only where a wave touches the x faces a wave-uniform branch re-bases it;
 //  * products and sums in the general kernel's order: same bits.
-template <bool FLIP>
+template <bool FLIP, bool HU = false>
 __global__ __launch_bounds__(1024) void drr_forward_fast_kernel(
     const float* __restrict__ vol, LrPoses poses, float sp0, float sp1, float sp2,
     float* __restrict__ out, int D, int W, int H, int d0, int d1, int P, int Rd, int Rh, int nseg) {
@@ -256,9 +272,17 @@ __global__ __launch_bounds__(1024) void drr_forward_fast_kernel(
       ph = __builtin_amdgcn_fmed3f(ph, -1.0f, xhi);
       const float fz = floorf(pd), fy = floorf(pw), fx = floorf(ph);
       const int z0 = (int)fz - d0, y0 = (int)fy, x0 = (int)fx;
-      const float wz0 = (fz + 1.0f) - pd, wz1 = pd - fz;   // (i1 - pix), (pix - i0) — ATen's generic 3D kernel
-      const float wy0 = (fy + 1.0f) - pw, wy1 = pw - fy;
+      float wz0 = (fz + 1.0f) - pd, wz1 = pd - fz;   // (i1 - pix), (pix - i0) — ATen's generic 3D kernel
+      float wy0 = (fy + 1.0f) - pw, wy1 = pw - fy;
       const float wx0 = (fx + 1.0f) - ph, wx1 = ph - fx;
+      if constexpr (HU) {
+        // HU input: a tap outside the slab / volume reads raw 0, which calc_relative_atten_coef would turn into 0.2 — its
+        // axis weight is zeroed instead (0 * mu = +0, the bits of the mu-input kernel where the tap itself is 0)
+        wz0 = ((unsigned)z0 < (unsigned)Dn) ? wz0 : 0.0f;
+        wz1 = ((unsigned)(z0 + 1) < (unsigned)Dn) ? wz1 : 0.0f;
+        wy0 = ((unsigned)y0 < (unsigned)W) ? wy0 : 0.0f;
+        wy1 = ((unsigned)(y0 + 1) < (unsigned)W) ? wy1 : 0.0f;
+      }
       const int r0 = FLIP ? (W - 1 - y0) : y0, r1 = FLIP ? r0 - 1 : r0 + 1;
       const int yo0 = ((unsigned)y0 < (unsigned)W) ? __mul24(r0, H) : OUTSIDE;
       const int yo1 = ((unsigned)(y0 + 1) < (unsigned)W) ? __mul24(r1, H) : OUTSIDE;
@@ -273,6 +297,10 @@ __global__ __launch_bounds__(1024) void drr_forward_fast_kernel(
                      __builtin_bit_cast(float, q01.x), __builtin_bit_cast(float, q01.y),
                      __builtin_bit_cast(float, q10.x), __builtin_bit_cast(float, q10.y),
                      __builtin_bit_cast(float, q11.x), __builtin_bit_cast(float, q11.y)};
+      if constexpr (HU) {
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8) tp[t8] = mu_of_fast(tp[t8]);
+      }
       if (__builtin_amdgcn_ballot_w64(shift != 0) != 0) {  // x0 in {-1, H-1, H}: re-base the pair, drop what is outside
         const bool ok0 = (unsigned)x0 < (unsigned)H, ok1 = (unsigned)(x0 + 1) < (unsigned)H;
 #pragma unroll
@@ -378,14 +406,16 @@ extern "C" int lr_drr_forward_f32(const float* vol_slab, const float* poses, con
                      vol_slab, lp, spacing[0], spacing[1], spacing[2], out, D, W, H, d0, d1, P, \
                      Rd, Rh, nseg)
   const int64_t sD64 = (int64_t)W * H;
-  if (!hu && H >= 2 && (int64_t)(d1 - d0) * sD64 * 4 + sD64 * 8 <= 0x80000000LL && sD64 < (1 << 23) &&
+  if (H >= 2 && (int64_t)(d1 - d0) * sD64 * 4 + sD64 * 8 <= 0x80000000LL && sD64 < (1 << 23) &&
       !getenv("LIFTREG_DRR_GENERAL")) {
-    if (flip)
-      hipLaunchKernelGGL(drr_forward_fast_kernel<true>, grid, block, lds, lr_stream(stream), vol_slab, lp, spacing[0],
-                         spacing[1], spacing[2], out, D, W, H, d0, d1, P, Rd, Rh, nseg);
-    else
-      hipLaunchKernelGGL(drr_forward_fast_kernel<false>, grid, block, lds, lr_stream(stream), vol_slab, lp, spacing[0],
-                         spacing[1], spacing[2], out, D, W, H, d0, d1, P, Rd, Rh, nseg);
+#define LR_FAST(FLV, HUV)                                                                                            \
+  hipLaunchKernelGGL((drr_forward_fast_kernel<FLV, HUV>), grid, block, lds, lr_stream(stream), vol_slab, lp, spacing[0], \
+                     spacing[1], spacing[2], out, D, W, H, d0, d1, P, Rd, Rh, nseg)
+    if (hu && flip) LR_FAST(true, true);
+    else if (hu) LR_FAST(false, true);
+    else if (flip) LR_FAST(true, false);
+    else LR_FAST(false, false);
+#undef LR_FAST
     return lr_launch_status();
   }
   if (hu && flip) LR_LAUNCH(true, true);

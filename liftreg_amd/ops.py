@@ -111,12 +111,13 @@ def hu_to_mu(vol):
 
 
 def drr_forward(vol, poses, resolution, spacing=(2.2, 2.2, 2.2), *, d0=0, d1=None, full_D=None,
-                hu_input=False, flip_w=False, nseg=0, out=None, fold_hu=False):
+                hu_input=False, flip_w=False, nseg=0, out=None, fold_hu=True):
     """Cone-beam DRR of `vol` (Ds,W,H) = rows [d0,d1) of a (D,W,H) volume → (P,Rd,Rh).
 
     Replaces calculate_projection (reference sdct_projection_utils.py:59-100).  `hu_input`: the volume is in HU;
-    it is converted once per voxel by `hu_to_mu` first (bit-identical to, and 1.4x faster than, converting on every
-    tap, which `fold_hu=True` still selects: no temporary volume).
+    calc_relative_atten_coef (:6-9) is folded into the projector's tap loads (the division by 1000 as a multiplication +
+    one exact correction step, lr_drr_forward_f32 with LR_DRR_HU_INPUT: same bits, no temporary volume, no extra pass);
+    `fold_hu=False` converts once per voxel with `hu_to_mu` first (A/B aid: 0.139-0.152 vs 0.133-0.139 ms per volume at C3).
     """
     vol = _dev(vol, "vol")
     if hu_input and not fold_hu:

@@ -214,3 +214,33 @@ def test_stride2_blocks_strided_batch_output_equals_dense(monkeypatch):
             ops.conv3d_k3_lrelu_bf16(xb, w, b, 2, in_layout=ops.LAYOUT_BF16_NDHWC_HPS, out_layout=lay, out=big[:, 1:1 + Do])
             assert torch.equal(big[:, 1:1 + Do], want) and bool((big[:, 0] == 3.0).all()) and bool((big[:, 1 + Do] == 3.0).all())
     monkeypatch.delenv("LIFTREG_CONV_ROWS_ALWAYS", raising=False)
+
+
+def test_hu_fold_in_fast_projector_equals_prologue_and_c_oracle():
+    """calc_relative_atten_coef folded into the fast projector's tap loads (division by 1000 = multiplication + one
+    exact correction step; out-of-volume taps removed through their axis weight) gives the bits of the one-pass prologue
+    (IEEE divide per voxel) and of the C oracle — on phantom-like HU, on values around the -1000 clamp, on huge / tiny /
+    signed-zero values, with the axis-1 flip, for a z-slab, and through the general kernel as well."""
+    from liftreg_amd import ops
+    from liftreg_amd.utils.sdct_projection_utils import scan_poses
+    from oracle import c_oracle as co
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    n, P = 48, 3
+    p32 = scan_poses(30, P, n).astype(np.float32)
+    sp = np.array((2.2, 2.2, 2.2), np.float32)
+    hu = torch.rand((n, n, n), generator=g, device=dev) * 2300 - 1150
+    hu.view(-1)[:8] = torch.tensor([-1000.0, -999.99994, -1000.0001, 0.0, -0.0, 1e-30, 3e38, -3e38], device=dev)
+    for flip in (False, True):
+        a = ops.drr_forward(hu, p32, (n + 8, n), sp, hu_input=True, flip_w=flip, fold_hu=False)
+        b = ops.drr_forward(hu, p32, (n + 8, n), sp, hu_input=True, flip_w=flip, fold_hu=True)
+        assert torch.equal(a, b), flip
+    want = co.drr_forward(hu.cpu().numpy(), p32, sp, (n, n), flags=1)
+    got = ops.drr_forward(hu, p32, (n, n), sp, hu_input=True, nseg=1)
+    assert np.array_equal(got.cpu().numpy(), want)
+    # a z-slab: partial DRRs of HU slabs (taps of the planes outside the slab are dropped through their weights)
+    d0, d1 = 10, 30
+    s1 = ops.drr_forward(hu[d0:d1].contiguous(), p32, (n, n), sp, d0=d0, d1=d1, full_D=n, hu_input=True, nseg=1)
+    s2 = ops.drr_forward(ops.hu_to_mu(hu[d0:d1].contiguous()), p32, (n, n), sp, d0=d0, d1=d1, full_D=n, nseg=1)
+    assert torch.equal(s1, s2)
