@@ -350,6 +350,12 @@ int lr_pca_bwd_coef_bf16basis_f32(const float* gdisp, const void* basis_bf16, fl
 int lr_conv3d_first_split_f32(const float* in0, const float* in_rest, const float* packed_w, const float* bias,
                               float* out, int B, int Cin, int Cout, int D, int W, int H, int out_layout,
                               float negative_slope, void* stream);
+/* ... for the sharded model (liftreg_amd/parallel.py): in0 is a z-slab VIEW of the whole, replicated moving volume (batch
+ * element b at in0 + b*in0_batch_stride) and the output a strided batch (lr_conv3d_k3_lrelu_obs_f32): no copy of the
+ * moving image, one launch for the whole batch.  Strides in elements, 0 = dense. */
+int lr_conv3d_first_split_obs_f32(const float* in0, int64_t in0_batch_stride, const float* in_rest, const float* packed_w,
+                                  const float* bias, float* out, int B, int Cin, int Cout, int D, int W, int H,
+                                  int out_layout, float negative_slope, int64_t out_batch_stride, void* stream);
 
 /* f1 ("backproject -> conv0: never write the P*V volume"): the same first block with the backprojection
  * computed INSIDE its staging.  Channel 0 = in0 (B,1,D,W,H), channels 1..P = the backprojection of proj (B,P,Pw,Ph)

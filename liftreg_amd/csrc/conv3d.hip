@@ -58,6 +58,8 @@ struct ConvDims {
   int nHq, nWq, nDq;
   long long out_bs;   // output elements between two batch elements (dense: Cout*Do*Wo*Ho; larger: `out` is a plane range of a
                       // bigger per-sample buffer, parallel.SlabShardedRegistration)
+  long long in0_bs;   // split input: elements between two batch elements of `in0` (dense: D*W*H; larger: in0 is a z-slab view
+                      // of the whole moving volume)
 };
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.0f ? v : v * slope; }
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(256, (SINGLE ? (WINO ? LR_C0_WINO_BLOCKS : 3) : 2))
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(org), (short)0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_c0 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(in0 ? in0 + (int64_t)b * V + wofs : org), (short)0, 0x7fffffff, 0x00020000);
+        const_cast<float*>(in0 ? in0 + (int64_t)b * d.in0_bs + wofs : org), (short)0, 0x7fffffff, 0x00020000);
     // ONE straight run of loads (no interior/edge branch: at a join the compiler can no longer count what is in
     // flight and drains the queue — prefetch included — at the next wait); the edge test costs ~8 ALU ops per slot
     const int xi = x0 + lf4 * 4;
@@ -998,7 +1000,7 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
                      float* out, int B, int Cin, int Cout, int D, int W, int H,
                      int stride, int in_layout, int out_layout,
                      float negative_slope, void* stream, const FusedBp* bpa = nullptr, unsigned char* mask_out = nullptr,
-                     int z_phase = 0, long long out_bs = 0) {
+                     int z_phase = 0, long long out_bs = 0, long long in0_bs = 0) {
   if (bpa) in = in0;   // no channel-1.. tensor exists: the staging never dereferences `in` for them
   if (!in || !packed_w || !out) return LR_ENULL;
   if (B < 1 || Cin < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
@@ -1017,6 +1019,8 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
   if (out_bs != 0 && out_bs < dense_bs) return LR_EINVAL;
   if (out_bs != 0 && out_bs != dense_bs && (bpa || mask_out)) return LR_EUNSUPPORTED;   // the fused / mask forms write dense outputs
   d.out_bs = out_bs ? out_bs : dense_bs;
+  if (in0_bs != 0 && in0_bs < (long long)D * W * H) return LR_EINVAL;
+  d.in0_bs = in0_bs ? in0_bs : (long long)D * W * H;
   hipStream_t st = lr_stream(stream);
   const int NT = Cout / 16;
   const dim3 block(256);
@@ -1087,7 +1091,7 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
     // backprojection (f1); for plain inputs it measured equal to the single-buffer kernel below (3.31-3.34 vs 3.29-3.30 ms
     // at C3, same bits), which therefore stays the default — LIFTREG_CONV0_PC=1 selects it (A/B aid).
     const bool pc_on = bpa || (getenv("LIFTREG_CONV0_PC") && atoi(getenv("LIFTREG_CONV0_PC")) != 0);
-    if (pc_on && d.out_bs == dense_bs && stride == 1 && NT == 1 && single && vec4 &&
+    if (pc_on && d.out_bs == dense_bs && d.in0_bs == (long long)D * W * H && stride == 1 && NT == 1 && single && vec4 &&
         (out_layout == LR_LAYOUT_NDHWC || out_layout == LR_LAYOUT_NDHWC_HPS)) {
       const int64_t V = (int64_t)D * W * H;
       int rc;
@@ -1209,6 +1213,18 @@ extern "C" int lr_conv3d_first_split_f32(const float* in0, const float* in_rest,
   if (!in0) return LR_ENULL;
   return conv_impl(in_rest, in0, packed_w, bias, out, B, Cin, Cout, D, W, H, 1, LR_LAYOUT_NCDHW, out_layout,
                    negative_slope, stream);
+}
+
+// lr_conv3d_first_split_f32 for the sharded model: in0 is a z-slab VIEW of the whole (replicated) moving volume — batch
+// element b starts at in0 + b*in0_batch_stride — and the output goes into a strided batch (see lr_conv3d_k3_lrelu_obs_f32).
+// No copy of the moving image, one launch for the whole batch.  Strides in elements, 0 = dense.
+extern "C" int lr_conv3d_first_split_obs_f32(const float* in0, int64_t in0_batch_stride, const float* in_rest, const float* packed_w,
+                                             const float* bias, float* out, int B, int Cin, int Cout, int D, int W, int H,
+                                             int out_layout, float negative_slope, int64_t out_batch_stride, void* stream) {
+  if (!in0) return LR_ENULL;
+  if (in0_batch_stride < 0 || out_batch_stride < 0) return LR_EINVAL;
+  return conv_impl(in_rest, in0, packed_w, bias, out, B, Cin, Cout, D, W, H, 1, LR_LAYOUT_NCDHW, out_layout,
+                   negative_slope, stream, nullptr, nullptr, 0, (long long)out_batch_stride, (long long)in0_batch_stride);
 }
 
 // f1: the encoder's first block with the backprojection computed inside its staging — the

@@ -331,17 +331,20 @@ def conv3d_k3_lrelu(x, weight, bias, stride, *, in_layout=LAYOUT_NCDHW, out_layo
 
 
 def conv3d_first_split_supported(x0, rest):
-    """True when `conv3d_first_split` can take these tensors (else: concatenate and call conv3d_k3_lrelu)."""
+    """True when `conv3d_first_split` can take these tensors (else: concatenate and call conv3d_k3_lrelu).  x0 may be a
+    z-slab view of a larger volume: dense per batch element, any batch stride."""
     return (x0.dim() == 5 and rest.dim() == 5 and x0.shape[1] == 1 and rest.shape[1] in (1, 2) and x0.shape[4] % 4 == 0 and
-            x0.shape[0] == rest.shape[0] and x0.shape[2:] == rest.shape[2:] and x0.is_contiguous() and rest.is_contiguous() and
-            x0.data_ptr() % 16 == 0 and rest.data_ptr() % 16 == 0)
+            x0.shape[0] == rest.shape[0] and x0.shape[2:] == rest.shape[2:] and x0[0].is_contiguous() and rest.is_contiguous() and
+            (x0.shape[0] == 1 or x0.stride(0) % 4 == 0) and x0.data_ptr() % 16 == 0 and rest.data_ptr() % 16 == 0)
 
 
 def conv3d_first_split(x0, rest, weight, bias, *, out_layout=LAYOUT_NCDHW, negative_slope=0.2, packed=None, out=None):
     """The encoder's first block on cat([x0, rest], dim=1) WITHOUT the concatenation: x0 (B,1,D,W,H) = the moving image,
     rest (B,P,D,W,H) = the backprojected views, P in {1,2}.  Same kernel and bits as conv3d_k3_lrelu on the
     concatenated tensor (reference …Backproj.py:95-98 + layers.py:365-369)."""
-    x0, rest = _dev(x0, "x0"), _dev(rest, "rest")
+    if not (isinstance(x0, torch.Tensor) and x0.is_cuda and x0.dtype == torch.float32):
+        raise _hip.LiftRegHipError("x0: must be a float32 GPU tensor (no CPU fallback)")
+    rest = _dev(rest, "rest")
     if not conv3d_first_split_supported(x0, rest):
         raise ValueError("conv3d_first_split: unsupported shapes (concatenate and use conv3d_k3_lrelu)")
     B, _, D, W, H = x0.shape
@@ -352,12 +355,19 @@ def conv3d_first_split(x0, rest, weight, bias, *, out_layout=LAYOUT_NCDHW, negat
         packed = conv3d_pack_weights(weight, LAYOUT_NCDHW)
     b = None if bias is None else _dev(bias.detach(), "bias")
     shape = (B, Cout, D, W, H) if out_layout == LAYOUT_NCDHW else (B, D, W, H, Cout)
-    y = _conv_out(out, shape, torch.float32, x0.device)
+    y = _conv_out(out, shape, torch.float32, x0.device, strided_batch=True)
+    obs = _batch_stride(y)
+    ibs = int(x0.stride(0)) if (B > 1 and not x0.is_contiguous()) else 0
     with _timed(f"conv3d_c{Cin}x{Cout}_s1_{D}", flops=2.0 * 27 * Cin * Cout * B * D * W * H,
                 bytes=4 * (x0.numel() + rest.numel()) + 4 * y.numel(), samples=B):
-        _hip.check(_hip.lib().lr_conv3d_first_split_f32(x0.data_ptr(), rest.data_ptr(), packed.data_ptr(), _ptr(b),
-                                                        y.data_ptr(), B, Cin, Cout, D, W, H, out_layout,
-                                                        float(negative_slope), _stream()), "lr_conv3d_first_split_f32")
+        if obs or ibs:
+            _hip.check(_hip.lib().lr_conv3d_first_split_obs_f32(x0.data_ptr(), ibs, rest.data_ptr(), packed.data_ptr(), _ptr(b),
+                                                                y.data_ptr(), B, Cin, Cout, D, W, H, out_layout,
+                                                                float(negative_slope), obs, _stream()), "lr_conv3d_first_split_obs_f32")
+        else:
+            _hip.check(_hip.lib().lr_conv3d_first_split_f32(x0.data_ptr(), rest.data_ptr(), packed.data_ptr(), _ptr(b),
+                                                            y.data_ptr(), B, Cin, Cout, D, W, H, out_layout,
+                                                            float(negative_slope), _stream()), "lr_conv3d_first_split_f32")
     return y
 
 

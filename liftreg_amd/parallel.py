@@ -324,8 +324,21 @@ class SlabShardedRegistration:
                                                packed=net._packed_weight(0, bf16=True), out=t["y0"][g0:g1, t["a0"]:t["a0"] + n_real])
                     tops.append(t["y0"][g0:g1, t["r"]:t["r"] + 1])
                     continue
+                mvs = moving[g0:g1, :, lo:hi]                      # a z-slab view of the replicated moving volume
+                blk = net.encoders[0]
+                if not bf16:
+                    tv = torch.empty((g1 - g0, P, n_real, W, H), dtype=torch.float32, device=moving.device)
+                    if ops.conv3d_first_split_supported(mvs, tv):
+                        # fp32, <= 2 views: the first block reads the moving slab in place (no copy, no concatenation) —
+                        # the same kernel, and bits, as the unsharded model's first block
+                        ops.backproject(proj[g0:g1].contiguous(), net._poses, (D, W, H), d0=lo, d1=hi, out=tv)
+                        ops.conv3d_first_split(mvs, tv, blk.conv.weight, blk.conv.bias, out_layout=layouts(0)[1], negative_slope=blk._slope,
+                                               packed=net._packed_weight(0), out=t["y0"][g0:g1, t["a0"]:t["a0"] + n_real])
+                        tops.append(t["y0"][g0:g1, t["r"]:t["r"] + 1])
+                        continue
+                    del tv
                 x = torch.empty((g1 - g0, P + 1, n_real, W, H), dtype=torch.float32, device=moving.device)
-                x[:, 0:1].copy_(moving[g0:g1, :, lo:hi])
+                x[:, 0:1].copy_(mvs)
                 ops.backproject(proj[g0:g1].contiguous(), net._poses, (D, W, H), d0=lo, d1=hi, out=x[:, 1:],
                                 out_batch_stride=(P + 1) * n_real * W * H)
                 conv(0, x, t["y0"][g0:g1, t["a0"]:t["a0"] + n_real])
