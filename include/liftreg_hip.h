@@ -433,6 +433,12 @@ int lr_backproject_encin_bf16(const float* proj, const float* moving, const floa
 int lr_conv3d_first_clin_bf16(const void* in, const void* packed_w, const float* bias, void* out, int B, int Cin, int Cout,
                               int D, int W, int H, int out_layout, float negative_slope, int64_t out_batch_stride,
                               void* stream);
+/* Training forward of the bf16 variant's first block (Cin <= 3): lr_conv3d_first_bf16 that ALSO writes mask_out
+ * (B,D,W,H,Cout/4) uint8 = LR_LAYOUT_SIGN4 of its bf16 output (bit r of byte q: stored channel 4q+r > 0).  lr_conv3d_dgrad_bf16
+ * and lr_conv3d_dgrad_f32 accept it as x_saved with x_layout = LR_LAYOUT_SIGN4: the LeakyReLU mask of
+ * src/liftreg/layers/layers.py:369 for the backward of the NEXT block at 4 bytes per voxel instead of 32. */
+int lr_conv3d_first_mask_bf16(const float* in, const void* packed_w, const float* bias, void* out, uint8_t* mask_out, int B,
+                              int Cin, int Cout, int D, int W, int H, int out_layout, float negative_slope, void* stream);
 /* ... into a strided batch (see lr_conv3d_k3_lrelu_obs_f32; stride in bf16 elements, 0 = dense). */
 int lr_conv3d_first_obs_bf16(const float* in, const void* packed_w, const float* bias, void* out, int B, int Cin, int Cout,
                              int D, int W, int H, int out_layout, float negative_slope, int64_t out_batch_stride,

@@ -78,6 +78,7 @@ SIGNATURES = {
     "lr_conv3d_first_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "lr_backproject_encin_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _p]),
     "lr_conv3d_first_clin_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i64, _p]),
+    "lr_conv3d_first_mask_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "lr_conv3d_first_obs_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i64, _p]),
     "lr_conv3d_dgrad_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _f, _p]),
     "lr_conv3d_wgrad_bf16g_f32": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

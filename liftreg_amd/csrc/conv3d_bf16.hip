@@ -359,7 +359,8 @@ __device__ __forceinline__ unsigned pack2_bf16(float a, float b) { return (unsig
 template <int NT, bool SINGLE, bool HPSOUT>
 __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv0_bf16_kernel(const float* __restrict__ in, const u32x4* __restrict__ wp,
                                                             const float* __restrict__ bias, void* __restrict__ out,
-                                                            ConvDimsH d, int out_layout, float slope, int vec4) {
+                                                            ConvDimsH d, int out_layout, float slope, int vec4,
+                                                            unsigned char* __restrict__ mask_out /* or null: LR_LAYOUT_SIGN4 */) {
   __shared__ __attribute__((aligned(16))) u16 brick[2 * WROWS * RB];
   const unsigned lb = lr_xcd_remap(blockIdx.x, gridDim.x);
   const int hq = lb % d.nHq, wq = (lb / d.nHq) % d.nWq, dq = (lb / d.nHq / d.nWq) % d.nDq;
@@ -414,7 +415,27 @@ __global__ __launch_bounds__(256, (SINGLE ? 3 : 2)) void conv0_bf16_kernel(const
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = lrelu(a[nt][q], slope);
       typedef unsigned u32x2nt __attribute__((ext_vector_type(2)));
-      __builtin_nontemporal_store((u32x2nt){pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])}, reinterpret_cast<u32x2nt*>(o + nt * 16));
+      const unsigned lo = pack2_bf16(v[0], v[1]), hi = pack2_bf16(v[2], v[3]);
+      __builtin_nontemporal_store((u32x2nt){lo, hi}, reinterpret_cast<u32x2nt*>(o + nt * 16));
+      if (mask_out) {
+        // training forward: the LeakyReLU sign mask of this lane's channel quad (LR_LAYOUT_SIGN4: one byte per (voxel,
+        // quad), bit r = "stored bf16 of channel 4q+r > 0") — the next block's data gradient reads 4 bytes per voxel
+        // instead of the 32-byte bf16 activation (7.2 GB -> 0.9 GB at C5)
+        const unsigned m = ((short)(lo & 0xffffu) > 0 ? 1u : 0u) | ((short)(lo >> 16) > 0 ? 2u : 0u) |
+                           ((short)(hi & 0xffffu) > 0 ? 4u : 0u) | ((short)(hi >> 16) > 0 ? 8u : 0u);
+        // the four quads of a voxel sit in the four 16-lane rows of the wave: gfx950's row / half swaps bring them into
+        // row 0, whose lanes store the voxel's four bytes as ONE dword (64 contiguous bytes per tile instead of 64 byte
+        // stores: the byte-store version cost this block's forward +0.5 ms at C5)
+        const auto s1 = __builtin_amdgcn_permlane32_swap(m, m, false, false);     // [1]: rows 0,1 <- rows 2,3 of m
+        const unsigned xa = s1[0], xb = s1[1];
+        const auto s2 = __builtin_amdgcn_permlane16_swap(xa, xa, false, false);   // [1]: row 0 <- row 1 of m
+        const auto s3 = __builtin_amdgcn_permlane16_swap(xb, xb, false, false);   // [1]: row 0 <- row 3 of m
+        const unsigned dw = (m & 0xffu) | (s2[1] & 0xffu) << 8 | (xb & 0xffu) << 16 | (s3[1] & 0xffu) << 24;
+        if (kq == 0 && NT == 1)
+          *reinterpret_cast<unsigned*>(mask_out + ((((int64_t)b * d.D + dz) * d.W + y0 + r) * d.H + x0 + t * 16 + col) * 4) = dw;
+        else if (NT != 1)
+          mask_out[((((int64_t)b * d.D + dz) * d.W + y0 + r) * d.H + x0 + t * 16 + col) * (d.Cout >> 2) + nt * 4 + kq] = (unsigned char)m;
+      }
     }
   };
   const int npass = (d.Cin + 2) / 3;
@@ -630,7 +651,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_dgrad_bf16_kernel(const u16* __
     for (int mt = 0; mt < 4; ++mt) {
       const int y = 2 * (yq0 + mt) + py;
       if (y >= d.W) continue;
-      const int64_t row = (((int64_t)b * d.D + z) * d.W + y) * d.H * d.Cx;
+      const int64_t rowv = (((int64_t)b * d.D + z) * d.W + y) * d.H, row = rowv * d.Cx;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -638,15 +659,24 @@ __global__ __launch_bounds__(256, 2) void conv3d_dgrad_bf16_kernel(const u16* __
           const int x = 2 * xq + px;
           if (x >= d.H) continue;
           const int c = nt * 16 + kq * 4;
-          // the producer's activation (bf16) at this voxel: rows [H][C] or [parity][H/2][C]
-          const int64_t xo = row + (int64_t)(d.xs_layout == LR_LAYOUT_BF16_NDHWC ? x : px * (d.H >> 1) + xq) * d.Cx + c;
-          const uint2 xs = *reinterpret_cast<const uint2*>(xsave + xo);
-          const short s0 = (short)(xs.x & 0xffffu), s1 = (short)(xs.x >> 16), s2 = (short)(xs.y & 0xffffu), s3 = (short)(xs.y >> 16);
           f32x4 v = accp[px][mt][nt];
-          v[0] = s0 > 0 ? v[0] : v[0] * d.slope;   // bf16 > 0  <=>  its bit pattern as int16 > 0
-          v[1] = s1 > 0 ? v[1] : v[1] * d.slope;
-          v[2] = s2 > 0 ? v[2] : v[2] * d.slope;
-          v[3] = s3 > 0 ? v[3] : v[3] * d.slope;
+          if (d.xs_layout == LR_LAYOUT_SIGN4) {
+            // the producer's sign mask (B,D,W,H,Cx/4) uint8, written by its forward: one byte for this lane's channel quad
+            const unsigned m = reinterpret_cast<const unsigned char*>(xsave)[(rowv + x) * (d.Cx >> 2) + (c >> 2)];
+            v[0] = (m & 1u) ? v[0] : v[0] * d.slope;
+            v[1] = (m & 2u) ? v[1] : v[1] * d.slope;
+            v[2] = (m & 4u) ? v[2] : v[2] * d.slope;
+            v[3] = (m & 8u) ? v[3] : v[3] * d.slope;
+          } else {
+            // the producer's activation (bf16) at this voxel: rows [H][C] or [parity][H/2][C]
+            const int64_t xo = row + (int64_t)(d.xs_layout == LR_LAYOUT_BF16_NDHWC ? x : px * (d.H >> 1) + xq) * d.Cx + c;
+            const uint2 xs = *reinterpret_cast<const uint2*>(xsave + xo);
+            const short s0 = (short)(xs.x & 0xffffu), s1 = (short)(xs.x >> 16), s2 = (short)(xs.y & 0xffffu), s3 = (short)(xs.y >> 16);
+            v[0] = s0 > 0 ? v[0] : v[0] * d.slope;   // bf16 > 0  <=>  its bit pattern as int16 > 0
+            v[1] = s1 > 0 ? v[1] : v[1] * d.slope;
+            v[2] = s2 > 0 ? v[2] : v[2] * d.slope;
+            v[3] = s3 > 0 ? v[3] : v[3] * d.slope;
+          }
           const unsigned lo = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
           const unsigned hi = (unsigned)to_bf16(v[2]) | ((unsigned)to_bf16(v[3]) << 16);
           *reinterpret_cast<uint2*>(gx + row + (int64_t)x * d.Cx + c) = make_uint2(lo, hi);
@@ -724,7 +754,7 @@ extern "C" int lr_conv3d_pack_weights_bf16_planar(const float* weight, void* pac
 // stride 1, bf16 channels-last output.
 static int first_bf16_impl(const float* in, const void* packed_w, const float* bias, void* out, int B, int Cin,
                            int Cout, int D, int W, int H, int out_layout, float negative_slope, long long out_bs,
-                           void* stream) {
+                           void* stream, unsigned char* mask_out = nullptr) {
   if (!in || !packed_w || !out) return LR_ENULL;
   if (B < 1 || Cin < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
   if (Cout != 16 && Cout != 32) return LR_EUNSUPPORTED;
@@ -745,7 +775,8 @@ static int first_bf16_impl(const float* in, const void* packed_w, const float* b
   const u32x4* wt = reinterpret_cast<const u32x4*>(packed_w);
   // many channels (C4): all of them staged once, channels-last in LDS (conv0_cl_bf16.hip); LIFTREG_CONV0_BF16_CL=1 sends the
   // 3-channel case there too (A/B aid), LIFTREG_CONV0_BF16_PASSES=1 keeps everything on the channel-pass kernel
-  if ((Cin > 3 || getenv("LIFTREG_CONV0_BF16_CL")) && !getenv("LIFTREG_CONV0_BF16_PASSES")) {
+  if (mask_out && Cin > 3) return LR_EUNSUPPORTED;   // the mask comes out of the single-pass kernel's per-tile store
+  if (!mask_out && (Cin > 3 || getenv("LIFTREG_CONV0_BF16_CL")) && !getenv("LIFTREG_CONV0_BF16_PASSES")) {
     const int e = lr_internal_conv0_cl_bf16(in, wt + (size_t)((Cin + 2) / 3) * 4 * (Cout / 16) * 64, bias, out, B, Cin, Cout, D, W, H,
                                             out_layout, negative_slope, d.out_bs, 0, st);
     if (e != LR_EUNSUPPORTED) return e;
@@ -753,9 +784,9 @@ static int first_bf16_impl(const float* in, const void* packed_w, const float* b
 #define LR_C0(NTV, SG)                                                                                                   \
   do {                                                                                                                    \
     if (out_layout == LR_LAYOUT_BF16_NDHWC_HPS)                                                                           \
-      hipLaunchKernelGGL((conv0_bf16_kernel<NTV, SG, true>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope, vec4);  \
+      hipLaunchKernelGGL((conv0_bf16_kernel<NTV, SG, true>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope, vec4, mask_out);  \
     else                                                                                                                  \
-      hipLaunchKernelGGL((conv0_bf16_kernel<NTV, SG, false>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope, vec4); \
+      hipLaunchKernelGGL((conv0_bf16_kernel<NTV, SG, false>), grid, block, 0, st, in, wt, bias, out, d, out_layout, negative_slope, vec4, mask_out); \
   } while (0)
   if (Cout == 16) { if (Cin <= 3) LR_C0(1, true); else LR_C0(1, false); }
   else            { if (Cin <= 3) LR_C0(2, true); else LR_C0(2, false); }
@@ -769,10 +800,11 @@ extern "C" int lr_conv3d_dgrad_bf16(const void* gpre, const void* packed_wT, voi
   if (!gpre || !packed_wT || !gx || !x_saved) return LR_ENULL;
   if (Cg != 32 || (Cx != 16 && Cx != 32)) return LR_EUNSUPPORTED;
   if (B < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
-  if (x_layout != LR_LAYOUT_BF16_NDHWC && x_layout != LR_LAYOUT_BF16_NDHWC_HPS) return LR_EINVAL;
+  if (x_layout != LR_LAYOUT_BF16_NDHWC && x_layout != LR_LAYOUT_BF16_NDHWC_HPS && x_layout != LR_LAYOUT_SIGN4) return LR_EINVAL;
   if (x_layout == LR_LAYOUT_BF16_NDHWC_HPS && (H & 1)) return LR_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(gpre) | reinterpret_cast<uintptr_t>(packed_wT)) & 15u) return LR_EALIGN;
-  if ((reinterpret_cast<uintptr_t>(gx) | reinterpret_cast<uintptr_t>(x_saved)) & 7u) return LR_EALIGN;
+  if (reinterpret_cast<uintptr_t>(gx) & 7u) return LR_EALIGN;
+  if (x_layout != LR_LAYOUT_SIGN4 && (reinterpret_cast<uintptr_t>(x_saved) & 7u)) return LR_EALIGN;
   DgDimsH d;
   d.B = B; d.Cx = Cx; d.D = D; d.W = W; d.H = H;
   d.Do = (D - 1) / 2 + 1; d.Wo = (W - 1) / 2 + 1; d.Ho = (H - 1) / 2 + 1;
@@ -882,6 +914,16 @@ extern "C" int lr_conv3d_first_bf16(const float* in, const void* packed_w, const
                                     int Cout, int D, int W, int H, int out_layout, float negative_slope,
                                     void* stream) {
   return first_bf16_impl(in, packed_w, bias, out, B, Cin, Cout, D, W, H, out_layout, negative_slope, 0, stream);
+}
+
+// Training forward of the bf16 variant's first block: lr_conv3d_first_bf16 (Cin <= 3) that ALSO writes mask_out
+// (B,D,W,H,Cout/4) uint8 (LR_LAYOUT_SIGN4): bit r of byte q = "stored bf16 of output channel 4q+r > 0" — what
+// lr_conv3d_dgrad_bf16 / lr_conv3d_dgrad_f32 take as x_saved with x_layout = LR_LAYOUT_SIGN4 instead of the activation.
+extern "C" int lr_conv3d_first_mask_bf16(const float* in, const void* packed_w, const float* bias, void* out, uint8_t* mask_out,
+                                         int B, int Cin, int Cout, int D, int W, int H, int out_layout, float negative_slope,
+                                         void* stream) {
+  if (!mask_out) return LR_ENULL;
+  return first_bf16_impl(in, packed_w, bias, out, B, Cin, Cout, D, W, H, out_layout, negative_slope, 0, stream, mask_out);
 }
 
 // lr_conv3d_first_bf16 writing into a strided batch (see lr_conv3d_k3_lrelu_obs_f32; stride in bf16 elements).

@@ -464,9 +464,11 @@ def conv3d_pack_weights_bf16_planar(weight):
     return packed
 
 
-def conv3d_first_bf16(x, weight, bias, *, out_layout, negative_slope=0.2, packed=None, out=None):
+def conv3d_first_bf16(x, weight, bias, *, out_layout, negative_slope=0.2, packed=None, out=None, mask_out=None):
     """The encoder's first block in the bf16 variant: x float32 (B,Cin,D,W,H), stride 1, output bfloat16
-    (B,D,W,H,Cout) in LAYOUT_BF16_NDHWC[_HPS].  Inputs are rounded to bf16 on the way into the MFMA."""
+    (B,D,W,H,Cout) in LAYOUT_BF16_NDHWC[_HPS].  Inputs are rounded to bf16 on the way into the MFMA.
+    mask_out (training, Cin <= 3): a (B,D,W,H,Cout/4) uint8 tensor that receives the LeakyReLU sign mask of the stored
+    output (LAYOUT_SIGN4) for the next block's data gradient."""
     x = _dev(x, "x")
     B, Cin, D, W, H = x.shape
     Cout = weight.shape[0]
@@ -479,7 +481,14 @@ def conv3d_first_bf16(x, weight, bias, *, out_layout, negative_slope=0.2, packed
     obs = _batch_stride(y)
     with _timed(f"conv3d_bf16_c{Cin}x{Cout}_s1_{D}", flops=2.0 * 27 * Cin * Cout * B * D * W * H,
                 bytes=4 * x.numel() + 2 * y.numel(), samples=B, peak_tf=MFMA_BF16_PEAK_TF, bound="hbm"):
-        if obs:
+        if mask_out is not None:
+            if obs or not mask_out.is_cuda or mask_out.dtype != torch.uint8 or tuple(mask_out.shape) != (B, D, W, H, Cout // 4) or \
+                    not mask_out.is_contiguous():
+                raise ValueError(f"mask_out must be a contiguous uint8 GPU tensor of shape {(B, D, W, H, Cout // 4)} (dense output only)")
+            _hip.check(_hip.lib().lr_conv3d_first_mask_bf16(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), mask_out.data_ptr(),
+                                                            B, Cin, Cout, D, W, H, out_layout, float(negative_slope), _stream()),
+                       "lr_conv3d_first_mask_bf16")
+        elif obs:
             _hip.check(_hip.lib().lr_conv3d_first_obs_bf16(x.data_ptr(), packed.data_ptr(), _ptr(b), y.data_ptr(), B, Cin, Cout,
                                                            D, W, H, out_layout, float(negative_slope), obs, _stream()),
                        "lr_conv3d_first_obs_bf16")

@@ -217,11 +217,12 @@ def conv3d_dgrad_wgrad0(gpre1, w1, mask0, slope0, x0):
     return gw0, gb0
 
 
-def conv3d_bwd_bf16g(x, x_layout, weight, gpre, stride, mask_input_slope=None, nblk=1024):
+def conv3d_bwd_bf16g(x, x_layout, weight, gpre, stride, mask_input_slope=None, nblk=1024, x_sign4=None):
     """conv3d_bwd of the bf16-GRADIENT training variant: `gpre` (B,Do,Wo,Ho,Cout) is a bfloat16 plain channels-last
     pre-activation gradient; x the block's saved input (bf16 LAYOUT_BF16_NDHWC[_HPS], or the first block's fp32 input
     with LAYOUT_NCDHW_RBF16).  Returns (the PRODUCER's pre-activation gradient as bf16 plain channels-last — its
-    LeakyReLU mask applied with `mask_input_slope` — or None, gw fp32, gb fp32)."""
+    LeakyReLU mask applied with `mask_input_slope` — or None, gw fp32, gb fp32).  `x_sign4`: the producer's
+    (B,D,W,H,Cin/4) uint8 sign mask (ops.conv3d_first_bf16(mask_out=…)): the data gradient reads it instead of x for the mask."""
     bf_layouts = (_hip.LAYOUT_BF16_NDHWC, _hip.LAYOUT_BF16_NDHWC_HPS)
     x = _dev(x, "x", torch.bfloat16 if x_layout in bf_layouts else torch.float32)
     gpre = _dev(gpre, "gpre", torch.bfloat16)
@@ -239,10 +240,15 @@ def conv3d_bwd_bf16g(x, x_layout, weight, gpre, stride, mask_input_slope=None, n
         from .ops import conv3d_pack_weights_bf16
         packed_t = conv3d_pack_weights_bf16(w.transpose(0, 1).contiguous())     # rounds like the forward's pack
         gx = torch.empty((B, D, W, H, Cin), dtype=torch.bfloat16, device=dev)
+        if x_sign4 is not None and (x_sign4.dtype != torch.uint8 or tuple(x_sign4.shape) != (B, D, W, H, Cin // 4) or
+                                    not x_sign4.is_cuda or not x_sign4.is_contiguous()):
+            raise ValueError(f"x_sign4 must be a contiguous uint8 GPU tensor of shape {(B, D, W, H, Cin // 4)}")
         with _timed(f"conv3d_dgrad_bf16_c{Cout}x{Cin}_{D}", flops=2.0 * 27 * Cin * Cout * gpre.numel() / Cout,
-                    bytes=2 * (gpre.numel() + 2 * gx.numel())):
+                    bytes=2 * (gpre.numel() + gx.numel()) + (x_sign4.numel() if x_sign4 is not None else 2 * gx.numel())):
             _hip.check(lib.lr_conv3d_dgrad_bf16(gpre.data_ptr(), packed_t.data_ptr(), gx.data_ptr(), B, Cout, Cin, D, W, H,
-                                                x.data_ptr(), x_layout, float(mask_input_slope), _stream()),
+                                                x_sign4.data_ptr() if x_sign4 is not None else x.data_ptr(),
+                                                _hip.LAYOUT_SIGN4 if x_sign4 is not None else x_layout,
+                                                float(mask_input_slope), _stream()),
                        "lr_conv3d_dgrad_bf16")
     npart = lib.lr_conv3d_wgrad_partial_floats(Cin, Cout, x_layout, nblk)
     partial = torch.empty((npart,), dtype=torch.float32, device=dev)

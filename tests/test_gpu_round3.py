@@ -244,3 +244,53 @@ def test_hu_fold_in_fast_projector_equals_prologue_and_c_oracle():
     s1 = ops.drr_forward(hu[d0:d1].contiguous(), p32, (n, n), sp, d0=d0, d1=d1, full_D=n, hu_input=True, nseg=1)
     s2 = ops.drr_forward(ops.hu_to_mu(hu[d0:d1].contiguous()), p32, (n, n), sp, d0=d0, d1=d1, full_D=n, nseg=1)
     assert torch.equal(s1, s2)
+
+
+@pytest.mark.parametrize("grad_dtype", ["fp32", "bf16"])
+def test_bf16_training_sign_mask_of_first_block_gives_the_same_gradients(grad_dtype, monkeypatch):
+    """bf16-forward training: the first block's forward also writes the LeakyReLU sign mask of its stored bf16 output
+    (lr_conv3d_first_mask_bf16, LR_LAYOUT_SIGN4) and block 1's data gradient reads that byte per channel quad instead of the
+    32-byte activation: every parameter gradient keeps its bits (the mask is the same predicate, bf16 bits > 0), for fp32 and
+    bf16 gradient storage; the mask equals the sign of the stored output."""
+    from liftreg_amd import ops
+    from liftreg_amd.losses.SubspaceLoss import loss as SubspaceLoss
+    from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+    dev = torch.device("cuda:0")
+    n, P, L, B = 64, 2, 8, 2
+    inp = _inputs(n, P, B, dev, 17)
+
+    def grads(no_sign4):
+        if no_sign4:
+            monkeypatch.setenv("LIFTREG_BF16_NO_SIGN4", "1")
+        else:
+            monkeypatch.delenv("LIFTREG_BF16_NO_SIGN4", raising=False)
+        torch.manual_seed(17)
+        net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:4", "conv_dtype": "bf16",
+                                "grad_dtype": grad_dtype}).to(dev).train()
+        crit = SubspaceLoss({"initial_reg_factor": 0.01, "min_reg_factor": 0.01, "reg_factor_decay_from": 2})
+        crit.sim.check_nan = False
+        with ops.kernel_timer() as kt:
+            out = net(inp)
+            out["epoch"] = 0
+            crit(out)["total_loss"].backward()
+            names = set(kt.summary())
+        return {k: p.grad.detach().clone() for k, p in net.named_parameters()}, names
+
+    g_old, _ = grads(True)
+    g_new, _ = grads(False)
+    for k in g_old:
+        assert torch.equal(g_old[k], g_new[k]), k
+    # the mask itself
+    g = torch.Generator(device=dev)
+    g.manual_seed(2)
+    x = torch.rand((B, 3, 12, 10, 64), generator=g, device=dev) * 2 - 1
+    w = torch.randn((16, 3, 3, 3, 3), generator=g, device=dev) * 0.2
+    b = torch.randn((16,), generator=g, device=dev) * 0.1
+    for lay in (ops.LAYOUT_BF16_NDHWC, ops.LAYOUT_BF16_NDHWC_HPS):
+        m = torch.zeros((B, 12, 10, 64, 4), dtype=torch.uint8, device=dev)
+        y = ops.conv3d_first_bf16(x, w, b, out_layout=lay, mask_out=m)
+        assert torch.equal(y, ops.conv3d_first_bf16(x, w, b, out_layout=lay))
+        yp = ops.bf16_hps_to_ndhwc(y) if lay == ops.LAYOUT_BF16_NDHWC_HPS else y
+        pos = (yp.float() > 0).reshape(B, 12, 10, 64, 4, 4).to(torch.uint8)
+        want = pos[..., 0] | (pos[..., 1] << 1) | (pos[..., 2] << 2) | (pos[..., 3] << 3)
+        assert torch.equal(m, want)
