@@ -457,7 +457,9 @@ int lr_internal_conv0_cl_bf16(const float* in, const void* packed, const float* 
   d.nunits = (int)nu; d.slope = slope;
   d.out_bs = out_bs ? out_bs : (long long)16 * D * W * H;
   d.abl = 0;
+#ifdef LR_C0CL_ABLATIONS   // diagnostic build only (make -B EXTRA=-DLR_C0CL_ABLATIONS, tools/abl_c0cl.py): the switches give WRONG results
   if (const char* e = getenv("LIFTREG_C0CL_ABL")) d.abl = atoi(e);
+#endif
   if (blocks > d.nunits) blocks = d.nunits;
   if (blocks < 1) blocks = 1;
   const int CQ = (Cin + 3) / 4;

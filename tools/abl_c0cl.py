@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Timing-only ablations of the many-channel first block (conv0_cl_bf16.hip) at the C4 shape, interleaved in one process."""
+"""Timing-only ablations of the many-channel first block (conv0_cl_bf16.hip) at the C4 shape, interleaved in one process.
+The LIFTREG_C0CL_ABL switches (skip loads / stores / sweep / LDS writes: wrong results) exist only in a diagnostic build:
+    make -C liftreg_amd/csrc -B -j8 EXTRA=-DLR_C0CL_ABLATIONS
+(the shape / chunk / channel-pass comparisons work with the product build)."""
 import os, sys, json
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
