@@ -219,10 +219,16 @@ def main():
                                                            "fuse_backproject; measured slower at C3, off by default)")
     ap.add_argument("--fuse-ncc", action="store_true", help="A/B aid: the similarity's moments in the decode's epilogue (opt key "
                                                             "fuse_ncc; measured 0.04 ms slower at C3, off by default)")
+    ap.add_argument("--conv0-split", action="store_true",
+                    help="A/B aid (fp32 lines): the first encoder block through csrc/conv0_split_f32.hip — its fp32 operands as "
+                         "exact three-way bf16 splits on the bf16 matrix pipe, 6 of the 9 partial products, fp32 accumulation "
+                         "(LIFTREG_CONV0_SPLIT=1); not the default, the line says so in dtype and config")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from one captured HIP graph (launch-bound small configs c1/c2); the "
                          "per-kernel table then comes from one extra eager step outside the timed region")
     args = ap.parse_args()
+    if args.conv0_split:
+        os.environ["LIFTREG_CONV0_SPLIT"] = "1"   # read by the launcher at every call
     cfg = dict(CONFIGS[args.config])
     if args.shard == "slab" and args.config in SLAB_GLOBAL_BATCH:
         cfg["B"] = SLAB_GLOBAL_BATCH[args.config]
@@ -481,15 +487,17 @@ def main():
         "ramp_seconds": args.ramp_seconds, "ramp_steps": ramp_steps,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if slab else "weak",
         "vs_baseline": None,
-        "dtype": "f32" if (args.conv_dtype, args.pca_dtype) == ("fp32", "fp32") else
-                 f"conv blocks {args.conv_dtype}, PCA basis storage {args.pca_dtype}, f32 elsewhere",
+        "dtype": ("f32" if (args.conv_dtype, args.pca_dtype) == ("fp32", "fp32") else
+                  f"conv blocks {args.conv_dtype}, PCA basis storage {args.pca_dtype}, f32 elsewhere") +
+                 ("; first block: fp32 operands as exact 3-way bf16 splits on the bf16 MFMA (6 of 9 partial products), f32 accumulation"
+                  if args.conv0_split and args.conv_dtype == "fp32" else ""),
         "data": "synthetic",
         "config": {"workload": f"{args.config}: {n}^3 CT, {P}x{cfg['R']}^2 DRR, batch {B}/GPU, latent {L}, "
                                "backproject+conv6(MFMA f32)+FC3+PCA+warp+NCC", "global_batch": B if slab else world * B,
                    "parallelism": (f"z-slab x{world}: ONE batch of {B} registrations sharded along D (rows {d0}:{d1} on rank 0); "
                                    "halo planes p2p, encoder features all-gather, NCC moments all-reduce over RCCL" if slab else
                                    f"replicas x{world} (independent registrations, no data-path collective)"),
-                   "streams": args.streams, "hip_graph": bool(args.graph),
+                   "streams": args.streams, "hip_graph": bool(args.graph), "conv0_split": bool(args.conv0_split),
                    "untimed_before_warmup": f"{ramp_steps} steps ({args.ramp_seconds:g} s clock ramp), then {args.warmup} warm-up steps"},
         "roofline": roof(dominant),
         "roofline_backproject": roof("backproject"),

@@ -962,7 +962,8 @@ extern "C" int64_t lr_conv3d_packed_floats(int Cin, int Cout, int in_layout) {
   if (Cin < 1 || (Cout != 16 && Cout != 32)) return LR_EUNSUPPORTED;
   const int NT = Cout / 16;
   if (in_layout == LR_LAYOUT_NDHWC || in_layout == LR_LAYOUT_NDHWC_HPS) return (int64_t)36 * ((Cin + 15) / 16) * NT * 64 * 4;
-  if (in_layout == LR_LAYOUT_NCDHW) return (int64_t)Cin * 7 * NT * 64 + ((Cin <= 3 && NT == 1) ? 4 * 7 * 64 : 0);
+  if (in_layout == LR_LAYOUT_NCDHW)
+    return (int64_t)Cin * 7 * NT * 64 + ((Cin <= 3 && NT == 1) ? 4 * 7 * 64 : 0) + (NT == 1 ? lr_internal_conv0_split_packed_floats(Cin, Cout) : 0);
   return LR_EINVAL;
 }
 
@@ -984,6 +985,10 @@ extern "C" int lr_conv3d_pack_weights_f32(const float* weight, float* packed, in
                        lr_stream(stream), weight, packed, Cin, Cout, NT);
     if (Cin <= 3 && NT == 1)
       hipLaunchKernelGGL(pack_planar_wino_kernel, dim3(7), dim3(256), 0, lr_stream(stream), weight, packed + total, Cin, Cout);
+    if (NT == 1 && lr_internal_conv0_split_packed_floats(Cin, Cout) > 0) {   // the split operands of conv0_split_f32.hip, behind both
+      const int rc = lr_internal_conv0_split_pack(weight, packed + total + (Cin <= 3 ? 4 * 7 * 64 : 0), Cin, Cout, lr_stream(stream));
+      if (rc != LR_OK) return rc;
+    }
   } else {
     return LR_EINVAL;
   }
@@ -1075,6 +1080,19 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
     const bool single = npass == 1;
     if (in0 && (!vec4 || !single || stride != 1 || Cin < 2 || (reinterpret_cast<uintptr_t>(in0) & 15u)))
       return LR_EUNSUPPORTED;  // split input: one 3-channel pass with 16-byte staging (the caller concatenates otherwise)
+    // LIFTREG_CONV0_SPLIT=1: conv0_split_f32.hip — the same block on the bf16 MFMA with exact three-way bf16 splits of its
+    // fp32 operands (a direct conv, half the rounding error of the Winograd sweep).  Measured equal to the fp32-MFMA
+    // Winograd kernel below at C3 (2.9-3.1 vs 3.0 ms: DESIGN.md §6·6), so it is NOT the default.
+    if (!bpa && !mask_out && stride == 1 && NT == 1 && Cin <= 4 && getenv("LIFTREG_CONV0_SPLIT") && atoi(getenv("LIFTREG_CONV0_SPLIT")) != 0 &&
+        (out_layout == LR_LAYOUT_NDHWC || out_layout == LR_LAYOUT_NDHWC_HPS)) {
+      const int64_t V = (int64_t)D * W * H;
+      const float* ps = packed_w + (int64_t)Cin * 7 * 64 + (Cin <= 3 ? 4 * 7 * 64 : 0);
+      const int rc = in0 ? lr_internal_conv0_split_f32(in0, d.in0_bs, in, (long long)(Cin - 1) * V, ps, bias, out, B, Cin, D, W, H, out_layout,
+                                                       negative_slope, d.out_bs, st)
+                         : lr_internal_conv0_split_f32(in, (long long)Cin * V, in + V, (long long)Cin * V, ps, bias, out, B, Cin, D, W, H,
+                                                       out_layout, negative_slope, d.out_bs, st);
+      if (rc != LR_EUNSUPPORTED) return rc;
+    }
     int64_t resident = 256 * (single ? 3 : 2);  // persistent blocks per CU (registers: <=168 | <=256 per lane)
     if (single && !getenv("LIFTREG_CONV0_DIRECT") && Cin <= 3 && stride == 1 && NT == 1 && (out_layout == LR_LAYOUT_NDHWC || out_layout == LR_LAYOUT_NDHWC_HPS))
       resident = 256 * LR_C0_WINO_BLOCKS;  // the Winograd instance (<=128 registers)

@@ -93,3 +93,11 @@ int64_t lr_internal_conv0_cl_bf16_packed_bytes(int Cin, int Cout);
 int lr_internal_conv0_cl_bf16_pack(const float* weight, void* packed, int Cin, int Cout, hipStream_t st);
 int lr_internal_conv0_cl_bf16(const float* in, const void* packed, const float* bias, void* out, int B, int Cin, int Cout, int D,
                               int W, int H, int out_layout, float slope, long long out_bs, int clin, hipStream_t st);
+
+// conv0_split_f32.hip: the first block (Cin <= 4, fp32 in / fp32 channels-last out) on the bf16 MFMA with exact three-way
+// operand splits (6 of the 9 partial products).  LR_EUNSUPPORTED -> conv3d.hip's fp32-MFMA kernels.
+int64_t lr_internal_conv0_split_packed_floats(int Cin, int Cout);
+int lr_internal_conv0_split_pack(const float* weight, float* packed, int Cin, int Cout, hipStream_t st);
+int lr_internal_conv0_split_f32(const float* in0, long long bs0, const float* in_rest, long long bsr, const float* packed,
+                                const float* bias, float* out, int B, int Cin, int D, int W, int H, int out_layout, float slope,
+                                long long out_bs, hipStream_t st);

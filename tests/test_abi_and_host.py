@@ -36,8 +36,9 @@ def test_library_exports_every_declared_symbol(hip):
 def test_argument_validation_without_gpu(hip):
     lib = hip.lib()
     assert lib.lr_backproject_f32(None, None, None, 1, 1, 4, 4, 4, 4, 4, 0, 4, 64, None) == -2
-    # first block: direct fragments (3·7·64) followed by the Winograd U fragments (4 r × 7 q × 64 lanes)
-    assert lib.lr_conv3d_packed_floats(3, 16, 0) == 3 * 7 * 64 + 4 * 7 * 64
+    # first block: direct fragments (3·7·64), the Winograd U fragments (4 r × 7 q × 64 lanes), then the three-way bf16 splits of
+    # conv0_split_f32.hip (4 k-blocks × 3 splits × 64 lanes × 16 bytes)
+    assert lib.lr_conv3d_packed_floats(3, 16, 0) == 3 * 7 * 64 + 4 * 7 * 64 + 4 * 3 * 64 * 4
     # channels-last: 27 taps + the 9 Winograd sums w(ty=0)+w(ty=2) per (tz,tx), each (CB x NT) fragments of 64 float4
     assert lib.lr_conv3d_packed_floats(16, 32, 1) == (27 + 9) * 1 * 2 * 64 * 4
     assert lib.lr_conv3d_packed_floats(3, 8, 0) == -3
