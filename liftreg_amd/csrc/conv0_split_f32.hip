@@ -64,16 +64,21 @@ constexpr int NTHR = BY / 2 * 64;        // a wave = two output rows of four 16-
 constexpr int NQ = 18;                   // aligned float4 quads of a window row: x0-4 .. x0+67
 constexpr int NREC = 4 * NQ;             // voxel records of a row: p = x - x0 + 4
 constexpr int SB = NREC * 8;             // bytes of one split of a row
-constexpr int RB = 3 * SB;               // a window row: [split 0][split 1][split 2]
-constexpr int PLB = WR * RB;             // a ring plane
 constexpr int NRING = 4;
 constexpr int ZPAD = 4096;               // zeros behind the ring for the lanes without a tap (largest immediate: RB + 2 SB + 3*128)
-constexpr int LDSB = NRING * PLB + ZPAD;
 constexpr int NITEMS = WR * NQ;          // staging items of a plane: one x-quad of a row, all channels
 constexpr int NKB = 4;
 constexpr unsigned OOR = 0x80000000u;
 static_assert(NITEMS <= NTHR, "one staging item per thread");
-static_assert(RB + 2 * SB + 3 * 128 + 8 <= ZPAD, "zero area covers every immediate");
+// NS = arrays per window row: 3 (the fp32 kernel: one per split) or 1 (the bf16-contract kernel: operands rounded once)
+template <int NS>
+struct SGeo {
+  static constexpr int RB = NS * SB;               // a window row: [split 0][split 1][split 2]
+  static constexpr int PLB = WR * RB;              // a ring plane (NS = 3 and 1: 128 mod 256 bytes — neighbouring planes
+                                                   // fall into opposite bank halves for the 32-lane ds_read_b64 groups)
+  static constexpr int LDSB = NRING * PLB + ZPAD;
+  static_assert(RB + 2 * SB + 3 * 128 + 8 <= ZPAD, "zero area covers every immediate");
+};
 
 // products (data split s, weight split t) in issue order: small ones first, the (0,0) product last
 constexpr int NPROD = LR_C0S_PRODUCTS;
@@ -137,11 +142,20 @@ __device__ __forceinline__ void unit_range(int bid, int nblk, int nunits, int& f
 #else
 #define LR_C0S_NO_DS_MERGE
 #endif
-template <int NC, bool HPSOUT>
-__global__ __launch_bounds__(NTHR, 2) LR_C0S_NO_DS_MERGE void conv0_split_f32_kernel(const float* __restrict__ in0, const float* __restrict__ in_rest,
+// NS = 3, BF16OUT = false: the fp32 kernel described above.  NS = 1, BF16OUT = true: the SAME march under the bf16 storage
+// contract of conv3d_bf16.hip (inputs and weights rounded once to bf16, exact products, fp32 accumulation, fp32 bias +
+// LeakyReLU, bf16 channels-last store): one array per window row, one product, 4 MFMAs per tile — the 3-channel first block
+// of the bf16 variant, bound by the 32 bytes per voxel it writes.
+// MASK (bf16 training forward): also the LeakyReLU sign mask of the STORED output, LR_LAYOUT_SIGN4 (B,D,W,H,4) uint8 — bit r
+// of byte q = "stored bf16 of channel 4q+r > 0" — which the next block's data gradient reads instead of the activation.
+template <int NC, bool HPSOUT, int NS = 3, bool BF16OUT = false, bool MASK = false>
+__global__ __launch_bounds__(NTHR, (NS == 1 && NC <= 3 ? 4 : 2)) LR_C0S_NO_DS_MERGE void conv0_split_f32_kernel(const float* __restrict__ in0, const float* __restrict__ in_rest,
                                                                  const u32x4* __restrict__ wp, const float* __restrict__ bias,
-                                                                 float* __restrict__ out, S0Dims d) {
+                                                                 void* __restrict__ out, S0Dims d, unsigned char* __restrict__ mask_out) {
+  static_assert(!MASK || BF16OUT, "the sign mask belongs to the bf16 training forward");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int RB = SGeo<NS>::RB, PLB = SGeo<NS>::PLB, LDSB = SGeo<NS>::LDSB;
+  constexpr int NP = NS == 1 ? 1 : NPROD;
   const int tid = threadIdx.x, lane = tid & 63;
   const int rh = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave = pair of output rows
   const int col = lane & 15, kq = lane >> 4;
@@ -162,11 +176,11 @@ __global__ __launch_bounds__(NTHR, 2) LR_C0S_NO_DS_MERGE void conv0_split_f32_ke
   const unsigned l_mul = item_live ? (unsigned)PLB : 0u;
 
   // weights: [k-block][split] fragments, 48 registers for the life of the block
-  u32x4 w[NKB][3];
+  u32x4 w[NKB][NS];
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-    for (int t = 0; t < 3; ++t) w[kb][t] = wp[(kb * 3 + t) * 64 + lane];
+    for (int t = 0; t < NS; ++t) w[kb][t] = wp[(kb * 3 + t) * 64 + lane];
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};
   if (bias) {
 #pragma unroll
@@ -242,8 +256,9 @@ __global__ __launch_bounds__(NTHR, 2) LR_C0S_NO_DS_MERGE void conv0_split_f32_ke
   };
   // wait until at most `younger` vector-memory operations issued after set SET's loads are outstanding
   auto wait_set = [&](auto setc, auto youngerc) __attribute__((always_inline)) {
-    constexpr int SET = decltype(setc)::value, N = decltype(youngerc)::value;
-    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    constexpr int SET = decltype(setc)::value, NY = decltype(youngerc)::value;
+    constexpr int N = NY > 63 ? 63 : NY;   // vmcnt is a 6-bit counter: waiting for fewer outstanding operations is always safe
+    static_assert(N >= 0, "younger operations");
     f32x4 (&L)[NC] = ld[SET];   // (named outside the asm statements: a generic lambda does not capture through an asm operand)
     if constexpr (NC == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(L[0]) : "n"(N));
     else if constexpr (NC == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(L[0]), "+v"(L[NC > 1 ? 1 : 0]) : "n"(N));
@@ -269,7 +284,7 @@ __global__ __launch_bounds__(NTHR, 2) LR_C0S_NO_DS_MERGE void conv0_split_f32_ke
     }
     unsigned char* const base = lds + ((unsigned)slot * l_mul + l_rec);
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < NS; ++s) {
       *reinterpret_cast<u32x4*>(base + s * SB) = (u32x4){rec[s][0][0], rec[s][0][1], rec[s][1][0], rec[s][1][1]};
       *reinterpret_cast<u32x4*>(base + s * SB + 16) = (u32x4){rec[s][2][0], rec[s][2][1], rec[s][3][0], rec[s][3][1]};
     }
@@ -300,32 +315,35 @@ __global__ __launch_bounds__(NTHR, 2) LR_C0S_NO_DS_MERGE void conv0_split_f32_ke
       const u32x2 b = *reinterpret_cast<const u32x2*>(lds + pa + off + dlt);
       return __builtin_bit_cast(bf16x8, (u32x4){a[0], a[1], b[0], b[1]});
     };
-    // one buffer resource per output plane: 31-bit offsets inside W*H*64 bytes
-    float* const pbase = out + (int64_t)u.b * d.out_bs + (int64_t)(live ? z0 : 0) * dW * dH * 16;
-    const __amdgpu_buffer_rsrc_t ores = make_rsrc(pbase, live ? (unsigned)(dW * dH * 64) : 0u);
+    // one buffer resource per output plane: 31-bit offsets inside W*H*16 output elements
+    constexpr int OSZ = BF16OUT ? 2 : 4;
+    unsigned char* const pbase = reinterpret_cast<unsigned char*>(out) + ((int64_t)u.b * d.out_bs + (int64_t)(live ? z0 : 0) * dW * dH * 16) * OSZ;
+    const __amdgpu_buffer_rsrc_t ores = make_rsrc(pbase, live ? (unsigned)(dW * dH * 16 * OSZ) : 0u);
+    const __amdgpu_buffer_rsrc_t mres = make_rsrc(MASK ? mask_out + ((int64_t)u.b * dD + (live ? z0 : 0)) * dW * dH * 4 : pbase,
+                                                  (MASK && live) ? (unsigned)(dW * dH * 4) : 0u);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       f32x4 hi[2] = {bv, bv}, lo[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-      bf16x8 F[4][3], G[2][3];
+      bf16x8 F[4][NS], G[2][NS];
 #pragma unroll
       for (int iy = 0; iy < 4; ++iy)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) F[iy][s] = frag(pF, iy * RB + s * SB + t * 128, 8);
+        for (int s = 0; s < NS; ++s) F[iy][s] = frag(pF, iy * RB + s * SB + t * 128, 8);
 #pragma unroll
       for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) G[r][s] = frag(r ? pG1 : pG, s * SB + t * 128, RB);
+        for (int s = 0; s < NS; ++s) G[r][s] = frag(r ? pG1 : pG, s * SB + t * 128, RB);
       // (fragment of row 0, its k-block) paired with (fragment of row 1, its k-block): the two rows alternate on the pipe
-      auto pair = [&](const bf16x8 (&f0)[3], int kb0, const bf16x8 (&f1)[3], int kb1) __attribute__((always_inline)) {
+      auto pair = [&](const bf16x8 (&f0)[NS], int kb0, const bf16x8 (&f1)[NS], int kb1) __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p < NPROD; ++p) {
-          const int s = prod_s(p), tw = prod_t(p);
+        for (int p = 0; p < NP; ++p) {
+          const int s = NS == 1 ? 0 : prod_s(p), tw = NS == 1 ? 0 : prod_t(p);
           if (s == 0 && tw == 0) {
             hi[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[kb0][0]), f0[0], hi[0], 0, 0, 0);
             hi[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[kb1][0]), f1[0], hi[1], 0, 0, 0);
           } else {
-            lo[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[kb0][tw]), f0[s], lo[0], 0, 0, 0);
-            lo[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[kb1][tw]), f1[s], lo[1], 0, 0, 0);
+            lo[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[kb0][NS == 1 ? 0 : tw]), f0[NS == 1 ? 0 : s], lo[0], 0, 0, 0);
+            lo[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[kb1][NS == 1 ? 0 : tw]), f1[NS == 1 ? 0 : s], lo[1], 0, 0, 0);
           }
         }
       };
@@ -339,10 +357,29 @@ __global__ __launch_bounds__(NTHR, 2) LR_C0S_NO_DS_MERGE void conv0_split_f32_ke
       for (int r = 0; r < 2; ++r) {
         const int y = u.y0 + 2 * rh + r;
         const int ok = (int)(z0 < u.zc1) & (int)(y < dW) & (int)(x < dH);
-        const unsigned off = (unsigned)(((y * dH + hp) * 16 + kq * 4) * 4) | (((unsigned)ok - 1u) & OOR);
-        f32x4 v = hi[r] + lo[r];
+        const unsigned off = (unsigned)(((y * dH + hp) * 16 + kq * 4) * OSZ) | (((unsigned)ok - 1u) & OOR);
+        f32x4 v = NS == 1 ? hi[r] : hi[r] + lo[r];
         v = __builtin_elementwise_max(v, v * d.slope);   // = LeakyReLU for 0 <= slope <= 1 (checked by the launcher)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ores, off, 0, 2 /* nt */);
+        if constexpr (BF16OUT) {
+          const bf16x2 a = __builtin_convertvector((f32x2){v[0], v[1]}, bf16x2), b2 = __builtin_convertvector((f32x2){v[2], v[3]}, bf16x2);
+          const u32x2 pk = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b2)};
+          __builtin_amdgcn_raw_buffer_store_b64(pk, ores, off, 0, 2 /* nt */);
+          if constexpr (MASK) {
+            // this lane's channel quad -> one byte; the four quads of a voxel sit in the four 16-lane rows of the wave: the
+            // row / half swaps bring them into row 0, whose lanes store the voxel's four bytes as one dword
+            const unsigned m = ((short)(pk[0] & 0xffffu) > 0 ? 1u : 0u) | ((short)(pk[0] >> 16) > 0 ? 2u : 0u) |
+                               ((short)(pk[1] & 0xffffu) > 0 ? 4u : 0u) | ((short)(pk[1] >> 16) > 0 ? 8u : 0u);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(m, m, false, false);     // [1]: rows 0,1 <- rows 2,3 of m
+            const unsigned xa = s1[0], xb = s1[1];
+            const auto s2 = __builtin_amdgcn_permlane16_swap(xa, xa, false, false);   // [1]: row 0 <- row 1 of m
+            const auto s3 = __builtin_amdgcn_permlane16_swap(xb, xb, false, false);   // [1]: row 0 <- row 3 of m
+            const unsigned dw = (m & 0xffu) | (s2[1] & 0xffu) << 8 | (xb & 0xffu) << 16 | (s3[1] & 0xffu) << 24;
+            const unsigned moff = (unsigned)((y * dH + x) * 4) | (((unsigned)(ok & (int)(kq == 0)) - 1u) & OOR);
+            __builtin_amdgcn_raw_buffer_store_b32(dw, mres, moff, 0, 0);
+          }
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ores, off, 0, 2 /* nt */);
+        }
       }
 #if LR_C0S_TFENCE
       __builtin_amdgcn_sched_barrier(0);   // keep the next tile column's 30 fragment reads behind this one's MFMAs (registers)
@@ -391,7 +428,7 @@ __global__ __launch_bounds__(NTHR, 2) LR_C0S_NO_DS_MERGE void conv0_split_f32_ke
   // (DEPTH-1) planes of loads and the stores of the sweeps since — DEPTH of them in the steady state, fewer in the first trip.
   auto iteration = [&](auto setw, auto nsweeps) __attribute__((always_inline)) -> bool {
     constexpr int SETW = decltype(setw)::value;
-    constexpr int YOUNGER = (DEPTH - 1) * NC + 8 * decltype(nsweeps)::value;
+    constexpr int YOUNGER = (DEPTH - 1) * NC + (MASK ? 16 : 8) * decltype(nsweeps)::value;   // (MASK: 8 more stores per sweep)
     const Pos nxt = advance(cur);
     // plane g (g >= 2) completes the window of output plane zc0 + g - 2, whose first input plane sits two slots back
     sweep(cur.u, cur.u.zc0 + cur.g - 2, (wpos + 2) & 3, cur.g >= 2);
@@ -474,24 +511,26 @@ int lr_internal_conv0_split_pack(const float* weight, float* packed, int Cin, in
 }
 
 // Channel 0 of batch element b at in0 + b*bs0, channels 1..Cin-1 at in_rest + b*bsr + (c-1)*D*W*H (elements).
-// LR_EUNSUPPORTED -> the caller runs conv3d.hip's fp32-MFMA kernels.  The rule looks at the plane (W, H) only, so a z-slab
-// of a volume takes the same kernel as the whole volume.
-int lr_internal_conv0_split_f32(const float* in0, long long bs0, const float* in_rest, long long bsr, const float* packed,
-                                const float* bias, float* out, int B, int Cin, int D, int W, int H, int out_layout, float slope,
-                                long long out_bs, hipStream_t st) {
+// LR_EUNSUPPORTED -> the caller runs its other kernels.  The rule looks at the plane (W, H) only, so a z-slab of a volume
+// takes the same kernel as the whole volume.
+template <int NS, bool BF16OUT, bool MASK = false>
+static int launch_march(const float* in0, long long bs0, const float* in_rest, long long bsr, const void* packed, const float* bias,
+                        void* out, int B, int Cin, int D, int W, int H, bool hps, float slope, long long out_bs, hipStream_t st,
+                        unsigned char* mask_out = nullptr) {
+  if (MASK && (Cin > 3 || (int64_t)W * H * 4 >= 0x7fffffffLL)) return LR_EUNSUPPORTED;
   if (Cin < 1 || Cin > 4 || (H & 3) || (reinterpret_cast<uintptr_t>(in0) & 15u) || (Cin > 1 && (reinterpret_cast<uintptr_t>(in_rest) & 15u)) ||
       (bs0 & 3) || (bsr & 3))
     return LR_EUNSUPPORTED;
-  if (out_layout != LR_LAYOUT_NDHWC && out_layout != LR_LAYOUT_NDHWC_HPS) return LR_EUNSUPPORTED;
-  if (out_layout == LR_LAYOUT_NDHWC_HPS && (H & 1)) return LR_EUNSUPPORTED;
+  if (hps && (H & 1)) return LR_EUNSUPPORTED;
   if (!(slope >= 0.0f && slope <= 1.0f)) return LR_EUNSUPPORTED;   // the epilogue computes LeakyReLU as max(v, slope * v)
-  if ((int64_t)W * H < 128 * 128) return LR_EUNSUPPORTED;   // small planes: too few columns for 256 persistent blocks
+  if ((int64_t)W * H < 128 * 128) return LR_EUNSUPPORTED;   // small planes: too few columns for the persistent blocks
   const int64_t V = (int64_t)D * W * H;
   if ((int64_t)3 * V * 4 + (int64_t)8 * W * H * 4 >= 0x7fffffffLL) return LR_EUNSUPPORTED;   // 31-bit byte offsets inside a batch element's channels
   if ((int64_t)W * H * 64 >= 0x7fffffffLL) return LR_EUNSUPPORTED;
+  constexpr int LDSB = SGeo<NS>::LDSB;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  int blocks = cus * (LDSB <= 80 * 1024 ? 2 : 1);   // blocks a CU holds (LDS)
+  int blocks = cus * (NS == 1 && Cin <= 3 ? 4 : (LDSB <= 80 * 1024 ? 2 : 1));   // blocks a CU holds (LDS, registers)
   if (const char* e = getenv("LIFTREG_CONV0_SPLIT_BLOCKS")) blocks = atoi(e);   // tuning aid
   S0Dims d;
   d.B = B; d.Cin = Cin; d.D = D; d.W = W; d.H = H;
@@ -516,19 +555,41 @@ int lr_internal_conv0_split_f32(const float* in0, long long bs0, const float* in
 #endif
   if (blocks > d.nunits) blocks = d.nunits;
   if (blocks < 1) blocks = 1;
-  const bool hps = out_layout == LR_LAYOUT_NDHWC_HPS;
   const u32x4* wt = reinterpret_cast<const u32x4*>(packed);
   if (!in_rest) in_rest = in0;   // Cin == 1: never dereferenced (zero-length resource)
 #define LR_C0S(NCV, HP)                                                                                                     \
   do {                                                                                                                      \
     static std::atomic<uint64_t> attr_done{0};                                                                              \
-    if (lr_raise_dyn_lds(reinterpret_cast<const void*>(&conv0_split_f32_kernel<NCV, HP>), LDSB, attr_done) != LR_OK) return LR_ELAUNCH; \
-    hipLaunchKernelGGL((conv0_split_f32_kernel<NCV, HP>), dim3((unsigned)blocks), dim3(NTHR), LDSB, st, in0, in_rest, wt, bias, out, d); \
+    if (lr_raise_dyn_lds(reinterpret_cast<const void*>(&conv0_split_f32_kernel<NCV, HP, NS, BF16OUT, MASK>), LDSB, attr_done) != LR_OK) return LR_ELAUNCH; \
+    hipLaunchKernelGGL((conv0_split_f32_kernel<NCV, HP, NS, BF16OUT, MASK>), dim3((unsigned)blocks), dim3(NTHR), LDSB, st, in0, in_rest, wt, bias, out, d, mask_out); \
   } while (0)
   if (Cin == 1) { if (hps) LR_C0S(1, true); else LR_C0S(1, false); }
   else if (Cin == 2) { if (hps) LR_C0S(2, true); else LR_C0S(2, false); }
   else if (Cin == 3) { if (hps) LR_C0S(3, true); else LR_C0S(3, false); }
-  else { if (hps) LR_C0S(4, true); else LR_C0S(4, false); }
+  else if constexpr (!MASK) { if (hps) LR_C0S(4, true); else LR_C0S(4, false); }
 #undef LR_C0S
   return lr_launch_status();
+}
+
+int lr_internal_conv0_split_f32(const float* in0, long long bs0, const float* in_rest, long long bsr, const float* packed,
+                                const float* bias, float* out, int B, int Cin, int D, int W, int H, int out_layout, float slope,
+                                long long out_bs, hipStream_t st) {
+  if (out_layout != LR_LAYOUT_NDHWC && out_layout != LR_LAYOUT_NDHWC_HPS) return LR_EUNSUPPORTED;
+  return launch_march<3, false>(in0, bs0, in_rest, bsr, packed, bias, out, B, Cin, D, W, H, out_layout == LR_LAYOUT_NDHWC_HPS, slope, out_bs, st);
+}
+
+// The 3-channel (Cin <= 4) first block of the bf16 variant: `in` is (B,Cin,D,W,H) fp32, `out` bf16 channels-last records;
+// `packed` = the buffer of lr_internal_conv0_split_pack (its first split IS the nearest-even bf16 weight).
+// mask_out != NULL (training forward, Cin <= 3, dense output): also the LR_LAYOUT_SIGN4 sign mask of the stored output.
+int lr_internal_conv0_march_bf16(const float* in, const void* packed, const float* bias, void* out, int B, int Cin, int D, int W,
+                                 int H, int out_layout, float slope, long long out_bs, unsigned char* mask_out, hipStream_t st) {
+  if (out_layout != LR_LAYOUT_BF16_NDHWC && out_layout != LR_LAYOUT_BF16_NDHWC_HPS) return LR_EUNSUPPORTED;
+  const int64_t V = (int64_t)D * W * H;
+  const bool hps = out_layout == LR_LAYOUT_BF16_NDHWC_HPS;
+  if (mask_out) {
+    if (out_bs != 0 && out_bs != 16 * V) return LR_EUNSUPPORTED;
+    return launch_march<1, true, true>(in, (long long)Cin * V, in + V, (long long)Cin * V, packed, bias, out, B, Cin, D, W, H, hps, slope,
+                                       out_bs, st, mask_out);
+  }
+  return launch_march<1, true>(in, (long long)Cin * V, in + V, (long long)Cin * V, packed, bias, out, B, Cin, D, W, H, hps, slope, out_bs, st);
 }

@@ -735,7 +735,9 @@ extern "C" int lr_conv3d_pack_weights_bf16(const float* weight, void* packed, in
 extern "C" int64_t lr_conv3d_packed_bf16_planar_bytes(int Cin, int Cout) {
   if (Cin < 1 || (Cout != 16 && Cout != 32)) return LR_EUNSUPPORTED;
   // [channel-pass packing | packing of the all-channels kernel (conv0_cl_bf16.hip), present for 4 < Cin <= 16]
-  return (int64_t)((Cin + 2) / 3) * 4 * (Cout / 16) * 64 * 16 + lr_internal_conv0_cl_bf16_packed_bytes(Cin, Cout);
+  // ... | packing of the z-marching 3-channel kernel (conv0_split_f32.hip, NS = 1), present for Cin <= 4]
+  return (int64_t)((Cin + 2) / 3) * 4 * (Cout / 16) * 64 * 16 + lr_internal_conv0_cl_bf16_packed_bytes(Cin, Cout) +
+         lr_internal_conv0_split_packed_floats(Cin, Cout) * 4;
 }
 
 extern "C" int lr_conv3d_pack_weights_bf16_planar(const float* weight, void* packed, int Cin, int Cout, void* stream) {
@@ -747,7 +749,9 @@ extern "C" int lr_conv3d_pack_weights_bf16_planar(const float* weight, void* pac
   hipLaunchKernelGGL(pack_bf16_planar_kernel, dim3((total + 255) / 256), dim3(256), 0, st, weight,
                      reinterpret_cast<u32x4*>(packed), Cin, Cout, Cout / 16);
   if (int e = lr_launch_status()) return e;
-  return lr_internal_conv0_cl_bf16_pack(weight, reinterpret_cast<unsigned char*>(packed) + (size_t)total * 16, Cin, Cout, st);
+  if (int e = lr_internal_conv0_cl_bf16_pack(weight, reinterpret_cast<unsigned char*>(packed) + (size_t)total * 16, Cin, Cout, st)) return e;
+  return lr_internal_conv0_split_pack(weight, reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(packed) + (size_t)total * 16 +
+                                                                       lr_internal_conv0_cl_bf16_packed_bytes(Cin, Cout)), Cin, Cout, st);
 }
 
 // The encoder's first block in the bf16 variant: fp32 NCDHW input (rounded to bf16 on the way into the MFMA),
@@ -776,6 +780,14 @@ static int first_bf16_impl(const float* in, const void* packed_w, const float* b
   // many channels (C4): all of them staged once, channels-last in LDS (conv0_cl_bf16.hip); LIFTREG_CONV0_BF16_CL=1 sends the
   // 3-channel case there too (A/B aid), LIFTREG_CONV0_BF16_PASSES=1 keeps everything on the channel-pass kernel
   if (mask_out && Cin > 3) return LR_EUNSUPPORTED;   // the mask comes out of the single-pass kernel's per-tile store
+  // few channels (C3 / C5: 3): the z-marching kernel of conv0_split_f32.hip under the bf16 contract — every input
+  // plane fetched once, 4 MFMAs per tile; LIFTREG_CONV0_BF16_PASSES=1 keeps the channel-pass kernel (A/B aid, tests)
+  if (Cin <= (mask_out ? 3 : 4) && Cout == 16 && !getenv("LIFTREG_CONV0_BF16_CL") && !getenv("LIFTREG_CONV0_BF16_PASSES")) {
+    const unsigned char* pm = reinterpret_cast<const unsigned char*>(packed_w) + (size_t)((Cin + 2) / 3) * 4 * (Cout / 16) * 64 * 16 +
+                              lr_internal_conv0_cl_bf16_packed_bytes(Cin, Cout);
+    const int e = lr_internal_conv0_march_bf16(in, pm, bias, out, B, Cin, D, W, H, out_layout, negative_slope, d.out_bs, mask_out, st);
+    if (e != LR_EUNSUPPORTED) return e;
+  }
   if (!mask_out && (Cin > 3 || getenv("LIFTREG_CONV0_BF16_CL")) && !getenv("LIFTREG_CONV0_BF16_PASSES")) {
     const int e = lr_internal_conv0_cl_bf16(in, wt + (size_t)((Cin + 2) / 3) * 4 * (Cout / 16) * 64, bias, out, B, Cin, Cout, D, W, H,
                                             out_layout, negative_slope, d.out_bs, 0, st);

@@ -101,3 +101,7 @@ int lr_internal_conv0_split_pack(const float* weight, float* packed, int Cin, in
 int lr_internal_conv0_split_f32(const float* in0, long long bs0, const float* in_rest, long long bsr, const float* packed,
                                 const float* bias, float* out, int B, int Cin, int D, int W, int H, int out_layout, float slope,
                                 long long out_bs, hipStream_t st);
+// the same march under the bf16 storage contract (one rounding of the operands, bf16 channels-last output): the 3-channel
+// first block of the bf16 variant; `packed` as written by lr_internal_conv0_split_pack
+int lr_internal_conv0_march_bf16(const float* in, const void* packed, const float* bias, void* out, int B, int Cin, int D, int W,
+                                 int H, int out_layout, float slope, long long out_bs, unsigned char* mask_out, hipStream_t st);
