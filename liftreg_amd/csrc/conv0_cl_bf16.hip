@@ -113,7 +113,8 @@ __global__ __launch_bounds__(512, 2) void conv0_cl_bf16_kernel(const float* __re
   constexpr int PLB = WR * RB;                      // bytes per ring plane
   constexpr int NRING = 2 * SZ + 2;
   constexpr int NPRE = (2 + SZ - 1) / SZ;           // groups of a unit before its first step (the two planes above it)
-  constexpr int LDSB = NRING * PLB + SLOT;
+  constexpr int LDSB = NRING * PLB + SLOT;          // (+ 64 bytes behind it: where threads without a staging item write, see write_group)
+  constexpr int DUMP = LDSB;
   constexpr int NCHK = 132;                         // CLIN: 16-byte chunks of a window row (66 records)
   constexpr int NITEMS = CLIN ? SZ * WR * NCHK : CQ * SZ * WR * NQ;   // planar: one item = 4 channels x one x-quad of a row
   constexpr int NIT = (NITEMS + 511) / 512;
@@ -219,7 +220,9 @@ __global__ __launch_bounds__(512, 2) void conv0_cl_bf16_kernel(const float* __re
         const int ok = (int)valid & (int)((pk >> 15) & 1u) & (int)(j >= jmin) & (int)(zi >= 0) & (int)(zi < dD) & (int)(yi >= 0) & (int)(yi < dW) &
                        (int)(xi >= 0) & (int)(xi < dH);
         unsigned voff = ((unsigned)org + g_rel[it]) | (((unsigned)ok - 1u) & OOR);
+#ifdef LR_C0CL_ABLATIONS
         if (d.abl & 1) voff = OOR;
+#endif
         ld[SET][it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
         continue;
       }
@@ -233,7 +236,9 @@ __global__ __launch_bounds__(512, 2) void conv0_cl_bf16_kernel(const float* __re
       for (int k = 0; k < 4; ++k) {
         const unsigned live = (unsigned)(ok & (int)(c0 + k < d.Cin));            // 1 | 0
         unsigned voff = (off + (unsigned)k * V4) | ((live - 1u) & OOR);           // dead element: bit 31 -> outside the resource -> 0
+#ifdef LR_C0CL_ABLATIONS
         if (d.abl & 1) voff = OOR;
+#endif
         ld[SET][it][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
       }
     }
@@ -241,30 +246,40 @@ __global__ __launch_bounds__(512, 2) void conv0_cl_bf16_kernel(const float* __re
   auto write_group = [&](int wposv, auto setc) __attribute__((always_inline)) {   // wpos = ring slot of the group's plane 0
     constexpr int SET = decltype(setc)::value;
     const int wpos = __builtin_amdgcn_readfirstlane(wposv);
+#ifdef LR_C0CL_ABLATIONS
     if (d.abl & 8) return;
+#endif
+    // No branch around the writes: a path that skips the waits for the loads makes every later wait in the loop conservative
+    // (vmcnt(0) with the sweep's stores in flight = every step waits for its own stores).  A thread without an item in its
+    // last slot loaded zeros and writes them into the dump area behind the ring.
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      if ((it + 1) * 512 <= NITEMS || it * 512 + tid < NITEMS) {
-        int sl = wpos + (int)(it_pk[it] & 7u);
-        sl -= sl >= NRING ? NRING : 0;
-        if constexpr (CLIN) {
-          *reinterpret_cast<f32x4*>(lds + (unsigned)sl * PLB + l_rec[it]) = ld[SET][it][0];
-          continue;
-        }
-        const unsigned xo = (it_pk[it] >> 2) & 64u;   // q odd (bit 8 of the pack): the quad's voxel pairs are swapped (64 bytes = two records)
-        const unsigned base = (unsigned)sl * PLB + l_rec[it];
-        const unsigned la = base + xo, lb2 = base + (64u - xo);
+      const bool has_item = (it + 1) * 512 <= NITEMS || it * 512 + tid < NITEMS;
+      int sl = wpos + (int)(it_pk[it] & 7u);
+      sl -= sl >= NRING ? NRING : 0;
+      if constexpr (CLIN) {
+        *reinterpret_cast<f32x4*>(lds + (has_item ? (unsigned)sl * PLB + l_rec[it] : (unsigned)DUMP)) = ld[SET][it][0];
+        continue;
+      }
+      const unsigned xo = (it_pk[it] >> 2) & 64u;   // q odd (bit 8 of the pack): the quad's voxel pairs are swapped (64 bytes = two records)
+      const unsigned base = (unsigned)sl * PLB + l_rec[it];
+      const unsigned la = base + xo, lb2 = base + (64u - xo);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const u32x2 rec = {pack2(ld[SET][it][0][j], ld[SET][it][1][j]), pack2(ld[SET][it][2][j], ld[SET][it][3][j])};
-          *reinterpret_cast<u32x2*>(lds + (j < 2 ? la : lb2) + (unsigned)(j & 1) * SLOT) = rec;
-        }
+      for (int j = 0; j < 4; ++j) {
+        const u32x2 rec = {pack2(ld[SET][it][0][j], ld[SET][it][1][j]), pack2(ld[SET][it][2][j], ld[SET][it][3][j])};
+        *reinterpret_cast<u32x2*>(lds + (has_item ? (j < 2 ? la : lb2) + (unsigned)(j & 1) * SLOT : (unsigned)DUMP)) = rec;
       }
     }
   };
   // the step whose output planes are z0 .. z0+SZ-1; rpos = ring slot of input plane z0 - 1
-  auto sweep = [&](const Unit& uv, int z0v, int rposv) __attribute__((always_inline)) {
+  // (livev false: the window is not complete yet — the first NPRE groups of a chunk; the sweep still runs on whatever the ring
+  // holds and its stores are dropped: a branch around it leaves two different store counts behind the next loads)
+  auto sweep = [&](const Unit& uv, int z0v, int rposv, bool livev) __attribute__((always_inline)) {
+    int live = __builtin_amdgcn_readfirstlane((int)livev);
+#ifdef LR_C0CL_ABLATIONS
     if (d.abl & 4) return;
+    if (d.abl & 2) live = 0;
+#endif
     const Unit u = uniform(uv);
     const int z0 = __builtin_amdgcn_readfirstlane(z0v), rpos = __builtin_amdgcn_readfirstlane(rposv);
     const int dz = z0 + zw;
@@ -273,7 +288,14 @@ __global__ __launch_bounds__(512, 2) void conv0_cl_bf16_kernel(const float* __re
     s2 -= s2 >= NRING ? NRING : 0;
     // this lane's voxel of tile (r, t): row y0 + 2 rh + r, x = x0 + 16 t + col; channels kq*4 .. kq*4+3
     const int hp_lane = HPSOUT ? (col & 1) * (dH >> 1) + (u.x0 >> 1) + (col >> 1) : u.x0 + col;
-    u16* const out_lane = out + (int64_t)u.b * d.out_bs + (((int64_t)dz * dW + (u.y0 + 2 * rh)) * dH + hp_lane) * 16 + kq * 4;
+    // one buffer resource per output plane of this wave (bounds-checked stores, no branch): W*H*32 bytes
+    const bool zok = live && dz < u.zc1;
+    const uint64_t oa = reinterpret_cast<uint64_t>(out + (int64_t)u.b * d.out_bs + (int64_t)(zok ? dz : 0) * dW * dH * 16);
+    const uint64_t os = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(oa >> 32)) << 32) |
+                        (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)oa);
+    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<u16*>(os), (short)0,
+                                                                          __builtin_amdgcn_readfirstlane(zok ? dW * dH * 32 : 0), 0x00020000);
+    const unsigned off_lane = (unsigned)((((u.y0 + 2 * rh) * dH + hp_lane) * 16 + kq * 4) * 2);
     const unsigned char* const pl0 = lds + (unsigned)s0 * PLB;
     const unsigned char* const pl2 = lds + (unsigned)s2 * PLB;
     const unsigned char* const cls[6] = {pl0 + offA[0], pl0 + offA[1], pl0 + offA[2], pl2 + offB, pl2 + offC, pl2 + offD};
@@ -308,11 +330,10 @@ __global__ __launch_bounds__(512, 2) void conv0_cl_bf16_kernel(const float* __re
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           const f32x4 a = r ? acc1 : acc0;
-          if (dz < u.zc1 && u.y0 + 2 * rh + r < dW && u.x0 + t * 16 + col < dH && !((d.abl & 2) && a[0] != 12345.f)) {
-            u16* o = out_lane + (int64_t)r * dH * 16 + t * (HPSOUT ? 8 : 16) * 16;
-            const u32x2 v = {pack2(lrelu(a[0], d.slope), lrelu(a[1], d.slope)), pack2(lrelu(a[2], d.slope), lrelu(a[3], d.slope))};
-            __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(o));
-          }
+          const int ok = (int)(u.y0 + 2 * rh + r < dW) & (int)(u.x0 + t * 16 + col < dH);
+          const unsigned off = (off_lane + (unsigned)((r * dH * 16 + t * (HPSOUT ? 8 : 16) * 16) * 2)) | (((unsigned)ok - 1u) & OOR);
+          const u32x2 v = {pack2(lrelu(a[0], d.slope), lrelu(a[1], d.slope)), pack2(lrelu(a[2], d.slope), lrelu(a[3], d.slope))};
+          __builtin_amdgcn_raw_buffer_store_b64(v, ores, off, 0, 2 /* nt */);
         }
         acc0 = bv; acc1 = bv;
       }
@@ -364,7 +385,7 @@ __global__ __launch_bounds__(512, 2) void conv0_cl_bf16_kernel(const float* __re
     // plane z0 - 1 sits two ring slots before this group's plane 0
     int rpos = wpos - 2;
     rpos += rpos < 0 ? NRING : 0;
-    if (cur.g >= NPRE) sweep(cur.u, cur.u.zc0 + SZ * (cur.g - NPRE), rpos);
+    sweep(cur.u, cur.u.zc0 + SZ * (cur.g - NPRE), rpos, cur.g >= NPRE);
     __builtin_amdgcn_sched_barrier(0);
     int wnext = wpos + SZ;
     wnext -= wnext >= NRING ? NRING : 0;
@@ -466,7 +487,7 @@ int lr_internal_conv0_cl_bf16(const float* in, const void* packed, const float* 
   const bool hps = out_layout == LR_LAYOUT_BF16_NDHWC_HPS;
   const u32x4* wt = reinterpret_cast<const u32x4*>(packed);
   u16* o = reinterpret_cast<u16*>(out);
-  const size_t ldsb = (size_t)(2 * SZv + 2) * (BYv + 2) * RB + SLOT;
+  const size_t ldsb = (size_t)(2 * SZv + 2) * (BYv + 2) * RB + SLOT + 64;   // + the dump area
 #define LR_C0CL3(CQV, HP, SZV, BYV)                                                                                        \
   do {                                                                                                                     \
     static std::atomic<uint64_t> attr_done{0};                                                                             \
