@@ -211,7 +211,14 @@ __global__ __launch_bounds__(256, (SINGLE ? (WINO ? LR_C0_WINO_BLOCKS : 3) : 2))
   constexpr int vec4 = 1, dbg = 0;
   (void)vec4_rt; (void)dbg_rt;
 #else
-  const int vec4 = vec4_rt, dbg = dbg_rt;
+  // The Winograd instances are only launched with 16-byte staging, and their timing-only ablation switches exist in a
+  // diagnostic build only (-DLR_CONV0_DBG): both as compile-time constants, no branch on a kernel argument sits between
+  // the prefetch of the next brick and the wait for it (at such a join hipcc waits for vmcnt(0) = for the sweep's stores).
+#ifdef LR_CONV0_DBG
+  const int vec4 = WINO ? 1 : vec4_rt, dbg = dbg_rt;
+#else
+  const int vec4 = WINO ? 1 : vec4_rt, dbg = WINO ? 0 : dbg_rt;
+#endif
 #endif
   // in0 != null ("split input", one pass, 16-byte staging only): channel 0 is read from in0 (B,1,D,W,H) and channels
   // 1.. from `in` (B,Cin-1,D,W,H) — the encoder's cat([moving, backprojected views]) without the copy of `moving`.
@@ -318,10 +325,13 @@ __global__ __launch_bounds__(256, (SINGLE ? (WINO ? LR_C0_WINO_BLOCKS : 3) : 2))
   // brick of unit u -> LDS (from the prefetched registers, or scalar loads when !vec4)
   auto stage = [&](int u) {
     if (vec4) {
+      // no branch around the writes (a lane or slot without a row loaded zeros and writes them into the dump area behind
+      // the brick): every path carries the same waits for the prefetch, so they can leave the sweep's stores in flight
 #pragma unroll
-      for (int it = 0; it < G::MAXIT; ++it)
-        if (slot_used(it) && lact)
-          *reinterpret_cast<float4*>(brick + slot_cc(it) * G::CS + slot_rz(it) * G::PS + slot_ry(it) * G::RSL + lane_dst) = st[it];
+      for (int it = 0; it < G::MAXIT; ++it) {
+        const int dst = (slot_used(it) && lact) ? slot_cc(it) * G::CS + slot_rz(it) * G::PS + slot_ry(it) * G::RSL + lane_dst : CC * G::CS;
+        *reinterpret_cast<float4*>(brick + dst) = st[it];
+      }
     } else {  // H % 4 != 0 or unaligned base: scalar staging of the same window, no prefetch
       int b, dq, wq, hq, pass;
       item_coords(unit_item(u), b, dq, wq, hq, pass);
@@ -1098,8 +1108,8 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
       resident = 256 * LR_C0_WINO_BLOCKS;  // the Winograd instance (<=128 registers)
     if (const char* e = getenv("LIFTREG_CONV0_BLOCKS")) resident = atoi(e);  // tuning aid
     const dim3 grid((unsigned)(nitems < resident ? nitems : resident));
-    const size_t lds1 = (size_t)3 * PlanarGeom<1, 3>::CS * sizeof(float);
-    const size_t lds2 = (size_t)1 * PlanarGeom<2, 1>::CS * sizeof(float);
+    const size_t lds1 = (size_t)3 * PlanarGeom<1, 3>::CS * sizeof(float) + 16;   // + the staging dump area (stage())
+    const size_t lds2 = (size_t)1 * PlanarGeom<2, 1>::CS * sizeof(float) + 16;
     const int ni = (int)nitems;
     const int dbg = getenv("LIFTREG_CONV0_DBG") ? atoi(getenv("LIFTREG_CONV0_DBG")) : 0;  // timing ablations only
 #define LR_PL(NTV, SV, CCV, SGL, LDSV, V4)                                                                   \
