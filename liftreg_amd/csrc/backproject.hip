@@ -483,11 +483,28 @@ __global__ __launch_bounds__(BE_THREADS) void backproject_encin_bf16_kernel(
     }
     poff[t] = off;
   }
+  // The thread's TJH x BE_TI moving-image voxels of an element travel with the element's detector rows — requested one
+  // element ahead, ready at the commit.  Loaded inside the sample loop (one dword per voxel, consumed at once) every sample
+  // waited for vmcnt(0): a full memory latency per voxel, and with it for the look-ahead and the stores in flight.
+  float mv[TJH][BE_TI], mvn[TJH][BE_TI];
+  const int kc = min(k, H - 1);
+  auto fetch_moving = [&](int b, float (&dst)[TJH][BE_TI]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int jj = 0; jj < TJH; ++jj) {
+      const int jc = min(j_base + jh * TJH + jj, W - 1);
+#pragma unroll
+      for (int ii = 0; ii < BE_TI; ++ii) {
+        const int ic = min(i_base + ii, Ds - 1);   // clamped, not branched: samples outside the slab are never stored
+        dst[jj][ii] = moving[(int64_t)b * V + ((int64_t)(d0 + ic) * W + jc) * H + kc];
+      }
+    }
+  };
   auto fetch = [&](int b) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(proj + (int64_t)b * NV * view_sz), (short)0,
                                                                         (int)(NV * view_sz * 4), 0x00020000);
 #pragma unroll
     for (int t = 0; t < BE_NPF; ++t) pre[t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[t], 0, 0));
+    fetch_moving(b, mvn);
   };
   auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -507,10 +524,15 @@ __global__ __launch_bounds__(BE_THREADS) void backproject_encin_bf16_kernel(
       reinterpret_cast<float4*>(tile)[idx] = val;
     }
   };
-  if constexpr (BE_PREFETCH) { fetch(0); commit(); } else { stage_direct(0); }
+  if constexpr (BE_PREFETCH) { fetch(0); commit(); } else { stage_direct(0); fetch_moving(0, mvn); }
   __syncthreads();
   for (int b = 0; b < B; ++b) {
+#pragma unroll
+    for (int jj = 0; jj < TJH; ++jj)
+#pragma unroll
+      for (int ii = 0; ii < BE_TI; ++ii) mv[jj][ii] = mvn[jj][ii];
     if (BE_PREFETCH && b + 1 < B) fetch(b + 1);
+    else if (!BE_PREFETCH && b + 1 < B) fetch_moving(b + 1, mvn);
     if (k < H) {
 #pragma unroll
       for (int jj = 0; jj < TJH; ++jj) {
@@ -523,7 +545,10 @@ __global__ __launch_bounds__(BE_THREADS) void backproject_encin_bf16_kernel(
           unsigned rec[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) rec[q] = 0u;
-          rec[0] = bp_bf16(moving[(int64_t)b * V + ((int64_t)(d0 + i) * W + j) * H + k]);
+          float m = mv[jj][0];   // (the ii loop is not unrolled: select, do not index)
+#pragma unroll
+          for (int q = 1; q < BE_TI; ++q) m = ii == q ? mv[jj][q] : m;
+          rec[0] = bp_bf16(m);
 #pragma unroll
           for (int v = 0; v < NV; ++v) {
             // a view the bundle's shadows miss entirely has zero weights and a zero-filled tile: acc = 0, no branch
