@@ -7,7 +7,12 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O, P = os.path.join(R, "gpurun_out", tag) + "/", os.path.join(R, "profiles") + "/"
 a, b = json.load(open(O + "pmc/traffic.json")), json.load(open(O + "pmc_c4/traffic.json"))
 old = json.load(open(P + "traffic.json"))
-json.dump({"_comment": old["_comment"], "bench_args": a["bench_args"], "c3": a["c3"], "c4": b["c4"], "bench_args_c4": b["bench_args"]},
+c3 = dict(a["c3"])
+if os.path.exists(O + "pmc_bf16/traffic.json"):   # the bf16 variant of c3: other op names, same section
+    for k, v in json.load(open(O + "pmc_bf16/traffic.json"))["c3"].items():
+        c3.setdefault(k, v)
+    shutil.copy(O + "pmc_bf16/summary.txt", P + rnd + "_pmc_bench_bf16_summary.txt")
+json.dump({"_comment": old["_comment"], "bench_args": a["bench_args"], "c3": c3, "c4": b["c4"], "bench_args_c4": b["bench_args"]},
           open(P + "traffic.json", "w"), indent=1)
 names = {"bench.json": "bench.json", "bench_bf16.json": "bench_bf16.json", "bench_c1_graph.json": "bench_c1_graph.json",
          "bench_c2_graph.json": "bench_c2_graph.json", "bench_c4_bf16.json": "bench_c4_bf16.json",

@@ -18,6 +18,8 @@ bash tools/pmc_bench.sh $TAG/pmc > /dev/null 2>&1
 tail -n 2 "$O/pmc/summary.txt"
 bash tools/pmc_bench.sh $TAG/pmc_c4 --config c4 --conv-dtype bf16 > /dev/null 2>&1
 tail -n 2 "$O/pmc_c4/summary.txt"
+bash tools/pmc_bench.sh $TAG/pmc_bf16 --conv-dtype bf16 > /dev/null 2>&1
+tail -n 2 "$O/pmc_bf16/summary.txt"
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/fwd" -- python3 "$R/bench.py" --no-cpu-baseline --no-drr --ramp-seconds 0 --steps 10 --warmup 3 > "$O/fwd.log" 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/fwd_c4" -- python3 "$R/bench.py" --no-cpu-baseline --no-drr --ramp-seconds 0 --steps 10 --warmup 3 --config c4 --conv-dtype bf16 > "$O/fwd_c4.log" 2>&1

@@ -45,12 +45,12 @@ def op_table(cfg, P, bf16):
     n = CONFIG_N[cfg]
     ops = [("backproject", r"^backproject_(tiled_)?kernel", 0), ("pca_warp", r"^pca_warp_kernel<.*, false>$", 0),
            ("pca_warp_ncc", r"^pca_warp_kernel<.*, true>$", 0), ("ncc_moments", r"^ncc_moments_kernel", 0),
-           (f"conv3d_c{P + 1}x16_s1_{n}", r"^conv3d_planar_kernel", 0), (f"conv3d_bp_c{P + 1}x16_s1_{n}", r"^conv0_pc_kernel<.*, true>$", 0),
+           (f"conv3d_c{P + 1}x16_s1_{n}", r"^(conv3d_planar_kernel|conv0_split_f32_kernel<.*, 3, false, false>)", 0), (f"conv3d_bp_c{P + 1}x16_s1_{n}", r"^conv0_pc_kernel<.*, true>$", 0),
            (f"conv3d_c16x32_s2_{n}", r"^conv3d_rows_wlds_kernel<2, 1,", 0)]
     # stride-2 blocks: planes of >= 64 x 64 outputs run the persistent Winograd rows kernel (one grid size for all of them:
     # told apart by rank only if there are several), smaller ones the direct rows kernel
     if bf16:   # --conv-dtype bf16: the first block (all channels at once for > 3 of them, else the channel-pass kernel), then the row kernels
-        ops = ops[:4] + [(f"conv3d_bf16_c{P + 1}x16_s1_{n}", r"^conv0_cl_bf16_kernel<.*, false>$" if P + 1 > 3 else r"^conv0_bf16_kernel", 0),
+        ops = ops[:4] + [(f"conv3d_bf16_c{P + 1}x16_s1_{n}", r"^conv0_cl_bf16_kernel<.*, false>$" if P + 1 > 3 else r"^(conv0_split_f32_kernel<.*, 1, true, (true|false)>|conv0_bf16_kernel)", 0),
                          (f"conv3d_bf16_c{P + 1}x16_s1_{n}_clin", r"^conv0_cl_bf16_kernel<.*, true>$", 0),
                          ("backproject_encin_bf16", r"^backproject_encin_bf16_kernel", 0),
                          (f"conv3d_bf16_c16x32_s2_{n}", r"^conv3d_cl_rows_bf16_kernel<2, 4, false>", 0)]
