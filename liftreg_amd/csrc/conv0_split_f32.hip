@@ -1,5 +1,11 @@
-// conv0_split_f32.hip — the encoder's first block (Cin <= 4 planar fp32 channels, stride 1, 16 output channels, fp32
-// channels-last output) with its fp32 operands fed to the bf16 matrix pipe as EXACT three-way splits.
+// conv0_split_f32.hip — the encoder's first block with few input channels (Cin <= 4 planar fp32 channels, stride 1, 16 output
+// channels, channels-last output) as a z-MARCHING kernel on the bf16 matrix pipe.  Two arithmetic contracts, one kernel:
+//   NS = 1, bf16 output  — the bf16 storage contract of conv3d_bf16.hip (operands rounded once to bf16, exact products, fp32
+//                          accumulation, fp32 bias + LeakyReLU, bf16 store): the DEFAULT first block of the bf16 variant for
+//                          Cin <= 4 on planes >= 128^2 (C3 bf16, C5), inference and training forward (+ LeakyReLU sign mask);
+//                          1.75 -> 1.09 ms at C3 (5.4 TB/s);
+//   NS = 3, fp32 output  — fp32 operands as EXACT three-way bf16 splits, described next; opt-in (LIFTREG_CONV0_SPLIT=1),
+//                          DESIGN.md 6.6.
 //
 // The fp32 MFMA (v_mfma_f32_16x16x4_f32, 157 TFLOP/s) bounds this block: 2.9 ms at C3 with the Winograd sweep of conv3d.hip
 // against a memory floor of 10.2 GB ~ 2.1 ms.  v_mfma_f32_16x16x32_bf16 multiplies 8x the K in half the cycles, and an fp32
@@ -13,14 +19,15 @@
 // LR_C0S_PRODUCTS=9 (build flag) keeps all nine.  Six bf16 MFMAs of 16 cycles per K = 32 against eight fp32 MFMAs of 32
 // cycles: 2.7x fewer matrix cycles; the block becomes bound by the 64 bytes per voxel it writes.
 //
-// Structure (that of conv0_cl_bf16.hip): persistent 4-wave blocks (two per CU) march DOWN z through chunks of (8 rows x 64 columns)
+// Structure (that of conv0_cl_bf16.hip): persistent 4-wave blocks (two per CU; four with NS = 1) march DOWN z through chunks of (8 rows x 64 columns)
 // columns of the volume; the LDS holds a ring of 4 input planes, each (10 rows x 72 voxels) as three arrays of 8-byte
 // records (4 channels of one voxel in bf16; channels Cin..3 zero) — one array per split; iteration f requests plane f+1
 // (16-byte bounds-checked buffer loads: outside the volume -> 0 = the conv's padding), sweeps output plane f out of the
 // ring, splits plane f+1 and writes it over the slot whose last reader finished an iteration ago: ONE barrier per plane,
 // every input plane fetched once per chunk.
 //   K of an MFMA = 8 taps x 4 channels; lane group kq supplies two taps that sit a FIXED distance apart in the LDS, so
-//   one ds_read2_b64 delivers the operand in four consecutive registers (no assembly moves):
+//   two ds_read_b64 deliver the operand in four consecutive registers (no assembly moves; NOT merged into a ds_read2_b64,
+//   which takes four times the LDS cycles — see LR_C0S_NO_DS_MERGE below):
 //     k-block ty = 0,1,2 (next voxel):  kq = 0..2: (tz=kq, ty, tx=0) | (tz=kq, ty, tx=1);   kq = 3: (tz=0, ty, tx=2) | weight 0
 //     k-block 3 (next window row):      kq = 0: (1,0,2) | (1,1,2);  kq = 1: (1,2,2) | weight 0;  kq = 2: (2,0,2) | (2,1,2);
 //                                       kq = 3: (2,2,2) | weight 0
