@@ -49,7 +49,8 @@ def _to_ncdhw(y, layout):
 
 
 @pytest.mark.parametrize("B,Cin,D,W,H,hps", [(2, 3, 12, 128, 128, True), (1, 3, 7, 130, 132, False), (1, 2, 5, 144, 200, True),
-                                             (1, 1, 4, 128, 136, False), (1, 4, 6, 128, 128, True), (1, 3, 40, 128, 192, True)])
+                                             (1, 1, 4, 128, 136, False), (1, 4, 6, 128, 128, True), (1, 3, 40, 128, 192, True),
+                                             (2, 3, 1, 128, 128, True), (1, 3, 2, 136, 128, False)])   # (thinner than the plane ring)
 def test_split_conv_is_fp32_accurate(B, Cin, D, W, H, hps):
     from liftreg_amd import ops
     g = torch.Generator().manual_seed(100 * Cin + D)
@@ -146,7 +147,8 @@ def _run_bf16(x, w, b, layout, passes=False, **kw):
 
 
 @pytest.mark.parametrize("B,Cin,D,W,H,hps", [(2, 3, 12, 128, 128, True), (1, 3, 7, 130, 132, False), (1, 2, 9, 144, 200, True),
-                                             (1, 1, 4, 128, 136, False)])
+                                             (1, 1, 4, 128, 136, False), (2, 3, 1, 128, 128, True), (1, 3, 2, 136, 128, False),
+                                             (1, 3, 35, 128, 128, True)])
 def test_bf16_march_keeps_the_bf16_contract(B, Cin, D, W, H, hps):
     """Against oracle/ref_ops.conv_block_bf16 (operands rounded to bf16, exact products, fp32 sum, bf16 store): >= 99.5 %
     of the outputs identical, the rest one bf16 ulp (a final rounding flipped by the summation order) — the bar of
