@@ -21,6 +21,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 constexpr int TD = 4;
@@ -575,7 +576,13 @@ struct DgDimsH {
   float slope;
 };
 
-template <int NT>
+// XSL = the layout of the mask source, a compile-time constant (a run-time switch around the loads makes hipcc drain the
+// memory queue at every join): LR_LAYOUT_SIGN4 | LR_LAYOUT_BF16_NDHWC | LR_LAYOUT_BF16_NDHWC_HPS.
+// The mask sources of a parity pass (8 * NT small loads per lane) are requested BEFORE the pass's MFMAs and consumed after
+// them.  Loaded in the epilogue, next to their use, every one of them was a load -> s_waitcnt vmcnt(0) -> store sequence: a
+// full memory latency per output tile with the previous tile's stores drained first — the kernel ran at 28 % of the HBM rate
+// (C5: 4.4 ms for 10 GB).  Stores are unconditional bounds-checked buffer stores on the output plane.
+template <int NT, int XSL>
 __global__ __launch_bounds__(256, 2) void conv3d_dgrad_bf16_kernel(const u16* __restrict__ gpre, const u32x4* __restrict__ wp,
                                                                    u16* __restrict__ gx, const u16* __restrict__ xsave,
                                                                    DgDimsH d) {
@@ -615,10 +622,44 @@ __global__ __launch_bounds__(256, 2) void conv3d_dgrad_bf16_kernel(const u16* __
   const int col = lane & 15, kq = lane >> 4;
   const int xq = xq0 + col;
   const u16* lts = ts + col * VS + kq * 8;
+  constexpr bool SIGN4 = XSL == LR_LAYOUT_SIGN4;
+  constexpr unsigned OORV = 0x80000000u;
+  // mask source of batch element b as one buffer resource (SIGN4: D*W*H*Cx/4 bytes; activation: D*W*H*Cx*2 bytes < 2^31: checked by the launcher)
+  const int64_t VX = (int64_t)d.D * d.W * d.H;
+  const __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u16*>(SIGN4 ? reinterpret_cast<const u16*>(reinterpret_cast<const unsigned char*>(xsave) + (int64_t)b * VX * (d.Cx >> 2))
+                             : xsave + (int64_t)b * VX * d.Cx),
+      (short)0, (int)(SIGN4 ? VX * (d.Cx >> 2) : VX * d.Cx * 2), 0x00020000);
   for (int pp = 3; pp >= 0; --pp) {
     const int py = pp & 1, pz = pp >> 1;
     const int z = 2 * zq + pz;
     if (z >= d.D) continue;  // wave-uniform; no barrier below
+    // ---- this pass's mask sources, in flight under its MFMAs
+    unsigned mk[4][2][NT];
+    u32x2 xsv[SIGN4 ? 1 : 4][SIGN4 ? 1 : 2][SIGN4 ? 1 : NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int y = 2 * (yq0 + mt) + py;
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        const int x = 2 * xq + px;
+        const int ok = (int)(y < d.W) & (int)(x < d.H);
+        const unsigned vox = (unsigned)((z * d.W + y) * d.H);   // (voxel index of the row's first voxel: < 2^27)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int c = nt * 16 + kq * 4;
+          if constexpr (SIGN4) {
+            const unsigned off = ((vox + (unsigned)x) * (unsigned)(d.Cx >> 2) + (unsigned)(c >> 2)) | (((unsigned)ok - 1u) & OORV);
+            mk[mt][px][nt] = __builtin_amdgcn_raw_buffer_load_b8(rxs, off, 0, 0);
+          } else {
+            const unsigned xpos = XSL == LR_LAYOUT_BF16_NDHWC ? (unsigned)x : (unsigned)(px * (d.H >> 1) + xq);
+            const unsigned off = (((vox + xpos) * (unsigned)d.Cx + (unsigned)c) * 2u) | (((unsigned)ok - 1u) & OORV);
+            xsv[mt][px][nt] = __builtin_amdgcn_raw_buffer_load_b64(rxs, off, 0, 0);
+            mk[mt][px][nt] = 0u;
+          }
+        }
+      }
+    }
     f32x4 accp[2][4][NT];
 #pragma unroll
     for (int px = 1; px >= 0; --px) {
@@ -647,31 +688,29 @@ __global__ __launch_bounds__(256, 2) void conv3d_dgrad_bf16_kernel(const u16* __
         }
       }
     }
+    // ---- epilogue: mask, round, store through the output plane's resource (W*H*Cx*2 bytes)
+    const __amdgpu_buffer_rsrc_t rgx = __builtin_amdgcn_make_buffer_rsrc(
+        gx + ((int64_t)b * d.D + z) * d.W * d.H * d.Cx, (short)0, d.W * d.H * d.Cx * 2, 0x00020000);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const int y = 2 * (yq0 + mt) + py;
-      if (y >= d.W) continue;
-      const int64_t rowv = (((int64_t)b * d.D + z) * d.W + y) * d.H, row = rowv * d.Cx;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int px = 0; px < 2; ++px) {
           const int x = 2 * xq + px;
-          if (x >= d.H) continue;
+          const int ok = (int)(y < d.W) & (int)(x < d.H);
           const int c = nt * 16 + kq * 4;
           f32x4 v = accp[px][mt][nt];
-          if (d.xs_layout == LR_LAYOUT_SIGN4) {
-            // the producer's sign mask (B,D,W,H,Cx/4) uint8, written by its forward: one byte for this lane's channel quad
-            const unsigned m = reinterpret_cast<const unsigned char*>(xsave)[(rowv + x) * (d.Cx >> 2) + (c >> 2)];
+          if constexpr (SIGN4) {
+            const unsigned m = mk[mt][px][nt];
             v[0] = (m & 1u) ? v[0] : v[0] * d.slope;
             v[1] = (m & 2u) ? v[1] : v[1] * d.slope;
             v[2] = (m & 4u) ? v[2] : v[2] * d.slope;
             v[3] = (m & 8u) ? v[3] : v[3] * d.slope;
           } else {
-            // the producer's activation (bf16) at this voxel: rows [H][C] or [parity][H/2][C]
-            const int64_t xo = row + (int64_t)(d.xs_layout == LR_LAYOUT_BF16_NDHWC ? x : px * (d.H >> 1) + xq) * d.Cx + c;
-            const uint2 xs = *reinterpret_cast<const uint2*>(xsave + xo);
-            const short s0 = (short)(xs.x & 0xffffu), s1 = (short)(xs.x >> 16), s2 = (short)(xs.y & 0xffffu), s3 = (short)(xs.y >> 16);
+            const u32x2 xs = xsv[mt][px][nt];
+            const short s0 = (short)(xs[0] & 0xffffu), s1 = (short)(xs[0] >> 16), s2 = (short)(xs[1] & 0xffffu), s3 = (short)(xs[1] >> 16);
             v[0] = s0 > 0 ? v[0] : v[0] * d.slope;   // bf16 > 0  <=>  its bit pattern as int16 > 0
             v[1] = s1 > 0 ? v[1] : v[1] * d.slope;
             v[2] = s2 > 0 ? v[2] : v[2] * d.slope;
@@ -679,7 +718,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_dgrad_bf16_kernel(const u16* __
           }
           const unsigned lo = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
           const unsigned hi = (unsigned)to_bf16(v[2]) | ((unsigned)to_bf16(v[3]) << 16);
-          *reinterpret_cast<uint2*>(gx + row + (int64_t)x * d.Cx + c) = make_uint2(lo, hi);
+          const unsigned off = (unsigned)(((y * d.H + x) * d.Cx + c) * 2) | (((unsigned)ok - 1u) & OORV);
+          __builtin_amdgcn_raw_buffer_store_b64((u32x2){lo, hi}, rgx, off, 0, 0);
         }
     }
   }
@@ -831,8 +871,16 @@ extern "C" int lr_conv3d_dgrad_bf16(const void* gpre, const void* packed_wT, voi
   const u32x4* wt = reinterpret_cast<const u32x4*>(packed_wT);
   u16* o = reinterpret_cast<u16*>(gx);
   const u16* xs = reinterpret_cast<const u16*>(x_saved);
-  if (Cx == 16) hipLaunchKernelGGL(conv3d_dgrad_bf16_kernel<1>, grid, blk, 0, st, g, wt, o, xs, d);
-  else hipLaunchKernelGGL(conv3d_dgrad_bf16_kernel<2>, grid, blk, 0, st, g, wt, o, xs, d);
+  // 31-bit byte offsets inside one batch element of the mask source / one plane of the output
+  if ((int64_t)D * W * H * Cx * 2 >= 0x7fffffffLL || (int64_t)W * H * Cx * 2 >= 0x7fffffffLL) return LR_EUNSUPPORTED;
+#define LR_DGB(NTV)                                                                                                          \
+  do {                                                                                                                       \
+    if (x_layout == LR_LAYOUT_SIGN4) hipLaunchKernelGGL((conv3d_dgrad_bf16_kernel<NTV, LR_LAYOUT_SIGN4>), grid, blk, 0, st, g, wt, o, xs, d);        \
+    else if (x_layout == LR_LAYOUT_BF16_NDHWC) hipLaunchKernelGGL((conv3d_dgrad_bf16_kernel<NTV, LR_LAYOUT_BF16_NDHWC>), grid, blk, 0, st, g, wt, o, xs, d); \
+    else hipLaunchKernelGGL((conv3d_dgrad_bf16_kernel<NTV, LR_LAYOUT_BF16_NDHWC_HPS>), grid, blk, 0, st, g, wt, o, xs, d);    \
+  } while (0)
+  if (Cx == 16) LR_DGB(1); else LR_DGB(2);
+#undef LR_DGB
   return lr_launch_status();
 }
 
