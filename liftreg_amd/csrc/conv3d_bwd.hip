@@ -18,6 +18,7 @@
 //
 // Replaces: autograd of src/liftreg/layers/layers.py:365-369 as wired at …Backproj.py:29-33,95-100.
 #include "lr_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -1299,7 +1300,10 @@ __global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_bf
                                                                                            WgDims d, int nbricks) {
   constexpr int CMAX = NTL * 16 / 27;          // 3 | 12 input channels
   constexpr int ROWS = CMAX * 18;              // window rows (channel, plane, row)
-  constexpr int CPY = ROWS * 64;               // elements of one shifted copy (64 per row)
+  constexpr int RS = 72;                       // elements per LDS row: 64 + 8 of padding — with 64 (128 bytes) the 16 rows a
+                                               // B-operand read touches sat on the same four banks (5.8 conflict cycles per
+                                               // LDS instruction by PMC); 144 bytes put them 36 banks apart
+  constexpr int CPY = ROWS * RS;               // elements of one shifted copy
   constexpr int XF4 = ROWS * 18;               // float4 chunks of the fp32 window (72 columns)
   constexpr int XIT = (XF4 + 255) / 256;
   constexpr int ONES = 3 * CPY, GOFF = ONES + 64;  // element offsets: copies | ones row | gradient rows
@@ -1332,7 +1336,7 @@ __global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_bf
     if (c >= 27 * d.Cin) c = 0;
     const int ci = c / 27, tap = c % 27;
     const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
-    bbase[j] = lds0 + 2u * (unsigned)(ones ? ONES + 8 * kq : tx * CPY + (ci * 18 + tz * 6 + ty + wave) * 64 + 8 * kq);
+    bbase[j] = lds0 + 2u * (unsigned)(ones ? ONES + 8 * kq : tx * CPY + (ci * 18 + tz * 6 + ty + wave) * RS + 8 * kq);
   }
   // A operand: transposing reads of this wave's gradient row image [64 voxels][16 co]
   const unsigned aoff = lds0 + 2u * (unsigned)(GOFF + wave * 64 * 16) + (unsigned)((kq * 8 + ((lane >> 2) & 3)) * 32 + (lane & 3) * 8);
@@ -1340,51 +1344,86 @@ __global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_bf
 #pragma unroll
   for (int j = 0; j < NTL; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float4 xst[XIT];
-  u32x4_t gst[2];
-  auto prefetch = [&](int brick) {
-    const bool live = brick < nbricks;
+  // A brick is 12 MFMAs per wave (NTL = 6): nowhere near a memory latency.  With the next brick requested one iteration
+  // ahead every brick waited for its loads in the open (C5: 4.4 ms for 10 GB = 2.3 TB/s).  The requests now run DEPTH
+  // bricks ahead in DEPTH register sets; they and their waits are inline asm with static counts (a brick is NL loads and
+  // the loop holds no other vector-memory operation) because hipcc's wait-count pass drains every request that is in flight
+  // across a loop's back edge.
+  // this block's contiguous run of bricks (z fastest, see prefetch)
+  const int per_blk = (nbricks + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int brick_begin = min(nbricks, (int)blockIdx.x * per_blk), brick_end = min(nbricks, brick_begin + per_blk);
+  constexpr int DEPTH = NTL > 6 ? 1 : 3;
+  constexpr int NL = XIT + 2;
+  typedef int i32x4_t __attribute__((ext_vector_type(4)));
+  f32x4 xst[DEPTH][XIT];
+  u32x4_t gst[DEPTH][2];
+  auto make_srd = [](const void* p) __attribute__((always_inline)) -> i32x4_t {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    i32x4_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(a >> 32)) & 0xffff;
+    r[2] = 0x7fffffff;
+    r[3] = 0x00020000;
+    return r;
+  };
+  auto prefetch = [&](int brick, auto setc) __attribute__((always_inline)) {
+    constexpr int SET = decltype(setc)::value;
+    // Brick order: z FASTEST, and a block owns a contiguous run of it — consecutive bricks of a block are the same (w, h)
+    // tile one plane further, so two of the three window planes were read by this CU an iteration ago and come from its
+    // XCD's L2.  (With the bricks dealt round-robin over the blocks, h fastest, every window came from HBM: 16.9 GB of
+    // L2 misses by PMC for 5.9 GB of tensors, TCC hit rate 0.5 % — the kernel sat on the HBM rate at 2.7 ms.)
+    const bool live = brick < brick_end;
     int r = live ? brick : 0;
+    const int z = r % d.D; r /= d.D;
     const int hq = r % nH; r /= nH;
-    const int wq = r % nW; r /= nW;
-    const int z = r % d.D;
-    const int b = r / d.D;
+    const int wq = r % nW;
+    const int b = r / nW;
     const int h0 = hq * 64, y0 = wq * 4;
-    const float* xb = xin + (int64_t)b * d.Cin * V;
-    const __amdgpu_buffer_rsrc_t rx =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), (short)0, 0x7fffffff, 0x00020000);
+    const i32x4_t rx = make_srd(xin + (int64_t)b * d.Cin * V);
     const unsigned org = (unsigned)(((((int64_t)(z - 1) * d.W + (y0 - 1)) * d.H) + h0 - 4) * 4);
+    f32x4 (&X)[XIT] = xst[SET];
+    u32x4_t (&Gs)[2] = gst[SET];
 #pragma unroll
     for (int it = 0; it < XIT; ++it) {
       const int zi = z - 1 + (xdec[it] & 3), yi = y0 - 1 + ((xdec[it] >> 2) & 7), xi = h0 - 4 + ((xdec[it] >> 9) & 31) * 4;
       const bool ok = (int)(live) & (int)(((xdec[it] >> 14) & 1)) & (int)(zi >= 0) & (int)(zi < d.D) & (int)(yi >= 0) & (int)(yi < d.W) & (int)(xi >= 0) & (int)(xi < d.H);  // bitwise: no exec-mask branches around the loads' address math
-      xst[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? org + xrel[it] : OOR, 0, 0));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(X[it]) : "v"(ok ? org + xrel[it] : OOR), "s"(rx));
     }
     // gradient rows: 4 rows x 64 voxels x 16 co bf16 = 512 chunks of 16 bytes, 2 per thread
-    const u16* gb = gpre + ((((int64_t)b * d.D + z) * d.W + y0) * d.H + h0) * 16;
-    const __amdgpu_buffer_rsrc_t rg =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(gb), (short)0, 0x7fffffff, 0x00020000);
+    const i32x4_t rg = make_srd(gpre + ((((int64_t)b * d.D + z) * d.W + y0) * d.H + h0) * 16);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int ch = k * 256 + tid, rr = ch >> 7, v = (ch >> 1) & 63, half = ch & 1;
-      const bool ok = live && y0 + rr < d.W && h0 + v < d.H;
-      gst[k] = __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? (unsigned)(((rr * d.H + v) * 16 + half * 8) * 2) : OOR, 0, 0);
+      const bool ok = (int)live & (int)(y0 + rr < d.W) & (int)(h0 + v < d.H);
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(Gs[k]) : "v"(ok ? (unsigned)(((rr * d.H + v) * 16 + half * 8) * 2) : OOR), "s"(rg));
     }
   };
-
-  int brick = blockIdx.x;
-  prefetch(brick);
-  for (; brick < nbricks; brick += gridDim.x) {
-    __syncthreads();
+  // wait until at most (DEPTH - 1) * NL younger loads are outstanding: set SET has landed
+  auto wait_set = [&](auto setc) __attribute__((always_inline)) {
+    constexpr int SET = decltype(setc)::value, N = (DEPTH - 1) * NL;
+    static_assert(N <= 63, "vmcnt is a 6-bit counter");
+    f32x4 (&X)[XIT] = xst[SET];
+    u32x4_t (&Gs)[2] = gst[SET];
+    if constexpr (XIT == 4)
+      asm volatile("s_waitcnt vmcnt(%6)" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[XIT > 3 ? 3 : 0]), "+v"(Gs[0]), "+v"(Gs[1]) : "n"(N));
+    else {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(Gs[0]), "+v"(Gs[1]));
+#pragma unroll
+      for (int it = 0; it < XIT; ++it) asm volatile("" : "+v"(X[it]));
+    }
+  };
+  auto stage = [&](auto setc) __attribute__((always_inline)) {
+    constexpr int SET = decltype(setc)::value;
 #pragma unroll
     for (int it = 0; it < XIT; ++it) {
       const int q = it * 256 + tid;
       if (q < XF4) {
         const int row = q / 18, f4 = q - row * 18;
         // copy_t[j] = window[j + t + 3]: this chunk (window 4f4..4f4+3) lands at j0 = 4f4 - t - 3 of copy t.
-        const unsigned h0 = __builtin_bit_cast(u16, (__bf16)xst[it].x), h1 = __builtin_bit_cast(u16, (__bf16)xst[it].y);
-        const unsigned h2 = __builtin_bit_cast(u16, (__bf16)xst[it].z), h3 = __builtin_bit_cast(u16, (__bf16)xst[it].w);
-        u16* r0 = lds + row * 64;
+        const f32x4 xv = xst[SET][it];
+        const unsigned h0 = __builtin_bit_cast(u16, (__bf16)xv[0]), h1 = __builtin_bit_cast(u16, (__bf16)xv[1]);
+        const unsigned h2 = __builtin_bit_cast(u16, (__bf16)xv[2]), h3 = __builtin_bit_cast(u16, (__bf16)xv[3]);
+        u16* r0 = lds + row * RS;
         // t = 1: j0 = 4(f4-1), an aligned 8-byte store, wholly inside or outside the 64 columns
         if (f4 >= 1 && f4 <= 16) *reinterpret_cast<uint2*>(r0 + CPY + 4 * (f4 - 1)) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
         // t = 0: j0 = 4(f4-1) + 1 -> 2 + 4 + 2 bytes; t = 2: j0 = 4(f4-2) + 3 -> 2 + 4 + 2 bytes (the 4-byte piece is aligned)
@@ -1406,10 +1445,10 @@ __global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_bf
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int ch = k * 256 + tid, rr = ch >> 7, v = (ch >> 1) & 63, half = ch & 1;
-      *reinterpret_cast<u32x4_t*>(lds + GOFF + (rr * 64 + v) * 16 + half * 8) = gst[k];
+      *reinterpret_cast<u32x4_t*>(lds + GOFF + (rr * 64 + v) * 16 + half * 8) = gst[SET][k];
     }
-    __syncthreads();
-    prefetch(brick + (int)gridDim.x);
+  };
+  auto sweep = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       unsigned long long ar[2];
@@ -1430,7 +1469,36 @@ __global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_bf
                                                          acc[j], 0, 0, 0);
       }
     }
+  };
+  int brick = brick_begin;
+  prefetch(brick, std::integral_constant<int, 0>{});
+  if constexpr (DEPTH >= 2) prefetch(brick + 1, std::integral_constant<int, DEPTH >= 2 ? 1 : 0>{});
+  if constexpr (DEPTH >= 3) prefetch(brick + 2, std::integral_constant<int, DEPTH >= 3 ? 2 : 0>{});
+  auto iteration = [&](auto setc) __attribute__((always_inline)) -> bool {
+    if (brick >= brick_end) return false;
+    __syncthreads();   // the previous brick's LDS reads are done
+    wait_set(setc);
+    stage(setc);
+    __syncthreads();
+    prefetch(brick + DEPTH, setc);   // into the set just consumed (past the end: NL loads that return zeros)
+    sweep();
+    brick += 1;
+    return true;
+  };
+  while (true) {
+    if (!iteration(std::integral_constant<int, 0>{})) break;
+    if constexpr (DEPTH >= 2) { if (!iteration(std::integral_constant<int, DEPTH >= 2 ? 1 : 0>{})) break; }
+    if constexpr (DEPTH >= 3) { if (!iteration(std::integral_constant<int, DEPTH >= 3 ? 2 : 0>{})) break; }
   }
+  // the look-ahead past the last brick must have landed before its registers are reused (the operands keep them alive)
+  if constexpr (XIT == 4 && DEPTH == 3)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xst[0][0]), "+v"(xst[0][1]), "+v"(xst[0][2]), "+v"(xst[0][3]), "+v"(gst[0][0]), "+v"(gst[0][1]),
+                 "+v"(xst[DEPTH > 1 ? 1 : 0][0]), "+v"(xst[DEPTH > 1 ? 1 : 0][1]), "+v"(xst[DEPTH > 1 ? 1 : 0][2]), "+v"(xst[DEPTH > 1 ? 1 : 0][3]),
+                 "+v"(gst[DEPTH > 1 ? 1 : 0][0]), "+v"(gst[DEPTH > 1 ? 1 : 0][1]),
+                 "+v"(xst[DEPTH > 2 ? 2 : 0][0]), "+v"(xst[DEPTH > 2 ? 2 : 0][1]), "+v"(xst[DEPTH > 2 ? 2 : 0][2]), "+v"(xst[DEPTH > 2 ? 2 : 0][3]),
+                 "+v"(gst[DEPTH > 2 ? 2 : 0][0]), "+v"(gst[DEPTH > 2 ? 2 : 0][1]));
+  else
+    wait_set(std::integral_constant<int, 0>{});   // DEPTH 1: vmcnt(0) over the only set
   const int ncols = d.ntiles * 16;
   const int64_t pb = (int64_t)blockIdx.x * 4 + wave;
 #pragma unroll
