@@ -305,14 +305,21 @@ __global__ __launch_bounds__(256, (SINGLE ? (WINO ? LR_C0_WINO_BLOCKS : 3) : 2))
   float w[G::T][NT];
   float a[2][PW * 4];
   float uw[WINO ? 4 : 1][WINO ? 7 : 1];  // WINO: transformed weights U_r of k-quad q (lane: cout = lane&15, k = 4q + kq)
-  int woff[WINO ? 7 : 1];                 // WINO: LDS offset of d0 for this lane's k of quad q (output pair `col`)
+  // WINO: LDS offset of d0 for this lane's k of quad q (output pair `col`), for output rows un>>1 even | odd.  Window row
+  // (z, y) is stored shifted right by (z + y) & 1 floats: the two lane groups a ds_read_b32 serves together (k and k + 1 =
+  // neighbouring rows in y, or (z + 1, y - 2)) then sit on banks of opposite parity — with every row stride a multiple of
+  // four floats and the lanes two floats apart, all 32 of them hit the same 16 banks (PMC: 3.4-4.8 conflict cycles per LDS
+  // instruction, the review's item).
+  int woff[WINO ? 7 : 1], woffo[WINO ? 7 : 1];
   if constexpr (WINO) {
     static_assert(NT == 1 && S == 1 && CC == 3 && SINGLE, "Winograd sweep: the model's first block");
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
       const int k = min(q * 4 + kq, 26);   // k = (c, tz, ty); k = 27 is padding (U = 0), address of k = 26
       const int c = k / 9, tz = (k / 3) % 3, ty = k % 3;
-      woff[q] = c * G::CS + (wave + tz) * G::PS + ty * G::RSL + G::XOFF + 2 * col;
+      const int w0 = c * G::CS + (wave + tz) * G::PS + ty * G::RSL + G::XOFF + 2 * col, pl = (wave + tz + ty) & 1;
+      woff[q] = w0 + pl;
+      woffo[q] = w0 + (pl ^ 1);
 #pragma unroll
       for (int r = 0; r < 4; ++r) uw[r][q] = wp[d.Cin * 7 * 64 + (r * 7 + q) * 64 + lane];
     }
@@ -330,7 +337,12 @@ __global__ __launch_bounds__(256, (SINGLE ? (WINO ? LR_C0_WINO_BLOCKS : 3) : 2))
 #pragma unroll
       for (int it = 0; it < G::MAXIT; ++it) {
         const int dst = (slot_used(it) && lact) ? slot_cc(it) * G::CS + slot_rz(it) * G::PS + slot_ry(it) * G::RSL + lane_dst : CC * G::CS;
-        *reinterpret_cast<float4*>(brick + dst) = st[it];
+        if constexpr (WINO) {   // rows shifted by (z + y) & 1 floats (see woff): four dword stores, any alignment
+          float* pd = brick + dst + ((slot_rz(it) + slot_ry(it) + lrow) & 1);
+          pd[0] = st[it].x; pd[1] = st[it].y; pd[2] = st[it].z; pd[3] = st[it].w;
+        } else {
+          *reinterpret_cast<float4*>(brick + dst) = st[it];
+        }
       }
     } else {  // H % 4 != 0 or unaligned base: scalar staging of the same window, no prefetch
       int b, dq, wq, hq, pass;
@@ -427,7 +439,7 @@ __global__ __launch_bounds__(256, (SINGLE ? (WINO ? LR_C0_WINO_BLOCKS : 3) : 2))
           constexpr int NU = PW * 2, NSW = NU * 7;
           auto rd4 = [&](int sidx, float (&dst)[4]) {
             const int un = sidx / 7, q = sidx % 7;
-            const float* dp = brick + woff[q] + (un >> 1) * G::RSL + (un & 1) * 32;
+            const float* dp = brick + (((un >> 1) & 1) ? woffo[q] : woff[q]) + (un >> 1) * G::RSL + (un & 1) * 32;
             dst[0] = dp[0]; dst[1] = dp[1]; dst[2] = dp[2]; dst[3] = dp[3];
           };
 #ifndef LR_WINO_AHEAD
@@ -1108,7 +1120,7 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
       resident = 256 * LR_C0_WINO_BLOCKS;  // the Winograd instance (<=128 registers)
     if (const char* e = getenv("LIFTREG_CONV0_BLOCKS")) resident = atoi(e);  // tuning aid
     const dim3 grid((unsigned)(nitems < resident ? nitems : resident));
-    const size_t lds1 = (size_t)3 * PlanarGeom<1, 3>::CS * sizeof(float) + 16;   // + the staging dump area (stage())
+    const size_t lds1 = (size_t)3 * PlanarGeom<1, 3>::CS * sizeof(float) + 32;   // + the staging dump area (stage(); one float of row shift)
     const size_t lds2 = (size_t)1 * PlanarGeom<2, 1>::CS * sizeof(float) + 16;
     const int ni = (int)nitems;
     const int dbg = getenv("LIFTREG_CONV0_DBG") ? atoi(getenv("LIFTREG_CONV0_DBG")) : 0;  // timing ablations only
