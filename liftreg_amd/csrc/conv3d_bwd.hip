@@ -903,7 +903,8 @@ __global__ __launch_bounds__(256 * CB, (CB == 1 ? 2 : 1)) void conv3d_wgrad_cl_k
   // one output plane further — one of the three window planes was read by this CU an iteration ago.  (Dealt round-robin
   // over the blocks with ho fastest, PMC showed a TCC hit rate of 0.4 %: 18.6 GB from HBM for 10.7 GB of tensors on block 1.)
   const int per_blk = (nbricks + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int brick_begin = min(nbricks, (int)blockIdx.x * per_blk), brick_end = min(nbricks, brick_begin + per_blk);
+  const int run = (int)lr_xcd_remap(blockIdx.x, gridDim.x);   // neighbouring runs (the next h segment / the next output rows) on the SAME XCD: they walk dz in step and share halo rows in its L2
+  const int brick_begin = min(nbricks, run * per_blk), brick_end = min(nbricks, brick_begin + per_blk);
   auto prefetch = [&](int brick) {
     const bool live = brick < brick_end;
     int r = live ? brick : 0;
@@ -1079,7 +1080,8 @@ __global__ __launch_bounds__(256 * CB, 2) void conv3d_wgrad_cl_bf16_kernel(const
   // brick order: dz fastest, a contiguous run per block (see conv3d_wgrad_cl_kernel: the window plane two consecutive
   // bricks share comes from the XCD's L2, not from HBM)
   const int per_blk = (nbricks + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int brick_begin = min(nbricks, (int)blockIdx.x * per_blk), brick_end = min(nbricks, brick_begin + per_blk);
+  const int run = (int)lr_xcd_remap(blockIdx.x, gridDim.x);   // neighbouring runs (the next h segment / the next output rows) on the SAME XCD: they walk dz in step and share halo rows in its L2
+  const int brick_begin = min(nbricks, run * per_blk), brick_end = min(nbricks, brick_begin + per_blk);
   auto prefetch = [&](int brick) {
     const bool live = brick < brick_end;
     int r = live ? brick : 0;
@@ -1360,7 +1362,8 @@ __global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_bf
   // across a loop's back edge.
   // this block's contiguous run of bricks (z fastest, see prefetch)
   const int per_blk = (nbricks + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int brick_begin = min(nbricks, (int)blockIdx.x * per_blk), brick_end = min(nbricks, brick_begin + per_blk);
+  const int run = (int)lr_xcd_remap(blockIdx.x, gridDim.x);   // neighbouring runs (the next h segment / the next output rows) on the SAME XCD: they walk dz in step and share halo rows in its L2
+  const int brick_begin = min(nbricks, run * per_blk), brick_end = min(nbricks, brick_begin + per_blk);
   constexpr int DEPTH = NTL > 6 ? 1 : 3;
   constexpr int NL = XIT + 2;
   typedef int i32x4_t __attribute__((ext_vector_type(4)));
