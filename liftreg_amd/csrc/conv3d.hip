@@ -1105,7 +1105,7 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
     // LIFTREG_CONV0_SPLIT=1: conv0_split_f32.hip — the same block on the bf16 MFMA with exact three-way bf16 splits of its
     // fp32 operands (a direct conv, half the rounding error of the Winograd sweep).  Measured equal to the fp32-MFMA
     // Winograd kernel below at C3 (2.9-3.1 vs 3.0 ms: DESIGN.md §6·6), so it is NOT the default.
-    if (!bpa && !mask_out && stride == 1 && NT == 1 && Cin <= 4 && getenv("LIFTREG_CONV0_SPLIT") && atoi(getenv("LIFTREG_CONV0_SPLIT")) != 0 &&
+    if (!bpa && !mask_out && stride == 1 && NT == 1 && Cin <= 4 && getenv("LIFTREG_CONV0_SPLIT") && atoi(getenv("LIFTREG_CONV0_SPLIT")) != 0 && !getenv("LIFTREG_CONV0_DIRECT") &&
         (out_layout == LR_LAYOUT_NDHWC || out_layout == LR_LAYOUT_NDHWC_HPS)) {
       const int64_t V = (int64_t)D * W * H;
       const float* ps = packed_w + (int64_t)Cin * 7 * 64 + (Cin <= 3 ? 4 * 7 * 64 : 0);
