@@ -316,19 +316,41 @@ __global__ __launch_bounds__(1024) void disp_reg_bwd_march_kernel(const float* _
   const bool active = j < W;
   const size_t tsz = (size_t)(R + 4) * H;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  auto ldp = [&](int i) -> f32x4 {  // this thread's quad of plane i (zero outside the volume: never selected by axis_g5)
-    return (active && i >= 0 && i < D) ? *reinterpret_cast<const f32x4*>(base + (int64_t)i * W * H + (int64_t)j * H + k) : zero;
+  // One buffer resource per channel volume: a plane / row outside the volume gets an out-of-range offset and reads 0 — no branch
+  // around a load.  A plane's registers (the thread's own quad + one quad of the four halo rows the first four thread rows
+  // fetch) are requested ONE ITERATION before they are written into the LDS ring: loaded and written in the same iteration,
+  // every z step waited a full memory latency in the open (and for the previous step's store with it).
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, (int)(V * 4), 0x00020000);
+  struct PlaneRegs { f32x4 own, halo; };
+  const int ht = r < 2 ? r : 2 + R + (r - 2);            // tile row of this thread's halo quad (thread rows 0..3 only)
+  const int hj = j0 - 2 + ht;                             // its volume row
+  const bool hok = r < 4 && hj >= 0 && hj < W;
+  auto load_plane = [&](int i) __attribute__((always_inline)) -> PlaneRegs {
+    const bool zin = i >= 0 && i < D;
+    PlaneRegs p;
+    const unsigned po = (unsigned)i * (unsigned)(W * H);
+    p.own = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (active && zin) ? (po + (unsigned)(j * H + k)) * 4u : 0x80000000u, 0, 0));
+    p.halo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (hok && zin) ? (po + (unsigned)(hj * H + k)) * 4u : 0x80000000u, 0, 0));
+    return p;
+  };
+  auto store_plane = [&](int i, const PlaneRegs& p) __attribute__((always_inline)) {
+    float* tile = mt + (i & 3) * tsz;
+    if (active) *reinterpret_cast<f32x4*>(tile + (size_t)(2 + r) * H + k) = p.own;
+    if (hok) *reinterpret_cast<f32x4*>(tile + (size_t)ht * H + k) = p.halo;
   };
   const G5c ky = g5_coefs(j, W, ihw);
   G5c kx[4];  // the x index of a thread's four voxels never changes along the march
 #pragma unroll
   for (int t = 0; t < 4; ++t) kx[t] = g5_coefs(k + t, H, ihh);
-  f32x4 fm2 = ldp(i0 - 2), fm1 = ldp(i0 - 1), f0 = ldp(i0), fp1 = ldp(i0 + 1), fp2;
-  march_store_plane<2>(mt + (i0 & 3) * tsz, base + (int64_t)i0 * W * H, f0, H, W, R, j0, r, k4, active);
-  if (i0 + 1 < D) march_store_plane<2>(mt + ((i0 + 1) & 3) * tsz, base + (int64_t)(i0 + 1) * W * H, fp1, H, W, R, j0, r, k4, active);
+  const PlaneRegs q0 = load_plane(i0), q1 = load_plane(i0 + 1);
+  f32x4 fm2 = load_plane(i0 - 2).own, fm1 = load_plane(i0 - 1).own, f0 = q0.own, fp1 = q1.own, fp2;
+  PlaneRegs cur2 = load_plane(i0 + 2);   // in flight while the first two tiles are written
+  store_plane(i0, q0);
+  if (i0 + 1 < D) store_plane(i0 + 1, q1);
   for (int i = i0; i < i1; ++i) {
-    fp2 = ldp(i + 2);
-    if (i + 2 < D) march_store_plane<2>(mt + ((i + 2) & 3) * tsz, base + (int64_t)(i + 2) * W * H, fp2, H, W, R, j0, r, k4, active);
+    const PlaneRegs nx = load_plane(i + 3);   // consumed in the NEXT iteration
+    fp2 = cur2.own;
+    if (i + 2 < D) store_plane(i + 2, cur2);
     __syncthreads();  // plane i's tile is complete (filled two steps ago / before the loop); the tile written now (plane i+2) was
                       // last read as plane i-2, two barriers ago
     if (active) {
@@ -351,6 +373,7 @@ __global__ __launch_bounds__(1024) void disp_reg_bwd_march_kernel(const float* _
       __builtin_nontemporal_store(g * scale, reinterpret_cast<f32x4*>(gb + (int64_t)i * W * H + (int64_t)j * H + k));
     }
     fm2 = fm1; fm1 = f0; f0 = fp1; fp1 = fp2;
+    cur2 = nx;
   }
 }
 
