@@ -234,15 +234,37 @@ __global__ __launch_bounds__(1024) void disp_reg_march_kernel(const float* __res
   const int k = k4 * 4;
   const float cw = (j == 0 || j == W - 1) ? ihw : 0.5f * ihw;
   f32x4 fm, f0, fp;  // planes i-1, i, i+1 of this thread's quad (clamped at the faces: the one-sided difference)
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  f0 = active ? *reinterpret_cast<const f32x4*>(base + (int64_t)i0 * W * H + (int64_t)j * H + k) : zero;
-  fm = (active && i0 > 0) ? *reinterpret_cast<const f32x4*>(base + (int64_t)(i0 - 1) * W * H + (int64_t)j * H + k) : f0;
-  march_store_plane<1>(mt + (i0 & 1) * tsz, base + (int64_t)i0 * W * H, f0, H, W, R, j0, r, k4, active);
+  // (as in disp_reg_bwd_march_kernel: bounds-checked buffer loads, a plane's registers requested one iteration before they
+  // are written into the LDS tile — loaded and written in the same iteration every z step waited a memory latency)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, (int)(V * 4), 0x00020000);
+  struct PlaneRegs { f32x4 own, halo; };
+  const int ht = r < 1 ? r : 1 + R + (r - 1);            // tile row of this thread's halo quad (thread rows 0 and 1 only)
+  const int hj = j0 - 1 + ht;
+  const bool hok = r < 2 && hj >= 0 && hj < W;
+  auto load_plane = [&](int i) __attribute__((always_inline)) -> PlaneRegs {
+    const bool zin = i >= 0 && i < D;
+    PlaneRegs p;
+    const unsigned po = (unsigned)i * (unsigned)(W * H);
+    p.own = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (active && zin) ? (po + (unsigned)(j * H + k)) * 4u : 0x80000000u, 0, 0));
+    p.halo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (hok && zin) ? (po + (unsigned)(hj * H + k)) * 4u : 0x80000000u, 0, 0));
+    return p;
+  };
+  auto store_plane = [&](int i, const PlaneRegs& p) __attribute__((always_inline)) {
+    float* tile = mt + (i & 1) * tsz;
+    if (active) *reinterpret_cast<f32x4*>(tile + (size_t)(1 + r) * H + k) = p.own;
+    if (hok) *reinterpret_cast<f32x4*>(tile + (size_t)ht * H + k) = p.halo;
+  };
+  const PlaneRegs q0 = load_plane(i0);
+  f0 = q0.own;
+  fm = i0 > 0 ? load_plane(i0 - 1).own : f0;
+  PlaneRegs cur1 = load_plane(i0 + 1);   // in flight while the first tile is written
+  store_plane(i0, q0);
   double acc = 0.0;
   for (int i = i0; i < i1; ++i) {
     const bool last = i == D - 1;
-    fp = (active && !last) ? *reinterpret_cast<const f32x4*>(base + (int64_t)(i + 1) * W * H + (int64_t)j * H + k) : f0;
-    if (!last) march_store_plane<1>(mt + ((i + 1) & 1) * tsz, base + (int64_t)(i + 1) * W * H, fp, H, W, R, j0, r, k4, active);
+    const PlaneRegs nx = load_plane(i + 2);   // consumed in the NEXT iteration
+    fp = last ? f0 : cur1.own;
+    if (!last) store_plane(i + 1, cur1);
     __syncthreads();  // plane i's tile (written one step ago, or before the loop) is complete; plane i+1's is being filled
     if (active) {
       const float* tl = mt + (i & 1) * tsz + (size_t)(1 + r) * H + k;
@@ -261,6 +283,7 @@ __global__ __launch_bounds__(1024) void disp_reg_march_kernel(const float* __res
     }
     fm = f0;
     f0 = fp;
+    cur1 = nx;
     __syncthreads();  // everyone has read plane i's tile before it is overwritten by plane i+2
   }
   __shared__ double red[16];
