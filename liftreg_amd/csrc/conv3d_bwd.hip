@@ -1521,6 +1521,197 @@ __global__ __launch_bounds__(256, (NTL > 6 ? 1 : 2)) void conv3d_wgrad_planar_bf
     }
 }
 
+// ------------------------------------------------------------------- the same weight gradient, SHIFTING THE GRADIENT
+// instead of the window (first block, Cin <= 3, bf16 gradients; round 3).  The kernel above keeps the bf16 window in three
+// copies shifted by the tap's tx so that every B operand is an aligned 16-byte read — 28 predicated LDS stores of 2 / 4 / 8
+// bytes per thread and brick for 12 MFMAs per wave: it was bound by its staging (PMC: 46 LDS instructions and 120 vector
+// instructions per wave and brick, 2 conflict cycles per LDS instruction).  A weight gradient sums over ALL voxels, so it
+// does not matter which brick adds a product x[u] * g[v]: here a brick owns the 64 ALIGNED window columns u = h0 .. h0+63
+// (no x halo, ONE unshifted copy, one aligned 8-byte store per staged chunk) and meets them, for tap tx, with the gradient
+// at v = u - tx + 1 — a shift of the A operand by whole voxel rows of its [voxel][16 co] image, which the transposing read
+// takes as an immediate.  The gradient row is staged with one voxel of halo on each side (zero outside the volume).
+// Columns are grouped by tx: N-tile j = (tx = j / 2, half = j % 2), column m = half * 16 + col = (ci, tz, ty) for m < 27;
+// column 27 of group tx = 1 (unshifted gradient = exactly the brick's own outputs) multiplies by ones: the bias gradient.
+// wgrad_finish_kernel maps this order with x_layout = LR_WG_PLANAR_TX.
+constexpr int LR_WG_PLANAR_TX = -7;
+__global__ __launch_bounds__(256, 2) void conv3d_wgrad_planar_bf16s_kernel(const float* __restrict__ xin, const u16* __restrict__ gpre,
+                                                                            float* __restrict__ partial, WgDims d, int nbricks) {
+  constexpr int NTL = 6, CMAX = 3;
+  constexpr int ROWS = CMAX * 18;              // window rows (channel, plane, row)
+  constexpr int RS = 72;                       // elements per LDS row (64 + 8 of padding: rows 36 banks apart)
+  constexpr int XF4 = ROWS * 16;               // float4 chunks of the fp32 window (64 columns)
+  constexpr int XIT = (XF4 + 255) / 256;       // 4
+  constexpr int GV = 66;                       // gradient voxels per row: 64 + one of halo each side
+  constexpr int GCH = 4 * GV * 2;              // 16-byte chunks of the four gradient rows
+  constexpr int GIT = (GCH + 255) / 256;       // 3
+  constexpr int ONES = ROWS * RS, GOFF = ONES + 64;  // element offsets: window | ones row | gradient rows
+  __shared__ __attribute__((aligned(16))) u16 lds[GOFF + 4 * GV * 16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, kq = lane >> 4;
+  const int64_t V = (int64_t)d.D * d.W * d.H;
+  const int nH = (d.H + 63) / 64, nW = (d.W + 3) / 4;
+  if (tid < 64) lds[ONES + tid] = 0x3f80;  // bf16 1.0
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) u16*)lds;
+
+  unsigned xrel[XIT];
+  int xdec[XIT];  // rz | ry<<2 | cc<<5 | f4<<9 | used<<14
+#pragma unroll
+  for (int it = 0; it < XIT; ++it) {
+    const int q = it * 256 + tid;
+    const bool used = q < XF4;
+    const int row = used ? q / 16 : 0, f4 = q % 16;
+    const int cc = row / 18, rz = (row / 6) % 3, ry = row % 6;
+    xdec[it] = rz | (ry << 2) | (cc << 5) | (f4 << 9) | ((used && cc < d.Cin) ? 1 << 14 : 0);
+    xrel[it] = (unsigned)(((int64_t)cc * V + ((int64_t)rz * d.W + ry) * d.H + f4 * 4) * 4);
+  }
+  // B operand: per N-tile the lane's byte address of window row (ci, tz, ty + wave), columns 8kq ..
+  unsigned bbase[NTL];
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) {
+    const int tx = j >> 1, m = (j & 1) * 16 + col;
+    const bool ones = tx == 1 && m == 27;
+    const int mm = m < 27 ? m : 0;
+    const int ci = mm / 9, tz = (mm / 3) % 3, ty = mm % 3;
+    bbase[j] = lds0 + 2u * (unsigned)(ones ? ONES + 8 * kq : (ci * 18 + tz * 6 + ty + wave) * RS + 8 * kq);
+  }
+  // A operand: transposing reads of this wave's gradient row image [66 voxels][16 co]; image row 0 = voxel h0 - 1
+  const unsigned aoff = lds0 + 2u * (unsigned)(GOFF + wave * GV * 16) + (unsigned)((kq * 8 + ((lane >> 2) & 3)) * 32 + (lane & 3) * 8);
+  f32x4 acc[NTL];
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int per_blk = (nbricks + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int run = (int)lr_xcd_remap(blockIdx.x, gridDim.x);
+  const int brick_begin = min(nbricks, run * per_blk), brick_end = min(nbricks, brick_begin + per_blk);
+  constexpr int DEPTH = 3, NL = XIT + GIT;
+  typedef int i32x4_t __attribute__((ext_vector_type(4)));
+  f32x4 xst[DEPTH][XIT];
+  u32x4_t gst[DEPTH][GIT];
+  auto make_srd = [](const void* p) __attribute__((always_inline)) -> i32x4_t {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    i32x4_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(a >> 32)) & 0xffff;
+    r[2] = 0x7fffffff;
+    r[3] = 0x00020000;
+    return r;
+  };
+  auto prefetch = [&](int brick, auto setc) __attribute__((always_inline)) {
+    constexpr int SET = decltype(setc)::value;
+    const bool live = brick < brick_end;
+    int r = live ? brick : 0;
+    const int z = r % d.D; r /= d.D;   // z fastest: consecutive bricks of a block share two of their three window planes (L2)
+    const int hq = r % nH; r /= nH;
+    const int wq = r % nW;
+    const int b = r / nW;
+    const int h0 = hq * 64, y0 = wq * 4;
+    const i32x4_t rx = make_srd(xin + (int64_t)b * d.Cin * V);
+    const unsigned org = (unsigned)(((((int64_t)(z - 1) * d.W + (y0 - 1)) * d.H) + h0) * 4);
+    f32x4 (&X)[XIT] = xst[SET];
+    u32x4_t (&Gs)[GIT] = gst[SET];
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+      const int zi = z - 1 + (xdec[it] & 3), yi = y0 - 1 + ((xdec[it] >> 2) & 7), xi = h0 + ((xdec[it] >> 9) & 31) * 4;
+      const bool ok = (int)(live) & (int)(((xdec[it] >> 14) & 1)) & (int)(zi >= 0) & (int)(zi < d.D) & (int)(yi >= 0) & (int)(yi < d.W) & (int)(xi < d.H);
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(X[it]) : "v"(ok ? org + xrel[it] : OOR), "s"(rx));
+    }
+    // gradient rows y0 .. y0+3, voxels h0-1 .. h0+64 (16 co bf16 = two 16-byte chunks per voxel)
+    const i32x4_t rg = make_srd(gpre + ((((int64_t)b * d.D + z) * d.W + y0) * d.H) * 16);
+#pragma unroll
+    for (int k = 0; k < GIT; ++k) {
+      const int ch = k * 256 + tid, rr = ch / (GV * 2), rem = ch - rr * (GV * 2), vi = rem >> 1, half = rem & 1;
+      const int v = h0 - 1 + vi;
+      const bool ok = (int)live & (int)(ch < GCH) & (int)(y0 + rr < d.W) & (int)(v >= 0) & (int)(v < d.H);
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(Gs[k]) : "v"(ok ? (unsigned)(((rr * d.H + v) * 16 + half * 8) * 2) : OOR), "s"(rg));
+    }
+  };
+  auto wait_set = [&](auto setc) __attribute__((always_inline)) {
+    constexpr int SET = decltype(setc)::value, N = (DEPTH - 1) * NL;
+    static_assert(N <= 63 && XIT == 4 && GIT == 3, "static wait counts");
+    f32x4 (&X)[XIT] = xst[SET];
+    u32x4_t (&Gs)[GIT] = gst[SET];
+    asm volatile("s_waitcnt vmcnt(%7)" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(Gs[0]), "+v"(Gs[1]), "+v"(Gs[2]) : "n"(N));
+  };
+  auto stage = [&](auto setc) __attribute__((always_inline)) {
+    constexpr int SET = decltype(setc)::value;
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+      const int q = it * 256 + tid;
+      if (q < XF4) {   // compile-time true but for the last slot
+        const int row = q / 16, f4 = q - row * 16;
+        const f32x4 xv = xst[SET][it];
+        const unsigned h0 = __builtin_bit_cast(u16, (__bf16)xv[0]), h1 = __builtin_bit_cast(u16, (__bf16)xv[1]);
+        const unsigned h2 = __builtin_bit_cast(u16, (__bf16)xv[2]), h3 = __builtin_bit_cast(u16, (__bf16)xv[3]);
+        *reinterpret_cast<uint2*>(lds + row * RS + 4 * f4) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < GIT; ++k) {
+      const int ch = k * 256 + tid, rr = ch / (GV * 2), rem = ch - rr * (GV * 2), vi = rem >> 1, half = rem & 1;
+      if (ch < GCH) *reinterpret_cast<u32x4_t*>(lds + GOFF + (rr * GV + vi) * 16 + half * 8) = gst[SET][k];
+    }
+  };
+  auto sweep = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      unsigned long long ar[3][2];
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)   // image row = K index + 2 - tx
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ar[tx][h]) : "v"(aoff), "n"(ks * 32 * 32 + h * 128 + (2 - tx) * 32) : "memory");
+      u32x4_t bv[NTL];
+#pragma unroll
+      for (int j = 0; j < NTL; ++j)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bv[j]) : "v"(bbase[j]), "n"(ks * 64) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        asm volatile("" : "+v"(ar[tx][0]), "+v"(ar[tx][1]));
+        const u32x4_t av = {(unsigned)ar[tx][0], (unsigned)(ar[tx][0] >> 32), (unsigned)ar[tx][1], (unsigned)(ar[tx][1] >> 32)};
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int j = 2 * tx + hh;
+          asm volatile("" : "+v"(bv[j]));
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, bv[j]),
+                                                           acc[j], 0, 0, 0);
+        }
+      }
+    }
+  };
+  int brick = brick_begin;
+  prefetch(brick, std::integral_constant<int, 0>{});
+  prefetch(brick + 1, std::integral_constant<int, 1>{});
+  prefetch(brick + 2, std::integral_constant<int, 2>{});
+  auto iteration = [&](auto setc) __attribute__((always_inline)) -> bool {
+    if (brick >= brick_end) return false;
+    __syncthreads();   // the previous brick's LDS reads are done
+    wait_set(setc);
+    stage(setc);
+    __syncthreads();
+    prefetch(brick + DEPTH, setc);   // into the set just consumed (past the end: NL loads that return zeros)
+    sweep();
+    brick += 1;
+    return true;
+  };
+  while (true) {
+    if (!iteration(std::integral_constant<int, 0>{})) break;
+    if (!iteration(std::integral_constant<int, 1>{})) break;
+    if (!iteration(std::integral_constant<int, 2>{})) break;
+  }
+  // the look-ahead past the last brick must have landed before its registers are reused (the operands keep them alive)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(xst[0][0]), "+v"(xst[0][1]), "+v"(xst[0][2]), "+v"(xst[0][3]), "+v"(gst[0][0]), "+v"(gst[0][1]), "+v"(gst[0][2]),
+               "+v"(xst[1][0]), "+v"(xst[1][1]), "+v"(xst[1][2]), "+v"(xst[1][3]), "+v"(gst[1][0]), "+v"(gst[1][1]), "+v"(gst[1][2]),
+               "+v"(xst[2][0]), "+v"(xst[2][1]), "+v"(xst[2][2]), "+v"(xst[2][3]), "+v"(gst[2][0]), "+v"(gst[2][1]), "+v"(gst[2][2]));
+  const int ncols = NTL * 16;
+  const int64_t pb = (int64_t)blockIdx.x * 4 + wave;
+#pragma unroll
+  for (int j = 0; j < NTL; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) partial[(pb * 16 + kq * 4 + r) * ncols + j * 16 + col] = acc[j][r];
+}
+
 // partial[k][co][n] summed over the nblk partials in double (fixed order), column n -> (ci, tap) of gw.
 // Block = 64 columns x 16 slices of k: consecutive threads read consecutive floats, the 16 slice sums meet in LDS.
 __global__ __launch_bounds__(1024) void wgrad_finish_kernel(const float* __restrict__ partial, float* __restrict__ gw,
@@ -1543,7 +1734,11 @@ __global__ __launch_bounds__(1024) void wgrad_finish_kernel(const float* __restr
   for (int i = 1; i < 16; ++i) s += red[i][tx];
   const int co = t / ncols, n = t - co * ncols;
   int ci, tap;
-  if (x_layout == LR_LAYOUT_NCDHW) {
+  if (x_layout == LR_WG_PLANAR_TX) {   // conv3d_wgrad_planar_bf16s_kernel: columns grouped by tx, 32 per group
+    const int tx = n >> 5, m = n & 31;
+    ci = m < 27 ? m / 9 : Cin;
+    tap = m < 27 ? ((m / 3) % 3) * 9 + (m % 3) * 3 + tx : 27;
+  } else if (x_layout == LR_LAYOUT_NCDHW) {
     ci = n / 27; tap = n - ci * 27;
   } else {
     const int cbn = (Cin + 15) >> 4, j = n >> 4;
@@ -1682,7 +1877,8 @@ extern "C" int64_t lr_conv3d_wgrad_partial_floats(int Cin, int Cout, int x_layou
   if (x_layout == LR_LAYOUT_NCDHW_RBF16) x_layout = LR_LAYOUT_NCDHW;  // planar either way
   // planar: ceil((27*Cin + 1)/16) tiles (one spare column carries the bias gradient), one partial per WAVE of
   // the fast path (its waves split the voxels); channels-last: 27*ceil(Cin/16) tiles + the ones tile
-  const int ntiles = x_layout == LR_LAYOUT_NCDHW ? (Cin * 27 + 16) / 16 : 27 * ((Cin + 15) / 16) + 1;
+  int ntiles = x_layout == LR_LAYOUT_NCDHW ? (Cin * 27 + 16) / 16 : 27 * ((Cin + 15) / 16) + 1;
+  if (x_layout == LR_LAYOUT_NCDHW && Cin <= 3 && ntiles < 6) ntiles = 6;   // conv3d_wgrad_planar_bf16s_kernel always writes its six tiles (three tx groups of 32 columns)
   return (int64_t)nblk * (x_layout == LR_LAYOUT_NCDHW ? 4 : 1) * Cout * ntiles * 16;
 }
 
@@ -1709,6 +1905,7 @@ static int wgrad_impl(const float* x, int x_layout, const float* gpre, int gbf, 
   const bool al16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gpre)) & 15u) == 0;
   const int64_t V = (int64_t)D * W * H;
   int nparts = 0;  // > 0: a fast path ran and left this many partials
+  bool planar_tx = false;  // the partial columns are in conv3d_wgrad_planar_bf16s_kernel's order
   if (x_layout != LR_LAYOUT_NCDHW && stride == 2 && (Cin == 16 || Cin == 32) && al16 &&
       (int64_t)4 * W * H * Cin * 4 < 0x7fffffffLL) {  // a 3-plane window within 31-bit offsets
     // blocks 1..5: LDS-staged bricks (one output row segment each)
@@ -1770,7 +1967,10 @@ static int wgrad_impl(const float* x, int x_layout, const float* gpre, int gbf, 
     const int64_t nbricks = (int64_t)B * D * ((W + 3) / 4) * ((H + 63) / 64);
     if (nbricks < 0x7fffffffLL) {
       const unsigned grid = (unsigned)(nbricks < nblk ? nbricks : nblk);
-      if (gbf && xround && Cin <= 3)
+      if (gbf && xround && Cin <= 3 && !getenv("LIFTREG_WGRAD0_COPIES")) {   // env: the three-copies kernel (A/B aid)
+        hipLaunchKernelGGL(conv3d_wgrad_planar_bf16s_kernel, dim3(grid), dim3(256), 0, st, x, reinterpret_cast<const u16*>(gpre), partial, d, (int)nbricks);
+        planar_tx = true;
+      } else if (gbf && xround && Cin <= 3)
         hipLaunchKernelGGL(conv3d_wgrad_planar_bf16_kernel<6>, dim3(grid), dim3(256), 0, st, x, reinterpret_cast<const u16*>(gpre), partial, d, (int)nbricks);
       else if (gbf && xround)
         hipLaunchKernelGGL(conv3d_wgrad_planar_bf16_kernel<21>, dim3(grid), dim3(256), 0, st, x, reinterpret_cast<const u16*>(gpre), partial, d, (int)nbricks);
@@ -1783,10 +1983,10 @@ static int wgrad_impl(const float* x, int x_layout, const float* gpre, int gbf, 
     if (int e = lr_launch_status()) return e;
     // fast-path partials carry one extra column/tile: the sum of gpre (bias gradient)
     const int planar = x_layout == LR_LAYOUT_NCDHW;
-    const int ncols = planar ? d.ntiles * 16 : (d.ntiles + 1) * 16;
+    const int ncols = planar_tx ? 96 : planar ? d.ntiles * 16 : (d.ntiles + 1) * 16;
     const int n = Cout * ncols;
     hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, partial, gw, gb, nparts, Cout, Cin,
-                       ncols, x_layout, planar ? 27 * Cin : d.ntiles * 16);
+                       ncols, planar_tx ? LR_WG_PLANAR_TX : x_layout, planar_tx ? 32 + 27 : planar ? 27 * Cin : d.ntiles * 16);
     return lr_launch_status();
   }
   if (xbf) return LR_EUNSUPPORTED;  // the generic kernel reads fp32 activations (bf16 gradients and the rounded first-block input are fine)
