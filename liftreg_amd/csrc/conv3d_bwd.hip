@@ -1055,10 +1055,12 @@ __global__ __launch_bounds__(256 * CB, 2) void conv3d_wgrad_cl_bf16_kernel(const
     xrel[it] = (unsigned)(((((pz * d.W + py) * d.H + (HPS ? hprel : pc)) * Cin) + c8 * 8) * 2);
     xdst[it] = (unsigned)((((row9 * CB + (c8 >> 1)) * NCP + pos) * 32) + (c8 & 1) * 16);
   }
-  // transposed-read lane address inside a 32-row (voxel) x 16-channel tile: group kq = lane>>4 owns voxels 8kq..8kq+7;
-  // lane 4q+p of the group supplies row q of the 4-row block, columns 4p..4p+3 (8 bytes); second read: +4 rows
+  // transposed-read lane address inside a 32-row (voxel) x 16-channel tile: lane 4q+p of group kq = lane>>4 supplies row q of
+  // the group's 4-row block, columns 4p..4p+3 (8 bytes); second read: +16 rows
+  // (K order: group kq owns voxels 4kq..4kq+3 and 16+4kq..16+4kq+3 — one read's 64 lanes cover 512 contiguous bytes; see
+  // conv3d_wgrad_cl_split_kernel)
   const int kq = lane >> 4, lq = (lane >> 2) & 3, lp = lane & 3;
-  const unsigned ltr = (unsigned)((kq * 8 + lq) * 32 + lp * 8);
+  const unsigned ltr = (unsigned)((kq * 4 + lq) * 32 + lp * 8);
   unsigned boff[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -1126,12 +1128,12 @@ __global__ __launch_bounds__(256 * CB, 2) void conv3d_wgrad_cl_bf16_kernel(const
     for (int nt = 0; nt < NTC; ++nt)
 #pragma unroll
       for (int h = 0; h < 2; ++h)
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ar[nt][h]) : "v"(aoff), "n"(nt * HB * 32 + h * 128) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ar[nt][h]) : "v"(aoff), "n"(nt * HB * 32 + h * 512) : "memory");
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
       for (int h = 0; h < 2; ++h)
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(br[t][h]) : "v"(boff[t]), "n"(h * 128) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(br[t][h]) : "v"(boff[t]), "n"(h * 512) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int nt = 0; nt < NTC; ++nt) asm volatile("" : "+v"(ar[nt][0]), "+v"(ar[nt][1]));
@@ -1146,6 +1148,202 @@ __global__ __launch_bounds__(256 * CB, 2) void conv3d_wgrad_cl_bf16_kernel(const
                                                              acc[t][nt], 0, 0, 0);
       }
     }
+  }
+  const int col = lane & 15;
+  const int ncols = (27 * CB + 1) * 16;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int j = wave + NW * t;
+    if (j <= 27 * CB) {
+#pragma unroll
+      for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          partial[((int64_t)blockIdx.x * Cout + nt * 16 + kq * 4 + r) * ncols + j * 16 + col] = acc[t][nt][r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------- wgrad, fp32 operands on the bf16 MFMA (exact splits)
+// The fp32 weight gradient of blocks 1..5 is bound by the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: 107 TFLOP/s on block 1's
+// 464 GFLOP).  Every fp32 value is EXACTLY the sum of three bf16 values (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 -
+// x1): 3 x 8 significant bits), so x·g = sum of nine bf16 products, each exact in the fp32 accumulator; the three smallest
+// (x1 g2, x2 g1, x2 g2 <= 2^-26 |x g|) are below the rounding of the fp32 product itself and are dropped — the same split as
+// the forward's conv0_split_f32.hip.  Six v_mfma_f32_16x16x32_bf16 (K = 32 voxels, 16 cycles) replace eight
+// v_mfma_f32_16x16x4_f32 (K = 4 voxels, 32 cycles): 96 instead of 256 matrix-pipe cycles per 32 voxels and tile.
+// Same bricks, window image, transposing operand reads and partial layout as conv3d_wgrad_cl_bf16_kernel; the operands are
+// split on their way into LDS (three images of the window, three of the gradient segment).  The bias gradient's ones tile
+// is 1.0 in the first image and 0 in the other two.
+typedef float wsf32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 wsbf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void wg_split3(float a, float b, unsigned (&p)[3]) {
+  wsf32x2_t v = {a, b};
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const wsbf16x2_t h = __builtin_convertvector(v, wsbf16x2_t);  // round to nearest even
+    const unsigned u = __builtin_bit_cast(unsigned, h);
+    p[s] = u;
+    if (s < 2) {
+      const wsf32x2_t f = {__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+      v = v - f;  // exact
+    }
+  }
+}
+
+template <int NTC, bool HPS>
+__global__ __launch_bounds__(256, 2) void conv3d_wgrad_cl_split_kernel(const float* __restrict__ xin,
+                                                                       const float* __restrict__ gpre,
+                                                                       float* __restrict__ partial, WgDims d, int nbricks) {
+  constexpr int CB = 1, Cin = 16, Cout = NTC * 16, HB = 32, NCP = 2 * HB + 1, NW = 4, NTH = 256;
+  constexpr int T = (27 * CB + 1 + NW - 1) / NW;  // 27 taps + the ones tile over 4 waves
+  constexpr int XCH = 9 * NCP * 2;                // 8-channel chunks of the window (two 16-byte loads each)
+  constexpr int XIT = (XCH + NTH - 1) / NTH;
+  constexpr int XBYTES = 9 * CB * NCP * 32, XSPL = XBYTES + HB * 32;  // one image: window | special tile (ones / zeros)
+  constexpr int GOFF = 3 * XSPL, GSPL = NTC * HB * 32;
+  static_assert(GOFF + 3 * GSPL <= 65536 && 2 * XSPL + 128 < 65536, "LDS image / DS offset range");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[GOFF + 3 * GSPL];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nseg = (d.Ho + HB - 1) / HB;
+  for (int i = tid; i < 3 * HB * 16; i += NTH)
+    reinterpret_cast<u16*>(lds + (i / (HB * 16)) * XSPL + XBYTES)[i % (HB * 16)] = i < HB * 16 ? 0x3f80 : 0;  // bf16 1.0 | 0
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+
+  unsigned xrel[XIT], xdst[XIT];
+  int xdec[XIT];  // pz | py<<2 | pc<<4 | used<<12
+#pragma unroll
+  for (int it = 0; it < XIT; ++it) {
+    const int q = it * NTH + tid;
+    const bool used = q < XCH;
+    const int c8 = q & 1, vox = q >> 1;
+    const int pos = vox % NCP, row9 = used ? vox / NCP : 0;
+    const int pz = row9 / 3, py = row9 % 3;
+    const int pc = pos <= HB ? 2 * pos : 2 * (pos - HB - 1) + 1;
+    const int hprel = (pc & 1) ? (pc - 1) / 2 : (d.H >> 1) - 1 + pc / 2;
+    xdec[it] = pz | (py << 2) | (pc << 4) | (used ? 1 << 12 : 0);
+    xrel[it] = (unsigned)(((((pz * d.W + py) * d.H + (HPS ? hprel : pc)) * Cin) + c8 * 8) * 4);
+    xdst[it] = (unsigned)(((row9 * NCP + pos) * 32) + c8 * 16);
+  }
+  // K order: lane group kq owns voxels 4kq..4kq+3 (first read) and 16+4kq..16+4kq+3 (second read), the same for both operands:
+  // the 64 lanes of ONE read then cover 16 consecutive 32-byte rows = 512 contiguous bytes, conflict-free.  (With 8
+  // consecutive voxels per group the groups sit 256 bytes apart — the same banks: PMC showed 480 conflict cycles per wave and
+  // brick, the LDS pipe 70 % busy.)
+  const int kq = lane >> 4, lq = (lane >> 2) & 3, lp = lane & 3;
+  const unsigned ltr = (unsigned)((kq * 4 + lq) * 32 + lp * 8);
+  unsigned boff[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int jr = wave + NW * t;
+    const int tap = min(jr, 26);
+    const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+    boff[t] = lds0 + ltr + (jr >= 27 ? (unsigned)XBYTES
+                                     : (unsigned)(((tz * 3 + ty) * NCP + (tx == 1 ? HB + 1 : (tx >> 1))) * 32));
+  }
+  const unsigned aoff = lds0 + GOFF + ltr;
+  f32x4 acc[T][NTC];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  f32x4 xst[XIT][2], gst;
+  const int per_blk = (nbricks + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int run = (int)lr_xcd_remap(blockIdx.x, gridDim.x);
+  const int brick_begin = min(nbricks, run * per_blk), brick_end = min(nbricks, brick_begin + per_blk);
+  const int gi = tid / (Cout / 4), gc4 = tid % (Cout / 4);   // this thread's gradient chunk: voxel, 4-channel group
+  auto prefetch = [&](int brick) {
+    const bool live = brick < brick_end;
+    int r = live ? brick : 0;
+    const int dz = r % d.Do; r /= d.Do;
+    const int hseg = r % nseg; r /= nseg;
+    const int wo = r % d.Wo;
+    const int b = r / d.Wo;
+    const int ho0 = hseg * HB;
+    const int zi0 = 2 * dz - 1, yi0 = 2 * wo - 1, xi0 = 2 * ho0 - 1;
+    const float* xb = xin + (int64_t)b * d.D * d.W * d.H * Cin + (((int64_t)zi0 * d.W + yi0) * d.H + (HPS ? ho0 : xi0)) * Cin;
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), (short)0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+      const int zi = zi0 + (xdec[it] & 3), yi = yi0 + ((xdec[it] >> 2) & 3), xi = xi0 + ((xdec[it] >> 4) & 255);
+      const bool ok = (int)(live) & (int)(((xdec[it] >> 12) & 1)) & (int)(zi >= 0) & (int)(zi < d.D) & (int)(yi >= 0) & (int)(yi < d.W) & (int)(xi >= 0) & (int)(xi < d.H);
+      const unsigned o = ok ? xrel[it] : OOR;
+      xst[it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, o, 0, 0));
+      xst[it][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, o, 16, 0));
+    }
+    const float* gb = gpre + ((((int64_t)b * d.Do + dz) * d.Wo + wo) * d.Ho + ho0) * Cout;
+    const __amdgpu_buffer_rsrc_t rg =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gb), (short)0, 0x7fffffff, 0x00020000);
+    const bool gok = live && gi < HB && ho0 + gi < d.Ho;
+    gst = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, gok ? (unsigned)tid * 16u : OOR, 0, 0));
+  };
+
+  int brick = brick_begin;
+  prefetch(brick);
+  for (; brick < brick_end; ++brick) {
+    __syncthreads();  // the previous brick's reads are done
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+      unsigned p[4][3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wg_split3(xst[it][j >> 1][(j & 1) * 2], xst[it][j >> 1][(j & 1) * 2 + 1], p[j]);
+      if ((xdec[it] >> 12) & 1) {
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp)
+          *reinterpret_cast<u32x4_t*>(lds + sp * XSPL + xdst[it]) = (u32x4_t){p[0][sp], p[1][sp], p[2][sp], p[3][sp]};
+      }
+    }
+    if (gi < HB) {
+      unsigned p[2][3];
+      wg_split3(gst[0], gst[1], p[0]);
+      wg_split3(gst[2], gst[3], p[1]);
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp)
+        *reinterpret_cast<u32x2_t*>(lds + GOFF + sp * GSPL + ((gc4 >> 2) * HB + gi) * 32 + (gc4 & 3) * 8) = (u32x2_t){p[0][sp], p[1][sp]};
+    }
+    __syncthreads();
+    prefetch(brick + 1);
+    unsigned long long ar[3][NTC][2], br[3][T][2];
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+      for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ar[sp][nt][h]) : "v"(aoff), "n"(sp * GSPL + nt * HB * 32 + h * 512) : "memory");
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(br[sp][t][h]) : "v"(boff[t]), "n"(sp * XSPL + h * 512) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) {
+#pragma unroll
+      for (int nt = 0; nt < NTC; ++nt) asm volatile("" : "+v"(ar[sp][nt][0]), "+v"(ar[sp][nt][1]));
+#pragma unroll
+      for (int t = 0; t < T; ++t) asm volatile("" : "+v"(br[sp][t][0]), "+v"(br[sp][t][1]));
+    }
+    // the six products, smallest first: (g split, x split) with the splits' indices summing to <= 2
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int pr = 0; pr < 6; ++pr) {
+        const unsigned long long b0 = br[PB[pr]][t][0], b1 = br[PB[pr]][t][1];
+        const u32x4_t bv = {(unsigned)b0, (unsigned)(b0 >> 32), (unsigned)b1, (unsigned)(b1 >> 32)};
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) {
+          const unsigned long long a0 = ar[PA[pr]][nt][0], a1 = ar[PA[pr]][nt][1];
+          const u32x4_t av = {(unsigned)a0, (unsigned)(a0 >> 32), (unsigned)a1, (unsigned)(a1 >> 32)};
+          acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, bv),
+                                                               acc[t][nt], 0, 0, 0);
+        }
+      }
   }
   const int col = lane & 15;
   const int ncols = (27 * CB + 1) * 16;
@@ -1930,6 +2128,23 @@ static int wgrad_impl(const float* x, int x_layout, const float* gpre, int gbf, 
 #undef LR_WB
         nparts = (int)grid;
       }
+    } else if (!gbf && !xbf && Cin == 16 && getenv("LIFTREG_WGRAD_SPLIT") && atoi(getenv("LIFTREG_WGRAD_SPLIT")) != 0 &&
+               (int64_t)B * d.Do * d.Wo * ((d.Ho + 31) / 32) < 0x7fffffffLL) {
+      // LIFTREG_WGRAD_SPLIT=1, fp32 x and gradient, 16 input channels (block 1): exact bf16 splits on the bf16 MFMA
+      // (conv3d_wgrad_cl_split_kernel).  Alone it is 3.5 ms against the fp32-MFMA kernel's 4.35 at C3; in the training step most
+      // of that comes back as a slower neighbour (the step runs at the package power limit: DESIGN.md §6·7), 31.86 -> 31.59 ms
+      // in an interleaved A/B — so, like the forward's LIFTREG_CONV0_SPLIT, it is NOT the default.
+      const int64_t nb32 = (int64_t)B * d.Do * d.Wo * ((d.Ho + 31) / 32);
+      const unsigned grid = (unsigned)(nb32 < nblk ? nb32 : nblk);
+      const bool hps = x_layout == LR_LAYOUT_NDHWC_HPS;
+      if (Cout == 16) {
+        if (hps) hipLaunchKernelGGL((conv3d_wgrad_cl_split_kernel<1, true>), dim3(grid), dim3(256), 0, st, x, gpre, partial, d, (int)nb32);
+        else hipLaunchKernelGGL((conv3d_wgrad_cl_split_kernel<1, false>), dim3(grid), dim3(256), 0, st, x, gpre, partial, d, (int)nb32);
+      } else {
+        if (hps) hipLaunchKernelGGL((conv3d_wgrad_cl_split_kernel<2, true>), dim3(grid), dim3(256), 0, st, x, gpre, partial, d, (int)nb32);
+        else hipLaunchKernelGGL((conv3d_wgrad_cl_split_kernel<2, false>), dim3(grid), dim3(256), 0, st, x, gpre, partial, d, (int)nb32);
+      }
+      nparts = (int)grid;
     } else if (nbricks < 0x7fffffffLL) {
       // two output rows per brick (15 staged window rows instead of 18, half the barriers per MFMA); LIFTREG_WGRAD_ROWS=1
       // selects the one-row bricks (A/B aid; partial sums then add in another order: equal to rounding)

@@ -294,3 +294,48 @@ def test_bf16_training_sign_mask_of_first_block_gives_the_same_gradients(grad_dt
         pos = (yp.float() > 0).reshape(B, 12, 10, 64, 4, 4).to(torch.uint8)
         want = pos[..., 0] | (pos[..., 1] << 1) | (pos[..., 2] << 2) | (pos[..., 3] << 3)
         assert torch.equal(m, want)
+
+
+def test_wgrad_split_operands_accuracy(monkeypatch):
+    """Block 1's fp32 weight gradient on the bf16 MFMA with exact three-way bf16 splits of both operands
+    (conv3d_wgrad_cl_split_kernel, LIFTREG_WGRAD_SPLIT=1, 6 of the 9 partial products): against an fp64 reference it is at
+    least as accurate as the default fp32-MFMA kernel, for plain and parity-split x, ragged row ends and
+    both output widths."""
+    from liftreg_amd import ops, ops_bwd
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(31)
+    for cout, shape, B, hps in ((32, (10, 12, 72), 2, True), (32, (7, 9, 38), 1, False), (16, (6, 8, 130), 1, True)):
+        D, W, H = shape
+        x = rs.normal(0, 1, (B, 16, D, W, H)).astype(np.float32)
+        o = lambda n: (n - 1) // 2 + 1
+        g = rs.normal(0, 1, (B, cout, o(D), o(W), o(H))).astype(np.float32)
+        xt = torch.from_numpy(x).double()
+        wt = torch.zeros((cout, 16, 3, 3, 3), dtype=torch.float64, requires_grad=True)
+        torch.nn.functional.conv3d(xt, wt, None, stride=2, padding=1).backward(torch.from_numpy(g).double())
+        want = wt.grad.numpy()
+        want_b = g.astype(np.float64).sum(axis=(0, 2, 3, 4))
+        xd = torch.from_numpy(x).to(dev).permute(0, 2, 3, 4, 1).contiguous()
+        lay = ops.LAYOUT_NDHWC
+        if hps:
+            h = torch.arange(H, device=dev)
+            inv = torch.empty(H, dtype=torch.long, device=dev)
+            inv[(h & 1) * (H // 2) + (h >> 1)] = h
+            xd = xd[:, :, :, inv].contiguous()
+            lay = ops.LAYOUT_NDHWC_HPS
+        gd = torch.from_numpy(g).to(dev).permute(0, 2, 3, 4, 1).contiguous()
+        w = torch.zeros((cout, 16, 3, 3, 3), device=dev)
+        y = torch.ones_like(gd)
+
+        def run():
+            _, gw, gb = ops_bwd.conv3d_bwd(xd, lay, w, y, ops.LAYOUT_NDHWC, gd, ops.LAYOUT_NDHWC, 2, gy_is_gpre=True, need_gx=False, nblk=16)
+            return gw.cpu().numpy().astype(np.float64), gb.cpu().numpy().astype(np.float64)
+
+        gw_f, gb_f = run()
+        monkeypatch.setenv("LIFTREG_WGRAD_SPLIT", "1")
+        gw_s, gb_s = run()
+        monkeypatch.delenv("LIFTREG_WGRAD_SPLIT")
+        scale = np.abs(want).max()
+        es, ef = np.abs(gw_s - want).max() / scale, np.abs(gw_f - want).max() / scale
+        assert es <= 3e-6 and es <= 1.5 * ef + 2e-7, (cout, shape, es, ef)
+        assert np.abs(gb_s - want_b).max() <= 3e-6 * np.abs(want_b).max() + 1e-4, (cout, shape)
+        assert not np.array_equal(gw_s, gw_f) or scale == 0     # the two kernels really are different code paths
