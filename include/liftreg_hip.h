@@ -278,6 +278,16 @@ int lr_ncc_loss_from_moments(const double* moments, float* loss, float* ncc_rows
  */
 int lr_disp_reg_f32(const float* disp, double* partial, float* out, int B, int D, int W, int H,
                     int nblk, void* stream);
+/* The same regulariser evaluated in COEFFICIENT space (training, subspace model): the field is affine in the PCA
+ * coefficients (src/liftreg/models/LiftRegDeformSubspaceBackproj.py:102: disp = coefs . basis^T + mean) and the
+ * regulariser (src/liftreg/losses/SubspaceLoss.py:51-67) is a quadratic form of the field, so
+ *     R = r0 + (1/B) sum_b (2 lin.c_b + c_b^T gram c_b),   dR/dc_b = (2 lin + 2 gram c_b) / B
+ * with gram[k][k'] = q(basis_k, basis_k'), lin[k] = q(mean, basis_k), r0 = q(mean, mean) for q = the bilinear form
+ * of lr_disp_reg_f32 (computed once per basis with lr_disp_reg_bwd_f32 + lr_pca_bwd_coef_f32: ops.subspace_reg_gram).
+ * coefs: dev (B,L) fp32; gram: dev (L,L) fp64; lin: dev (L) fp64; r0: dev 1 fp64; out: dev 1 float;
+ * gcoefs: dev (B,L) fp32 = dR/dcoefs, nullable. */
+int lr_subspace_reg_f32(const float* coefs, const double* gram, const double* lin, const double* r0, float* out,
+                        float* gcoefs, int B, int L, void* stream);
 
 /* ========================================================================
  * Backward kernels of the training step (the reference gets these from ATen autograd at

@@ -60,6 +60,7 @@ SIGNATURES = {
     "lr_ncc_moments_f32": (_i, [_p, _p, _p, _p, _i, _i64, _i, _p]),
     "lr_ncc_loss_from_moments": (_i, [_p, _p, _p, _i, _i64, _i, _i, _p]),
     "lr_disp_reg_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "lr_subspace_reg_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "lr_ncc_bwd_f32": (_i, [_p, _p, _p, _p, _p, _i, _i64, _i64, _i, _p]),
     "lr_warp_bwd_disp_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "lr_warp_bwd_disp_acc_f32": (_i, [_p] * 9 + [_i, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -270,3 +270,18 @@ class DispRegFn(torch.autograd.Function):
     def backward(ctx, gout):
         (disp,) = ctx.saved_tensors
         return ops_bwd.disp_reg_bwd(disp.contiguous(), gout)
+
+
+class SubspaceRegFn(torch.autograd.Function):
+    """The regulariser on the PCA coefficients (ops.subspace_reg): forward and gradient come out of one tiny kernel."""
+
+    @staticmethod
+    def forward(ctx, coefs, gram, lin, r0):
+        out, gc = ops.subspace_reg(coefs.contiguous(), gram, lin, r0, want_grad=True)
+        ctx.save_for_backward(gc)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (gc,) = ctx.saved_tensors
+        return gc * gout, None, None, None

@@ -478,3 +478,41 @@ extern "C" int lr_disp_reg_f32(const float* disp, double* partial, float* out, i
                      (double)B * D * W * H);
   return lr_launch_status();
 }
+
+// ------------------------------------------------------------------- the regulariser in coefficient space
+// The model's displacement field is affine in the PCA coefficients (disp_b = mean + sum_k c_bk * basis_k) and the
+// regulariser is a quadratic form of the field, so with  G[k][k'] = q(basis_k, basis_k'),  h[k] = q(mean, basis_k),
+// r0 = q(mean, mean)  (q = the bilinear form of lr_disp_reg_f32, computed once per basis with the field kernels)
+//     R = r0 + (1/B) sum_b (2 h.c_b + c_b^T G c_b),      dR/dc_b = (2 h + 2 G c_b) / B
+// — B x L numbers instead of a pass over the (B,3,D,W,H) field forward and two passes backward.  One block; fp64.
+namespace {
+__global__ __launch_bounds__(256) void subspace_reg_kernel(const float* __restrict__ coefs, const double* __restrict__ G,
+                                                           const double* __restrict__ h, const double* __restrict__ r0,
+                                                           float* __restrict__ out, float* __restrict__ gcoefs, int B, int L) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < B * L; i += 256) {
+    const int b = i / L, k = i - b * L;
+    double gc = 0.0;
+    for (int j = 0; j < L; ++j) gc += G[(int64_t)k * L + j] * (double)coefs[b * L + j];
+    const double c = (double)coefs[i];
+    acc += c * (2.0 * h[k] + gc);
+    if (gcoefs) gcoefs[i] = (float)((2.0 * h[k] + 2.0 * gc) / (double)B);
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(r0[0] + red[0] / (double)B);
+}
+}  // namespace
+
+extern "C" int lr_subspace_reg_f32(const float* coefs, const double* gram, const double* lin, const double* r0, float* out,
+                                   float* gcoefs, int B, int L, void* stream) {
+  if (!coefs || !gram || !lin || !r0 || !out) return LR_ENULL;
+  if (B < 1 || L < 1 || L > 4096 || (int64_t)B * L > (1 << 24)) return LR_EINVAL;
+  hipLaunchKernelGGL(subspace_reg_kernel, dim3(1), dim3(256), 0, lr_stream(stream), coefs, gram, lin, r0, out, gcoefs, B, L);
+  return lr_launch_status();
+}

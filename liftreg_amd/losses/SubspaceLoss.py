@@ -7,7 +7,8 @@ Drop-in for `train.loss_class` (interface of the reference's src/liftreg/losses/
 
     total = similarity(warped, target) + λ(epoch) · R(params)
     λ(epoch) = max(sigmoid_decay(epoch, static=reg_factor_decay_from, k=2) · initial_reg_factor, min_reg_factor)
-    R        = mean over voxels of Σ_{component, axis} (∂_axis disp_component)²      (one streaming HIP pass)
+    R        = mean over voxels of Σ_{component, axis} (∂_axis disp_component)²      (one streaming HIP pass — or, when the
+               model hands over "pca_coefs" and "pca_reg_gram", the same quadratic form evaluated on the coefficients)
 
 R's finite-difference stencil lives in `mermaid` (un-vendored, absent from the reference checkout): PARITY UNPINNED,
 the assumed stencil is documented in liftreg_amd/csrc/reg.hip.  Both terms are autograd nodes whose backward runs
@@ -15,7 +16,7 @@ HIP kernels (liftreg_amd.autograd), so `out["total_loss"].backward()` works as i
 """
 import torch.nn as nn
 
-from ..autograd import DispRegFn
+from ..autograd import DispRegFn, SubspaceRegFn
 from ..utils.general import get_class
 from ..utils.utils import sigmoid_decay
 
@@ -63,6 +64,12 @@ class loss(nn.Module):
             similarity = self.sim(input["warped"], input["target"], moments=moments)
         else:
             similarity = self.sim(input["warped"], input["target"])
-        smoothness = self.compute_reg_loss(input["params"])
+        gram = input.get("pca_reg_gram") if hasattr(input, "get") else None
+        if gram is not None and input.get("pca_coefs") is not None:
+            # the subspace model in training: params = pca_coefs . basis^T + mean, so R(params) is a quadratic form of the
+            # coefficients — the same number to fp32 rounding, without the passes over the field (model opt key reg_in_coef_space)
+            smoothness = SubspaceRegFn.apply(input["pca_coefs"], *gram)
+        else:
+            smoothness = self.compute_reg_loss(input["params"])
         total = self.sim_factor * similarity + self.get_reg_factor(input["epoch"]) * smoothness
         return {"total_loss": total, "sim_loss": similarity.item(), "reg_loss": smoothness.item()}

@@ -149,6 +149,13 @@ class model(nn.Module):
         # are one autograd node whose backward computes block 1's data gradient and block 0's weight gradient in one kernel
         # (autograd.ConvPair01Fn); False = one node per block (the gradient between them goes through memory)
         self.fuse_first_backward = bool(_opt(opt, "fuse_first_backward", True))
+        # optional (non-reference) key "reg_in_coef_space" (default True): in training the output dict also carries
+        # "pca_reg_gram" = the regulariser's quadratic form on the PCA basis (ops.subspace_reg_gram, computed once per
+        # basis), so that liftreg_amd.losses.SubspaceLoss evaluates R(params) and its gradient on the (B,L) coefficients
+        # instead of streaming the (B,3,D,W,H) field once forward and twice backward — the same number to fp32 rounding
+        # (params = coefs . basis^T + mean is affine in the coefficients and R is a quadratic form of the field)
+        self.reg_in_coef_space = bool(_opt(opt, "reg_in_coef_space", True))
+        self._reg_gram = None      # (key, (gram, lin, r0))
         self._poses = None         # geometry of the first batch's element 0, cached like :85-87
         self._packed = {}          # conv weights in MFMA operand order, keyed by parameter version
         self._pca_slabs = {}       # compact per-rank column slabs of the basis (pca_slab)
@@ -196,6 +203,16 @@ class model(nn.Module):
             self.pca_mean = torch.zeros((M,), dtype=torch.float32, device=device)
         elif self.pca_dtype == "bf16" and self.pca_vectors_LxM.dtype != torch.bfloat16:
             self.pca_vectors_LxM = self._basis_storage(self.pca_vectors_LxM)     # a basis loaded from pca_path
+
+    def reg_gram(self):
+        """(gram, lin, r0) of ops.subspace_reg_gram for the resident basis, computed on first use and kept until the
+        basis tensor changes (one pass of the regulariser's gradient kernel and of the PCA-gradient kernel per 8 rows)."""
+        vec, mu = self.pca_vectors_LxM, self.pca_mean
+        key = (vec.data_ptr(), vec._version, mu.data_ptr(), mu._version, str(vec.device), tuple(vec.shape))
+        if self._reg_gram is None or self._reg_gram[0] != key:
+            with torch.no_grad():
+                self._reg_gram = (key, ops.subspace_reg_gram(vec, mu, self.img_sz))
+        return self._reg_gram[1]
 
     def pca_slab(self, d0, d1, device):
         """(basis (L, 3·Dn·W·H), mean (3·Dn·W·H,)): the COMPACT column slab of rows [d0,d1) of D — what one rank of a
@@ -411,7 +428,11 @@ class model(nn.Module):
 
         coefs = self.encode(moving, target_proj, input['target_poses'])
         disp_field, deform_field, warped_source, *mom = self.decode(moving, coefs, moving_seg, target=target_cp)
+        extra = {}
+        if self.reg_in_coef_space and torch.is_grad_enabled() and coefs.requires_grad:
+            extra["pca_reg_gram"] = self.reg_gram()      # training: the regulariser on the coefficients (SubspaceLoss)
         return {**({"ncc_moments": mom[0]} if mom else {}),      # only with the non-reference opt key fuse_ncc
+                **extra,
                 "warped": warped_source,
                 "phi": deform_field,
                 "params": disp_field,

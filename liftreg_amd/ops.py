@@ -808,6 +808,52 @@ def disp_reg(disp, nblk=None):
     return out
 
 
+def subspace_reg_gram(basis_LxM, mean, img_sz):
+    """(gram (L,L) fp64, lin (L,) fp64, r0 (1,) fp64) of the regulariser's bilinear form q on the PCA basis:
+    gram[k][k'] = q(basis_k, basis_k'), lin[k] = q(mean, basis_k), r0 = q(mean, mean), with q(u,u) = disp_reg(u) for one
+    field — what `subspace_reg` needs to evaluate the regulariser (reference losses/SubspaceLoss.py:51-67) on the
+    coefficients instead of on the field.  One-off per basis, computed with the FIELD kernels so that both routes share the
+    stencil: A·u comes from the regulariser's own gradient kernel (8 basis rows at a time as a batch of fields), the inner
+    products with all rows from the PCA-gradient kernel with its partial sums added in fp64."""
+    from . import ops_bwd
+    L, M = basis_LxM.shape
+    D, W, H = (int(v) for v in img_sz)
+    if M != 3 * D * W * H or mean.numel() != M:
+        raise ValueError("basis / mean do not match the image size")
+    dev = basis_LxM.device
+    one = torch.ones((), dtype=torch.float32, device=dev)
+    gram = torch.empty((L, L), dtype=torch.float64, device=dev)
+    for k0 in range(0, L, 8):
+        k1 = min(L, k0 + 8)
+        n = k1 - k0
+        fields = basis_LxM[k0:k1].to(torch.float32).contiguous().view(n, 3, D, W, H)   # (a view for an fp32 basis)
+        g = ops_bwd.disp_reg_bwd(fields, one)              # d/du_i of (1/n) sum_i q(u_i,u_i) = (2/n) A u_i
+        gram[k0:k1] = ops_bwd.pca_bwd_coef_f64(g, basis_LxM) * (n / 2.0)
+        del g, fields
+    gram = 0.5 * (gram + gram.t())
+    mu = mean.to(torch.float32).contiguous().view(1, 3, D, W, H)
+    g = ops_bwd.disp_reg_bwd(mu, one)                      # 2 A mean
+    lin = ops_bwd.pca_bwd_coef_f64(g, basis_LxM)[0] * 0.5
+    r0 = disp_reg(mu).to(torch.float64).reshape(1)
+    return gram.contiguous(), lin.contiguous(), r0
+
+
+def subspace_reg(coefs, gram, lin, r0, want_grad=True):
+    """The regulariser of SubspaceLoss evaluated on the PCA coefficients: R = r0 + mean_b(2 lin.c_b + c_b^T gram c_b)
+    (see `subspace_reg_gram`).  Returns (R as a 0-d fp32 tensor, dR/dcoefs (B,L) fp32 or None)."""
+    coefs = _dev(coefs, "coefs")
+    B, L = coefs.shape
+    if tuple(gram.shape) != (L, L) or tuple(lin.shape) != (L,) or gram.dtype != torch.float64 or lin.dtype != torch.float64 or \
+            r0.dtype != torch.float64 or not (gram.is_cuda and lin.is_cuda and r0.is_cuda) or not gram.is_contiguous():
+        raise ValueError("gram / lin / r0 must be contiguous float64 GPU tensors of shapes (L,L) / (L,) / (1,)")
+    out = torch.empty((), dtype=torch.float32, device=coefs.device)
+    gc = torch.empty_like(coefs) if want_grad else None
+    with _timed("subspace_reg", bytes=8 * L * L):
+        _hip.check(_hip.lib().lr_subspace_reg_f32(coefs.data_ptr(), gram.data_ptr(), lin.data_ptr(), r0.data_ptr(),
+                                                  out.data_ptr(), _ptr(gc), B, L, _stream()), "lr_subspace_reg_f32")
+    return out, gc
+
+
 # ----------------------------------------------------------------------------- f3/f4: prologue and evaluation
 def normalize_clip(img, lo, hi, out=None):
     """((clamp(img, lo, hi) - lo)/(hi - lo))*2 - 1 — the dataset's intensity normalisation

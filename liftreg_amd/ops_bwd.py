@@ -76,6 +76,25 @@ def pca_bwd_coef(gdisp, basis_LxM, nblk=None):
     return gcoefs
 
 
+def pca_bwd_coef_f64(gdisp, basis_LxM, nblk=2048):
+    """`pca_bwd_coef` with the kernel's per-block fp32 partial sums added in fp64 — for one-off precomputations
+    (ops.subspace_reg_gram), not for the training step.  Returns (B,L) float64."""
+    gdisp = _dev(gdisp, "gdisp")
+    B = gdisp.shape[0]
+    g2 = gdisp.reshape(B, -1)
+    L, M = basis_LxM.shape
+    if g2.shape[1] != M or basis_LxM.stride(1) != 1 or B > 8:
+        raise ValueError("gdisp/basis shape mismatch (at most 8 rows)")
+    nblk = max(8, (min(int(nblk), M // 1024 + 8) // 8) * 8)     # a multiple of 8: the vector kernel launches whole groups of 8 blocks
+    partial = torch.zeros((nblk, B, L), dtype=torch.float32, device=gdisp.device)
+    gcoefs = torch.empty((B, L), dtype=torch.float32, device=gdisp.device)
+    bf = basis_LxM.dtype == torch.bfloat16
+    fn = _hip.lib().lr_pca_bwd_coef_bf16basis_f32 if bf else _hip.lib().lr_pca_bwd_coef_f32
+    _hip.check(fn(g2.data_ptr(), basis_LxM.data_ptr(), partial.data_ptr(), gcoefs.data_ptr(), B, L, M,
+                  basis_LxM.stride(0), M, nblk, _stream()), "lr_pca_bwd_coef_f32")
+    return partial.to(torch.float64).sum(0)
+
+
 def _act_dims(t, layout):
     """(B, C, D, W, H) of an activation tensor stored in `layout`."""
     if layout in (_hip.LAYOUT_NCDHW, _hip.LAYOUT_NCDHW_RBF16):

@@ -172,6 +172,58 @@ def test_training_step_runs_no_library_compute_kernel(dev):
         assert forbidden not in text, forbidden
     ours = ("conv3d_planar_kernel", "conv3d_cl_rows_kernel",   # (small planes: the direct stride-2 kernel)
             "conv3d_dgrad", "conv3d_wgrad", "backproject", "pca_warp_kernel",
-            "pca_bwd_kernel", "warp_bwd", "ncc_moments_kernel", "ncc_bwd", "linear_kernel", "disp_reg")
+            "pca_bwd_kernel", "warp_bwd", "ncc_moments_kernel", "ncc_bwd", "linear_kernel", "subspace_reg_kernel")
     missing = [k for k in ours if k not in text]
     assert not missing, missing
+    assert "disp_reg" not in text      # the regulariser runs on the coefficients: no pass over the field in the step
+
+
+@pytest.mark.parametrize("pca_dtype,labels", [("fp32", False), ("bf16", True)])
+def test_regulariser_in_coefficient_space_equals_field_path(dev, pca_dtype, labels):
+    """Model opt key reg_in_coef_space (default on): SubspaceLoss evaluates R(params) on the PCA coefficients through the
+    precomputed quadratic form (ops.subspace_reg_gram / lr_subspace_reg_f32) — the same loss and the same parameter
+    gradients as the passes over the (B,3,D,W,H) field (reference losses/SubspaceLoss.py:51-67), for a non-zero mean and a
+    bf16-stored basis too.  The regulariser's factor is raised so that its gradient dominates the step."""
+    from liftreg_amd import ops, ops_bwd
+    from liftreg_amd.losses.SubspaceLoss import loss as SubspaceLoss
+    from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+    shape, P, L, B = (32, 28, 36), 2, 6, 3
+    torch.manual_seed(11)
+    net = model(list(shape), {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:11", "pca_dtype": pca_dtype}).to(dev).train()
+    inp = _inputs(shape, P, 32, B, 11, labels)
+    dinp = {k: v.to(dev) if k != "target_poses" else v for k, v in inp.items()}
+    net._ensure_pca(dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    net.pca_mean = torch.empty_like(net.pca_mean).normal_(0.0, 0.01, generator=g)      # the synthetic mean is zero
+    crit = SubspaceLoss({"initial_reg_factor": 50.0, "min_reg_factor": 50.0, "reg_factor_decay_from": 2})
+
+    def step(coef_space):
+        net.reg_in_coef_space = coef_space
+        net.zero_grad()
+        out = net(dinp)
+        assert ("pca_reg_gram" in out) == coef_space
+        out["epoch"] = 0
+        res = crit(out)
+        res["total_loss"].backward()
+        return res, {k: p.grad.clone() for k, p in net.named_parameters()}, out
+
+    res_f, grads_f, out_f = step(False)
+    res_c, grads_c, out_c = step(True)
+    assert res_f["reg_loss"] > 0
+    assert abs(res_c["reg_loss"] - res_f["reg_loss"]) <= 2e-6 * abs(res_f["reg_loss"])
+    assert abs(float(res_c["total_loss"].detach()) - float(res_f["total_loss"].detach())) <= 2e-6 * abs(float(res_f["total_loss"].detach()))
+    for k in grads_f:
+        scale = float(grads_f[k].abs().max())
+        assert scale > 0, k
+        assert float((grads_c[k] - grads_f[k]).abs().max()) <= 2e-4 * scale, k
+    # the op itself against the field kernels, on the step's own coefficients
+    coefs = out_c["pca_coefs"].detach()
+    gram, lin, r0 = net.reg_gram()
+    r_c, g_c = ops.subspace_reg(coefs, gram, lin, r0)
+    disp = out_f["params"].detach()
+    r_f = ops.disp_reg(disp)
+    g_f = ops_bwd.pca_bwd_coef(ops_bwd.disp_reg_bwd(disp, torch.ones((), device=dev)), net.pca_vectors_LxM)
+    assert abs(float(r_c) - float(r_f)) <= 2e-6 * float(r_f)
+    assert float((g_c - g_f).abs().max()) <= 2e-5 * float(g_f.abs().max())
+    assert float((gram - gram.t()).abs().max()) == 0.0 and float(torch.linalg.eigvalsh(gram.cpu()).min()) > -1e-9 * float(gram.abs().max())
