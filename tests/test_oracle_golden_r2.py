@@ -49,3 +49,29 @@ def test_landmark_tre(golden):
     assert np.array_equal(warped.numpy(), g["warped"])
     assert tre == float(g["tre"]) and np.array_equal(np.array(xyz), g["tre_xyz"])
     assert (g["warped"][:4] == 0).any()          # the fixture does hold landmarks outside the map (zeros padding)
+
+
+def test_regulariser_is_a_quadratic_form_of_the_pca_coefficients():
+    """The identity behind lr_subspace_reg_f32 / ops.subspace_reg_gram, on the oracle alone (fp64): the field is affine in
+    the coefficients (…Backproj.py:102) and compute_reg_loss (losses/SubspaceLoss.py:51-67) is a quadratic form of the
+    field, so R(mean + c·basis) = r0 + mean_b(2 lin·c_b + c_b^T G c_b) with G, lin, r0 the form's values on the basis."""
+    import torch
+    rs = np.random.RandomState(4)
+    L, B, shape = 4, 3, (6, 5, 8)
+    basis = torch.from_numpy(rs.normal(0, 1, (L, 3) + shape))
+    mean = torch.from_numpy(rs.normal(0, 1, (3,) + shape))
+    coefs = torch.from_numpy(rs.normal(0, 1, (B, L)))
+    r = lambda f: ro.disp_reg(f[None])                                   # one field
+    q = lambda u, w: (r(u + w) - r(u - w)) / 4                          # polarisation
+    G = torch.stack([torch.stack([q(basis[k], basis[j]) for j in range(L)]) for k in range(L)])
+    lin = torch.stack([q(mean, basis[k]) for k in range(L)])
+    r0 = r(mean)
+    disp = mean[None] + torch.einsum("bl,lcdwh->bcdwh", coefs, basis)
+    want = ro.disp_reg(disp)
+    got = r0 + (2 * coefs @ lin + ((coefs @ G) * coefs).sum(1)).mean()
+    assert abs(float(got) - float(want)) <= 1e-12 * abs(float(want))
+    # and its gradient w.r.t. the coefficients
+    c = coefs.clone().requires_grad_(True)
+    ro.disp_reg(mean[None] + torch.einsum("bl,lcdwh->bcdwh", c, basis)).backward()
+    gc = (2 * lin[None] + 2 * coefs @ G) / B
+    assert float((c.grad - gc).abs().max()) <= 1e-12 * float(gc.abs().max())
