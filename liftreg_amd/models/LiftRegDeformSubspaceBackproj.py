@@ -429,7 +429,7 @@ class model(nn.Module):
         coefs = self.encode(moving, target_proj, input['target_poses'])
         disp_field, deform_field, warped_source, *mom = self.decode(moving, coefs, moving_seg, target=target_cp)
         extra = {}
-        if self.reg_in_coef_space and torch.is_grad_enabled() and coefs.requires_grad:
+        if self.reg_in_coef_space and torch.is_grad_enabled() and coefs.requires_grad and self.pca_vectors_LxM.is_cuda:
             extra["pca_reg_gram"] = self.reg_gram()      # training: the regulariser on the coefficients (SubspaceLoss)
         return {**({"ncc_moments": mom[0]} if mom else {}),      # only with the non-reference opt key fuse_ncc
                 **extra,
