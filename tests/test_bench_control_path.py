@@ -101,3 +101,26 @@ def test_training_two_ranks_on_one_gpu_same_data_equals_single_process():
     two = _launch(2, args + ["--same-data"], env, script=tb)
     assert two["n_gpus"] == 2 and two["global_batch"] == 2 and "data parallel x2" in two["parallelism"]
     assert two["losses"] == pytest.approx(one["losses"], rel=2e-4, abs=1e-6), (one["losses"], two["losses"])
+
+
+def test_sclk_sampler_parses_sysfs_and_degrades_to_none(tmp_path, monkeypatch):
+    """bench.SclkSampler: reads the starred level of a pp_dpm_sclk file; without the file (this container, or a driver that
+    does not expose it) the roofline's sclk_mhz is None and nothing else changes."""
+    import importlib.util
+    import os
+    import time
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    s = bench.SclkSampler(0)
+    if s.path is None:                       # no GPU here
+        with s:
+            pass
+        assert s.median() is None
+    f = tmp_path / "pp_dpm_sclk"
+    f.write_text("0: 500Mhz\n1: 2245Mhz *\n2: 2400Mhz\n")
+    s = bench.SclkSampler(0)
+    s.path = str(f)
+    with s:
+        time.sleep(0.2)
+    assert s.median() == 2245.0

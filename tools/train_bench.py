@@ -49,6 +49,7 @@ def main():
                     help="every rank trains on the SAME batch (test hook: the averaged gradient then equals one rank's, "
                          "so the loss trajectory must equal the single-process run's)")
     ap.add_argument("--no-kernel-table", action="store_true")
+    ap.add_argument("--adam-foreach", action="store_true", help="torch's default (multi-pass) Adam instead of fused=True (A/B aid)")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo control-path self-test with a stand-in module")
     a = ap.parse_args()
     c = CONFIGS[a.config]
@@ -122,7 +123,9 @@ def main():
             out["epoch"] = ep
             return crit(out)["total_loss"]
 
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4, eps=1e-5)     # RegistrationNet.py:245
+    # RegistrationNet.py:245 (Adam, eps 1e-5).  fused=True is torch's own single-kernel implementation of the same update
+    # (one pass over p, g, m, v instead of the default's ~8 elementwise passes); --adam-foreach selects the default
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, eps=1e-5, **({} if (a.adam_foreach or a.dry_run) else {"fused": True}))
     ddp = GradientAllReduce(net) if (world > 1 or a.ddp) else None
 
     def step(ep):
