@@ -309,6 +309,19 @@ int lr_warp_bwd_disp_acc_f32(const float* img, const float* seg, const float* di
                              const float* id1, const float* id2, const float* gwarped, const float* gadd,
                              float* gdisp, int B, int C, int D, int W, int H, int d0, int d1, int flags,
                              void* stream);
+/* The similarity's gradient THROUGH ITS MOMENTS (training; replaces the pass of lr_ncc_bwd_f32 over both volumes):
+ * lr_ncc_bwd_moments: gmoments (R,5) fp64 = d loss / d (sum x, sum y, sum xy, sum x^2, sum y^2) for the loss of
+ * lr_ncc_loss_from_moments (layers/losses.py:14-29; layers.py:238-255), gout = dev pointer to the upstream scalar.
+ * lr_warp_bwd_disp_ncc_f32: lr_warp_bwd_disp[_acc]_f32 for single-channel images with the gradient of `warped` formed on
+ * the fly, gw_i = gm0 + gm2 * target_i + 2 gm3 * warped_i (the chain rule through the moments), instead of read from a
+ * tensor; gadd nullable; LR_EUNSUPPORTED where the vectorised kernel does not apply (H % 4, alignment): materialise the
+ * gradient with lr_ncc_bwd_f32 then. */
+int lr_ncc_bwd_moments(const double* moments, const float* gout, double* gmoments, int R, int64_t n_total,
+                       int variant, void* stream);
+int lr_warp_bwd_disp_ncc_f32(const float* img, const float* disp, const float* id0, const float* id1,
+                             const float* id2, const float* warped, const float* target, const double* gmoments,
+                             const float* gadd, float* gdisp, int B, int D, int W, int H, int d0, int d1,
+                             int flags, void* stream);
 /* d/d coefs of lr_pca_reconstruct_f32: gcoefs (B,L) = gdisp (B,M) · basis^T.  B <= 8.
  * partial: dev workspace nblk*B*L floats. */
 int lr_pca_bwd_coef_f32(const float* gdisp, const float* basis, float* partial, float* gcoefs, int B,

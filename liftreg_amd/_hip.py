@@ -64,6 +64,8 @@ SIGNATURES = {
     "lr_ncc_bwd_f32": (_i, [_p, _p, _p, _p, _p, _i, _i64, _i64, _i, _p]),
     "lr_warp_bwd_disp_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "lr_warp_bwd_disp_acc_f32": (_i, [_p] * 9 + [_i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "lr_ncc_bwd_moments": (_i, [_p, _p, _p, _i, _i64, _i, _p]),
+    "lr_warp_bwd_disp_ncc_f32": (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _i, _i, _p]),
     "lr_pca_bwd_coef_f32": (_i, [_p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _i, _p]),
     "lr_linear_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p]),
     "lr_lrelu_bwd_f32": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),

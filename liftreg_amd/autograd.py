@@ -208,32 +208,40 @@ class DecodeFn(torch.autograd.Function):
     the warp-gradient kernel (`gadd`) instead of by a pass of autograd's own, then projected onto the basis."""
 
     @staticmethod
-    def forward(ctx, coefs, basis_LxM, mean, img, id0, id1, id2, seg, using_scale):
+    def forward(ctx, coefs, basis_LxM, mean, img, id0, id1, id2, seg, using_scale, target=None):
+        """`target` (B,1,D,W,H), single-channel images without a label mask: a 4th output = the similarity's five fp64
+        moments of (warped, target) as a DIFFERENTIABLE result of this node — a loss that is a function of them (NCCFn) sends
+        its gradient back as (B,5) numbers and the warp-gradient kernel forms d loss / d warped on the fly
+        (ops_bwd.warp_bwd_disp_ncc) instead of reading it from a tensor another pass wrote."""
         B, _, D, W, H = img.shape
         if seg is None and ops.pca_warp_supported(coefs, basis_LxM, img):
             disp, phi, warped = ops.pca_warp(coefs, basis_LxM, mean, (id0, id1, id2), img, using_scale=using_scale)
         else:
             disp = ops.pca_reconstruct(coefs, basis_LxM, mean).view(B, 3, D, W, H)
             phi, warped = ops.warp(img, disp, (id0, id1, id2), seg, using_scale=using_scale, zero_boundary=True)
-        ctx.save_for_backward(basis_LxM, img, disp, id0, id1, id2, seg if seg is not None else img.new_empty(0))
-        ctx.cfg = (using_scale, seg is not None)
+        with_m = target is not None
+        ctx.save_for_backward(basis_LxM, img, disp, id0, id1, id2, seg if seg is not None else img.new_empty(0),
+                              warped if with_m else img.new_empty(0), target if with_m else img.new_empty(0))
+        ctx.cfg = (using_scale, seg is not None, with_m)
         ctx.set_materialize_grads(False)
+        if with_m:
+            return disp, phi, warped, ops.ncc_moments(warped, target, B)
         return disp, phi, warped
 
     @staticmethod
-    def backward(ctx, gdisp, gphi, gwarped):
-        basis, img, disp, id0, id1, id2, seg = ctx.saved_tensors
-        using_scale, has_seg = ctx.cfg
+    def backward(ctx, gdisp, gphi, gwarped, gmoments=None):
+        basis, img, disp, id0, id1, id2, seg, warped, target = ctx.saved_tensors
+        using_scale, has_seg, with_m = ctx.cfg
         direct = gdisp if gphi is None else (gphi if gdisp is None else gdisp + gphi)   # phi = disp + id
+        g = None if direct is None else direct.contiguous()
         if gwarped is not None:
             g = ops_bwd.warp_bwd_disp(img, disp, (id0, id1, id2), seg if has_seg else None, gwarped.contiguous(),
-                                      using_scale=using_scale, zero_boundary=True,
-                                      gadd=None if direct is None else direct.contiguous())
-        else:
-            g = direct
+                                      using_scale=using_scale, zero_boundary=True, gadd=g)
+        if with_m and gmoments is not None:        # the similarity's gradient arrives through the moments
+            g = ops_bwd.warp_bwd_disp_ncc(img, disp, (id0, id1, id2), warped, target, gmoments, using_scale=using_scale, gadd=g)
         if g is None:
-            return (None,) * 9
-        return (ops_bwd.pca_bwd_coef(g.contiguous(), basis),) + (None,) * 8
+            return (None,) * 10
+        return (ops_bwd.pca_bwd_coef(g.contiguous(), basis),) + (None,) * 9
 
 
 class NCCFn(torch.autograd.Function):
@@ -249,14 +257,20 @@ class NCCFn(torch.autograd.Function):
         elif tuple(m.shape) != (rows, 5) or m.dtype != torch.float64 or m.device != x.device:
             raise ValueError(f"moments must be a float64 ({rows},5) tensor on {x.device}")
         loss, _ = ops.ncc_loss_from_moments(m, x.numel() // rows, n_batch, variant)
-        ctx.save_for_backward(x, y, m)
-        ctx.cfg = (variant, x.numel() // rows)
+        # moments that require grad are a differentiable function of (x, y) computed by their producer (DecodeFn): the
+        # gradient then goes back THROUGH them — (rows,5) numbers — and not to x directly (the producer carries it on)
+        via_m = moments is not None and ctx.needs_input_grad[3]
+        ctx.save_for_backward(*((m,) if via_m else (x, y, m)))
+        ctx.cfg = (variant, x.numel() // rows, via_m)
         return loss
 
     @staticmethod
     def backward(ctx, gout):
+        variant, n, via_m = ctx.cfg
+        if via_m:
+            (m,) = ctx.saved_tensors
+            return None, None, None, ops_bwd.ncc_bwd_moments(m, gout, n, variant)
         x, y, m = ctx.saved_tensors
-        variant, n = ctx.cfg
         return ops_bwd.ncc_bwd(x.contiguous(), y.contiguous(), m, gout, n, variant).view_as(x), None, None, None
 
 

@@ -46,6 +46,39 @@ __global__ __launch_bounds__(256) void ncc_bwd_kernel(const float* __restrict__ 
     gr[i] = fmaf(fcy, yr[i] - fmy, fcx * (xr[i] - fmx));
 }
 
+// d loss / d moments (R,5): the similarity as a function of the five sums (sum x, sum y, sum xy, sum x^2, sum y^2) that the
+// decode node produced.  Chain rule to the voxels:  d loss / d x_i = gm0 + gm2 * y_i + 2 gm3 * x_i  — affine in (x_i, y_i),
+// so the warp-gradient kernel forms it on the fly (warp_bwd_fast_kernel<…, NCC>) and ncc_bwd_kernel's pass is not needed.
+__global__ __launch_bounds__(64) void ncc_bwd_moments_kernel(const double* __restrict__ moments, const float* __restrict__ gout,
+                                                             double* __restrict__ gm, int R, double n_total, int variant) {
+  const int r = blockIdx.x * 64 + threadIdx.x;
+  if (r >= R) return;
+  const double* m = moments + (int64_t)r * 5;
+  const double n = n_total;
+  const double mx = m[0] / n, my = m[1] / n;
+  const double cov = m[2] / n - mx * my, vx = fmax(m[3] / n - mx * mx, 0.0), vy = fmax(m[4] / n - my * my, 0.0);
+  const double g = -(double)(*gout) / (double)R;
+  double dcov, dvx, dvy;   // d ncc_r / d cov, vx, vy
+  if (variant == LR_NCC_CONFIGURED) {
+    const double e2 = 1e-20, s = sqrt((vx + e2) * (vy + e2));
+    const double ncc = (cov + e2) / s;
+    dcov = 1.0 / s;
+    dvx = -ncc / (2.0 * (vx + e2));
+    dvy = -ncc / (2.0 * (vy + e2));
+  } else {
+    const double q = vx * vy + 1e-12;
+    dcov = 2.0 * cov / q;
+    dvx = -cov * cov * vy / (q * q);
+    dvy = -cov * cov * vx / (q * q);
+  }
+  double* o = gm + (int64_t)r * 5;
+  o[2] = g * dcov / n;
+  o[3] = g * dvx / n;
+  o[4] = g * dvy / n;
+  o[0] = -o[2] * my - 2.0 * o[3] * mx;
+  o[1] = -o[2] * mx - 2.0 * o[4] * my;
+}
+
 // ------------------------------------------------------------------------------------------------ warp
 struct AxisB {
   int i0, i1;
@@ -170,12 +203,16 @@ __device__ __forceinline__ AxisBF axis_bf(float g, int size) {
   return a;
 }
 
-template <bool SCALE>
+// NCC: the gradient of `warped` is not read but formed from the similarity's moment gradient (ncc_bwd_moments_kernel):
+// gw_i = gm0 + gm2 * target_i + 2 gm3 * warped_i (single-channel images; gw = warped, ncc_y = target, gm = (B,5) fp64)
+template <bool SCALE, bool NCC = false>
 __global__ __launch_bounds__(256) void warp_bwd_fast_kernel(const float* __restrict__ img, const float* __restrict__ disp,
                                                             const float* __restrict__ id0, const float* __restrict__ id1,
                                                             const float* __restrict__ id2, const float* __restrict__ gw,
                                                             float* __restrict__ gdisp, const float* __restrict__ gadd,
-                                                            int C, int D, int W, int H, int Dn, float rcp_hv) {
+                                                            int C, int D, int W, int H, int Dn, float rcp_hv,
+                                                            const float* __restrict__ ncc_y = nullptr,
+                                                            const double* __restrict__ gm = nullptr) {
   const int HV = H >> 2;
   const int t = blockIdx.x * 256 + threadIdx.x;  // float4 index inside plane i
   const int i = blockIdx.y, b = blockIdx.z;
@@ -207,7 +244,14 @@ __global__ __launch_bounds__(256) void warp_bwd_fast_kernel(const float* __restr
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(img + ((int64_t)b * C + c) * V), (short)0, (int)(V * 4), 0x00020000);
     const float4 g4 = *reinterpret_cast<const float4*>(gw + ((int64_t)b * C + c) * slabV + (int64_t)i * sD + inplane);
-    const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+    float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+    if constexpr (NCC) {
+      const float4 y4 = *reinterpret_cast<const float4*>(ncc_y + ((int64_t)b * C + c) * slabV + (int64_t)i * sD + inplane);
+      const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+      const float c0 = (float)gm[b * 5 + 0], cy = (float)gm[b * 5 + 2], cx = (float)(2.0 * gm[b * 5 + 3]);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) gv[v] = fmaf(cy, yv[v], fmaf(cx, gv[v], c0));
+    }
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const AxisBF ax = axis_bf(p2[v], H), ay = axis_bf(p1[v], W), az = axis_bf(p0[v], D);
@@ -507,6 +551,41 @@ extern "C" int lr_warp_bwd_disp_f32(const float* img, const float* seg, const fl
                                     const float* id1, const float* id2, const float* gwarped, float* gdisp, int B,
                                     int C, int D, int W, int H, int d0, int d1, int flags, void* stream) {
   return warp_bwd_impl(img, seg, disp, id0, id1, id2, gwarped, gdisp, nullptr, B, C, D, W, H, d0, d1, flags, stream);
+}
+
+extern "C" int lr_ncc_bwd_moments(const double* moments, const float* gout, double* gmoments, int R, int64_t n_total,
+                                  int variant, void* stream) {
+  if (!moments || !gout || !gmoments) return LR_ENULL;
+  if (R < 1 || n_total < 1) return LR_EINVAL;
+  if (variant != LR_NCC_CONFIGURED && variant != LR_NCC_SQUARED) return LR_EUNSUPPORTED;
+  hipLaunchKernelGGL(ncc_bwd_moments_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, lr_stream(stream), moments, gout, gmoments,
+                     R, (double)n_total, variant);
+  return lr_launch_status();
+}
+
+extern "C" int lr_warp_bwd_disp_ncc_f32(const float* img, const float* disp, const float* id0, const float* id1,
+                                        const float* id2, const float* warped, const float* target, const double* gmoments,
+                                        const float* gadd, float* gdisp, int B, int D, int W, int H, int d0, int d1,
+                                        int flags, void* stream) {
+  if (!img || !disp || !warped || !target || !gmoments || !gdisp) return LR_ENULL;
+  if (B < 1 || B > 65535 || D < 1 || W < 1 || H < 1 || d0 < 0 || d1 > D || d1 <= d0) return LR_EINVAL;
+  if (flags & ~LR_WARP_USING_SCALE) return LR_EUNSUPPORTED;   // zeros padding only (the model's case)
+  const bool any_id = id0 || id1 || id2, all_id = id0 && id1 && id2;
+  if (any_id && !all_id) return LR_ENULL;
+  const int Dn = d1 - d0;
+  const int64_t sD = (int64_t)W * H, V = sD * D;
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  if (!(H % 4 == 0 && al16(disp) && al16(warped) && al16(target) && al16(gdisp) && (!gadd || al16(gadd)) && (!id2 || al16(id2)) &&
+        V * 4 + sD * 8 <= 0x80000000LL && sD < (1 << 23) && sD / 4 <= (1 << 20) && Dn <= 65535))
+    return LR_EUNSUPPORTED;   // the caller materialises the gradient (lr_ncc_bwd_f32) and uses lr_warp_bwd_disp_f32
+  const dim3 g3((unsigned)((sD / 4 + 255) / 256), (unsigned)Dn, (unsigned)B);
+  const float rcp_hv = 1.0f / (float)(H / 4);
+  hipStream_t st = lr_stream(stream);
+  if (flags & LR_WARP_USING_SCALE)
+    hipLaunchKernelGGL((warp_bwd_fast_kernel<true, true>), g3, dim3(256), 0, st, img, disp, id0, id1, id2, warped, gdisp, gadd, 1, D, W, H, Dn, rcp_hv, target, gmoments);
+  else
+    hipLaunchKernelGGL((warp_bwd_fast_kernel<false, true>), g3, dim3(256), 0, st, img, disp, id0, id1, id2, warped, gdisp, gadd, 1, D, W, H, Dn, rcp_hv, target, gmoments);
+  return lr_launch_status();
 }
 
 // Same, plus `gadd` (B,3,Dn,W,H): gdisp = d warped / d disp · gwarped + gadd — the sum autograd would otherwise form

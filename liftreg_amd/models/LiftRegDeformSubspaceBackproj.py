@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, ops_bwd
 from ..autograd import ConvPair01Fn, DecodeFn, EncoderBf16Fn
 from ..layers.layers import convBlock, FullyConnectBlock, GaussianSmoothing
 from ..utils.net_utils import Bilinear, identity_axis_tables
@@ -155,6 +155,11 @@ class model(nn.Module):
         # instead of streaming the (B,3,D,W,H) field once forward and twice backward — the same number to fp32 rounding
         # (params = coefs . basis^T + mean is affine in the coefficients and R is a quadratic form of the field)
         self.reg_in_coef_space = bool(_opt(opt, "reg_in_coef_space", True))
+        # optional (non-reference) key "ncc_grad_via_moments" (default True): in training (single-channel images, no label
+        # masks) the decode node also returns the similarity's five moments as a differentiable output ("ncc_moments");
+        # NCCLoss is a function of them, its gradient comes back as (B,5) numbers, and the warp-gradient kernel forms
+        # d loss / d warped = gm0 + gm2·target + 2·gm3·warped on the fly — the pass that writes that gradient is gone
+        self.ncc_grad_via_moments = bool(_opt(opt, "ncc_grad_via_moments", True))
         self._reg_gram = None      # (key, (gram, lin, r0))
         self._poses = None         # geometry of the first batch's element 0, cached like :85-87
         self._packed = {}          # conv weights in MFMA operand order, keyed by parameter version
@@ -408,6 +413,12 @@ class model(nn.Module):
             return ops.pca_warp(coefs, self.pca_vectors_LxM, self.pca_mean, (self._id0, self._id1, self._id2), moving)
         # training: one autograd node for PCA reconstruction → (+ identity) → warp; the mask compose of moving
         # ((moving+1)*seg-1, :57) happens on the warp's taps
+        if (self.ncc_grad_via_moments and moving_seg is None and target is not None and C == 1 and target.is_cuda and
+                target.dtype == torch.float32 and target.is_contiguous() and target.shape == moving.shape and
+                torch.is_grad_enabled() and coefs.requires_grad and ops_bwd.warp_bwd_disp_ncc_supported(moving)):
+            # training: the similarity's moments are a differentiable output of the decode node (output key "ncc_moments")
+            return DecodeFn.apply(coefs, self.pca_vectors_LxM, self.pca_mean, moving, self._id0, self._id1, self._id2,
+                                  None, True, target)
         return DecodeFn.apply(coefs, self.pca_vectors_LxM, self.pca_mean, moving, self._id0, self._id1, self._id2,
                               moving_seg, True)
 

@@ -52,6 +52,56 @@ def warp_bwd_disp(img, disp, ids, seg, gwarped, *, using_scale=True, zero_bounda
     return gdisp
 
 
+def ncc_bwd_moments(moments, gout, n, variant):
+    """d loss / d moments (R,5) fp64 for the loss ops.ncc_loss_from_moments computes from the five sums of (x, y) — the
+    similarity's gradient as far as the moments; `warp_bwd_disp_ncc` carries it on to the displacement field."""
+    if moments.dtype != torch.float64 or not moments.is_cuda or moments.dim() != 2 or moments.shape[1] != 5:
+        raise ValueError("moments must be a float64 (R,5) GPU tensor")
+    gout = _dev(gout.reshape(()).to(torch.float32), "gout")
+    m = moments.contiguous()
+    gm = torch.empty_like(m)
+    with _timed("ncc_bwd_moments", bytes=80 * m.shape[0]):
+        _hip.check(_hip.lib().lr_ncc_bwd_moments(m.data_ptr(), gout.data_ptr(), gm.data_ptr(), m.shape[0], int(n), int(variant),
+                                                 _stream()), "lr_ncc_bwd_moments")
+    return gm
+
+
+def warp_bwd_disp_ncc_supported(img):
+    """True when `warp_bwd_disp_ncc` can take this image (single channel, the vectorised kernel's shape rules)."""
+    B, C, D, W, H = img.shape
+    sD = W * H
+    return C == 1 and H % 4 == 0 and 4 * D * sD + 8 * sD <= 2 ** 31 and sD < 2 ** 23 and sD // 4 <= 2 ** 20 and D <= 65535
+
+
+def warp_bwd_disp_ncc(img, disp, ids, warped, target, gmoments, *, using_scale=True, gadd=None):
+    """`warp_bwd_disp` with the gradient of `warped` given THROUGH THE SIMILARITY'S MOMENTS (`gmoments` (B,5) fp64 from
+    `ncc_bwd_moments`): gw = gm0 + gm2·target + 2·gm3·warped is formed inside the kernel — the pass that wrote it
+    (lr_ncc_bwd_f32: two volumes read, one written) and its read here are gone."""
+    img, disp, warped, target = _dev(img, "img"), _dev(disp, "disp"), _dev(warped, "warped"), _dev(target, "target")
+    B, C, D, W, H = img.shape
+    if not warp_bwd_disp_ncc_supported(img) or tuple(disp.shape) != (B, 3, D, W, H) or not disp.is_contiguous() or \
+            warped.shape != img.shape or target.shape != img.shape or not warped.is_contiguous() or not target.is_contiguous():
+        raise ValueError("warp_bwd_disp_ncc: unsupported shapes")
+    if gmoments.dtype != torch.float64 or tuple(gmoments.shape) != (B, 5) or not gmoments.is_cuda:
+        raise ValueError("gmoments must be a float64 (B,5) GPU tensor")
+    i0 = i1 = i2 = None
+    if ids is not None:
+        i0, i1, i2 = (_dev(t, "id table") for t in ids)
+    if gadd is not None:
+        gadd = _dev(gadd, "gadd")
+        if gadd.shape != disp.shape:
+            raise ValueError("gadd must have the displacement field's shape")
+    gdisp = torch.empty_like(disp)
+    gm = gmoments.contiguous()
+    with _timed("warp_bwd_disp_ncc", bytes=4 * ((2 if gadd is None else 3) * disp.numel() + 2 * warped.numel())):
+        _hip.check(_hip.lib().lr_warp_bwd_disp_ncc_f32(img.data_ptr(), disp.data_ptr(), _ptr(i0), _ptr(i1), _ptr(i2),
+                                                       warped.data_ptr(), target.data_ptr(), gm.data_ptr(), _ptr(gadd),
+                                                       gdisp.data_ptr(), B, D, W, H, 0, D,
+                                                       _hip.WARP_USING_SCALE if using_scale else 0, _stream()),
+                   "lr_warp_bwd_disp_ncc_f32")
+    return gdisp
+
+
 def pca_bwd_coef(gdisp, basis_LxM, nblk=None):
     """gcoefs (B,L) = gdisp (B,M) @ basis (L,M)^T — the second read of the PCA basis."""
     gdisp = _dev(gdisp, "gdisp")

@@ -227,3 +227,72 @@ def test_regulariser_in_coefficient_space_equals_field_path(dev, pca_dtype, labe
     assert abs(float(r_c) - float(r_f)) <= 2e-6 * float(r_f)
     assert float((g_c - g_f).abs().max()) <= 2e-5 * float(g_f.abs().max())
     assert float((gram - gram.t()).abs().max()) == 0.0 and float(torch.linalg.eigvalsh(gram.cpu()).min()) > -1e-9 * float(gram.abs().max())
+
+
+@pytest.mark.parametrize("variant_name", ["configured", "squared"])
+def test_similarity_gradient_through_its_moments(dev, variant_name):
+    """lr_ncc_bwd_moments + lr_warp_bwd_disp_ncc_f32 (the similarity's gradient carried as (B,5) numbers and expanded
+    inside the warp-gradient kernel) against lr_ncc_bwd_f32 + lr_warp_bwd_disp_acc_f32 (the gradient as a tensor), and the
+    moment gradient itself against fp64 autograd of the loss formula (layers/losses.py:14-29; layers.py:238-255)."""
+    from liftreg_amd import _hip, ops, ops_bwd
+    from liftreg_amd.utils.net_utils import identity_axis_tables
+    variant = _hip.NCC_CONFIGURED if variant_name == "configured" else _hip.NCC_SQUARED
+    rs = np.random.RandomState(8)
+    B, D, W, H = 3, 12, 10, 24
+    img = torch.from_numpy(rs.uniform(-1, 1, (B, 1, D, W, H)).astype(np.float32)).to(dev)
+    tgt = torch.from_numpy(rs.uniform(-1, 1, (B, 1, D, W, H)).astype(np.float32)).to(dev)
+    disp = torch.from_numpy(rs.normal(0, 0.08, (B, 3, D, W, H)).astype(np.float32)).to(dev)
+    gadd = torch.from_numpy(rs.normal(0, 1e-4, (B, 3, D, W, H)).astype(np.float32)).to(dev)
+    ids = [torch.from_numpy(t).to(dev) for t in identity_axis_tables((D, W, H))]
+    _, warped = ops.warp(img, disp, ids, None, using_scale=True, zero_boundary=True)
+    m = ops.ncc_moments(warped, tgt, B)
+    n = D * W * H
+    gout = torch.tensor(0.7, device=dev)
+    gw = ops_bwd.ncc_bwd(warped, tgt, m, gout, n, variant).view_as(warped)
+    want = ops_bwd.warp_bwd_disp(img, disp, ids, None, gw, using_scale=True, zero_boundary=True, gadd=gadd)
+    gm = ops_bwd.ncc_bwd_moments(m, gout, n, variant)
+    assert ops_bwd.warp_bwd_disp_ncc_supported(img)
+    got = ops_bwd.warp_bwd_disp_ncc(img, disp, ids, warped, tgt, gm, using_scale=True, gadd=gadd)
+    scale = float((want - gadd).abs().max())
+    assert scale > 0 and float((got - want).abs().max()) <= 2e-5 * scale
+    got0 = ops_bwd.warp_bwd_disp_ncc(img, disp, ids, warped, tgt, gm, using_scale=True)
+    assert float((got0 + gadd - want).abs().max()) <= 2e-5 * scale
+    # the moment gradient against fp64 autograd of the loss as a function of the five sums
+    mm = m.cpu().clone().requires_grad_(True)
+    mx, my = mm[:, 0] / n, mm[:, 1] / n
+    cov, vx, vy = mm[:, 2] / n - mx * my, mm[:, 3] / n - mx * mx, mm[:, 4] / n - my * my
+    if variant_name == "configured":
+        ncc = (cov + 1e-20) / torch.sqrt((vx + 1e-20) * (vy + 1e-20))
+    else:
+        ncc = cov * cov / (vx * vy + 1e-12)
+    (0.7 * (1 - ncc.mean())).backward()
+    ref = mm.grad
+    assert float((gm.cpu() - ref).abs().max()) <= 1e-6 * float(ref.abs().max())     # gout is an fp32 0.7
+
+
+def test_training_step_with_and_without_the_moments_route(dev):
+    """Model opt key ncc_grad_via_moments (default on): same loss, same parameter gradients as the route that writes
+    d loss / d warped as a tensor."""
+    from liftreg_amd.losses.SubspaceLoss import loss as SubspaceLoss
+    shape, P, L, B = (32, 28, 36), 2, 6, 2
+    net = _net(shape, P, L, dev, 13).train()
+    inp = _inputs(shape, P, 32, B, 13, False)
+    dinp = {k: v.to(dev) if k != "target_poses" else v for k, v in inp.items()}
+    crit = SubspaceLoss(dict(LOSS_OPT))
+
+    def step(via):
+        net.ncc_grad_via_moments = via
+        net.zero_grad()
+        out = net(dinp)
+        assert ("ncc_moments" in out) == via
+        out["epoch"] = 0
+        res = crit(out)
+        res["total_loss"].backward()
+        return res, {k: p.grad.clone() for k, p in net.named_parameters()}
+
+    res_t, g_t = step(False)
+    res_m, g_m = step(True)
+    assert abs(res_m["sim_loss"] - res_t["sim_loss"]) <= 1e-6
+    for k in g_t:
+        scale = float(g_t[k].abs().max())
+        assert scale > 0 and float((g_m[k] - g_t[k]).abs().max()) <= 2e-4 * scale, k
