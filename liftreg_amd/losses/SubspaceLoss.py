@@ -47,6 +47,11 @@ class loss(nn.Module):
         for name in ("initial_reg_factor", "min_reg_factor", "reg_factor_decay_from"):
             setattr(self, name, _read(opt, name))
         self.sim = get_class(_read(opt, "sim_class"))()
+        try:
+            import inspect
+            self._sim_takes_moments = "moments" in inspect.signature(self.sim.forward).parameters
+        except (TypeError, ValueError):
+            self._sim_takes_moments = False
         self.sim_factor = 1.
 
     def get_reg_factor(self, epoch):
@@ -60,7 +65,9 @@ class loss(nn.Module):
 
     def forward(self, input):
         moments = input.get("ncc_moments") if hasattr(input, "get") else None
-        if moments is not None:          # the decode's epilogue already accumulated them (model opt key fuse_ncc)
+        if moments is not None and not self._sim_takes_moments:
+            moments = None               # a similarity class without the (non-reference) `moments` argument: the plain call
+        if moments is not None:          # the decode node already accumulated them (model opt keys ncc_grad_via_moments, fuse_ncc)
             similarity = self.sim(input["warped"], input["target"], moments=moments)
         else:
             similarity = self.sim(input["warped"], input["target"])

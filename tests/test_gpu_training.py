@@ -296,3 +296,21 @@ def test_training_step_with_and_without_the_moments_route(dev):
     for k in g_t:
         scale = float(g_t[k].abs().max())
         assert scale > 0 and float((g_m[k] - g_t[k]).abs().max()) <= 2e-4 * scale, k
+
+
+def test_loss_plugin_with_a_similarity_class_that_takes_no_moments(dev):
+    """sim_class = the squared-NCC variant (layers/layers.py:238-255), whose forward has no `moments` argument: the loss
+    plugin calls it plainly and the gradient reaches the decode node as a tensor, although the model offers the moments."""
+    from liftreg_amd.losses.SubspaceLoss import loss as SubspaceLoss
+    net = _net((32, 32, 32), 2, 8, dev, 17).train()
+    inp = _inputs((32, 32, 32), 2, 32, 2, 17, False)
+    dinp = {k: v.to(dev) if k != "target_poses" else v for k, v in inp.items()}
+    crit = SubspaceLoss({**LOSS_OPT, "sim_class": "liftreg_amd.layers.layers.NCCLoss"})
+    assert not crit._sim_takes_moments
+    out = net(dinp)
+    assert "ncc_moments" in out
+    out["epoch"] = 0
+    res = crit(out)
+    res["total_loss"].backward()
+    g = net.encoders[0].conv.weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
