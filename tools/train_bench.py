@@ -49,6 +49,8 @@ def main():
                     help="every rank trains on the SAME batch (test hook: the averaged gradient then equals one rank's, "
                          "so the loss trajectory must equal the single-process run's)")
     ap.add_argument("--no-kernel-table", action="store_true")
+    ap.add_argument("--model-opt", action="append", default=[], metavar="KEY=BOOL",
+                    help="a boolean model option, e.g. reg_in_coef_space=false ncc_grad_via_moments=false (A/B aid)")
     ap.add_argument("--adam-foreach", action="store_true", help="torch's default (multi-pass) Adam instead of fused=True (A/B aid)")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo control-path self-test with a stand-in module")
     a = ap.parse_args()
@@ -108,7 +110,8 @@ def main():
         from liftreg_amd.utils.sdct_projection_utils import scan_poses
         net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:2021",
                                 "conv_dtype": a.conv_dtype, "grad_dtype": a.grad_dtype,
-                                "pca_dtype": a.pca_dtype}).to(dev).train()
+                                "pca_dtype": a.pca_dtype,
+                                **{k: (v.lower() in ("1", "true", "yes")) for k, v in (kv.split("=", 1) for kv in a.model_opt)}}).to(dev).train()
         crit = SubspaceLoss({"initial_reg_factor": 0.01, "min_reg_factor": 0.01, "reg_factor_decay_from": 2})
         crit.sim.check_nan = False
         g = torch.Generator(device=dev)
