@@ -21,7 +21,8 @@ names = {"bench.json": "bench.json", "bench_bf16.json": "bench_bf16.json", "benc
          "bench_conv0_split.json": "bench_conv0_split.json", "pmc/summary.txt": "pmc_bench_summary.txt",
          "pmc_c4/summary.txt": "pmc_bench_c4_bf16_summary.txt", "train_modes.jsonl": "train_modes.jsonl",
          "train_c3_kernels.jsonl": "train_c3_kernels.jsonl", "train_c5_bf16_kernels.jsonl": "train_c5_bf16_kernels.jsonl",
-         "shard_bench.jsonl": "shard_bench.jsonl", "ab_conv0_split.txt": "ab_conv0_split.txt"}
+         "shard_bench.jsonl": "shard_bench.jsonl", "ab_conv0_split.txt": "ab_conv0_split.txt",
+         "ab_train_algebra.txt": "ab_train_algebra.txt", "power_trace.txt": "power_trace.txt"}
 for s, d in names.items():
     if os.path.exists(O + s):
         shutil.copy(O + s, P + rnd + "_" + d)

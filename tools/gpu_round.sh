@@ -54,6 +54,8 @@ timeout 120 python3 tools/abl_c0cl.py > "$O/abl_c0cl.txt" 2>/dev/null
 timeout 120 python3 tools/ab_encin.py > "$O/ab_encin.txt" 2>/dev/null
 timeout 200 python3 tools/ab_conv0_split.py > "$O/ab_conv0_split.txt" 2>/dev/null
 timeout 300 python3 bench.py --no-drr --conv0-split 2>/dev/null | tail -n 1 > "$O/bench_conv0_split.json"
+bash tools/ab_train_algebra.sh > "$O/ab_train_algebra.txt" 2>/dev/null
+bash tools/power_round.sh "$TAG/power" > "$O/power_trace.txt" 2>/dev/null
 cat "$O/train_modes.jsonl" "$O/shard_bench.jsonl"
 python3 - "$O" <<'PY'
 import json, sys, glob, os
