@@ -380,6 +380,28 @@ int lr_conv3d_first_split_obs_f32(const float* in0, int64_t in0_batch_stride, co
                                   const float* bias, float* out, int B, int Cin, int Cout, int D, int W, int H,
                                   int out_layout, float negative_slope, int64_t out_batch_stride, void* stream);
 
+/* Encoder blocks 0 AND 1 in one kernel (conv01_fused.hip): Conv3d(Cin -> 16, 3x3x3, stride 1, pad 1) + LeakyReLU(slope0)
+ * followed by Conv3d(16 -> 32, 3x3x3, stride 2, pad 1) + LeakyReLU(slope1) — src/liftreg/layers/layers.py:365-369 twice, as
+ * wired at src/liftreg/models/LiftRegDeformSubspaceBackproj.py:95-100 for encoders[0] and encoders[1].  The 16-channel
+ * activation between the blocks never reaches memory.  fp32 in, fp32 out; both stages run on the bf16 MFMA with EXACT
+ * three-way bf16 splits of their fp32 operands (six exact partial products, fp32 accumulation: a direct convolution with
+ * fp32-class error, tests/test_gpu_conv01_fused.py).
+ *   in0      : dev, channel 0 (the moving image), batch element b at in0 + b*in0_batch_stride (elements; 0 = D*W*H)
+ *   in_rest  : dev, channels 1..Cin-1 planar, batch element b at in_rest + b*rest_batch_stride (0 = (Cin-1)*D*W*H);
+ *              the concatenated (B,Cin,D,W,H) tensor x is (x, Cin*V, x + V, Cin*V)
+ *   packed   : dev, lr_conv3d_pair01_packed_floats() floats written by lr_conv3d_pair01_pack_f32 from the two
+ *              (Cout,Cin,3,3,3) weights
+ *   out      : dev, (B,Do,Wo,Ho,32) in out_layout LR_LAYOUT_NDHWC or LR_LAYOUT_NDHWC_HPS, Xo = (X-1)/2+1;
+ *              out_batch_stride in elements (0 = dense)
+ * Cin in 1..4, H % 4 == 0, 16-byte aligned pointers, 0 <= slope <= 1 — otherwise LR_EUNSUPPORTED / LR_EALIGN and the
+ * caller runs the two blocks as two kernels. */
+int64_t lr_conv3d_pair01_packed_floats(int Cin, int C0, int C1);
+int lr_conv3d_pair01_pack_f32(const float* w0, const float* w1, float* packed, int Cin, int C0, int C1, void* stream);
+int lr_conv3d_pair01_f32(const float* in0, int64_t in0_batch_stride, const float* in_rest, int64_t rest_batch_stride,
+                         const float* packed, const float* bias0, const float* bias1, float* out, int B, int Cin,
+                         int D, int W, int H, int out_layout, float slope0, float slope1, int64_t out_batch_stride,
+                         void* stream);
+
 /* f1 ("backproject -> conv0: never write the P*V volume"): the same first block with the backprojection
  * computed INSIDE its staging.  Channel 0 = in0 (B,1,D,W,H), channels 1..P = the backprojection of proj (B,P,Pw,Ph)
  * for `poses` (host, P x 3 fp32, ONE geometry for the batch, …Backproj.py:85-87) — sample for sample the arithmetic

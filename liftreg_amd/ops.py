@@ -371,6 +371,62 @@ def conv3d_first_split(x0, rest, weight, bias, *, out_layout=LAYOUT_NCDHW, negat
     return y
 
 
+def conv3d_pair01_supported(x0, rest, w0, w1, out_layout=LAYOUT_NDHWC_HPS):
+    """True when `conv3d_pair01` (encoder blocks 0 and 1 as one kernel, csrc/conv01_fused.hip) can take these tensors."""
+    if not (x0.dim() == 5 and rest.dim() == 5 and x0.shape[1] == 1 and rest.shape[1] in (1, 2, 3) and x0.shape[4] % 4 == 0 and
+            x0.shape[0] == rest.shape[0] and x0.shape[2:] == rest.shape[2:] and x0[0].is_contiguous() and rest.is_contiguous() and
+            (x0.shape[0] == 1 or x0.stride(0) % 4 == 0) and x0.data_ptr() % 16 == 0 and rest.data_ptr() % 16 == 0):
+        return False
+    B, _, D, W, H = x0.shape
+    if tuple(w0.shape) != (16, 1 + rest.shape[1], 3, 3, 3) or tuple(w1.shape) != (32, 16, 3, 3, 3):
+        return False
+    if out_layout not in (LAYOUT_NDHWC, LAYOUT_NDHWC_HPS) or (out_layout == LAYOUT_NDHWC_HPS and ((H - 1) // 2 + 1) % 2):
+        return False
+    V = D * W * H
+    return 12 * V + 32 * W * H < 2 ** 31 - 1 and ((W - 1) // 2 + 1) * ((H - 1) // 2 + 1) * 128 < 2 ** 31 - 1
+
+
+def conv3d_pair01_pack(w0, w1):
+    """The two (Cout,Cin,3,3,3) weights as the three-way bf16 split fragments of lr_conv3d_pair01_f32."""
+    w0, w1 = _dev(w0.detach(), "w0"), _dev(w1.detach(), "w1")
+    Cin = w0.shape[1]
+    n = _hip.lib().lr_conv3d_pair01_packed_floats(Cin, w0.shape[0], w1.shape[0])
+    if n <= 0:
+        raise ValueError("conv3d_pair01_pack: the pair kernel is built for Cin in 1..4 -> 16 -> 32 channels")
+    packed = torch.empty((n,), dtype=torch.float32, device=w0.device)
+    _hip.check(_hip.lib().lr_conv3d_pair01_pack_f32(w0.data_ptr(), w1.data_ptr(), packed.data_ptr(), Cin, w0.shape[0],
+                                                    w1.shape[0], _stream()), "lr_conv3d_pair01_pack_f32")
+    return packed
+
+
+def conv3d_pair01(x0, rest, w0, b0, w1, b1, *, out_layout=LAYOUT_NDHWC_HPS, slope0=0.2, slope1=0.2, packed=None, out=None):
+    """Encoder blocks 0 and 1 on cat([x0, rest], dim=1) as ONE kernel: Conv3d(Cin->16, s1) + LeakyReLU, Conv3d(16->32, s2) +
+    LeakyReLU (reference layers.py:365-369 twice, …Backproj.py:95-100); the 16-channel activation never reaches memory.
+    fp32 in / fp32 out, exact three-way bf16 operand splits on the bf16 MFMA.  Returns (B,Do,Wo,Ho,32) in `out_layout`."""
+    if not (isinstance(x0, torch.Tensor) and x0.is_cuda and x0.dtype == torch.float32):
+        raise _hip.LiftRegHipError("x0: must be a float32 GPU tensor (no CPU fallback)")
+    rest = _dev(rest, "rest")
+    if not conv3d_pair01_supported(x0, rest, w0, w1, out_layout):
+        raise ValueError("conv3d_pair01: unsupported shapes (run the two blocks separately)")
+    B, _, D, W, H = x0.shape
+    Cin = 1 + rest.shape[1]
+    if packed is None:
+        packed = conv3d_pair01_pack(w0, w1)
+    b0 = None if b0 is None else _dev(b0.detach(), "b0")
+    b1 = None if b1 is None else _dev(b1.detach(), "b1")
+    Do, Wo, Ho = (D - 1) // 2 + 1, (W - 1) // 2 + 1, (H - 1) // 2 + 1
+    y = _conv_out(out, (B, Do, Wo, Ho, 32), torch.float32, x0.device, strided_batch=True)
+    obs = _batch_stride(y)
+    ibs = int(x0.stride(0)) if (B > 1 and not x0.is_contiguous()) else 0
+    V = D * W * H
+    flops = 2.0 * 27 * B * (Cin * 16 * V + 16 * 32 * Do * Wo * Ho)
+    with _timed(f"conv3d_pair01_c{Cin}x16x32_{D}", flops=flops, bytes=4 * (x0.numel() + rest.numel()) + 4 * y.numel(), samples=B):
+        _hip.check(_hip.lib().lr_conv3d_pair01_f32(x0.data_ptr(), ibs, rest.data_ptr(), 0, packed.data_ptr(), _ptr(b0), _ptr(b1),
+                                                   y.data_ptr(), B, Cin, D, W, H, out_layout, float(slope0), float(slope1),
+                                                   obs, _stream()), "lr_conv3d_pair01_f32")
+    return y
+
+
 def conv3d_first_fused_bp_supported(x0, proj):
     """True when `conv3d_first_fused_bp` can take these tensors (else: backproject + conv3d_first_split)."""
     return (x0.dim() == 5 and proj.dim() == 4 and x0.shape[1] == 1 and proj.shape[1] in (1, 2) and x0.shape[4] % 4 == 0 and
