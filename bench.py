@@ -97,6 +97,7 @@ class SclkSampler:
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* fp32-input matrix peak
+MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the pipe the fused split-operand pair kernel runs on)
 
 
 def synth_inputs(cfg, dev, seed=2021):
@@ -282,6 +283,9 @@ def main():
                     help="A/B aid (fp32 lines): the first encoder block through csrc/conv0_split_f32.hip — its fp32 operands as "
                          "exact three-way bf16 splits on the bf16 matrix pipe, 6 of the 9 partial products, fp32 accumulation "
                          "(LIFTREG_CONV0_SPLIT=1); not the default, the line says so in dtype and config")
+    ap.add_argument("--no-pair01", action="store_true",
+                    help="A/B aid (fp32 lines): encoder blocks 0 and 1 as two fp32-MFMA kernels (the round-3 path) instead of the "
+                         "fused split-operand pair kernel csrc/conv01_fused.hip (model opt key fuse_pair01)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from one captured HIP graph (launch-bound small configs c1/c2); the "
                          "per-kernel table then comes from one extra eager step outside the timed region")
@@ -323,7 +327,8 @@ def main():
     n, P, B, L = cfg["n"], cfg["P"], cfg["B"], cfg["L"]
     net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:2021",
                             "conv_dtype": args.conv_dtype, "pca_dtype": args.pca_dtype,
-                            "fuse_ncc": args.fuse_ncc, "fuse_backproject": args.fuse_bp}).to(dev).eval()
+                            "fuse_ncc": args.fuse_ncc, "fuse_backproject": args.fuse_bp,
+                            "fuse_pair01": not args.no_pair01}).to(dev).eval()
     slab = args.shard == "slab"
     inp = synth_inputs(cfg, dev, seed=2021 if slab else 2021 + rank)   # slab: every rank holds the SAME batch
     sim = NCCLoss(check_nan=False)
@@ -444,6 +449,10 @@ def main():
                 k["issued_share"] = 28.0 / 42.0
             elif st_ == 2 and ((dd - 1) // 2 + 1) ** 2 >= 4096 and not os.environ.get("LIFTREG_CONV_DIRECT"):
                 k["issued_share"] = 10.0 / 12.0
+        if "issued_bf16_flops" in info:   # the fused split-operand pair kernel: fp32 results from six bf16 MFMAs per K block
+            k["issued_bf16_tflops"] = info["issued_bf16_flops"] / (ms * 1e-3) / 1e12
+            k["frac_bf16_issued"] = k["issued_bf16_tflops"] / MFMA_BF16_PEAK_TF
+            k["compulsory_bytes"] = info["bytes"]
         kernels[name] = k
     # PMC-derived HBM bytes per launch (tools/pmc_bench.sh over this very command).  Every entry is stamped with the
     # kernel instance it was measured on and the sha256 of that kernel's source file: an entry whose source has changed
@@ -477,7 +486,15 @@ def main():
                 "unit": k["unit"], "frac": k["frac"], "traffic": k["traffic"], "avg_ms": k["avg_ms"],
                 "traffic_measured_on": k.get("traffic_kernel"), **at_clock,
                 **({"flops": "algorithmic (direct conv); fp32 Winograd kernel", "mfma_issued_share": k["issued_share"],
-                    "frac_mfma_issued": k["frac"] * k["issued_share"]} if "issued_share" in k else {})}
+                    "frac_mfma_issued": k["frac"] * k["issued_share"]} if "issued_share" in k else {}),
+                **({"flops": "algorithmic fp32 flops of the two direct convolutions, priced against the fp32 MFMA peak (the "
+                             "arithmetic type of the path); the kernel computes them as exact 3-way bf16 splits on the bf16 "
+                             "MFMA: `issued_bf16_tflops` / `frac_bf16_issued` price the MFMAs it really issues (6 per K block "
+                             "of 32, K padded 81 -> 128 and 432 -> 448, 13 % halo recompute in block 0) against the dense bf16 peak",
+                    "issued_bf16_tflops": k["issued_bf16_tflops"], "frac_bf16_issued": k["frac_bf16_issued"],
+                    "peak_bf16": MFMA_BF16_PEAK_TF, "compulsory_bytes": k["compulsory_bytes"],
+                    "traffic_over_compulsory": (k["traffic"] / k["compulsory_bytes"]) if k["traffic"] else None}
+                   if "issued_bf16_tflops" in k else {})}
 
     # the projector on its own and the simulate+register rate — outside the timed region
     drr = None
@@ -544,6 +561,7 @@ def main():
                        "note": f"rows {d0}:{d1} of each of the {B} volumes on rank 0; partial DRRs summed over {world} rank(s) "
                                "(fp32 sums in another order than the single-GPU ray walk: ~1e-7 relative)"}
 
+    pair01_ran = any(kname.startswith("conv3d_pair01") for kname in kernels)
     result = {
         "metric": "registrations/sec (256^3 CT, 2-view DRR)" if args.config == "c3" else f"registrations/sec ({args.config})",
         "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -555,14 +573,18 @@ def main():
         "dtype": ("f32" if (args.conv_dtype, args.pca_dtype) == ("fp32", "fp32") else
                   f"conv blocks {args.conv_dtype}, PCA basis storage {args.pca_dtype}, f32 elsewhere") +
                  ("; first block: fp32 operands as exact 3-way bf16 splits on the bf16 MFMA (6 of 9 partial products), f32 accumulation"
-                  if args.conv0_split and args.conv_dtype == "fp32" else ""),
+                  if args.conv0_split and args.conv_dtype == "fp32" and not pair01_ran else "") +
+                 ("; encoder blocks 0-1 (one fused kernel): fp32 operands as exact 3-way bf16 splits on the bf16 MFMA (6 of the 9 "
+                  "partial products, each exact), f32 accumulation — closer to an fp64 convolution than the fp32 fmaf chain "
+                  "(tests/test_gpu_conv01_fused.py)" if pair01_ran else ""),
         "data": "synthetic",
         "config": {"workload": f"{args.config}: {n}^3 CT, {P}x{cfg['R']}^2 DRR, batch {B}/GPU, latent {L}, "
-                               "backproject+conv6(MFMA f32)+FC3+PCA+warp+NCC", "global_batch": B if slab else world * B,
+                               "backproject+conv6(MFMA)+FC3+PCA+warp+NCC", "global_batch": B if slab else world * B,
                    "parallelism": (f"z-slab x{world}: ONE batch of {B} registrations sharded along D (rows {d0}:{d1} on rank 0); "
                                    "halo planes p2p, encoder features all-gather, NCC moments all-reduce over RCCL" if slab else
                                    f"replicas x{world} (independent registrations, no data-path collective)"),
                    "streams": args.streams, "hip_graph": bool(args.graph), "conv0_split": bool(args.conv0_split),
+                   "fused_pair01": pair01_ran,
                    "untimed_before_warmup": f"{ramp_steps} steps ({args.ramp_seconds:g} s clock ramp), then {args.warmup} warm-up steps"},
         "roofline": roof(dominant),
         "roofline_backproject": roof("backproject"),

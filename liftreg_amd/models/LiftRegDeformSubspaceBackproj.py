@@ -149,6 +149,12 @@ class model(nn.Module):
         # are one autograd node whose backward computes block 1's data gradient and block 0's weight gradient in one kernel
         # (autograd.ConvPair01Fn); False = one node per block (the gradient between them goes through memory)
         self.fuse_first_backward = bool(_opt(opt, "fuse_first_backward", True))
+        # optional (non-reference) key "fuse_pair01" (default True): in fp32 inference with P <= 2 views, encoder blocks 0 and 1
+        # run as ONE kernel (csrc/conv01_fused.hip): both on the bf16 matrix pipe with exact three-way bf16 splits of their fp32
+        # operands (six exact partial products, fp32 accumulation — closer to an fp64 convolution than the fp32 fmaf chain,
+        # tests/test_gpu_conv01_fused.py); the 16-channel activation between them (8.6 GB per batch of 8 at 256^3) never reaches
+        # HBM.  False = one fp32-MFMA kernel per block (the round-3 path).
+        self.fuse_pair01 = bool(_opt(opt, "fuse_pair01", True))
         # optional (non-reference) key "reg_in_coef_space" (default True): in training the output dict also carries
         # "pca_reg_gram" = the regulariser's quadratic form on the PCA basis (ops.subspace_reg_gram, computed once per
         # basis), so that liftreg_amd.losses.SubspaceLoss evaluates R(params) and its gradient on the (B,L) coefficients
@@ -303,6 +309,18 @@ class model(nn.Module):
             self._packed[(i, bf16)] = hit
         return hit[1]
 
+    def _packed_pair01(self):
+        """The split-operand fragments of encoder blocks 0 and 1 (ops.conv3d_pair01_pack), cached like _packed_weight."""
+        w0, w1 = self.encoders[0].conv.weight, self.encoders[1].conv.weight
+        key = (w0.data_ptr(), w0._version, w1.data_ptr(), w1._version, str(w0.device))
+        hit = self._packed.get("pair01")
+        if self.training and (w0.requires_grad or w1.requires_grad):
+            hit = None
+        if hit is None or hit[0] != key:
+            hit = (key, ops.conv3d_pair01_pack(w0, w1))
+            self._packed["pair01"] = hit
+        return hit[1]
+
     def _estimate_flow(self, moving, target_proj, poses):
         coefs = self.encode(moving, target_proj, poses)
         B, _, D, W, H = moving.shape
@@ -335,6 +353,15 @@ class model(nn.Module):
                     x = self.encoders[i](x, packed=self._packed_weight(i))
                 return self.encoders[6](x)
             tv = torch.empty((B, P, D, W, H), dtype=torch.float32, device=moving.device)
+            b0, b1 = self.encoders[0], self.encoders[1]
+            if (self.fuse_pair01 and not self.fuse_backproject and b1.stride == 2 and b0.out_layout == b1.in_layout and
+                    ops.conv3d_pair01_supported(mv, tv, b0.conv.weight, b1.conv.weight, b1.out_layout)):
+                ops.backproject(target_proj, self._poses, (D, W, H), out=tv, out_batch_stride=P * V)
+                x = ops.conv3d_pair01(mv, tv, b0.conv.weight, b0.conv.bias, b1.conv.weight, b1.conv.bias,
+                                      out_layout=b1.out_layout, slope0=b0._slope, slope1=b1._slope, packed=self._packed_pair01())
+                for i in range(2, 6):
+                    x = self.encoders[i](x, packed=self._packed_weight(i))
+                return self.encoders[6](x)
             if ops.conv3d_first_split_supported(mv, tv):
                 ops.backproject(target_proj, self._poses, (D, W, H), out=tv, out_batch_stride=P * V)
                 blk = self.encoders[0]

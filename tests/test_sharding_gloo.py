@@ -35,6 +35,10 @@ class OracleOps:
         return False      # … and the concatenated encoder input
 
     @staticmethod
+    def conv3d_pair01_supported(*_):
+        return False      # … and one kernel per encoder block
+
+    @staticmethod
     def encoder_input_bf16_supported(*_):
         return False      # … and the fp32 feature volume
 
