@@ -420,9 +420,9 @@ def conv3d_pair01(x0, rest, w0, b0, w1, b1, *, out_layout=LAYOUT_NDHWC_HPS, slop
     ibs = int(x0.stride(0)) if (B > 1 and not x0.is_contiguous()) else 0
     V = D * W * H
     flops = 2.0 * 27 * B * (Cin * 16 * V + 16 * 32 * Do * Wo * Ho)
-    # what the matrix pipe is really asked for: 408 v_mfma_f32_16x16x32_bf16 per wave and step (38 x 24 + 4 x 42 x ... see the
-    # kernel header), 4 waves per column of 8 x 8 outputs, Do steps per column
-    issued = 16384.0 * 408 * 4 * Do * B * (-(-Wo // 8)) * (-(-Ho // 8))
+    # what the matrix pipe is really asked for: per column of 4 x 8 outputs and step, 4 x 120 v_mfma_f32_16x16x32_bf16 for block 0
+    # (20 tiles x 24) and 4 x 84 for block 1 (see the kernel header); Do steps per column
+    issued = 16384.0 * 816 * Do * B * (-(-Wo // 4)) * (-(-Ho // 8))
     with _timed(f"conv3d_pair01_c{Cin}x16x32_{D}", flops=flops, issued_bf16_flops=issued,
                 bytes=4 * (x0.numel() + rest.numel()) + 4 * y.numel(), samples=B):
         _hip.check(_hip.lib().lr_conv3d_pair01_f32(x0.data_ptr(), ibs, rest.data_ptr(), 0, packed.data_ptr(), _ptr(b0), _ptr(b1),

@@ -17,16 +17,16 @@ b1 = torch.randn(32, device=dev, generator=g) * 0.1
 pk = ops.conv3d_pair01_pack(w0, w1)
 lib = _hip.lib()
 lib.lr_debug_read_c01_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
-buf = (ctypes.c_ulonglong * 32)()
+buf = (ctypes.c_ulonglong * 64)()
 for _ in range(3):
     ops.conv3d_pair01(x0, rest, w0, b0, w1, b1, packed=pk)
 torch.cuda.synchronize(); lib.lr_debug_read_c01_stamps(buf, 1)
 ops.conv3d_pair01(x0, rest, w0, b0, w1, b1, packed=pk)
 torch.cuda.synchronize(); lib.lr_debug_read_c01_stamps(buf, 0)
-names = ["0 issue loads", "1 A: row pairs", "2 A: single tiles", "3 wait B1", "4 B: block 1", "5 C: partials + ring 0", "6 wait B2", "7 D: sum + store"]
-steps = 256 * 8 * 128 / 256   # per block
-for w in range(4):
+names = ["0 step top", "1 A: first fragments | B: staging", "2 A stage 0 | B: finish", "3 A stage 1 | B: MFMAs", "4 A stage 2 | B: partial", "5 A tail", "6 barrier", "7"]
+steps = (256 * 8 * 2) * 129 / 256   # per block
+for w in range(8):
     tot = sum(buf[w * 8 + i] for i in range(8))
     print(f"wave {w}: {tot / 256 / steps:8.0f} cycles per step")
     for i, nme in enumerate(names):
-        print(f"   {nme:24s} {buf[w * 8 + i] / tot:6.1%}   {buf[w * 8 + i] / 256 / steps:8.0f}")
+        print(f"   {nme:36s} {buf[w * 8 + i] / max(tot, 1):6.1%}   {buf[w * 8 + i] / 256 / steps:8.0f}")
