@@ -140,6 +140,9 @@ __device__ unsigned long long g_lr_c01_stamps[8 * 8];
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), b, c, 0, 0, 0)
 #define C01_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef LR_C01_BPRIO
+#define LR_C01_BPRIO 1
+#endif
 
 template <int NC>
 __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
@@ -384,15 +387,16 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
           Epi E0, E1;
           // the first pair's fragments: the one LDS round trip of the step this wave waits for (its SIMD partner computes)
 #pragma unroll
-          for (int n = 0; n < 18; ++n) load_pair_n(n, bP0, fa);
+          for (int n = 0; n < 6; ++n) load_pair_n(n, bP0, fa);
           C01_FENCE();
           C01_STAMP(1);
-          // stage 0: pair of plane 0 | fragments of the pair of plane 1
+          // stage 0: pair of plane 0 | its other 12 fragments (two groups ahead of their use), then those of the pair of plane 1
           aa.v[0] = bv; aa.v[1] = bv;
 #pragma unroll
           for (int I = 0; I < 48; ++I) {
             mma_pair_n(I, fa, aa);
-            if ((I & 1) == 0 && I < 36) load_pair_n(I >> 1, bP1, fb);
+            if (I < 12) load_pair_n(6 + I, bP0, fa);
+            else if ((I & 1) == 0) load_pair_n((I - 12) >> 1, bP1, fb);
             C01_FENCE();
           }
           C01_STAMP(2);
@@ -434,6 +438,11 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
       }
   }
   } else {
+  // The SIMD's arbiter serves the OLDER wave first (waves 0..3, the A role, were dispatched first): left alone, B only got
+  // matrix and issue slots once A had finished its step (B's 84 MFMAs took 5.1 k cycles, A then waited 1.8 k at the barrier).
+  // B's stream is the light one (MFMAs paced by LDS reads, little vector work): with static priority it takes its slots when
+  // its operands are there and A fills the rest (MI355X_MICROARCH.md, two waves per SIMD, item 4).
+  __builtin_amdgcn_s_setprio(LR_C01_BPRIO);
   for (int uid = first; uid < end; uid += stride) {
     const int utx = uid % d.nTx, uty = (uid / d.nTx) % d.nTy, ub = __builtin_amdgcn_readfirstlane(uid / d.nTx / d.nTy);
     const int oy0 = __builtin_amdgcn_readfirstlane(uty * TY), ox0 = __builtin_amdgcn_readfirstlane(utx * TX);
@@ -528,26 +537,55 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
       }
       if (!o_in) ooff = OOR;
       f32x4 own = {0.f, 0.f, 0.f, 0.f};
-      // output plane oz: K half 0 + K half 1 + bias, LeakyReLU, store (oz < 0: nothing yet — zero-length resource, no branch)
-      auto finish = [&](int oz) __attribute__((always_inline)) {
-        float* const pbase = out + ((int64_t)ub * d.out_bs + (int64_t)(oz < 0 ? 0 : oz) * d.Wo * d.Ho * 32);
-        const __amdgpu_buffer_rsrc_t ores = make_rsrc(pbase, oz < 0 ? 0u : (unsigned)(d.Wo * d.Ho * 32 * 4));
-        const f32x4 other = *reinterpret_cast<const f32x4*>(lds + SCR_OFF + (((oz & 1) * 4 + (wq ^ 2)) * 64 + lane) * 16);
-        f32x4 v = (own + other) + bv;
-        v = __builtin_elementwise_max(v, v * d.slope1);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ores, (int)ooff, 0, 0);
+      // staging of this thread's item in 12 slices: unpack | per voxel j: split channels 01, split channels 23 | 3 x two stores
+      float sv[4][4];
+      unsigned rec[3][4][2];
+      auto stage_slice = [&](int k, const u32x4 (&L)[NC], int addr) __attribute__((always_inline)) {
+        if (k == 0) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const uint4 q = __builtin_bit_cast(uint4, L[cc < NC ? cc : 0]);
+            sv[cc][0] = cc < NC ? __builtin_bit_cast(float, q.x) : 0.0f; sv[cc][1] = cc < NC ? __builtin_bit_cast(float, q.y) : 0.0f;
+            sv[cc][2] = cc < NC ? __builtin_bit_cast(float, q.z) : 0.0f; sv[cc][3] = cc < NC ? __builtin_bit_cast(float, q.w) : 0.0f;
+          }
+        } else if (k <= 8) {
+          const int vj = (k - 1) >> 1, hf = (k - 1) & 1;
+          unsigned pp[3] = {0u, 0u, 0u};
+          if (hf) { if (NC > 2) split3(sv[2][vj], sv[3][vj], pp); }
+          else split3(sv[0][vj], sv[1][vj], pp);
+#pragma unroll
+          for (int sp = 0; sp < 3; ++sp) rec[sp][vj][hf] = pp[sp];
+        } else {
+          const int sp = k - 9;
+          *reinterpret_cast<u32x4*>(lds + addr + sp * SB0) = (u32x4){rec[sp][0][0], rec[sp][0][1], rec[sp][1][0], rec[sp][1][1]};
+          *reinterpret_cast<u32x4*>(lds + addr + sp * SB0 + 16) = (u32x4){rec[sp][2][0], rec[sp][2][1], rec[sp][3][0], rec[sp][3][1]};
+        }
+      };
+      // output plane oz in 2 slices: read the partner's K half | sum, bias, LeakyReLU, store (oz < 0: zero-length resource)
+      f32x4 fin_o = {0.f, 0.f, 0.f, 0.f};
+      auto fin_slice = [&](int k, int oz) __attribute__((always_inline)) {
+        if (k == 0) {
+          fin_o = *reinterpret_cast<const f32x4*>(lds + SCR_OFF + (((oz & 1) * 4 + (wq ^ 2)) * 64 + lane) * 16);
+        } else {
+          float* const pbase = out + ((int64_t)ub * d.out_bs + (int64_t)(oz < 0 ? 0 : oz) * d.Wo * d.Ho * 32);
+          const __amdgpu_buffer_rsrc_t ores = make_rsrc(pbase, oz < 0 ? 0u : (unsigned)(d.Wo * d.Ho * 32 * 4));
+          f32x4 v = (own + fin_o) + bv;
+          v = __builtin_elementwise_max(v, v * d.slope1);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ores, (int)ooff, 0, 0);
+        }
       };
 
       for (int s = 0; s <= d.Do; ++s) {
         C01_STAMP(0);
-        // staging: the planes requested a step ago -> ring 0; request the next two
-        write_item(item_live, 2 * s + 3 + ipl, irow, iq, ldn);
+        // the planes requested a step ago move to `ldc`; the next two are requested now (a whole step of latency)
+        u32x4 ldc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) ldc[c] = ldn[c];
         issue_item(item_live, 2 * s + 5 + ipl, irow, iq, ldn);
+        const int r0addr = item_live ? ((2 * s + 3 + ipl + 1) % NRING0) * PLB0 + irow * RB0 + iq * 32 : DUMP_OFF;
         C01_STAMP(1);
         if (s >= 1) {
           const int oz = s - 1;
-          finish(oz - 1);   // its partials were exchanged a step ago
-          C01_STAMP(2);
           // planes 2oz-1, 2oz, 2oz+1 of block 0's output: slots (2oz - 1 + 5) % 5 ...
           const int p0 = (2 * oz + 4) % NRING1;
           const unsigned so0 = (unsigned)(p0 * PLB1), so1 = (unsigned)(((p0 + 1) % NRING1) * PLB1), so2 = (unsigned)(((p0 + 2) % NRING1) * PLB1);
@@ -558,12 +596,14 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
             pa[kb][0] = base1[0] + ko; pa[kb][1] = base1[1] + ko;
           }
           f32x4 hi[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, lo[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-          // 14 groups (k-block, tile) of 6 MFMAs; the fragments of group g + 2 are requested at the head of group g
+          // 14 groups (k-block, tile) of 6 MFMAs; the fragments of group g + 2 are requested at the head of group g; behind
+          // each group one slice of the staging (groups 0..11) or of the output of the step before (groups 12, 13)
           bf16x8 fr[3][3];
 #pragma unroll
           for (int g = 0; g < 2; ++g)
 #pragma unroll
             for (int sp = 0; sp < 3; ++sp) fr[g][sp] = frag(pa[g >> 1][g & 1], sp * SPB1, 2 * QS1 * 8);
+          C01_FENCE();
 #pragma unroll
           for (int g = 0; g < 2 * NKB1; ++g) {
             const int kb = g >> 1, t = g & 1;
@@ -575,6 +615,9 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
             lo[t] = MFMA(wr[kb][1], f[1], lo[t]);
             lo[t] = MFMA(wr[kb][2], f[0], lo[t]);
             lo[t] = MFMA(wr[kb][0], f[2], lo[t]);
+            C01_FENCE();
+            if (g < 12) stage_slice(g, ldc, r0addr); else fin_slice(g - 12, oz - 1);
+            C01_FENCE();
             lo[t] = MFMA(wr[kb][1], f[0], lo[t]);
             lo[t] = MFMA(wr[kb][0], f[1], lo[t]);
             hi[t] = MFMA(wr[kb][0], f[0], hi[t]);
@@ -586,11 +629,15 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
           own = bkh ? a1 : a0;
           *reinterpret_cast<f32x4*>(lds + SCR_OFF + (((oz & 1) * 4 + wq) * 64 + lane) * 16) = bkh ? a0 : a1;
           C01_STAMP(4);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 12; ++k) stage_slice(k, ldc, r0addr);
         }
         __syncthreads();
         C01_STAMP(6);
       }
-      finish(d.Do - 1);
+      fin_slice(0, d.Do - 1);
+      fin_slice(1, d.Do - 1);
   }
   }
 #ifdef LR_C01_STAMPS
