@@ -67,11 +67,11 @@ constexpr int NRING1 = 5;                // B reads planes 2s-3 .. 2s-1 while A 
 constexpr int RING1_OFF = RING0;
 constexpr int RING1 = NRING1 * PLB1;     // 77760
 constexpr int SCR_OFF = RING1_OFF + RING1;   // 116928
-constexpr int SCR = 2 * 4 * 64 * 16;     // 8192: [step parity][B wave][lane] partial sums of the tile the wave does not own
+constexpr int SCR = 2 * 4 * 4 * 64 * 16; // 32768: [step parity][B wave = K quarter][accumulator (tile, cout tile)][lane] partial sums
 constexpr int DUMP_OFF = SCR_OFF + SCR;  // 125120: where the threads without a staging item write
 constexpr int LDSB = DUMP_OFF + 512;     // 125632
 constexpr int NITEM = 2 * R0Y * NQ0;     // 132 staging items of a step: (plane, row, x-quad), all channels
-constexpr int NKB0 = 4, NKB1 = 7;
+constexpr int NKB0 = 4, NKB1 = 4;   // k-blocks of block 0 | of a K quarter of block 1 (taps 0..7 | 8..15 | 16..21 | 22..26)
 constexpr unsigned OOR = 0x80000000u;
 static_assert(NITEM <= 256 && 4 * R0Y * NQ0 <= NTHR, "one staging item per thread");
 static_assert(4 * QS1 <= RS1 && (QS1 & 1) == 1 && (RS1 & 15) == 8, "ring-1 bank geometry");
@@ -163,15 +163,15 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
 
   // ---- stationary operands: ONE register array for both roles — A: the 12 fragments [k-block][split] of block 0,
   // B (cout tile c, K half kh): the 21 fragments [k-block][split] of its half of block 1
-  const int bc = wq & 1, bkh = wq >> 1;
-  u32x4 wr[NKB1][3];
+  const int kq = wq;                                        // B: K quarter; it also owns accumulator kq = (tile kq >> 1, cout tile kq & 1)
+  const int tap0 = kq == 0 ? 0 : kq == 1 ? 8 : kq == 2 ? 16 : 22, tap1 = kq == 0 ? 8 : kq == 1 ? 16 : kq == 2 ? 22 : 27;
+  const int nkb = __builtin_amdgcn_readfirstlane((tap1 - tap0 + 1) >> 1);   // 4, 4, 3, 3
+  const int bc = kq & 1;
+  u32x4 wr[24];   // A: [k-block][split]; B: [k-block][cout tile][split]
   {
-    const u32x4* src = is_a ? wp0 : wp1 + (size_t)((bkh * NKB1) * 2 + bc) * 3 * 64;
-    const int kstride = is_a ? 3 * 64 : 2 * 3 * 64;
+    const u32x4* src = is_a ? wp0 : wp1 + (size_t)kq * 24 * 64;
 #pragma unroll
-    for (int kb = 0; kb < NKB1; ++kb)
-#pragma unroll
-      for (int t = 0; t < 3; ++t) wr[kb][t] = (is_a && kb >= NKB0) ? (u32x4){0u, 0u, 0u, 0u} : src[kb * kstride + t * 64 + lane];
+    for (int i = 0; i < 24; ++i) wr[i] = (is_a && i >= 12) ? (u32x4){0u, 0u, 0u, 0u} : src[i * 64 + lane];
   }
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};   // A: block 0's bias of this lane's channel quad; B: block 1's of cout tile c
   {
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
         const int wt = j == 0 ? 1 : j == 1 ? 2 : j == 2 ? 0 : j == 3 ? 1 : 0;
         const int fs = j == 0 ? 1 : j == 1 ? 0 : j == 2 ? 2 : j == 3 ? 0 : j == 4 ? 1 : 0;
         const bf16x8& f = g == 3 ? q.G[r][fs] : q.F[r == 0 ? g : (g == 0 ? 3 : g)][fs];
-        a.v[r] = MFMA(wr[kb][wt], f, a.v[r]);
+        a.v[r] = MFMA(wr[kb * 3 + wt], f, a.v[r]);
       };
       auto load_one_n = [&](int n, const Base& b, OneFrags& q) __attribute__((always_inline)) {   // n = 0..11: F0 F1 F2 G
         const int grp = n / 3, sp = n % 3;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
         const int wt = j == 0 ? 1 : j == 1 ? 2 : j == 2 ? 0 : j == 3 ? 1 : 0;
         const int fs = j == 0 ? 1 : j == 1 ? 0 : j == 2 ? 2 : j == 3 ? 0 : j == 4 ? 1 : 0;
         const bf16x8& f = kb == 3 ? q.G[fs] : q.F[kb][fs];
-        a.v[kb & 1] = MFMA(wr[kb][wt], f, a.v[kb & 1]);
+        a.v[kb & 1] = MFMA(wr[kb * 3 + wt], f, a.v[kb & 1]);
       };
       // the epilogue of one block-0 tile in 7 slices: LeakyReLU, the two three-way splits, the three stores into ring 1
       struct Epi { f32x4 x, y; f32x2 r; u32x2 s0, s1, s2; };   // s_k = the 8-byte record of split k: (channels 01 | channels 23)
@@ -510,23 +510,23 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
 
       // =========================================================== B: block 1 ===========================================
       // Tile t = output rows 2t + {0,1} of the column; lane column = (row r1, voxel oxl); lq = (tap of the k-block's pair,
-      // channel half).  K half bkh: taps 14*bkh + 2*kb + {0,1}; cout tile bc.
+      // channel half).  K quarter kq: taps tap0 + 2*kb + {0,1} < tap1, both cout tiles.
       const int r1 = col >> 3, oxl = col & 7, hh = lq & 1, tsel = lq >> 1;
-      unsigned base1[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) base1[t] = (unsigned)(RING1_OFF + ((2 * (2 * t + r1)) * RS1 + 2 * oxl + hh * QS1) * 8);
-      unsigned toff[NKB1];
-      int tdz[NKB1];
+      // ring-1 byte offset of this lane's operand half for tile 0, k-block kb, without the plane slot (tile 1: + T1OFF);
+      // tdzp: two bits per k-block = the plane (0..2) its tap lies in
+      constexpr int T1OFF = 2 * 2 * RS1 * 8;
+      unsigned pq[NKB1];
+      unsigned tdzp = 0;
 #pragma unroll
       for (int kb = 0; kb < NKB1; ++kb) {
-        int tap = 14 * bkh + 2 * kb + tsel;
-        tap = tap > 26 ? 26 : tap;   // the 28th slot: weight 0 on a real voxel
+        int tap = tap0 + 2 * kb + tsel;
+        tap = tap >= tap1 ? tap1 - 1 : tap;   // slots behind the quarter: weight 0 on a real voxel
         const int dz = tap / 9, dy = (tap % 9) / 3, dx = tap % 3;
-        toff[kb] = (unsigned)((dy * RS1 + dx) * 8);
-        tdz[kb] = dz;
+        pq[kb] = (unsigned)(RING1_OFF + ((2 * r1 + dy) * RS1 + 2 * oxl + hh * QS1 + dx) * 8);
+        tdzp |= (unsigned)dz << (2 * kb);
       }
-      // the output voxel this lane stores: tile bkh of the column, cout tile bc
-      const int oy = oy0 + 2 * bkh + r1, ox = ox0 + oxl;
+      // the output voxel this lane stores: tile kq >> 1 of the column, cout tile bc = kq & 1
+      const int oy = oy0 + 2 * (kq >> 1) + r1, ox = ox0 + oxl;
       const bool o_in = oy < d.Wo && ox < d.Ho;
       unsigned ooff;
       if (d.hps) {   // row = [channel block of 16][parity][Ho/2][16 floats]
@@ -537,51 +537,55 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
       }
       if (!o_in) ooff = OOR;
       f32x4 own = {0.f, 0.f, 0.f, 0.f};
-      // staging of this thread's item in 12 slices: unpack | per voxel j: split channels 01, split channels 23 | 3 x two stores
-      float sv[4][4];
-      unsigned rec[3][4][2];
-      auto stage_slice = [&](int k, const u32x4 (&L)[NC], int addr) __attribute__((always_inline)) {
-        if (k == 0) {
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) {
-            const uint4 q = __builtin_bit_cast(uint4, L[cc < NC ? cc : 0]);
-            sv[cc][0] = cc < NC ? __builtin_bit_cast(float, q.x) : 0.0f; sv[cc][1] = cc < NC ? __builtin_bit_cast(float, q.y) : 0.0f;
-            sv[cc][2] = cc < NC ? __builtin_bit_cast(float, q.z) : 0.0f; sv[cc][3] = cc < NC ? __builtin_bit_cast(float, q.w) : 0.0f;
-          }
-        } else if (k <= 8) {
-          const int vj = (k - 1) >> 1, hf = (k - 1) & 1;
-          unsigned pp[3] = {0u, 0u, 0u};
-          if (hf) { if (NC > 2) split3(sv[2][vj], sv[3][vj], pp); }
-          else split3(sv[0][vj], sv[1][vj], pp);
-#pragma unroll
-          for (int sp = 0; sp < 3; ++sp) rec[sp][vj][hf] = pp[sp];
-        } else {
-          const int sp = k - 9;
-          *reinterpret_cast<u32x4*>(lds + addr + sp * SB0) = (u32x4){rec[sp][0][0], rec[sp][0][1], rec[sp][1][0], rec[sp][1][1]};
-          *reinterpret_cast<u32x4*>(lds + addr + sp * SB0 + 16) = (u32x4){rec[sp][2][0], rec[sp][2][1], rec[sp][3][0], rec[sp][3][1]};
-        }
+      // staging of this thread's item in 2 slices: per voxel pair (0,1 | 2,3) four splits (voxel x channels 01 | 23) and the
+      // pair's three 16-byte stores; the slices read the requested quads where they landed (`ldn`), the next request goes out
+      // behind the second slice (most of a step of latency).  (Finer slices kept 12 more registers alive across the MFMA groups
+      // than this role has.)
+      auto lval = [&](int c, int j) __attribute__((always_inline)) -> float {
+        if (c >= NC) return 0.0f;
+        const uint4 q = __builtin_bit_cast(uint4, ldn[c < NC ? c : 0]);
+        return __builtin_bit_cast(float, j == 0 ? q.x : j == 1 ? q.y : j == 2 ? q.z : q.w);
       };
-      // output plane oz in 2 slices: read the partner's K half | sum, bias, LeakyReLU, store (oz < 0: zero-length resource)
-      f32x4 fin_o = {0.f, 0.f, 0.f, 0.f};
+      auto stage_slice = [&](int half, int addr) __attribute__((always_inline)) {
+        unsigned rec[3][2][2];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int vj = 2 * half + (kk >> 1), hf = kk & 1;
+          unsigned pp[3] = {0u, 0u, 0u};
+          if (hf) { if (NC > 2) split3(lval(2, vj), lval(3, vj), pp); }
+          else split3(lval(0, vj), lval(1, vj), pp);
+#pragma unroll
+          for (int sp = 0; sp < 3; ++sp) rec[sp][kk >> 1][hf] = pp[sp];
+        }
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp)
+          *reinterpret_cast<u32x4*>(lds + addr + sp * SB0 + 16 * half) = (u32x4){rec[sp][0][0], rec[sp][0][1], rec[sp][1][0], rec[sp][1][1]};
+      };
+      // output plane oz in 3 slices: the K quarters of this wave's accumulator, summed in quarter order (its own from registers),
+      // bias, LeakyReLU, store (oz < 0: zero-length resource, no branch)
+      f32x4 fin_a, fin_b;
+      auto fin_read = [&](int q, int oz) __attribute__((always_inline)) -> f32x4 {
+        return *reinterpret_cast<const f32x4*>(lds + SCR_OFF + ((((oz & 1) * 4 + q) * 4 + kq) * 64 + lane) * 16);
+      };
       auto fin_slice = [&](int k, int oz) __attribute__((always_inline)) {
-        if (k == 0) {
-          fin_o = *reinterpret_cast<const f32x4*>(lds + SCR_OFF + (((oz & 1) * 4 + (wq ^ 2)) * 64 + lane) * 16);
+        if (k == 0) { fin_a = fin_read(0, oz); fin_b = fin_read(1, oz); }
+        else if (k == 1) {
+          fin_a = (kq == 0 ? own : fin_a) + (kq == 1 ? own : fin_b);
+          fin_b = fin_read(2, oz);
         } else {
+          const f32x4 p3 = fin_read(3, oz);
           float* const pbase = out + ((int64_t)ub * d.out_bs + (int64_t)(oz < 0 ? 0 : oz) * d.Wo * d.Ho * 32);
           const __amdgpu_buffer_rsrc_t ores = make_rsrc(pbase, oz < 0 ? 0u : (unsigned)(d.Wo * d.Ho * 32 * 4));
-          f32x4 v = (own + fin_o) + bv;
+          f32x4 v = fin_a + (kq == 2 ? own : fin_b);
+          v = (v + (kq == 3 ? own : p3)) + bv;
           v = __builtin_elementwise_max(v, v * d.slope1);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ores, (int)ooff, 0, 0);
         }
       };
+      constexpr int NST = 2, NSL = 5;   // slices of a step: 2 staging + 3 output
 
       for (int s = 0; s <= d.Do; ++s) {
         C01_STAMP(0);
-        // the planes requested a step ago move to `ldc`; the next two are requested now (a whole step of latency)
-        u32x4 ldc[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) ldc[c] = ldn[c];
-        issue_item(item_live, 2 * s + 5 + ipl, irow, iq, ldn);
         const int r0addr = item_live ? ((2 * s + 3 + ipl + 1) % NRING0) * PLB0 + irow * RB0 + iq * 32 : DUMP_OFF;
         C01_STAMP(1);
         if (s >= 1) {
@@ -589,55 +593,75 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
           // planes 2oz-1, 2oz, 2oz+1 of block 0's output: slots (2oz - 1 + 5) % 5 ...
           const int p0 = (2 * oz + 4) % NRING1;
           const unsigned so0 = (unsigned)(p0 * PLB1), so1 = (unsigned)(((p0 + 1) % NRING1) * PLB1), so2 = (unsigned)(((p0 + 2) % NRING1) * PLB1);
-          unsigned pa[NKB1][2];
+          unsigned pa[NKB1];
 #pragma unroll
           for (int kb = 0; kb < NKB1; ++kb) {
-            const unsigned ko = toff[kb] + (tdz[kb] == 0 ? so0 : tdz[kb] == 1 ? so1 : so2);
-            pa[kb][0] = base1[0] + ko; pa[kb][1] = base1[1] + ko;
+            const unsigned dz = (tdzp >> (2 * kb)) & 3u;
+            pa[kb] = pq[kb] + (dz == 0 ? so0 : dz == 1 ? so1 : so2);
           }
-          f32x4 hi[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, lo[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-          // 14 groups (k-block, tile) of 6 MFMAs; the fragments of group g + 2 are requested at the head of group g; behind
-          // each group one slice of the staging (groups 0..11) or of the output of the step before (groups 12, 13)
-          bf16x8 fr[3][3];
+          f32x4 hi[2][2], lo[2][2];
 #pragma unroll
-          for (int g = 0; g < 2; ++g)
+          for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp) fr[g][sp] = frag(pa[g >> 1][g & 1], sp * SPB1, 2 * QS1 * 8);
+            for (int c = 0; c < 2; ++c) { hi[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+          // 2 nkb groups (k-block, tile) of 12 MFMAs (both cout tiles: every fragment feeds four MFMAs); the fragments of group
+          // g + 1 are requested at the head of group g; behind each half group one slice of the staging (12) or of the output of
+          // the step before (2)
+          bf16x8 fr[2][3];
+#pragma unroll
+          for (int sp = 0; sp < 3; ++sp) fr[0][sp] = frag(pa[0], sp * SPB1, 2 * QS1 * 8);
           C01_FENCE();
-#pragma unroll
-          for (int g = 0; g < 2 * NKB1; ++g) {
+          auto group = [&](int g) __attribute__((always_inline)) {
             const int kb = g >> 1, t = g & 1;
-            if (g + 2 < 2 * NKB1) {
+            if (g + 1 < 6 || (g + 1 < 8 && nkb == 4)) {
 #pragma unroll
-              for (int sp = 0; sp < 3; ++sp) fr[(g + 2) % 3][sp] = frag(pa[(g + 2) >> 1][(g + 2) & 1], sp * SPB1, 2 * QS1 * 8);
+              for (int sp = 0; sp < 3; ++sp) fr[(g + 1) & 1][sp] = frag(pa[(g + 1) >> 1], ((g + 1) & 1) * T1OFF + sp * SPB1, 2 * QS1 * 8);
             }
-            const bf16x8 (&f)[3] = fr[g % 3];
-            lo[t] = MFMA(wr[kb][1], f[1], lo[t]);
-            lo[t] = MFMA(wr[kb][2], f[0], lo[t]);
-            lo[t] = MFMA(wr[kb][0], f[2], lo[t]);
+            const bf16x8 (&f)[3] = fr[g & 1];
+            const u32x4 (&w)[24] = wr;
+#define C01_W(C, T) w[(kb * 2 + (C)) * 3 + (T)]
+            lo[t][0] = MFMA(C01_W(0, 1), f[1], lo[t][0]); lo[t][1] = MFMA(C01_W(1, 1), f[1], lo[t][1]);
+            lo[t][0] = MFMA(C01_W(0, 2), f[0], lo[t][0]); lo[t][1] = MFMA(C01_W(1, 2), f[0], lo[t][1]);
+            lo[t][0] = MFMA(C01_W(0, 0), f[2], lo[t][0]); lo[t][1] = MFMA(C01_W(1, 0), f[2], lo[t][1]);
             C01_FENCE();
-            if (g < 12) stage_slice(g, ldc, r0addr); else fin_slice(g - 12, oz - 1);
+            if (2 * g < NST) stage_slice(2 * g, r0addr); else if (2 * g < NSL) fin_slice(2 * g - NST, oz - 1);
             C01_FENCE();
-            lo[t] = MFMA(wr[kb][1], f[0], lo[t]);
-            lo[t] = MFMA(wr[kb][0], f[1], lo[t]);
-            hi[t] = MFMA(wr[kb][0], f[0], hi[t]);
+            lo[t][0] = MFMA(C01_W(0, 1), f[0], lo[t][0]); lo[t][1] = MFMA(C01_W(1, 1), f[0], lo[t][1]);
+            lo[t][0] = MFMA(C01_W(0, 0), f[1], lo[t][0]); lo[t][1] = MFMA(C01_W(1, 0), f[1], lo[t][1]);
+            hi[t][0] = MFMA(C01_W(0, 0), f[0], hi[t][0]); hi[t][1] = MFMA(C01_W(1, 0), f[0], hi[t][1]);
+#undef C01_W
             C01_FENCE();
+            if (2 * g + 1 < NST) stage_slice(2 * g + 1, r0addr); else if (2 * g + 1 < NSL) fin_slice(2 * g + 1 - NST, oz - 1);
+            if (2 * g + 1 == NST - 1) issue_item(item_live, 2 * s + 5 + ipl, irow, iq, ldn);
+            C01_FENCE();
+          };
+#pragma unroll
+          for (int g = 0; g < 6; ++g) group(g);
+          if (nkb == 4) {   // (all 11 slices fit into the first six groups)
+            group(6);
+            group(7);
           }
           C01_STAMP(3);
-          // the tile this wave does not own -> LDS (read by its partner after the barrier)
-          const f32x4 a0 = hi[0] + lo[0], a1 = hi[1] + lo[1];
-          own = bkh ? a1 : a0;
-          *reinterpret_cast<f32x4*>(lds + SCR_OFF + (((oz & 1) * 4 + wq) * 64 + lane) * 16) = bkh ? a0 : a1;
+          // the accumulators this wave does not own -> LDS (read by their owners after the barrier); its own stays in registers
+          f32x4 acc[4];
+#pragma unroll
+          for (int a4 = 0; a4 < 4; ++a4) acc[a4] = hi[a4 >> 1][a4 & 1] + lo[a4 >> 1][a4 & 1];
+          own = kq == 0 ? acc[0] : kq == 1 ? acc[1] : kq == 2 ? acc[2] : acc[3];
+#pragma unroll
+          for (int a4 = 0; a4 < 4; ++a4)
+            *reinterpret_cast<f32x4*>(lds + SCR_OFF + ((((oz & 1) * 4 + kq) * 4 + a4) * 64 + lane) * 16) = acc[a4];
           C01_STAMP(4);
         } else {
 #pragma unroll
-          for (int k = 0; k < 12; ++k) stage_slice(k, ldc, r0addr);
+          for (int k = 0; k < NST; ++k) stage_slice(k, r0addr);
+          issue_item(item_live, 2 * s + 5 + ipl, irow, iq, ldn);
         }
         __syncthreads();
         C01_STAMP(6);
       }
       fin_slice(0, d.Do - 1);
       fin_slice(1, d.Do - 1);
+      fin_slice(2, d.Do - 1);
   }
   }
 #ifdef LR_C01_STAMPS
@@ -648,14 +672,16 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
 #endif
 }
 
-// packed1[((((kh*7 + kb)*2 + c)*3) + t)*64 + lane]: lane (co = lane & 15, lq = lane >> 4) holds split t of
-// W1[c*16 + co][ch = 8*(lq & 1) + e][tap = 14*kh + 2*kb + (lq >> 1)], e = 0..7 (tap 27: zeros)
+// packed1[(((kq*4 + kb)*2 + c)*3 + t)*64 + lane]: lane (co = lane & 15, lq = lane >> 4) holds split t of
+// W1[c*16 + co][ch = 8*(lq & 1) + e][tap = tap0(kq) + 2*kb + (lq >> 1)], e = 0..7 — zeros for taps behind the quarter
+// (quarters: taps 0..7 | 8..15 | 16..21 | 22..26)
 __global__ void pack_c01_w1_kernel(const float* __restrict__ w, u32x4* __restrict__ packed) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= 2 * NKB1 * 2 * 64) return;
-  const int lane = idx & 63, c = (idx >> 6) & 1, kb = (idx >> 7) % NKB1, kh = (idx >> 7) / NKB1;
+  if (idx >= 4 * 4 * 2 * 64) return;
+  const int lane = idx & 63, c = (idx >> 6) & 1, kb = (idx >> 7) & 3, kq = idx >> 9;
   const int co = lane & 15, lq = lane >> 4;
-  const int tap = 14 * kh + 2 * kb + (lq >> 1);
+  const int tap0 = kq == 0 ? 0 : kq == 1 ? 8 : kq == 2 ? 16 : 22, tap1 = kq == 0 ? 8 : kq == 1 ? 16 : kq == 2 ? 22 : 27;
+  const int tap = tap0 + 2 * kb + (lq >> 1);
   unsigned r[3][4];
 #pragma unroll
   for (int pr = 0; pr < 4; ++pr) {
@@ -663,7 +689,7 @@ __global__ void pack_c01_w1_kernel(const float* __restrict__ w, u32x4* __restric
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       const int ch = 8 * (lq & 1) + 2 * pr + hh;
-      v[hh] = tap < 27 ? w[((int64_t)(c * 16 + co) * 16 + ch) * 27 + tap] : 0.0f;
+      v[hh] = tap < tap1 ? w[((int64_t)(c * 16 + co) * 16 + ch) * 27 + tap] : 0.0f;
     }
     unsigned p[3];
     split3(v[0], v[1], p);
@@ -672,10 +698,10 @@ __global__ void pack_c01_w1_kernel(const float* __restrict__ w, u32x4* __restric
   }
 #pragma unroll
   for (int t = 0; t < 3; ++t)
-    packed[((((kh * NKB1 + kb) * 2 + c) * 3) + t) * 64 + lane] = (u32x4){r[t][0], r[t][1], r[t][2], r[t][3]};
+    packed[((((kq * 4 + kb) * 2 + c) * 3) + t) * 64 + lane] = (u32x4){r[t][0], r[t][1], r[t][2], r[t][3]};
 }
 
-constexpr int64_t W1_FLOATS = (int64_t)2 * NKB1 * 2 * 3 * 64 * 4;
+constexpr int64_t W1_FLOATS = (int64_t)4 * 4 * 2 * 3 * 64 * 4;
 
 }  // namespace
 
@@ -704,7 +730,7 @@ extern "C" int lr_conv3d_pair01_pack_f32(const float* w0, const float* w1, float
   const int rc = lr_internal_conv0_split_pack(w0, packed, Cin, C0, st);
   if (rc != LR_OK) return rc;
   u32x4* p1 = reinterpret_cast<u32x4*>(packed + lr_internal_conv0_split_packed_floats(Cin, C0));
-  hipLaunchKernelGGL(pack_c01_w1_kernel, dim3((2 * NKB1 * 2 * 64 + 255) / 256), dim3(256), 0, st, w1, p1);
+  hipLaunchKernelGGL(pack_c01_w1_kernel, dim3((4 * 4 * 2 * 64 + 255) / 256), dim3(256), 0, st, w1, p1);
   return lr_launch_status();
 }
 
