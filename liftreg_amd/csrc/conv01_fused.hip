@@ -139,6 +139,11 @@ __device__ unsigned long long g_lr_c01_stamps[8 * 8];
 #endif
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), b, c, 0, 0, 0)
+// timing-only ablation bits of a diagnostic build (`make abl`, tools/c01_abl.py; WRONG results): 1 B no MFMAs, 2 A idle, 4 A no
+// epilogue, 8 B no fragment reads, 16 A no MFMAs, 32 A no fragment reads
+#ifndef LR_C01_ABL
+#define LR_C01_ABL 0
+#endif
 #define C01_FENCE() __builtin_amdgcn_sched_barrier(0)
 #ifndef LR_C01_BPRIO
 #define LR_C01_BPRIO 1
@@ -279,7 +284,11 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
       const unsigned laneF = (unsigned)((col + 2 + (lq == 3 ? 2 : 0)) * 8);
       const unsigned laneG = (unsigned)((lq & 1) * 2 * RB0 + (col + 4) * 8);
       const int spl = wq & 1, scol = wq >> 1;                                    // the single tile: plane | row 8 or column 16
-      const int sry = scol ? col : 8, srx = scol ? 16 : col;
+#ifndef LR_C01_COLCLAMP
+#define LR_C01_COLCLAMP 1
+#endif
+      // (column tile: lanes 9..15 have no voxel; with LR_C01_COLCLAMP they re-read row 8 — same addresses as lane 8, no extra bank conflicts)
+      const int sry = scol ? (LR_C01_COLCLAMP ? (col < 8 ? col : 8) : col) : 8, srx = scol ? 16 : col;
       const unsigned laneFs = (unsigned)(sry * RB0 + (srx + 2 + (lq == 3 ? 2 : 0)) * 8);
       const unsigned laneGs = (unsigned)((sry + (lq & 1) * 2) * RB0 + (srx + 4) * 8);
       const unsigned qpos = (unsigned)(((lq & 1) << 1) | (lq >> 1));   // ring-1 position of channel quad lq: order 0,2,1,3
@@ -289,16 +298,18 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
       const int ry0 = 2 * wq;
       const bool xok = (unsigned)(X1 + col) < (unsigned)dH;
       const bool ok_p0 = xok && (unsigned)(Y1 + ry0) < (unsigned)dW, ok_p1 = xok && (unsigned)(Y1 + ry0 + 1) < (unsigned)dW;
-      const bool ok_s = (unsigned)(Y1 + sry) < (unsigned)dW && (unsigned)(X1 + srx) < (unsigned)dH && sry < R1Y;
+      const bool ok_s = (unsigned)(Y1 + sry) < (unsigned)dW && (unsigned)(X1 + srx) < (unsigned)dH && (!scol || col < R1Y);
       const int st_p0 = RING1_OFF + (ry0 * RS1 + (int)qpos * QS1 + col) * 8, st_p1 = st_p0 + RS1 * 8;
       const int st_s = RING1_OFF + (sry * RS1 + (int)qpos * QS1 + srx) * 8;
 
+      constexpr bool a_mma_g = !(LR_C01_ABL & 16), a_ld_g = !(LR_C01_ABL & 32), a_epi_g = !(LR_C01_ABL & 4);
       struct PairFrags { bf16x8 F[4][3], G[2][3]; };
       struct OneFrags { bf16x8 F[3][3], G[3]; };
       struct Acc2 { f32x4 v[2]; };   // block 0 (K = 81): one fp32 chain per tile, small products first inside each k-block
       struct Base { unsigned pF, pG, pG1; };
       // fragment n (0..17) of a pair, in the order the MFMAs use them: F0 F3 F1 F2 G0 G1, three splits each
       auto load_pair_n = [&](int n, const Base& b, PairFrags& q) __attribute__((always_inline)) {
+        if (!a_ld_g) return;
         const int grp = n / 3, sp = n % 3;
         if (grp < 4) {
           const int iy = grp == 0 ? 0 : grp == 1 ? 3 : grp == 2 ? 1 : 2;
@@ -315,9 +326,10 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
         const int wt = j == 0 ? 1 : j == 1 ? 2 : j == 2 ? 0 : j == 3 ? 1 : 0;
         const int fs = j == 0 ? 1 : j == 1 ? 0 : j == 2 ? 2 : j == 3 ? 0 : j == 4 ? 1 : 0;
         const bf16x8& f = g == 3 ? q.G[r][fs] : q.F[r == 0 ? g : (g == 0 ? 3 : g)][fs];
-        a.v[r] = MFMA(wr[kb * 3 + wt], f, a.v[r]);
+        if (a_mma_g) a.v[r] = MFMA(wr[kb * 3 + wt], f, a.v[r]);
       };
       auto load_one_n = [&](int n, const Base& b, OneFrags& q) __attribute__((always_inline)) {   // n = 0..11: F0 F1 F2 G
+        if (!a_ld_g) return;
         const int grp = n / 3, sp = n % 3;
         if (grp < 3) q.F[grp][sp] = frag(b.pF, grp * RB0 + sp * SB0, 8);
         else q.G[sp] = frag(b.pG, sp * SB0, RB0);
@@ -327,7 +339,7 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
         const int wt = j == 0 ? 1 : j == 1 ? 2 : j == 2 ? 0 : j == 3 ? 1 : 0;
         const int fs = j == 0 ? 1 : j == 1 ? 0 : j == 2 ? 2 : j == 3 ? 0 : j == 4 ? 1 : 0;
         const bf16x8& f = kb == 3 ? q.G[fs] : q.F[kb][fs];
-        a.v[kb & 1] = MFMA(wr[kb * 3 + wt], f, a.v[kb & 1]);
+        if (a_mma_g) a.v[kb & 1] = MFMA(wr[kb * 3 + wt], f, a.v[kb & 1]);
       };
       // the epilogue of one block-0 tile in 7 slices: LeakyReLU, the two three-way splits, the three stores into ring 1
       struct Epi { f32x4 x, y; f32x2 r; u32x2 s0, s1, s2; };   // s_k = the 8-byte record of split k: (channels 01 | channels 23)
@@ -348,6 +360,7 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
         return o;
       };
       auto epi_slice = [&](int sl, Epi& E, const f32x4& acc, int addr) __attribute__((always_inline)) {
+        if (!a_epi_g) return;
         if (sl == 0) { E.x = acc; E.y = E.x * d.slope0; }
         else if (sl == 1) E.x = __builtin_elementwise_max(E.x, E.y);   // = LeakyReLU for 0 <= slope <= 1 (launcher)
         else if (sl == 2) { const L0 t = lvl0(E.x[0], E.x[1]); E.s0 = (u32x2){t.p, 0u}; E.r = t.r; }
@@ -363,7 +376,8 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
 
       int e6 = 0, m5 = 0;   // (2s) mod 6 = ring-0 slot of plane 2s-1; (2s) mod 5 = ring-1 slot of plane 2s
       for (int s = 0; s <= d.Do; ++s) {
-        if (s < d.Do) {
+        constexpr bool a_on = !(LR_C01_ABL & 2);
+        if (s < d.Do && a_on) {
           C01_STAMP(0);
           if (2 * s + 1 >= dD)   // odd D, last step: plane 2s+1 lies below the volume — its slot must read 0 (its stores are dropped)
             for (int o = tid * 16; o < PLB1; o += 256 * 16) *reinterpret_cast<u32x4*>(lds + RING1_OFF + ((m5 + 1) % NRING1) * PLB1 + o) = (u32x4){0u, 0u, 0u, 0u};
@@ -599,6 +613,7 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
             const unsigned dz = (tdzp >> (2 * kb)) & 3u;
             pa[kb] = pq[kb] + (dz == 0 ? so0 : dz == 1 ? so1 : so2);
           }
+          constexpr bool b_ld = !(LR_C01_ABL & 8), b_mma = !(LR_C01_ABL & 1);
           f32x4 hi[2][2], lo[2][2];
 #pragma unroll
           for (int t = 0; t < 2; ++t)
@@ -613,22 +628,26 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
           C01_FENCE();
           auto group = [&](int g) __attribute__((always_inline)) {
             const int kb = g >> 1, t = g & 1;
-            if (g + 1 < 6 || (g + 1 < 8 && nkb == 4)) {
+            if ((g + 1 < 6 || (g + 1 < 8 && nkb == 4)) && b_ld) {
 #pragma unroll
               for (int sp = 0; sp < 3; ++sp) fr[(g + 1) & 1][sp] = frag(pa[(g + 1) >> 1], ((g + 1) & 1) * T1OFF + sp * SPB1, 2 * QS1 * 8);
             }
             const bf16x8 (&f)[3] = fr[g & 1];
             const u32x4 (&w)[24] = wr;
 #define C01_W(C, T) w[(kb * 2 + (C)) * 3 + (T)]
+            if (b_mma) {
             lo[t][0] = MFMA(C01_W(0, 1), f[1], lo[t][0]); lo[t][1] = MFMA(C01_W(1, 1), f[1], lo[t][1]);
             lo[t][0] = MFMA(C01_W(0, 2), f[0], lo[t][0]); lo[t][1] = MFMA(C01_W(1, 2), f[0], lo[t][1]);
             lo[t][0] = MFMA(C01_W(0, 0), f[2], lo[t][0]); lo[t][1] = MFMA(C01_W(1, 0), f[2], lo[t][1]);
+            }
             C01_FENCE();
             if (2 * g < NST) stage_slice(2 * g, r0addr); else if (2 * g < NSL) fin_slice(2 * g - NST, oz - 1);
             C01_FENCE();
+            if (b_mma) {
             lo[t][0] = MFMA(C01_W(0, 1), f[0], lo[t][0]); lo[t][1] = MFMA(C01_W(1, 1), f[0], lo[t][1]);
             lo[t][0] = MFMA(C01_W(0, 0), f[1], lo[t][0]); lo[t][1] = MFMA(C01_W(1, 0), f[1], lo[t][1]);
             hi[t][0] = MFMA(C01_W(0, 0), f[0], hi[t][0]); hi[t][1] = MFMA(C01_W(1, 0), f[0], hi[t][1]);
+            }
 #undef C01_W
             C01_FENCE();
             if (2 * g + 1 < NST) stage_slice(2 * g + 1, r0addr); else if (2 * g + 1 < NSL) fin_slice(2 * g + 1 - NST, oz - 1);
