@@ -401,6 +401,16 @@ int lr_conv3d_pair01_f32(const float* in0, int64_t in0_batch_stride, const float
                          const float* packed, const float* bias0, const float* bias1, float* out, int B, int Cin,
                          int D, int W, int H, int out_layout, float slope0, float slope1, int64_t out_batch_stride,
                          void* stream);
+/* ... on a z-slab (liftreg_amd/parallel.py): the buffers in0 / in_rest hold the D global planes
+ * [z_lo, z_lo + D) of a volume of D_global planes; output planes [oz_lo, oz_lo + n_oz) are computed into planes 0..n_oz-1 of
+ * `out`.  They read input planes 2*oz_lo - 2 .. 2*(oz_lo + n_oz) — those that exist must lie inside the buffers
+ * (LR_EINVAL otherwise); planes outside the GLOBAL volume are the convs' zero padding.  The two blocks need no halo
+ * exchange this way: in0 is a view of the replicated moving volume, in_rest the rank's own backprojection of planes
+ * [z_lo, z_lo + D).  Same bits as the whole-volume call. */
+int lr_conv3d_pair01_slab_f32(const float* in0, int64_t in0_batch_stride, const float* in_rest, int64_t rest_batch_stride,
+                              const float* packed, const float* bias0, const float* bias1, float* out, int B, int Cin,
+                              int D, int W, int H, int out_layout, float slope0, float slope1, int64_t out_batch_stride,
+                              int D_global, int z_lo, int oz_lo, int n_oz, void* stream);
 
 /* f1 ("backproject -> conv0: never write the P*V volume"): the same first block with the backprojection
  * computed INSIDE its staging.  Channel 0 = in0 (B,1,D,W,H), channels 1..P = the backprojection of proj (B,P,Pw,Ph)

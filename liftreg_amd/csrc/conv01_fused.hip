@@ -79,7 +79,8 @@ static_assert((PLB0 & 255) == 128 && (RB0 & 127) == 64, "ring-0 bank geometry");
 static_assert(LDSB <= 160 * 1024, "LDS");
 
 struct FDims {
-  int B, Cin, D, W, H, Do, Wo, Ho;
+  int B, Cin, D, W, H, Do, Wo, Ho;   // D = planes of the input buffers (a z-slab), Do = output planes to compute
+  int Dg, zoff, zlo;                  // global depth | global z of local plane 0 (= 2 x first output plane) | global z of buffer plane 0
   int nTx, nTy, nunits;
   int hps;                 // output layout: 1 = LR_LAYOUT_NDHWC_HPS, 0 = LR_LAYOUT_NDHWC
   long long bs0, bsr;      // elements between batch elements of channel 0 | of channels 1..Cin-1
@@ -161,7 +162,13 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
   const int wq = wave & 3;                    // index inside the role
   const int col = lane & 15, lq = lane >> 4;
   const int dD = d.D, dW = d.W, dH = d.H;
-  const unsigned V4 = (unsigned)dD * dW * dH * 4u;   // bytes of one channel volume (3 of them < 2^31: launcher)
+  const unsigned V4 = (unsigned)dD * dW * dH * 4u;   // bytes of one channel volume of the buffers (3 of them < 2^31: launcher)
+  // z bookkeeping: the kernel counts planes LOCALLY (output plane 0 = the first one it computes, input / block-0 plane z_l
+  // = global z - zoff); a plane exists iff 0 <= z_l + zoff < Dg and then sits at plane z_l + zoff - zlo of the buffers
+  const int Dg = d.Dg, zoff = d.zoff, zrel = d.zoff - d.zlo;
+  // a slab that does not start at the top of the volume: block-0 plane -1 (global zoff - 1) exists — one step s = -1 in front
+  // computes it (A: planes -2, -1, the first into a slot nobody reads; B: staging only)
+  const int s0 = __builtin_amdgcn_readfirstlane(zoff > 0 ? -1 : 0);
 
   // zero everything once: a "weight 0" operand slot multiplies whatever lies behind a row / plane and needs finite numbers
   for (int o = tid * 16; o < LDSB; o += NTHR * 16) *reinterpret_cast<u32x4*>(lds + o) = (u32x4){0u, 0u, 0u, 0u};
@@ -220,9 +227,10 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
     // other elements undefined — DESIGN.md 6a: the quads are viewed through HIP's uint4, a struct, where they are used)
     auto issue_item = [&](bool live, int zi, int irow, int iq, u32x4 (&L)[NC]) __attribute__((always_inline)) {
       const int yi = Y0 + irow, xi = X0a + 4 * iq;
-      const int ok = (int)live & (int)(zi >= 0) & (int)(zi < dD) & (int)(yi >= 0) & (int)(yi < dW) & (int)(xi >= 0) & (int)(xi < dH);
+      const int zg = zi + zoff;
+      const int ok = (int)live & (int)(zg >= 0) & (int)(zg < Dg) & (int)(yi >= 0) & (int)(yi < dW) & (int)(xi >= 0) & (int)(xi < dH);
       const unsigned dead = ((unsigned)ok - 1u) & OOR;   // dead item: bit 31 -> outside the resource -> 0
-      const unsigned voff = (unsigned)(((zi * dW + yi) * dH + xi) * 4);
+      const unsigned voff = (unsigned)((((zi + zrel) * dW + yi) * dH + xi) * 4);
       L[0] = __builtin_amdgcn_raw_buffer_load_b128(r0, (int)(voff | dead), 0, 0);
 #pragma unroll
       for (int c = 1; c < NC; ++c) L[c] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)((voff + (unsigned)(c - 1) * V4) | dead), 0, 0);
@@ -254,8 +262,8 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
       }
     };
 
-    // ---- unit prologue: ring 1 <- 0 (plane -1, and every voxel of the column outside the volume), ring 0 <- planes -1..2
-    // (all 512 threads: 4 x 66 items); the B threads also request planes 3, 4 (their items of step 0)
+    // ---- unit prologue: ring 1 <- 0 (every voxel of the column outside the volume), ring 0 <- planes 2 s0 - 1 .. 2 s0 + 2
+    // (all 512 threads: 4 x 66 items); the B threads also request planes 2 s0 + 3, + 4 (their items of the first step)
     const int bt = tid - 256;                                       // B: thread index inside the role
     const bool item_live = !is_a && bt < NITEM;
     const int ipl = item_live ? bt / (R0Y * NQ0) : 0, irow = item_live ? (bt % (R0Y * NQ0)) / NQ0 : 0, iq = item_live ? bt % NQ0 : 0;
@@ -263,10 +271,10 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
     __syncthreads();   // (the zero fill of the whole LDS | every read of the unit before)
     {
       const bool pl_live = tid < 4 * R0Y * NQ0;
-      const int pz = pl_live ? tid / (R0Y * NQ0) - 1 : 0, prow = pl_live ? (tid % (R0Y * NQ0)) / NQ0 : 0, pq = pl_live ? tid % NQ0 : 0;
+      const int pz = pl_live ? tid / (R0Y * NQ0) - 1 + 2 * s0 : 0, prow = pl_live ? (tid % (R0Y * NQ0)) / NQ0 : 0, pq = pl_live ? tid % NQ0 : 0;
       u32x4 lp[NC];
       issue_item(pl_live, pz, prow, pq, lp);
-      issue_item(item_live, 3 + ipl, irow, iq, ldn);
+      issue_item(item_live, 2 * s0 + 3 + ipl, irow, iq, ldn);
       for (int o = tid * 16; o < RING1; o += NTHR * 16) *reinterpret_cast<u32x4*>(lds + RING1_OFF + o) = (u32x4){0u, 0u, 0u, 0u};
       write_item(pl_live, pz, prow, pq, lp);
     }
@@ -374,14 +382,14 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
         }
       };
 
-      int e6 = 0, m5 = 0;   // (2s) mod 6 = ring-0 slot of plane 2s-1; (2s) mod 5 = ring-1 slot of plane 2s
-      for (int s = 0; s <= d.Do; ++s) {
+      int e6 = (2 * s0 + NRING0) % NRING0, m5 = (2 * s0 + NRING1) % NRING1;   // (2s) mod 6 = ring-0 slot of plane 2s-1; (2s) mod 5 = ring-1 slot of plane 2s
+      for (int s = s0; s <= d.Do; ++s) {
         constexpr bool a_on = !(LR_C01_ABL & 2);
         if (s < d.Do && a_on) {
           C01_STAMP(0);
-          if (2 * s + 1 >= dD)   // odd D, last step: plane 2s+1 lies below the volume — its slot must read 0 (its stores are dropped)
+          if (2 * s + 1 + zoff >= Dg)   // odd D, last step: plane 2s+1 lies below the volume — its slot must read 0 (its stores are dropped)
             for (int o = tid * 16; o < PLB1; o += 256 * 16) *reinterpret_cast<u32x4*>(lds + RING1_OFF + ((m5 + 1) % NRING1) * PLB1 + o) = (u32x4){0u, 0u, 0u, 0u};
-          const bool zok0 = 2 * s < dD, zok1 = 2 * s + 1 < dD;
+          const bool zok0 = 2 * s + zoff < Dg, zok1 = 2 * s + 1 + zoff < Dg;
           const int so0 = m5 * PLB1, so1 = ((m5 + 1) % NRING1) * PLB1;
           // ring-1 store addresses of the five tiles
           const int a00 = zok0 && ok_p0 ? st_p0 + so0 : dump1, a01 = zok0 && ok_p1 ? st_p1 + so0 : dump1;
@@ -470,9 +478,10 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
     // other elements undefined — DESIGN.md 6a: the quads are viewed through HIP's uint4, a struct, where they are used)
     auto issue_item = [&](bool live, int zi, int irow, int iq, u32x4 (&L)[NC]) __attribute__((always_inline)) {
       const int yi = Y0 + irow, xi = X0a + 4 * iq;
-      const int ok = (int)live & (int)(zi >= 0) & (int)(zi < dD) & (int)(yi >= 0) & (int)(yi < dW) & (int)(xi >= 0) & (int)(xi < dH);
+      const int zg = zi + zoff;
+      const int ok = (int)live & (int)(zg >= 0) & (int)(zg < Dg) & (int)(yi >= 0) & (int)(yi < dW) & (int)(xi >= 0) & (int)(xi < dH);
       const unsigned dead = ((unsigned)ok - 1u) & OOR;   // dead item: bit 31 -> outside the resource -> 0
-      const unsigned voff = (unsigned)(((zi * dW + yi) * dH + xi) * 4);
+      const unsigned voff = (unsigned)((((zi + zrel) * dW + yi) * dH + xi) * 4);
       L[0] = __builtin_amdgcn_raw_buffer_load_b128(r0, (int)(voff | dead), 0, 0);
 #pragma unroll
       for (int c = 1; c < NC; ++c) L[c] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)((voff + (unsigned)(c - 1) * V4) | dead), 0, 0);
@@ -504,8 +513,8 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
       }
     };
 
-    // ---- unit prologue: ring 1 <- 0 (plane -1, and every voxel of the column outside the volume), ring 0 <- planes -1..2
-    // (all 512 threads: 4 x 66 items); the B threads also request planes 3, 4 (their items of step 0)
+    // ---- unit prologue: ring 1 <- 0 (every voxel of the column outside the volume), ring 0 <- planes 2 s0 - 1 .. 2 s0 + 2
+    // (all 512 threads: 4 x 66 items); the B threads also request planes 2 s0 + 3, + 4 (their items of the first step)
     const int bt = tid - 256;                                       // B: thread index inside the role
     const bool item_live = !is_a && bt < NITEM;
     const int ipl = item_live ? bt / (R0Y * NQ0) : 0, irow = item_live ? (bt % (R0Y * NQ0)) / NQ0 : 0, iq = item_live ? bt % NQ0 : 0;
@@ -513,10 +522,10 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
     __syncthreads();   // (the zero fill of the whole LDS | every read of the unit before)
     {
       const bool pl_live = tid < 4 * R0Y * NQ0;
-      const int pz = pl_live ? tid / (R0Y * NQ0) - 1 : 0, prow = pl_live ? (tid % (R0Y * NQ0)) / NQ0 : 0, pq = pl_live ? tid % NQ0 : 0;
+      const int pz = pl_live ? tid / (R0Y * NQ0) - 1 + 2 * s0 : 0, prow = pl_live ? (tid % (R0Y * NQ0)) / NQ0 : 0, pq = pl_live ? tid % NQ0 : 0;
       u32x4 lp[NC];
       issue_item(pl_live, pz, prow, pq, lp);
-      issue_item(item_live, 3 + ipl, irow, iq, ldn);
+      issue_item(item_live, 2 * s0 + 3 + ipl, irow, iq, ldn);
       for (int o = tid * 16; o < RING1; o += NTHR * 16) *reinterpret_cast<u32x4*>(lds + RING1_OFF + o) = (u32x4){0u, 0u, 0u, 0u};
       write_item(pl_live, pz, prow, pq, lp);
     }
@@ -598,7 +607,7 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
       };
       constexpr int NST = 2, NSL = 5;   // slices of a step: 2 staging + 3 output
 
-      for (int s = 0; s <= d.Do; ++s) {
+      for (int s = s0; s <= d.Do; ++s) {
         C01_STAMP(0);
         const int r0addr = item_live ? ((2 * s + 3 + ipl + 1) % NRING0) * PLB0 + irow * RB0 + iq * 32 : DUMP_OFF;
         C01_STAMP(1);
@@ -753,12 +762,20 @@ extern "C" int lr_conv3d_pair01_pack_f32(const float* w0, const float* w1, float
   return lr_launch_status();
 }
 
-extern "C" int lr_conv3d_pair01_f32(const float* in0, int64_t in0_batch_stride, const float* in_rest, int64_t rest_batch_stride,
-                                    const float* packed, const float* bias0, const float* bias1, float* out, int B, int Cin,
-                                    int D, int W, int H, int out_layout, float slope0, float slope1, int64_t out_batch_stride,
-                                    void* stream) {
+extern "C" int lr_conv3d_pair01_slab_f32(const float* in0, int64_t in0_batch_stride, const float* in_rest, int64_t rest_batch_stride,
+                                         const float* packed, const float* bias0, const float* bias1, float* out, int B, int Cin,
+                                         int D, int W, int H, int out_layout, float slope0, float slope1, int64_t out_batch_stride,
+                                         int D_global, int z_lo, int oz_lo, int n_oz, void* stream) {
   if (!in0 || !packed || !out || (Cin > 1 && !in_rest)) return LR_ENULL;
-  if (B < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
+  if (B < 1 || D < 1 || W < 1 || H < 1 || D_global < 1 || n_oz < 1 || oz_lo < 0 || z_lo < 0) return LR_EINVAL;
+  // the buffers hold global planes [z_lo, z_lo + D); output planes [oz_lo, oz_lo + n_oz) read input planes 2*oz_lo - 2 ..
+  // 2*(oz_lo + n_oz - 1) + 2: every one of them that exists must lie inside the buffers
+  if (oz_lo + n_oz > (D_global - 1) / 2 + 1 || z_lo + D > D_global) return LR_EINVAL;
+  {
+    const int need_lo = 2 * oz_lo - 2 < 0 ? 0 : 2 * oz_lo - 2;
+    const int need_hi = 2 * (oz_lo + n_oz - 1) + 2 >= D_global ? D_global - 1 : 2 * (oz_lo + n_oz - 1) + 2;
+    if (need_lo < z_lo || need_hi >= z_lo + D) return LR_EINVAL;
+  }
   if (Cin < 1 || Cin > 4) return LR_EUNSUPPORTED;
   if (out_layout != LR_LAYOUT_NDHWC && out_layout != LR_LAYOUT_NDHWC_HPS) return LR_EUNSUPPORTED;
   if (!(slope0 >= 0.0f && slope0 <= 1.0f) || !(slope1 >= 0.0f && slope1 <= 1.0f)) return LR_EUNSUPPORTED;   // LeakyReLU = max(v, slope v)
@@ -766,7 +783,8 @@ extern "C" int lr_conv3d_pair01_f32(const float* in0, int64_t in0_batch_stride, 
   const int64_t V = (int64_t)D * W * H;
   FDims d;
   d.B = B; d.Cin = Cin; d.D = D; d.W = W; d.H = H;
-  d.Do = (D - 1) / 2 + 1; d.Wo = (W - 1) / 2 + 1; d.Ho = (H - 1) / 2 + 1;
+  d.Do = n_oz; d.Wo = (W - 1) / 2 + 1; d.Ho = (H - 1) / 2 + 1;
+  d.Dg = D_global; d.zoff = 2 * oz_lo; d.zlo = z_lo;
   d.hps = out_layout == LR_LAYOUT_NDHWC_HPS;
   if (d.hps && (d.Ho & 1)) return LR_EUNSUPPORTED;
   d.bs0 = in0_batch_stride ? in0_batch_stride : V;
@@ -804,4 +822,13 @@ extern "C" int lr_conv3d_pair01_f32(const float* in0, int64_t in0_batch_stride, 
   else LR_C01(4);
 #undef LR_C01
   return lr_launch_status();
+}
+
+extern "C" int lr_conv3d_pair01_f32(const float* in0, int64_t in0_batch_stride, const float* in_rest, int64_t rest_batch_stride,
+                                    const float* packed, const float* bias0, const float* bias1, float* out, int B, int Cin,
+                                    int D, int W, int H, int out_layout, float slope0, float slope1, int64_t out_batch_stride,
+                                    void* stream) {
+  if (D < 1) return LR_EINVAL;
+  return lr_conv3d_pair01_slab_f32(in0, in0_batch_stride, in_rest, rest_batch_stride, packed, bias0, bias1, out, B, Cin, D, W, H,
+                                   out_layout, slope0, slope1, out_batch_stride, D, 0, 0, (D - 1) / 2 + 1, stream);
 }

@@ -371,11 +371,13 @@ def conv3d_first_split(x0, rest, weight, bias, *, out_layout=LAYOUT_NCDHW, negat
     return y
 
 
-def conv3d_pair01_supported(x0, rest, w0, w1, out_layout=LAYOUT_NDHWC_HPS):
-    """True when `conv3d_pair01` (encoder blocks 0 and 1 as one kernel, csrc/conv01_fused.hip) can take these tensors."""
+def conv3d_pair01_supported(x0, rest, w0, w1, out_layout=LAYOUT_NDHWC_HPS, probe=False):
+    """True when `conv3d_pair01` (encoder blocks 0 and 1 as one kernel, csrc/conv01_fused.hip) can take these tensors
+    (probe: `rest` is a shape-only stand-in — a freshly allocated tensor of that shape is contiguous and aligned)."""
     if not (x0.dim() == 5 and rest.dim() == 5 and x0.shape[1] == 1 and rest.shape[1] in (1, 2, 3) and x0.shape[4] % 4 == 0 and
-            x0.shape[0] == rest.shape[0] and x0.shape[2:] == rest.shape[2:] and x0[0].is_contiguous() and rest.is_contiguous() and
-            (x0.shape[0] == 1 or x0.stride(0) % 4 == 0) and x0.data_ptr() % 16 == 0 and rest.data_ptr() % 16 == 0):
+            x0.shape[0] == rest.shape[0] and x0.shape[2:] == rest.shape[2:] and x0[0].is_contiguous() and
+            (probe or rest.is_contiguous()) and (x0.shape[0] == 1 or x0.stride(0) % 4 == 0) and x0.data_ptr() % 16 == 0 and
+            (probe or rest.data_ptr() % 16 == 0)):
         return False
     B, _, D, W, H = x0.shape
     if tuple(w0.shape) != (16, 1 + rest.shape[1], 3, 3, 3) or tuple(w1.shape) != (32, 16, 3, 3, 3):
@@ -399,10 +401,13 @@ def conv3d_pair01_pack(w0, w1):
     return packed
 
 
-def conv3d_pair01(x0, rest, w0, b0, w1, b1, *, out_layout=LAYOUT_NDHWC_HPS, slope0=0.2, slope1=0.2, packed=None, out=None):
+def conv3d_pair01(x0, rest, w0, b0, w1, b1, *, out_layout=LAYOUT_NDHWC_HPS, slope0=0.2, slope1=0.2, packed=None, out=None,
+                  slab=None):
     """Encoder blocks 0 and 1 on cat([x0, rest], dim=1) as ONE kernel: Conv3d(Cin->16, s1) + LeakyReLU, Conv3d(16->32, s2) +
     LeakyReLU (reference layers.py:365-369 twice, …Backproj.py:95-100); the 16-channel activation never reaches memory.
-    fp32 in / fp32 out, exact three-way bf16 operand splits on the bf16 MFMA.  Returns (B,Do,Wo,Ho,32) in `out_layout`."""
+    fp32 in / fp32 out, exact three-way bf16 operand splits on the bf16 MFMA.  Returns (B,Do,Wo,Ho,32) in `out_layout`.
+    slab = (D_global, z_lo, oz_lo, n_oz): x0 / rest hold the global planes [z_lo, z_lo + D) of a D_global-plane volume and
+    the output planes [oz_lo, oz_lo + n_oz) are computed (z-slab sharding, parallel.py) — same bits as the whole volume."""
     if not (isinstance(x0, torch.Tensor) and x0.is_cuda and x0.dtype == torch.float32):
         raise _hip.LiftRegHipError("x0: must be a float32 GPU tensor (no CPU fallback)")
     rest = _dev(rest, "rest")
@@ -414,20 +419,22 @@ def conv3d_pair01(x0, rest, w0, b0, w1, b1, *, out_layout=LAYOUT_NDHWC_HPS, slop
         packed = conv3d_pair01_pack(w0, w1)
     b0 = None if b0 is None else _dev(b0.detach(), "b0")
     b1 = None if b1 is None else _dev(b1.detach(), "b1")
-    Do, Wo, Ho = (D - 1) // 2 + 1, (W - 1) // 2 + 1, (H - 1) // 2 + 1
+    Dg, z_lo, oz_lo, Do = (D, 0, 0, (D - 1) // 2 + 1) if slab is None else (int(v) for v in slab)
+    Wo, Ho = (W - 1) // 2 + 1, (H - 1) // 2 + 1
     y = _conv_out(out, (B, Do, Wo, Ho, 32), torch.float32, x0.device, strided_batch=True)
     obs = _batch_stride(y)
     ibs = int(x0.stride(0)) if (B > 1 and not x0.is_contiguous()) else 0
-    V = D * W * H
+    V = 2 * Do * W * H
     flops = 2.0 * 27 * B * (Cin * 16 * V + 16 * 32 * Do * Wo * Ho)
     # what the matrix pipe is really asked for: per column of 4 x 8 outputs and step, 4 x 120 v_mfma_f32_16x16x32_bf16 for block 0
-    # (20 tiles x 24) and 4 x 84 for block 1 (see the kernel header); Do steps per column
+    # (20 tiles x 24) and 96 + 96 + 72 + 72 for block 1 (see the kernel header); Do steps per column
     issued = 16384.0 * 816 * Do * B * (-(-Wo // 4)) * (-(-Ho // 8))
-    with _timed(f"conv3d_pair01_c{Cin}x16x32_{D}", flops=flops, issued_bf16_flops=issued,
-                bytes=4 * (x0.numel() + rest.numel()) + 4 * y.numel(), samples=B):
-        _hip.check(_hip.lib().lr_conv3d_pair01_f32(x0.data_ptr(), ibs, rest.data_ptr(), 0, packed.data_ptr(), _ptr(b0), _ptr(b1),
-                                                   y.data_ptr(), B, Cin, D, W, H, out_layout, float(slope0), float(slope1),
-                                                   obs, _stream()), "lr_conv3d_pair01_f32")
+    with _timed(f"conv3d_pair01_c{Cin}x16x32_{Dg}" + ("" if slab is None else "_slab"), flops=flops, issued_bf16_flops=issued,
+                bytes=4 * B * Cin * 2 * Do * W * H + 4 * y.numel(), samples=B):
+        _hip.check(_hip.lib().lr_conv3d_pair01_slab_f32(x0.data_ptr(), ibs, rest.data_ptr(), 0, packed.data_ptr(), _ptr(b0),
+                                                        _ptr(b1), y.data_ptr(), B, Cin, D, W, H, out_layout, float(slope0),
+                                                        float(slope1), obs, Dg, z_lo, oz_lo, Do, _stream()),
+                   "lr_conv3d_pair01_slab_f32")
     return y
 
 

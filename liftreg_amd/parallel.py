@@ -285,6 +285,17 @@ class SlabShardedRegistration:
         ngroups = 2 if (B >= 2 and comm.world > 1) else 1
         gb = [(g * B // ngroups, (g + 1) * B // ngroups) for g in range(ngroups)]
         c0, c1 = net.encoders[0].conv.out_channels, net.encoders[1].conv.out_channels
+        # fp32, <= 2 views: blocks 0 and 1 as the ONE fused kernel of the unsharded model (csrc/conv01_fused.hip) on the rank's
+        # slab — output planes [d0/2, d1/2) read input planes d0-2 .. d1 of the replicated moving volume (a view) and of the
+        # rank's OWN backprojection: no halo exchange for the two big blocks, no 16-channel activation, and the same bits as
+        # the unsharded model
+        b0_, b1_ = net.encoders[0], net.encoders[1]
+        pair = (not bf16 and getattr(net, "fuse_pair01", False) and P <= 2 and b1_.stride == 2 and
+                b0_.out_layout == b1_.in_layout and all(d0 % 2 == 0 and d1 % 2 == 0 for d0, d1 in bounds) and
+                all(ops.conv3d_pair01_supported(inp["source"][:, :, max(d0 - 2, 0):min(d1 + 1, D)],
+                                                torch.empty((B, P, min(d1 + 1, D) - max(d0 - 2, 0), W, H), device="meta"),
+                                                b0_.conv.weight, b1_.conv.weight, layouts(1)[1], probe=True)
+                    for inp, (d0, d1) in zip(inputs, bounds)))
         st = []                                     # per local rank: buffers and views
         for inp, (d0, d1) in zip(inputs, bounds):
             moving = inp["source"]
@@ -296,6 +307,11 @@ class SlabShardedRegistration:
             n_in = r + 2
             lo, hi = max(d0 - 1, 0), min(d1 + 1, D)
             a0 = lo - (d0 - 1)                      # first output plane block 0 really computes (1 on rank 0)
+            n_out = o(n_in)                         # planes block 1 produces from [filler, halo, slab]: 1 junk + r/2
+            nb = torch.empty((B, 1 + n_out, o(W), o(H), c1), dtype=act_dt, device=moving.device)
+            if pair:                                # (no block-0 output buffer at all)
+                st.append(dict(r=r, nb=nb, n_out=n_out))
+                continue
             buf0 = torch.empty((1 + B * n_in, W, H, c0), dtype=act_dt, device=moving.device)
             y0 = buf0[1:].view(B, n_in, W, H, c0)   # block 0's outputs [d0-1 | slab | d1] per sample
             in1 = buf0[:B * n_in].view(B, n_in, W, H, c0)   # block 1's inputs [filler | halo | slab] per sample: one plane earlier
@@ -304,11 +320,20 @@ class SlabShardedRegistration:
                     y0[:, 0].zero_()
                 if hi - lo + a0 < n_in:
                     y0[:, n_in - 1].zero_()
-            n_out = o(n_in)                         # planes block 1 produces from [filler, halo, slab]: 1 junk + r/2
-            nb = torch.empty((B, 1 + n_out, o(W), o(H), c1), dtype=act_dt, device=moving.device)
             st.append(dict(r=r, n_in=n_in, lo=lo, hi=hi, a0=a0, y0=y0, in1=in1, nb=nb, n_out=n_out))
+        if pair:
+            for inp, (d0, d1), t in zip(inputs, bounds, st):
+                moving, proj = inp["source"], inp["target_proj"]
+                lo2, hi2 = max(d0 - 2, 0), min(d1 + 1, D)
+                tv = torch.empty((B, P, hi2 - lo2, W, H), dtype=torch.float32, device=moving.device)
+                ops.backproject(proj.contiguous(), net._poses, (D, W, H), d0=lo2, d1=hi2, out=tv)
+                rows1 = t["r"] // 2
+                ops.conv3d_pair01(moving[:, :, lo2:hi2], tv, b0_.conv.weight, b0_.conv.bias, b1_.conv.weight, b1_.conv.bias,
+                                  out_layout=layouts(1)[1], slope0=b0_._slope, slope1=b1_._slope, packed=net._packed_pair01(),
+                                  out=t["nb"][:, 2:2 + rows1], slab=(D, lo2, d0 // 2, rows1))
+                del tv
         pend = []
-        for g0, g1 in gb:                           # ---- block 0 of every group, its halo posted at once
+        for g0, g1 in (() if pair else gb):         # ---- block 0 of every group, its halo posted at once
             tops = []
             for inp, (d0, d1), t in zip(inputs, bounds, st):
                 moving, proj = inp["source"], inp["target_proj"]
@@ -344,7 +369,7 @@ class SlabShardedRegistration:
                 conv(0, x, t["y0"][g0:g1, t["a0"]:t["a0"] + n_real])
                 tops.append(t["y0"][g0:g1, t["r"]:t["r"] + 1])       # the slab's top plane (d1 - 1) -> the rank above
             pend.append(comm.shift_up_start(tops))
-        for (g0, g1), h in zip(gb, pend):           # ---- block 1 of every group, behind its halo
+        for (g0, g1), h in zip(() if pair else gb, pend):   # ---- block 1 of every group, behind its halo
             halos = h.wait()
             for (d0, _), t, hl in zip(bounds, st, halos):
                 if hl is None:

@@ -136,3 +136,27 @@ def test_pair_kernel_is_deterministic_and_batch_independent():
     torch.cuda.synchronize()
     assert torch.equal(a, b)
     assert torch.equal(a[1:2], c)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_pair_kernel_on_z_slabs_gives_the_bits_of_the_whole_volume(world):
+    """The z-slab form (parallel.SlabShardedRegistration): each rank computes output planes [d0/2, d1/2) from input planes
+    d0-2 .. d1 — a view of the replicated moving volume and its own planes of the feature volume; no halo exchange."""
+    from liftreg_amd import ops
+    B, Cin, D, W, H = 2, 3, 32, 40, 32
+    x, w0, b0, w1, b1 = _make(B, Cin, D, W, H, 11)
+    xd, w0d, b0d, w1d, b1d = (t.to(DEV) for t in (x, w0, b0, w1, b1))
+    x0, rest = xd[:, 0:1].contiguous(), xd[:, 1:].contiguous()
+    full = ops.conv3d_pair01(x0, rest, w0d, b0d, w1d, b1d, out_layout=ops.LAYOUT_NDHWC_HPS)
+    for r in range(world):
+        d0, d1 = r * D // world, (r + 1) * D // world
+        lo, hi = max(d0 - 2, 0), min(d1 + 1, D)
+        rows = (d1 - d0) // 2
+        buf = torch.full((B, rows + 3, (W - 1) // 2 + 1, (H - 1) // 2 + 1, 32), 5.0, device=DEV)
+        y = ops.conv3d_pair01(x0[:, :, lo:hi], rest[:, :, lo:hi].contiguous(), w0d, b0d, w1d, b1d, out_layout=ops.LAYOUT_NDHWC_HPS,
+                              out=buf[:, 2:2 + rows], slab=(D, lo, d0 // 2, rows))
+        torch.cuda.synchronize()
+        assert torch.equal(y, full[:, d0 // 2:d1 // 2]), f"rank {r} of {world}"
+        assert float(buf[:, :2].min()) == 5.0 and float(buf[:, 2 + rows:].max()) == 5.0
+    with pytest.raises(Exception):      # input planes the slab needs but the buffers do not hold
+        ops.conv3d_pair01(x0[:, :, 4:12], rest[:, :, 4:12].contiguous(), w0d, b0d, w1d, b1d, slab=(D, 4, 2, 4))

@@ -35,7 +35,7 @@ class OracleOps:
         return False      # … and the concatenated encoder input
 
     @staticmethod
-    def conv3d_pair01_supported(*_):
+    def conv3d_pair01_supported(*_, **__):
         return False      # … and one kernel per encoder block
 
     @staticmethod
