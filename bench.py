@@ -490,7 +490,7 @@ def main():
                 **({"flops": "algorithmic fp32 flops of the two direct convolutions, priced against the fp32 MFMA peak (the "
                              "arithmetic type of the path); the kernel computes them as exact 3-way bf16 splits on the bf16 "
                              "MFMA: `issued_bf16_tflops` / `frac_bf16_issued` price the MFMAs it really issues (6 per K block "
-                             "of 32, K padded 81 -> 128 and 432 -> 448, 13 % halo recompute in block 0) against the dense bf16 peak",
+                             "of 32, K padded 81 -> 128 and 432 -> 448, 20 % halo recompute in block 0) against the dense bf16 peak",
                     "issued_bf16_tflops": k["issued_bf16_tflops"], "frac_bf16_issued": k["frac_bf16_issued"],
                     "peak_bf16": MFMA_BF16_PEAK_TF, "compulsory_bytes": k["compulsory_bytes"],
                     "traffic_over_compulsory": (k["traffic"] / k["compulsory_bytes"]) if k["traffic"] else None}

@@ -46,7 +46,8 @@ def op_table(cfg, P, bf16):
     ops = [("backproject", r"^backproject_(tiled_)?kernel", 0), ("pca_warp", r"^pca_warp_kernel<.*, false>$", 0),
            ("pca_warp_ncc", r"^pca_warp_kernel<.*, true>$", 0), ("ncc_moments", r"^ncc_moments_kernel", 0),
            (f"conv3d_c{P + 1}x16_s1_{n}", r"^(conv3d_planar_kernel|conv0_split_f32_kernel<.*, 3, false, false>)", 0), (f"conv3d_bp_c{P + 1}x16_s1_{n}", r"^conv0_pc_kernel<.*, true>$", 0),
-           (f"conv3d_c16x32_s2_{n}", r"^conv3d_rows_wlds_kernel<2, 1,", 0)]
+           (f"conv3d_c16x32_s2_{n}", r"^conv3d_rows_wlds_kernel<2, 1,", 0),
+           (f"conv3d_pair01_c{P + 1}x16x32_{n}", r"^conv01_fused_kernel", 0)]
     # stride-2 blocks: planes of >= 64 x 64 outputs run the persistent Winograd rows kernel (one grid size for all of them:
     # told apart by rank only if there are several), smaller ones the direct rows kernel
     if bf16:   # --conv-dtype bf16: the first block (all channels at once for > 3 of them, else the channel-pass kernel), then the row kernels
