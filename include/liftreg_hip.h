@@ -46,6 +46,48 @@ int lr_abi_version(void);
 const char* lr_target_arch(void);
 
 /* ------------------------------------------------------------------------
+ * Run-time switches.  The library reads the following environment variables ONCE per process (at its first launch,
+ * thread-safe) — a launch never calls getenv().  They select between kernels that compute the same function (tests
+ * cross-check them; the "oracle's bits" variants are the direct fmaf chains of oracle/liftreg_oracle.c) or tune launch
+ * geometry; none of them is needed in production.  lr_reload_switches() re-reads them (tests / A-B tools that flip a
+ * switch between two calls in one process; liftreg_amd/_hip.py: reload_switches()); it returns the number of switches.
+ * lr_switch_name(i), 0 <= i < that number, is the variable's name.  Timing-only diagnostics that give WRONG results exist
+ * only in builds with -DLR_DIAG_ABLATIONS / -DLR_C0CL_ABLATIONS / -DLR_C0S_ABLATIONS / -DLR_C01_ABL=... (never shipped).
+ *   LIFTREG_HIP_DEBUG              print the HIP error text of a failed launch to stderr
+ *   LIFTREG_CONV_DIRECT            stride-2 fp32 blocks: the direct row walk = the oracle's fmaf chain bit for bit (default: Winograd F(2,2) rows kernel)
+ *   LIFTREG_CONV0_DIRECT           first fp32 block: the direct sweep = the oracle's fmaf chain (default: Winograd F(2,3) along H)
+ *   LIFTREG_CONV0_SPLIT            first fp32 block alone on the bf16 MFMA with exact 3-way operand splits (conv0_split_f32.hip; A/B aid — the model's default is the fused pair kernel)
+ *   LIFTREG_CONV0_PC               first fp32 block as the producer/consumer kernel (conv0_pc.hip; same bits)
+ *   LIFTREG_CONV_TAPMAJOR          stride-2 blocks: the tap-major kernel instead of the row kernels (same bits as the direct walk)
+ *   LIFTREG_CONV_ROWS_ALWAYS       persistent Winograd rows kernel also on planes below 64 x 64 outputs (tests)
+ *   LIFTREG_CONV0_BF16_CL          bf16 first block: the all-channels brick kernel also for <= 3 channels
+ *   LIFTREG_CONV0_BF16_PASSES      bf16 first block: the channel-pass kernel (round-2 path)
+ *   LIFTREG_WARP_GENERAL           trilinear warp / its gradient: the general kernels instead of the fast ones (same bits)
+ *   LIFTREG_DRR_GENERAL            projector: the general kernel instead of the fast one (same bits)
+ *   LIFTREG_REG_NOMARCH            displacement regulariser: the generic kernels instead of the marching ones
+ *   LIFTREG_DGRAD_OLD              data gradient: the per-tile kernels instead of the persistent weights-in-LDS ones (tests cross-check both)
+ *   LIFTREG_WGRAD_SPLIT            block 1's weight gradient on exact 3-way bf16 splits (opt-in)
+ *   LIFTREG_WGRAD_ROWS             weight gradient: bricks of 1 instead of 2 rows
+ *   LIFTREG_WGRAD0_COPIES          bf16 training: first block's weight gradient through the three-copies kernel
+ *   LIFTREG_CONV0_BLOCKS           persistent blocks of the fp32 first-block kernels
+ *   LIFTREG_CONV0_SPLIT_BLOCKS     persistent blocks of conv0_split_f32.hip
+ *   LIFTREG_CONV0_SPLIT_CHUNKS     z chunks per column of conv0_split_f32.hip (tests: chunk boundaries)
+ *   LIFTREG_CONV0_CL_BLOCKS        persistent blocks of conv0_cl_bf16.hip
+ *   LIFTREG_C0CL_SHAPE             brick shape of conv0_cl_bf16.hip
+ *   LIFTREG_C0CL_CHUNKS            z chunks per column of conv0_cl_bf16.hip
+ *   LIFTREG_CONV_LDS               dynamic LDS bytes that cap the resident blocks of the channels-last conv kernels
+ *   LIFTREG_CONV_ROWS_MT1_BELOW    block count below which the 32->32 blocks take one output row per wave
+ *   LIFTREG_CONV_ROWS_BLOCKS       persistent blocks of conv3d_rows.hip
+ *   LIFTREG_CONV_ROWS_XMAP         0: plain strided tile order instead of the XCD-aware one
+ *   LIFTREG_BF16_MT                output rows per tile of the bf16 row kernels (4 | 8)
+ *   LIFTREG_DGRAD_BLOCKS           persistent blocks of the data-gradient kernels
+ *   LIFTREG_FUSED_BWD_BLOCKS       persistent blocks of the fused dgrad1 + wgrad0 kernel
+ *   LIFTREG_REG_BWD_BLOCKS         block cap of the regulariser's gradient kernel
+ */
+int lr_reload_switches(void);
+const char* lr_switch_name(int id);
+
+/* ------------------------------------------------------------------------
  * K1  DRR cone-beam forward projector.
  * Replaces project_grid_multi + F.grid_sample(3D) + sum + *dx*0.1:
  *   src/liftreg/utils/sdct_projection_utils.py:15-57 (grid, dx)

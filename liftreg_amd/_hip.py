@@ -29,6 +29,8 @@ SIGNATURES = {
     "lr_strerror": (C.c_char_p, [_i]),
     "lr_abi_version": (_i, []),
     "lr_target_arch": (C.c_char_p, []),
+    "lr_reload_switches": (_i, []),
+    "lr_switch_name": (C.c_char_p, [_i]),
     "lr_drr_forward_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "lr_hu_to_mu_f32": (_i, [_p, _p, _i64, _p]),
     "lr_drr_sample_coords_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -133,6 +135,30 @@ def lib():
             raise LiftRegHipError("libliftreg_hip.so was not built for gfx950")
         _lib = handle
     return _lib
+
+
+def reload_switches():
+    """Re-read the library's LIFTREG_* environment switches (it reads them once per process; include/liftreg_hip.h lists
+    them): call after changing os.environ between two launches of one process (tests, A/B tools)."""
+    return lib().lr_reload_switches()
+
+
+# Tests and A/B tools flip switches between two launches of ONE process.  With AUTOSYNC on (tests/conftest.py sets it; never in
+# production) every launch first compares the switches' environment values with the last snapshot and reloads on a change.
+AUTOSYNC = bool(os.environ.get("LIFTREG_SWITCH_AUTOSYNC"))
+_switch_names = None
+_switch_snapshot = None
+
+
+def sync_switches():
+    global _switch_names, _switch_snapshot
+    if _switch_names is None:
+        h = lib()
+        _switch_names = [h.lr_switch_name(i).decode() for i in range(h.lr_reload_switches())]
+    snap = tuple(os.environ.get(n) for n in _switch_names)
+    if snap != _switch_snapshot:
+        lib().lr_reload_switches()
+        _switch_snapshot = snap
 
 
 def check(code, what):

@@ -541,7 +541,7 @@ static int warp_bwd_impl(const float* img, const float* seg, const float* disp, 
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     if (!seg && !bo && H % 4 == 0 && al16(disp) && al16(gwarped) && al16(gdisp) && (!gadd || al16(gadd)) && (!id2 || al16(id2)) &&
         V * 4 + sD * 8 <= 0x80000000LL && sD < (1 << 23) && sD / 4 <= (1 << 20) && Dn <= 65535 &&
-        !getenv("LIFTREG_WARP_GENERAL")) {
+        !lr_sw_set(LR_SW_WARP_GENERAL)) {
       const dim3 g3((unsigned)((sD / 4 + 255) / 256), (unsigned)Dn, (unsigned)B);
       const float rcp_hv = 1.0f / (float)(H / 4);
       if (sc) hipLaunchKernelGGL(warp_bwd_fast_kernel<true>, g3, dim3(256), 0, st, img, disp, id0, id1, id2, gwarped, gdisp, gadd, C, D, W, H, Dn, rcp_hv);

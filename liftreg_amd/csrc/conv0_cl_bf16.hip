@@ -456,9 +456,9 @@ int lr_internal_conv0_cl_bf16(const float* in, const void* packed, const float* 
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   int blocks = cus;
-  if (const char* e = getenv("LIFTREG_CONV0_CL_BLOCKS")) blocks = atoi(e);   // tuning aid
+  blocks = lr_sw_int(LR_SW_CONV0_CL_BLOCKS, blocks);   // tuning aid
   int shape = 116;                                                          // planes x rows of a step: 4x4 | 2x8 | 1x16
-  if (const char* e = getenv("LIFTREG_C0CL_SHAPE")) shape = atoi(e);
+  shape = lr_sw_int(LR_SW_C0CL_SHAPE, shape);
   if (shape != 44 && shape != 28) shape = 116;
   const int SZv = shape == 44 ? 4 : (shape == 28 ? 2 : 1), BYv = 16 / SZv;
   C0Dims d;
@@ -468,7 +468,7 @@ int lr_internal_conv0_cl_bf16(const float* in, const void* packed, const float* 
   // exposed load latency)
   const int64_t cols = (int64_t)B * d.nWq * d.nHq;
   int nch = (int)((8 * (int64_t)blocks + cols - 1) / cols);
-  if (const char* e = getenv("LIFTREG_C0CL_CHUNKS")) nch = atoi(e);          // tuning aid
+  nch = lr_sw_int(LR_SW_C0CL_CHUNKS, nch);          // tuning aid
   if (nch > D / 16) nch = D / 16;
   if (nch < 1) nch = 1;
   d.ZC = ((D + nch - 1) / nch + SZv - 1) / SZv * SZv;

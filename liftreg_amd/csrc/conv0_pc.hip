@@ -337,10 +337,14 @@ int lr_internal_conv0_pc(const float* in0, int64_t bs0, const float* in_rest, in
   if (nb > 0x7fffffffLL) return LR_EINVAL;
   d.nbricks = (int)nb;
   int resident = 512;  // 2 persistent blocks per CU
-  if (const char* e = getenv("LIFTREG_CONV0_BLOCKS")) resident = atoi(e);  // tuning aid
+  resident = lr_sw_int(LR_SW_CONV0_BLOCKS, resident);  // tuning aid
   const dim3 grid((unsigned)(nb < resident ? nb : resident)), block(384);
   const size_t ldsb = (size_t)2 * BRICK * sizeof(float);
-  const int dbg = getenv("LIFTREG_CONV0_DBG") ? atoi(getenv("LIFTREG_CONV0_DBG")) : 0;  // timing ablations only
+#ifdef LR_DIAG_ABLATIONS   // diagnostic build only (make -B EXTRA=-DLR_DIAG_ABLATIONS): timing ablations, WRONG results
+  const int dbg = getenv("LIFTREG_CONV0_DBG") ? atoi(getenv("LIFTREG_CONV0_DBG")) : 0;
+#else
+  const int dbg = 0;
+#endif
   BpArgs a;
   a.proj = proj; a.P = P; a.Pw = Pw; a.Ph = Ph;
   for (int p = 0; p < LR_MAX_VIEWS; ++p)

@@ -538,7 +538,7 @@ static int launch_march(const float* in0, long long bs0, const float* in_rest, l
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   int blocks = cus * (NS == 1 && Cin <= 3 ? 4 : (LDSB <= 80 * 1024 ? 2 : 1));   // blocks a CU holds (LDS, registers)
-  if (const char* e = getenv("LIFTREG_CONV0_SPLIT_BLOCKS")) blocks = atoi(e);   // tuning aid
+  blocks = lr_sw_int(LR_SW_CONV0_SPLIT_BLOCKS, blocks);   // tuning aid
   S0Dims d;
   d.B = B; d.Cin = Cin; d.D = D; d.W = W; d.H = H;
   d.nHq = (H + BX - 1) / BX; d.nWq = (W + BY - 1) / BY;
@@ -546,7 +546,7 @@ static int launch_march(const float* in0, long long bs0, const float* in_rest, l
   // results are dropped and one exposed latency: one chunk per column measured 2.92 ms at C3, four 3.14)
   const int64_t cols = (int64_t)B * d.nWq * d.nHq;
   int nch = (int)((2 * (int64_t)blocks + cols - 1) / cols);
-  if (const char* e = getenv("LIFTREG_CONV0_SPLIT_CHUNKS")) nch = atoi(e);      // tuning aid
+  nch = lr_sw_int(LR_SW_CONV0_SPLIT_CHUNKS, nch);      // tuning aid
   if (nch > D / 16) nch = D / 16;
   if (nch < 1) nch = 1;
   d.ZC = (D + nch - 1) / nch;

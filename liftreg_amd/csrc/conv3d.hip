@@ -1063,16 +1063,16 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
     if (nblk > 0x7fffffffLL) return LR_EINVAL;
     const dim3 grid((unsigned)nblk);
     const float4* wt = reinterpret_cast<const float4*>(packed_w);
-    const size_t occ_lds = getenv("LIFTREG_CONV_LDS") ? (size_t)atoi(getenv("LIFTREG_CONV_LDS")) : 0;  // tuning aid: caps resident blocks
-    const bool rows_ok = ps && (Cin == 16 || Cin == 32) && !getenv("LIFTREG_CONV_TAPMAJOR");  // tuning aid: the tap-major kernel
+    const size_t occ_lds = (size_t)lr_sw_int(LR_SW_CONV_LDS, 0);  // tuning aid: caps resident blocks
+    const bool rows_ok = ps && (Cin == 16 || Cin == 32) && !lr_sw_set(LR_SW_CONV_TAPMAJOR);  // tuning aid: the tap-major kernel
     // default for the parity-split stride-2 blocks: conv3d_rows.hip (persistent, Winograd F(2,2) along W, fragments in
     // LDS); LIFTREG_CONV_DIRECT=1 selects the direct walk below — the oracle's fmaf chain, bit for bit (A/B aid, tests)
-    if (rows_ok && !getenv("LIFTREG_CONV_DIRECT")) {
+    if (rows_ok && !lr_sw_set(LR_SW_CONV_DIRECT)) {
       const int rc = lr_internal_conv_rows_wlds(in, packed_w, bias, out, B, Cin, Cout, D, W, H, out_layout, negative_slope,
                                                 z_phase, d.out_bs, st);
       if (rc != LR_EUNSUPPORTED) return rc;
     }
-    if (rows_ok && Cin == 32 && NT == 2 && nblk < (getenv("LIFTREG_CONV_ROWS_MT1_BELOW") ? atoi(getenv("LIFTREG_CONV_ROWS_MT1_BELOW")) : 512)) {  // env: tuning aid
+    if (rows_ok && Cin == 32 && NT == 2 && nblk < lr_sw_int(LR_SW_CONV_ROWS_MT1_BELOW, 512)) {  // env: tuning aid
       // the last tiny blocks (32 -> 32): one output row per wave, four times the waves, a quarter of the serial walk; same bits
       d.nWq = d.Wo;
       const dim3 g1((unsigned)((int64_t)B * d.nDq * d.nWq * d.nHq));
@@ -1105,7 +1105,7 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
     // LIFTREG_CONV0_SPLIT=1: conv0_split_f32.hip — the same block on the bf16 MFMA with exact three-way bf16 splits of its
     // fp32 operands (a direct conv, half the rounding error of the Winograd sweep).  Measured equal to the fp32-MFMA
     // Winograd kernel below at C3 (2.9-3.1 vs 3.0 ms: DESIGN.md §6·6), so it is NOT the default.
-    if (!bpa && !mask_out && stride == 1 && NT == 1 && Cin <= 4 && getenv("LIFTREG_CONV0_SPLIT") && atoi(getenv("LIFTREG_CONV0_SPLIT")) != 0 && !getenv("LIFTREG_CONV0_DIRECT") &&
+    if (!bpa && !mask_out && stride == 1 && NT == 1 && Cin <= 4 && lr_sw_on(LR_SW_CONV0_SPLIT) && !lr_sw_set(LR_SW_CONV0_DIRECT) &&
         (out_layout == LR_LAYOUT_NDHWC || out_layout == LR_LAYOUT_NDHWC_HPS)) {
       const int64_t V = (int64_t)D * W * H;
       const float* ps = packed_w + (int64_t)Cin * 7 * 64 + (Cin <= 3 ? 4 * 7 * 64 : 0);
@@ -1116,21 +1116,25 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
       if (rc != LR_EUNSUPPORTED) return rc;
     }
     int64_t resident = 256 * (single ? 3 : 2);  // persistent blocks per CU (registers: <=168 | <=256 per lane)
-    if (single && !getenv("LIFTREG_CONV0_DIRECT") && Cin <= 3 && stride == 1 && NT == 1 && (out_layout == LR_LAYOUT_NDHWC || out_layout == LR_LAYOUT_NDHWC_HPS))
+    if (single && !lr_sw_set(LR_SW_CONV0_DIRECT) && Cin <= 3 && stride == 1 && NT == 1 && (out_layout == LR_LAYOUT_NDHWC || out_layout == LR_LAYOUT_NDHWC_HPS))
       resident = 256 * LR_C0_WINO_BLOCKS;  // the Winograd instance (<=128 registers)
-    if (const char* e = getenv("LIFTREG_CONV0_BLOCKS")) resident = atoi(e);  // tuning aid
+    resident = lr_sw_int(LR_SW_CONV0_BLOCKS, resident);  // tuning aid
     const dim3 grid((unsigned)(nitems < resident ? nitems : resident));
     const size_t lds1 = (size_t)3 * PlanarGeom<1, 3>::CS * sizeof(float) + 32;   // + the staging dump area (stage(); one float of row shift)
     const size_t lds2 = (size_t)1 * PlanarGeom<2, 1>::CS * sizeof(float) + 16;
     const int ni = (int)nitems;
-    const int dbg = getenv("LIFTREG_CONV0_DBG") ? atoi(getenv("LIFTREG_CONV0_DBG")) : 0;  // timing ablations only
+#ifdef LR_DIAG_ABLATIONS   // diagnostic build only (make -B EXTRA=-DLR_DIAG_ABLATIONS): timing ablations, WRONG results
+    const int dbg = getenv("LIFTREG_CONV0_DBG") ? atoi(getenv("LIFTREG_CONV0_DBG")) : 0;
+#else
+    const int dbg = 0;
+#endif
 #define LR_PL(NTV, SV, CCV, SGL, LDSV, V4)                                                                   \
   hipLaunchKernelGGL((conv3d_planar_kernel<NTV, SV, CCV, SGL>), grid, block, LDSV, st, in, packed_w, bias, out, d, \
                      out_layout, negative_slope, V4, ni, npass, dbg, in0)
     // conv0_pc.hip: the same block as a producer/consumer kernel with a double-buffered brick.  It carries the fused
     // backprojection (f1); for plain inputs it measured equal to the single-buffer kernel below (3.31-3.34 vs 3.29-3.30 ms
     // at C3, same bits), which therefore stays the default — LIFTREG_CONV0_PC=1 selects it (A/B aid).
-    const bool pc_on = bpa || (getenv("LIFTREG_CONV0_PC") && atoi(getenv("LIFTREG_CONV0_PC")) != 0);
+    const bool pc_on = bpa || (lr_sw_on(LR_SW_CONV0_PC));
     if (pc_on && d.out_bs == dense_bs && d.in0_bs == (long long)D * W * H && stride == 1 && NT == 1 && single && vec4 &&
         (out_layout == LR_LAYOUT_NDHWC || out_layout == LR_LAYOUT_NDHWC_HPS)) {
       const int64_t V = (int64_t)D * W * H;
@@ -1149,7 +1153,7 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
     if (bpa) return LR_EUNSUPPORTED;
     // the Winograd F(2,3)-along-H sweep (default for the model's first block); LIFTREG_CONV0_DIRECT=1 selects the direct
     // sweep (the exact fmaf chain of the oracle; A/B aid)
-    const bool wino = !getenv("LIFTREG_CONV0_DIRECT") && Cin <= 3 && vec4;
+    const bool wino = !lr_sw_set(LR_SW_CONV0_DIRECT) && Cin <= 3 && vec4;
     if (mask_out) {  // training forward of the first block: activation + LeakyReLU sign mask (one byte per channel quad)
       if (!(stride == 1 && NT == 1 && single && vec4)) return LR_EUNSUPPORTED;
       if (out_layout == LR_LAYOUT_NDHWC_HPS && wino)

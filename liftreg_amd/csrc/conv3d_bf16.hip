@@ -822,13 +822,13 @@ static int first_bf16_impl(const float* in, const void* packed_w, const float* b
   if (mask_out && Cin > 3) return LR_EUNSUPPORTED;   // the mask comes out of the single-pass kernel's per-tile store
   // few channels (C3 / C5: 3): the z-marching kernel of conv0_split_f32.hip under the bf16 contract — every input
   // plane fetched once, 4 MFMAs per tile; LIFTREG_CONV0_BF16_PASSES=1 keeps the channel-pass kernel (A/B aid, tests)
-  if (Cin <= (mask_out ? 3 : 4) && Cout == 16 && !getenv("LIFTREG_CONV0_BF16_CL") && !getenv("LIFTREG_CONV0_BF16_PASSES")) {
+  if (Cin <= (mask_out ? 3 : 4) && Cout == 16 && !lr_sw_set(LR_SW_CONV0_BF16_CL) && !lr_sw_set(LR_SW_CONV0_BF16_PASSES)) {
     const unsigned char* pm = reinterpret_cast<const unsigned char*>(packed_w) + (size_t)((Cin + 2) / 3) * 4 * (Cout / 16) * 64 * 16 +
                               lr_internal_conv0_cl_bf16_packed_bytes(Cin, Cout);
     const int e = lr_internal_conv0_march_bf16(in, pm, bias, out, B, Cin, D, W, H, out_layout, negative_slope, d.out_bs, mask_out, st);
     if (e != LR_EUNSUPPORTED) return e;
   }
-  if (!mask_out && (Cin > 3 || getenv("LIFTREG_CONV0_BF16_CL")) && !getenv("LIFTREG_CONV0_BF16_PASSES")) {
+  if (!mask_out && (Cin > 3 || lr_sw_set(LR_SW_CONV0_BF16_CL)) && !lr_sw_set(LR_SW_CONV0_BF16_PASSES)) {
     const int e = lr_internal_conv0_cl_bf16(in, wt + (size_t)((Cin + 2) / 3) * 4 * (Cout / 16) * 64, bias, out, B, Cin, Cout, D, W, H,
                                             out_layout, negative_slope, d.out_bs, 0, st);
     if (e != LR_EUNSUPPORTED) return e;
@@ -920,8 +920,8 @@ static int conv_bf16_impl(const void* in, const void* packed_w, const float* bia
   if ((int64_t)12 * W * H * Cin * 2 + 4096 >= 0x7fffffffLL) return LR_EINVAL;  // 31-bit offsets inside a window
   // rows per wave: 8 for the big first stride-2 block (fewer weight loads per MFMA), 4 otherwise; LIFTREG_BF16_MT overrides
   int mtb = (Cin == 16 && d.Wo >= 64) ? 8 : 4;
-  if (const char* e = getenv("LIFTREG_BF16_MT")) mtb = atoi(e) == 8 ? 8 : 4;  // tuning aid
-  const bool rows = ps && !getenv("LIFTREG_CONV_TAPMAJOR");  // parity-split rows: the row-major kernel (tuning aid: tap-major)
+  if (lr_sw_set(LR_SW_BF16_MT)) mtb = lr_sw_int(LR_SW_BF16_MT, 4) == 8 ? 8 : 4;  // tuning aid
+  const bool rows = ps && !lr_sw_set(LR_SW_CONV_TAPMAJOR);  // parity-split rows: the row-major kernel (tuning aid: tap-major)
   if (rows) mtb = 4;  // 4 rows per wave: 8 would not fit three waves per SIMD
   d.nHq = (d.Ho + 15) / 16; d.nWq = (d.Wo + mtb - 1) / mtb; d.nDq = (d.Do + TD - 1) / TD;
   const int64_t nblk = (int64_t)B * d.nDq * d.nWq * d.nHq;

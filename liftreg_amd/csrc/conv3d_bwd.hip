@@ -2024,10 +2024,14 @@ extern "C" int lr_conv3d_dgrad_f32(const float* gpre, const float* packed_wT, fl
   const float4* wt = reinterpret_cast<const float4*>(packed_wT);
   hipStream_t st = lr_stream(stream);
   const dim3 grid((unsigned)nblk), blk(256);
-  const int dbgv = getenv("LIFTREG_DGRAD_DBG") ? atoi(getenv("LIFTREG_DGRAD_DBG")) : 0;  // timing ablations only
+#ifdef LR_DIAG_ABLATIONS   // diagnostic build only (make -B EXTRA=-DLR_DIAG_ABLATIONS): timing ablations, WRONG results
+  const int dbgv = getenv("LIFTREG_DGRAD_DBG") ? atoi(getenv("LIFTREG_DGRAD_DBG")) : 0;
+#else
+  const int dbgv = 0;
+#endif
   const float* xs_eff = (dbgv & 1) ? nullptr : x_saved;
   const int mk = !xs_eff ? 0 : x_layout == LR_LAYOUT_NDHWC ? 1 : x_layout == LR_LAYOUT_NDHWC_HPS ? 2 : x_layout == LR_LAYOUT_SIGN4 ? 3 : -1;
-  if (Cx == 16 && (Cg == 32 || Cg == 16) && mk >= 0 && !getenv("LIFTREG_DGRAD_OLD")) {
+  if (Cx == 16 && (Cg == 32 || Cg == 16) && mk >= 0 && !lr_sw_set(LR_SW_DGRAD_OLD)) {
     // 16-channel gx (the encoder's block 1): persistent 8-wave blocks, all weights in LDS (conv3d_dgrad_wlds_kernel)
     const int CBv = Cg / 16;
     const int nWq2 = (d.Wo + WMT - 1) / WMT, nDq2 = (d.Do + 7) / 8;
@@ -2035,7 +2039,7 @@ extern "C" int lr_conv3d_dgrad_f32(const float* gpre, const float* packed_wT, fl
     if (nt <= 0x7fffffffLL && (int64_t)10 * d.Wo * d.Ho * Cg * 4 < 0x7fffffffLL) {
       const size_t ldsb = ((size_t)27 * CBv * 64 * 4 + (size_t)9 * (WMT + 1) * 17 * (Cg + 4)) * sizeof(float);
       int resident = 256;  // one 8-wave block per CU
-      if (const char* e = getenv("LIFTREG_DGRAD_BLOCKS")) resident = atoi(e);  // tuning aid
+      resident = lr_sw_int(LR_SW_DGRAD_BLOCKS, resident);  // tuning aid
       const dim3 g2((unsigned)(nt < resident ? nt : resident)), b2(512);
 #define LR_DGW(CBV, MKV)                                                                                                  \
   do {                                                                                                                    \
@@ -2053,14 +2057,14 @@ extern "C" int lr_conv3d_dgrad_f32(const float* gpre, const float* packed_wT, fl
       return lr_launch_status();
     }
   }
-  if (Cx == 32 && Cg == 32 && mk >= 0 && mk <= 2 && !getenv("LIFTREG_DGRAD_OLD")) {
+  if (Cx == 32 && Cg == 32 && mk >= 0 && mk <= 2 && !lr_sw_set(LR_SW_DGRAD_OLD)) {
     // 32-channel gx (blocks 2..5): persistent 8-wave blocks, all fragments in LDS (conv3d_dgrad_wlds32_kernel)
     const int nDq2 = (d.Do + 7) / 8;
     const int64_t nt = (int64_t)B * nDq2 * d.Wo * d.nHq;
     if (nt <= 0x7fffffffLL && (int64_t)10 * d.Wo * d.Ho * Cg * 4 < 0x7fffffffLL) {
       const size_t ldsb = ((size_t)27 * 2 * 2 * 64 * 4 + (size_t)9 * 2 * 17 * (Cg + 4)) * sizeof(float);
       int resident = 256;  // one 8-wave block per CU
-      if (const char* e = getenv("LIFTREG_DGRAD_BLOCKS")) resident = atoi(e);  // tuning aid
+      resident = lr_sw_int(LR_SW_DGRAD_BLOCKS, resident);  // tuning aid
       const dim3 g2((unsigned)(nt < resident ? nt : resident)), b2(512);
 #define LR_DGW32(MKV)                                                                                                      \
   do {                                                                                                                    \
@@ -2139,7 +2143,7 @@ static int wgrad_impl(const float* x, int x_layout, const float* gpre, int gbf, 
 #undef LR_WB
         nparts = (int)grid;
       }
-    } else if (!gbf && !xbf && Cin == 16 && getenv("LIFTREG_WGRAD_SPLIT") && atoi(getenv("LIFTREG_WGRAD_SPLIT")) != 0 &&
+    } else if (!gbf && !xbf && Cin == 16 && lr_sw_on(LR_SW_WGRAD_SPLIT) &&
                (int64_t)B * d.Do * d.Wo * ((d.Ho + 31) / 32) < 0x7fffffffLL) {
       // LIFTREG_WGRAD_SPLIT=1, fp32 x and gradient, 16 input channels (block 1): exact bf16 splits on the bf16 MFMA
       // (conv3d_wgrad_cl_split_kernel).  Alone it is 3.5 ms against the fp32-MFMA kernel's 4.35 at C3; in the training step most
@@ -2159,7 +2163,7 @@ static int wgrad_impl(const float* x, int x_layout, const float* gpre, int gbf, 
     } else if (nbricks < 0x7fffffffLL) {
       // two output rows per brick (15 staged window rows instead of 18, half the barriers per MFMA); LIFTREG_WGRAD_ROWS=1
       // selects the one-row bricks (A/B aid; partial sums then add in another order: equal to rounding)
-      const int rows = (getenv("LIFTREG_WGRAD_ROWS") && atoi(getenv("LIFTREG_WGRAD_ROWS")) == 1) ? 1 : 2;
+      const int rows = (lr_sw_int(LR_SW_WGRAD_ROWS, 0) == 1) ? 1 : 2;
       const int64_t nbr = rows == 1 ? nbricks : (int64_t)B * d.Do * ((d.Wo + 1) / 2) * ((d.Ho + hb - 1) / hb);
       const unsigned grid = (unsigned)(nbr < nblk ? nbr : nblk);
       const bool hps = x_layout == LR_LAYOUT_NDHWC_HPS;
@@ -2193,7 +2197,7 @@ static int wgrad_impl(const float* x, int x_layout, const float* gpre, int gbf, 
     const int64_t nbricks = (int64_t)B * D * ((W + 3) / 4) * ((H + 63) / 64);
     if (nbricks < 0x7fffffffLL) {
       const unsigned grid = (unsigned)(nbricks < nblk ? nbricks : nblk);
-      if (gbf && xround && Cin <= 3 && !getenv("LIFTREG_WGRAD0_COPIES")) {   // env: the three-copies kernel (A/B aid)
+      if (gbf && xround && Cin <= 3 && !lr_sw_set(LR_SW_WGRAD0_COPIES)) {   // env: the three-copies kernel (A/B aid)
         hipLaunchKernelGGL(conv3d_wgrad_planar_bf16s_kernel, dim3(grid), dim3(256), 0, st, x, reinterpret_cast<const u16*>(gpre), partial, d, (int)nbricks);
         planar_tx = true;
       } else if (gbf && xround && Cin <= 3)

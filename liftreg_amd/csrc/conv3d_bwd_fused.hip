@@ -395,7 +395,7 @@ extern "C" int lr_conv3d_dgrad_wgrad0_f32(const float* gpre1, const float* packe
   const int64_t nt = (int64_t)B * d.nDq * d.nWq * d.nHq;
   if (nt > 0x7fffffffLL) return LR_EINVAL;
   int blocks = 256;  // one 8-wave block per CU; the partial buffer is sized for 256
-  if (const char* e = getenv("LIFTREG_FUSED_BWD_BLOCKS")) { blocks = atoi(e); if (blocks < 1 || blocks > 256) blocks = 256; }  // tuning aid
+  if (lr_sw_set(LR_SW_FUSED_BWD_BLOCKS)) { blocks = lr_sw_int(LR_SW_FUSED_BWD_BLOCKS, 256); if (blocks < 1 || blocks > 256) blocks = 256; }  // tuning aid
   if (nt < blocks) blocks = (int)nt;
   hipStream_t st = lr_stream(stream);
   if (Cin0 == 3) return launch<3>(gpre1, packed_w1T, mask0, x0, partial, gw0, gb0, d, (int)nt, blocks, st);

@@ -358,12 +358,12 @@ int launch_l(const float* in, const float* packed_w, const float* bias, float* o
   if (lr_raise_dyn_lds(reinterpret_cast<const void*>(conv3d_rows_wlds_kernel<NT, CB, OUTL>), lds, attr_done) != LR_OK) return LR_ELAUNCH;
   const int ntrip = (ntiles + 2) / 3;
   int blocks = cu_count();
-  if (const char* e = getenv("LIFTREG_CONV_ROWS_BLOCKS")) blocks = atoi(e);  // tuning aid
+  blocks = lr_sw_int(LR_SW_CONV_ROWS_BLOCKS, blocks);  // tuning aid
   if (blocks > ntrip) blocks = ntrip;
   if (blocks < 1) blocks = 1;
   // the XCD-aware order needs whole column groups per XCD and enough work to fill them
   int xmap = (blocks % 8 == 0) && (d.nHq * d.nWq >= blocks / 8) && ((int64_t)d.B * ((d.nDq + 2) / 3) * ((d.nHq * d.nWq + blocks / 8 - 1) / (blocks / 8)) >= 16);
-  if (const char* e = getenv("LIFTREG_CONV_ROWS_XMAP")) xmap = xmap && atoi(e) != 0;  // A/B aid
+  if (lr_sw_set(LR_SW_CONV_ROWS_XMAP)) xmap = xmap && lr_sw_int(LR_SW_CONV_ROWS_XMAP, 1) != 0;  // A/B aid
   hipLaunchKernelGGL((conv3d_rows_wlds_kernel<NT, CB, OUTL>), dim3((unsigned)blocks), dim3(NWAVE * 64), lds, st, in,
                      reinterpret_cast<const float4*>(packed_w), bias, out, d, slope, ntiles, xmap, z_phase);
   return lr_launch_status();
@@ -389,7 +389,7 @@ int lr_internal_conv_rows_wlds(const float* in, const float* packed_w, const flo
   // hundred tiles cannot amortise the per-block fragment staging and the serial 27/54-row walk (measured at C3: 0.14 /
   // 0.07 / 0.07 ms here against 0.12 / 0.03 / 0.03 ms).  The rule looks at the PLANE only, so a z-slab of a volume takes
   // the same kernel as the whole volume (the sharded model is bit-identical to the unsharded one).
-  if ((int64_t)((W - 1) / 2 + 1) * ((H - 1) / 2 + 1) < 4096 && !getenv("LIFTREG_CONV_ROWS_ALWAYS")) return LR_EUNSUPPORTED;
+  if ((int64_t)((W - 1) / 2 + 1) * ((H - 1) / 2 + 1) < 4096 && !lr_sw_set(LR_SW_CONV_ROWS_ALWAYS)) return LR_EUNSUPPORTED;
   if (out_layout != LR_LAYOUT_NDHWC && out_layout != LR_LAYOUT_NDHWC_HPS && out_layout != LR_LAYOUT_NCDHW)
     return LR_EUNSUPPORTED;
   RowsDims d;

@@ -407,7 +407,7 @@ extern "C" int lr_drr_forward_f32(const float* vol_slab, const float* poses, con
                      Rd, Rh, nseg)
   const int64_t sD64 = (int64_t)W * H;
   if (H >= 2 && (int64_t)(d1 - d0) * sD64 * 4 + sD64 * 8 <= 0x80000000LL && sD64 < (1 << 23) &&
-      !getenv("LIFTREG_DRR_GENERAL")) {
+      !lr_sw_set(LR_SW_DRR_GENERAL)) {
 #define LR_FAST(FLV, HUV)                                                                                            \
   hipLaunchKernelGGL((drr_forward_fast_kernel<FLV, HUV>), grid, block, lds, lr_stream(stream), vol_slab, lp, spacing[0], \
                      spacing[1], spacing[2], out, D, W, H, d0, d1, P, Rd, Rh, nseg)

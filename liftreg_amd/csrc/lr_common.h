@@ -9,10 +9,53 @@
 
 #define LR_WAVE 64
 
+// ---- run-time switches.  The library reads its LIFTREG_* environment variables ONCE per process (first launch; thread-safe)
+// into this table — a launcher looks a value up, it never calls getenv().  lr_reload_switches() (C ABI) re-reads them: tests and
+// A/B tools that flip a switch between two calls of one process call it after changing the environment.  The list (with the
+// meaning of each variable) is part of the header: include/liftreg_hip.h.
+enum LrSwitch {
+  LR_SW_HIP_DEBUG,   // LIFTREG_HIP_DEBUG: print the HIP error text of a failed launch to stderr
+  LR_SW_CONV_DIRECT,   // LIFTREG_CONV_DIRECT: stride-2 fp32 blocks: the direct row walk = the oracle's fmaf chain bit for bit (default: Winograd F(2,2) rows kernel)
+  LR_SW_CONV0_DIRECT,   // LIFTREG_CONV0_DIRECT: first fp32 block: the direct sweep = the oracle's fmaf chain (default: Winograd F(2,3) along H)
+  LR_SW_CONV0_SPLIT,   // LIFTREG_CONV0_SPLIT: first fp32 block alone on the bf16 MFMA with exact 3-way operand splits (conv0_split_f32.hip; A/B aid — the model's default is the fused pair kernel)
+  LR_SW_CONV0_PC,   // LIFTREG_CONV0_PC: first fp32 block as the producer/consumer kernel (conv0_pc.hip; same bits)
+  LR_SW_CONV_TAPMAJOR,   // LIFTREG_CONV_TAPMAJOR: stride-2 blocks: the tap-major kernel instead of the row kernels (same bits as the direct walk)
+  LR_SW_CONV_ROWS_ALWAYS,   // LIFTREG_CONV_ROWS_ALWAYS: persistent Winograd rows kernel also on planes below 64 x 64 outputs (tests)
+  LR_SW_CONV0_BF16_CL,   // LIFTREG_CONV0_BF16_CL: bf16 first block: the all-channels brick kernel also for <= 3 channels
+  LR_SW_CONV0_BF16_PASSES,   // LIFTREG_CONV0_BF16_PASSES: bf16 first block: the channel-pass kernel (round-2 path)
+  LR_SW_WARP_GENERAL,   // LIFTREG_WARP_GENERAL: trilinear warp / its gradient: the general kernels instead of the fast ones (same bits)
+  LR_SW_DRR_GENERAL,   // LIFTREG_DRR_GENERAL: projector: the general kernel instead of the fast one (same bits)
+  LR_SW_REG_NOMARCH,   // LIFTREG_REG_NOMARCH: displacement regulariser: the generic kernels instead of the marching ones
+  LR_SW_DGRAD_OLD,   // LIFTREG_DGRAD_OLD: data gradient: the per-tile kernels instead of the persistent weights-in-LDS ones (tests cross-check both)
+  LR_SW_WGRAD_SPLIT,   // LIFTREG_WGRAD_SPLIT: block 1's weight gradient on exact 3-way bf16 splits (opt-in)
+  LR_SW_WGRAD_ROWS,   // LIFTREG_WGRAD_ROWS: weight gradient: bricks of 1 instead of 2 rows
+  LR_SW_WGRAD0_COPIES,   // LIFTREG_WGRAD0_COPIES: bf16 training: first block's weight gradient through the three-copies kernel
+  LR_SW_CONV0_BLOCKS,   // LIFTREG_CONV0_BLOCKS: persistent blocks of the fp32 first-block kernels
+  LR_SW_CONV0_SPLIT_BLOCKS,   // LIFTREG_CONV0_SPLIT_BLOCKS: persistent blocks of conv0_split_f32.hip
+  LR_SW_CONV0_SPLIT_CHUNKS,   // LIFTREG_CONV0_SPLIT_CHUNKS: z chunks per column of conv0_split_f32.hip (tests: chunk boundaries)
+  LR_SW_CONV0_CL_BLOCKS,   // LIFTREG_CONV0_CL_BLOCKS: persistent blocks of conv0_cl_bf16.hip
+  LR_SW_C0CL_SHAPE,   // LIFTREG_C0CL_SHAPE: brick shape of conv0_cl_bf16.hip
+  LR_SW_C0CL_CHUNKS,   // LIFTREG_C0CL_CHUNKS: z chunks per column of conv0_cl_bf16.hip
+  LR_SW_CONV_LDS,   // LIFTREG_CONV_LDS: dynamic LDS bytes that cap the resident blocks of the channels-last conv kernels
+  LR_SW_CONV_ROWS_MT1_BELOW,   // LIFTREG_CONV_ROWS_MT1_BELOW: block count below which the 32->32 blocks take one output row per wave
+  LR_SW_CONV_ROWS_BLOCKS,   // LIFTREG_CONV_ROWS_BLOCKS: persistent blocks of conv3d_rows.hip
+  LR_SW_CONV_ROWS_XMAP,   // LIFTREG_CONV_ROWS_XMAP: 0: plain strided tile order instead of the XCD-aware one
+  LR_SW_BF16_MT,   // LIFTREG_BF16_MT: output rows per tile of the bf16 row kernels (4 | 8)
+  LR_SW_DGRAD_BLOCKS,   // LIFTREG_DGRAD_BLOCKS: persistent blocks of the data-gradient kernels
+  LR_SW_FUSED_BWD_BLOCKS,   // LIFTREG_FUSED_BWD_BLOCKS: persistent blocks of the fused dgrad1 + wgrad0 kernel
+  LR_SW_REG_BWD_BLOCKS,   // LIFTREG_REG_BWD_BLOCKS: block cap of the regulariser's gradient kernel
+  LR_SW_COUNT
+};
+#define LR_SW_UNSET (-2147483647 - 1)
+int lr_sw_raw(int id);   // LR_SW_UNSET, or atoi() of the variable's value
+static inline bool lr_sw_set(int id) { return lr_sw_raw(id) != LR_SW_UNSET; }                          // variable present
+static inline bool lr_sw_on(int id) { const int v = lr_sw_raw(id); return v != LR_SW_UNSET && v != 0; }  // present and non-zero
+static inline int lr_sw_int(int id, int dflt) { const int v = lr_sw_raw(id); return v == LR_SW_UNSET ? dflt : v; }
+
 // Launch check: report, never throw (C ABI).
 static inline int lr_launch_status() {
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess && getenv("LIFTREG_HIP_DEBUG"))
+  if (e != hipSuccess && lr_sw_set(LR_SW_HIP_DEBUG))
     fprintf(stderr, "liftreg_hip: launch failed: %s (%s)\n", hipGetErrorName(e), hipGetErrorString(e));
   return e == hipSuccess ? LR_OK : LR_ELAUNCH;
 }

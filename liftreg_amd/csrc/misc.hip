@@ -16,3 +16,61 @@ extern "C" const char* lr_strerror(int code) {
 extern "C" int lr_abi_version(void) { return 1; }
 
 extern "C" const char* lr_target_arch(void) { return "gfx950"; }
+
+// ---- run-time switches (lr_common.h): one table, read once
+#include <mutex>
+namespace {
+const char* const kSwitchNames[LR_SW_COUNT] = {
+    "LIFTREG_HIP_DEBUG",
+    "LIFTREG_CONV_DIRECT",
+    "LIFTREG_CONV0_DIRECT",
+    "LIFTREG_CONV0_SPLIT",
+    "LIFTREG_CONV0_PC",
+    "LIFTREG_CONV_TAPMAJOR",
+    "LIFTREG_CONV_ROWS_ALWAYS",
+    "LIFTREG_CONV0_BF16_CL",
+    "LIFTREG_CONV0_BF16_PASSES",
+    "LIFTREG_WARP_GENERAL",
+    "LIFTREG_DRR_GENERAL",
+    "LIFTREG_REG_NOMARCH",
+    "LIFTREG_DGRAD_OLD",
+    "LIFTREG_WGRAD_SPLIT",
+    "LIFTREG_WGRAD_ROWS",
+    "LIFTREG_WGRAD0_COPIES",
+    "LIFTREG_CONV0_BLOCKS",
+    "LIFTREG_CONV0_SPLIT_BLOCKS",
+    "LIFTREG_CONV0_SPLIT_CHUNKS",
+    "LIFTREG_CONV0_CL_BLOCKS",
+    "LIFTREG_C0CL_SHAPE",
+    "LIFTREG_C0CL_CHUNKS",
+    "LIFTREG_CONV_LDS",
+    "LIFTREG_CONV_ROWS_MT1_BELOW",
+    "LIFTREG_CONV_ROWS_BLOCKS",
+    "LIFTREG_CONV_ROWS_XMAP",
+    "LIFTREG_BF16_MT",
+    "LIFTREG_DGRAD_BLOCKS",
+    "LIFTREG_FUSED_BWD_BLOCKS",
+    "LIFTREG_REG_BWD_BLOCKS"
+};
+std::atomic<int> g_sw[LR_SW_COUNT];
+std::once_flag g_sw_once;
+void sw_load() {
+  for (int i = 0; i < LR_SW_COUNT; ++i) {
+    const char* e = getenv(kSwitchNames[i]);
+    g_sw[i].store(e ? atoi(e) : LR_SW_UNSET, std::memory_order_relaxed);
+  }
+}
+}  // namespace
+
+int lr_sw_raw(int id) {
+  std::call_once(g_sw_once, sw_load);
+  return (id >= 0 && id < LR_SW_COUNT) ? g_sw[id].load(std::memory_order_relaxed) : LR_SW_UNSET;
+}
+
+extern "C" int lr_reload_switches(void) {
+  std::call_once(g_sw_once, sw_load);
+  sw_load();
+  return LR_SW_COUNT;
+}
+
+extern "C" const char* lr_switch_name(int id) { return (id >= 0 && id < LR_SW_COUNT) ? kSwitchNames[id] : nullptr; }

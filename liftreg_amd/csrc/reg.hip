@@ -410,7 +410,7 @@ extern "C" int lr_disp_reg_bwd_f32(const float* disp, const float* gout, float* 
   const float ihw = W > 1 ? 0.5f * (float)(W - 1) : 0.0f;
   const float ihh = H > 1 ? 0.5f * (float)(H - 1) : 0.0f;
   const int64_t total = (int64_t)B * 3 * D * W * H;
-  if (H % 4 == 0 && H >= 64 && H <= 1024 && W >= 4 && !getenv("LIFTREG_REG_NOMARCH") &&
+  if (H % 4 == 0 && H >= 64 && H <= 1024 && W >= 4 && !lr_sw_set(LR_SW_REG_NOMARCH) &&
       ((reinterpret_cast<uintptr_t>(disp) | reinterpret_cast<uintptr_t>(gdisp)) & 15u) == 0 && (int64_t)B * 3 <= 65535) {
     // z-marching kernel: R full rows per block (>= 4: two halo rows each side are fetched by the first four thread rows)
     const int H4 = H / 4;
@@ -427,7 +427,7 @@ extern "C" int lr_disp_reg_bwd_f32(const float* disp, const float* gout, float* 
   if (H % 4 == 0 && H >= 8 && total / 4 < 0xffffffffLL &&
       ((reinterpret_cast<uintptr_t>(disp) | reinterpret_cast<uintptr_t>(gdisp)) & 15u) == 0) {
     int64_t nb = (total / 4 + 255) / 256;
-    if (const char* e = getenv("LIFTREG_REG_BWD_BLOCKS")) { if (nb > atoi(e)) nb = atoi(e); } else if (nb > 16384) nb = 16384;  // env: tuning aid
+    { const int cap = lr_sw_int(LR_SW_REG_BWD_BLOCKS, 16384); if (nb > cap) nb = cap; }  // (switch: tuning aid)
     hipLaunchKernelGGL(disp_reg_bwd_vec_kernel, dim3((unsigned)nb), dim3(256), 0, lr_stream(stream), disp, gout, gdisp,
                        B, D, W, H, ihd, ihw, ihh);
     return lr_launch_status();
@@ -448,7 +448,7 @@ extern "C" int lr_disp_reg_f32(const float* disp, double* partial, float* out, i
   const float ihw = W > 1 ? 0.5f * (float)(W - 1) : 0.0f;
   const float ihh = H > 1 ? 0.5f * (float)(H - 1) : 0.0f;
   hipStream_t st = lr_stream(stream);
-  if (H % 4 == 0 && H >= 64 && H <= 1024 && W >= 2 && !getenv("LIFTREG_REG_NOMARCH") && (reinterpret_cast<uintptr_t>(disp) & 15u) == 0 &&
+  if (H % 4 == 0 && H >= 64 && H <= 1024 && W >= 2 && !lr_sw_set(LR_SW_REG_NOMARCH) && (reinterpret_cast<uintptr_t>(disp) & 15u) == 0 &&
       (int64_t)B * 3 <= 65535) {
     // z-marching kernel: as many row-block x plane-chunk partials per (b, c) as fit the caller's nblk per batch element
     const int H4 = H / 4;

@@ -590,7 +590,7 @@ extern "C" int lr_warp_trilinear_f32(const float* img, const float* seg, const f
   const bool vec4 = (H % 4 == 0) && aligned16(disp) && aligned16(warped) &&
                     (!phi_out || aligned16(phi_out));
   if (vec4 && !seg && !(flags & (LR_WARP_BORDER | LR_WARP_NEAREST)) && (!id2 || aligned16(id2)) &&
-      !getenv("LIFTREG_WARP_GENERAL")) {
+      !lr_sw_set(LR_SW_WARP_GENERAL)) {
     const int64_t sD = (int64_t)W * H, V = sD * D;
     if (V * 4 + sD * 4 <= 0x80000000LL && sD < (1 << 23) && sD / 4 <= (1 << 20) && Dn <= 65535 && B <= 65535) {
       const dim3 grid((unsigned)((sD / 4 + 255) / 256), (unsigned)Dn, (unsigned)B), block(256);

@@ -46,6 +46,8 @@ def _ptr(t):
 
 
 def _stream():
+    if _hip.AUTOSYNC:            # tests / A-B tools only: the library reads its LIFTREG_* switches once per process
+        _hip.sync_switches()
     return torch.cuda.current_stream().cuda_stream
 
 

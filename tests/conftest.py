@@ -13,6 +13,10 @@ if os.path.join(ROOT, "tests") not in sys.path:
     sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+# the library reads its LIFTREG_* switches once per process; the tests flip them between calls (kernel cross-checks)
+os.environ.setdefault("LIFTREG_SWITCH_AUTOSYNC", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -1,6 +1,7 @@
 """A/B on the GPU box: the first block at C3 (B=8, 3 x 256^3 -> 16 channels, fp32 HPS output) — default fp32-MFMA Winograd kernel
 against conv0_split_f32.hip (LIFTREG_CONV0_SPLIT=1); errors of both against an fp64 convolution on a crop."""
-import os, sys, time
+import os
+os.environ.setdefault("LIFTREG_SWITCH_AUTOSYNC", "1")   # this tool flips library switches between calls, sys, time
 import torch
 import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

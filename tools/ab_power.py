@@ -2,7 +2,8 @@
 kernel) timed with HIP events (a) back to back with itself, (b) behind the default first block, (c) behind the split
 first block (LIFTREG_CONV0_SPLIT=1: 0.3 ms faster), (d) behind a low-power spin of the same length as the first block,
 (e) behind a 6 ms spin.  If (c) > (b) and (d),(e) < (b), a faster neighbour is paid back by a lower clock."""
-import os, sys
+import os
+os.environ.setdefault("LIFTREG_SWITCH_AUTOSYNC", "1")   # this tool flips library switches between calls, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from liftreg_amd import ops

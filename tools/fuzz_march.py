@@ -1,7 +1,8 @@
 """Development aid (GPU box): 60 random shapes through the z-marching first-block kernels (conv0_split_f32.hip) — the bf16
 contract against the channel-pass kernel (>= 99.9 % identical, one bf16 ulp) and the split-operand fp32 block against the
 default fp32-MFMA kernel (2e-6 of the scale).  Ragged W / H, 1..4 channels, 1..18 planes, both output layouts."""
-import os, sys, random
+import os
+os.environ.setdefault("LIFTREG_SWITCH_AUTOSYNC", "1")   # this tool flips library switches between calls, sys, random
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from liftreg_amd import ops
