@@ -411,7 +411,8 @@ extern "C" int lr_disp_reg_bwd_f32(const float* disp, const float* gout, float* 
   const float ihh = H > 1 ? 0.5f * (float)(H - 1) : 0.0f;
   const int64_t total = (int64_t)B * 3 * D * W * H;
   if (H % 4 == 0 && H >= 64 && H <= 1024 && W >= 4 && !lr_sw_set(LR_SW_REG_NOMARCH) &&
-      ((reinterpret_cast<uintptr_t>(disp) | reinterpret_cast<uintptr_t>(gdisp)) & 15u) == 0 && (int64_t)B * 3 <= 65535) {
+      ((reinterpret_cast<uintptr_t>(disp) | reinterpret_cast<uintptr_t>(gdisp)) & 15u) == 0 && (int64_t)B * 3 <= 65535 &&
+      (int64_t)D * W * H * 4 + 16 <= 0x7fffffffLL) {   // (a channel volume is one buffer resource with 31-bit byte offsets; bit 31 = "outside")
     // z-marching kernel: R full rows per block (>= 4: two halo rows each side are fetched by the first four thread rows)
     const int H4 = H / 4;
     int R = 512 / H4; if (R < 4) R = 4; if (R > 16) R = 16;
@@ -449,7 +450,7 @@ extern "C" int lr_disp_reg_f32(const float* disp, double* partial, float* out, i
   const float ihh = H > 1 ? 0.5f * (float)(H - 1) : 0.0f;
   hipStream_t st = lr_stream(stream);
   if (H % 4 == 0 && H >= 64 && H <= 1024 && W >= 2 && !lr_sw_set(LR_SW_REG_NOMARCH) && (reinterpret_cast<uintptr_t>(disp) & 15u) == 0 &&
-      (int64_t)B * 3 <= 65535) {
+      (int64_t)B * 3 <= 65535 && (int64_t)D * W * H * 4 + 16 <= 0x7fffffffLL) {
     // z-marching kernel: as many row-block x plane-chunk partials per (b, c) as fit the caller's nblk per batch element
     const int H4 = H / 4;
     int R = 512 / H4; if (R < 2) R = 2; if (R > 16) R = 16;

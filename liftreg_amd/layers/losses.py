@@ -20,7 +20,9 @@ class NCCLoss(nn.Module):
 
     def forward(self, input, target, moments=None):
         """`moments` (optional, non-reference): the (B,5) fp64 moments of exactly (input, target) when the model's one-pass
-        decode already accumulated them (output key "ncc_moments", opt key fuse_ncc) — the pass over both volumes is skipped."""
+        decode already accumulated them (output key "ncc_moments": training with ncc_grad_via_moments, or the opt key fuse_ncc) — the
+        pass over both volumes is skipped.  The caller vouches that they describe THESE tensors (SubspaceLoss checks
+        "ncc_moments_of")."""
         loss = NCCFn.apply(input, target, NCC_CONFIGURED, moments)
         if self.check_nan:
             assert not torch.isnan(loss), 'NCC loss is Nan.'

@@ -64,17 +64,28 @@ class loss(nn.Module):
         return DispRegFn.apply(disp)
 
     def forward(self, input):
-        moments = input.get("ncc_moments") if hasattr(input, "get") else None
+        get = input.get if hasattr(input, "get") else (lambda k: None)
+        moments = get("ncc_moments")
         if moments is not None and not self._sim_takes_moments:
             moments = None               # a similarity class without the (non-reference) `moments` argument: the plain call
-        if moments is not None:          # the decode node already accumulated them (model opt keys ncc_grad_via_moments, fuse_ncc)
+        if moments is not None:
+            # the decode node already accumulated them (model opt keys ncc_grad_via_moments, fuse_ncc) — for the tensors named
+            # in "ncc_moments_of".  A caller that masked or replaced warped / target between model and loss gets the plain pass.
+            of = get("ncc_moments_of")
+            if of is None or input["warped"] is not of[0] or of[0]._version != of[1] or input["target"] is not of[2] or \
+                    of[2]._version != of[3]:
+                moments = None
+        if moments is not None:
             similarity = self.sim(input["warped"], input["target"], moments=moments)
         else:
             similarity = self.sim(input["warped"], input["target"])
-        gram = input.get("pca_reg_gram") if hasattr(input, "get") else None
-        if gram is not None and input.get("pca_coefs") is not None:
+        gram = get("pca_reg_gram")
+        of = get("pca_reg_gram_of")
+        if gram is not None and of is not None and input["params"] is of[0] and of[0]._version == of[1] and \
+                get("pca_coefs") is of[2] and of[2]._version == of[3]:
             # the subspace model in training: params = pca_coefs . basis^T + mean, so R(params) is a quadratic form of the
-            # coefficients — the same number to fp32 rounding, without the passes over the field (model opt key reg_in_coef_space)
+            # coefficients — the same number to fp32 rounding, without the passes over the field (model opt key
+            # reg_in_coef_space); only while "params" and "pca_coefs" are the tensors the model produced, unmodified
             smoothness = SubspaceRegFn.apply(input["pca_coefs"], *gram)
         else:
             smoothness = self.compute_reg_loss(input["params"])

@@ -219,11 +219,13 @@ class model(nn.Module):
         """(gram, lin, r0) of ops.subspace_reg_gram for the resident basis, computed on first use and kept until the
         basis tensor changes (one pass of the regulariser's gradient kernel and of the PCA-gradient kernel per 8 rows)."""
         vec, mu = self.pca_vectors_LxM, self.pca_mean
-        key = (vec.data_ptr(), vec._version, mu.data_ptr(), mu._version, str(vec.device), tuple(vec.shape))
-        if self._reg_gram is None or self._reg_gram[0] != key:
+        # keyed on the tensors THEMSELVES (held here, so their addresses cannot be reused) and their versions: a reassigned or
+        # reloaded basis / mean is another object, an in-place update bumps _version
+        hit = self._reg_gram
+        if hit is None or hit[0] is not vec or hit[1] != vec._version or hit[2] is not mu or hit[3] != mu._version:
             with torch.no_grad():
-                self._reg_gram = (key, ops.subspace_reg_gram(vec, mu, self.img_sz))
-        return self._reg_gram[1]
+                self._reg_gram = (vec, vec._version, mu, mu._version, ops.subspace_reg_gram(vec, mu, self.img_sz))
+        return self._reg_gram[4]
 
     def pca_slab(self, d0, d1, device):
         """(basis (L, 3·Dn·W·H), mean (3·Dn·W·H,)): the COMPACT column slab of rows [d0,d1) of D — what one rank of a
@@ -442,7 +444,8 @@ class model(nn.Module):
         # ((moving+1)*seg-1, :57) happens on the warp's taps
         if (self.ncc_grad_via_moments and moving_seg is None and target is not None and C == 1 and target.is_cuda and
                 target.dtype == torch.float32 and target.is_contiguous() and target.shape == moving.shape and
-                torch.is_grad_enabled() and coefs.requires_grad and ops_bwd.warp_bwd_disp_ncc_supported(moving)):
+                torch.is_grad_enabled() and coefs.requires_grad and
+                ops_bwd.warp_bwd_disp_ncc_supported(moving, target, (self._id0, self._id1, self._id2))):
             # training: the similarity's moments are a differentiable output of the decode node (output key "ncc_moments")
             return DecodeFn.apply(coefs, self.pca_vectors_LxM, self.pca_mean, moving, self._id0, self._id1, self._id2,
                                   None, True, target)
@@ -469,7 +472,10 @@ class model(nn.Module):
         extra = {}
         if self.reg_in_coef_space and torch.is_grad_enabled() and coefs.requires_grad and self.pca_vectors_LxM.is_cuda:
             extra["pca_reg_gram"] = self.reg_gram()      # training: the regulariser on the coefficients (SubspaceLoss)
-        return {**({"ncc_moments": mom[0]} if mom else {}),      # only with the non-reference opt key fuse_ncc
+            extra["pca_reg_gram_of"] = (disp_field, disp_field._version, coefs, coefs._version)
+        if mom:      # what the moments describe: the loss uses them only for these very tensors, unmodified
+            extra["ncc_moments_of"] = (warped_source, warped_source._version, target_cp, target_cp._version)
+        return {**({"ncc_moments": mom[0]} if mom else {}),      # training (ncc_grad_via_moments) or the opt key fuse_ncc
                 **extra,
                 "warped": warped_source,
                 "phi": deform_field,

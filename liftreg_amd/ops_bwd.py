@@ -66,11 +66,18 @@ def ncc_bwd_moments(moments, gout, n, variant):
     return gm
 
 
-def warp_bwd_disp_ncc_supported(img):
-    """True when `warp_bwd_disp_ncc` can take this image (single channel, the vectorised kernel's shape rules)."""
+def warp_bwd_disp_ncc_supported(img, target=None, ids=None):
+    """True when `warp_bwd_disp_ncc` can take this image (single channel, the vectorised kernel's shape rules) and — when
+    given — this target and these identity tables (the kernel reads them with 16-byte loads: lr_warp_bwd_disp_ncc_f32 returns
+    LR_EUNSUPPORTED for an unaligned view, and a decode node that has committed to the moments route has no other backward)."""
     B, C, D, W, H = img.shape
     sD = W * H
-    return C == 1 and H % 4 == 0 and 4 * D * sD + 8 * sD <= 2 ** 31 and sD < 2 ** 23 and sD // 4 <= 2 ** 20 and D <= 65535
+    ok = C == 1 and H % 4 == 0 and 4 * D * sD + 8 * sD <= 2 ** 31 and sD < 2 ** 23 and sD // 4 <= 2 ** 20 and D <= 65535
+    if ok and target is not None:
+        ok = target.is_contiguous() and target.data_ptr() % 16 == 0
+    if ok and ids is not None:
+        ok = ids[2].data_ptr() % 16 == 0
+    return bool(ok)
 
 
 def warp_bwd_disp_ncc(img, disp, ids, warped, target, gmoments, *, using_scale=True, gadd=None):

@@ -313,6 +313,7 @@ class SlabShardedRegistration:
                 st.append(dict(r=r, nb=nb, n_out=n_out))
                 continue
             buf0 = torch.empty((1 + B * n_in, W, H, c0), dtype=act_dt, device=moving.device)
+            buf0[0].zero_()                         # the leading filler plane only feeds a discarded output plane: keep it finite
             y0 = buf0[1:].view(B, n_in, W, H, c0)   # block 0's outputs [d0-1 | slab | d1] per sample
             in1 = buf0[:B * n_in].view(B, n_in, W, H, c0)   # block 1's inputs [filler | halo | slab] per sample: one plane earlier
             if hi - lo < n_in:                      # edge ranks: the planes block 0 does not write (halo slot / last filler)

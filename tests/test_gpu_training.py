@@ -314,3 +314,51 @@ def test_loss_plugin_with_a_similarity_class_that_takes_no_moments(dev):
     res["total_loss"].backward()
     g = net.encoders[0].conv.weight.grad
     assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
+
+
+def test_loss_uses_the_moments_and_the_gram_only_for_the_tensors_they_describe(dev):
+    """"ncc_moments" / "pca_reg_gram" travel with the tensors they were computed from ("ncc_moments_of",
+    "pca_reg_gram_of").  A caller that replaces or modifies warped / target / params between model and loss gets the plain
+    passes over the volumes — the loss of what it actually handed in — not the stale shortcut."""
+    from liftreg_amd.losses.SubspaceLoss import loss as SubspaceLoss
+    net = _net((32, 32, 32), 2, 8, dev, 19).train()
+    inp = _inputs((32, 32, 32), 2, 32, 2, 19, False)
+    dinp = {k: v.to(dev) if k != "target_poses" else v for k, v in inp.items()}
+    crit = SubspaceLoss(dict(LOSS_OPT))
+    out = net(dinp)
+    assert {"ncc_moments", "ncc_moments_of", "pca_reg_gram", "pca_reg_gram_of"} <= set(out)
+    out["epoch"] = 0
+    base = crit(out)
+    plain = crit({k: v for k, v in out.items() if k not in ("ncc_moments", "pca_reg_gram")})
+    assert abs(base["sim_loss"] - plain["sim_loss"]) <= 1e-6 and abs(base["reg_loss"] - plain["reg_loss"]) <= 1e-5 * abs(plain["reg_loss"]) + 1e-9
+    # a masked warped image: the moments no longer describe it
+    mod = dict(out)
+    mod["warped"] = torch.roll(out["warped"], 1, dims=4)
+    ref = crit({k: v for k, v in mod.items() if k not in ("ncc_moments", "pca_reg_gram")})
+    got = crit(mod)
+    assert abs(got["sim_loss"] - ref["sim_loss"]) <= 1e-6 and abs(got["sim_loss"] - base["sim_loss"]) > 1e-4
+    # an edited field: the coefficient-space form no longer describes it
+    mod = dict(out)
+    mod["params"] = out["params"] * 2.0
+    ref = crit({k: v for k, v in mod.items() if k not in ("ncc_moments", "pca_reg_gram")})
+    got = crit(mod)
+    assert abs(got["reg_loss"] - ref["reg_loss"]) <= 1e-6 * abs(ref["reg_loss"]) and got["reg_loss"] > 3.0 * base["reg_loss"]
+    got["total_loss"].backward()          # the fallbacks are differentiable passes
+    assert net.encoders[0].conv.weight.grad is not None
+
+
+def test_reg_gram_follows_a_replaced_basis(dev):
+    """the coefficient-space regulariser's cache is keyed on the basis / mean tensors themselves (held, so an
+    address cannot be reused) and their versions."""
+    net = _net((32, 32, 32), 2, 8, dev, 23).train()
+    net._ensure_pca(dev)
+    g = torch.Generator(device=dev).manual_seed(1)
+    net.pca_mean = torch.randn(net.pca_mean.shape, device=dev, generator=g) * 1e-3
+    g0 = [t.clone() for t in net.reg_gram()]
+    assert net.reg_gram()[0] is net._reg_gram[4][0]          # cached
+    net.pca_mean = (net.pca_mean * 3.0).contiguous()          # a NEW tensor (could land on the freed address of the old one)
+    g1 = net.reg_gram()
+    assert float(g0[2]) > 0 and abs(float(g1[2]) - 9.0 * float(g0[2])) <= 1e-4 * 9.0 * float(g0[2])   # r0 = R(mean)
+    net.pca_vectors_LxM.mul_(2.0)                             # in place: the version changes
+    g2 = net.reg_gram()
+    assert float((g2[0] - 4.0 * g0[0]).abs().max()) <= 1e-4 * float(g0[0].abs().max())
