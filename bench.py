@@ -178,6 +178,32 @@ def parity_vs_cpu(net, inp, out, ref=None):
                    "by ~1e-3 relative (tests/test_gpu_bf16.py); the 1e-4 bar applies to the fp32 path"}
 
 
+def vs_fp32_reference(net, inp, out):
+    """bf16 lines only: how far the GPU output (bf16 activations / basis as configured) is from the REFERENCE's arithmetic —
+    the fp32 CPU restatement of the reference's forward (oracle/ref_ops.model_forward, conv_dtype fp32, fp32 basis) on sample 0
+    of the timed batch.  north_star asks for displacement fields within 1e-4 of the reference; this record states where the
+    bf16 configurations (BASELINE configs C4 / C5 say bf16) stand against that bar.  Checker only — after the timed region."""
+    from oracle import ref_ops as ro
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    one = {k: v[:1].cpu().contiguous() for k, v in inp.items()}
+    vec, mean = net.pca_vectors_LxM.float().cpu(), net.pca_mean.float().cpu()
+    with torch.no_grad():
+        ref = ro.model_forward(sd, one, vec, mean, conv_dtype="fp32")
+    g = {k: out[k][:1].detach().float().cpu() for k in ("params", "pca_coefs", "warped")}
+    dd = (g["params"] - ref["params"]).abs()
+    cs = float(ref["pca_coefs"].abs().max())
+    return {"sample": "sample 0 of the timed batch vs oracle/ref_ops.model_forward(conv_dtype='fp32') — the reference's fp32 arithmetic",
+            "max_abs_disp": float(dd.max()), "mean_abs_disp": float(dd.mean()),
+            "disp_scale": float(ref["params"].abs().max()),
+            "max_rel_disp": float(dd.max()) / max(float(ref["params"].abs().max()), 1e-30),
+            "max_rel_coefs": float((g["pca_coefs"] - ref["pca_coefs"]).abs().max()) / max(cs, 1e-30),
+            "mean_rel_coefs": float((g["pca_coefs"] - ref["pca_coefs"]).abs().mean()) / max(cs, 1e-30),
+            "max_abs_warped": float((g["warped"] - ref["warped"]).abs().max()),
+            "mean_abs_warped": float((g["warped"] - ref["warped"]).abs().mean()),
+            "bar": "north_star: displacement fields within 1e-4 of the reference — max_abs_disp is in the field's own units (normalised "
+                   "coordinates, [-1, 1] across the volume: one voxel = 2/(n-1)); max_rel_disp relates it to the field's scale"}
+
+
 def cpu_baseline(cfg, net, inp, budget_s=30.0):
     """Torch-CPU oracle (the reference's ATen op sequence) on ONE registration of the same workload.
     Returns (the cpu_baseline record, the CPU forward's outputs for sample 0 — kept for parity_vs_cpu)."""
@@ -608,6 +634,8 @@ def main():
             with torch.no_grad():
                 gpu_out = net(inp)
             result["parity_vs_cpu"] = parity_vs_cpu(net, inp, gpu_out, ref)
+            if (args.conv_dtype, args.pca_dtype) != ("fp32", "fp32"):
+                result["vs_fp32_reference"] = vs_fp32_reference(net, inp, gpu_out)
     elif rank == 0:
         result["cpu_baseline"] = None
     if rank == 0:

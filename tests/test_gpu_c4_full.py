@@ -52,6 +52,24 @@ def test_c4_full_size_forward_vs_bf16_cpu_restatement(c4):
     assert coef_scale > 0 and out["warped"].dtype == torch.float32 and out["params"].dtype == torch.float32
 
 
+def test_c4_full_size_distance_from_the_fp32_reference(c4):
+    """the bf16 configurations are pinned to a bf16 contract the builder wrote — so state, at C4's own size, how
+    far the bf16 path is from the REFERENCE's fp32 arithmetic (oracle/ref_ops.model_forward, conv_dtype fp32; the bench line
+    prints the same record as `vs_fp32_reference`).  Measured on bench.py's C4 inputs (round 4): displacement max 3.4e-7
+    absolute = 8.5e-5 of the field's scale, coefficients 1.0e-4 of theirs — bf16 activations are averaged over 16 K-wide
+    sums before they reach a coefficient.  Bars: north_star's 1e-4 on the displacement in absolute units, and 2e-3 relative
+    (20 x the measured values: a lost block or a wrong layout moves these by O(1))."""
+    import bench
+    net, inp, out = c4
+    rec = bench.vs_fp32_reference(net, inp, out)
+    print("C4 bf16 path vs the fp32 reference forward:", rec)
+    assert rec["max_abs_disp"] <= 1e-4, rec                  # north_star's bar, in the field's own units
+    assert rec["max_rel_coefs"] <= 2e-3, rec
+    assert rec["max_rel_disp"] <= 2e-3, rec
+    assert rec["mean_abs_disp"] <= 5e-4 * rec["disp_scale"], rec
+    assert rec["max_rel_coefs"] > 1e-6          # it IS another arithmetic: the record must not silently compare bf16 with bf16
+
+
 def test_c4_full_size_four_virtual_ranks_equal_unsharded(c4):
     from liftreg_amd import parallel as par
     from liftreg_amd.layers.losses import NCCLoss
