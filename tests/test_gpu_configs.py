@@ -7,6 +7,8 @@
                                                         (crops checked against the CPU oracles; full-size oracle
                                                         runs would take minutes)
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -233,14 +235,16 @@ def test_first_block_full_size_store_paths_agree(dev, monkeypatch):
     assert err <= 4e-6 and float(y_nc.abs().max()) <= 4.0, err
 
 
-@pytest.mark.parametrize("grad_dtype", ["fp32", "bf16"])
-def test_c5_whole_bf16_training_step_at_384(dev, grad_dtype):
+@pytest.mark.parametrize("grad_dtype,B", [("fp32", 1), ("bf16", 4)])
+def test_c5_whole_bf16_training_step_at_384(dev, grad_dtype, B):
     """BASELINE configs[4] as a CONFIGURATION, not as parts: 384^3 CT, 2 x 512^2 DRR, bf16 convs + fp32 warp, a training
     loop with the NCC loss backward — model(input) -> SubspaceLoss -> backward -> Adam.step (RegistrationNet.py:389-406)
-    at batch 1 per GPU.  Every loss is finite, every parameter receives a finite gradient, and Adam reduces the loss."""
+    — at the configuration's 4 registrations per GPU (batch 32 over 8 GPUs) with bf16 gradients, and at batch 1 with fp32
+    gradients.  Every loss is finite, every parameter receives a finite gradient, and Adam reduces the loss.  (What the
+    gradients ARE is pinned on the 96^3 twin below.)"""
     from liftreg_amd.losses.SubspaceLoss import loss as SubspaceLoss
     from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
-    n, R, P, L, B = 384, 512, 2, 56, 1
+    n, R, P, L = 384, 512, 2, 56
     torch.manual_seed(5)
     g = torch.Generator(device=dev)
     g.manual_seed(5)
@@ -251,7 +255,7 @@ def test_c5_whole_bf16_training_step_at_384(dev, grad_dtype):
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, eps=1e-5)            # RegistrationNet.py:245
     ax = torch.linspace(-1, 1, n, device=dev)
     blob = torch.exp(-4 * (ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :] ** 2))
-    target = (blob * 2 - 1)[None, None].contiguous()
+    target = (blob * 2 - 1)[None, None].expand(B, 1, n, n, n).contiguous()
     moving = torch.roll(target, shifts=(6, -4, 5), dims=(2, 3, 4)).contiguous()      # a displaced copy: NCC can improve
     poses = ro.scan_poses(30, P, n).astype(np.float32)
     inp = {"source": moving, "target": target, "target_proj": torch.rand((B, P, R, R), generator=g, device=dev) * 2 - 1,
@@ -272,3 +276,49 @@ def test_c5_whole_bf16_training_step_at_384(dev, grad_dtype):
     assert losses[-1] < losses[0], losses
     del net, opt, out
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("grad_dtype", ["bf16", "fp32"])
+def test_c5_twin_first_step_gradients_vs_aten_autograd(dev, grad_dtype):
+    """C5's training step on a 96^3 twin (same model family and options: bf16 convs + fp32 warp, 2 views, B = 4 per GPU,
+    latent 56): the loss and EVERY parameter gradient of the first step against ATen autograd of the CPU restatement of the
+    bf16 contract (oracle/ref_ops.model_forward(conv_dtype="bf16", grad_dtype=...) + subspace_loss) — what the reference's
+    own loss.backward() would compute under that storage contract.  The two forwards differ by rare one-ulp bf16 rounding
+    flips, so gradients agree to a few 1e-3 of their scale and in direction to 0.999."""
+    from liftreg_amd.losses.SubspaceLoss import loss as SubspaceLoss
+    from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+    n, R, P, L, B = 96, 128, 2, 56, 4
+    torch.manual_seed(7)
+    net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:7", "conv_dtype": "bf16",
+                            "grad_dtype": grad_dtype}).to(dev).train()
+    rs = np.random.RandomState(7)
+    ax = np.linspace(-1, 1, n, dtype=np.float32)
+    blob = np.exp(-4 * (ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :] ** 2)).astype(np.float32)
+    tgt = np.stack([np.roll(blob, s, axis=0) for s in range(B)])[:, None] * 2 - 1 + rs.normal(0, 0.02, (B, 1, n, n, n)).astype(np.float32)
+    mov = np.roll(tgt, (3, -2, 2), axis=(2, 3, 4))
+    poses = ro.scan_poses(30, P, n).astype(np.float32)
+    inp = {"source": torch.from_numpy(mov.astype(np.float32)).contiguous(), "target": torch.from_numpy(tgt.astype(np.float32)).contiguous(),
+           "target_proj": torch.from_numpy(rs.uniform(-1, 1, (B, P, R, R)).astype(np.float32)),
+           "target_poses": torch.from_numpy(np.broadcast_to(poses, (B, P, 3)).copy())}
+    opt = {"initial_reg_factor": 0.01, "min_reg_factor": 0.01, "reg_factor_decay_from": 2}
+    out = net({k: v.to(dev) if k != "target_poses" else v for k, v in inp.items()})
+    out["epoch"] = 0
+    got = SubspaceLoss({**opt, "sim_class": "liftreg_amd.layers.losses.NCCLoss"})(out)
+    got["total_loss"].backward()
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    params = {k: v.detach().cpu().clone().requires_grad_("gaussian" not in k) for k, v in net.state_dict().items()}
+    ref = ro.model_forward(params, inp, net.pca_vectors_LxM.cpu(), net.pca_mean.cpu(), conv_dtype="bf16", grad_dtype=grad_dtype)
+    want = ro.subspace_loss(ref, 0, **opt)
+    want["total_loss"].backward()
+    assert abs(float(got["total_loss"].detach()) - float(want["total_loss"].detach())) < 1e-4
+    tol = 2e-2 if grad_dtype == "fp32" else 4e-2
+    worst = 0.0
+    for k, p in net.named_parameters():
+        g, w = p.grad.cpu().numpy().ravel().astype(np.float64), params[k].grad.numpy().ravel().astype(np.float64)
+        scale = np.abs(w).max()
+        assert scale > 0, k
+        rel = np.abs(g - w).max() / scale
+        worst = max(worst, rel)
+        assert rel <= tol, (k, rel)
+        assert float(np.dot(g, w) / (np.linalg.norm(g) * np.linalg.norm(w))) > 0.999, k
+    print(f"C5 twin (96^3, B=4, grad_dtype {grad_dtype}): worst parameter-gradient distance {worst:.2e} of the gradient's scale")
