@@ -161,6 +161,20 @@ class DistComm:
         dist.all_gather(parts, mine, group=self.group)
         return [torch.cat(parts, dim=dim).to(src.device)]
 
+    def all_gather_planes(self, slabs):
+        """slabs[0] = this rank's (B, rows, ...) plane slab of a channels-last activation → [the whole (B, world*rows, ...)
+        activation].  ONE collective, `all_gather_into_tensor` into a (world, B, rows, ...) buffer — no Python list of
+        per-rank tensors, no torch.cat — and one strided copy that brings a sample's planes together."""
+        if self.world == 1:
+            return [slabs[0]]
+        src = slabs[0].contiguous()
+        mine = src.cpu() if (self.host_stage and src.is_cuda) else src
+        B, rows = mine.shape[0], mine.shape[1]
+        buf = torch.empty((self.world * B,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)   # rank-major
+        dist.all_gather_into_tensor(buf, mine, group=self.group)
+        full = buf.view((self.world, B) + tuple(mine.shape[1:])).transpose(0, 1).reshape((B, self.world * rows) + tuple(mine.shape[2:]))
+        return [full.to(src.device)]
+
     def all_reduce_sum(self, ts):
         if self.world == 1:
             return ts
@@ -171,6 +185,19 @@ class DistComm:
         else:
             dist.all_reduce(ts[0], op=dist.ReduceOp.SUM, group=self.group)
         return ts
+
+    def all_reduce_sum_fused(self, tensors):
+        """Several small same-dtype tensors (NCC moments, partial DRR images …) summed over the ranks in ONE collective:
+        packed into one flat buffer, reduced, unpacked in place.  Returns the same list."""
+        if self.world == 1 or not tensors:
+            return tensors
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        self.all_reduce_sum([flat])
+        off = 0
+        for t in tensors:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+        return tensors
 
 
 class _Done:
@@ -213,6 +240,10 @@ class LocalComm:
         full = torch.cat(pieces, dim=dim)
         return [full for _ in pieces]
 
+    def all_gather_planes(self, slabs):
+        full = torch.cat(slabs, dim=1)
+        return [full for _ in slabs]
+
     def all_reduce_sum(self, ts):
         total = sum(ts[1:], ts[0].clone())
         return [total.clone() for _ in ts]
@@ -227,6 +258,8 @@ class SlabShardedRegistration:
     the 32·(n/32)³ encoder features (all-gather), five NCC moments per sample (all-reduce).
     Needs D % (32·world) == 0 so slabs stay aligned through the five stride-2 blocks.
     """
+
+    GATHER_DEPTH = 32      # all-gather the activation behind the first block with at most this many output planes (SURVEY 8e)
 
     def __init__(self, net, comm, sim_variant=NCC_CONFIGURED):
         self.net, self.comm, self.variant = net, comm, sim_variant
@@ -380,8 +413,15 @@ class SlabShardedRegistration:
                 conv(1, t["in1"][g0:g1], t["nb"][g0:g1, 1:1 + t["n_out"]], d0)
         acts_p = [t["nb"] for t in st]
         rows = [t["r"] // 2 for t in st]
-        # ---- blocks 2..5: small activations, batched launches; the (small) output is copied behind the two leading planes
-        for i in range(2, 6):
+        # ---- blocks 2..: small activations, batched launches; the (small) output is copied behind the two leading planes.
+        # "gather once spatial <= 32^3" — behind the first block whose output has at most GATHER_DEPTH planes the
+        # slabs are all-gathered (ONE collective) and the remaining blocks + the FC head run replicated on the whole (tiny)
+        # activation: at 256^3 that is block 3 (32^3, 4 MB per sample), and the halo rounds of blocks 4 and 5 are gone.
+        depth = [D]
+        for i in range(6):
+            depth.append((depth[-1] - 1) // net.strides[i] + 1)
+        last_sharded = next((i for i in range(1, 6) if depth[i + 1] <= self.GATHER_DEPTH), 5)
+        for i in range(2, last_sharded + 1):
             tops = [a[:, 1 + r:2 + r].contiguous() for a, r in zip(acts_p, rows)]
             halos = comm.shift_up(tops)
             nxt, nrows = [], []
@@ -400,9 +440,23 @@ class SlabShardedRegistration:
                     nxt.append(nb)
                 nrows.append(r // 2)
             acts_p, rows = nxt, nrows
-        acts = acts_p
-        # ---- FC head on the gathered features (replicated), then the slab-local decode
-        feats = comm.all_gather_cat(acts, dim=2)     # last block writes NCDHW: (B,32,rows,·,·)
+        if last_sharded == 5:
+            # (volumes whose last block still has more than GATHER_DEPTH planes) the features themselves are gathered
+            feats = [f.permute(0, 2, 1, 3, 4) for f in comm.all_gather_planes([a.permute(0, 2, 1, 3, 4) for a in acts_p])]
+        else:
+            whole = comm.all_gather_planes([a[:, 2:2 + r] for a, r in zip(acts_p, rows)])   # real planes sit behind [filler | halo]
+            feats = []
+            for x in whole:
+                for j in range(last_sharded + 1, 6):
+                    blk = net.encoders[j]
+                    if bf16:
+                        lin, lout = layouts(j)
+                        x = ops.conv3d_k3_lrelu_bf16(x, blk.conv.weight, blk.conv.bias, blk.stride, in_layout=lin, out_layout=lout,
+                                                     negative_slope=blk._slope, packed=net._packed_weight(j, bf16=True))
+                    else:
+                        x = blk(x, packed=net._packed_weight(j))
+                feats.append(x)                      # last block: NCDHW, so nn.Flatten sees the reference's element order
+        # ---- FC head (replicated), then the slab-local decode
         outs = []
         moms = []
         for inp, f, (d0, d1) in zip(inputs, feats, bounds):
@@ -433,7 +487,7 @@ class SlabShardedRegistration:
                 moms.append(mom if (mom is not None and mom.shape[0] == rows) else ops.ncc_moments(warped, tgt, rows))
             outs.append(out)
         if moms:
-            moms = comm.all_reduce_sum(moms)
+            moms = comm.all_reduce_sum_fused(moms) if hasattr(comm, "all_reduce_sum_fused") else comm.all_reduce_sum(moms)
             for out, m, inp in zip(outs, moms, inputs):
                 B = inp["source"].shape[0]
                 out["sim_loss"], _ = ops.ncc_loss_from_moments(m, D * W * H * (inp["source"].shape[1]), B, self.variant)

@@ -21,7 +21,7 @@ def _inputs(n, P, B, dev, seed):
 
 
 def test_fuse_ncc_key_hands_the_moments_over_explicitly():
-    """opt key fuse_ncc: the output dict carries "ncc_moments" (an 8th, non-reference key), NCCLoss / SubspaceLoss take them
+    """opt key fuse_ncc: the output dict carries "ncc_moments" (+ "ncc_moments_of": non-reference keys), NCCLoss / SubspaceLoss take them
     explicitly (no pass over the volumes, same value); without the key the output has exactly the reference's 7 keys.
     A later in-place change of `warped` cannot meet stale moments: nothing is cached by tensor identity any more."""
     from liftreg_amd import ops
@@ -39,7 +39,7 @@ def test_fuse_ncc_key_hands_the_moments_over_explicitly():
     with torch.no_grad():
         o0, o1 = plain(inp), fused(inp)
         assert sorted(o0) == sorted(["warped", "phi", "params", "target", "pca_coefs", "target_proj", "warped_proj"])
-        assert sorted(o1) == sorted(list(o0) + ["ncc_moments"])
+        assert sorted(o1) == sorted(list(o0) + ["ncc_moments", "ncc_moments_of"])      # the moments and the tensors they describe
         for k in ("warped", "phi", "params", "pca_coefs"):
             assert torch.equal(o0[k], o1[k]), k
         want = float(sim(o0["warped"], o0["target"]))
