@@ -69,11 +69,12 @@ constexpr int RING1 = NRING1 * PLB1;     // 77760
 constexpr int SCR_OFF = RING1_OFF + RING1;   // 116928
 constexpr int SCR = 2 * 4 * 4 * 64 * 16; // 32768: [step parity][B wave = K quarter][accumulator (tile, cout tile)][lane] partial sums
 constexpr int DUMP_OFF = SCR_OFF + SCR;  // 125120: where the threads without a staging item write
-constexpr int LDSB = DUMP_OFF + 512;     // 125632
+constexpr int DUMPB = 64 * 16 + 2 * SB0 + 32;   // a 16-byte lane stride: the lanes without an item never write one address
+constexpr int LDSB = DUMP_OFF + ((DUMPB + 255) / 256) * 256;
 constexpr int NITEM = 2 * R0Y * NQ0;     // 132 staging items of a step: (plane, row, x-quad), all channels
 constexpr int NKB0 = 4, NKB1 = 4;   // k-blocks of block 0 | of a K quarter of block 1 (taps 0..7 | 8..15 | 16..21 | 22..26)
 constexpr unsigned OOR = 0x80000000u;
-static_assert(NITEM <= 256 && 4 * R0Y * NQ0 <= NTHR, "one staging item per thread");
+static_assert(NITEM <= 3 * 44 && 4 * R0Y * NQ0 <= NTHR, "one staging item per thread");
 static_assert(4 * QS1 <= RS1 && (QS1 & 1) == 1 && (RS1 & 15) == 8, "ring-1 bank geometry");
 static_assert((PLB0 & 255) == 128 && (RB0 & 127) == 64, "ring-0 bank geometry");
 static_assert(LDSB <= 160 * 1024, "LDS");
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
     // ... -> split -> ring 0 (plane z sits in slot (z + 1) mod 6); a thread without an item writes zeros into the dump area
     auto write_item = [&](bool live, int zi, int irow, int iq, const u32x4 (&L)[NC]) __attribute__((always_inline)) {
       const int slot = (zi + 1 + NRING0) % NRING0;
-      unsigned char* const base = lds + (live ? slot * PLB0 + irow * RB0 + iq * 32 : DUMP_OFF);
+      unsigned char* const base = lds + (live ? slot * PLB0 + irow * RB0 + iq * 32 : DUMP_OFF + lane * 16);
       float v[4][4];   // [channel][voxel]
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -264,9 +265,11 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
 
     // ---- unit prologue: ring 1 <- 0 (every voxel of the column outside the volume), ring 0 <- planes 2 s0 - 1 .. 2 s0 + 2
     // (all 512 threads: 4 x 66 items); the B threads also request planes 2 s0 + 3, + 4 (their items of the first step)
-    const int bt = tid - 256;                                       // B: thread index inside the role
-    const bool item_live = !is_a && bt < NITEM;
-    const int ipl = item_live ? bt / (R0Y * NQ0) : 0, irow = item_live ? (bt % (R0Y * NQ0)) / NQ0 : 0, iq = item_live ? bt % NQ0 : 0;
+    // staging items of a step: B waves 1..3 take 44 each (wave 0 = K quarter 0 has the most MFMAs and none)
+    const int bi = (wq - 1) * 44 + lane;
+    const bool item_live = !is_a && wq >= 1 && lane < 44;
+    const bool wave_stages = !is_a && wq >= 1;   // wave-uniform
+    const int ipl = item_live ? bi / (R0Y * NQ0) : 0, irow = item_live ? (bi % (R0Y * NQ0)) / NQ0 : 0, iq = item_live ? bi % NQ0 : 0;
     u32x4 ldn[NC];
     __syncthreads();   // (the zero fill of the whole LDS | every read of the unit before)
     {
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
     // ... -> split -> ring 0 (plane z sits in slot (z + 1) mod 6); a thread without an item writes zeros into the dump area
     auto write_item = [&](bool live, int zi, int irow, int iq, const u32x4 (&L)[NC]) __attribute__((always_inline)) {
       const int slot = (zi + 1 + NRING0) % NRING0;
-      unsigned char* const base = lds + (live ? slot * PLB0 + irow * RB0 + iq * 32 : DUMP_OFF);
+      unsigned char* const base = lds + (live ? slot * PLB0 + irow * RB0 + iq * 32 : DUMP_OFF + lane * 16);
       float v[4][4];   // [channel][voxel]
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -515,9 +518,11 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
 
     // ---- unit prologue: ring 1 <- 0 (every voxel of the column outside the volume), ring 0 <- planes 2 s0 - 1 .. 2 s0 + 2
     // (all 512 threads: 4 x 66 items); the B threads also request planes 2 s0 + 3, + 4 (their items of the first step)
-    const int bt = tid - 256;                                       // B: thread index inside the role
-    const bool item_live = !is_a && bt < NITEM;
-    const int ipl = item_live ? bt / (R0Y * NQ0) : 0, irow = item_live ? (bt % (R0Y * NQ0)) / NQ0 : 0, iq = item_live ? bt % NQ0 : 0;
+    // staging items of a step: B waves 1..3 take 44 each (wave 0 = K quarter 0 has the most MFMAs and none)
+    const int bi = (wq - 1) * 44 + lane;
+    const bool item_live = !is_a && wq >= 1 && lane < 44;
+    const bool wave_stages = !is_a && wq >= 1;   // wave-uniform
+    const int ipl = item_live ? bi / (R0Y * NQ0) : 0, irow = item_live ? (bi % (R0Y * NQ0)) / NQ0 : 0, iq = item_live ? bi % NQ0 : 0;
     u32x4 ldn[NC];
     __syncthreads();   // (the zero fill of the whole LDS | every read of the unit before)
     {
@@ -609,7 +614,7 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
 
       for (int s = s0; s <= d.Do; ++s) {
         C01_STAMP(0);
-        const int r0addr = item_live ? ((2 * s + 3 + ipl + 1) % NRING0) * PLB0 + irow * RB0 + iq * 32 : DUMP_OFF;
+        const int r0addr = item_live ? ((2 * s + 3 + ipl + 1) % NRING0) * PLB0 + irow * RB0 + iq * 32 : DUMP_OFF + lane * 16;
         C01_STAMP(1);
         if (s >= 1) {
           const int oz = s - 1;
@@ -650,7 +655,7 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
             lo[t][0] = MFMA(C01_W(0, 0), f[2], lo[t][0]); lo[t][1] = MFMA(C01_W(1, 0), f[2], lo[t][1]);
             }
             C01_FENCE();
-            if (2 * g < NST) stage_slice(2 * g, r0addr); else if (2 * g < NSL) fin_slice(2 * g - NST, oz - 1);
+            if (2 * g < NST) { if (wave_stages) stage_slice(2 * g, r0addr); } else if (2 * g < NSL) fin_slice(2 * g - NST, oz - 1);
             C01_FENCE();
             if (b_mma) {
             lo[t][0] = MFMA(C01_W(0, 1), f[0], lo[t][0]); lo[t][1] = MFMA(C01_W(1, 1), f[0], lo[t][1]);
@@ -659,8 +664,8 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
             }
 #undef C01_W
             C01_FENCE();
-            if (2 * g + 1 < NST) stage_slice(2 * g + 1, r0addr); else if (2 * g + 1 < NSL) fin_slice(2 * g + 1 - NST, oz - 1);
-            if (2 * g + 1 == NST - 1) issue_item(item_live, 2 * s + 5 + ipl, irow, iq, ldn);
+            if (2 * g + 1 < NST) { if (wave_stages) stage_slice(2 * g + 1, r0addr); } else if (2 * g + 1 < NSL) fin_slice(2 * g + 1 - NST, oz - 1);
+            if (2 * g + 1 == NST - 1 && wave_stages) issue_item(item_live, 2 * s + 5 + ipl, irow, iq, ldn);
             C01_FENCE();
           };
 #pragma unroll
@@ -680,9 +685,11 @@ __global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
             *reinterpret_cast<f32x4*>(lds + SCR_OFF + ((((oz & 1) * 4 + kq) * 4 + a4) * 64 + lane) * 16) = acc[a4];
           C01_STAMP(4);
         } else {
+          if (wave_stages) {
 #pragma unroll
-          for (int k = 0; k < NST; ++k) stage_slice(k, r0addr);
-          issue_item(item_live, 2 * s + 5 + ipl, irow, iq, ldn);
+            for (int k = 0; k < NST; ++k) stage_slice(k, r0addr);
+            issue_item(item_live, 2 * s + 5 + ipl, irow, iq, ldn);
+          }
         }
         __syncthreads();
         C01_STAMP(6);
