@@ -128,7 +128,16 @@ __global__ __launch_bounds__(256) void backproject_kernel(
 // conflict-light ds_read2_b32 of two neighbouring columns and every store is a
 // fully coalesced 256-byte wavefront store.  Arithmetic (weights, 4-term sum
 // order) is identical to backproject_kernel above, so results are bit-identical.
-constexpr int BT_TI = 8, BT_TJ = 4, BT_RCAP = 18, BT_PAD = 4;
+#ifndef LR_BP_NT
+#define LR_BP_NT 1
+#endif
+#ifndef LR_BP_TI
+#define LR_BP_TI 8
+#endif
+#ifndef LR_BP_TJ
+#define LR_BP_TJ 4
+#endif
+constexpr int BT_TI = LR_BP_TI, BT_TJ = LR_BP_TJ, BT_RCAP = 18, BT_PAD = 4;
 constexpr int BT_SENTINEL = -0x40000000;
 
 struct TapU {
@@ -274,7 +283,11 @@ __global__ __launch_bounds__(256) void backproject_tiled_kernel(
           acc = acc + bq * ne;
           acc = acc + c * sw;
           acc = acc + d * se;
+#if LR_BP_NT
           __builtin_nontemporal_store(acc, &ob[(((int64_t)p * Ds + i) * W + j) * H + k]);  // written once, read by block 0 long after it left the L2
+#else
+          ob[(((int64_t)p * Ds + i) * W + j) * H + k] = acc;
+#endif
         }
       }
     }

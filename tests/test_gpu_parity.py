@@ -682,3 +682,4 @@ def test_first_block_with_fused_backprojection_equals_two_kernels(ops, dev):
                 got = ops.conv3d_first_fused_bp(moving, proj, poses, w, b, out_layout=lay)
                 assert torch.equal(got, want), (shape, pshape, P, pose_kind, lay, float((got - want).abs().max()))
     assert not ops.conv3d_first_fused_bp_supported(T(np.zeros((1, 1, 4, 4, 6), np.float32), dev), proj[:1])   # H % 4
+
