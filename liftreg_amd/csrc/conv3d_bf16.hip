@@ -338,6 +338,141 @@ __global__ __launch_bounds__(256, 3) void conv3d_cl_rows_bf16_kernel(const u16* 
 }
 
 // ===========================================================================================================
+// The 16 -> 32 stride-2 block (block 1 of the bf16 encoder, the biggest bf16 kernel) as a z-MARCH: a block owns a
+// column of MZ_TY x MZ_TX outputs and walks down the output planes; every input plane of the column's (2TY+1) x
+// (2TX+1) region is read from HBM ONCE, two planes per step, by 16-byte bounds-checked buffer loads issued a whole
+// step ahead, and parked in a 5-plane LDS ring in the parity-split order of the input rows ([17 odd | 16 even]
+// 32-byte records per row: the lanes of one MFMA operand read consecutive records = conflict-free ds_read_b128).
+// The row kernel above re-reads every plane from L2/HBM for 1.5 output planes and every row for 9/8 tiles.
+//   wave w: cout tile nt = w & 1 (its 14 weight fragments stay in registers for the whole column), output rows
+//   2(w>>1), 2(w>>1)+1; K order = the packing's tap pairs (2kb, 2kb+1), fp32 accumulation on top of the bias.
+// One barrier per step: step oz reads planes 2oz-1..2oz+1 (slots k, k+1, k+2) and fills planes 2oz+2, 2oz+3
+// (slots k+3, k+4) after its MFMAs.
+constexpr int MZ_TY = 4, MZ_TX = 16;
+constexpr int MZ_RY = 2 * MZ_TY + 1, MZ_NO = MZ_TX + 1, MZ_NE = MZ_TX;
+constexpr int MZ_ROWB = (MZ_NO + MZ_NE) * 32, MZ_PLB = MZ_RY * MZ_ROWB, MZ_NCH = MZ_PLB / 16;  // 1056, 9504, 594
+constexpr int MZ_NSLOT = 5, MZ_NIT = (2 * MZ_NCH + 255) / 256;                                  // 5 chunks per thread and step
+constexpr int MZ_DUMP = MZ_NSLOT * MZ_PLB, MZ_LDSB = MZ_DUMP + (MZ_NIT * 256 - 2 * MZ_NCH) * 16;
+static_assert(MZ_NIT == 5 && 2 * 256 < MZ_NCH && 3 * 256 >= MZ_NCH && 4 * 256 < 2 * MZ_NCH, "item -> plane map below");
+
+__global__ __launch_bounds__(256, 3) void conv3d_march_s2_bf16_kernel(const u16* __restrict__ in, const u32x4* __restrict__ wp,
+                                                                      const float* __restrict__ bias, void* __restrict__ out,
+                                                                      ConvDimsH d, int zc, int out_layout, float slope) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[MZ_LDSB];
+  const unsigned lb = lr_xcd_remap(blockIdx.x, gridDim.x);
+  const int hq = lb % d.nHq, wq = (lb / d.nHq) % d.nWq, dq = (lb / d.nHq / d.nWq) % d.nDq;
+  const int b = lb / d.nHq / d.nWq / d.nDq;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, kq = lane >> 4;
+  const int nt = wave & 1, mp = wave >> 1;
+  const int dD = __builtin_amdgcn_readfirstlane(d.D), dW = __builtin_amdgcn_readfirstlane(d.W),
+            dH = __builtin_amdgcn_readfirstlane(d.H);
+  const int ox0 = hq * MZ_TX, oy0 = wq * MZ_TY, oz0 = dq * zc;
+  const int oz1 = min(oz0 + zc, d.Do);
+  const int half_h = dH >> 1;
+  const unsigned plane_b = (unsigned)dW * (unsigned)dH * 32u;
+
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(wp), (short)0, 0x7fffffff, 0x00020000);
+  // the batch element's bytes exactly: planes past the end read 0
+  const u16* inb = in + (int64_t)b * dD * dW * dH * 16;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(inb), (short)0, (int)((unsigned)dD * plane_b), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_null = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(inb), (short)0, 0, 0x00020000);
+  constexpr unsigned OOR = 0x80000000u;
+
+  u32x4 w[14];
+#pragma unroll
+  for (int kb = 0; kb < 14; ++kb) w[kb] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)lane * 16u, (unsigned)((kb * 2 + nt) * 1024), 0);
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = bias[nt * 16 + kq * 4 + r];
+  }
+
+  // LDS byte offset (without the plane slot) of this lane's operand of k-block kb, output row 2mp (row 2mp+1: + 2 rows)
+  unsigned toff[14];
+#pragma unroll
+  for (int kb = 0; kb < 14; ++kb) {
+    const int Ta = 2 * kb, Tb = 2 * kb + 1 > 26 ? 26 : 2 * kb + 1;
+    auto tap_off = [&](int T) -> unsigned {
+      const int ty = (T / 3) % 3, tx = T % 3;
+      return (unsigned)(ty * MZ_ROWB + (tx == 1 ? MZ_NO * 32 : 0) + (tx == 2 ? 32 : 0));
+    };
+    toff[kb] = ((kq >> 1) ? tap_off(Tb) : tap_off(Ta)) + (unsigned)(4 * mp * MZ_ROWB + col * 32 + (kq & 1) * 16);
+  }
+
+  // staging items: chunk c = tid + 256 j of the 2 x 594 16-byte chunks of a plane pair (j = 0,1: plane 0; 2: both; 3,4: plane 1)
+  unsigned goff[MZ_NIT], loff[MZ_NIT];
+  bool p2 = false;
+#pragma unroll
+  for (int j = 0; j < MZ_NIT; ++j) {
+    const int c = tid + 256 * j;
+    const bool live = c < 2 * MZ_NCH;
+    const int p = c >= MZ_NCH ? 1 : 0;
+    if (j == 2) p2 = p != 0;
+    const int ci = c - p * MZ_NCH;
+    const int row = ci / (2 * (MZ_NO + MZ_NE)), cc = ci - row * 2 * (MZ_NO + MZ_NE);
+    const bool odd = cc < 2 * MZ_NO;
+    const int rec = odd ? (cc >> 1) : ((cc - 2 * MZ_NO) >> 1);
+    const int y = 2 * oy0 - 1 + row;
+    const int xi = odd ? ox0 - 1 + rec : ox0 + rec;
+    const bool ok = live && y >= 0 && y < dW && xi >= 0 && xi < half_h;
+    const unsigned mrec = (unsigned)(odd ? half_h + xi : xi);
+    goff[j] = ok ? ((unsigned)(p * dW + y) * (unsigned)dH + mrec) * 32u + (unsigned)(cc & 1) * 16u : OOR;
+    loff[j] = live ? (unsigned)ci * 16u : (unsigned)(MZ_DUMP + (c - 2 * MZ_NCH) * 16);
+  }
+
+  u32x4 st[MZ_NIT];
+  auto stage_load = [&](int zbase, bool real) {  // planes zbase, zbase+1 (zbase >= 0 when real)
+    const unsigned zo = (unsigned)zbase * plane_b;
+#pragma unroll
+    for (int j = 0; j < MZ_NIT; ++j) st[j] = __builtin_amdgcn_raw_buffer_load_b128(real ? rsrc : rsrc_null, goff[j] + zo, 0, 0);
+  };
+  auto stage_write = [&](unsigned s0b, unsigned s1b) {  // LDS bases of the two planes' slots
+#pragma unroll
+    for (int j = 0; j < MZ_NIT; ++j) {
+      const bool live = tid + 256 * j < 2 * MZ_NCH;
+      const unsigned sb = j < 2 ? s0b : j == 2 ? (p2 ? s1b : s0b) : (live ? s1b : 0u);
+      *reinterpret_cast<u32x4*>(lds + sb + loff[j]) = st[j];
+    }
+  };
+
+  // prologue: planes 2oz0-2 (unused), 2oz0-1 -> slots 0, 1; planes 2oz0, 2oz0+1 -> slots 2, 3
+  stage_load(2 * oz0 - 2, oz0 > 0);
+  stage_write(0u, (unsigned)MZ_PLB);
+  stage_load(2 * oz0, true);
+  stage_write(2u * MZ_PLB, 3u * MZ_PLB);
+  __syncthreads();
+  int k = 1;  // slot of plane 2oz-1
+  for (int oz = oz0; oz < oz1; ++oz) {
+    stage_load(2 * oz + 2, oz + 1 < oz1);
+    __builtin_amdgcn_sched_barrier(0);
+    const int k1 = k + 1 >= MZ_NSLOT ? k + 1 - MZ_NSLOT : k + 1, k2 = k + 2 >= MZ_NSLOT ? k + 2 - MZ_NSLOT : k + 2;
+    const int k3 = k + 3 >= MZ_NSLOT ? k + 3 - MZ_NSLOT : k + 3, k4 = k + 4 >= MZ_NSLOT ? k + 4 - MZ_NSLOT : k + 4;
+    const unsigned sb0 = (unsigned)k * MZ_PLB, sb1 = (unsigned)k1 * MZ_PLB, sb2 = (unsigned)k2 * MZ_PLB;
+    f32x4 acc0 = bv, acc1 = bv;
+#pragma unroll
+    for (int kb = 0; kb < 14; ++kb) {
+      // taps 2kb, 2kb+1: tz = 0 for kb < 4, 1 for 5..8, 2 for 9..13; kb = 4 straddles (tap 8 | tap 9)
+      const unsigned sb = kb < 4 ? sb0 : kb == 4 ? ((kq >> 1) ? sb1 : sb0) : kb < 9 ? sb1 : sb2;
+      const unsigned char* a = lds + sb + toff[kb];
+      const u32x4 x0 = *reinterpret_cast<const u32x4*>(a);
+      const u32x4 x1 = *reinterpret_cast<const u32x4*>(a + 2 * MZ_ROWB);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[kb]), __builtin_bit_cast(bf16x8, x0), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[kb]), __builtin_bit_cast(bf16x8, x1), acc1, 0, 0, 0);
+    }
+    store_tile_any(acc0, out, d, b, oz, oy0 + 2 * mp, ox0 + col, nt, lane, out_layout, slope);
+    store_tile_any(acc1, out, d, b, oz, oy0 + 2 * mp + 1, ox0 + col, nt, lane, out_layout, slope);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_write((unsigned)k3 * MZ_PLB, (unsigned)k4 * MZ_PLB);
+    __syncthreads();
+    k = k2;
+  }
+}
+
+// ===========================================================================================================
 // First block (planar fp32 input, stride 1) on the bf16 MFMA.  Brick = 4 planes (one per wave) x 4 rows x 64
 // voxels.  K order: 27 window rows (channel, tz, ty) x 4 columns (tx = 0..2 and a zero-weight 4th) = 108 -> 128 =
 // four 16x16x32 MFMAs per 16-voxel tile (the fp32 kernel needs 21 16x16x4 MFMAs = 10x the matrix-pipe time): the
@@ -936,6 +1071,22 @@ static int conv_bf16_impl(const void* in, const void* packed_w, const float* bia
     else hipLaunchKernelGGL((conv3d_cl_bf16_kernel<NTV, C32, PSV, 4>), grid, block, 0, st, x, wt, bias, out, d, out_layout, negative_slope);          \
   } while (0)
   const int NT = Cout / 16;
+  // the 16 -> 32 block on parity-split rows: the z-marching kernel (LIFTREG_BF16_NO_MARCH: the row kernel)
+  if (rows && Cin == 16 && NT == 2 && !lr_sw_on(LR_SW_BF16_NO_MARCH) && (int64_t)(D + 4) * W * H * 32 < 0x7fffffffLL) {
+    const int nTy = (d.Wo + MZ_TY - 1) / MZ_TY, nTx = (d.Ho + MZ_TX - 1) / MZ_TX;
+    // z chunks: columns of >= 16 steps, enough units for ~8 rounds of the 768 resident blocks
+    int zc = lr_sw_int(LR_SW_BF16_MARCH_ZC, 0);
+    if (zc < 1) {
+      int nz = 1;
+      while ((int64_t)B * nTy * nTx * nz < 6144 && d.Do / (nz * 2) >= 16) nz *= 2;
+      zc = (d.Do + nz - 1) / nz;
+    }
+    d.nHq = nTx; d.nWq = nTy; d.nDq = (d.Do + zc - 1) / zc;
+    const int64_t nb = (int64_t)B * d.nDq * d.nWq * d.nHq;
+    if (nb > 0x7fffffffLL) return LR_EINVAL;
+    hipLaunchKernelGGL(conv3d_march_s2_bf16_kernel, dim3((unsigned)nb), block, 0, st, x, wt, bias, out, d, zc, out_layout, negative_slope);
+    return lr_launch_status();
+  }
   if (rows) {
 #define LR_BR(NTV, C32) hipLaunchKernelGGL((conv3d_cl_rows_bf16_kernel<NTV, 4, C32>), grid, block, 0, st, x, wt, bias, out, d, out_layout, negative_slope)
     if (Cin == 32) { if (NT == 2) LR_BR(2, true); else LR_BR(1, true); }

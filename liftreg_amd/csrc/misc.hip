@@ -48,6 +48,8 @@ const char* const kSwitchNames[LR_SW_COUNT] = {
     "LIFTREG_CONV_ROWS_BLOCKS",
     "LIFTREG_CONV_ROWS_XMAP",
     "LIFTREG_BF16_MT",
+    "LIFTREG_BF16_NO_MARCH",
+    "LIFTREG_BF16_MARCH_ZC",
     "LIFTREG_DGRAD_BLOCKS",
     "LIFTREG_FUSED_BWD_BLOCKS",
     "LIFTREG_REG_BWD_BLOCKS"

@@ -54,7 +54,7 @@ def op_table(cfg, P, bf16):
         ops = ops[:4] + [(f"conv3d_bf16_c{P + 1}x16_s1_{n}", r"^conv0_cl_bf16_kernel<.*, false>$" if P + 1 > 3 else r"^(conv0_split_f32_kernel<.*, 1, true, (true|false)>|conv0_bf16_kernel)", 0),
                          (f"conv3d_bf16_c{P + 1}x16_s1_{n}_clin", r"^conv0_cl_bf16_kernel<.*, true>$", 0),
                          ("backproject_encin_bf16", r"^backproject_encin_bf16_kernel", 0),
-                         (f"conv3d_bf16_c16x32_s2_{n}", r"^conv3d_cl_rows_bf16_kernel<2, 4, false>", 0)]
+                         (f"conv3d_bf16_c16x32_s2_{n}", r"^(conv3d_march_s2_bf16_kernel|conv3d_cl_rows_bf16_kernel<2, 4, false>)", 0)]
         size, rank = n // 2, 0
         while size >= 16:
             ops.append((f"conv3d_bf16_c32x32_s2_{size}", r"^conv3d_cl_rows_bf16_kernel<(1|2), 4, true>", rank))
