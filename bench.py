@@ -288,6 +288,8 @@ def main():
                     help="2: batch i's HBM-bound decode half overlaps batch i+1's MFMA-bound encode half on two HIP "
                          "streams (measured +1.3 %% at C3: every kernel already fills the chip; per-kernel timings "
                          "are only meaningful with 1)")
+    ap.add_argument("--decode-cus", type=int, default=0,
+                    help="with --streams 2: compute units reserved for the decode stream (CU-masked streams)")
     ap.add_argument("--pca-dtype", default="fp32", choices=("fp32", "bf16"),
                     help="bf16: the PCA basis stored as bfloat16 in HBM (opt-in, not the headline configuration)")
     ap.add_argument("--conv-dtype", default="fp32", choices=("fp32", "bf16"),
@@ -372,7 +374,7 @@ def main():
             return sharded.forward([my])[0]["sim_loss"]
     elif args.streams == 2:
         from liftreg_amd.pipeline import TwoStreamRegistrar
-        reg = TwoStreamRegistrar(net, sim)
+        reg = TwoStreamRegistrar(net, sim, decode_cus=args.decode_cus)
 
         def step():
             return reg.submit(inp)[1]

@@ -80,6 +80,7 @@ const char* lr_target_arch(void);
  *   LIFTREG_CONV_ROWS_BLOCKS       persistent blocks of conv3d_rows.hip
  *   LIFTREG_CONV_ROWS_XMAP         0: plain strided tile order instead of the XCD-aware one
  *   LIFTREG_BF16_MT                output rows per tile of the bf16 row kernels (4 | 8)
+ *   LIFTREG_PAIR01_BLOCKS          persistent blocks of the fused pair kernel (default: one per CU)
  *   LIFTREG_BF16_NO_MARCH          bf16 16->32 block: the row kernel instead of the z-marching one (A/B aid)
  *   LIFTREG_BF16_MARCH_ZC          output planes per z chunk of the bf16 z-marching kernel (tests: chunk boundaries)
  *   LIFTREG_DGRAD_BLOCKS           persistent blocks of the data-gradient kernels

@@ -855,6 +855,9 @@ extern "C" int lr_conv3d_pair01_slab_f32(const float* in0, int64_t in0_batch_str
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   int blocks = cus;   // one block per CU (LDS)
+  // LIFTREG_PAIR01_BLOCKS: fewer persistent blocks leave whole CUs to a kernel of another stream (the HBM-bound decode of the
+  // previous batch: liftreg_amd/pipeline.py) — this kernel fills the register file of every CU it sits on
+  if (lr_sw_set(LR_SW_PAIR01_BLOCKS)) { const int v = lr_sw_int(LR_SW_PAIR01_BLOCKS, cus); if (v >= 1 && v < blocks) blocks = v; }
   if (blocks > d.nunits) blocks = d.nunits;
   hipStream_t st = lr_stream(stream);
   const u32x4* wp0 = reinterpret_cast<const u32x4*>(packed);

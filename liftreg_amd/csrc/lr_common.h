@@ -41,6 +41,7 @@ enum LrSwitch {
   LR_SW_CONV_ROWS_BLOCKS,   // LIFTREG_CONV_ROWS_BLOCKS: persistent blocks of conv3d_rows.hip
   LR_SW_CONV_ROWS_XMAP,   // LIFTREG_CONV_ROWS_XMAP: 0: plain strided tile order instead of the XCD-aware one
   LR_SW_BF16_MT,   // LIFTREG_BF16_MT: output rows per tile of the bf16 row kernels (4 | 8)
+  LR_SW_PAIR01_BLOCKS,   // LIFTREG_PAIR01_BLOCKS: persistent blocks of the fused pair kernel (default: one per CU)
   LR_SW_BF16_NO_MARCH,   // LIFTREG_BF16_NO_MARCH: bf16 16->32 block: the row kernel instead of the z-marching one (A/B aid)
   LR_SW_BF16_MARCH_ZC,   // LIFTREG_BF16_MARCH_ZC: output planes per z chunk of the bf16 z-marching kernel (tests: chunk boundaries)
   LR_SW_DGRAD_BLOCKS,   // LIFTREG_DGRAD_BLOCKS: persistent blocks of the data-gradient kernels

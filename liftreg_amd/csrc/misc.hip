@@ -48,6 +48,7 @@ const char* const kSwitchNames[LR_SW_COUNT] = {
     "LIFTREG_CONV_ROWS_BLOCKS",
     "LIFTREG_CONV_ROWS_XMAP",
     "LIFTREG_BF16_MT",
+    "LIFTREG_PAIR01_BLOCKS",
     "LIFTREG_BF16_NO_MARCH",
     "LIFTREG_BF16_MARCH_ZC",
     "LIFTREG_DGRAD_BLOCKS",

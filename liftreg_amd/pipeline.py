@@ -10,15 +10,38 @@ Results are identical to `model.forward` + `NCCLoss` (same kernels, same order w
 import torch
 
 
+def _masked_stream(dev, cus, ncu):
+    """A HIP stream whose kernels run only on the compute units `cus` (hipExtStreamCreateWithCUMask; bit i of the mask = CU i,
+    and the driver deals consecutive bits round-robin over the XCDs, so a contiguous range is spread evenly over the 8 dies)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    nw = (ncu + 31) // 32
+    words = [0] * nw
+    for c in cus:
+        words[c // 32] |= 1 << (c % 32)
+    arr = (ctypes.c_uint32 * nw)(*words)
+    st = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(nw), arr)
+    if rc != 0 or not st.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    return torch.cuda.ExternalStream(st.value, device=dev)
+
+
 class TwoStreamRegistrar:
     """`submit(batch)` enqueues one batch; outputs are valid after `synchronize()` (or an event wait)."""
 
-    def __init__(self, net, sim=None):
+    def __init__(self, net, sim=None, decode_cus=0):
         self.net = net
         self.sim = sim
         dev = next(net.parameters()).device
-        self.enc = torch.cuda.Stream(device=dev)
-        self.dec = torch.cuda.Stream(device=dev)
+        if decode_cus > 0:
+            ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+            self.dec = _masked_stream(dev, range(0, decode_cus), ncu)
+            self.enc = _masked_stream(dev, range(decode_cus, ncu), ncu)
+        else:
+            self.enc = torch.cuda.Stream(device=dev)
+            self.dec = torch.cuda.Stream(device=dev)
         self._hold = []  # keeps the previous batch's cross-stream tensors alive while the GPU still uses them
 
     def submit(self, batch):
