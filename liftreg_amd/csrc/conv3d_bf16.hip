@@ -472,6 +472,131 @@ __global__ __launch_bounds__(256, 3) void conv3d_march_s2_bf16_kernel(const u16*
   }
 }
 
+// The 32 -> 32 stride-2 blocks the same way (Cin = 32: one tap per MFMA, 64-byte records).  Column of 4 x 8 outputs = two
+// M-tiles of 2 rows x 8 voxels; wave w: cout tile w & 1, M-tile w >> 1, all 27 taps (27 weight fragments in registers).
+// Records of 64 bytes put the four 16-byte channel chunks of voxels 4 apart into the same banks: chunk k of a record in
+// region row r is stored at position k ^ (r & 3) (found by enumeration: every ds_read_b128 lane group then covers all 64
+// banks exactly once, for both row parities and the +1 shift of the third tap column).
+constexpr int M3_TY = 4, M3_TX = 8;
+constexpr int M3_RY = 2 * M3_TY + 1, M3_NO = M3_TX + 1, M3_NE = M3_TX;
+constexpr int M3_ROWB = (M3_NO + M3_NE) * 64, M3_PLB = M3_RY * M3_ROWB, M3_NCH = M3_PLB / 16;  // 1088, 9792, 612
+constexpr int M3_NSLOT = 5, M3_NIT = (2 * M3_NCH + 255) / 256;
+constexpr int M3_DUMP = M3_NSLOT * M3_PLB, M3_LDSB = M3_DUMP + (M3_NIT * 256 - 2 * M3_NCH) * 16;
+static_assert(M3_NIT == 5 && 2 * 256 < M3_NCH && 3 * 256 >= M3_NCH && 4 * 256 < 2 * M3_NCH, "item -> plane map below");
+
+#ifndef LR_M3_BLOCKS
+#define LR_M3_BLOCKS 2
+#endif
+__global__ __launch_bounds__(256, LR_M3_BLOCKS) void conv3d_march_s2_c32_bf16_kernel(const u16* __restrict__ in, const u32x4* __restrict__ wp,
+                                                                          const float* __restrict__ bias, void* __restrict__ out,
+                                                                          ConvDimsH d, int zc, int out_layout, float slope) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[M3_LDSB];
+  const unsigned lb = lr_xcd_remap(blockIdx.x, gridDim.x);
+  const int hq = lb % d.nHq, wq = (lb / d.nHq) % d.nWq, dq = (lb / d.nHq / d.nWq) % d.nDq;
+  const int b = lb / d.nHq / d.nWq / d.nDq;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, kq = lane >> 4;
+  const int nt = wave & 1, mt = wave >> 1;
+  const int rl = col >> 3, xl = col & 7;   // this lane's output row (of the M-tile's two) and voxel
+  const int dD = __builtin_amdgcn_readfirstlane(d.D), dW = __builtin_amdgcn_readfirstlane(d.W),
+            dH = __builtin_amdgcn_readfirstlane(d.H);
+  const int ox0 = hq * M3_TX, oy0 = wq * M3_TY, oz0 = dq * zc;
+  const int oz1 = min(oz0 + zc, d.Do);
+  const int half_h = dH >> 1;
+  const unsigned plane_b = (unsigned)dW * (unsigned)dH * 64u;
+
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(wp), (short)0, 0x7fffffff, 0x00020000);
+  const u16* inb = in + (int64_t)b * dD * dW * dH * 32;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(inb), (short)0, (int)((unsigned)dD * plane_b), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_null = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(inb), (short)0, 0, 0x00020000);
+  constexpr unsigned OOR = 0x80000000u;
+
+  u32x4 w[27];
+#pragma unroll
+  for (int T = 0; T < 27; ++T) w[T] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)lane * 16u, (unsigned)((T * 2 + nt) * 1024), 0);
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = bias[nt * 16 + kq * 4 + r];
+  }
+
+  // LDS byte offset (without the plane slot) of this lane's operand of tap (ty, tx)
+  // (tx adds a lane-invariant constant: 0 | the even half | one record — an immediate of the ds_read)
+  unsigned toff[3];
+#pragma unroll
+  for (int ty = 0; ty < 3; ++ty) {
+    const int row = 4 * mt + 2 * rl + ty;
+    toff[ty] = (unsigned)(row * M3_ROWB + xl * 64 + ((kq ^ (row & 3)) * 16));
+  }
+
+  // staging items: chunk c = tid + 256 j of the 2 x 612 16-byte chunks of a plane pair (j = 0,1: plane 0; 2: both; 3,4: plane 1)
+  unsigned goff[M3_NIT], loff[M3_NIT];
+  bool p2 = false;
+#pragma unroll
+  for (int j = 0; j < M3_NIT; ++j) {
+    const int c = tid + 256 * j;
+    const bool live = c < 2 * M3_NCH;
+    const int p = c >= M3_NCH ? 1 : 0;
+    if (j == 2) p2 = p != 0;
+    const int ci = c - p * M3_NCH;
+    const int row = ci / (4 * (M3_NO + M3_NE)), cc = ci - row * 4 * (M3_NO + M3_NE);
+    const bool odd = cc < 4 * M3_NO;
+    const int rec = odd ? (cc >> 2) : ((cc - 4 * M3_NO) >> 2);
+    const int k = cc & 3;
+    const int y = 2 * oy0 - 1 + row;
+    const int xi = odd ? ox0 - 1 + rec : ox0 + rec;
+    const bool ok = live && y >= 0 && y < dW && xi >= 0 && xi < half_h;
+    const unsigned mrec = (unsigned)(odd ? half_h + xi : xi);
+    goff[j] = ok ? ((unsigned)(p * dW + y) * (unsigned)dH + mrec) * 64u + (unsigned)k * 16u : OOR;
+    loff[j] = live ? (unsigned)(ci - k + (k ^ (row & 3))) * 16u : (unsigned)(M3_DUMP + (c - 2 * M3_NCH) * 16);
+  }
+
+  u32x4 st[M3_NIT];
+  auto stage_load = [&](int zbase, bool real) {
+    const unsigned zo = (unsigned)zbase * plane_b;
+#pragma unroll
+    for (int j = 0; j < M3_NIT; ++j) st[j] = __builtin_amdgcn_raw_buffer_load_b128(real ? rsrc : rsrc_null, goff[j] + zo, 0, 0);
+  };
+  auto stage_write = [&](unsigned s0b, unsigned s1b) {
+#pragma unroll
+    for (int j = 0; j < M3_NIT; ++j) {
+      const bool live = tid + 256 * j < 2 * M3_NCH;
+      const unsigned sb = j < 2 ? s0b : j == 2 ? (p2 ? s1b : s0b) : (live ? s1b : 0u);
+      *reinterpret_cast<u32x4*>(lds + sb + loff[j]) = st[j];
+    }
+  };
+
+  stage_load(2 * oz0 - 2, oz0 > 0);
+  stage_write(0u, (unsigned)M3_PLB);
+  stage_load(2 * oz0, true);
+  stage_write(2u * M3_PLB, 3u * M3_PLB);
+  __syncthreads();
+  int k = 1;  // slot of plane 2oz-1
+  const int wo = oy0 + 2 * mt + rl, ho = ox0 + xl;
+  for (int oz = oz0; oz < oz1; ++oz) {
+    stage_load(2 * oz + 2, oz + 1 < oz1);
+    __builtin_amdgcn_sched_barrier(0);
+    const int k1 = k + 1 >= M3_NSLOT ? k + 1 - M3_NSLOT : k + 1, k2 = k + 2 >= M3_NSLOT ? k + 2 - M3_NSLOT : k + 2;
+    const int k3 = k + 3 >= M3_NSLOT ? k + 3 - M3_NSLOT : k + 3, k4 = k + 4 >= M3_NSLOT ? k + 4 - M3_NSLOT : k + 4;
+    const unsigned sb[3] = {(unsigned)k * M3_PLB, (unsigned)k1 * M3_PLB, (unsigned)k2 * M3_PLB};
+    f32x4 acc = bv;
+#pragma unroll
+    for (int T = 0; T < 27; ++T) {
+      constexpr int TXO[3] = {0, M3_NO * 64, 64};
+      const u32x4 x = *reinterpret_cast<const u32x4*>(lds + sb[T / 9] + toff[(T / 3) % 3] + TXO[T % 3]);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[T]), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+    }
+    store_tile_any(acc, out, d, b, oz, wo, ho, nt, lane, out_layout, slope);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_write((unsigned)k3 * M3_PLB, (unsigned)k4 * M3_PLB);
+    __syncthreads();
+    k = k2;
+  }
+}
+
 // ===========================================================================================================
 // First block (planar fp32 input, stride 1) on the bf16 MFMA.  Brick = 4 planes (one per wave) x 4 rows x 64
 // voxels.  K order: 27 window rows (channel, tz, ty) x 4 columns (tx = 0..2 and a zero-weight 4th) = 108 -> 128 =
@@ -1071,21 +1196,29 @@ static int conv_bf16_impl(const void* in, const void* packed_w, const float* bia
     else hipLaunchKernelGGL((conv3d_cl_bf16_kernel<NTV, C32, PSV, 4>), grid, block, 0, st, x, wt, bias, out, d, out_layout, negative_slope);          \
   } while (0)
   const int NT = Cout / 16;
-  // the 16 -> 32 block on parity-split rows: the z-marching kernel (LIFTREG_BF16_NO_MARCH: the row kernel)
-  if (rows && Cin == 16 && NT == 2 && !lr_sw_on(LR_SW_BF16_NO_MARCH) && (int64_t)(D + 4) * W * H * 32 < 0x7fffffffLL) {
-    const int nTy = (d.Wo + MZ_TY - 1) / MZ_TY, nTx = (d.Ho + MZ_TX - 1) / MZ_TX;
-    // z chunks: columns of >= 16 steps, enough units for ~8 rounds of the 768 resident blocks
-    int zc = lr_sw_int(LR_SW_BF16_MARCH_ZC, 0);
-    if (zc < 1) {
-      int nz = 1;
-      while ((int64_t)B * nTy * nTx * nz < 6144 && d.Do / (nz * 2) >= 16) nz *= 2;
-      zc = (d.Do + nz - 1) / nz;
+  // 32 couts on parity-split rows: the z-marching kernels (LIFTREG_BF16_NO_MARCH: the row kernel)
+  if (rows && NT == 2 && !lr_sw_on(LR_SW_BF16_NO_MARCH) && (int64_t)(D + 4) * W * H * Cin * 2 < 0x7fffffffLL) {
+    const int mty = Cin == 16 ? MZ_TY : M3_TY, mtx = Cin == 16 ? MZ_TX : M3_TX;
+    const int nTy = (d.Wo + mty - 1) / mty, nTx = (d.Ho + mtx - 1) / mtx;
+    // columns are serial walks: below ~one column per CU the row kernel's many small blocks win (measured: 32^3 and 16^3 inputs
+    // at B = 8).  The rule looks at the plane and the batch only, never at D: a z-slab of a volume takes the same kernel as
+    // the whole volume (sharded == unsharded bit for bit).  LIFTREG_BF16_MARCH_ZC set: always (tests).
+    const bool march_pays = (int64_t)B * nTy * nTx >= 256 || lr_sw_set(LR_SW_BF16_MARCH_ZC);
+    if (march_pays) {
+      // z chunks: columns of >= 16 steps, enough units for ~8 rounds of the resident blocks
+      int zc = lr_sw_int(LR_SW_BF16_MARCH_ZC, 0);
+      if (zc < 1) {
+        int nz = 1;
+        while ((int64_t)B * nTy * nTx * nz < 6144 && d.Do / (nz * 2) >= 16) nz *= 2;
+        zc = (d.Do + nz - 1) / nz;
+      }
+      d.nHq = nTx; d.nWq = nTy; d.nDq = (d.Do + zc - 1) / zc;
+      const int64_t nb = (int64_t)B * d.nDq * d.nWq * d.nHq;
+      if (nb > 0x7fffffffLL) return LR_EINVAL;
+      if (Cin == 16) hipLaunchKernelGGL(conv3d_march_s2_bf16_kernel, dim3((unsigned)nb), block, 0, st, x, wt, bias, out, d, zc, out_layout, negative_slope);
+      else hipLaunchKernelGGL(conv3d_march_s2_c32_bf16_kernel, dim3((unsigned)nb), block, 0, st, x, wt, bias, out, d, zc, out_layout, negative_slope);
+      return lr_launch_status();
     }
-    d.nHq = nTx; d.nWq = nTy; d.nDq = (d.Do + zc - 1) / zc;
-    const int64_t nb = (int64_t)B * d.nDq * d.nWq * d.nHq;
-    if (nb > 0x7fffffffLL) return LR_EINVAL;
-    hipLaunchKernelGGL(conv3d_march_s2_bf16_kernel, dim3((unsigned)nb), block, 0, st, x, wt, bias, out, d, zc, out_layout, negative_slope);
-    return lr_launch_status();
   }
   if (rows) {
 #define LR_BR(NTV, C32) hipLaunchKernelGGL((conv3d_cl_rows_bf16_kernel<NTV, 4, C32>), grid, block, 0, st, x, wt, bias, out, d, out_layout, negative_slope)

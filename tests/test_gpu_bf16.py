@@ -65,9 +65,10 @@ def test_bf16_blocks_all_layouts(dev):
             _close_bf16(y.float().permute(0, 4, 1, 2, 3).cpu().numpy(), want.numpy(), tag)
 
 
+@pytest.mark.parametrize("cin", [16, 32])
 @pytest.mark.parametrize("zc", [None, 1, 3])
-def test_bf16_block1_z_march_vs_oracle_and_row_kernel(dev, zc, monkeypatch):
-    """The 16->32 block on parity-split rows runs as the z-marching kernel (conv3d_bf16.hip: conv3d_march_s2_bf16_kernel):
+def test_bf16_z_march_vs_oracle_and_row_kernel(dev, zc, cin, monkeypatch):
+    """The 16->32 and 32->32 blocks on parity-split rows run as z-marching kernels (conv3d_bf16.hip: conv3d_march_s2_*):
     ragged tiles (Wo % 4, Ho % 16 != 0), odd depths, every z-chunk boundary (LIFTREG_BF16_MARCH_ZC), all three output
     layouts — against the CPU restatement and against the row kernel (LIFTREG_BF16_NO_MARCH) it replaces."""
     from liftreg_amd import ops
@@ -83,8 +84,8 @@ def test_bf16_block1_z_march_vs_oracle_and_row_kernel(dev, zc, monkeypatch):
         ((12, 33, 68), 1, L.LAYOUT_BF16_NDHWC_HPS),
     ]
     for shape, B, ol in cases:
-        x = torch.from_numpy(rs.uniform(-1, 1, (B, 16) + shape).astype(np.float32)).to(torch.bfloat16)
-        w = torch.from_numpy((rs.normal(0, 1, (32, 16, 3, 3, 3)) / np.sqrt(27 * 16)).astype(np.float32))
+        x = torch.from_numpy(rs.uniform(-1, 1, (B, cin) + shape).astype(np.float32)).to(torch.bfloat16)
+        w = torch.from_numpy((rs.normal(0, 1, (32, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32))
         b = torch.from_numpy(rs.uniform(-0.1, 0.1, 32).astype(np.float32))
         want = ro.conv_block_bf16(x.float(), w, b, 2, round_out=(ol != L.LAYOUT_NCDHW)).numpy()
         xd = _to_hps(x.permute(0, 2, 3, 4, 1).contiguous().to(dev))
@@ -103,7 +104,7 @@ def test_bf16_block1_z_march_vs_oracle_and_row_kernel(dev, zc, monkeypatch):
         monkeypatch.setenv("LIFTREG_BF16_NO_MARCH", "1")
         rows = run()
         monkeypatch.delenv("LIFTREG_BF16_NO_MARCH")
-        tag = str((shape, B, ol, zc))
+        tag = str((cin, shape, B, ol, zc))
         if ol == L.LAYOUT_NCDHW:
             np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6, err_msg=tag)
             np.testing.assert_allclose(got, rows, rtol=2e-5, atol=2e-6, err_msg=tag)

@@ -55,10 +55,16 @@ def op_table(cfg, P, bf16):
                          (f"conv3d_bf16_c{P + 1}x16_s1_{n}_clin", r"^conv0_cl_bf16_kernel<.*, true>$", 0),
                          ("backproject_encin_bf16", r"^backproject_encin_bf16_kernel", 0),
                          (f"conv3d_bf16_c16x32_s2_{n}", r"^(conv3d_march_s2_bf16_kernel|conv3d_cl_rows_bf16_kernel<2, 4, false>)", 0)]
-        size, rank = n // 2, 0
+        # 32 -> 32 blocks: the z-marching kernel while batch x columns >= 256 (conv3d_bf16.hip: march_pays), else the row kernel
+        batch = {"c1": 1, "c2": 4, "c3": 8, "c4": 4, "c5": 4}.get(cfg, 8)
+        size, rank_m, rank_r = n // 2, 0, 0
         while size >= 16:
-            ops.append((f"conv3d_bf16_c32x32_s2_{size}", r"^conv3d_cl_rows_bf16_kernel<(1|2), 4, true>", rank))
-            rank += 1
+            if batch * ((size // 2 + 3) // 4) * ((size // 2 + 7) // 8) >= 256:
+                ops.append((f"conv3d_bf16_c32x32_s2_{size}", r"^conv3d_march_s2_c32_bf16_kernel", rank_m))
+                rank_m += 1
+            else:
+                ops.append((f"conv3d_bf16_c32x32_s2_{size}", r"^conv3d_cl_rows_bf16_kernel<(1|2), 4, true>", rank_r))
+                rank_r += 1
             size //= 2
         return ops
     size, rank_w, rank_d = n // 2, 0, 0
