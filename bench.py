@@ -284,10 +284,13 @@ def main():
                     help="untimed seconds of the same step before the W warm-up steps (GPU clock ramp; 0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-drr", action="store_true", help="skip the projector-only legs after the timed region (profiling runs)")
-    ap.add_argument("--streams", type=int, default=1, choices=(1, 2),
-                    help="2: batch i's HBM-bound decode half overlaps batch i+1's MFMA-bound encode half on two HIP "
-                         "streams (measured +1.3 %% at C3: every kernel already fills the chip; per-kernel timings "
-                         "are only meaningful with 1)")
+    ap.add_argument("--streams", type=int, default=0, choices=(0, 1, 2, 3),
+                    help="0 (default) = 1: one stream.  "
+                         "3: liftreg_amd.pipeline.ShadowRegistrar — the next batch's backprojection and the previous batch's NCC "
+                         "moments on side streams beside the pair kernel (identical results; the per-kernel table then comes "
+                         "from eager steps after the timed region).  2: TwoStreamRegistrar (decode of batch i beside the "
+                         "encode of batch i+1: measured slower, profiles/NOTES_r04.md).  3 measured +1…4 %% over 1 depending on the box "
+                         "(profiles/NOTES_r04.md): inside the box-to-box spread, so the headline stays on one stream")
     ap.add_argument("--decode-cus", type=int, default=0,
                     help="with --streams 2: compute units reserved for the decode stream (CU-masked streams)")
     ap.add_argument("--pca-dtype", default="fp32", choices=("fp32", "bf16"),
@@ -358,6 +361,8 @@ def main():
                             "fuse_ncc": args.fuse_ncc, "fuse_backproject": args.fuse_bp,
                             "fuse_pair01": not args.no_pair01}).to(dev).eval()
     slab = args.shard == "slab"
+    if args.streams == 0:
+        args.streams = 1
     inp = synth_inputs(cfg, dev, seed=2021 if slab else 2021 + rank)   # slab: every rank holds the SAME batch
     sim = NCCLoss(check_nan=False)
 
@@ -372,6 +377,12 @@ def main():
 
         def step():
             return sharded.forward([my])[0]["sim_loss"]
+    elif args.streams == 3:
+        from liftreg_amd.pipeline import ShadowRegistrar
+        reg = ShadowRegistrar(net, sim)
+
+        def step():
+            return reg.submit(inp)[1]
     elif args.streams == 2:
         from liftreg_amd.pipeline import TwoStreamRegistrar
         reg = TwoStreamRegistrar(net, sim, decode_cus=args.decode_cus)
@@ -422,12 +433,15 @@ def main():
             fence()
             elapsed = time.perf_counter() - t0
         ksum = kt.summary()
-        if args.graph:                    # a replay records no per-launch events: take them from one eager step
+        if args.graph or args.streams == 3:   # a replay records no per-launch events, kernels that overlap have no duration of their own: one eager step
+            n_eager = 1 if args.graph else 5
             with ops.kernel_timer() as kt:
-                out = net(inp)
-                sim(out["warped"], out["target"])
+                for _ in range(n_eager):
+                    out = net(inp)
+                    sim(out["warped"], out["target"])
                 torch.cuda.synchronize()
-            ksum = {k: {"ms": v["ms"] * args.steps, "info": v["info"]} for k, v in kt.summary().items()}
+            ksum = {k: {"ms": (v["ms"] * args.steps)[:args.steps * len(v["ms"]) // n_eager], "info": v["info"]}
+                    for k, v in kt.summary().items()}
     assert torch.isfinite(loss), "NCC is not finite"
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -611,7 +625,8 @@ def main():
                    "parallelism": (f"z-slab x{world}: ONE batch of {B} registrations sharded along D (rows {d0}:{d1} on rank 0); "
                                    "halo planes p2p, encoder features all-gather, NCC moments all-reduce over RCCL" if slab else
                                    f"replicas x{world} (independent registrations, no data-path collective)"),
-                   "streams": args.streams, "hip_graph": bool(args.graph), "conv0_split": bool(args.conv0_split),
+                   "streams": args.streams, "pipeline": ("shadow: bp(i+1) and ncc(i-1) beside pair(i); per-kernel table from 5 eager steps after the timed region"
+                                                         if args.streams == 3 else None), "hip_graph": bool(args.graph), "conv0_split": bool(args.conv0_split),
                    "fused_pair01": pair01_ran,
                    "untimed_before_warmup": f"{ramp_steps} steps ({args.ramp_seconds:g} s clock ramp), then {args.warmup} warm-up steps"},
         "roofline": roof(dominant),

@@ -151,6 +151,14 @@ int lr_backproject_f32(const float* proj, const float* poses, float* out,
                        int B, int P, int Pw, int Ph, int D, int W, int H,
                        int d0, int d1, int64_t out_batch_stride, void* stream);
 
+/* lr_backproject_f32 through the register-light kernel (one voxel per thread, 28 registers, no LDS; the same results bit for
+ * bit, 0.36 instead of 0.27 ms alone at C3): its waves fit beside the fused pair kernel's on every CU, so a pipeline
+ * (liftreg_amd/pipeline.py: ShadowRegistrar) runs the NEXT batch's backprojection on a second stream in the shadow of the
+ * current batch's lr_conv3d_pair01_f32.  Replaces the same reference lines (…Backproj.py:85-93). */
+int lr_backproject_light_f32(const float* proj, const float* poses, float* out,
+                             int B, int P, int Pw, int Ph, int D, int W, int H,
+                             int d0, int d1, int64_t out_batch_stride, void* stream);
+
 /* Parity / API compatibility (backproj_grids_with_poses): detector coordinates of every
  * voxel shadow. normalized=0: pixel units; normalized=1: the reference's [-1,1] grid.
  * pix: dev (P,D,W,H,2) ordered (Pw axis, Ph axis). */

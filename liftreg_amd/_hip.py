@@ -35,6 +35,7 @@ SIGNATURES = {
     "lr_hu_to_mu_f32": (_i, [_p, _p, _i64, _p]),
     "lr_drr_sample_coords_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "lr_backproject_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _p]),
+    "lr_backproject_light_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _p]),
     "lr_backproject_coords_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "lr_backproject_coords_poseless_f64": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "lr_sample_points_f64": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -163,7 +163,13 @@ __device__ unsigned long long g_lr_c01_stamps[8 * 8];
 #endif
 
 template <int NC>
-__global__ __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
+// LR_C01_NUM_VGPR (build flag): cap the kernel's registers per lane (the attribute counts half of the unified file's total)
+#ifdef LR_C01_NUM_VGPR
+#define LR_C01_VGPR_CAP __attribute__((amdgpu_num_vgpr(LR_C01_NUM_VGPR / 2)))
+#else
+#define LR_C01_VGPR_CAP
+#endif
+__global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv01_fused_kernel(
     const float* __restrict__ in0, const float* __restrict__ in_rest, const u32x4* __restrict__ wp0,
     const u32x4* __restrict__ wp1, const float* __restrict__ bias0, const float* __restrict__ bias1,
     float* __restrict__ out, FDims d) {

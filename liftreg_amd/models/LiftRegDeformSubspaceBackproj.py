@@ -329,8 +329,22 @@ class model(nn.Module):
         disp = ops.pca_reconstruct(coefs, self.pca_vectors_LxM, self.pca_mean).view(B, 3, D, W, H)
         return coefs, disp
 
-    def encode(self, moving, target_proj, poses):
-        """MFMA-bound half: backprojection → 6 conv blocks → FC head → PCA coefficients (B,L)."""
+    def backproject_views(self, target_proj, poses, img_shape, out=None, light=False):
+        """target_volume (:89-93) alone: the (B,P,D,W,H) backprojection of the views.  A pipeline computes it for batch
+        i+1 while batch i's MFMA-bound blocks run (liftreg_amd/pipeline.py) and hands it to encode(target_volume=…)."""
+        if self._poses is None:
+            p = poses.detach().cpu().numpy() if isinstance(poses, torch.Tensor) else np.asarray(poses)
+            self._poses = np.ascontiguousarray(p[0], dtype=np.float32)  # poses[0:1] (:87)
+        D, W, H = img_shape
+        B, P = target_proj.shape[:2]
+        if out is None:
+            out = torch.empty((B, P, D, W, H), dtype=torch.float32, device=target_proj.device)
+        ops.backproject(target_proj, self._poses, (D, W, H), out=out, out_batch_stride=P * D * W * H, light=light)
+        return out
+
+    def encode(self, moving, target_proj, poses, target_volume=None):
+        """MFMA-bound half: backprojection → 6 conv blocks → FC head → PCA coefficients (B,L).  target_volume: the
+        backprojection already computed by backproject_views() (fp32 inference path; ignored elsewhere)."""
         self._ensure_pca(moving.device)
         B, _, D, W, H = moving.shape
         P = target_proj.shape[1]
@@ -354,18 +368,22 @@ class model(nn.Module):
                 for i in range(1, 6):
                     x = self.encoders[i](x, packed=self._packed_weight(i))
                 return self.encoders[6](x)
-            tv = torch.empty((B, P, D, W, H), dtype=torch.float32, device=moving.device)
+            have_tv = (target_volume is not None and tuple(target_volume.shape) == (B, P, D, W, H) and
+                       target_volume.dtype == torch.float32 and target_volume.is_contiguous())
+            tv = target_volume if have_tv else torch.empty((B, P, D, W, H), dtype=torch.float32, device=moving.device)
             b0, b1 = self.encoders[0], self.encoders[1]
             if (self.fuse_pair01 and not self.fuse_backproject and b1.stride == 2 and b0.out_layout == b1.in_layout and
                     ops.conv3d_pair01_supported(mv, tv, b0.conv.weight, b1.conv.weight, b1.out_layout)):
-                ops.backproject(target_proj, self._poses, (D, W, H), out=tv, out_batch_stride=P * V)
+                if not have_tv:
+                    ops.backproject(target_proj, self._poses, (D, W, H), out=tv, out_batch_stride=P * V)
                 x = ops.conv3d_pair01(mv, tv, b0.conv.weight, b0.conv.bias, b1.conv.weight, b1.conv.bias,
                                       out_layout=b1.out_layout, slope0=b0._slope, slope1=b1._slope, packed=self._packed_pair01())
                 for i in range(2, 6):
                     x = self.encoders[i](x, packed=self._packed_weight(i))
                 return self.encoders[6](x)
             if ops.conv3d_first_split_supported(mv, tv):
-                ops.backproject(target_proj, self._poses, (D, W, H), out=tv, out_batch_stride=P * V)
+                if not have_tv:
+                    ops.backproject(target_proj, self._poses, (D, W, H), out=tv, out_batch_stride=P * V)
                 blk = self.encoders[0]
                 x = ops.conv3d_first_split(mv, tv, blk.conv.weight, blk.conv.bias, out_layout=blk.out_layout,
                                            negative_slope=blk._slope, packed=self._packed_weight(0))

@@ -164,8 +164,9 @@ def drr_sample_coords(poses, spacing, shape, resolution, device, normalized=Fals
 
 
 # ----------------------------------------------------------------------------- K2 backprojection
-def backproject(proj, poses, img_shape, *, d0=0, d1=None, out=None, out_batch_stride=None):
+def backproject(proj, poses, img_shape, *, d0=0, d1=None, out=None, out_batch_stride=None, light=False):
     """(B,P,Pw,Ph) views → (B,P,Ds,W,H) feature volume for ONE emitter geometry `poses` (P,3).
+    light: the register-light kernel (lr_backproject_light_f32: same bits; for a launch beside the pair kernel).
 
     Replaces backproj_grids_with_poses + F.grid_sample (reference …Backproj.py:85-93).
     `out` may be a view into a larger buffer whose batch stride is `out_batch_stride`
@@ -198,9 +199,9 @@ def backproject(proj, poses, img_shape, *, d0=0, d1=None, out=None, out_batch_st
                                  f"{out_batch_stride}, got shape {tuple(out.shape)} strides {tuple(out.stride())}")
         optr = out.data_ptr()
     with _timed("backproject", bytes=4 * (B * P * Ds * W * H + B * P * Pw * Ph), samples=B):
-        _hip.check(_hip.lib().lr_backproject_f32(proj.data_ptr(), poses.ctypes.data, optr, B, P, Pw, Ph, D, W,
-                                                 H, d0, d1, int(out_batch_stride), _stream()),
-                   "lr_backproject_f32")
+        fn = _hip.lib().lr_backproject_light_f32 if light else _hip.lib().lr_backproject_f32
+        _hip.check(fn(proj.data_ptr(), poses.ctypes.data, optr, B, P, Pw, Ph, D, W, H, d0, d1, int(out_batch_stride), _stream()),
+                   "lr_backproject_light_f32" if light else "lr_backproject_f32")
     return out
 
 

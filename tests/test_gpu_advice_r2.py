@@ -143,6 +143,49 @@ def test_two_stream_registrar_serving_loop_that_drops_its_batches(dev):
         assert torch.equal(w, gw) and abs(l - float(gl)) < 1e-6
 
 
+@pytest.mark.parametrize("labels", [False, True])
+def test_shadow_registrar_equals_the_plain_forward(dev, labels):
+    """liftreg_amd/pipeline.py: ShadowRegistrar — the next batch's backprojection (register-light kernel) and the previous
+    batch's NCC moments run on side streams beside the fused pair kernel; every batch's outputs and loss equal the plain
+    forward's bit for bit (same kernels' arithmetic, same order inside a batch), also when the caller drops its batches."""
+    from liftreg_amd.layers.losses import NCCLoss
+    from liftreg_amd.pipeline import ShadowRegistrar
+    net = _net(dev, n=64)
+    sim = NCCLoss(check_nan=False)
+    reg = ShadowRegistrar(net, sim)
+    want = []
+    with torch.no_grad():
+        for i in range(5):
+            b = _batch(dev, n=64, seed=i, labels=labels)
+            o = net(b)
+            want.append((o["warped"].clone(), o["phi"].clone(), o["pca_coefs"].clone(), float(sim(o["warped"], o["target"]))))
+        torch.cuda.synchronize()
+        got = []
+        for i in range(5):
+            b = _batch(dev, n=64, seed=i, labels=labels)
+            out, loss = reg.submit(b)
+            got.append((out["warped"], out["phi"], out["pca_coefs"], loss))
+            del b, out
+            junk = torch.full((2, 1, 64, 64, 64), float(i), device=dev)
+            del junk
+        reg.synchronize()
+    for (w, p, c, l), (gw, gp, gc, gl) in zip(want, got):
+        assert torch.equal(c, gc) and torch.equal(p, gp) and torch.equal(w, gw) and abs(l - float(gl)) < 1e-6
+
+
+def test_backproject_light_kernel_same_bits(dev):
+    from liftreg_amd import ops
+    from liftreg_amd.utils.sdct_projection_utils import scan_poses
+    g = torch.Generator(device=dev).manual_seed(5)
+    for (B, P, n, pw) in ((2, 2, 48, 40), (1, 3, 36, 52)):
+        proj = torch.rand(B, P, pw, pw, device=dev, generator=g)
+        poses = scan_poses(30, P, n).astype(np.float32)
+        a = ops.backproject(proj, poses, (n, n, n))
+        b = ops.backproject(proj, poses, (n, n, n), light=True)
+        c = ops.backproject(proj, poses, (n, n, n), d0=8, d1=24, light=True)
+        assert torch.equal(a, b) and torch.equal(a[:, :, 8:24], c)
+
+
 def test_slab_sharded_forward_masks_the_target_like_the_unsharded_model(dev):
     from liftreg_amd import parallel as par
     from liftreg_amd.layers.losses import NCCLoss

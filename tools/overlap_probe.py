@@ -54,7 +54,34 @@ def main():
         torch.cuda.synchronize()
         return (ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3]) if fa else 0.0, ev[4].elapsed_time(ev[5]) if fb else 0.0)
 
-    for nf in (1, 2, 3):
+    # the plain backprojection kernel (28 VGPRs: LIFTREG_BP_LIGHT) and the NCC moments in the pair kernel's shadow
+    import numpy as np
+    from liftreg_amd import _hip
+    proj = torch.rand(B, 2, 256, 256, device=dev, generator=g)
+    poses = np.array([[0.0, -160.0, 0.0], [-160.0, 0.0, 0.0]], np.float32)
+    tv = torch.empty(B, 2, N, N, N, device=dev)
+    wv = torch.rand(B, 1, N, N, N, device=dev, generator=g)
+
+    light_box = [False]
+
+    def bp():
+        ops.backproject(proj, poses, (N, N, N), out=tv, out_batch_stride=2 * N ** 3, light=light_box[0])
+
+    def ncc():
+        ops.ncc_moments(wv, x0, B)
+
+    for light in ("0", "1"):
+        light_box[0] = light == "1"
+        for name, fn in (("backproject", bp), ("ncc_moments", ncc)):
+            for _ in range(2):
+                timed(pair, fn)
+            for rep in range(2):
+                a = timed(pair, None)
+                b = timed(None, fn)
+                c = timed(pair, fn)
+                print(f"BP_LIGHT={light} {name}: pair alone {a[0]:.3f} | {name} alone {b[0]:.3f} | both wall {c[0]:.3f} (pair {c[1]:.3f}, {name} {c[2]:.3f}) | sum {a[0] + b[0]:.3f}")
+
+    for nf in (2,):
         nfill_box[0] = nf
         for _ in range(2):
             timed(pair, fill)
