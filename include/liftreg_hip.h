@@ -465,6 +465,18 @@ int lr_conv3d_pair01_slab_f32(const float* in0, int64_t in0_batch_stride, const 
                               int D, int W, int H, int out_layout, float slope0, float slope1, int64_t out_batch_stride,
                               int D_global, int z_lo, int oz_lo, int n_oz, void* stream);
 
+/* Training forward of the two blocks: lr_conv3d_pair01_f32 (dense output) that ALSO writes
+ *   act0  : dev (B,D,W,H,16) fp32, block 0's activation in mid_layout (LR_LAYOUT_NDHWC | LR_LAYOUT_NDHWC_HPS) — exactly the
+ *           fp32 values whose three-way splits fed block 1; what block 1's weight gradient reads;
+ *   mask0 : dev (B,D,W,H,4) uint8 (LR_LAYOUT_SIGN4), its LeakyReLU sign mask as lr_conv3d_k3_lrelu_mask_f32 writes it — what
+ *           the fused data-gradient + block-0 weight-gradient kernel (lr_conv3d_dgrad_wgrad0_f32) reads.
+ * Whole volumes only; act0 16-byte, mask0 4-byte aligned; D*W*H*64 < 2^31.  Replaces layers.py:365-369 twice in the
+ * training forward (RegistrationNet.py:389-406 drives it). */
+int lr_conv3d_pair01_train_f32(const float* in0, int64_t in0_batch_stride, const float* in_rest, int64_t rest_batch_stride,
+                               const float* packed, const float* bias0, const float* bias1, float* out, float* act0,
+                               uint8_t* mask0, int B, int Cin, int D, int W, int H, int mid_layout, int out_layout,
+                               float slope0, float slope1, void* stream);
+
 /* f1 ("backproject -> conv0: never write the P*V volume"): the same first block with the backprojection
  * computed INSIDE its staging.  Channel 0 = in0 (B,1,D,W,H), channels 1..P = the backprojection of proj (B,P,Pw,Ph)
  * for `poses` (host, P x 3 fp32, ONE geometry for the batch, …Backproj.py:85-87) — sample for sample the arithmetic

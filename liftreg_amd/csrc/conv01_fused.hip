@@ -87,6 +87,12 @@ struct FDims {
   long long bs0, bsr;      // elements between batch elements of channel 0 | of channels 1..Cin-1
   long long out_bs;        // output elements between batch elements
   float slope0, slope1;
+  // training forward (SAVE): block 0's activation (B,D,W,H,16) fp32 channels-last (save_hps: rows parity-split) and its LeakyReLU
+  // sign mask (B,D,W,H,4) uint8 (LR_LAYOUT_SIGN4) are ALSO written — what block 1's weight gradient and the fused
+  // dgrad1 + wgrad0 kernel read (autograd.ConvPair01Fn)
+  float* act0;
+  unsigned char* mask0;
+  int save_hps;
 };
 
 // (a, b) -> three packed bf16 pairs with a = a0 + a1 + a2 and b = b0 + b1 + b2 exactly
@@ -162,7 +168,7 @@ __device__ unsigned long long g_lr_c01_stamps[8 * 8];
 #define LR_C01_BPRIO 1
 #endif
 
-template <int NC>
+template <int NC, bool SAVE>
 // LR_C01_NUM_VGPR (build flag): cap the kernel's registers per lane (the attribute counts half of the unified file's total)
 #ifdef LR_C01_NUM_VGPR
 #define LR_C01_VGPR_CAP __attribute__((amdgpu_num_vgpr(LR_C01_NUM_VGPR / 2)))
@@ -329,6 +335,22 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
       const bool ok_s = (unsigned)(Y1 + sry) < (unsigned)dW && (unsigned)(X1 + srx) < (unsigned)dH && (!scol || col < R1Y);
       const int st_p0 = RING1_OFF + (ry0 * RS1 + (int)qpos * QS1 + col) * 8, st_p1 = st_p0 + RS1 * 8;
       const int st_s = RING1_OFF + (sry * RS1 + (int)qpos * QS1 + srx) * 8;
+      // SAVE: byte offsets inside a plane of this lane's three kinds of tiles in the activation / the mask (bit 31: not this
+      // column's voxel — region row 0 and column 0 are the neighbours' — or outside the volume); the plane goes in soffset
+      unsigned svo_p0 = OOR, svo_p1 = OOR, svo_s = OOR, mko_p0 = OOR, mko_p1 = OOR, mko_s = OOR;
+      __amdgpu_buffer_rsrc_t rs_act = make_rsrc(out, 0u), rs_msk = rs_act;
+      if constexpr (SAVE) {
+        auto sv = [&](bool own, int y, int x, unsigned& so, unsigned& mo) __attribute__((always_inline)) {
+          const int hp = d.save_hps ? (x & 1) * (dH >> 1) + (x >> 1) : x;
+          so = own ? (unsigned)((y * dH + hp) * 64 + lq * 16) : OOR;
+          mo = (own && lq == 0) ? (unsigned)((y * dH + x) * 4) : OOR;
+        };
+        sv(ok_p0 && ry0 >= 1 && col >= 1, Y1 + ry0, X1 + col, svo_p0, mko_p0);
+        sv(ok_p1 && col >= 1, Y1 + ry0 + 1, X1 + col, svo_p1, mko_p1);
+        sv(ok_s && sry >= 1 && srx >= 1, Y1 + sry, X1 + srx, svo_s, mko_s);
+        rs_act = make_rsrc(d.act0 + (int64_t)ub * dD * dW * dH * 16, (unsigned)dD * dW * dH * 64u);
+        rs_msk = make_rsrc(d.mask0 + (int64_t)ub * dD * dW * dH * 4, (unsigned)dD * dW * dH * 4u);
+      }
 
       constexpr bool a_mma_g = !(LR_C01_ABL & 16), a_ld_g = !(LR_C01_ABL & (32 | 64)), a_epi_g = !(LR_C01_ABL & 4);
       struct PairFrags { bf16x8 F[4][3], G[2][3]; };
@@ -387,10 +409,28 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
         o.p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
         return o;
       };
-      auto epi_slice = [&](int sl, Epi& E, const f32x4& acc, int addr) __attribute__((always_inline)) {
+      // (SAVE: so / mo = the tile's activation / mask offsets, zb = its plane (scalar); a plane below the volume never comes here
+      // with live offsets: the caller passes OOR)
+      auto epi_slice = [&](int sl, Epi& E, const f32x4& acc, int addr, unsigned so = OOR, unsigned mo = OOR, int zb = 0) __attribute__((always_inline)) {
         if (!a_epi_g) return;
         if (sl == 0) { E.x = acc; E.y = E.x * d.slope0; }
-        else if (sl == 1) E.x = __builtin_elementwise_max(E.x, E.y);   // = LeakyReLU for 0 <= slope <= 1 (launcher)
+        else if (sl == 1) {
+          E.x = __builtin_elementwise_max(E.x, E.y);   // = LeakyReLU for 0 <= slope <= 1 (launcher)
+          if constexpr (SAVE)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, E.x), rs_act, (int)so, zb * dW * dH * 64, 0);
+        }
+        else if (SAVE && sl == 3) {   // (the slice's own work follows below)
+          // the four channel quads of a voxel sit in the four 16-lane rows: row/half swaps bring their sign nibbles into row 0,
+          // whose lanes store one dword per voxel (conv3d.hip, MASK)
+          const unsigned x = (E.x[0] > 0.0f ? 1u : 0u) | (E.x[1] > 0.0f ? 2u : 0u) | (E.x[2] > 0.0f ? 4u : 0u) | (E.x[3] > 0.0f ? 8u : 0u);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+          const unsigned xa = s1[0], xb = s1[1];
+          const auto s2 = __builtin_amdgcn_permlane16_swap(xa, xa, false, false);
+          const auto s3 = __builtin_amdgcn_permlane16_swap(xb, xb, false, false);
+          const unsigned dw = x | (s2[1] << 8) | (xb << 16) | (s3[1] << 24);
+          __builtin_amdgcn_raw_buffer_store_b32(dw, rs_msk, (int)mo, zb * dW * dH * 4, 0);
+          const L12 t = lvl12(E.r); E.s1 = (u32x2){t.p1, 0u}; E.s2 = (u32x2){t.p2, 0u};
+        }
         else if (sl == 2) { const L0 t = lvl0(E.x[0], E.x[1]); E.s0 = (u32x2){t.p, 0u}; E.r = t.r; }
         else if (sl == 3) { const L12 t = lvl12(E.r); E.s1 = (u32x2){t.p1, 0u}; E.s2 = (u32x2){t.p2, 0u}; }
         else if (sl == 4) { const L0 t = lvl0(E.x[2], E.x[3]); E.s0[1] = t.p; E.r = t.r; }
@@ -473,7 +513,8 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
             if ((I & 1) == 0 && I < 24) load_one_n(I >> 1, bS, fs);
             if (I >= 3 && I < 45 && (I % 3) == 0) {
               const int k_ = I / 3 - 1;
-              if (k_ < 7) epi_slice(k_, E0, aa.v[0], a00); else epi_slice(k_ - 7, E1, aa.v[1], a01);
+              if (k_ < 7) epi_slice(k_, E0, aa.v[0], a00, zok0 ? svo_p0 : OOR, zok0 ? mko_p0 : OOR, 2 * s);
+              else epi_slice(k_ - 7, E1, aa.v[1], a01, zok0 ? svo_p1 : OOR, zok0 ? mko_p1 : OOR, 2 * s);
             }
             C01_FENCE();
           }
@@ -485,7 +526,8 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
             mma_one_n(I, fs, aa);
             if (I >= 2 && I < 23 && (I % 3) != 1) {   // I = 2,3,5,6,...,20,21: slices 0..13
               const int k_ = (I - 2) / 3 * 2 + ((I - 2) % 3 == 0 ? 0 : 1);
-              if (k_ < 7) epi_slice(k_, E0, ab.v[0], a10); else epi_slice(k_ - 7, E1, ab.v[1], a11);
+              if (k_ < 7) epi_slice(k_, E0, ab.v[0], a10, zok1 ? svo_p0 : OOR, zok1 ? mko_p0 : OOR, 2 * s + 1);
+              else epi_slice(k_ - 7, E1, ab.v[1], a11, zok1 ? svo_p1 : OOR, zok1 ? mko_p1 : OOR, 2 * s + 1);
             }
             C01_FENCE();
           }
@@ -493,7 +535,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
           // tail: epilogue of the single tile
           const f32x4 accS = aa.v[0] + aa.v[1];
 #pragma unroll
-          for (int k = 0; k < 7; ++k) epi_slice(k, E0, accS, as_);
+          for (int k = 0; k < 7; ++k) epi_slice(k, E0, accS, as_, (spl ? zok1 : zok0) ? svo_s : OOR, (spl ? zok1 : zok0) ? mko_s : OOR, 2 * s + spl);
           C01_STAMP(5);
         }
         __syncthreads();
@@ -818,11 +860,20 @@ extern "C" int lr_conv3d_pair01_pack_f32(const float* w0, const float* w1, float
   return lr_launch_status();
 }
 
-extern "C" int lr_conv3d_pair01_slab_f32(const float* in0, int64_t in0_batch_stride, const float* in_rest, int64_t rest_batch_stride,
-                                         const float* packed, const float* bias0, const float* bias1, float* out, int B, int Cin,
-                                         int D, int W, int H, int out_layout, float slope0, float slope1, int64_t out_batch_stride,
-                                         int D_global, int z_lo, int oz_lo, int n_oz, void* stream) {
+static int pair01_impl(const float* in0, int64_t in0_batch_stride, const float* in_rest, int64_t rest_batch_stride,
+                       const float* packed, const float* bias0, const float* bias1, float* out, int B, int Cin,
+                       int D, int W, int H, int out_layout, float slope0, float slope1, int64_t out_batch_stride,
+                       int D_global, int z_lo, int oz_lo, int n_oz, float* act0, unsigned char* mask0, int mid_layout, void* stream) {
   if (!in0 || !packed || !out || (Cin > 1 && !in_rest)) return LR_ENULL;
+  const bool save = act0 != nullptr || mask0 != nullptr;
+  if (save) {   // training forward: the whole volume, both side outputs, dense
+    if (!act0 || !mask0) return LR_ENULL;
+    if (D != D_global || z_lo != 0 || oz_lo != 0 || n_oz != (D - 1) / 2 + 1) return LR_EUNSUPPORTED;
+    if (mid_layout != LR_LAYOUT_NDHWC && mid_layout != LR_LAYOUT_NDHWC_HPS) return LR_EUNSUPPORTED;
+    if (mid_layout == LR_LAYOUT_NDHWC_HPS && (H & 1)) return LR_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(act0) & 15u) || (reinterpret_cast<uintptr_t>(mask0) & 3u)) return LR_EALIGN;
+    if ((int64_t)D * W * H * 64 >= 0x7fffffffLL) return LR_EUNSUPPORTED;   // one batch element of the activation is one buffer resource
+  }
   if (B < 1 || D < 1 || W < 1 || H < 1 || D_global < 1 || n_oz < 1 || oz_lo < 0 || z_lo < 0) return LR_EINVAL;
   // the buffers hold global planes [z_lo, z_lo + D); output planes [oz_lo, oz_lo + n_oz) read input planes 2*oz_lo - 2 ..
   // 2*(oz_lo + n_oz - 1) + 2: every one of them that exists must lie inside the buffers
@@ -858,6 +909,7 @@ extern "C" int lr_conv3d_pair01_slab_f32(const float* in0, int64_t in0_batch_str
   if (nu > 0x7fffffffLL) return LR_EINVAL;
   d.nunits = (int)nu;
   d.slope0 = slope0; d.slope1 = slope1;
+  d.act0 = act0; d.mask0 = mask0; d.save_hps = mid_layout == LR_LAYOUT_NDHWC_HPS;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   int blocks = cus;   // one block per CU (LDS)
@@ -869,18 +921,47 @@ extern "C" int lr_conv3d_pair01_slab_f32(const float* in0, int64_t in0_batch_str
   const u32x4* wp0 = reinterpret_cast<const u32x4*>(packed);
   const u32x4* wp1 = reinterpret_cast<const u32x4*>(packed + lr_internal_conv0_split_packed_floats(Cin, 16));
   if (!in_rest) in_rest = in0;   // Cin == 1: never dereferenced (zero-length resource)
-#define LR_C01(NCV)                                                                                                          \
+#define LR_C01(NCV, SV)                                                                                                      \
   do {                                                                                                                       \
     static std::atomic<uint64_t> attr_done{0};                                                                               \
-    if (lr_raise_dyn_lds(reinterpret_cast<const void*>(&conv01_fused_kernel<NCV>), LDSB, attr_done) != LR_OK) return LR_ELAUNCH; \
-    hipLaunchKernelGGL((conv01_fused_kernel<NCV>), dim3((unsigned)blocks), dim3(NTHR), LDSB, st, in0, in_rest, wp0, wp1, bias0, bias1, out, d); \
+    if (lr_raise_dyn_lds(reinterpret_cast<const void*>(&conv01_fused_kernel<NCV, SV>), LDSB, attr_done) != LR_OK) return LR_ELAUNCH; \
+    hipLaunchKernelGGL((conv01_fused_kernel<NCV, SV>), dim3((unsigned)blocks), dim3(NTHR), LDSB, st, in0, in_rest, wp0, wp1, bias0, bias1, out, d); \
   } while (0)
-  if (Cin == 1) LR_C01(1);
-  else if (Cin == 2) LR_C01(2);
-  else if (Cin == 3) LR_C01(3);
-  else LR_C01(4);
+  if (save) {
+    if (Cin == 1) LR_C01(1, true);
+    else if (Cin == 2) LR_C01(2, true);
+    else if (Cin == 3) LR_C01(3, true);
+    else LR_C01(4, true);
+  } else {
+    if (Cin == 1) LR_C01(1, false);
+    else if (Cin == 2) LR_C01(2, false);
+    else if (Cin == 3) LR_C01(3, false);
+    else LR_C01(4, false);
+  }
 #undef LR_C01
   return lr_launch_status();
+}
+
+extern "C" int lr_conv3d_pair01_slab_f32(const float* in0, int64_t in0_batch_stride, const float* in_rest, int64_t rest_batch_stride,
+                                         const float* packed, const float* bias0, const float* bias1, float* out, int B, int Cin,
+                                         int D, int W, int H, int out_layout, float slope0, float slope1, int64_t out_batch_stride,
+                                         int D_global, int z_lo, int oz_lo, int n_oz, void* stream) {
+  return pair01_impl(in0, in0_batch_stride, in_rest, rest_batch_stride, packed, bias0, bias1, out, B, Cin, D, W, H, out_layout,
+                     slope0, slope1, out_batch_stride, D_global, z_lo, oz_lo, n_oz, nullptr, nullptr, 0, stream);
+}
+
+// Training forward of the two blocks: lr_conv3d_pair01_f32 that ALSO writes block 0's activation act0 (B,D,W,H,16) fp32 in
+// mid_layout (LR_LAYOUT_NDHWC | LR_LAYOUT_NDHWC_HPS) and its LeakyReLU sign mask mask0 (B,D,W,H,4) uint8 (LR_LAYOUT_SIGN4, as
+// lr_conv3d_k3_lrelu_mask_f32) — the two tensors the backward of the pair reads (block 1's weight gradient; the fused
+// data-gradient + block-0 weight-gradient kernel).  act0 holds exactly the fp32 values whose three-way splits fed block 1.
+extern "C" int lr_conv3d_pair01_train_f32(const float* in0, int64_t in0_batch_stride, const float* in_rest, int64_t rest_batch_stride,
+                                          const float* packed, const float* bias0, const float* bias1, float* out, float* act0,
+                                          uint8_t* mask0, int B, int Cin, int D, int W, int H, int mid_layout, int out_layout,
+                                          float slope0, float slope1, void* stream) {
+  if (D < 1) return LR_EINVAL;
+  if (!act0 || !mask0) return LR_ENULL;
+  return pair01_impl(in0, in0_batch_stride, in_rest, rest_batch_stride, packed, bias0, bias1, out, B, Cin, D, W, H, out_layout,
+                     slope0, slope1, 0, D, 0, 0, (D - 1) / 2 + 1, act0, mask0, mid_layout, stream);
 }
 
 extern "C" int lr_conv3d_pair01_f32(const float* in0, int64_t in0_batch_stride, const float* in_rest, int64_t rest_batch_stride,

@@ -155,6 +155,10 @@ class model(nn.Module):
         # tests/test_gpu_conv01_fused.py); the 16-channel activation between them (8.6 GB per batch of 8 at 256^3) never reaches
         # HBM.  False = one fp32-MFMA kernel per block (the round-3 path).
         self.fuse_pair01 = bool(_opt(opt, "fuse_pair01", True))
+        # optional key "fuse_pair01_train" (default True): the TRAINING forward of blocks 0 + 1 through the same fused kernel, which
+        # then also writes block 0's activation and sign mask for the backward (ops.conv3d_pair01_train); False = the two
+        # fp32-MFMA kernels of rounds 2-3
+        self.fuse_pair01_train = bool(_opt(opt, "fuse_pair01_train", True))
         # optional (non-reference) key "reg_in_coef_space" (default True): in training the output dict also carries
         # "pca_reg_gram" = the regulariser's quadratic form on the PCA basis (ops.subspace_reg_gram, computed once per
         # basis), so that liftreg_amd.losses.SubspaceLoss evaluates R(params) and its gradient on the (B,L) coefficients
@@ -439,7 +443,8 @@ class model(nn.Module):
                 tuple(b1.conv.weight.shape[:2]) == (32, 16) and x.shape[1] in (2, 3) and x[0].numel() * 4 < 2 ** 31 - 1):
             # training, fp32: blocks 0 and 1 as one autograd node — the gradient between them never reaches memory
             x = ConvPair01Fn.apply(x, b0.conv.weight, b0.conv.bias, b1.conv.weight, b1.conv.bias, b0._slope, b1._slope,
-                                   b0.out_layout, b1.out_layout, self._packed_weight(0), self._packed_weight(1), b1.premasked_grad)
+                                   b0.out_layout, b1.out_layout, self._packed_weight(0), self._packed_weight(1), b1.premasked_grad,
+                                   self._packed_pair01() if (self.fuse_pair01 and self.fuse_pair01_train) else None)
             first = 2
         for i in range(first, 6):
             x = self.encoders[i](x, packed=self._packed_weight(i))

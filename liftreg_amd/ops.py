@@ -441,6 +441,50 @@ def conv3d_pair01(x0, rest, w0, b0, w1, b1, *, out_layout=LAYOUT_NDHWC_HPS, slop
     return y
 
 
+def conv3d_pair01_train_supported(x, w0, w1, mid_layout, out_layout):
+    """True when `conv3d_pair01_train` can take the (B,Cin,D,W,H) NCDHW input of the encoder (training forward)."""
+    if not (x.dim() == 5 and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] in (1, 2, 3, 4) and
+            x.shape[4] % 4 == 0 and x.data_ptr() % 16 == 0):
+        return False
+    B, Cin, D, W, H = x.shape
+    if tuple(w0.shape) != (16, Cin, 3, 3, 3) or tuple(w1.shape) != (32, 16, 3, 3, 3):
+        return False
+    if mid_layout not in (LAYOUT_NDHWC, LAYOUT_NDHWC_HPS) or out_layout not in (LAYOUT_NDHWC, LAYOUT_NDHWC_HPS):
+        return False
+    if out_layout == LAYOUT_NDHWC_HPS and ((H - 1) // 2 + 1) % 2:
+        return False
+    V = D * W * H
+    return 64 * V < 2 ** 31 - 1 and 12 * V + 32 * W * H < 2 ** 31 - 1
+
+
+def conv3d_pair01_train(x, w0, b0, w1, b1, *, mid_layout=LAYOUT_NDHWC_HPS, out_layout=LAYOUT_NDHWC_HPS, slope0=0.2, slope1=0.2,
+                        packed=None):
+    """Training forward of encoder blocks 0 and 1 as the fused pair kernel (conv3d_pair01) that also writes what the backward
+    reads: returns (y1 (B,Do,Wo,Ho,32), y0 (B,D,W,H,16) in mid_layout, mask0 (B,D,W,H,4) uint8)."""
+    x = _dev(x, "x")
+    if not conv3d_pair01_train_supported(x, w0, w1, mid_layout, out_layout):
+        raise ValueError("conv3d_pair01_train: unsupported shapes (run the two blocks separately)")
+    B, Cin, D, W, H = x.shape
+    if packed is None:
+        packed = conv3d_pair01_pack(w0, w1)
+    b0 = None if b0 is None else _dev(b0.detach(), "b0")
+    b1 = None if b1 is None else _dev(b1.detach(), "b1")
+    Do, Wo, Ho = (D - 1) // 2 + 1, (W - 1) // 2 + 1, (H - 1) // 2 + 1
+    y1 = torch.empty((B, Do, Wo, Ho, 32), dtype=torch.float32, device=x.device)
+    y0 = torch.empty((B, D, W, H, 16), dtype=torch.float32, device=x.device)
+    mask0 = torch.empty((B, D, W, H, 4), dtype=torch.uint8, device=x.device)
+    V = D * W * H
+    flops = 2.0 * 27 * B * (Cin * 16 * 2 * Do * W * H + 16 * 32 * Do * Wo * Ho)
+    issued = 16384.0 * 816 * Do * B * (-(-Wo // 4)) * (-(-Ho // 8))
+    with _timed(f"conv3d_pair01_train_c{Cin}x16x32_{D}", flops=flops, issued_bf16_flops=issued,
+                bytes=4 * x.numel() + 4 * y1.numel() + 4 * y0.numel() + mask0.numel(), samples=B):
+        _hip.check(_hip.lib().lr_conv3d_pair01_train_f32(x.data_ptr(), Cin * V, x.data_ptr() + 4 * V, Cin * V, packed.data_ptr(),
+                                                         _ptr(b0), _ptr(b1), y1.data_ptr(), y0.data_ptr(), mask0.data_ptr(), B, Cin,
+                                                         D, W, H, mid_layout, out_layout, float(slope0), float(slope1), _stream()),
+                   "lr_conv3d_pair01_train_f32")
+    return y1, y0, mask0
+
+
 def conv3d_first_fused_bp_supported(x0, proj):
     """True when `conv3d_first_fused_bp` can take these tensors (else: backproject + conv3d_first_split)."""
     return (x0.dim() == 5 and proj.dim() == 4 and x0.shape[1] == 1 and proj.shape[1] in (1, 2) and x0.shape[4] % 4 == 0 and

@@ -101,6 +101,36 @@ def test_pair_kernel_is_fp32_accurate(B, Cin, D, W, H, hps):
         assert e_got <= 1.5 * e_nat[0] + 1e-9
 
 
+@pytest.mark.parametrize("B,Cin,D,W,H,hps", [(2, 3, 12, 32, 32, True), (1, 3, 7, 36, 44, True), (1, 2, 6, 40, 24, False),
+                                             (1, 3, 4, 72, 136, True), (1, 3, 9, 34, 28, False)])
+def test_pair_kernel_training_forward_writes_activation_and_mask(B, Cin, D, W, H, hps):
+    """lr_conv3d_pair01_train_f32: the same block-1 output bit for bit, plus block 0's activation (every voxel written exactly
+    once, fp32-accurate against an fp64 convolution) and its sign mask in the layout lr_conv3d_k3_lrelu_mask_f32 writes."""
+    from liftreg_amd import ops
+    x, w0, b0, w1, b1 = _make(B, Cin, D, W, H, 77 * Cin + D + W)
+    out_l = ops.LAYOUT_NDHWC_HPS if (hps and ((H - 1) // 2 + 1) % 2 == 0) else ops.LAYOUT_NDHWC
+    mid_l = ops.LAYOUT_NDHWC_HPS if hps else ops.LAYOUT_NDHWC
+    xd, w0d, b0d, w1d, b1d = (t.to(DEV) for t in (x, w0, b0, w1, b1))
+    want1 = ops.conv3d_pair01(xd[:, 0:1].contiguous(), xd[:, 1:].contiguous(), w0d, b0d, w1d, b1d, out_layout=out_l)
+    y1, y0, m0 = ops.conv3d_pair01_train(xd, w0d, b0d, w1d, b1d, mid_layout=mid_l, out_layout=out_l)
+    assert torch.equal(y1, want1)
+    ref0 = F.leaky_relu(F.conv3d(x.double(), w0.double(), b0.double(), stride=1, padding=1), 0.2)
+    got0 = _to_ncdhw(y0, mid_l).cpu().double()
+    assert torch.isfinite(got0).all()
+    assert float((got0 - ref0).abs().max()) <= 2e-6 * float(ref0.abs().max())
+    # the mask: bit r of byte q of a voxel = "channel 4q + r > 0" of the STORED activation
+    y0p = ops.hps_to_ndhwc(y0) if mid_l == ops.LAYOUT_NDHWC_HPS else y0          # (B,D,W,H,16), plain rows
+    bits = (y0p > 0).view(B, D, W, H, 4, 4).to(torch.uint8)
+    want_m = bits[..., 0] | (bits[..., 1] << 1) | (bits[..., 2] << 2) | (bits[..., 3] << 3)
+    assert torch.equal(m0, want_m)
+    # and against the two-kernel training forward's side outputs (same layout, fp32-close values)
+    if H % 4 == 0 and W * H >= 256:
+        m_nat = torch.empty_like(m0)
+        y_nat = ops.conv3d_k3_lrelu(xd, w0d, b0d, 1, in_layout=ops.LAYOUT_NCDHW, out_layout=mid_l, mask_out=m_nat)
+        torch.testing.assert_close(y0, y_nat, rtol=0, atol=4e-6 * float(ref0.abs().max()))
+        assert (m0 != m_nat).float().mean() < 1e-4        # sign flips only where the activation is ~0
+
+
 def test_pair_kernel_strided_batches_and_slopes():
     """in0 as a z-slab view of a larger volume (batch stride), the output into a strided batch, other slopes, no bias."""
     from liftreg_amd import ops

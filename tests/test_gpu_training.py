@@ -170,7 +170,8 @@ def test_training_step_runs_no_library_compute_kernel(dev):
     text = " ".join(names).lower()
     for forbidden in ("miopen", "cijk_", "hipblaslt", "rocblas", "grid_sampler", "aten::conv", "aten::addmm", "aten::mm"):
         assert forbidden not in text, forbidden
-    ours = ("conv3d_planar_kernel", "conv3d_cl_rows_kernel",   # (small planes: the direct stride-2 kernel)
+    ours = ("conv01_fused_kernel",                              # (blocks 0 + 1 of the forward: the fused pair kernel, training form)
+            "conv3d_cl_rows_kernel",                            # (small planes: the direct stride-2 kernel)
             "conv3d_dgrad", "conv3d_wgrad", "backproject", "pca_warp_kernel",
             "pca_bwd_kernel", "warp_bwd", "ncc_moments_kernel", "ncc_bwd", "linear_kernel", "subspace_reg_kernel")
     missing = [k for k in ours if k not in text]
