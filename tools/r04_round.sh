@@ -43,3 +43,11 @@ for f in sorted(glob.glob(o + "/bench*.json")):
     except Exception as e:
         print(os.path.basename(f), "unreadable", e)
 PY
+# bf16 z-march A/B, training A/B, pipelines (round 4, second half)
+bash tools/ab_bf16_march.sh $TAG/bf16_march > /dev/null 2>&1
+cp "$O/bf16_march/ab.txt" "$O/ab_bf16_march.txt" 2>/dev/null
+bash tools/ab_pair01_train.sh > "$O/ab_pair01_train.txt" 2>&1
+for s in 1 3 1 3; do timeout 300 python3 bench.py --no-cpu-baseline --no-drr --streams $s 2>/dev/null | tail -n 1 | python3 -c "import json,sys; r=json.loads(sys.stdin.read()); print('streams', r['config'].get('streams'), round(r['value'],1), 'reg/s', round(r['ms_per_step'],3), 'ms')" >> "$O/ab_streams.txt"; done
+bash tools/pmc_bench.sh $TAG/pmc_bf16 --conv-dtype bf16 > /dev/null 2>&1
+bash tools/pmc_bench.sh $TAG/pmc_c4_bf16 --config c4 --conv-dtype bf16 > /dev/null 2>&1
+cat "$O/ab_bf16_march.txt" "$O/ab_pair01_train.txt" "$O/ab_streams.txt"
