@@ -498,6 +498,15 @@ int lr_conv3d_first_fused_bp_f32(const float* in0, const float* proj, const floa
 int lr_pca_warp_f32(const float* coefs, const float* basis, const float* mean, const float* img, const float* id0,
                     const float* id1, const float* id2, float* disp, float* phi, float* warped, int B, int L, int C,
                     int D, int W, int H, int64_t ldb, int flags, void* stream);
+/* lr_pca_warp_f32 (single-channel image, fp32 basis, whole volume, B <= 8) through a register-light persistent kernel — one voxel
+ * per thread, 84 registers instead of 213, the same results bit for bit — for a launch on a second stream beside
+ * lr_conv3d_pair01_f32, whose waves leave part of every SIMD's register file free (liftreg_amd/pipeline.py).
+ *   coefs_t : dev (Lp, 8) fp32, the coefficients TRANSPOSED and zero-padded (rows L..Lp-1, columns B..7), Lp = L rounded up to 8
+ *   blocks  : persistent 256-thread blocks (0 = one per CU).  Replaces …Backproj.py:102 + :68-69 like lr_pca_warp_f32. */
+int lr_pca_warp_light_f32(const float* coefs_t, const float* basis, const float* mean, const float* img,
+                          const float* id0, const float* id1, const float* id2, float* disp, float* phi, float* warped,
+                          int B, int L, int D, int W, int H, int64_t ldb, int flags, int blocks, void* stream);
+
 int lr_pca_warp_bf16basis_f32(const float* coefs, const void* basis_bf16, const float* mean, const float* img,
                               const float* id0, const float* id1, const float* id2, float* disp, float* phi,
                               float* warped, int B, int L, int C, int D, int W, int H, int64_t ldb, int flags,

@@ -168,6 +168,22 @@ __device__ unsigned long long g_lr_c01_stamps[8 * 8];
 #define LR_C01_BPRIO 1
 #endif
 
+// max of two fp32 quads as four bare v_max_f32: llvm.maxnum on an MFMA result first canonicalises it (v_max x, x — four more
+// vector instructions per tile in the role whose vector issue is the kernel's limit); operands here are finite
+__device__ __forceinline__ f32x4 max4(const f32x4& a, const f32x4& b) {
+#ifdef LR_C01_MAXNUM   // A/B build: the compiler's maxnum
+  return __builtin_elementwise_max(a, b);
+#endif
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float t;
+    asm("v_max_f32 %0, %1, %2" : "=v"(t) : "v"(a[i]), "v"(b[i]));
+    r[i] = t;
+  }
+  return r;
+}
+
 template <int NC, bool SAVE>
 // LR_C01_NUM_VGPR (build flag): cap the kernel's registers per lane (the attribute counts half of the unified file's total)
 #ifdef LR_C01_NUM_VGPR
@@ -415,14 +431,24 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
         if (!a_epi_g) return;
         if (sl == 0) { E.x = acc; E.y = E.x * d.slope0; }
         else if (sl == 1) {
-          E.x = __builtin_elementwise_max(E.x, E.y);   // = LeakyReLU for 0 <= slope <= 1 (launcher)
-          if constexpr (SAVE)
+          E.x = max4(E.x, E.y);   // = LeakyReLU for 0 <= slope <= 1 (launcher)
+#ifndef LR_C01_SAVE_PARTS
+#define LR_C01_SAVE_PARTS 3   // timing builds: 1 = activation only, 2 = mask only
+#endif
+          if constexpr (SAVE && (LR_C01_SAVE_PARTS & 1))
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, E.x), rs_act, (int)so, zb * dW * dH * 64, 0);
         }
-        else if (SAVE && sl == 3) {   // (the slice's own work follows below)
+        else if (SAVE && (LR_C01_SAVE_PARTS & 2) && sl == 3) {   // (the slice's own work follows below)
           // the four channel quads of a voxel sit in the four 16-lane rows: row/half swaps bring their sign nibbles into row 0,
           // whose lanes store one dword per voxel (conv3d.hip, MASK)
-          const unsigned x = (E.x[0] > 0.0f ? 1u : 0u) | (E.x[1] > 0.0f ? 2u : 0u) | (E.x[2] > 0.0f ? 4u : 0u) | (E.x[3] > 0.0f ? 8u : 0u);
+          // x > 0  <=>  its bit pattern as a signed integer is > 0 (+0, -0 and every negative are <= 0): one v_med3_i32 per value
+          // (inline asm: hipcc turns the min/max form back into v_cmp + v_cndmask with s_nop hazards between them)
+          auto pos = [](float v) __attribute__((always_inline)) -> unsigned {
+            unsigned r;
+            asm("v_med3_i32 %0, %1, 0, 1" : "=v"(r) : "v"(v));
+            return r;
+          };
+          const unsigned x = pos(E.x[0]) | (pos(E.x[1]) << 1) | (pos(E.x[2]) << 2) | (pos(E.x[3]) << 3);
           const auto s1 = __builtin_amdgcn_permlane32_swap(x, x, false, false);
           const unsigned xa = s1[0], xb = s1[1];
           const auto s2 = __builtin_amdgcn_permlane16_swap(xa, xa, false, false);
@@ -688,7 +714,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
           const __amdgpu_buffer_rsrc_t ores = make_rsrc(pbase, oz < 0 ? 0u : (unsigned)(d.Wo * d.Ho * 32 * 4));
           f32x4 v = fin_a + (kq == 2 ? own : fin_b);
           v = (v + (kq == 3 ? own : p3)) + bv;
-          v = __builtin_elementwise_max(v, v * d.slope1);
+          v = max4(v, v * d.slope1);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ores, (int)ooff, 0, 0);
         }
       };

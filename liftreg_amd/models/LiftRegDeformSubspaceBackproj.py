@@ -450,11 +450,16 @@ class model(nn.Module):
             x = self.encoders[i](x, packed=self._packed_weight(i))
         return self.encoders[6](x)
 
-    def decode(self, moving, coefs, moving_seg=None, target=None):
+    def decode(self, moving, coefs, moving_seg=None, target=None, light=False):
         """HBM-bound half: PCA reconstruction → identity add + trilinear warp.  Returns (disp, phi, warped).
         `target` (inference, single-channel, opt key fuse_ncc): the similarity's five moments of (warped, target) are
-        accumulated in the same pass and returned as a 4th value → output key "ncc_moments" (SURVEY §8 f1)."""
+        accumulated in the same pass and returned as a 4th value → output key "ncc_moments" (SURVEY §8 f1).
+        `light`: the register-light persistent kernel (same bits) — for a launch beside the next batch's pair kernel
+        (tools/light_decode_probe.py); falls back to the regular kernel where it does not apply."""
         B, C, D, W, H = moving.shape
+        if (light and moving_seg is None and not (torch.is_grad_enabled() and coefs.requires_grad) and
+                ops.pca_warp_light_supported(coefs, self.pca_vectors_LxM, moving)):
+            return ops.pca_warp_light(coefs, self.pca_vectors_LxM, self.pca_mean, (self._id0, self._id1, self._id2), moving)
         if (moving_seg is None and not (torch.is_grad_enabled() and coefs.requires_grad) and
                 ops.pca_warp_supported(coefs, self.pca_vectors_LxM, moving)):
             # inference: one pass writes params, phi and warped (SURVEY §8 f1) — the same bits as the two kernels below

@@ -786,6 +786,37 @@ def pca_warp_supported(coefs, basis_LxM, img, d0=0, d1=None):
             coefs.shape[0] == B)
 
 
+def pca_warp_light_supported(coefs, basis_LxM, img):
+    B, C, D, W, H = img.shape
+    return (C == 1 and B <= 8 and basis_LxM.dtype == torch.float32 and basis_LxM.shape[1] == 3 * D * W * H and
+            pca_warp_supported(coefs, basis_LxM, img) and 8 * basis_LxM.stride(0) * 4 + 12 * D * W * H < 2 ** 31)
+
+
+def pca_warp_light(coefs, basis_LxM, mean, ids, img, *, using_scale=True, blocks=0):
+    """`pca_warp` through the register-light persistent kernel (lr_pca_warp_light_f32; same bits): for a launch on a second
+    stream beside the fused pair kernel (tools/light_decode_probe.py).  Single-channel image, fp32 basis, B <= 8."""
+    coefs, mean, img = _dev(coefs, "coefs"), _dev(mean, "mean"), _dev(img, "img")
+    if not pca_warp_light_supported(coefs, basis_LxM, img):
+        raise ValueError("pca_warp_light: unsupported shapes (use pca_warp)")
+    B, C, D, W, H = img.shape
+    L = basis_LxM.shape[0]
+    Lp = (L + 7) // 8 * 8
+    ct = torch.zeros((Lp, 8), dtype=torch.float32, device=img.device)
+    ct[:L, :B] = coefs.t()
+    i0, i1, i2 = (_dev(t, "id table") for t in ids)
+    disp = torch.empty((B, 3, D, W, H), dtype=torch.float32, device=img.device)
+    phi = torch.empty_like(disp)
+    warped = torch.empty((B, 1, D, W, H), dtype=torch.float32, device=img.device)
+    V = D * W * H
+    with _timed("pca_warp_light", bytes=4 * L * 3 * V + 4 * 3 * V + B * 4 * V * 8, samples=B):
+        _hip.check(_hip.lib().lr_pca_warp_light_f32(ct.data_ptr(), basis_LxM.data_ptr(), mean.data_ptr(), img.data_ptr(),
+                                                    i0.data_ptr(), i1.data_ptr(), i2.data_ptr(), disp.data_ptr(), phi.data_ptr(),
+                                                    warped.data_ptr(), B, L, D, W, H, basis_LxM.stride(0),
+                                                    _hip.WARP_USING_SCALE if using_scale else 0, int(blocks), _stream()),
+                   "lr_pca_warp_light_f32")
+    return disp, phi, warped
+
+
 def pca_warp(coefs, basis_LxM, mean, ids, img, *, using_scale=True, d0=0, d1=None, target=None):
     """disp = coefs·basis + mean ; phi = disp + identity ; warped = Bilinear(img, phi) in ONE kernel:
     the displacement field is written once and never read back.  Returns (disp, phi, warped), bit-identical to

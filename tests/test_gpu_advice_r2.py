@@ -173,6 +173,26 @@ def test_shadow_registrar_equals_the_plain_forward(dev, labels):
         assert torch.equal(c, gc) and torch.equal(p, gp) and torch.equal(w, gw) and abs(l - float(gl)) < 1e-6
 
 
+@pytest.mark.parametrize("B,n,L", [(2, 32, 6), (8, 48, 11), (3, 40, 16)])
+def test_pca_warp_light_kernel_same_bits(dev, B, n, L):
+    """lr_pca_warp_light_f32 (one voxel per thread, persistent grid, coefficients as scalars, packed FMAs): the bits of the
+    one-pass decode lr_pca_warp_f32 — disp, phi and warped — for every batch size up to 8 and a latent size that is not a
+    multiple of its 8-row chunks."""
+    from liftreg_amd import ops
+    net = _net(dev, n=n, L=L)
+    b = _batch(dev, n=n, B=B, seed=B + n)
+    with torch.no_grad():
+        coefs = net.encode(b["source"], b["target_proj"], b["target_poses"])
+        ids = (net._id0, net._id1, net._id2)
+        want = ops.pca_warp(coefs, net.pca_vectors_LxM, net.pca_mean, ids, b["source"])
+        for blocks in (0, 3):
+            got = ops.pca_warp_light(coefs, net.pca_vectors_LxM, net.pca_mean, ids, b["source"], blocks=blocks)
+            for w, g in zip(want, got):
+                assert torch.equal(w, g)
+        got = net.decode(b["source"], coefs, light=True)
+        assert all(torch.equal(w, g) for w, g in zip(want, got))
+
+
 def test_backproject_light_kernel_same_bits(dev):
     from liftreg_amd import ops
     from liftreg_amd.utils.sdct_projection_utils import scan_poses
