@@ -51,7 +51,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 constexpr int NTHR = 512;
 constexpr int TY = 4, TX = 8;            // block-1 outputs of a column (rows x voxels)
 constexpr int R1Y = 2 * TY + 1;          // 9 rows of block 0's output a plane of the column needs
-constexpr int R1X = 2 * TX + 1;          // 17 voxels
 constexpr int R0Y = R1Y + 2;             // 11 input rows
 constexpr int NQ0 = 6;                   // aligned float4 quads of an input row: x = 2*ox0 - 4 .. 2*ox0 + 19 (record p = x - (2*ox0 - 4))
 constexpr int SB0 = NQ0 * 4 * 8;         // 192 bytes: one split of a ring-0 row
@@ -72,7 +71,7 @@ constexpr int DUMP_OFF = SCR_OFF + SCR;  // 125120: where the threads without a 
 constexpr int DUMPB = 64 * 16 + 2 * SB0 + 32;   // a 16-byte lane stride: the lanes without an item never write one address
 constexpr int LDSB = DUMP_OFF + ((DUMPB + 255) / 256) * 256;
 constexpr int NITEM = 2 * R0Y * NQ0;     // 132 staging items of a step: (plane, row, x-quad), all channels
-constexpr int NKB0 = 4, NKB1 = 4;   // k-blocks of block 0 | of a K quarter of block 1 (taps 0..7 | 8..15 | 16..21 | 22..26)
+constexpr int NKB1 = 4;   // k-blocks of block 0 | of a K quarter of block 1 (taps 0..7 | 8..15 | 16..21 | 22..26)
 constexpr unsigned OOR = 0x80000000u;
 static_assert(NITEM <= 3 * 44 && 4 * R0Y * NQ0 <= NTHR, "one staging item per thread");
 static_assert(4 * QS1 <= RS1 && (QS1 & 1) == 1 && (RS1 & 15) == 8, "ring-1 bank geometry");
@@ -307,7 +306,6 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
     // staging items of a step: B waves 1..3 take 44 each (wave 0 = K quarter 0 has the most MFMAs and none)
     const int bi = (wq - 1) * 44 + lane;
     const bool item_live = !is_a && wq >= 1 && lane < 44;
-    const bool wave_stages = !is_a && wq >= 1;   // wave-uniform
     const int ipl = item_live ? bi / (R0Y * NQ0) : 0, irow = item_live ? (bi % (R0Y * NQ0)) / NQ0 : 0, iq = item_live ? bi % NQ0 : 0;
     u32x4 ldn[NC];
     __syncthreads();   // (the zero fill of the whole LDS | every read of the unit before)
@@ -579,7 +577,6 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
   for (int uid = first; uid < end; uid += stride) {
     const int utx = uid % d.nTx, uty = (uid / d.nTx) % d.nTy, ub = __builtin_amdgcn_readfirstlane(uid / d.nTx / d.nTy);
     const int oy0 = __builtin_amdgcn_readfirstlane(uty * TY), ox0 = __builtin_amdgcn_readfirstlane(utx * TX);
-    const int Y1 = 2 * oy0 - 1, X1 = 2 * ox0 - 1;       // volume coordinates of region-1 (0, 0)
     const int Y0 = 2 * oy0 - 2, X0a = 2 * ox0 - 4;      // volume coordinates of ring-0 row 0 / record 0
     const __amdgpu_buffer_rsrc_t r0 = make_rsrc(in0 + (int64_t)ub * d.bs0, V4);
     const __amdgpu_buffer_rsrc_t rr = make_rsrc(in_rest + (int64_t)ub * d.bsr, NC > 1 ? (unsigned)(NC - 1) * V4 : 0u);
