@@ -138,7 +138,7 @@ class ShadowRegistrar:
         with torch.cuda.stream(self.side_bp):
             if self._enc_start is not None:
                 self.side_bp.wait_event(self._enc_start)     # one batch ahead, not more (and buffer `slot` is free again:
-                if self.head_start:
+                if self.head_start and hasattr(torch.cuda, "_sleep"):
                     torch.cuda._sleep(self.head_start)       # let the pair kernel's 256 blocks take their CUs first
             if self._tv[slot] is None or tuple(self._tv[slot].shape) != (B, P, D, W, H):   # its reader finished before that event)
                 self._tv[slot] = torch.empty((B, P, D, W, H), dtype=torch.float32, device=moving.device)
@@ -162,7 +162,7 @@ class ShadowRegistrar:
                 t.record_stream(self.side_ncc)
             with torch.cuda.stream(self.side_ncc):
                 self.side_ncc.wait_event(dec_done)
-                if self.head_start:
+                if self.head_start and hasattr(torch.cuda, "_sleep"):
                     torch.cuda._sleep(self.head_start)
                 loss = self.sim(warped, target_cp, moments=mom[0]) if mom else self.sim(warped, target_cp)
         out = {"warped": warped, "phi": phi, "params": disp, "target": target_cp, "pca_coefs": coefs,
