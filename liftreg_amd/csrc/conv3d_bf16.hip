@@ -348,17 +348,21 @@ __global__ __launch_bounds__(256, 3) void conv3d_cl_rows_bf16_kernel(const u16* 
 //   2(w>>1), 2(w>>1)+1; K order = the packing's tap pairs (2kb, 2kb+1), fp32 accumulation on top of the bias.
 // One barrier per step: step oz reads planes 2oz-1..2oz+1 (slots k, k+1, k+2) and fills planes 2oz+2, 2oz+3
 // (slots k+3, k+4) after its MFMAs.
-constexpr int MZ_TY = 4, MZ_TX = 16;
-constexpr int MZ_RY = 2 * MZ_TY + 1, MZ_NO = MZ_TX + 1, MZ_NE = MZ_TX;
-constexpr int MZ_ROWB = (MZ_NO + MZ_NE) * 32, MZ_PLB = MZ_RY * MZ_ROWB, MZ_NCH = MZ_PLB / 16;  // 1056, 9504, 594
-constexpr int MZ_NSLOT = 5, MZ_NIT = (2 * MZ_NCH + 255) / 256;                                  // 5 chunks per thread and step
-constexpr int MZ_DUMP = MZ_NSLOT * MZ_PLB, MZ_LDSB = MZ_DUMP + (MZ_NIT * 256 - 2 * MZ_NCH) * 16;
-static_assert(MZ_NIT == 5 && 2 * 256 < MZ_NCH && 3 * 256 >= MZ_NCH && 4 * 256 < 2 * MZ_NCH, "item -> plane map below");
+constexpr int MZ_TX = 16, MZ_NO = MZ_TX + 1, MZ_NE = MZ_TX, MZ_ROWB = (MZ_NO + MZ_NE) * 32, MZ_NSLOT = 5;   // row: 1056 bytes
+template <int TY>   // output rows of a column: 4 (256 threads, 3 blocks per CU) | 8 (512 threads, one block per CU: half the row halo)
+struct MZ {
+  static constexpr int NTHR = 64 * TY, RY = 2 * TY + 1, PLB = RY * MZ_ROWB, NCH = PLB / 16;   // TY = 4: 9504 bytes, 594 chunks
+  static constexpr int NIT = (2 * NCH + NTHR - 1) / NTHR;                                      // 16-byte chunks per thread and step
+  static constexpr int DUMP = MZ_NSLOT * PLB, LDSB = DUMP + (NIT * NTHR - 2 * NCH) * 16;
+};
 
-__global__ __launch_bounds__(256, 3) void conv3d_march_s2_bf16_kernel(const u16* __restrict__ in, const u32x4* __restrict__ wp,
+template <int TY>
+__global__ __launch_bounds__(64 * TY, TY == 4 ? 3 : 1) void conv3d_march_s2_bf16_kernel(const u16* __restrict__ in, const u32x4* __restrict__ wp,
                                                                       const float* __restrict__ bias, void* __restrict__ out,
                                                                       ConvDimsH d, int zc, int out_layout, float slope) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[MZ_LDSB];
+  using G = MZ<TY>;
+  constexpr int MZ_NIT = G::NIT, MZ_NCH = G::NCH, MZ_PLB = G::PLB, MZ_DUMP = G::DUMP, NTHR = G::NTHR;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDSB];
   const unsigned lb = lr_xcd_remap(blockIdx.x, gridDim.x);
   const int hq = lb % d.nHq, wq = (lb / d.nHq) % d.nWq, dq = (lb / d.nHq / d.nWq) % d.nDq;
   const int b = lb / d.nHq / d.nWq / d.nDq;
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(256, 3) void conv3d_march_s2_bf16_kernel(const u16*
   const int nt = wave & 1, mp = wave >> 1;
   const int dD = __builtin_amdgcn_readfirstlane(d.D), dW = __builtin_amdgcn_readfirstlane(d.W),
             dH = __builtin_amdgcn_readfirstlane(d.H);
-  const int ox0 = hq * MZ_TX, oy0 = wq * MZ_TY, oz0 = dq * zc;
+  const int ox0 = hq * MZ_TX, oy0 = wq * TY, oz0 = dq * zc;
   const int oz1 = min(oz0 + zc, d.Do);
   const int half_h = dH >> 1;
   const unsigned plane_b = (unsigned)dW * (unsigned)dH * 32u;
@@ -403,15 +407,15 @@ __global__ __launch_bounds__(256, 3) void conv3d_march_s2_bf16_kernel(const u16*
     toff[kb] = ((kq >> 1) ? tap_off(Tb) : tap_off(Ta)) + (unsigned)(4 * mp * MZ_ROWB + col * 32 + (kq & 1) * 16);
   }
 
-  // staging items: chunk c = tid + 256 j of the 2 x 594 16-byte chunks of a plane pair (j = 0,1: plane 0; 2: both; 3,4: plane 1)
+  // staging items: chunk c = tid + NTHR j of the 2 x NCH 16-byte chunks of a plane pair
   unsigned goff[MZ_NIT], loff[MZ_NIT];
   bool p2 = false;
 #pragma unroll
   for (int j = 0; j < MZ_NIT; ++j) {
-    const int c = tid + 256 * j;
+    const int c = tid + NTHR * j;
     const bool live = c < 2 * MZ_NCH;
     const int p = c >= MZ_NCH ? 1 : 0;
-    if (j == 2) p2 = p != 0;
+    if (NTHR * j < MZ_NCH && NTHR * (j + 1) > MZ_NCH) p2 = p != 0;   // the one item that straddles the two planes
     const int ci = c - p * MZ_NCH;
     const int row = ci / (2 * (MZ_NO + MZ_NE)), cc = ci - row * 2 * (MZ_NO + MZ_NE);
     const bool odd = cc < 2 * MZ_NO;
@@ -433,8 +437,9 @@ __global__ __launch_bounds__(256, 3) void conv3d_march_s2_bf16_kernel(const u16*
   auto stage_write = [&](unsigned s0b, unsigned s1b) {  // LDS bases of the two planes' slots
 #pragma unroll
     for (int j = 0; j < MZ_NIT; ++j) {
-      const bool live = tid + 256 * j < 2 * MZ_NCH;
-      const unsigned sb = j < 2 ? s0b : j == 2 ? (p2 ? s1b : s0b) : (live ? s1b : 0u);
+      const bool live = tid + NTHR * j < 2 * MZ_NCH;
+      // item j covers chunks [NTHR j, NTHR (j + 1)): all of plane 0 | straddling the planes (one item) | plane 1 (the last one partly dead)
+      const unsigned sb = NTHR * (j + 1) <= MZ_NCH ? s0b : NTHR * j < MZ_NCH ? (p2 ? s1b : s0b) : (live ? s1b : 0u);
       *reinterpret_cast<u32x4*>(lds + sb + loff[j]) = st[j];
     }
   };
@@ -1198,7 +1203,8 @@ static int conv_bf16_impl(const void* in, const void* packed_w, const float* bia
   const int NT = Cout / 16;
   // 32 couts on parity-split rows: the z-marching kernels (LIFTREG_BF16_NO_MARCH: the row kernel)
   if (rows && NT == 2 && !lr_sw_on(LR_SW_BF16_NO_MARCH) && (int64_t)(D + 4) * W * H * Cin * 2 < 0x7fffffffLL) {
-    const int mty = Cin == 16 ? MZ_TY : M3_TY, mtx = Cin == 16 ? MZ_TX : M3_TX;
+    const bool ty8 = Cin == 16 && lr_sw_on(LR_SW_BF16_MARCH_TY8);
+    const int mty = Cin == 16 ? (ty8 ? 8 : 4) : M3_TY, mtx = Cin == 16 ? MZ_TX : M3_TX;
     const int nTy = (d.Wo + mty - 1) / mty, nTx = (d.Ho + mtx - 1) / mtx;
     // columns are serial walks: below ~one column per CU the row kernel's many small blocks win (measured: 32^3 and 16^3 inputs
     // at B = 8).  The rule looks at the plane and the batch only, never at D: a z-slab of a volume takes the same kernel as
@@ -1215,7 +1221,8 @@ static int conv_bf16_impl(const void* in, const void* packed_w, const float* bia
       d.nHq = nTx; d.nWq = nTy; d.nDq = (d.Do + zc - 1) / zc;
       const int64_t nb = (int64_t)B * d.nDq * d.nWq * d.nHq;
       if (nb > 0x7fffffffLL) return LR_EINVAL;
-      if (Cin == 16) hipLaunchKernelGGL(conv3d_march_s2_bf16_kernel, dim3((unsigned)nb), block, 0, st, x, wt, bias, out, d, zc, out_layout, negative_slope);
+      if (Cin == 16 && ty8) hipLaunchKernelGGL(conv3d_march_s2_bf16_kernel<8>, dim3((unsigned)nb), dim3(512), 0, st, x, wt, bias, out, d, zc, out_layout, negative_slope);
+      else if (Cin == 16) hipLaunchKernelGGL(conv3d_march_s2_bf16_kernel<4>, dim3((unsigned)nb), block, 0, st, x, wt, bias, out, d, zc, out_layout, negative_slope);
       else hipLaunchKernelGGL(conv3d_march_s2_c32_bf16_kernel, dim3((unsigned)nb), block, 0, st, x, wt, bias, out, d, zc, out_layout, negative_slope);
       return lr_launch_status();
     }

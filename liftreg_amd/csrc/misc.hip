@@ -50,6 +50,7 @@ const char* const kSwitchNames[LR_SW_COUNT] = {
     "LIFTREG_BF16_MT",
     "LIFTREG_PAIR01_BLOCKS",
     "LIFTREG_BF16_NO_MARCH",
+    "LIFTREG_BF16_MARCH_TY8",
     "LIFTREG_BF16_MARCH_ZC",
     "LIFTREG_DGRAD_BLOCKS",
     "LIFTREG_FUSED_BWD_BLOCKS",

@@ -65,7 +65,7 @@ def test_bf16_blocks_all_layouts(dev):
             _close_bf16(y.float().permute(0, 4, 1, 2, 3).cpu().numpy(), want.numpy(), tag)
 
 
-@pytest.mark.parametrize("cin", [16, 32])
+@pytest.mark.parametrize("cin", [16, 32, "16-ty8"])
 @pytest.mark.parametrize("zc", [None, 1, 3])
 def test_bf16_z_march_vs_oracle_and_row_kernel(dev, zc, cin, monkeypatch):
     """The 16->32 and 32->32 blocks on parity-split rows run as z-marching kernels (conv3d_bf16.hip: conv3d_march_s2_*):
@@ -74,6 +74,9 @@ def test_bf16_z_march_vs_oracle_and_row_kernel(dev, zc, cin, monkeypatch):
     from liftreg_amd import ops
     L = ops
     rs = np.random.RandomState(77)
+    if cin == "16-ty8":      # the 8 x 16-output columns (512 threads, one block per CU: LIFTREG_BF16_MARCH_TY8)
+        cin = 16
+        monkeypatch.setenv("LIFTREG_BF16_MARCH_TY8", "1")
     if zc is not None:
         monkeypatch.setenv("LIFTREG_BF16_MARCH_ZC", str(zc))
     cases = [  # shape (D, W, H), B, out_layout
