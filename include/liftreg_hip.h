@@ -91,6 +91,13 @@ const char* lr_target_arch(void);
 int lr_reload_switches(void);
 const char* lr_switch_name(int id);
 
+/* A HIP stream restricted to the compute units of `mask` (nwords 32-bit words, bit i = CU i; consecutive bits go round-robin over
+ * the XCDs, so a contiguous range is spread evenly over the dies): hipExtStreamCreateWithCUMask through the runtime this library is
+ * bound to.  For CU-partitioned pipelines (liftreg_amd/pipeline.py: TwoStreamRegistrar(decode_cus=…); measured not to pay,
+ * profiles/NOTES_r04.md).  lr_stream_destroy releases it. */
+int lr_stream_create_cu_mask(const uint32_t* mask, int nwords, void** stream_out);
+int lr_stream_destroy(void* stream);
+
 /* ------------------------------------------------------------------------
  * K1  DRR cone-beam forward projector.
  * Replaces project_grid_multi + F.grid_sample(3D) + sum + *dx*0.1:

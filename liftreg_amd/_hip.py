@@ -60,6 +60,8 @@ SIGNATURES = {
     "lr_conv3d_pair01_slab_f32": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _i64, _i, _i, _i, _i, _p]),
     "lr_conv3d_first_fused_bp_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "lr_pca_warp_f32": (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _i, _i64, _i, _p]),
+    "lr_stream_create_cu_mask": (_i, [_p, _i, _p]),
+    "lr_stream_destroy": (_i, [_p]),
     "lr_pca_warp_light_f32": (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _i64, _i, _i, _p]),
     "lr_pca_warp_bf16basis_f32": (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _i, _i64, _i, _p]),
     "lr_pca_warp_slab_f32": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i,

@@ -11,10 +11,11 @@ import torch
 
 
 def _masked_stream(dev, cus, ncu):
-    """A HIP stream whose kernels run only on the compute units `cus` (hipExtStreamCreateWithCUMask; bit i of the mask = CU i,
-    and the driver deals consecutive bits round-robin over the XCDs, so a contiguous range is spread evenly over the 8 dies)."""
+    """A HIP stream whose kernels run only on the compute units `cus` (lr_stream_create_cu_mask: hipExtStreamCreateWithCUMask
+    through the runtime the library is bound to; bit i of the mask = CU i, and the driver deals consecutive bits round-robin over
+    the XCDs, so a contiguous range is spread evenly over the 8 dies).  The stream lives as long as the process."""
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
+    from . import _hip
     nw = (ncu + 31) // 32
     words = [0] * nw
     for c in cus:
@@ -22,9 +23,8 @@ def _masked_stream(dev, cus, ncu):
     arr = (ctypes.c_uint32 * nw)(*words)
     st = ctypes.c_void_p()
     with torch.cuda.device(dev):
-        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(nw), arr)
-    if rc != 0 or not st.value:
-        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+        _hip.check(_hip.lib().lr_stream_create_cu_mask(ctypes.cast(arr, ctypes.c_void_p), nw, ctypes.cast(ctypes.byref(st), ctypes.c_void_p)),
+                   "lr_stream_create_cu_mask")
     return torch.cuda.ExternalStream(st.value, device=dev)
 
 
