@@ -754,6 +754,8 @@ extern "C" int lr_pca_warp_light_f32(const float* coefs_t, const float* basis, c
   const int64_t sD = (int64_t)W * H, V = sD * D;
   if (B > 8 || L > 2048 || ldb < 3 * V) return LR_EUNSUPPORTED;
   if (!(V * 4 + sD * 4 <= 0x80000000LL && sD < (1 << 23) && D <= 65535)) return LR_EUNSUPPORTED;
+  // the kernel addresses LR_PWL_U basis rows through ONE buffer resource with 31-bit scalar offsets
+  if (((int64_t)(LR_PWL_U - 1) * ldb + 3 * V) * 4 >= 0x7fffffffLL) return LR_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(coefs_t) & 31u) || ((reinterpret_cast<uintptr_t>(basis) | reinterpret_cast<uintptr_t>(mean) |
        reinterpret_cast<uintptr_t>(disp) | reinterpret_cast<uintptr_t>(phi) | reinterpret_cast<uintptr_t>(warped)) & 3u))
     return LR_EALIGN;
