@@ -81,6 +81,7 @@ const char* lr_target_arch(void);
  *   LIFTREG_CONV_ROWS_XMAP         0: plain strided tile order instead of the XCD-aware one
  *   LIFTREG_BF16_MT                output rows per tile of the bf16 row kernels (4 | 8)
  *   LIFTREG_PAIR01_BLOCKS          persistent blocks of the fused pair kernel (default: one per CU)
+ *   LIFTREG_PAIR01_DENSE           0: three-channel pair kernel with block 0's padded K (24 MFMAs per tile) instead of the dense 17 (A/B aid)
  *   LIFTREG_BF16_NO_MARCH          bf16 16->32 block: the row kernel instead of the z-marching one (A/B aid)
  *   LIFTREG_BF16_MARCH_TY8         bf16 16->32 z-march: columns of 8 x 16 outputs (512 threads, one block per CU; A/B aid)
  *   LIFTREG_BF16_MARCH_ZC          output planes per z chunk of the bf16 z-marching kernel (tests: chunk boundaries)

@@ -38,6 +38,7 @@
 //   src/liftreg/models/LiftRegDeformSubspaceBackproj.py:95-100 for encoders[0] and encoders[1].
 #include "lr_common.h"
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -56,8 +57,10 @@ constexpr int NQ0 = 6;                   // aligned float4 quads of an input row
 constexpr int SB0 = NQ0 * 4 * 8;         // 192 bytes: one split of a ring-0 row
 constexpr int RB0 = 3 * SB0;             // 576 = 64 mod 128: the k-block-3 lane pairs (two window rows apart) use opposite bank halves
 constexpr int PLB0 = R0Y * RB0 + 192;    // 6528 = 128 mod 256: neighbouring planes use opposite bank halves
-constexpr int NRING0 = 6;                // A reads planes 2s-1 .. 2s+2 while B writes 2s+3, 2s+4
-constexpr int RING0 = NRING0 * PLB0;     // 39168
+constexpr int NRING0 = 8;                // A reads planes 2s-1 .. 2s+2 (and, ahead of the barrier, its first fragments of step s+1: .. 2s+3) while B writes 2s+5, 2s+6
+constexpr int PA0 = NRING0 - 6;          // planes the staging runs ahead of what the next step reads
+constexpr int NPRO0 = 4 + PA0;           // planes the unit prologue stages
+constexpr int RING0 = NRING0 * PLB0;     // 52224
 constexpr int QS1 = 17;                  // 8-byte chunks between the channel-quad runs of a ring-1 row (odd)
 constexpr int RS1 = 72;                  // chunks of a ring-1 row (= 8 mod 16)
 constexpr int SPB1 = R1Y * RS1 * 8;      // 5184 bytes: one split of a ring-1 plane
@@ -66,14 +69,14 @@ constexpr int NRING1 = 5;                // B reads planes 2s-3 .. 2s-1 while A 
 constexpr int RING1_OFF = RING0;
 constexpr int RING1 = NRING1 * PLB1;     // 77760
 constexpr int SCR_OFF = RING1_OFF + RING1;   // 116928
-constexpr int SCR = 2 * 4 * 4 * 64 * 16; // 32768: [step parity][B wave = K quarter][accumulator (tile, cout tile)][lane] partial sums
+constexpr int SCR = 2 * 4 * 3 * 64 * 16; // 24576: [step parity][B wave = K quarter][the three accumulators (tile, cout tile) it does not own][lane] partial sums
 constexpr int DUMP_OFF = SCR_OFF + SCR;  // 125120: where the threads without a staging item write
 constexpr int DUMPB = 64 * 16 + 2 * SB0 + 32;   // a 16-byte lane stride: the lanes without an item never write one address
 constexpr int LDSB = DUMP_OFF + ((DUMPB + 255) / 256) * 256;
 constexpr int NITEM = 2 * R0Y * NQ0;     // 132 staging items of a step: (plane, row, x-quad), all channels
 constexpr int NKB1 = 4;   // k-blocks of block 0 | of a K quarter of block 1 (taps 0..7 | 8..15 | 16..21 | 22..26)
 constexpr unsigned OOR = 0x80000000u;
-static_assert(NITEM <= 3 * 44 && 4 * R0Y * NQ0 <= NTHR, "one staging item per thread");
+static_assert(NITEM <= 3 * 44 && NPRO0 * R0Y * NQ0 <= NTHR, "one staging item per thread");
 static_assert(4 * QS1 <= RS1 && (QS1 & 1) == 1 && (RS1 & 15) == 8, "ring-1 bank geometry");
 static_assert((PLB0 & 255) == 128 && (RB0 & 127) == 64, "ring-0 bank geometry");
 static_assert(LDSB <= 160 * 1024, "LDS");
@@ -183,7 +186,66 @@ __device__ __forceinline__ f32x4 max4(const f32x4& a, const f32x4& b) {
   return r;
 }
 
-template <int NC, bool SAVE>
+// ---- DENSE block 0 (three input channels): K without padding.  A voxel's nine bf16 (3 channels x 3 splits d0, d1, d2) are laid
+// out as three 8-byte records (in the place of the three per-split records, same LDS footprint)
+//   E = [d0c0 d0c1 d0c2 d1c0]   F = [d1c1 d1c2 d2c0 d2c1]   G = [d2c2 d1c1 d1c2 0]
+// and a tap contributes FIVE record slots to K instead of six (six products x (3 channels + 1 pad)):
+//   E x [w0c0 w0c1 w0c2 w0c0]   (w0 d0 x3, w0 d1 c0)        E x [w1c0 w1c1 w1c2 w1c0]   (w1 d0 x3, w1 d1 c0)
+//   E x [w2c0 w2c1 w2c2 0]      (w2 d0 x3)                  F x [w0c1 w0c2 w0c0 w0c1]   (w0 d1 c1 c2, w0 d2 c0 c1)
+//   G x [w0c2 w1c1 w1c2 0]      (w0 d2 c2, w1 d1 c1 c2)
+// = the same 18 exact products per tap.  27 taps x 5 = 135 record slots = 17 MFMAs of 8 slots per 16-voxel tile (24 before):
+// per tap row ty, the 8 taps (tz, ty, tx) without (2, ty, 2) form one data fragment per record kind, used with three (E) or
+// one (F, G) weight fragments = 15 MFMAs whose fragments two vertically adjacent tiles SHARE (input row iy is tap row iy of
+// the upper and iy - 1 of the lower tile); the three taps (2, ty, 2) x 5 slots fill two more MFMAs.  A tile's chain runs from
+// the small products to the large: G, E x w2, F, E x w1, the two leftover MFMAs, E x w0.
+__device__ __forceinline__ void dense_records(const unsigned (&p01)[3], const unsigned (&p2)[3], unsigned (&rec)[3][2]) {
+  rec[0][0] = p01[0];
+  rec[0][1] = p2[0] | (p01[1] << 16);
+  rec[1][0] = __builtin_amdgcn_alignbit(p2[1], p01[1], 16);
+  rec[1][1] = p01[2];
+  rec[2][0] = (p01[1] & 0xffff0000u) | p2[2];
+  rec[2][1] = p2[1];
+}
+constexpr int ND0 = 17;   // MFMAs (= weight fragments) of a dense block-0 tile, in chain order: WG[3] WE2[3] WF[3] WE1[3] WL[2] WE0[3]
+// leftover slot s = 0..14 (two MFMAs x 8 slots; 15: weight 0): tap (2, s / 5, 2), kind s % 5 = E x w0, E x w1, E x w2, F, G
+constexpr int dense_left_ty(int s) { return (s > 14 ? 14 : s) / 5; }
+constexpr int dense_left_arr(int s) { return (s > 14 ? 14 : s) % 5 < 3 ? 0 : (s > 14 ? 14 : s) % 5 - 2; }   // record array: E 0, F 1, G 2
+// the fragment loads of a step of the dense producer, in the order of their first use.  Fragment n of a pair of tiles:
+// 0..8 = G, E, F of input rows 0..2 (n / 3 = kind, n % 3 = row), 9, 10 = the upper tile's leftover fragments, 11..13 = G, E, F of
+// input row 3, 14, 15 = the lower tile's leftover fragments; the single tile has fragments 0..10.  MFMA slot g = 17 t + k of the
+// step (tiles t = 0..4) issues at most one fragment load: the next one whose first use is <= 8 slots away (LDS latency under
+// load; lgkmcnt counts 15 operations = 7 fragments in flight).  Fragments 0..5 of the first pair are requested in front.
+constexpr int dense_need(int set, int n) {   // the slot of the first MFMA that reads fragment n of set (0, 1 = the pairs, 2 = the single tile)
+  const int base = set * 34;
+  if (n < 3) return base + n;            // G rows 0..2: MFMAs 0..2 of the upper tile
+  if (n < 6) return base + 3 + (n - 3);  // E
+  if (n < 9) return base + 6 + (n - 6);  // F
+  if (n < 11) return base + 12 + (n - 9);
+  if (n == 11) return base + 17 + 2;     // G row 3: MFMA 2 of the lower tile
+  if (n == 12) return base + 17 + 5;
+  if (n == 13) return base + 17 + 8;
+  return base + 17 + 12 + (n - 14);
+}
+constexpr int DENSE_PRE = 6, DENSE_AHEAD = 8;
+constexpr int dense_load_at(int g) {   // -1 | set * 16 + n: the fragment load issued behind MFMA slot g
+  int set = 0, n = DENSE_PRE;
+  for (int s = 0; s <= g; ++s) {
+    if (set > 2) return -1;
+    const bool go = dense_need(set, n) - s <= DENSE_AHEAD;
+    if (s == g) return go ? set * 16 + n : -1;
+    if (go) {
+      ++n;
+      if (n == (set == 2 ? 11 : 16)) { n = 0; ++set; }
+    }
+  }
+  return -1;
+}
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <int NC, bool SAVE, bool DENSE>
 // LR_C01_NUM_VGPR (build flag): cap the kernel's registers per lane (the attribute counts half of the unified file's total)
 #ifdef LR_C01_NUM_VGPR
 #define LR_C01_VGPR_CAP __attribute__((amdgpu_num_vgpr(LR_C01_NUM_VGPR / 2)))
@@ -212,7 +274,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
   // zero everything once: a "weight 0" operand slot multiplies whatever lies behind a row / plane and needs finite numbers
   for (int o = tid * 16; o < LDSB; o += NTHR * 16) *reinterpret_cast<u32x4*>(lds + o) = (u32x4){0u, 0u, 0u, 0u};
 
-  // ---- stationary operands: ONE register array for both roles — A: the 12 fragments [k-block][split] of block 0,
+  // ---- stationary operands: ONE register array for both roles — A: the 12 fragments [k-block][split] of block 0 (DENSE: its 17),
   // B (cout tile c, K half kh): the 21 fragments [k-block][split] of its half of block 1
   const int kq = wq;                                        // B: K quarter; it also owns accumulator kq = (tile kq >> 1, cout tile kq & 1)
   const int tap0 = kq == 0 ? 0 : kq == 1 ? 8 : kq == 2 ? 16 : 22, tap1 = kq == 0 ? 8 : kq == 1 ? 16 : kq == 2 ? 22 : 27;
@@ -222,7 +284,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
   {
     const u32x4* src = is_a ? wp0 : wp1 + (size_t)kq * 24 * 64;
 #pragma unroll
-    for (int i = 0; i < 24; ++i) wr[i] = (is_a && i >= 12) ? (u32x4){0u, 0u, 0u, 0u} : src[i * 64 + lane];
+    for (int i = 0; i < 24; ++i) wr[i] = (is_a && i >= (DENSE ? ND0 : 12)) ? (u32x4){0u, 0u, 0u, 0u} : src[i * 64 + lane];
   }
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};   // A: block 0's bias of this lane's channel quad; B: block 1's of cout tile c
   {
@@ -285,14 +347,21 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
         v[c][0] = c < NC ? __builtin_bit_cast(float, q.x) : 0.0f; v[c][1] = c < NC ? __builtin_bit_cast(float, q.y) : 0.0f;
         v[c][2] = c < NC ? __builtin_bit_cast(float, q.z) : 0.0f; v[c][3] = c < NC ? __builtin_bit_cast(float, q.w) : 0.0f;
       }
-      unsigned rec[3][4][2];   // [split][voxel][channels 01 | 23]
+      unsigned rec[3][4][2];   // [split][voxel][channels 01 | 23]   (DENSE: [record E, F, G][voxel][half])
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         unsigned p01[3], p23[3] = {0u, 0u, 0u};
         split3(v[0][j], v[1][j], p01);
         if (NC > 2) split3(v[2][j], v[3][j], p23);
+        if constexpr (DENSE) {
+          unsigned r3[3][2];
+          dense_records(p01, p23, r3);
 #pragma unroll
-        for (int s = 0; s < 3; ++s) { rec[s][j][0] = p01[s]; rec[s][j][1] = p23[s]; }
+          for (int s = 0; s < 3; ++s) { rec[s][j][0] = r3[s][0]; rec[s][j][1] = r3[s][1]; }
+        } else {
+#pragma unroll
+          for (int s = 0; s < 3; ++s) { rec[s][j][0] = p01[s]; rec[s][j][1] = p23[s]; }
+        }
       }
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
@@ -301,8 +370,8 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
       }
     };
 
-    // ---- unit prologue: ring 1 <- 0 (every voxel of the column outside the volume), ring 0 <- planes 2 s0 - 1 .. 2 s0 + 2
-    // (all 512 threads: 4 x 66 items); the B threads also request planes 2 s0 + 3, + 4 (their items of the first step)
+    // ---- unit prologue: ring 1 <- 0 (every voxel of the column outside the volume), ring 0 <- planes 2 s0 - 1 .. 2 s0 + 4
+    // (NPRO0 x 66 items); the B threads also request planes 2 s0 + 5, + 6 (their items of the first step)
     // staging items of a step: B waves 1..3 take 44 each (wave 0 = K quarter 0 has the most MFMAs and none)
     const int bi = (wq - 1) * 44 + lane;
     const bool item_live = !is_a && wq >= 1 && lane < 44;
@@ -310,11 +379,11 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
     u32x4 ldn[NC];
     __syncthreads();   // (the zero fill of the whole LDS | every read of the unit before)
     {
-      const bool pl_live = tid < 4 * R0Y * NQ0;
+      const bool pl_live = tid < NPRO0 * R0Y * NQ0;
       const int pz = pl_live ? tid / (R0Y * NQ0) - 1 + 2 * s0 : 0, prow = pl_live ? (tid % (R0Y * NQ0)) / NQ0 : 0, pq = pl_live ? tid % NQ0 : 0;
       u32x4 lp[NC];
       issue_item(pl_live, pz, prow, pq, lp);
-      issue_item(item_live, 2 * s0 + 3 + ipl, irow, iq, ldn);
+      issue_item(item_live, 2 * s0 + 3 + PA0 + ipl, irow, iq, ldn);
       for (int o = tid * 16; o < RING1; o += NTHR * 16) *reinterpret_cast<u32x4*>(lds + RING1_OFF + o) = (u32x4){0u, 0u, 0u, 0u};
       write_item(pl_live, pz, prow, pq, lp);
     }
@@ -349,6 +418,20 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
       const bool ok_s = (unsigned)(Y1 + sry) < (unsigned)dW && (unsigned)(X1 + srx) < (unsigned)dH && (!scol || col < R1Y);
       const int st_p0 = RING1_OFF + (ry0 * RS1 + (int)qpos * QS1 + col) * 8, st_p1 = st_p0 + RS1 * 8;
       const int st_s = RING1_OFF + (sry * RS1 + (int)qpos * QS1 + srx) * 8;
+      // DENSE: ring-0 byte offsets of this lane's two fragment halves inside (plane, tile row 0) — pair tiles | the single tile — and
+      // of its four leftover halves [MFMA w][half]
+      const unsigned dnA = (unsigned)((col + 2 + (lq == 3 ? 2 : 0)) * 8), dnB = (unsigned)((col + (lq == 3 ? 4 : 3)) * 8);
+      const unsigned dnAs = (unsigned)(sry * RB0 + (srx + 2 + (lq == 3 ? 2 : 0)) * 8), dnBs = (unsigned)(sry * RB0 + (srx + (lq == 3 ? 4 : 3)) * 8);
+      unsigned dnL[2][2], dnLs[2][2];
+#pragma unroll
+      for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int sidx = w * 8 + lq * 2 + h, sc = sidx > 14 ? 14 : sidx, lty = sc / 5, lk = sc % 5;
+          const int o = lty * RB0 + (lk < 3 ? 0 : lk - 2) * SB0;
+          dnL[w][h] = (unsigned)(o + (col + 4) * 8);
+          dnLs[w][h] = (unsigned)(o + sry * RB0 + (srx + 4) * 8);
+        }
       // SAVE: byte offsets inside a plane of this lane's three kinds of tiles in the activation / the mask (bit 31: not this
       // column's voxel — region row 0 and column 0 are the neighbours' — or outside the volume); the plane goes in soffset
       unsigned svo_p0 = OOR, svo_p1 = OOR, svo_s = OOR, mko_p0 = OOR, mko_p1 = OOR, mko_s = OOR;
@@ -487,7 +570,44 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
         for (int sp = 0; sp < 3; ++sp) fs.G[sp] = frag(gb + 2 * PLB0, sp * SB0, RB0);
       }
 #endif
-      int e6 = (2 * s0 + NRING0) % NRING0, m5 = (2 * s0 + NRING1) % NRING1;   // (2s) mod 6 = ring-0 slot of plane 2s-1; (2s) mod 5 = ring-1 slot of plane 2s
+      int e6 = (2 * s0 + NRING0) % NRING0, m5 = (2 * s0 + NRING1) % NRING1;   // (2s) mod 8 = ring-0 slot of plane 2s-1; (2s) mod 5 = ring-1 slot of plane 2s
+      // ---- DENSE: fragment addressing and the MFMA chain of a tile (comment of dense_records)
+      struct DBase { unsigned pA, pB, pL[2][2]; };
+      struct DFr { bf16x8 G[4], E[4], F[4], L[2][2]; };
+      auto dfrag = [&](unsigned pa, unsigned pb, int off) __attribute__((always_inline)) -> bf16x8 {
+        const u32x2 a = *reinterpret_cast<const u32x2*>(lds + pa + off);
+        const u32x2 b = *reinterpret_cast<const u32x2*>(lds + pb + off);
+        return __builtin_bit_cast(bf16x8, (u32x4){a[0], a[1], b[0], b[1]});
+      };
+      auto dload = [&](auto nc, const DBase& b, DFr& q) __attribute__((always_inline)) {
+        constexpr int n = decltype(nc)::value;
+        if constexpr (n < 9 || (n >= 11 && n < 14)) {
+          constexpr int kind = n < 9 ? n / 3 : n - 11, iy = n < 9 ? n % 3 : 3;   // kind 0 G, 1 E, 2 F
+          constexpr int off = iy * RB0 + (kind == 0 ? 2 : kind == 1 ? 0 : 1) * SB0;
+          const bf16x8 f = dfrag(b.pA, b.pB, off);
+          if constexpr (kind == 0) q.G[iy] = f; else if constexpr (kind == 1) q.E[iy] = f; else q.F[iy] = f;
+        } else {
+          constexpr int r = n < 11 ? 0 : 1, w = n < 11 ? n - 9 : n - 14;
+          q.L[r][w] = dfrag(b.pL[w][0], b.pL[w][1], r * RB0);
+        }
+      };
+      auto dmma = [&](auto kc, auto rc, const DFr& q, f32x4& acc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value, r = decltype(rc)::value;
+        if constexpr (k < 3) acc = MFMA(wr[k], q.G[r + k], acc);
+        else if constexpr (k < 6) acc = MFMA(wr[k], q.E[r + k - 3], acc);
+        else if constexpr (k < 9) acc = MFMA(wr[k], q.F[r + k - 6], acc);
+        else if constexpr (k < 12) acc = MFMA(wr[k], q.E[r + k - 9], acc);
+        else if constexpr (k < 14) acc = MFMA(wr[k], q.L[r][k - 12], acc);
+        else acc = MFMA(wr[k], q.E[r + k - 14], acc);
+      };
+      DFr fa;
+      if constexpr (DENSE) {   // the first six fragments of the column's first step (later steps: requested ahead of the barrier)
+        const int t0 = (e6 % NRING0) * PLB0, t1 = ((e6 + 1) % NRING0) * PLB0, t2 = ((e6 + 2) % NRING0) * PLB0;
+        DBase b0;
+        b0.pA = (unsigned)((lq == 1 ? t1 : lq == 2 ? t2 : t0) + ry0 * RB0) + dnA;
+        b0.pB = (unsigned)((lq == 0 ? t0 : lq == 2 ? t2 : t1) + ry0 * RB0) + dnB;
+        static_for<DENSE_PRE>([&](auto nc) __attribute__((always_inline)) { dload(nc, b0, fa); });
+      }
       for (int s = s0; s <= d.Do; ++s) {
         constexpr bool a_on = !(LR_C01_ABL & 2);
         if (s < d.Do && a_on) {
@@ -500,6 +620,64 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
           const int a00 = zok0 && ok_p0 ? st_p0 + so0 : dump1, a01 = zok0 && ok_p1 ? st_p1 + so0 : dump1;
           const int a10 = zok1 && ok_p0 ? st_p0 + so1 : dump1, a11 = zok1 && ok_p1 ? st_p1 + so1 : dump1;
           const int as_ = (spl ? zok1 : zok0) && ok_s ? st_s + (spl ? so1 : so0) : dump1;
+          if constexpr (DENSE) {
+          // ---- dense K (three channels): five tiles x 17 MFMAs, one chain each; the epilogue of tile t rides beside tile t + 1.
+          // The first six fragments of the step were requested before the barrier (ring 0 is staged a step ahead).
+          const int sl0 = ((e6 + 0) % NRING0) * PLB0, sl1 = ((e6 + 1) % NRING0) * PLB0, sl2 = ((e6 + 2) % NRING0) * PLB0,
+                    sl3 = ((e6 + 3) % NRING0) * PLB0, sl4 = ((e6 + 4) % NRING0) * PLB0;
+          // first half: lq < 3: tap (tz = lq, ty, 0); lq = 3: (0, ty, 2).  second half: lq < 3: (lq, ty, 1); lq = 3: (1, ty, 2)
+          const int plA0 = lq == 1 ? sl1 : lq == 2 ? sl2 : sl0, plA1 = lq == 1 ? sl2 : lq == 2 ? sl3 : sl1, plA2 = lq == 1 ? sl3 : lq == 2 ? sl4 : sl2;
+          const int plB0 = lq == 0 ? sl0 : lq == 2 ? sl2 : sl1, plB1 = lq == 0 ? sl1 : lq == 2 ? sl3 : sl2, plB2 = lq == 0 ? sl2 : lq == 2 ? sl4 : sl3;
+          DBase bP0, bP1, bS, bN;
+          bP0.pA = (unsigned)(plA0 + ry0 * RB0) + dnA; bP0.pB = (unsigned)(plB0 + ry0 * RB0) + dnB;
+          bP1.pA = (unsigned)(plA1 + ry0 * RB0) + dnA; bP1.pB = (unsigned)(plB1 + ry0 * RB0) + dnB;
+          bN.pA = (unsigned)(plA2 + ry0 * RB0) + dnA; bN.pB = (unsigned)(plB2 + ry0 * RB0) + dnB;   // the first pair of step s + 1
+          bS.pA = (unsigned)(spl ? plA1 : plA0) + dnAs; bS.pB = (unsigned)(spl ? plB1 : plB0) + dnBs;
+#pragma unroll
+          for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              bP0.pL[w][h] = (unsigned)(sl2 + ry0 * RB0) + dnL[w][h];
+              bP1.pL[w][h] = (unsigned)(sl3 + ry0 * RB0) + dnL[w][h];
+              bS.pL[w][h] = (unsigned)(spl ? sl3 : sl2) + dnLs[w][h];
+              bN.pL[w][h] = 0u;
+            }
+          DFr fb, fs;
+          f32x4 acc0, acc1;
+          Epi E0;
+          C01_STAMP(1);
+          auto epi_tile = [&](auto tc, int sl, const f32x4& acc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            if constexpr (t == 0) epi_slice(sl, E0, acc, a00, zok0 ? svo_p0 : OOR, zok0 ? mko_p0 : OOR, 2 * s);
+            else if constexpr (t == 1) epi_slice(sl, E0, acc, a01, zok0 ? svo_p1 : OOR, zok0 ? mko_p1 : OOR, 2 * s);
+            else if constexpr (t == 2) epi_slice(sl, E0, acc, a10, zok1 ? svo_p0 : OOR, zok1 ? mko_p0 : OOR, 2 * s + 1);
+            else if constexpr (t == 3) epi_slice(sl, E0, acc, a11, zok1 ? svo_p1 : OOR, zok1 ? mko_p1 : OOR, 2 * s + 1);
+            else epi_slice(sl, E0, acc, as_, (spl ? zok1 : zok0) ? svo_s : OOR, (spl ? zok1 : zok0) ? mko_s : OOR, 2 * s + spl);
+          };
+          static_for<5 * ND0>([&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value, t = g / ND0, k = g % ND0;
+            f32x4& acc = (t & 1) ? acc1 : acc0;
+            const f32x4& prev = (t & 1) ? acc0 : acc1;
+            if constexpr (k == 0) acc = bv;
+            if constexpr (t < 2) dmma(std::integral_constant<int, k>{}, std::integral_constant<int, t>{}, fa, acc);
+            else if constexpr (t < 4) dmma(std::integral_constant<int, k>{}, std::integral_constant<int, t - 2>{}, fb, acc);
+            else dmma(std::integral_constant<int, k>{}, std::integral_constant<int, 0>{}, fs, acc);
+            constexpr int ld = dense_load_at(g);
+            if constexpr (ld >= 0) {
+              constexpr int set = ld / 16, n = ld % 16;
+              if constexpr (set == 0) dload(std::integral_constant<int, n>{}, bP0, fa);
+              else if constexpr (set == 1) dload(std::integral_constant<int, n>{}, bP1, fb);
+              else dload(std::integral_constant<int, n>{}, bS, fs);
+            }
+            if constexpr (g >= 5 * ND0 - DENSE_PRE) dload(std::integral_constant<int, g - (5 * ND0 - DENSE_PRE)>{}, bN, fa);
+            if constexpr (t >= 1 && k >= 2 && k <= 14 && (k & 1) == 0) epi_tile(std::integral_constant<int, t - 1>{}, k / 2 - 1, prev);
+            C01_FENCE();
+          });
+          C01_STAMP(4);
+#pragma unroll
+          for (int k = 0; k < 7; ++k) epi_tile(std::integral_constant<int, 4>{}, k, acc0);
+          C01_STAMP(5);
+          } else {
           // ring-0 fragment bases: plane pl of the step, the lane's taps in plane (2s - 1 + pl) + tz
           const int f0 = ((e6 + dlF) % NRING0) * PLB0, f1 = ((e6 + 1 + dlF) % NRING0) * PLB0;
           const int g0 = ((e6 + dlG) % NRING0) * PLB0, g1 = ((e6 + 1 + dlG) % NRING0) * PLB0;
@@ -561,6 +739,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
 #pragma unroll
           for (int k = 0; k < 7; ++k) epi_slice(k, E0, accS, as_, (spl ? zok1 : zok0) ? svo_s : OOR, (spl ? zok1 : zok0) ? mko_s : OOR, 2 * s + spl);
           C01_STAMP(5);
+          }
         }
         __syncthreads();
         C01_STAMP(6);
@@ -605,14 +784,21 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
         v[c][0] = c < NC ? __builtin_bit_cast(float, q.x) : 0.0f; v[c][1] = c < NC ? __builtin_bit_cast(float, q.y) : 0.0f;
         v[c][2] = c < NC ? __builtin_bit_cast(float, q.z) : 0.0f; v[c][3] = c < NC ? __builtin_bit_cast(float, q.w) : 0.0f;
       }
-      unsigned rec[3][4][2];   // [split][voxel][channels 01 | 23]
+      unsigned rec[3][4][2];   // [split][voxel][channels 01 | 23]   (DENSE: [record E, F, G][voxel][half])
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         unsigned p01[3], p23[3] = {0u, 0u, 0u};
         split3(v[0][j], v[1][j], p01);
         if (NC > 2) split3(v[2][j], v[3][j], p23);
+        if constexpr (DENSE) {
+          unsigned r3[3][2];
+          dense_records(p01, p23, r3);
 #pragma unroll
-        for (int s = 0; s < 3; ++s) { rec[s][j][0] = p01[s]; rec[s][j][1] = p23[s]; }
+          for (int s = 0; s < 3; ++s) { rec[s][j][0] = r3[s][0]; rec[s][j][1] = r3[s][1]; }
+        } else {
+#pragma unroll
+          for (int s = 0; s < 3; ++s) { rec[s][j][0] = p01[s]; rec[s][j][1] = p23[s]; }
+        }
       }
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
@@ -621,8 +807,8 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
       }
     };
 
-    // ---- unit prologue: ring 1 <- 0 (every voxel of the column outside the volume), ring 0 <- planes 2 s0 - 1 .. 2 s0 + 2
-    // (all 512 threads: 4 x 66 items); the B threads also request planes 2 s0 + 3, + 4 (their items of the first step)
+    // ---- unit prologue: ring 1 <- 0 (every voxel of the column outside the volume), ring 0 <- planes 2 s0 - 1 .. 2 s0 + 4
+    // (NPRO0 x 66 items); the B threads also request planes 2 s0 + 5, + 6 (their items of the first step)
     // staging items of a step: B waves 1..3 take 44 each (wave 0 = K quarter 0 has the most MFMAs and none)
     const int bi = (wq - 1) * 44 + lane;
     const bool item_live = !is_a && wq >= 1 && lane < 44;
@@ -631,11 +817,11 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
     u32x4 ldn[NC];
     __syncthreads();   // (the zero fill of the whole LDS | every read of the unit before)
     {
-      const bool pl_live = tid < 4 * R0Y * NQ0;
+      const bool pl_live = tid < NPRO0 * R0Y * NQ0;
       const int pz = pl_live ? tid / (R0Y * NQ0) - 1 + 2 * s0 : 0, prow = pl_live ? (tid % (R0Y * NQ0)) / NQ0 : 0, pq = pl_live ? tid % NQ0 : 0;
       u32x4 lp[NC];
       issue_item(pl_live, pz, prow, pq, lp);
-      issue_item(item_live, 2 * s0 + 3 + ipl, irow, iq, ldn);
+      issue_item(item_live, 2 * s0 + 3 + PA0 + ipl, irow, iq, ldn);
       for (int o = tid * 16; o < RING1; o += NTHR * 16) *reinterpret_cast<u32x4*>(lds + RING1_OFF + o) = (u32x4){0u, 0u, 0u, 0u};
       write_item(pl_live, pz, prow, pq, lp);
     }
@@ -681,6 +867,18 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
       };
       auto stage_slice = [&](int half, int addr) __attribute__((always_inline)) {
         unsigned rec[3][2][2];
+        if constexpr (DENSE) {
+#pragma unroll
+          for (int vv = 0; vv < 2; ++vv) {
+            const int vj = 2 * half + vv;
+            unsigned p01[3], p2[3], r3[3][2];
+            split3(lval(0, vj), lval(1, vj), p01);
+            split3(lval(2, vj), 0.0f, p2);
+            dense_records(p01, p2, r3);
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) { rec[sp][vv][0] = r3[sp][0]; rec[sp][vv][1] = r3[sp][1]; }
+          }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const int vj = 2 * half + (kk >> 1), hf = kk & 1;
@@ -690,6 +888,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
 #pragma unroll
           for (int sp = 0; sp < 3; ++sp) rec[sp][kk >> 1][hf] = pp[sp];
         }
+        }
 #pragma unroll
         for (int sp = 0; sp < 3; ++sp)
           *reinterpret_cast<u32x4*>(lds + addr + sp * SB0 + 16 * half) = (u32x4){rec[sp][0][0], rec[sp][0][1], rec[sp][1][0], rec[sp][1][1]};
@@ -698,7 +897,8 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
       // bias, LeakyReLU, store (oz < 0: zero-length resource, no branch)
       f32x4 fin_a, fin_b;
       auto fin_read = [&](int q, int oz) __attribute__((always_inline)) -> f32x4 {
-        return *reinterpret_cast<const f32x4*>(lds + SCR_OFF + ((((oz & 1) * 4 + q) * 4 + kq) * 64 + lane) * 16);
+        const int slot = q == kq ? 0 : kq - (kq > q ? 1 : 0);   // (q == kq: its own partial sum is in registers — the value read is dropped)
+        return *reinterpret_cast<const f32x4*>(lds + SCR_OFF + ((((oz & 1) * 4 + q) * 3 + slot) * 64 + lane) * 16);
       };
       auto fin_slice = [&](int k, int oz) __attribute__((always_inline)) {
         if (k == 0) { fin_a = fin_read(0, oz); fin_b = fin_read(1, oz); }
@@ -726,7 +926,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
 #endif
       for (int s = s0; s <= d.Do; ++s) {
         C01_STAMP(0);
-        const int r0addr = item_live ? ((2 * s + 3 + ipl + 1) % NRING0) * PLB0 + irow * RB0 + iq * 32 : DUMP_OFF + lane * 16;
+        const int r0addr = item_live ? ((2 * s + 3 + PA0 + ipl + 1) % NRING0) * PLB0 + irow * RB0 + iq * 32 : DUMP_OFF + lane * 16;
         C01_STAMP(1);
         if (s >= 1) {
           const int oz = s - 1;
@@ -779,7 +979,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
 #undef C01_W
             C01_FENCE();
             if (2 * g + 1 < NST) { if (wave_stages) stage_slice(2 * g + 1, r0addr); } else if (2 * g + 1 < NSL) fin_slice(2 * g + 1 - NST, oz - 1);
-            if (2 * g + 1 == NST - 1 && wave_stages) issue_item(item_live, 2 * s + 5 + ipl, irow, iq, ldn);
+            if (2 * g + 1 == NST - 1 && wave_stages) issue_item(item_live, 2 * s + 5 + PA0 + ipl, irow, iq, ldn);
             C01_FENCE();
           };
 #pragma unroll
@@ -795,14 +995,16 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
           for (int a4 = 0; a4 < 4; ++a4) acc[a4] = hi[a4 >> 1][a4 & 1] + lo[a4 >> 1][a4 & 1];
           own = kq == 0 ? acc[0] : kq == 1 ? acc[1] : kq == 2 ? acc[2] : acc[3];
 #pragma unroll
-          for (int a4 = 0; a4 < 4; ++a4)
-            *reinterpret_cast<f32x4*>(lds + SCR_OFF + ((((oz & 1) * 4 + kq) * 4 + a4) * 64 + lane) * 16) = acc[a4];
+          for (int a3 = 0; a3 < 3; ++a3) {   // accumulator a4 = a3 + (a3 >= kq)
+            const f32x4 v = kq == 0 ? acc[a3 + 1] : kq == 1 ? acc[a3 == 0 ? 0 : a3 + 1] : kq == 2 ? acc[a3 == 2 ? 3 : a3] : acc[a3];
+            *reinterpret_cast<f32x4*>(lds + SCR_OFF + ((((oz & 1) * 4 + kq) * 3 + a3) * 64 + lane) * 16) = v;
+          }
           C01_STAMP(4);
         } else {
           if (wave_stages) {
 #pragma unroll
             for (int k = 0; k < NST; ++k) stage_slice(k, r0addr);
-            issue_item(item_live, 2 * s + 5 + ipl, irow, iq, ldn);
+            issue_item(item_live, 2 * s + 5 + PA0 + ipl, irow, iq, ldn);
           }
         }
         __syncthreads();
@@ -852,6 +1054,42 @@ __global__ void pack_c01_w1_kernel(const float* __restrict__ w, u32x4* __restric
 
 constexpr int64_t W1_FLOATS = (int64_t)4 * 4 * 2 * 3 * 64 * 4;
 
+// The 17 weight fragments of the DENSE block 0 (three input channels), in the order of a tile's chain: WG[ty] WE2[ty] WF[ty]
+// WE1[ty] WL0 WL1 WE0[ty].  Lane (co = lane & 15, lq = lane >> 4) holds the 8 bf16 of its two record slots (half h = e >> 2,
+// position e & 3).  Main fragments (tap row ty): slot (lq, h) = tap (tz = lq, ty, tx = h) for lq < 3, (tz = h, ty, 2) for lq = 3;
+// leftover fragments: slot s = 8 w + 2 lq + h = tap (2, s / 5, 2), kind s % 5 (dense_left_*); the patterns per kind are in
+// the comment of dense_records.
+__global__ void pack_c01_w0_dense_kernel(const float* __restrict__ w, u32x4* __restrict__ packed) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ND0 * 64) return;
+  const int f = idx >> 6, lane = idx & 63, co = lane & 15, lq = lane >> 4;
+  unsigned el[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int h = e >> 2, pos = e & 3;
+    int kind, tap;   // kind 0..2 = E x w_kind, 3 = F, 4 = G, -1 = empty slot
+    if (f < 12 || f >= 14) {
+      const int grp = f < 12 ? f / 3 : 4, ty = f < 12 ? f % 3 : f - 14;
+      kind = grp == 0 ? 4 : grp == 1 ? 2 : grp == 2 ? 3 : grp == 3 ? 1 : 0;
+      const int tz = lq < 3 ? lq : h, tx = lq < 3 ? h : 2;
+      tap = (tz * 3 + ty) * 3 + tx;
+    } else {
+      const int sidx = (f - 12) * 8 + lq * 2 + h;
+      kind = sidx > 14 ? -1 : sidx % 5;
+      tap = (2 * 3 + (sidx > 14 ? 0 : sidx / 5)) * 3 + 2;
+    }
+    int sp = -1, c = 0;   // weight split, channel
+    if (kind >= 0 && kind <= 2) { if (pos < 3) { sp = kind; c = pos; } else if (kind < 2) { sp = kind; c = 0; } }
+    else if (kind == 3) { sp = 0; c = pos == 0 ? 1 : pos == 1 ? 2 : pos == 2 ? 0 : 1; }
+    else if (kind == 4) { if (pos == 0) { sp = 0; c = 2; } else if (pos < 3) { sp = 1; c = pos; } }
+    unsigned p[3] = {0u, 0u, 0u};
+    if (sp >= 0) split3(w[((int64_t)co * 3 + c) * 27 + tap], 0.0f, p);
+    el[e] = sp >= 0 ? (p[sp == 0 ? 0 : sp == 1 ? 1 : 2] & 0xffffu) : 0u;
+  }
+  packed[f * 64 + lane] = (u32x4){el[0] | (el[1] << 16), el[2] | (el[3] << 16), el[4] | (el[5] << 16), el[6] | (el[7] << 16)};
+}
+constexpr int64_t W0D_FLOATS = (int64_t)ND0 * 64 * 4;
+
 }  // namespace
 
 #ifdef LR_C01_STAMPS
@@ -868,7 +1106,7 @@ extern "C" int lr_debug_read_c01_stamps(unsigned long long* host64, int reset) {
 // ---- C ABI (include/liftreg_hip.h)
 extern "C" int64_t lr_conv3d_pair01_packed_floats(int Cin, int C0, int C1) {
   if (Cin < 1 || Cin > 4 || C0 != 16 || C1 != 32) return 0;
-  return lr_internal_conv0_split_packed_floats(Cin, C0) + W1_FLOATS;
+  return lr_internal_conv0_split_packed_floats(Cin, C0) + W1_FLOATS + (Cin == 3 ? W0D_FLOATS : 0);   // [block 0][block 1][block 0, dense K]
 }
 
 extern "C" int lr_conv3d_pair01_pack_f32(const float* w0, const float* w1, float* packed, int Cin, int C0, int C1, void* stream) {
@@ -880,6 +1118,9 @@ extern "C" int lr_conv3d_pair01_pack_f32(const float* w0, const float* w1, float
   if (rc != LR_OK) return rc;
   u32x4* p1 = reinterpret_cast<u32x4*>(packed + lr_internal_conv0_split_packed_floats(Cin, C0));
   hipLaunchKernelGGL(pack_c01_w1_kernel, dim3((4 * 4 * 2 * 64 + 255) / 256), dim3(256), 0, st, w1, p1);
+  if (Cin == 3)
+    hipLaunchKernelGGL(pack_c01_w0_dense_kernel, dim3((ND0 * 64 + 255) / 256), dim3(256), 0, st, w0,
+                       reinterpret_cast<u32x4*>(packed + lr_internal_conv0_split_packed_floats(Cin, C0) + W1_FLOATS));
   return lr_launch_status();
 }
 
@@ -944,22 +1185,27 @@ static int pair01_impl(const float* in0, int64_t in0_batch_stride, const float* 
   const u32x4* wp0 = reinterpret_cast<const u32x4*>(packed);
   const u32x4* wp1 = reinterpret_cast<const u32x4*>(packed + lr_internal_conv0_split_packed_floats(Cin, 16));
   if (!in_rest) in_rest = in0;   // Cin == 1: never dereferenced (zero-length resource)
-#define LR_C01(NCV, SV)                                                                                                      \
+  // three channels: block 0 with K packed densely (17 instead of 24 MFMAs per tile); LIFTREG_PAIR01_DENSE=0: the padded form (A/B aid)
+  const bool densek = Cin == 3 && lr_sw_int(LR_SW_PAIR01_DENSE, 1) != 0;
+  if (densek) wp0 = reinterpret_cast<const u32x4*>(packed + lr_internal_conv0_split_packed_floats(Cin, 16) + W1_FLOATS);
+#define LR_C01(NCV, SV, DN)                                                                                                    \
   do {                                                                                                                       \
     static std::atomic<uint64_t> attr_done{0};                                                                               \
-    if (lr_raise_dyn_lds(reinterpret_cast<const void*>(&conv01_fused_kernel<NCV, SV>), LDSB, attr_done) != LR_OK) return LR_ELAUNCH; \
-    hipLaunchKernelGGL((conv01_fused_kernel<NCV, SV>), dim3((unsigned)blocks), dim3(NTHR), LDSB, st, in0, in_rest, wp0, wp1, bias0, bias1, out, d); \
+    if (lr_raise_dyn_lds(reinterpret_cast<const void*>(&conv01_fused_kernel<NCV, SV, DN>), LDSB, attr_done) != LR_OK) return LR_ELAUNCH; \
+    hipLaunchKernelGGL((conv01_fused_kernel<NCV, SV, DN>), dim3((unsigned)blocks), dim3(NTHR), LDSB, st, in0, in_rest, wp0, wp1, bias0, bias1, out, d); \
   } while (0)
   if (save) {
-    if (Cin == 1) LR_C01(1, true);
-    else if (Cin == 2) LR_C01(2, true);
-    else if (Cin == 3) LR_C01(3, true);
-    else LR_C01(4, true);
+    if (Cin == 1) LR_C01(1, true, false);
+    else if (Cin == 2) LR_C01(2, true, false);
+    else if (Cin == 3 && densek) LR_C01(3, true, true);
+    else if (Cin == 3) LR_C01(3, true, false);
+    else LR_C01(4, true, false);
   } else {
-    if (Cin == 1) LR_C01(1, false);
-    else if (Cin == 2) LR_C01(2, false);
-    else if (Cin == 3) LR_C01(3, false);
-    else LR_C01(4, false);
+    if (Cin == 1) LR_C01(1, false, false);
+    else if (Cin == 2) LR_C01(2, false, false);
+    else if (Cin == 3 && densek) LR_C01(3, false, true);
+    else if (Cin == 3) LR_C01(3, false, false);
+    else LR_C01(4, false, false);
   }
 #undef LR_C01
   return lr_launch_status();

@@ -42,6 +42,7 @@ enum LrSwitch {
   LR_SW_CONV_ROWS_XMAP,   // LIFTREG_CONV_ROWS_XMAP: 0: plain strided tile order instead of the XCD-aware one
   LR_SW_BF16_MT,   // LIFTREG_BF16_MT: output rows per tile of the bf16 row kernels (4 | 8)
   LR_SW_PAIR01_BLOCKS,   // LIFTREG_PAIR01_BLOCKS: persistent blocks of the fused pair kernel (default: one per CU)
+  LR_SW_PAIR01_DENSE,   // LIFTREG_PAIR01_DENSE: 0: three-channel pair kernel with the padded K of block 0 (24 MFMAs per tile; A/B aid) instead of the dense 17
   LR_SW_BF16_NO_MARCH,   // LIFTREG_BF16_NO_MARCH: bf16 16->32 block: the row kernel instead of the z-marching one (A/B aid)
   LR_SW_BF16_MARCH_TY8,   // LIFTREG_BF16_MARCH_TY8: bf16 16->32 z-march: columns of 8 x 16 outputs (512 threads, one block per CU; A/B aid)
   LR_SW_BF16_MARCH_ZC,   // LIFTREG_BF16_MARCH_ZC: output planes per z chunk of the bf16 z-marching kernel (tests: chunk boundaries)

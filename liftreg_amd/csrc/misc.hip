@@ -49,6 +49,7 @@ const char* const kSwitchNames[LR_SW_COUNT] = {
     "LIFTREG_CONV_ROWS_XMAP",
     "LIFTREG_BF16_MT",
     "LIFTREG_PAIR01_BLOCKS",
+    "LIFTREG_PAIR01_DENSE",
     "LIFTREG_BF16_NO_MARCH",
     "LIFTREG_BF16_MARCH_TY8",
     "LIFTREG_BF16_MARCH_ZC",

@@ -6,6 +6,7 @@ torch.empty and launches through the C ABI on torch's current stream.  There is 
 CPU path: a CPU tensor or a missing library raises.
 """
 import contextlib
+import os
 
 import numpy as np
 import torch
@@ -393,6 +394,14 @@ def conv3d_pair01_supported(x0, rest, w0, w1, out_layout=LAYOUT_NDHWC_HPS, probe
     return 12 * V + 32 * W * H < 2 ** 31 - 1 and ((W - 1) // 2 + 1) * ((H - 1) // 2 + 1) * 128 < 2 ** 31 - 1
 
 
+def _pair01_mfmas_per_step(Cin):
+    """What the matrix pipe is really asked for by the pair kernel: v_mfma_f32_16x16x32_bf16 per column of 4 x 8 outputs and
+    step (one block-1 output plane).  Block 0: 20 tiles of 16 voxels x 17 MFMAs (three channels: K packed densely, 135 record
+    slots of 136) or x 24 (K padded 27 taps -> 32, channels -> 4); block 1: 96 + 96 + 72 + 72 (see the kernel header)."""
+    dense = Cin == 3 and os.environ.get("LIFTREG_PAIR01_DENSE", "1") != "0"
+    return 20 * (17 if dense else 24) + 336
+
+
 def conv3d_pair01_pack(w0, w1):
     """The two (Cout,Cin,3,3,3) weights as the three-way bf16 split fragments of lr_conv3d_pair01_f32."""
     w0, w1 = _dev(w0.detach(), "w0"), _dev(w1.detach(), "w1")
@@ -431,9 +440,7 @@ def conv3d_pair01(x0, rest, w0, b0, w1, b1, *, out_layout=LAYOUT_NDHWC_HPS, slop
     ibs = int(x0.stride(0)) if (B > 1 and not x0.is_contiguous()) else 0
     V = 2 * Do * W * H
     flops = 2.0 * 27 * B * (Cin * 16 * V + 16 * 32 * Do * Wo * Ho)
-    # what the matrix pipe is really asked for: per column of 4 x 8 outputs and step, 4 x 120 v_mfma_f32_16x16x32_bf16 for block 0
-    # (20 tiles x 24) and 96 + 96 + 72 + 72 for block 1 (see the kernel header); Do steps per column
-    issued = 16384.0 * 816 * Do * B * (-(-Wo // 4)) * (-(-Ho // 8))
+    issued = 16384.0 * _pair01_mfmas_per_step(Cin) * Do * B * (-(-Wo // 4)) * (-(-Ho // 8))
     with _timed(f"conv3d_pair01_c{Cin}x16x32_{Dg}" + ("" if slab is None else "_slab"), flops=flops, issued_bf16_flops=issued,
                 bytes=4 * B * Cin * 2 * Do * W * H + 4 * y.numel(), samples=B):
         _hip.check(_hip.lib().lr_conv3d_pair01_slab_f32(x0.data_ptr(), ibs, rest.data_ptr(), 0, packed.data_ptr(), _ptr(b0),
@@ -477,7 +484,7 @@ def conv3d_pair01_train(x, w0, b0, w1, b1, *, mid_layout=LAYOUT_NDHWC_HPS, out_l
     mask0 = torch.empty((B, D, W, H, 4), dtype=torch.uint8, device=x.device)
     V = D * W * H
     flops = 2.0 * 27 * B * (Cin * 16 * 2 * Do * W * H + 16 * 32 * Do * Wo * Ho)
-    issued = 16384.0 * 816 * Do * B * (-(-Wo // 4)) * (-(-Ho // 8))
+    issued = 16384.0 * _pair01_mfmas_per_step(Cin) * Do * B * (-(-Wo // 4)) * (-(-Ho // 8))
     with _timed(f"conv3d_pair01_train_c{Cin}x16x32_{D}", flops=flops, issued_bf16_flops=issued,
                 bytes=4 * x.numel() + 4 * y1.numel() + 4 * y0.numel() + mask0.numel(), samples=B):
         _hip.check(_hip.lib().lr_conv3d_pair01_train_f32(x.data_ptr(), Cin * V, x.data_ptr() + 4 * V, Cin * V, packed.data_ptr(),
