@@ -34,6 +34,10 @@ CONFIGS = {  # BASELINE.json configs (single-GPU ones)
     "c2": dict(n=128, P=2, R=128, B=4, L=56),
     "c3": dict(n=256, P=2, R=256, B=8, L=56),
     "c4": dict(n=256, P=11, R=256, B=4, L=56),   # C4 per GPU in replica mode (batch 16 over 4 GPUs); use --conv-dtype bf16
+    # the reference's OWN shipped configuration (/root/reference/cur_task_setting.json:30,56-57: drr_feature_num 4, latent_dim 56,
+    # batch_size 30; …/models/LiftRegDeformSubspaceBackproj.py:36 hard-codes 160^3; detector int(1.5 * 160) = 240,
+    # sdct_projection_utils.py:146-151) — not a BASELINE.json config: an extra line, never the headline
+    "native160": dict(n=160, P=4, R=240, B=30, L=56),
 }
 SLAB_GLOBAL_BATCH = {"c4": 16}   # --shard slab: C4 is ONE batch of 16 sharded by z-slab over the ranks (BASELINE configs[3])
 class SclkSampler:
@@ -284,15 +288,6 @@ def main():
                     help="untimed seconds of the same step before the W warm-up steps (GPU clock ramp; 0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-drr", action="store_true", help="skip the projector-only legs after the timed region (profiling runs)")
-    ap.add_argument("--streams", type=int, default=0, choices=(0, 1, 2, 3),
-                    help="0 (default) = 1: one stream.  "
-                         "3: liftreg_amd.pipeline.ShadowRegistrar — the next batch's backprojection and the previous batch's NCC "
-                         "moments on side streams beside the pair kernel (identical results; the per-kernel table then comes "
-                         "from eager steps after the timed region).  2: TwoStreamRegistrar (decode of batch i beside the "
-                         "encode of batch i+1: measured slower, profiles/NOTES_r04.md).  3 measured +1…4 %% over 1 depending on the box "
-                         "(profiles/NOTES_r04.md): inside the box-to-box spread, so the headline stays on one stream")
-    ap.add_argument("--decode-cus", type=int, default=0,
-                    help="with --streams 2: compute units reserved for the decode stream (CU-masked streams)")
     ap.add_argument("--pca-dtype", default="fp32", choices=("fp32", "bf16"),
                     help="bf16: the PCA basis stored as bfloat16 in HBM (opt-in, not the headline configuration)")
     ap.add_argument("--conv-dtype", default="fp32", choices=("fp32", "bf16"),
@@ -322,7 +317,8 @@ def main():
                          "per-kernel table then comes from one extra eager step outside the timed region")
     args = ap.parse_args()
     if args.conv0_split:
-        os.environ["LIFTREG_CONV0_SPLIT"] = "1"   # read by the launcher at every call
+        os.environ["LIFTREG_CONV0_SPLIT"] = "1"   # set before the library's first launch (switches are read once per process)
+        args.no_pair01 = True                     # the pair kernel would run in front of it: the split block is what this flag measures
     cfg = dict(CONFIGS[args.config])
     if args.shard == "slab" and args.config in SLAB_GLOBAL_BATCH:
         cfg["B"] = SLAB_GLOBAL_BATCH[args.config]
@@ -361,15 +357,13 @@ def main():
                             "fuse_ncc": args.fuse_ncc, "fuse_backproject": args.fuse_bp,
                             "fuse_pair01": not args.no_pair01}).to(dev).eval()
     slab = args.shard == "slab"
-    if args.streams == 0:
-        args.streams = 1
     inp = synth_inputs(cfg, dev, seed=2021 if slab else 2021 + rank)   # slab: every rank holds the SAME batch
     sim = NCCLoss(check_nan=False)
 
     if slab:
         from liftreg_amd import parallel as par
-        if args.streams != 1 or args.graph:
-            sys.exit("--shard slab runs eagerly on one stream")
+        if args.graph:
+            sys.exit("--shard slab runs eagerly")
         sharded = par.SlabShardedRegistration(net, par.DistComm())
         d0, d1 = par.slab_bounds(n, world, rank)
         # a rank needs the whole moving volume and the views (replicated), and only its slab of the target
@@ -377,18 +371,6 @@ def main():
 
         def step():
             return sharded.forward([my])[0]["sim_loss"]
-    elif args.streams == 3:
-        from liftreg_amd.pipeline import ShadowRegistrar
-        reg = ShadowRegistrar(net, sim)
-
-        def step():
-            return reg.submit(inp)[1]
-    elif args.streams == 2:
-        from liftreg_amd.pipeline import TwoStreamRegistrar
-        reg = TwoStreamRegistrar(net, sim, decode_cus=args.decode_cus)
-
-        def step():
-            return reg.submit(inp)[1]
     elif args.graph:
         from liftreg_amd.pipeline import GraphedRegistrar
         greg = GraphedRegistrar(net, inp, sim=sim)
@@ -432,7 +414,7 @@ def main():
                 loss = step()
             fence()
         live_op = None
-        if args.streams == 1 and not args.graph:
+        if not args.graph:
             tot = {k: sum(v["ms"]) for k, v in kt_w.summary().items()}
             live_op = max(tot, key=tot.get) if tot else None
         with ops.kernel_timer(only=live_op) as kt, SclkSampler(local) as sclk:
@@ -453,8 +435,8 @@ def main():
                     for k, v in kt_a.summary().items()}
             if live is not None:
                 ksum[live_op] = live
-        if args.graph or args.streams == 3:   # a replay records no per-launch events, kernels that overlap have no duration of their own: one eager step
-            n_eager = 1 if args.graph else 5
+        if args.graph:   # a replay records no per-launch events: one eager step
+            n_eager = 1
             with ops.kernel_timer() as kt:
                 for _ in range(n_eager):
                     out = net(inp)
@@ -514,6 +496,7 @@ def main():
         if "issued_bf16_flops" in info:   # the fused split-operand pair kernel: fp32 results from six bf16 MFMAs per K block
             k["issued_bf16_tflops"] = info["issued_bf16_flops"] / (ms * 1e-3) / 1e12
             k["frac_bf16_issued"] = k["issued_bf16_tflops"] / MFMA_BF16_PEAK_TF
+            k["useful_mfma_share"] = 6.0 * info["flops"] / info["issued_bf16_flops"]   # six exact products per fp32 multiply-add
             k["compulsory_bytes"] = info["bytes"]
         kernels[name] = k
     # PMC-derived HBM bytes per launch (tools/pmc_bench.sh over this very command).  Every entry is stamped with the
@@ -551,9 +534,12 @@ def main():
                     "frac_mfma_issued": k["frac"] * k["issued_share"]} if "issued_share" in k else {}),
                 **({"flops": "algorithmic fp32 flops of the two direct convolutions, priced against the fp32 MFMA peak (the "
                              "arithmetic type of the path); the kernel computes them as exact 3-way bf16 splits on the bf16 "
-                             "MFMA: `issued_bf16_tflops` / `frac_bf16_issued` price the MFMAs it really issues (6 per K block "
-                             "of 32, K padded 81 -> 128 and 432 -> 448, 20 % halo recompute in block 0) against the dense bf16 peak",
+                             "MFMA: `issued_bf16_tflops` / `frac_bf16_issued` price the MFMAs it really issues against the dense "
+                             "bf16 peak, `useful_mfma_share` = 6 x algorithmic multiply-adds / issued ones (three channels: block 0's "
+                             "K packed 486 products -> 17 MFMAs of 512 per 16-voxel tile, block 1's 432 -> 448, 20 % halo recompute "
+                             "in block 0; other channel counts: block 0's K padded 27 taps -> 32, channels -> 4)",
                     "issued_bf16_tflops": k["issued_bf16_tflops"], "frac_bf16_issued": k["frac_bf16_issued"],
+                    "useful_mfma_share": k["useful_mfma_share"],
                     "peak_bf16": MFMA_BF16_PEAK_TF, "compulsory_bytes": k["compulsory_bytes"],
                     "traffic_over_compulsory": (k["traffic"] / k["compulsory_bytes"]) if k["traffic"] else None}
                    if "issued_bf16_tflops" in k else {})}
@@ -648,8 +634,7 @@ def main():
                    "kernel_timing": (f"`{live_op}` (the dominant kernel, found in the warm-up steps) bracketed by HIP events in every timed step; the other "
                                      "kernels' rows from 5 steps with every op bracketed right after the timed region (twelve event pairs per step cost 1 % of the line)"
                                      if live_op is not None else "every op bracketed by HIP events"),
-                   "streams": args.streams, "pipeline": ("shadow: bp(i+1) and ncc(i-1) beside pair(i); per-kernel table from 5 eager steps after the timed region"
-                                                         if args.streams == 3 else None), "hip_graph": bool(args.graph), "conv0_split": bool(args.conv0_split),
+                   "streams": 1, "hip_graph": bool(args.graph), "conv0_split": bool(args.conv0_split and not pair01_ran),
                    "fused_pair01": pair01_ran,
                    "untimed_before_warmup": f"{ramp_steps} steps ({args.ramp_seconds:g} s clock ramp), then {args.warmup} warm-up steps"},
         "roofline": roof(dominant),

@@ -40,7 +40,10 @@ extern "C" {
 #define LR_MAX_VIEWS 32  /* emitter poses travel in kernel arguments        */
 
 const char* lr_strerror(int code);
-/* ABI version; bumped when a signature changes. */
+/* ABI version; bumped when a signature or a documented behaviour changes.  2 (round 5): the LIFTREG_* switches below are read
+ * ONCE per process (version 1 read them at every call) — call lr_reload_switches() after changing the environment; the
+ * register-light kernels (lr_backproject_light_f32, lr_pca_warp_light_f32) and the CU-masked stream calls (lr_stream_*) of
+ * version 1 are gone; lr_drr_forward_batch_f32 is new. */
 int lr_abi_version(void);
 /* Name of the code object's target ("gfx950"). */
 const char* lr_target_arch(void);
@@ -91,13 +94,6 @@ const char* lr_target_arch(void);
  */
 int lr_reload_switches(void);
 const char* lr_switch_name(int id);
-
-/* A HIP stream restricted to the compute units of `mask` (nwords 32-bit words, bit i = CU i; consecutive bits go round-robin over
- * the XCDs, so a contiguous range is spread evenly over the dies): hipExtStreamCreateWithCUMask through the runtime this library is
- * bound to.  For CU-partitioned pipelines (liftreg_amd/pipeline.py: TwoStreamRegistrar(decode_cus=…); measured not to pay,
- * profiles/NOTES_r04.md).  lr_stream_destroy releases it. */
-int lr_stream_create_cu_mask(const uint32_t* mask, int nwords, void** stream_out);
-int lr_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------------
  * K1  DRR cone-beam forward projector.
@@ -159,14 +155,6 @@ int lr_drr_sample_coords_f32(const float* poses, const float* spacing, float* pi
 int lr_backproject_f32(const float* proj, const float* poses, float* out,
                        int B, int P, int Pw, int Ph, int D, int W, int H,
                        int d0, int d1, int64_t out_batch_stride, void* stream);
-
-/* lr_backproject_f32 through the register-light kernel (one voxel per thread, 28 registers, no LDS; the same results bit for
- * bit, 0.36 instead of 0.27 ms alone at C3): its waves fit beside the fused pair kernel's on every CU, so a pipeline
- * (liftreg_amd/pipeline.py: ShadowRegistrar) runs the NEXT batch's backprojection on a second stream in the shadow of the
- * current batch's lr_conv3d_pair01_f32.  Replaces the same reference lines (…Backproj.py:85-93). */
-int lr_backproject_light_f32(const float* proj, const float* poses, float* out,
-                             int B, int P, int Pw, int Ph, int D, int W, int H,
-                             int d0, int d1, int64_t out_batch_stride, void* stream);
 
 /* Parity / API compatibility (backproj_grids_with_poses): detector coordinates of every
  * voxel shadow. normalized=0: pixel units; normalized=1: the reference's [-1,1] grid.
@@ -507,14 +495,6 @@ int lr_conv3d_first_fused_bp_f32(const float* in0, const float* proj, const floa
 int lr_pca_warp_f32(const float* coefs, const float* basis, const float* mean, const float* img, const float* id0,
                     const float* id1, const float* id2, float* disp, float* phi, float* warped, int B, int L, int C,
                     int D, int W, int H, int64_t ldb, int flags, void* stream);
-/* lr_pca_warp_f32 (single-channel image, fp32 basis, whole volume, B <= 8) through a register-light persistent kernel — one voxel
- * per thread, 84 registers instead of 213, the same results bit for bit — for a launch on a second stream beside
- * lr_conv3d_pair01_f32, whose waves leave part of every SIMD's register file free (liftreg_amd/pipeline.py).
- *   coefs_t : dev (Lp, 8) fp32, the coefficients TRANSPOSED and zero-padded (rows L..Lp-1, columns B..7), Lp = L rounded up to 8
- *   blocks  : persistent 256-thread blocks (0 = one per CU).  Replaces …Backproj.py:102 + :68-69 like lr_pca_warp_f32. */
-int lr_pca_warp_light_f32(const float* coefs_t, const float* basis, const float* mean, const float* img,
-                          const float* id0, const float* id1, const float* id2, float* disp, float* phi, float* warped,
-                          int B, int L, int D, int W, int H, int64_t ldb, int flags, int blocks, void* stream);
 
 int lr_pca_warp_bf16basis_f32(const float* coefs, const void* basis_bf16, const float* mean, const float* img,
                               const float* id0, const float* id1, const float* id2, float* disp, float* phi,

@@ -35,7 +35,6 @@ SIGNATURES = {
     "lr_hu_to_mu_f32": (_i, [_p, _p, _i64, _p]),
     "lr_drr_sample_coords_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "lr_backproject_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _p]),
-    "lr_backproject_light_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _p]),
     "lr_backproject_coords_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "lr_backproject_coords_poseless_f64": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "lr_sample_points_f64": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
@@ -60,9 +59,6 @@ SIGNATURES = {
     "lr_conv3d_pair01_slab_f32": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _i64, _i, _i, _i, _i, _p]),
     "lr_conv3d_first_fused_bp_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "lr_pca_warp_f32": (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _i, _i64, _i, _p]),
-    "lr_stream_create_cu_mask": (_i, [_p, _i, _p]),
-    "lr_stream_destroy": (_i, [_p]),
-    "lr_pca_warp_light_f32": (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _i64, _i, _i, _p]),
     "lr_pca_warp_bf16basis_f32": (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _i, _i64, _i, _p]),
     "lr_pca_warp_slab_f32": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i,
                                   _p, _p, _p, _p]),
@@ -150,7 +146,14 @@ def reload_switches():
 
 # Tests and A/B tools flip switches between two launches of ONE process.  With AUTOSYNC on (tests/conftest.py sets it; never in
 # production) every launch first compares the switches' environment values with the last snapshot and reloads on a change.
-AUTOSYNC = bool(os.environ.get("LIFTREG_SWITCH_AUTOSYNC"))
+def _env_int(name, dflt=0):
+    try:
+        return int(os.environ.get(name, dflt))
+    except ValueError:
+        return dflt
+
+
+AUTOSYNC = _env_int("LIFTREG_SWITCH_AUTOSYNC") != 0      # "0" and unset are off
 _switch_names = None
 _switch_snapshot = None
 

@@ -602,7 +602,7 @@ int fill_poses(LrPoses& lp, const float* poses, int P) {
 
 static int backproject_impl(const float* proj, const float* poses, float* out,
                             int B, int P, int Pw, int Ph, int D, int W, int H,
-                            int d0, int d1, int64_t out_batch_stride, bool light, void* stream) {
+                            int d0, int d1, int64_t out_batch_stride, void* stream) {
   if (!proj || !out) return LR_ENULL;
   if (B < 1 || Pw < 1 || Ph < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
   if (d0 < 0 || d1 > D || d1 <= d0) return LR_EINVAL;
@@ -612,9 +612,7 @@ static int backproject_impl(const float* proj, const float* poses, float* out,
   if (out_batch_stride < (int64_t)P * Ds * W * H) return LR_EINVAL;
   // Tiled kernel: H <= 1024 (<= 4 columns per thread) and the staged rows fit in LDS.
   const size_t tile_lds = ((size_t)BT_RCAP * (Ph + 2 * BT_PAD) + 4 * BT_TI * BT_TJ) * sizeof(float);
-  // light: the plain one-voxel-per-thread kernel (28 registers, no LDS; same bits) — 0.36 instead of 0.27 ms alone at C3, but
-  // its waves fit beside the fused pair kernel's on every CU: a pipeline runs it in that kernel's shadow (liftreg_amd/pipeline.py)
-  if (H <= 1024 && tile_lds <= 64 * 1024 && !light) {
+  if (H <= 1024 && tile_lds <= 64 * 1024) {
     const int64_t nb = (int64_t)P * ((Ds + BT_TI - 1) / BT_TI) * ((W + BT_TJ - 1) / BT_TJ);
     if (nb > 0x7fffffffLL) return LR_EINVAL;
     const bool v4 = (Ph % 4 == 0) && ((reinterpret_cast<uintptr_t>(proj) & 15u) == 0);
@@ -633,7 +631,7 @@ static int backproject_impl(const float* proj, const float* poses, float* out,
     return lr_launch_status();
   }
   const bool vec4 = (H % 4 == 0) && (out_batch_stride % 4 == 0) &&
-                    ((reinterpret_cast<uintptr_t>(out) & 15u) == 0) && !light;
+                    ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
   const int64_t total = (int64_t)P * Ds * W * (vec4 ? H / 4 : H);
   const int64_t nblk = (total + 255) / 256;
   if (nblk > 0x7fffffffLL) return LR_EINVAL;
@@ -649,15 +647,7 @@ static int backproject_impl(const float* proj, const float* poses, float* out,
 extern "C" int lr_backproject_f32(const float* proj, const float* poses, float* out,
                                   int B, int P, int Pw, int Ph, int D, int W, int H,
                                   int d0, int d1, int64_t out_batch_stride, void* stream) {
-  return backproject_impl(proj, poses, out, B, P, Pw, Ph, D, W, H, d0, d1, out_batch_stride, false, stream);
-}
-
-// lr_backproject_f32 through the register-light kernel (same results bit for bit): for a pipeline that runs the
-// backprojection of the next batch on a second stream beside the fused pair kernel of the current one.
-extern "C" int lr_backproject_light_f32(const float* proj, const float* poses, float* out,
-                                        int B, int P, int Pw, int Ph, int D, int W, int H,
-                                        int d0, int d1, int64_t out_batch_stride, void* stream) {
-  return backproject_impl(proj, poses, out, B, P, Pw, Ph, D, W, H, d0, d1, out_batch_stride, true, stream);
+  return backproject_impl(proj, poses, out, B, P, Pw, Ph, D, W, H, d0, d1, out_batch_stride, stream);
 }
 
 // (B,P,Pw,Ph) views + (B,1,D,W,H) moving image -> rows [d0,d1) of the bf16 channels-last encoder input (B,Ds,W,H,16):

@@ -226,7 +226,10 @@ constexpr int dense_need(int set, int n) {   // the slot of the first MFMA that 
   if (n == 13) return base + 17 + 8;
   return base + 17 + 12 + (n - 14);
 }
-constexpr int DENSE_PRE = 6, DENSE_AHEAD = 8;
+#ifndef LR_C01_DENSE_AHEAD
+#define LR_C01_DENSE_AHEAD 8
+#endif
+constexpr int DENSE_PRE = 6, DENSE_AHEAD = LR_C01_DENSE_AHEAD;
 constexpr int dense_load_at(int g) {   // -1 | set * 16 + n: the fragment load issued behind MFMA slot g
   int set = 0, n = DENSE_PRE;
   for (int s = 0; s <= g; ++s) {

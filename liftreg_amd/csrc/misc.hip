@@ -13,7 +13,9 @@ extern "C" const char* lr_strerror(int code) {
   }
 }
 
-extern "C" int lr_abi_version(void) { return 1; }
+// 2 (round 5): the LIFTREG_* switches are read ONCE per process (lr_reload_switches re-reads them); the register-light kernels and the
+// CU-masked stream calls of version 1 are gone; lr_drr_forward_batch_f32 and the five-channel pair kernel are new
+extern "C" int lr_abi_version(void) { return 2; }
 
 extern "C" const char* lr_target_arch(void) { return "gfx950"; }
 
@@ -79,19 +81,3 @@ extern "C" int lr_reload_switches(void) {
 }
 
 extern "C" const char* lr_switch_name(int id) { return (id >= 0 && id < LR_SW_COUNT) ? kSwitchNames[id] : nullptr; }
-
-// A HIP stream whose kernels run only on the compute units of `mask` (bit i of word i / 32 = CU i; the driver deals consecutive
-// bits round-robin over the XCDs) — created by the runtime THIS library is bound to, so the handle is valid for every lr_* call.
-extern "C" int lr_stream_create_cu_mask(const uint32_t* mask, int nwords, void** stream_out) {
-  if (!mask || !stream_out) return LR_ENULL;
-  if (nwords < 1) return LR_EINVAL;
-  hipStream_t st = nullptr;
-  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)nwords, mask) != hipSuccess || !st) return LR_ELAUNCH;
-  *stream_out = st;
-  return LR_OK;
-}
-
-extern "C" int lr_stream_destroy(void* stream) {
-  if (!stream) return LR_ENULL;
-  return hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)) == hipSuccess ? LR_OK : LR_ELAUNCH;
-}

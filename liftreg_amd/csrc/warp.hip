@@ -530,91 +530,6 @@ __global__ __launch_bounds__(256) void pca_warp_kernel(const float* __restrict__
   }
 }
 
-// ---- the decode for a launch BESIDE the fused pair kernel (tools/light_decode_probe.py) -----------------------
-// pca_warp_kernel needs 213 registers per lane; two waves of the pair kernel leave 64 of a SIMD's 512.  This form owns ONE voxel
-// per thread and all (<= 8) batch rows (24 accumulators), streams the basis with 4-byte loads, 3 x LR_PWL_U of them in flight,
-// takes the coefficients as scalars ((L,8) transposed, zero-padded rows) and walks the volume with a persistent grid (a wave that
-// rides in a spare slot must carry its own parallelism: one-shot waves of one voxel each are dispatch-bound there).  The fmaf
-// chain per element is pca_kernel's, the sample is tri_sample_fast: the bits of lr_pca_warp_f32.  C == 1, fp32 basis, whole volume.
-#ifndef LR_PWL_U
-#define LR_PWL_U 8
-#endif
-template <bool SCALE>
-__global__ __launch_bounds__(256) void pca_warp_light_kernel(
-    const float* __restrict__ coefs_t, const float* __restrict__ basis, const float* __restrict__ mean,
-    const float* __restrict__ img, const float* __restrict__ id0, const float* __restrict__ id1, const float* __restrict__ id2,
-    float* __restrict__ disp_out, float* __restrict__ phi_out, float* __restrict__ warped, int B, int L, int D, int W, int H,
-    int64_t ldb) {
-  const int sD = W * H;
-  const int V = D * sD;   // 4 V + 4 sD <= 2^31 (launcher)
-  const int nthr = (int)gridDim.x * 256;
-  for (int m = (int)blockIdx.x * 256 + (int)threadIdx.x; m < V; m += nthr) {
-    float acc[8][3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float mu = mean[(int64_t)c * V + m];
-#pragma unroll
-      for (int b = 0; b < 8; ++b) acc[b][c] = mu;
-    }
-    const unsigned vo = (unsigned)m * 4u;
-    for (int l0 = 0; l0 < L; l0 += LR_PWL_U) {
-      // ONE buffer resource per chunk of LR_PWL_U basis rows (its bytes < 2^31: launcher); row and component go in the scalar offset
-      const __amdgpu_buffer_rsrc_t rb =
-          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(basis + (int64_t)l0 * ldb), (short)0, 0x7ffffffc, 0x00020000);
-      float v[LR_PWL_U][3];
-#pragma unroll
-      for (int u = 0; u < LR_PWL_U; ++u) {
-        const int lu = l0 + u < L ? u : L - 1 - l0;   // (the tail re-reads the last row; its coefficients below are 0)
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-          v[u][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (int)vo, (int)(((int64_t)lu * ldb + (int64_t)c * V) * 4), 2));
-      }
-#pragma unroll
-      for (int u = 0; u < LR_PWL_U; ++u) {
-        const float* cr = coefs_t + (int64_t)(l0 + u) * 8;   // uniform: scalar loads; rows L .. are zeros (caller pads to a multiple of U)
-        // two batch rows per v_pk_fma_f32 (the same fused multiply-add per element as fmaf: the bits of pca_kernel) — half the
-        // vector instructions this kernel puts into the issue slots it shares with the pair kernel
-        typedef float f32x2w __attribute__((ext_vector_type(2)));
-#pragma unroll
-        for (int b = 0; b < 8; b += 2) {
-          const f32x2w cf = {cr[b], cr[b + 1]};
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const f32x2w vv = {v[u][c], v[u][c]};
-            f32x2w a2 = {acc[b][c], acc[b + 1][c]};
-            a2 = __builtin_elementwise_fma(cf, vv, a2);
-            acc[b][c] = a2[0]; acc[b + 1][c] = a2[1];
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);   // one row's eight coefficients at a time (else all 64 scalars are fetched up front and spill)
-      }
-    }
-    const int i = m / sD, rem = m - i * sD, j = rem / H, k = rem - j * H;
-    const float a0 = id0[i], a1 = id1[j], a2 = id2[k];
-    float res[8];
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      if (b >= B) break;
-      const __amdgpu_buffer_rsrc_t rsrc =
-          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img + (int64_t)b * V), (short)0, V * 4, 0x00020000);
-      res[b] = tri_sample_fast<SCALE>(rsrc, acc[b][0] + a0, acc[b][1] + a1, acc[b][2] + a2, D, W, H, sD);
-      __builtin_amdgcn_sched_barrier(0);   // one row at a time: its eight taps and weights are the register peak
-    }
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      if (b >= B) break;
-      float* dp = disp_out + (int64_t)b * 3 * V + m;
-      float* pp = phi_out + (int64_t)b * 3 * V + m;
-      __builtin_nontemporal_store(acc[b][0], dp);
-      __builtin_nontemporal_store(acc[b][1], dp + V);
-      __builtin_nontemporal_store(acc[b][2], dp + 2 * (int64_t)V);
-      __builtin_nontemporal_store(acc[b][0] + a0, pp);
-      __builtin_nontemporal_store(acc[b][1] + a1, pp + V);
-      __builtin_nontemporal_store(acc[b][2] + a2, pp + 2 * (int64_t)V);
-      __builtin_nontemporal_store(res[b], warped + (int64_t)b * V + m);
-    }
-  }
-}
 
 __global__ __launch_bounds__(256) void mask_compose_kernel(const float* __restrict__ img,
                                                            const float* __restrict__ seg,
@@ -739,42 +654,6 @@ extern "C" int lr_pca_warp_f32(const float* coefs, const float* basis, const flo
                                void* stream) {
   return pca_warp_impl(false, coefs, basis, mean, img, id0, id1, id2, disp, phi, warped, B, L, C, D, W, H, 0, D, ldb,
                        (int64_t)D * W * H, flags, nullptr, nullptr, nullptr, stream);
-}
-
-// lr_pca_warp_f32 (single-channel image, fp32 basis, whole volume, B <= 8) through the register-light persistent kernel: the same
-// results bit for bit, for a launch on a second stream beside lr_conv3d_pair01_f32 (liftreg_amd/pipeline.py).
-//   coefs_t : dev (Lp, 8) fp32 — the coefficients TRANSPOSED, rows L .. Lp-1 and columns B .. 7 zero, Lp = L rounded up to a
-//             multiple of 8;  blocks: persistent 256-thread blocks (0 = one per CU)
-extern "C" int lr_pca_warp_light_f32(const float* coefs_t, const float* basis, const float* mean, const float* img,
-                                     const float* id0, const float* id1, const float* id2, float* disp, float* phi, float* warped,
-                                     int B, int L, int D, int W, int H, int64_t ldb, int flags, int blocks, void* stream) {
-  if (!coefs_t || !basis || !mean || !img || !id0 || !id1 || !id2 || !disp || !phi || !warped) return LR_ENULL;
-  if (B < 1 || L < 1 || D < 1 || W < 1 || H < 1 || blocks < 0) return LR_EINVAL;
-  if (flags & ~LR_WARP_USING_SCALE) return LR_EUNSUPPORTED;
-  const int64_t sD = (int64_t)W * H, V = sD * D;
-  if (B > 8 || L > 2048 || ldb < 3 * V) return LR_EUNSUPPORTED;
-  if (!(V * 4 + sD * 4 <= 0x80000000LL && sD < (1 << 23) && D <= 65535)) return LR_EUNSUPPORTED;
-  // the kernel addresses LR_PWL_U basis rows through ONE buffer resource with 31-bit scalar offsets
-  if (((int64_t)(LR_PWL_U - 1) * ldb + 3 * V) * 4 >= 0x7fffffffLL) return LR_EUNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(coefs_t) & 31u) || ((reinterpret_cast<uintptr_t>(basis) | reinterpret_cast<uintptr_t>(mean) |
-       reinterpret_cast<uintptr_t>(disp) | reinterpret_cast<uintptr_t>(phi) | reinterpret_cast<uintptr_t>(warped)) & 3u))
-    return LR_EALIGN;
-  int nb = blocks;
-  if (nb == 0) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    nb = cus;
-  }
-  const int64_t need = (V + 255) / 256;
-  if (nb > need) nb = (int)need;
-  hipStream_t st = lr_stream(stream);
-  if (flags & LR_WARP_USING_SCALE)
-    hipLaunchKernelGGL(pca_warp_light_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, coefs_t, basis, mean, img, id0, id1, id2,
-                       disp, phi, warped, B, L, D, W, H, ldb);
-  else
-    hipLaunchKernelGGL(pca_warp_light_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, coefs_t, basis, mean, img, id0, id1, id2,
-                       disp, phi, warped, B, L, D, W, H, ldb);
-  return lr_launch_status();
 }
 
 extern "C" int lr_pca_warp_bf16basis_f32(const float* coefs, const void* basis_bf16, const float* mean, const float* img,

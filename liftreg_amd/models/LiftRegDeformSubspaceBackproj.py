@@ -49,6 +49,7 @@ class model(nn.Module):
     # bf16 inference: from this many views on, the encoder input is written as 32-byte channels-last bf16 records
     # (ops.backproject_encoder_input_bf16) instead of the fp32 planar feature volume (4 (P + 1) bytes per voxel)
     ENCIN_MIN_VIEWS = 8
+    PAIR01_MAX_VIEWS = 4   # fp32 inference: up to this many views the first block reads `moving` and the views from their own buffers (pair kernel: Cin <= 5)
 
     def __init__(self, img_sz, opt=None):
         super().__init__()
@@ -302,30 +303,30 @@ class model(nn.Module):
     def _packed_weight(self, i, bf16=False):
         blk = self.encoders[i]
         w = blk.conv.weight
-        key = (w.data_ptr(), w._version, str(w.device))
+        # the cache holds the weight TENSOR it was packed from and compares identity + version: an address-based key would
+        # accept a replaced Parameter that landed on the freed address with the same version counter
         hit = self._packed.get((i, bf16))
         if self.training and w.requires_grad:
             hit = None                       # training: never trust the cache (see invalidate_packed)
-        if hit is None or hit[0] != key:
+        if hit is None or hit[0] is not w or hit[1] != w._version:
             if bf16:
                 pk = ops.conv3d_pack_weights_bf16_planar(w) if i == 0 else ops.conv3d_pack_weights_bf16(w)
             else:
                 pk = ops.conv3d_pack_weights(w, blk.in_layout)
-            hit = (key, pk)
+            hit = (w, w._version, pk)
             self._packed[(i, bf16)] = hit
-        return hit[1]
+        return hit[2]
 
     def _packed_pair01(self):
         """The split-operand fragments of encoder blocks 0 and 1 (ops.conv3d_pair01_pack), cached like _packed_weight."""
         w0, w1 = self.encoders[0].conv.weight, self.encoders[1].conv.weight
-        key = (w0.data_ptr(), w0._version, w1.data_ptr(), w1._version, str(w0.device))
         hit = self._packed.get("pair01")
         if self.training and (w0.requires_grad or w1.requires_grad):
             hit = None
-        if hit is None or hit[0] != key:
-            hit = (key, ops.conv3d_pair01_pack(w0, w1))
+        if hit is None or hit[0] is not w0 or hit[1] is not w1 or hit[2] != (w0._version, w1._version):
+            hit = (w0, w1, (w0._version, w1._version), ops.conv3d_pair01_pack(w0, w1))
             self._packed["pair01"] = hit
-        return hit[1]
+        return hit[3]
 
     def _estimate_flow(self, moving, target_proj, poses):
         coefs = self.encode(moving, target_proj, poses)
@@ -333,7 +334,7 @@ class model(nn.Module):
         disp = ops.pca_reconstruct(coefs, self.pca_vectors_LxM, self.pca_mean).view(B, 3, D, W, H)
         return coefs, disp
 
-    def backproject_views(self, target_proj, poses, img_shape, out=None, light=False):
+    def backproject_views(self, target_proj, poses, img_shape, out=None):
         """target_volume (:89-93) alone: the (B,P,D,W,H) backprojection of the views.  A pipeline computes it for batch
         i+1 while batch i's MFMA-bound blocks run (liftreg_amd/pipeline.py) and hands it to encode(target_volume=…)."""
         if self._poses is None:
@@ -343,7 +344,7 @@ class model(nn.Module):
         B, P = target_proj.shape[:2]
         if out is None:
             out = torch.empty((B, P, D, W, H), dtype=torch.float32, device=target_proj.device)
-        ops.backproject(target_proj, self._poses, (D, W, H), out=out, out_batch_stride=P * D * W * H, light=light)
+        ops.backproject(target_proj, self._poses, (D, W, H), out=out, out_batch_stride=P * D * W * H)
         return out
 
     def encode(self, moving, target_proj, poses, target_volume=None):
@@ -357,7 +358,7 @@ class model(nn.Module):
             self._poses = np.ascontiguousarray(p[0], dtype=np.float32)  # poses[0:1] (:87)
         V = D * W * H
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if self.conv_dtype != "bf16" and not needs_grad and P <= 2:
+        if self.conv_dtype != "bf16" and not needs_grad and P <= self.PAIR01_MAX_VIEWS:
             # inference, fp32: the first block reads `moving` and the backprojected views from their own buffers —
             # cat([moving, target_volume], dim=1) (:95-98) is never materialised (no copy of `moving`)
             mv = moving if moving.is_contiguous() else moving.contiguous()
@@ -450,16 +451,12 @@ class model(nn.Module):
             x = self.encoders[i](x, packed=self._packed_weight(i))
         return self.encoders[6](x)
 
-    def decode(self, moving, coefs, moving_seg=None, target=None, light=False):
+    def decode(self, moving, coefs, moving_seg=None, target=None):
         """HBM-bound half: PCA reconstruction → identity add + trilinear warp.  Returns (disp, phi, warped).
         `target` (inference, single-channel, opt key fuse_ncc): the similarity's five moments of (warped, target) are
         accumulated in the same pass and returned as a 4th value → output key "ncc_moments" (SURVEY §8 f1).
-        `light`: the register-light persistent kernel (same bits) — for a launch beside the next batch's pair kernel
-        (tools/light_decode_probe.py); falls back to the regular kernel where it does not apply."""
+        """
         B, C, D, W, H = moving.shape
-        if (light and moving_seg is None and not (torch.is_grad_enabled() and coefs.requires_grad) and
-                ops.pca_warp_light_supported(coefs, self.pca_vectors_LxM, moving)):
-            return ops.pca_warp_light(coefs, self.pca_vectors_LxM, self.pca_mean, (self._id0, self._id1, self._id2), moving)
         if (moving_seg is None and not (torch.is_grad_enabled() and coefs.requires_grad) and
                 ops.pca_warp_supported(coefs, self.pca_vectors_LxM, moving)):
             # inference: one pass writes params, phi and warped (SURVEY §8 f1) — the same bits as the two kernels below

@@ -167,9 +167,8 @@ def drr_sample_coords(poses, spacing, shape, resolution, device, normalized=Fals
 
 
 # ----------------------------------------------------------------------------- K2 backprojection
-def backproject(proj, poses, img_shape, *, d0=0, d1=None, out=None, out_batch_stride=None, light=False):
+def backproject(proj, poses, img_shape, *, d0=0, d1=None, out=None, out_batch_stride=None):
     """(B,P,Pw,Ph) views → (B,P,Ds,W,H) feature volume for ONE emitter geometry `poses` (P,3).
-    light: the register-light kernel (lr_backproject_light_f32: same bits; for a launch beside the pair kernel).
 
     Replaces backproj_grids_with_poses + F.grid_sample (reference …Backproj.py:85-93).
     `out` may be a view into a larger buffer whose batch stride is `out_batch_stride`
@@ -202,9 +201,8 @@ def backproject(proj, poses, img_shape, *, d0=0, d1=None, out=None, out_batch_st
                                  f"{out_batch_stride}, got shape {tuple(out.shape)} strides {tuple(out.stride())}")
         optr = out.data_ptr()
     with _timed("backproject", bytes=4 * (B * P * Ds * W * H + B * P * Pw * Ph), samples=B):
-        fn = _hip.lib().lr_backproject_light_f32 if light else _hip.lib().lr_backproject_f32
-        _hip.check(fn(proj.data_ptr(), poses.ctypes.data, optr, B, P, Pw, Ph, D, W, H, d0, d1, int(out_batch_stride), _stream()),
-                   "lr_backproject_light_f32" if light else "lr_backproject_f32")
+        _hip.check(_hip.lib().lr_backproject_f32(proj.data_ptr(), poses.ctypes.data, optr, B, P, Pw, Ph, D, W, H, d0, d1,
+                                                 int(out_batch_stride), _stream()), "lr_backproject_f32")
     return out
 
 
@@ -375,6 +373,18 @@ def conv3d_first_split(x0, rest, weight, bias, *, out_layout=LAYOUT_NCDHW, negat
                                                             y.data_ptr(), B, Cin, Cout, D, W, H, out_layout,
                                                             float(negative_slope), _stream()), "lr_conv3d_first_split_f32")
     return y
+
+
+def conv3d_pair01_shapes_supported(B, Cin, D, W, H, w0, w1, out_layout=LAYOUT_NDHWC_HPS):
+    """The shape half of `conv3d_pair01_supported` (no pointers, no strides): the same answer in every process."""
+    if not (2 <= Cin <= 4 and H % 4 == 0 and B >= 1 and D >= 1):
+        return False
+    if tuple(w0.shape) != (16, Cin, 3, 3, 3) or tuple(w1.shape) != (32, 16, 3, 3, 3):
+        return False
+    if out_layout not in (LAYOUT_NDHWC, LAYOUT_NDHWC_HPS) or (out_layout == LAYOUT_NDHWC_HPS and ((H - 1) // 2 + 1) % 2):
+        return False
+    V = D * W * H
+    return 12 * V + 32 * W * H < 2 ** 31 - 1 and ((W - 1) // 2 + 1) * ((H - 1) // 2 + 1) * 128 < 2 ** 31 - 1
 
 
 def conv3d_pair01_supported(x0, rest, w0, w1, out_layout=LAYOUT_NDHWC_HPS, probe=False):
@@ -793,37 +803,6 @@ def pca_warp_supported(coefs, basis_LxM, img, d0=0, d1=None):
     return (H % 4 == 0 and cols in (3 * V, 3 * Dn * W * H) and basis_LxM.stride(1) == 1 and basis_LxM.stride(0) % 4 == 0 and
             basis_LxM.shape[0] <= 2048 and 4 * V + 4 * W * H <= 2 ** 31 and W * H < 2 ** 22 and D <= 65535 and
             coefs.shape[0] == B)
-
-
-def pca_warp_light_supported(coefs, basis_LxM, img):
-    B, C, D, W, H = img.shape
-    return (C == 1 and B <= 8 and basis_LxM.dtype == torch.float32 and basis_LxM.shape[1] == 3 * D * W * H and
-            pca_warp_supported(coefs, basis_LxM, img) and 8 * basis_LxM.stride(0) * 4 + 12 * D * W * H < 2 ** 31)
-
-
-def pca_warp_light(coefs, basis_LxM, mean, ids, img, *, using_scale=True, blocks=0):
-    """`pca_warp` through the register-light persistent kernel (lr_pca_warp_light_f32; same bits): for a launch on a second
-    stream beside the fused pair kernel (tools/light_decode_probe.py).  Single-channel image, fp32 basis, B <= 8."""
-    coefs, mean, img = _dev(coefs, "coefs"), _dev(mean, "mean"), _dev(img, "img")
-    if not pca_warp_light_supported(coefs, basis_LxM, img):
-        raise ValueError("pca_warp_light: unsupported shapes (use pca_warp)")
-    B, C, D, W, H = img.shape
-    L = basis_LxM.shape[0]
-    Lp = (L + 7) // 8 * 8
-    ct = torch.zeros((Lp, 8), dtype=torch.float32, device=img.device)
-    ct[:L, :B] = coefs.t()
-    i0, i1, i2 = (_dev(t, "id table") for t in ids)
-    disp = torch.empty((B, 3, D, W, H), dtype=torch.float32, device=img.device)
-    phi = torch.empty_like(disp)
-    warped = torch.empty((B, 1, D, W, H), dtype=torch.float32, device=img.device)
-    V = D * W * H
-    with _timed("pca_warp_light", bytes=4 * L * 3 * V + 4 * 3 * V + B * 4 * V * 8, samples=B):
-        _hip.check(_hip.lib().lr_pca_warp_light_f32(ct.data_ptr(), basis_LxM.data_ptr(), mean.data_ptr(), img.data_ptr(),
-                                                    i0.data_ptr(), i1.data_ptr(), i2.data_ptr(), disp.data_ptr(), phi.data_ptr(),
-                                                    warped.data_ptr(), B, L, D, W, H, basis_LxM.stride(0),
-                                                    _hip.WARP_USING_SCALE if using_scale else 0, int(blocks), _stream()),
-                   "lr_pca_warp_light_f32")
-    return disp, phi, warped
 
 
 def pca_warp(coefs, basis_LxM, mean, ids, img, *, using_scale=True, d0=0, d1=None, target=None):

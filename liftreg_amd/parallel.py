@@ -323,12 +323,18 @@ class SlabShardedRegistration:
         # rank's OWN backprojection: no halo exchange for the two big blocks, no 16-channel activation, and the same bits as
         # the unsharded model
         b0_, b1_ = net.encoders[0], net.encoders[1]
-        pair = (not bf16 and getattr(net, "fuse_pair01", False) and P <= 2 and b1_.stride == 2 and
-                b0_.out_layout == b1_.in_layout and all(d0 % 2 == 0 and d1 % 2 == 0 for d0, d1 in bounds) and
-                all(ops.conv3d_pair01_supported(inp["source"][:, :, max(d0 - 2, 0):min(d1 + 1, D)],
-                                                torch.empty((B, P, min(d1 + 1, D) - max(d0 - 2, 0), W, H), device="meta"),
-                                                b0_.conv.weight, b1_.conv.weight, layouts(1)[1], probe=True)
-                    for inp, (d0, d1) in zip(inputs, bounds)))
+        # The decision gates the block-0/1 halo collectives, so it must be the SAME on every rank: it looks at the slabs of ALL
+        # ranks of the world (shapes only), never at this process's pointers.
+        all_bounds = [slab_bounds(D, comm.world, r) for r in range(comm.world)]
+        pair = (not bf16 and getattr(net, "fuse_pair01", False) and P <= 3 and b1_.stride == 2 and
+                b0_.out_layout == b1_.in_layout and all(d0 % 2 == 0 and d1 % 2 == 0 for d0, d1 in all_bounds) and
+                all(ops.conv3d_pair01_shapes_supported(B, P + 1, min(d1 + 1, D) - max(d0 - 2, 0), W, H, b0_.conv.weight,
+                                                       b1_.conv.weight, layouts(1)[1]) for d0, d1 in all_bounds))
+        if pair:   # what the shape rule cannot see is a property of this process alone: fail loudly, never diverge silently
+            for inp, (d0, d1) in zip(inputs, bounds):
+                v = inp["source"][:, :, max(d0 - 2, 0):min(d1 + 1, D)]
+                if v.data_ptr() % 16 or not v[0].is_contiguous() or (B > 1 and v.stride(0) % 4):
+                    raise ValueError("SlabShardedRegistration: `source` must be a contiguous, 16-byte aligned tensor")
         st = []                                     # per local rank: buffers and views
         for inp, (d0, d1) in zip(inputs, bounds):
             moving = inp["source"]

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(hip):
         assert hasattr(raw, name), f"{name} declared in the header but not exported"
     assert sorted(hip.SIGNATURES) == declared                      # binding covers exactly the header
     lib = hip.lib()
-    assert lib.lr_abi_version() == 1 and lib.lr_target_arch() == b"gfx950"
+    assert lib.lr_abi_version() == 2 and lib.lr_target_arch() == b"gfx950"
 
 
 def test_argument_validation_without_gpu(hip):

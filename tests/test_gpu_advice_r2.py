@@ -115,97 +115,6 @@ def test_packed_weight_cache_follows_state_dict_and_explicit_invalidation(dev):
     np.testing.assert_allclose(d.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=1e-6)
 
 
-def test_two_stream_registrar_serving_loop_that_drops_its_batches(dev):
-    """Each batch is created, submitted and dropped; the next batch's allocation may reuse its blocks on the caller's
-    stream.  With the inputs recorded on the encode/decode streams the results equal the plain forward's."""
-    from liftreg_amd.layers.losses import NCCLoss
-    from liftreg_amd.pipeline import TwoStreamRegistrar
-    net = _net(dev)
-    sim = NCCLoss(check_nan=False)
-    reg = TwoStreamRegistrar(net, sim)
-    want = []
-    with torch.no_grad():
-        for i in range(6):
-            b = _batch(dev, seed=i)
-            o = net(b)
-            want.append((o["warped"].clone(), float(sim(o["warped"], o["target"]))))
-        torch.cuda.synchronize()
-        got = []
-        for i in range(6):
-            b = _batch(dev, seed=i)
-            out, loss = reg.submit(b)
-            got.append((out["warped"], loss))
-            del b, out                                    # the caller drops the batch right after submit()
-            junk = torch.full((2, 1, 32, 32, 32), float(i), device=dev)   # and allocates again on its own stream
-            del junk
-        reg.synchronize()
-    for (w, l), (gw, gl) in zip(want, got):
-        assert torch.equal(w, gw) and abs(l - float(gl)) < 1e-6
-
-
-@pytest.mark.parametrize("labels", [False, True])
-def test_shadow_registrar_equals_the_plain_forward(dev, labels):
-    """liftreg_amd/pipeline.py: ShadowRegistrar — the next batch's backprojection (register-light kernel) and the previous
-    batch's NCC moments run on side streams beside the fused pair kernel; every batch's outputs and loss equal the plain
-    forward's bit for bit (same kernels' arithmetic, same order inside a batch), also when the caller drops its batches."""
-    from liftreg_amd.layers.losses import NCCLoss
-    from liftreg_amd.pipeline import ShadowRegistrar
-    net = _net(dev, n=64)
-    sim = NCCLoss(check_nan=False)
-    reg = ShadowRegistrar(net, sim)
-    want = []
-    with torch.no_grad():
-        for i in range(5):
-            b = _batch(dev, n=64, seed=i, labels=labels)
-            o = net(b)
-            want.append((o["warped"].clone(), o["phi"].clone(), o["pca_coefs"].clone(), float(sim(o["warped"], o["target"]))))
-        torch.cuda.synchronize()
-        got = []
-        for i in range(5):
-            b = _batch(dev, n=64, seed=i, labels=labels)
-            out, loss = reg.submit(b)
-            got.append((out["warped"], out["phi"], out["pca_coefs"], loss))
-            del b, out
-            junk = torch.full((2, 1, 64, 64, 64), float(i), device=dev)
-            del junk
-        reg.synchronize()
-    for (w, p, c, l), (gw, gp, gc, gl) in zip(want, got):
-        assert torch.equal(c, gc) and torch.equal(p, gp) and torch.equal(w, gw) and abs(l - float(gl)) < 1e-6
-
-
-@pytest.mark.parametrize("B,n,L", [(2, 32, 6), (8, 48, 11), (3, 40, 16)])
-def test_pca_warp_light_kernel_same_bits(dev, B, n, L):
-    """lr_pca_warp_light_f32 (one voxel per thread, persistent grid, coefficients as scalars, packed FMAs): the bits of the
-    one-pass decode lr_pca_warp_f32 — disp, phi and warped — for every batch size up to 8 and a latent size that is not a
-    multiple of its 8-row chunks."""
-    from liftreg_amd import ops
-    net = _net(dev, n=n, L=L)
-    b = _batch(dev, n=n, B=B, seed=B + n)
-    with torch.no_grad():
-        coefs = net.encode(b["source"], b["target_proj"], b["target_poses"])
-        ids = (net._id0, net._id1, net._id2)
-        want = ops.pca_warp(coefs, net.pca_vectors_LxM, net.pca_mean, ids, b["source"])
-        for blocks in (0, 3):
-            got = ops.pca_warp_light(coefs, net.pca_vectors_LxM, net.pca_mean, ids, b["source"], blocks=blocks)
-            for w, g in zip(want, got):
-                assert torch.equal(w, g)
-        got = net.decode(b["source"], coefs, light=True)
-        assert all(torch.equal(w, g) for w, g in zip(want, got))
-
-
-def test_backproject_light_kernel_same_bits(dev):
-    from liftreg_amd import ops
-    from liftreg_amd.utils.sdct_projection_utils import scan_poses
-    g = torch.Generator(device=dev).manual_seed(5)
-    for (B, P, n, pw) in ((2, 2, 48, 40), (1, 3, 36, 52)):
-        proj = torch.rand(B, P, pw, pw, device=dev, generator=g)
-        poses = scan_poses(30, P, n).astype(np.float32)
-        a = ops.backproject(proj, poses, (n, n, n))
-        b = ops.backproject(proj, poses, (n, n, n), light=True)
-        c = ops.backproject(proj, poses, (n, n, n), d0=8, d1=24, light=True)
-        assert torch.equal(a, b) and torch.equal(a[:, :, 8:24], c)
-
-
 def test_slab_sharded_forward_masks_the_target_like_the_unsharded_model(dev):
     from liftreg_amd import parallel as par
     from liftreg_amd.layers.losses import NCCLoss

@@ -38,6 +38,8 @@ class OracleOps:
     def conv3d_pair01_supported(*_, **__):
         return False      # … and one kernel per encoder block
 
+    conv3d_pair01_shapes_supported = conv3d_pair01_supported
+
     @staticmethod
     def encoder_input_bf16_supported(*_):
         return False      # … and the fp32 feature volume
