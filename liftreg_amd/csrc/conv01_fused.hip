@@ -55,31 +55,40 @@ constexpr int R1Y = 2 * TY + 1;          // 9 rows of block 0's output a plane o
 constexpr int R0Y = R1Y + 2;             // 11 input rows
 constexpr int NQ0 = 6;                   // aligned float4 quads of an input row: x = 2*ox0 - 4 .. 2*ox0 + 19 (record p = x - (2*ox0 - 4))
 constexpr int SB0 = NQ0 * 4 * 8;         // 192 bytes: one split of a ring-0 row
-constexpr int RB0 = 3 * SB0;             // 576 = 64 mod 128: the k-block-3 lane pairs (two window rows apart) use opposite bank halves
-constexpr int PLB0 = R0Y * RB0 + 192;    // 6528 = 128 mod 256: neighbouring planes use opposite bank halves
-constexpr int NRING0 = 8;                // A reads planes 2s-1 .. 2s+2 (and, ahead of the barrier, its first fragments of step s+1: .. 2s+3) while B writes 2s+5, 2s+6
-constexpr int PA0 = NRING0 - 6;          // planes the staging runs ahead of what the next step reads
-constexpr int NPRO0 = 4 + PA0;           // planes the unit prologue stages
-constexpr int RING0 = NRING0 * PLB0;     // 52224
 constexpr int QS1 = 17;                  // 8-byte chunks between the channel-quad runs of a ring-1 row (odd)
 constexpr int RS1 = 72;                  // chunks of a ring-1 row (= 8 mod 16)
 constexpr int SPB1 = R1Y * RS1 * 8;      // 5184 bytes: one split of a ring-1 plane
 constexpr int PLB1 = 3 * SPB1;           // 15552
 constexpr int NRING1 = 5;                // B reads planes 2s-3 .. 2s-1 while A writes 2s, 2s+1
-constexpr int RING1_OFF = RING0;
 constexpr int RING1 = NRING1 * PLB1;     // 77760
-constexpr int SCR_OFF = RING1_OFF + RING1;   // 116928
 constexpr int SCR = 2 * 4 * 3 * 64 * 16; // 24576: [step parity][B wave = K quarter][the three accumulators (tile, cout tile) it does not own][lane] partial sums
-constexpr int DUMP_OFF = SCR_OFF + SCR;  // 125120: where the threads without a staging item write
-constexpr int DUMPB = 64 * 16 + 2 * SB0 + 32;   // a 16-byte lane stride: the lanes without an item never write one address
-constexpr int LDSB = DUMP_OFF + ((DUMPB + 255) / 256) * 256;
+// Ring 0 (the split input planes) depends on the channel count: three 8-byte record arrays per voxel for <= 4 channels (one per
+// split; three channels: the dense records E, F, G), four for five channels (A1..A4, comment of dense5_records)
+template <int NC>
+struct Geo {
+  static constexpr int NARR = NC == 5 ? 4 : 3;
+  static constexpr int RB0 = NARR * SB0 + (NC == 5 ? 64 : 0);   // 576 | 832 = 64 mod 128: the lane pairs two window rows apart use opposite bank halves
+  static constexpr int PLB0 = R0Y * RB0 + 192;    // 6528 | 9344 = 128 mod 256: neighbouring planes use opposite bank halves
+  // NC <= 4: A reads planes 2s-1 .. 2s+2 (and, ahead of the barrier, its first fragments of step s+1: .. 2s+3) while B writes 2s+5,
+  // 2s+6; five channels (LDS): A reads 2s-1 .. 2s+2 while B writes 2s+3, 2s+4
+  static constexpr int NRING0 = NC == 5 ? 6 : 8;
+  static constexpr int PA0 = NRING0 - 6;          // planes the staging runs ahead of what the next step reads
+  static constexpr int NPRO0 = 4 + PA0;           // planes the unit prologue stages
+  static constexpr int RING0 = NRING0 * PLB0;     // 52224 | 56064
+  static constexpr int RING1_OFF = RING0;
+  static constexpr int SCR_OFF = RING1_OFF + RING1;
+  static constexpr int DUMP_OFF = SCR_OFF + SCR;  // where the threads without a staging item write
+  static constexpr int DUMPB = 64 * 16 + (NARR - 1) * SB0 + 32;   // a 16-byte lane stride: the lanes without an item never write one address
+  static constexpr int LDSB = DUMP_OFF + ((DUMPB + 255) / 256) * 256;
+  static_assert(NPRO0 * R0Y * NQ0 <= NTHR, "one staging item per thread");
+  static_assert((PLB0 & 255) == 128 && (RB0 & 127) == 64, "ring-0 bank geometry");
+  static_assert(LDSB <= 160 * 1024, "LDS");
+};
 constexpr int NITEM = 2 * R0Y * NQ0;     // 132 staging items of a step: (plane, row, x-quad), all channels
 constexpr int NKB1 = 4;   // k-blocks of block 0 | of a K quarter of block 1 (taps 0..7 | 8..15 | 16..21 | 22..26)
 constexpr unsigned OOR = 0x80000000u;
-static_assert(NITEM <= 3 * 44 && NPRO0 * R0Y * NQ0 <= NTHR, "one staging item per thread");
+static_assert(NITEM <= 3 * 44, "one staging item per thread");
 static_assert(4 * QS1 <= RS1 && (QS1 & 1) == 1 && (RS1 & 15) == 8, "ring-1 bank geometry");
-static_assert((PLB0 & 255) == 128 && (RB0 & 127) == 64, "ring-0 bank geometry");
-static_assert(LDSB <= 160 * 1024, "LDS");
 
 struct FDims {
   int B, Cin, D, W, H, Do, Wo, Ho;   // D = planes of the input buffers (a z-slab), Do = output planes to compute
@@ -206,43 +215,107 @@ __device__ __forceinline__ void dense_records(const unsigned (&p01)[3], const un
   rec[2][0] = (p01[1] & 0xffff0000u) | p2[2];
   rec[2][1] = p2[1];
 }
-constexpr int ND0 = 17;   // MFMAs (= weight fragments) of a dense block-0 tile, in chain order: WG[3] WE2[3] WF[3] WE1[3] WL[2] WE0[3]
-// leftover slot s = 0..14 (two MFMAs x 8 slots; 15: weight 0): tap (2, s / 5, 2), kind s % 5 = E x w0, E x w1, E x w2, F, G
-constexpr int dense_left_ty(int s) { return (s > 14 ? 14 : s) / 5; }
-constexpr int dense_left_arr(int s) { return (s > 14 ? 14 : s) % 5 < 3 ? 0 : (s > 14 ? 14 : s) % 5 - 2; }   // record array: E 0, F 1, G 2
-// the fragment loads of a step of the dense producer, in the order of their first use.  Fragment n of a pair of tiles:
-// 0..8 = G, E, F of input rows 0..2 (n / 3 = kind, n % 3 = row), 9, 10 = the upper tile's leftover fragments, 11..13 = G, E, F of
-// input row 3, 14, 15 = the lower tile's leftover fragments; the single tile has fragments 0..10.  MFMA slot g = 17 t + k of the
-// step (tiles t = 0..4) issues at most one fragment load: the next one whose first use is <= 8 slots away (LDS latency under
-// load; lgkmcnt counts 15 operations = 7 fragments in flight).  Fragments 0..5 of the first pair are requested in front.
-constexpr int dense_need(int set, int n) {   // the slot of the first MFMA that reads fragment n of set (0, 1 = the pairs, 2 = the single tile)
-  const int base = set * 34;
-  if (n < 3) return base + n;            // G rows 0..2: MFMAs 0..2 of the upper tile
-  if (n < 6) return base + 3 + (n - 3);  // E
-  if (n < 9) return base + 6 + (n - 6);  // F
-  if (n < 11) return base + 12 + (n - 9);
-  if (n == 11) return base + 17 + 2;     // G row 3: MFMA 2 of the lower tile
-  if (n == 12) return base + 17 + 5;
-  if (n == 13) return base + 17 + 8;
-  return base + 17 + 12 + (n - 14);
+// FIVE input channels (the reference's shipped configuration: four views): the 15 bf16 of a voxel as FOUR records
+//   A1 = [d0c0 d0c1 d0c2 d0c3]   A2 = [d0c4 d1c0 d1c1 d1c2]   A3 = [d1c3 d1c4 d2c0 d2c1]   A4 = [d2c2 d2c3 d2c4 d0c4]
+// and EIGHT record slots per tap, 30 exact products in 32 element slots:
+//   A1 x w0[c0..c3], A1 x w1[c0..c3], A1 x w2[c0..c3]          A2 x [w0c4 w0c0 w0c1 w0c2], A2 x [w1c4 w1c0 w1c1 w1c2]
+//   A3 x [w0c3 w0c4 w0c0 w0c1], A3 x [w1c3 w1c4 0 0]           A4 x [w0c2 w0c3 w0c4 w2c4]
+// 27 taps x 8 = 216 slots = 27 MFMAs per 16-voxel tile with no padding at all: per tap row ty the 8 taps without (2, ty, 2) form one
+// fragment per record kind (8 MFMAs), and the leftover tap (2, ty, 2) fills exactly one more (its 8 slots = the 8 patterns above).
+// Every fragment belongs to ONE tap row, so two vertically adjacent tiles share all of them.  Chain, small products first:
+// A1 w2, A4, A3 w1, A3 w0, A2 w1, A1 w1, leftover, A2 w0, A1 w0 (three tap rows each).
+__device__ __forceinline__ void dense5_records(const unsigned (&p01)[3], const unsigned (&p23)[3], const unsigned (&d4)[3], unsigned (&rec)[4][2]) {
+  rec[0][0] = p01[0];                          // (d4[s]: split s of channel 4 in the low half, high half 0)
+  rec[0][1] = p23[0];
+  rec[1][0] = d4[0] | (p01[1] << 16);
+  rec[1][1] = __builtin_amdgcn_alignbit(p23[1], p01[1], 16);
+  rec[2][0] = (p23[1] >> 16) | (d4[1] << 16);
+  rec[2][1] = p01[2];
+  rec[3][0] = p23[2];
+  rec[3][1] = d4[2] | (d4[0] << 16);
 }
+
+// The chain of a dense block-0 tile: which fragment each MFMA reads, the order the fragments are first used in, the loads.
+//   fragment n of a PAIR of vertically adjacent tiles (upper r = 0, lower r = 1; the single tile has the first NFS): the fragments
+//   of input rows 0..2 kind by kind in the order of their first use, then those of input row 3 (lower tile only).
+template <int NC> struct Chain;
+template <> struct Chain<3> {   // kinds: 0 G, 1 E, 2 F (arrays 2, 0, 1), 3 = the two leftover fragments of a tile (not shared)
+  static constexpr int NMF = 17, NFP = 16, NFS = 11;
+  static constexpr bool is_left(int n) { return (n >= 9 && n < 11) || n >= 14; }
+  static constexpr int arr(int n) { const int kind = n < 9 ? n / 3 : n - 11; return kind == 0 ? 2 : kind == 1 ? 0 : 1; }
+  static constexpr int iy(int n) { return n < 9 ? n % 3 : 3; }
+  static constexpr int left_w(int n) { return n < 11 ? n - 9 : n - 14; }          // which of the lane's leftover bases
+  static constexpr int left_row(int n) { return n < 11 ? 0 : 1; }                 // rows below the pair's first
+  static constexpr int frag(int k, int r) {
+    if (k >= 12 && k < 14) return (r == 0 ? 9 : 14) + (k - 12);
+    const int kind = k < 3 ? 0 : k < 6 ? 1 : k < 9 ? 2 : 1;     // G E F E (L L) E
+    const int i = r + (k < 12 ? k % 3 : k - 14);
+    return i < 3 ? kind * 3 + i : 11 + kind;
+  }
+  static constexpr int need(int n) {   // the MFMA slot (relative to the pair's first) of the fragment's first use
+    if (n < 9) return n;
+    if (n < 11) return 12 + (n - 9);
+    if (n < 14) return NMF + 2 + 3 * (n - 11);
+    return NMF + 12 + (n - 14);
+  }
+  static constexpr int epi_slice_at(int k) { return (k >= 2 && k <= 14 && (k & 1) == 0) ? k / 2 - 1 : -1; }
+};
+template <> struct Chain<5> {   // load kinds: 0 A1, 1 A4, 2 A3, 3 A2 (arrays 0, 3, 2, 1), 4 = the leftover fragment of a tap row (shared like the others)
+  static constexpr int NMF = 27, NFP = 20, NFS = 15;
+  static constexpr int lk(int n) { return n < 15 ? n / 3 : n - 15; }
+  static constexpr bool is_left(int n) { return lk(n) == 4; }
+  static constexpr int arr(int n) { return lk(n) == 0 ? 0 : lk(n) == 1 ? 3 : lk(n) == 2 ? 2 : 1; }
+  static constexpr int iy(int n) { return n < 15 ? n % 3 : 3; }
+  static constexpr int left_w(int) { return 0; }
+  static constexpr int left_row(int n) { return iy(n); }
+  static constexpr int phase_kind(int p) { return p == 0 ? 0 : p == 1 ? 1 : p == 2 ? 2 : p == 3 ? 2 : p == 4 ? 3 : p == 5 ? 0 : p == 6 ? 4 : p == 7 ? 3 : 0; }
+  static constexpr int frag(int k, int r) {
+    const int kind = phase_kind(k / 3), i = r + k % 3;
+    return i < 3 ? kind * 3 + i : 15 + kind;
+  }
+  static constexpr int first_phase(int kind) { return kind == 0 ? 0 : kind == 1 ? 1 : kind == 2 ? 2 : kind == 3 ? 4 : 6; }
+  static constexpr int need(int n) { return n < 15 ? first_phase(lk(n)) * 3 + iy(n) : NMF + first_phase(lk(n)) * 3 + 2; }
+  static constexpr int epi_slice_at(int k) { return (k >= 3 && k <= 21 && k % 3 == 0) ? k / 3 - 1 : -1; }
+};
+template <int NC, bool DENSE> constexpr int block0_fragments() { if constexpr (DENSE) return Chain<NC>::NMF; else return 12; }
+// MFMA slot g = NMF t + k of a step (tiles t = 0..4: pair 0 upper / lower, pair 1 upper / lower, the single tile) issues at most one
+// fragment load: the next one (sets 0, 1 = the pairs, 2 = the single tile, in the order above) whose first use is <= DENSE_AHEAD
+// slots away (LDS latency under load; lgkmcnt counts 15 operations = 7 fragments in flight).  The first DENSE_PRE fragments of the
+// step are requested in front (ahead of the barrier when ring 0 is staged a step early).
 #ifndef LR_C01_DENSE_AHEAD
 #define LR_C01_DENSE_AHEAD 8
 #endif
 constexpr int DENSE_PRE = 6, DENSE_AHEAD = LR_C01_DENSE_AHEAD;
-constexpr int dense_load_at(int g) {   // -1 | set * 16 + n: the fragment load issued behind MFMA slot g
+template <int NC>
+constexpr int dense_load_at(int g) {   // -1 | set * 32 + n: the fragment load issued behind MFMA slot g
+  using C = Chain<NC>;
   int set = 0, n = DENSE_PRE;
   for (int s = 0; s <= g; ++s) {
     if (set > 2) return -1;
-    const bool go = dense_need(set, n) - s <= DENSE_AHEAD;
-    if (s == g) return go ? set * 16 + n : -1;
+    const bool go = set * 2 * C::NMF + C::need(n) - s <= DENSE_AHEAD;
+    if (s == g) return go ? set * 32 + n : -1;
     if (go) {
       ++n;
-      if (n == (set == 2 ? 11 : 16)) { n = 0; ++set; }
+      if (n == (set == 2 ? C::NFS : C::NFP)) { n = 0; ++set; }
     }
   }
   return -1;
 }
+template <int NC>
+constexpr bool dense_schedule_ok() {   // every fragment is requested before the MFMA that first reads it (one replay of dense_load_at's walk)
+  using C = Chain<NC>;
+  int set = 0, n = DENSE_PRE;
+  for (int s = 0; s < 5 * C::NMF && set <= 2; ++s) {
+    const int need = set * 2 * C::NMF + C::need(n);
+    if (need - s <= DENSE_AHEAD) {
+      if (s >= need) return false;
+      ++n;
+      if (n == (set == 2 ? C::NFS : C::NFP)) { n = 0; ++set; }
+    }
+  }
+  return set == 3;
+}
+static_assert(dense_schedule_ok<3>() && dense_schedule_ok<5>(), "dense fragment schedule");
 template <class F, int... Is>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N, class F>
@@ -260,6 +333,9 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
     const u32x4* __restrict__ wp1, const float* __restrict__ bias0, const float* __restrict__ bias1,
     float* __restrict__ out, FDims d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  using G = Geo<NC>;
+  constexpr int RB0 = G::RB0, PLB0 = G::PLB0, NRING0 = G::NRING0, PA0 = G::PA0, NPRO0 = G::NPRO0, RING1_OFF = G::RING1_OFF,
+                SCR_OFF = G::SCR_OFF, DUMP_OFF = G::DUMP_OFF, LDSB = G::LDSB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool is_a = wave < 4;                 // block-0 producer | block-1 consumer
@@ -283,11 +359,12 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
   const int tap0 = kq == 0 ? 0 : kq == 1 ? 8 : kq == 2 ? 16 : 22, tap1 = kq == 0 ? 8 : kq == 1 ? 16 : kq == 2 ? 22 : 27;
   const int nkb = __builtin_amdgcn_readfirstlane((tap1 - tap0 + 1) >> 1);   // 4, 4, 3, 3
   const int bc = kq & 1;
-  u32x4 wr[24];   // A: [k-block][split]; B: [k-block][cout tile][split]
+  constexpr int NA = block0_fragments<NC, DENSE>(), NWR = NA > 24 ? NA : 24;
+  u32x4 wr[NWR];   // A: [k-block][split] (DENSE: the chain's fragments); B: [k-block][cout tile][split]
   {
     const u32x4* src = is_a ? wp0 : wp1 + (size_t)kq * 24 * 64;
 #pragma unroll
-    for (int i = 0; i < 24; ++i) wr[i] = (is_a && i >= (DENSE ? ND0 : 12)) ? (u32x4){0u, 0u, 0u, 0u} : src[i * 64 + lane];
+    for (int i = 0; i < NWR; ++i) wr[i] = (i >= (is_a ? NA : 24)) ? (u32x4){0u, 0u, 0u, 0u} : src[i * 64 + lane];
   }
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};   // A: block 0's bias of this lane's channel quad; B: block 1's of cout tile c
   {
@@ -343,6 +420,36 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
     auto write_item = [&](bool live, int zi, int irow, int iq, const u32x4 (&L)[NC]) __attribute__((always_inline)) {
       const int slot = (zi + 1 + NRING0) % NRING0;
       unsigned char* const base = lds + (live ? slot * PLB0 + irow * RB0 + iq * 32 : DUMP_OFF + lane * 16);
+      if constexpr (NC == 5) {   // four records per voxel (dense5_records); channel 4 is split in voxel pairs
+        auto val = [&](int c, int j) __attribute__((always_inline)) -> float {
+          const uint4 q = __builtin_bit_cast(uint4, L[c]);
+          return __builtin_bit_cast(float, j == 0 ? q.x : j == 1 ? q.y : j == 2 ? q.z : q.w);
+        };
+        unsigned rec5[4][4][2];   // [record][voxel][half]
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          unsigned p4[3];
+          split3(val(4, 2 * jp), val(4, 2 * jp + 1), p4);
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * jp + jj;
+            unsigned p01[3], p23[3], d4[3], r4[4][2];
+            split3(val(0, j), val(1, j), p01);
+            split3(val(2, j), val(3, j), p23);
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) d4[sp] = jj ? (p4[sp] >> 16) : (p4[sp] & 0xffffu);
+            dense5_records(p01, p23, d4, r4);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { rec5[a][j][0] = r4[a][0]; rec5[a][j][1] = r4[a][1]; }
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          *reinterpret_cast<u32x4*>(base + a * SB0) = (u32x4){rec5[a][0][0], rec5[a][0][1], rec5[a][1][0], rec5[a][1][1]};
+          *reinterpret_cast<u32x4*>(base + a * SB0 + 16) = (u32x4){rec5[a][2][0], rec5[a][2][1], rec5[a][3][0], rec5[a][3][1]};
+        }
+        return;
+      }
       float v[4][4];   // [channel][voxel]
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -422,7 +529,8 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
       const int st_p0 = RING1_OFF + (ry0 * RS1 + (int)qpos * QS1 + col) * 8, st_p1 = st_p0 + RS1 * 8;
       const int st_s = RING1_OFF + (sry * RS1 + (int)qpos * QS1 + srx) * 8;
       // DENSE: ring-0 byte offsets of this lane's two fragment halves inside (plane, tile row 0) — pair tiles | the single tile — and
-      // of its four leftover halves [MFMA w][half]
+      // of its leftover halves [fragment w][half]: three channels: slot 8 w + 2 lq + h = tap (2, slot / 5, 2), kind slot % 5 = E x w0,
+      // E x w1, E x w2, F, G (slot 15: weight 0); five channels: slot 2 lq + h = the record array 0 0 0 1 1 2 2 3 of tap (2, ty, 2)
       const unsigned dnA = (unsigned)((col + 2 + (lq == 3 ? 2 : 0)) * 8), dnB = (unsigned)((col + (lq == 3 ? 4 : 3)) * 8);
       const unsigned dnAs = (unsigned)(sry * RB0 + (srx + 2 + (lq == 3 ? 2 : 0)) * 8), dnBs = (unsigned)(sry * RB0 + (srx + (lq == 3 ? 4 : 3)) * 8);
       unsigned dnL[2][2], dnLs[2][2];
@@ -430,8 +538,14 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
       for (int w = 0; w < 2; ++w)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int sidx = w * 8 + lq * 2 + h, sc = sidx > 14 ? 14 : sidx, lty = sc / 5, lk = sc % 5;
-          const int o = lty * RB0 + (lk < 3 ? 0 : lk - 2) * SB0;
+          int o;
+          if constexpr (NC == 5) {
+            const int sidx = lq * 2 + h;
+            o = (sidx < 3 ? 0 : sidx < 5 ? 1 : sidx < 7 ? 2 : 3) * SB0;
+          } else {
+            const int sidx = w * 8 + lq * 2 + h, sc = sidx > 14 ? 14 : sidx, lty = sc / 5, lk = sc % 5;
+            o = lty * RB0 + (lk < 3 ? 0 : lk - 2) * SB0;
+          }
           dnL[w][h] = (unsigned)(o + (col + 4) * 8);
           dnLs[w][h] = (unsigned)(o + sry * RB0 + (srx + 4) * 8);
         }
@@ -574,9 +688,11 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
       }
 #endif
       int e6 = (2 * s0 + NRING0) % NRING0, m5 = (2 * s0 + NRING1) % NRING1;   // (2s) mod 8 = ring-0 slot of plane 2s-1; (2s) mod 5 = ring-1 slot of plane 2s
-      // ---- DENSE: fragment addressing and the MFMA chain of a tile (comment of dense_records)
+      // ---- DENSE: fragment addressing and the MFMA chain of a tile (Chain<NC>)
+      constexpr int NCH = DENSE ? NC : 3;
+      using CH = Chain<NCH>;
       struct DBase { unsigned pA, pB, pL[2][2]; };
-      struct DFr { bf16x8 G[4], E[4], F[4], L[2][2]; };
+      struct DFr { bf16x8 f[CH::NFP]; };
       auto dfrag = [&](unsigned pa, unsigned pb, int off) __attribute__((always_inline)) -> bf16x8 {
         const u32x2 a = *reinterpret_cast<const u32x2*>(lds + pa + off);
         const u32x2 b = *reinterpret_cast<const u32x2*>(lds + pb + off);
@@ -584,27 +700,15 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
       };
       auto dload = [&](auto nc, const DBase& b, DFr& q) __attribute__((always_inline)) {
         constexpr int n = decltype(nc)::value;
-        if constexpr (n < 9 || (n >= 11 && n < 14)) {
-          constexpr int kind = n < 9 ? n / 3 : n - 11, iy = n < 9 ? n % 3 : 3;   // kind 0 G, 1 E, 2 F
-          constexpr int off = iy * RB0 + (kind == 0 ? 2 : kind == 1 ? 0 : 1) * SB0;
-          const bf16x8 f = dfrag(b.pA, b.pB, off);
-          if constexpr (kind == 0) q.G[iy] = f; else if constexpr (kind == 1) q.E[iy] = f; else q.F[iy] = f;
-        } else {
-          constexpr int r = n < 11 ? 0 : 1, w = n < 11 ? n - 9 : n - 14;
-          q.L[r][w] = dfrag(b.pL[w][0], b.pL[w][1], r * RB0);
-        }
+        if constexpr (CH::is_left(n)) q.f[n] = dfrag(b.pL[CH::left_w(n)][0], b.pL[CH::left_w(n)][1], CH::left_row(n) * RB0);
+        else q.f[n] = dfrag(b.pA, b.pB, CH::iy(n) * RB0 + CH::arr(n) * SB0);
       };
       auto dmma = [&](auto kc, auto rc, const DFr& q, f32x4& acc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value, r = decltype(rc)::value;
-        if constexpr (k < 3) acc = MFMA(wr[k], q.G[r + k], acc);
-        else if constexpr (k < 6) acc = MFMA(wr[k], q.E[r + k - 3], acc);
-        else if constexpr (k < 9) acc = MFMA(wr[k], q.F[r + k - 6], acc);
-        else if constexpr (k < 12) acc = MFMA(wr[k], q.E[r + k - 9], acc);
-        else if constexpr (k < 14) acc = MFMA(wr[k], q.L[r][k - 12], acc);
-        else acc = MFMA(wr[k], q.E[r + k - 14], acc);
+        acc = MFMA(wr[k], q.f[CH::frag(k, r)], acc);
       };
       DFr fa;
-      if constexpr (DENSE) {   // the first six fragments of the column's first step (later steps: requested ahead of the barrier)
+      if constexpr (DENSE && PA0 > 0) {   // the first fragments of the column's first step (later steps: requested ahead of the barrier)
         const int t0 = (e6 % NRING0) * PLB0, t1 = ((e6 + 1) % NRING0) * PLB0, t2 = ((e6 + 2) % NRING0) * PLB0;
         DBase b0;
         b0.pA = (unsigned)((lq == 1 ? t1 : lq == 2 ? t2 : t0) + ry0 * RB0) + dnA;
@@ -657,23 +761,28 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
             else if constexpr (t == 3) epi_slice(sl, E0, acc, a11, zok1 ? svo_p1 : OOR, zok1 ? mko_p1 : OOR, 2 * s + 1);
             else epi_slice(sl, E0, acc, as_, (spl ? zok1 : zok0) ? svo_s : OOR, (spl ? zok1 : zok0) ? mko_s : OOR, 2 * s + spl);
           };
-          static_for<5 * ND0>([&](auto gc) __attribute__((always_inline)) {
-            constexpr int g = decltype(gc)::value, t = g / ND0, k = g % ND0;
+          if constexpr (PA0 == 0) {   // (ring 0 is not staged ahead: the step's first fragments are requested here)
+            static_for<DENSE_PRE>([&](auto nc) __attribute__((always_inline)) { dload(nc, bP0, fa); });
+            C01_FENCE();
+          }
+          constexpr int NMF = CH::NMF;
+          static_for<5 * NMF>([&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value, t = g / NMF, k = g % NMF;
             f32x4& acc = (t & 1) ? acc1 : acc0;
             const f32x4& prev = (t & 1) ? acc0 : acc1;
             if constexpr (k == 0) acc = bv;
             if constexpr (t < 2) dmma(std::integral_constant<int, k>{}, std::integral_constant<int, t>{}, fa, acc);
             else if constexpr (t < 4) dmma(std::integral_constant<int, k>{}, std::integral_constant<int, t - 2>{}, fb, acc);
             else dmma(std::integral_constant<int, k>{}, std::integral_constant<int, 0>{}, fs, acc);
-            constexpr int ld = dense_load_at(g);
+            constexpr int ld = dense_load_at<NCH>(g);
             if constexpr (ld >= 0) {
-              constexpr int set = ld / 16, n = ld % 16;
+              constexpr int set = ld / 32, n = ld % 32;
               if constexpr (set == 0) dload(std::integral_constant<int, n>{}, bP0, fa);
               else if constexpr (set == 1) dload(std::integral_constant<int, n>{}, bP1, fb);
               else dload(std::integral_constant<int, n>{}, bS, fs);
             }
-            if constexpr (g >= 5 * ND0 - DENSE_PRE) dload(std::integral_constant<int, g - (5 * ND0 - DENSE_PRE)>{}, bN, fa);
-            if constexpr (t >= 1 && k >= 2 && k <= 14 && (k & 1) == 0) epi_tile(std::integral_constant<int, t - 1>{}, k / 2 - 1, prev);
+            if constexpr (PA0 > 0 && g >= 5 * NMF - DENSE_PRE) dload(std::integral_constant<int, g - (5 * NMF - DENSE_PRE)>{}, bN, fa);
+            if constexpr (t >= 1 && CH::epi_slice_at(k) >= 0) epi_tile(std::integral_constant<int, t - 1>{}, CH::epi_slice_at(k), prev);
             C01_FENCE();
           });
           C01_STAMP(4);
@@ -780,6 +889,36 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
     auto write_item = [&](bool live, int zi, int irow, int iq, const u32x4 (&L)[NC]) __attribute__((always_inline)) {
       const int slot = (zi + 1 + NRING0) % NRING0;
       unsigned char* const base = lds + (live ? slot * PLB0 + irow * RB0 + iq * 32 : DUMP_OFF + lane * 16);
+      if constexpr (NC == 5) {   // four records per voxel (dense5_records); channel 4 is split in voxel pairs
+        auto val = [&](int c, int j) __attribute__((always_inline)) -> float {
+          const uint4 q = __builtin_bit_cast(uint4, L[c]);
+          return __builtin_bit_cast(float, j == 0 ? q.x : j == 1 ? q.y : j == 2 ? q.z : q.w);
+        };
+        unsigned rec5[4][4][2];   // [record][voxel][half]
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          unsigned p4[3];
+          split3(val(4, 2 * jp), val(4, 2 * jp + 1), p4);
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * jp + jj;
+            unsigned p01[3], p23[3], d4[3], r4[4][2];
+            split3(val(0, j), val(1, j), p01);
+            split3(val(2, j), val(3, j), p23);
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) d4[sp] = jj ? (p4[sp] >> 16) : (p4[sp] & 0xffffu);
+            dense5_records(p01, p23, d4, r4);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { rec5[a][j][0] = r4[a][0]; rec5[a][j][1] = r4[a][1]; }
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          *reinterpret_cast<u32x4*>(base + a * SB0) = (u32x4){rec5[a][0][0], rec5[a][0][1], rec5[a][1][0], rec5[a][1][1]};
+          *reinterpret_cast<u32x4*>(base + a * SB0 + 16) = (u32x4){rec5[a][2][0], rec5[a][2][1], rec5[a][3][0], rec5[a][3][1]};
+        }
+        return;
+      }
       float v[4][4];   // [channel][voxel]
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -869,6 +1008,26 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
         return __builtin_bit_cast(float, j == 0 ? q.x : j == 1 ? q.y : j == 2 ? q.z : q.w);
       };
       auto stage_slice = [&](int half, int addr) __attribute__((always_inline)) {
+        if constexpr (NC == 5) {
+          unsigned p4[3], rec5[4][2][2];
+          split3(lval(4, 2 * half), lval(4, 2 * half + 1), p4);
+#pragma unroll
+          for (int vv = 0; vv < 2; ++vv) {
+            const int vj = 2 * half + vv;
+            unsigned p01[3], p23[3], d4[3], r4[4][2];
+            split3(lval(0, vj), lval(1, vj), p01);
+            split3(lval(2, vj), lval(3, vj), p23);
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) d4[sp] = vv ? (p4[sp] >> 16) : (p4[sp] & 0xffffu);
+            dense5_records(p01, p23, d4, r4);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { rec5[a][vv][0] = r4[a][0]; rec5[a][vv][1] = r4[a][1]; }
+          }
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+            *reinterpret_cast<u32x4*>(lds + addr + a * SB0 + 16 * half) = (u32x4){rec5[a][0][0], rec5[a][0][1], rec5[a][1][0], rec5[a][1][1]};
+          return;
+        }
         unsigned rec[3][2][2];
         if constexpr (DENSE) {
 #pragma unroll
@@ -964,7 +1123,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
               for (int sp = 0; sp < 3; ++sp) fr[(g + 1) & 1][sp] = frag(pa[(g + 1) >> 1], ((g + 1) & 1) * T1OFF + sp * SPB1, 2 * QS1 * 8);
             }
             const bf16x8 (&f)[3] = fr[g & 1];
-            const u32x4 (&w)[24] = wr;
+            const u32x4 (&w)[NWR] = wr;
 #define C01_W(C, T) w[(kb * 2 + (C)) * 3 + (T)]
             if (b_mma) {
             lo[t][0] = MFMA(C01_W(0, 1), f[1], lo[t][0]); lo[t][1] = MFMA(C01_W(1, 1), f[1], lo[t][1]);
@@ -1064,7 +1223,7 @@ constexpr int64_t W1_FLOATS = (int64_t)4 * 4 * 2 * 3 * 64 * 4;
 // the comment of dense_records.
 __global__ void pack_c01_w0_dense_kernel(const float* __restrict__ w, u32x4* __restrict__ packed) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= ND0 * 64) return;
+  if (idx >= Chain<3>::NMF * 64) return;
   const int f = idx >> 6, lane = idx & 63, co = lane & 15, lq = lane >> 4;
   unsigned el[8];
 #pragma unroll
@@ -1091,7 +1250,43 @@ __global__ void pack_c01_w0_dense_kernel(const float* __restrict__ w, u32x4* __r
   }
   packed[f * 64 + lane] = (u32x4){el[0] | (el[1] << 16), el[2] | (el[3] << 16), el[4] | (el[5] << 16), el[6] | (el[7] << 16)};
 }
-constexpr int64_t W0D_FLOATS = (int64_t)ND0 * 64 * 4;
+constexpr int64_t W0D_FLOATS = (int64_t)Chain<3>::NMF * 64 * 4;
+
+// The 27 weight fragments of block 0 with FIVE input channels, in the order of a tile's chain (Chain<5>): phase k / 3 = A1 w2, A4,
+// A3 w1, A3 w0, A2 w1, A1 w1, leftover, A2 w0, A1 w0; tap row ty = k % 3.  Slots of a main fragment as in pack_c01_w0_dense_kernel;
+// the leftover fragment of tap row ty: slot 2 lq + h = pattern A1 w0, A1 w1, A1 w2, A2 w0, A2 w1, A3 w0, A3 w1, A4 of tap (2, ty, 2).
+// Patterns (weight split, channel) per position: comment of dense5_records.
+__global__ void pack_c01_w0_dense5_kernel(const float* __restrict__ w, u32x4* __restrict__ packed) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Chain<5>::NMF * 64) return;
+  const int f = idx >> 6, lane = idx & 63, co = lane & 15, lq = lane >> 4;
+  const int phase = f / 3, ty = f % 3;
+  unsigned el[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int h = e >> 2, pos = e & 3;
+    int pat, tap;   // pattern 0..7 = A1 w0, A1 w1, A1 w2, A2 w0, A2 w1, A3 w0, A3 w1, A4
+    if (phase == 6) {
+      pat = lq * 2 + h;
+      tap = (2 * 3 + ty) * 3 + 2;
+    } else {
+      pat = phase == 0 ? 2 : phase == 1 ? 7 : phase == 2 ? 6 : phase == 3 ? 5 : phase == 4 ? 4 : phase == 5 ? 1 : phase == 7 ? 3 : 0;
+      const int tz = lq < 3 ? lq : h, tx = lq < 3 ? h : 2;
+      tap = (tz * 3 + ty) * 3 + tx;
+    }
+    int sp = -1, c = 0;
+    if (pat < 3) { sp = pat; c = pos; }
+    else if (pat < 5) { sp = pat - 3; c = pos == 0 ? 4 : pos - 1; }
+    else if (pat == 5) { sp = 0; c = pos == 0 ? 3 : pos == 1 ? 4 : pos == 2 ? 0 : 1; }
+    else if (pat == 6) { if (pos < 2) { sp = 1; c = 3 + pos; } }
+    else { sp = pos == 3 ? 2 : 0; c = pos == 3 ? 4 : 2 + pos; }
+    unsigned p[3] = {0u, 0u, 0u};
+    if (sp >= 0) split3(w[((int64_t)co * 5 + c) * 27 + tap], 0.0f, p);
+    el[e] = sp >= 0 ? (p[sp == 0 ? 0 : sp == 1 ? 1 : 2] & 0xffffu) : 0u;
+  }
+  packed[f * 64 + lane] = (u32x4){el[0] | (el[1] << 16), el[2] | (el[3] << 16), el[4] | (el[5] << 16), el[6] | (el[7] << 16)};
+}
+constexpr int64_t W0D5_FLOATS = (int64_t)Chain<5>::NMF * 64 * 4;
 
 }  // namespace
 
@@ -1108,22 +1303,31 @@ extern "C" int lr_debug_read_c01_stamps(unsigned long long* host64, int reset) {
 
 // ---- C ABI (include/liftreg_hip.h)
 extern "C" int64_t lr_conv3d_pair01_packed_floats(int Cin, int C0, int C1) {
-  if (Cin < 1 || Cin > 4 || C0 != 16 || C1 != 32) return 0;
+  if (Cin < 1 || Cin > 5 || C0 != 16 || C1 != 32) return 0;
+  if (Cin == 5) return W1_FLOATS + W0D5_FLOATS;   // [block 1][block 0, dense K]
   return lr_internal_conv0_split_packed_floats(Cin, C0) + W1_FLOATS + (Cin == 3 ? W0D_FLOATS : 0);   // [block 0][block 1][block 0, dense K]
 }
+
+// floats in front of block 1's fragments
+static int64_t pair01_w1_offset(int Cin) { return Cin == 5 ? 0 : lr_internal_conv0_split_packed_floats(Cin, 16); }
 
 extern "C" int lr_conv3d_pair01_pack_f32(const float* w0, const float* w1, float* packed, int Cin, int C0, int C1, void* stream) {
   if (!w0 || !w1 || !packed) return LR_ENULL;
   if (lr_conv3d_pair01_packed_floats(Cin, C0, C1) == 0) return LR_EUNSUPPORTED;
   if (reinterpret_cast<uintptr_t>(packed) & 15u) return LR_EALIGN;
   hipStream_t st = lr_stream(stream);
-  const int rc = lr_internal_conv0_split_pack(w0, packed, Cin, C0, st);
-  if (rc != LR_OK) return rc;
-  u32x4* p1 = reinterpret_cast<u32x4*>(packed + lr_internal_conv0_split_packed_floats(Cin, C0));
+  if (Cin <= 4) {
+    const int rc = lr_internal_conv0_split_pack(w0, packed, Cin, C0, st);
+    if (rc != LR_OK) return rc;
+  }
+  u32x4* p1 = reinterpret_cast<u32x4*>(packed + pair01_w1_offset(Cin));
   hipLaunchKernelGGL(pack_c01_w1_kernel, dim3((4 * 4 * 2 * 64 + 255) / 256), dim3(256), 0, st, w1, p1);
   if (Cin == 3)
-    hipLaunchKernelGGL(pack_c01_w0_dense_kernel, dim3((ND0 * 64 + 255) / 256), dim3(256), 0, st, w0,
-                       reinterpret_cast<u32x4*>(packed + lr_internal_conv0_split_packed_floats(Cin, C0) + W1_FLOATS));
+    hipLaunchKernelGGL(pack_c01_w0_dense_kernel, dim3((Chain<3>::NMF * 64 + 255) / 256), dim3(256), 0, st, w0,
+                       reinterpret_cast<u32x4*>(packed + pair01_w1_offset(Cin) + W1_FLOATS));
+  if (Cin == 5)
+    hipLaunchKernelGGL(pack_c01_w0_dense5_kernel, dim3((Chain<5>::NMF * 64 + 255) / 256), dim3(256), 0, st, w0,
+                       reinterpret_cast<u32x4*>(packed + W1_FLOATS));
   return lr_launch_status();
 }
 
@@ -1150,7 +1354,7 @@ static int pair01_impl(const float* in0, int64_t in0_batch_stride, const float* 
     const int need_hi = 2 * (oz_lo + n_oz - 1) + 2 >= D_global ? D_global - 1 : 2 * (oz_lo + n_oz - 1) + 2;
     if (need_lo < z_lo || need_hi >= z_lo + D) return LR_EINVAL;
   }
-  if (Cin < 1 || Cin > 4) return LR_EUNSUPPORTED;
+  if (Cin < 1 || Cin > 5 || (Cin == 5 && save)) return LR_EUNSUPPORTED;   // (five channels: inference form only)
   if (out_layout != LR_LAYOUT_NDHWC && out_layout != LR_LAYOUT_NDHWC_HPS) return LR_EUNSUPPORTED;
   if (!(slope0 >= 0.0f && slope0 <= 1.0f) || !(slope1 >= 0.0f && slope1 <= 1.0f)) return LR_EUNSUPPORTED;   // LeakyReLU = max(v, slope v)
   if (H & 3) return LR_EUNSUPPORTED;
@@ -1169,7 +1373,7 @@ static int pair01_impl(const float* in0, int64_t in0_batch_stride, const float* 
   if ((reinterpret_cast<uintptr_t>(in0) & 15u) || (Cin > 1 && (reinterpret_cast<uintptr_t>(in_rest) & 15u)) ||
       (reinterpret_cast<uintptr_t>(packed) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u) || (d.bs0 & 3) || (d.bsr & 3) || (d.out_bs & 3))
     return LR_EALIGN;
-  if ((int64_t)3 * V * 4 + (int64_t)8 * W * H * 4 >= 0x7fffffffLL) return LR_EUNSUPPORTED;   // 31-bit byte offsets inside a batch element
+  if ((int64_t)(Cin > 4 ? Cin - 1 : 3) * V * 4 + (int64_t)8 * W * H * 4 >= 0x7fffffffLL) return LR_EUNSUPPORTED;   // 31-bit byte offsets inside a batch element
   if ((int64_t)d.Wo * d.Ho * 32 * 4 >= 0x7fffffffLL) return LR_EUNSUPPORTED;                // an output plane is one buffer resource
   d.nTx = (d.Ho + TX - 1) / TX; d.nTy = (d.Wo + TY - 1) / TY;
   const int64_t nu = (int64_t)B * d.nTy * d.nTx;
@@ -1186,16 +1390,16 @@ static int pair01_impl(const float* in0, int64_t in0_batch_stride, const float* 
   if (blocks > d.nunits) blocks = d.nunits;
   hipStream_t st = lr_stream(stream);
   const u32x4* wp0 = reinterpret_cast<const u32x4*>(packed);
-  const u32x4* wp1 = reinterpret_cast<const u32x4*>(packed + lr_internal_conv0_split_packed_floats(Cin, 16));
+  const u32x4* wp1 = reinterpret_cast<const u32x4*>(packed + pair01_w1_offset(Cin));
   if (!in_rest) in_rest = in0;   // Cin == 1: never dereferenced (zero-length resource)
   // three channels: block 0 with K packed densely (17 instead of 24 MFMAs per tile); LIFTREG_PAIR01_DENSE=0: the padded form (A/B aid)
   const bool densek = Cin == 3 && lr_sw_int(LR_SW_PAIR01_DENSE, 1) != 0;
-  if (densek) wp0 = reinterpret_cast<const u32x4*>(packed + lr_internal_conv0_split_packed_floats(Cin, 16) + W1_FLOATS);
+  if (densek || Cin == 5) wp0 = reinterpret_cast<const u32x4*>(packed + pair01_w1_offset(Cin) + W1_FLOATS);
 #define LR_C01(NCV, SV, DN)                                                                                                    \
   do {                                                                                                                       \
     static std::atomic<uint64_t> attr_done{0};                                                                               \
-    if (lr_raise_dyn_lds(reinterpret_cast<const void*>(&conv01_fused_kernel<NCV, SV, DN>), LDSB, attr_done) != LR_OK) return LR_ELAUNCH; \
-    hipLaunchKernelGGL((conv01_fused_kernel<NCV, SV, DN>), dim3((unsigned)blocks), dim3(NTHR), LDSB, st, in0, in_rest, wp0, wp1, bias0, bias1, out, d); \
+    if (lr_raise_dyn_lds(reinterpret_cast<const void*>(&conv01_fused_kernel<NCV, SV, DN>), Geo<NCV>::LDSB, attr_done) != LR_OK) return LR_ELAUNCH; \
+    hipLaunchKernelGGL((conv01_fused_kernel<NCV, SV, DN>), dim3((unsigned)blocks), dim3(NTHR), Geo<NCV>::LDSB, st, in0, in_rest, wp0, wp1, bias0, bias1, out, d); \
   } while (0)
   if (save) {
     if (Cin == 1) LR_C01(1, true, false);
@@ -1208,7 +1412,8 @@ static int pair01_impl(const float* in0, int64_t in0_batch_stride, const float* 
     else if (Cin == 2) LR_C01(2, false, false);
     else if (Cin == 3 && densek) LR_C01(3, false, true);
     else if (Cin == 3) LR_C01(3, false, false);
-    else LR_C01(4, false, false);
+    else if (Cin == 4) LR_C01(4, false, false);
+    else LR_C01(5, false, true);
   }
 #undef LR_C01
   return lr_launch_status();

@@ -377,20 +377,20 @@ def conv3d_first_split(x0, rest, weight, bias, *, out_layout=LAYOUT_NCDHW, negat
 
 def conv3d_pair01_shapes_supported(B, Cin, D, W, H, w0, w1, out_layout=LAYOUT_NDHWC_HPS):
     """The shape half of `conv3d_pair01_supported` (no pointers, no strides): the same answer in every process."""
-    if not (2 <= Cin <= 4 and H % 4 == 0 and B >= 1 and D >= 1):
+    if not (2 <= Cin <= 5 and H % 4 == 0 and B >= 1 and D >= 1):
         return False
     if tuple(w0.shape) != (16, Cin, 3, 3, 3) or tuple(w1.shape) != (32, 16, 3, 3, 3):
         return False
     if out_layout not in (LAYOUT_NDHWC, LAYOUT_NDHWC_HPS) or (out_layout == LAYOUT_NDHWC_HPS and ((H - 1) // 2 + 1) % 2):
         return False
     V = D * W * H
-    return 12 * V + 32 * W * H < 2 ** 31 - 1 and ((W - 1) // 2 + 1) * ((H - 1) // 2 + 1) * 128 < 2 ** 31 - 1
+    return 4 * max(Cin - 1, 3) * V + 32 * W * H < 2 ** 31 - 1 and ((W - 1) // 2 + 1) * ((H - 1) // 2 + 1) * 128 < 2 ** 31 - 1
 
 
 def conv3d_pair01_supported(x0, rest, w0, w1, out_layout=LAYOUT_NDHWC_HPS, probe=False):
     """True when `conv3d_pair01` (encoder blocks 0 and 1 as one kernel, csrc/conv01_fused.hip) can take these tensors
     (probe: `rest` is a shape-only stand-in — a freshly allocated tensor of that shape is contiguous and aligned)."""
-    if not (x0.dim() == 5 and rest.dim() == 5 and x0.shape[1] == 1 and rest.shape[1] in (1, 2, 3) and x0.shape[4] % 4 == 0 and
+    if not (x0.dim() == 5 and rest.dim() == 5 and x0.shape[1] == 1 and rest.shape[1] in (1, 2, 3, 4) and x0.shape[4] % 4 == 0 and
             x0.shape[0] == rest.shape[0] and x0.shape[2:] == rest.shape[2:] and x0[0].is_contiguous() and
             (probe or rest.is_contiguous()) and (x0.shape[0] == 1 or x0.stride(0) % 4 == 0) and x0.data_ptr() % 16 == 0 and
             (probe or rest.data_ptr() % 16 == 0)):
@@ -401,15 +401,16 @@ def conv3d_pair01_supported(x0, rest, w0, w1, out_layout=LAYOUT_NDHWC_HPS, probe
     if out_layout not in (LAYOUT_NDHWC, LAYOUT_NDHWC_HPS) or (out_layout == LAYOUT_NDHWC_HPS and ((H - 1) // 2 + 1) % 2):
         return False
     V = D * W * H
-    return 12 * V + 32 * W * H < 2 ** 31 - 1 and ((W - 1) // 2 + 1) * ((H - 1) // 2 + 1) * 128 < 2 ** 31 - 1
+    return 4 * max(rest.shape[1], 3) * V + 32 * W * H < 2 ** 31 - 1 and ((W - 1) // 2 + 1) * ((H - 1) // 2 + 1) * 128 < 2 ** 31 - 1
 
 
 def _pair01_mfmas_per_step(Cin):
     """What the matrix pipe is really asked for by the pair kernel: v_mfma_f32_16x16x32_bf16 per column of 4 x 8 outputs and
     step (one block-1 output plane).  Block 0: 20 tiles of 16 voxels x 17 MFMAs (three channels: K packed densely, 135 record
-    slots of 136) or x 24 (K padded 27 taps -> 32, channels -> 4); block 1: 96 + 96 + 72 + 72 (see the kernel header)."""
+    slots of 136), x 27 (five channels: 216 of 216) or x 24 (K padded 27 taps -> 32, channels -> 4); block 1: 96 + 96 + 72 + 72
+    (see the kernel header)."""
     dense = Cin == 3 and os.environ.get("LIFTREG_PAIR01_DENSE", "1") != "0"
-    return 20 * (17 if dense else 24) + 336
+    return 20 * (27 if Cin == 5 else 17 if dense else 24) + 336
 
 
 def conv3d_pair01_pack(w0, w1):
@@ -418,7 +419,7 @@ def conv3d_pair01_pack(w0, w1):
     Cin = w0.shape[1]
     n = _hip.lib().lr_conv3d_pair01_packed_floats(Cin, w0.shape[0], w1.shape[0])
     if n <= 0:
-        raise ValueError("conv3d_pair01_pack: the pair kernel is built for Cin in 1..4 -> 16 -> 32 channels")
+        raise ValueError("conv3d_pair01_pack: the pair kernel is built for Cin in 1..5 -> 16 -> 32 channels")
     packed = torch.empty((n,), dtype=torch.float32, device=w0.device)
     _hip.check(_hip.lib().lr_conv3d_pair01_pack_f32(w0.data_ptr(), w1.data_ptr(), packed.data_ptr(), Cin, w0.shape[0],
                                                     w1.shape[0], _stream()), "lr_conv3d_pair01_pack_f32")

@@ -64,7 +64,9 @@ def _make(B, Cin, D, W, H, seed):
 
 CASES = [(2, 3, 12, 32, 32, True), (1, 3, 7, 36, 44, True), (1, 2, 5, 40, 24, False), (1, 3, 9, 34, 28, False),
          (1, 2, 4, 16, 16, True), (1, 4, 6, 48, 32, True), (1, 3, 1, 32, 32, True), (2, 3, 2, 20, 36, False),
-         (1, 3, 20, 128, 128, True), (1, 3, 3, 70, 132, True)]
+         (1, 3, 20, 128, 128, True), (1, 3, 3, 70, 132, True),
+         # five channels (four views: the reference's shipped configuration): block 0 with 27 MFMAs per tile, ring 0 six planes deep
+         (2, 5, 12, 32, 32, True), (1, 5, 7, 36, 44, True), (1, 5, 9, 34, 28, False), (1, 5, 1, 32, 32, True), (1, 5, 20, 80, 160, True)]
 
 
 @pytest.mark.parametrize("B,Cin,D,W,H,hps", CASES)
@@ -168,12 +170,12 @@ def test_pair_kernel_is_deterministic_and_batch_independent():
     assert torch.equal(a[1:2], c)
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_pair_kernel_on_z_slabs_gives_the_bits_of_the_whole_volume(world):
+@pytest.mark.parametrize("world,Cin", [(2, 3), (4, 3), (8, 3), (2, 5), (4, 5)])
+def test_pair_kernel_on_z_slabs_gives_the_bits_of_the_whole_volume(world, Cin):
     """The z-slab form (parallel.SlabShardedRegistration): each rank computes output planes [d0/2, d1/2) from input planes
     d0-2 .. d1 — a view of the replicated moving volume and its own planes of the feature volume; no halo exchange."""
     from liftreg_amd import ops
-    B, Cin, D, W, H = 2, 3, 32, 40, 32
+    B, D, W, H = 2, 32, 40, 32
     x, w0, b0, w1, b1 = _make(B, Cin, D, W, H, 11)
     xd, w0d, b0d, w1d, b1d = (t.to(DEV) for t in (x, w0, b0, w1, b1))
     x0, rest = xd[:, 0:1].contiguous(), xd[:, 1:].contiguous()
