@@ -242,6 +242,46 @@ def cpu_baseline(cfg, net, inp, budget_s=30.0):
                       f"torch {torch.__version__} CPU ops, median of runs after the first; s/reg={best:.3f}"}, out
 
 
+EXTRA = (  # (name, script, arguments): each line is measured in its OWN process, after the headline's timed region
+    ("c3_bf16", "bench.py", ["--config", "c3", "--conv-dtype", "bf16", "--no-drr", "--fp32-ref-only"]),
+    ("c4_bf16", "bench.py", ["--config", "c4", "--conv-dtype", "bf16", "--no-drr", "--fp32-ref-only"]),
+    ("native160_fp32", "bench.py", ["--config", "native160", "--no-drr", "--cpu-budget", "0"]),
+    ("train_c3_fp32", os.path.join("tools", "train_bench.py"), ["--config", "c3"]),
+)
+
+
+def extra_lines(timeout_s=170):
+    """The lines the driver would otherwise never see: every entry is the JSON line of a child process —
+    its own inputs, clock ramp, warm-up, timed steps, ms_per_step and dominant-kernel roofline — plus `wall_s`, the child's
+    whole run by this process's clock.  A child is an ordinary `python bench.py …` (or tools/train_bench.py) started AFTER the
+    headline is measured; nothing here touches the headline's numbers."""
+    import subprocess
+    out = {}
+    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "ms_per_train_step", "dtype", "config", "roofline",
+            "roofline_backproject", "kernels", "vs_fp32_reference", "parity_vs_cpu", "cpu_baseline", "ncc_loss", "conv_dtype",
+            "grad_dtype", "global_batch", "losses", "peak_mem_GB", "samples_per_s")
+    for name, script, argv in EXTRA:
+        t0 = time.perf_counter()
+        try:
+            cmd = [sys.executable, os.path.join(ROOT, script)] + (["--extra-lines", "off"] if script == "bench.py" else []) + argv
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[name] = {"error": f"rc {r.returncode}: {r.stderr[-300:]}"}
+            elif script == "bench.py":
+                d = json.loads(lines[-1])
+                out[name] = {k: d[k] for k in keep if k in d}
+            else:   # tools/train_bench.py: the summary line, then one line per kernel
+                d = json.loads(lines[0])
+                out[name] = {k: d[k] for k in keep if k in d}
+                out[name]["ms_per_step"] = d.get("ms_per_train_step")
+                out[name]["kernels"] = [json.loads(ln) for ln in lines[1:]]
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": f"timeout after {timeout_s} s"}
+        out[name]["wall_s"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
 def dry_run(args, rank, world):
     """The N-rank control path without a GPU: what the driver's `torch.distributed.run … bench.py --gpus N` exercises
     around the measurement — rendezvous, warm-up, barrier-fenced timed region, MAX over ranks, one JSON line from
@@ -312,6 +352,15 @@ def main():
     ap.add_argument("--no-pair01", action="store_true",
                     help="A/B aid (fp32 lines): encoder blocks 0 and 1 as two fp32-MFMA kernels (the round-3 path) instead of the "
                          "fused split-operand pair kernel csrc/conv01_fused.hip (model opt key fuse_pair01)")
+    ap.add_argument("--cpu-budget", type=float, default=30.0,
+                    help="seconds of CPU-oracle forwards the cpu_baseline leg may spend after the first one")
+    ap.add_argument("--fp32-ref-only", action="store_true",
+                    help="(extra lines) no timed CPU baseline: only the ONE fp32 CPU forward `vs_fp32_reference` needs (bf16 lines)")
+    ap.add_argument("--extra-lines", default="auto", choices=("auto", "on", "off"),
+                    help="after the headline's timed region, also time — each in its own child process, with its own warm-up / "
+                         "steps / ms_per_step / dominant-kernel roofline — C3 bf16, C4 bf16 (B = 4; both with vs_fp32_reference), the "
+                         "reference's shipped 160^3 / 4-view / B = 30 configuration and the C3 fp32 training step; emitted under "
+                         "`extra_lines`.  auto: only for the plain single-GPU headline invocation (what the driver runs)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from one captured HIP graph (launch-bound small configs c1/c2); the "
                          "per-kernel table then comes from one extra eager step outside the timed region")
@@ -653,8 +702,12 @@ def main():
         "drr_forward": drr,
         **({"drr_forward_sharded": drr_sharded} if drr_sharded is not None else {}),
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not slab:
-        result["cpu_baseline"], ref = cpu_baseline(cfg, net, inp)
+    if rank == 0 and world == 1 and args.fp32_ref_only and not slab:
+        result["cpu_baseline"] = None
+        with torch.no_grad():
+            result["vs_fp32_reference"] = vs_fp32_reference(net, inp, net(inp))
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline and not slab:
+        result["cpu_baseline"], ref = cpu_baseline(cfg, net, inp, budget_s=args.cpu_budget)
         if ref is not None:       # the CPU forward is paid for: compare the GPU output of the SAME input with it
             with torch.no_grad():
                 gpu_out = net(inp)
@@ -663,6 +716,12 @@ def main():
                 result["vs_fp32_reference"] = vs_fp32_reference(net, inp, gpu_out)
     elif rank == 0:
         result["cpu_baseline"] = None
+    plain = (args.config == "c3" and (args.conv_dtype, args.pca_dtype) == ("fp32", "fp32") and not slab and not args.graph and
+             not args.no_pair01 and not args.conv0_split and not args.fuse_bp and not args.fuse_ncc and not args.no_cpu_baseline and
+             not args.no_drr)
+    if rank == 0 and world == 1 and (args.extra_lines == "on" or (args.extra_lines == "auto" and plain)):
+        torch.cuda.empty_cache()     # (the children allocate their own ~30 GB each; this process keeps its ~15 GB of live tensors)
+        result["extra_lines"] = extra_lines()
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

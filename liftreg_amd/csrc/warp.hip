@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void warp_tri_fast_kernel(
 // (warped, target) per batch row are reduced here — the similarity never re-reads `warped` (layers/losses.py:18-29
 // made ~8 passes, ncc_moments_kernel one): per-wave partials [b][4*block+wave][5], fixed order, no atomics; the caller's
 // ncc_reduce pass (ncc.hip) sums the blocks.  C == 1 only.
-template <bool BF, bool SCALE, int BT /* batch rows per thread: 8, or 4 for small batches (half the accumulators) */, bool NCC>
+template <bool BF, bool SCALE, int BT /* batch rows per thread: 8, or 4 for small batches (half the accumulators) */, bool NCC, bool MULTI = false>
 __global__ __launch_bounds__(256) void pca_warp_kernel(const float* __restrict__ coefs, const float* __restrict__ basis,
                                                        const float* __restrict__ mean, const float* __restrict__ img,
                                                        const float* __restrict__ id0, const float* __restrict__ id1,
@@ -348,17 +348,37 @@ __global__ __launch_bounds__(256) void pca_warp_kernel(const float* __restrict__
                                                        float* __restrict__ phi_out, float* __restrict__ warped, int B,
                                                        int L, int C, int D, int W, int H, int64_t ldb, float rcp_hv,
                                                        int64_t bcs, const float* __restrict__ target,
-                                                       double* __restrict__ ncc_partial) {
+                                                       double* __restrict__ ncc_partial, int gx, int Dn, int nch) {
   extern __shared__ float cs[];  // [L][BT]
+  // Batches above BT rows: `nch` chunks of BT rows, each (tile, chunk) its own block.  The hardware deals consecutive block ids
+  // round-robin over the 8 XCDs: ids g*8*nch + chunk*8 + x (x = 0..7) are the nch chunks of tile 8 g + x, dispatched back to
+  // back on ONE XCD — the chunks stream the same basis columns at the same time and all but the first find them in that
+  // XCD's L2 (the basis leaves HBM once per batch, not once per chunk).
+  int bx, i;   // float4 tile inside the plane | slab row (global row d0 + i)
+  if constexpr (MULTI) {
+    const int bid = (int)blockIdx.x, per = 8 * nch, g = bid / per, r = bid - g * per;
+    const int chunk = r >> 3, tile = g * 8 + (r & 7);
+    if (tile >= gx * Dn) return;
+    i = tile / gx;
+    bx = tile - i * gx;
+    const int64_t Vc = (int64_t)D * W * H, Vsc = (int64_t)Dn * W * H;
+    coefs += (int64_t)chunk * BT * L;
+    img += (int64_t)chunk * BT * C * Vc;
+    disp_out += (int64_t)chunk * BT * 3 * Vsc;
+    phi_out += (int64_t)chunk * BT * 3 * Vsc;
+    warped += (int64_t)chunk * BT * C * Vsc;
+    B = B - chunk * BT < BT ? B - chunk * BT : BT;
+  } else {
+    bx = (int)blockIdx.x;
+    i = (int)blockIdx.y;
+  }
   for (int t = threadIdx.x; t < L * BT; t += blockDim.x) {
     const int l = t / BT, b = t % BT;
     cs[t] = b < B ? coefs[(int64_t)b * L + l] : 0.0f;
   }
   __syncthreads();
   const int HV = H >> 2;
-  const int t = blockIdx.x * 256 + threadIdx.x;  // float4 index inside plane i
-  const int i = blockIdx.y;                       // slab row (global row d0 + i)
-  const int Dn = gridDim.y;
+  const int t = bx * 256 + threadIdx.x;  // float4 index inside plane i
   const int jj = (int)(((float)t + 0.5f) * rcp_hv);
   const bool active = jj < W;
   if (!NCC && !active) return;
@@ -385,14 +405,15 @@ __global__ __launch_bounds__(256) void pca_warp_kernel(const float* __restrict__
     for (int c = 0; c < 3; ++c) {
       if (BF) {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        const u32x2 raw = __builtin_nontemporal_load(
-            reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(basis) + (int64_t)l * ldb + c * bcs + m));
+        const u32x2* bp = reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(basis) + (int64_t)l * ldb + c * bcs + m);
+        const u32x2 raw = MULTI ? *bp : __builtin_nontemporal_load(bp);   // MULTI: the other chunks of the tile read the same lines from L2
         v[c][0] = __builtin_bit_cast(float, raw.x << 16);
         v[c][1] = __builtin_bit_cast(float, raw.x & 0xffff0000u);
         v[c][2] = __builtin_bit_cast(float, raw.y << 16);
         v[c][3] = __builtin_bit_cast(float, raw.y & 0xffff0000u);
       } else {
-        v[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(basis + (int64_t)l * ldb + c * bcs + m));
+        const f32x4v* bp = reinterpret_cast<const f32x4v*>(basis + (int64_t)l * ldb + c * bcs + m);
+        v[c] = MULTI ? *bp : __builtin_nontemporal_load(bp);
       }
     }
 #pragma unroll
@@ -625,22 +646,27 @@ static int pca_warp_impl(bool bf, const float* coefs, const float* basis, const 
   if (ncc && C != 1) return LR_EUNSUPPORTED;
   const int Dn = d1 - d0;
   const int64_t sD = (int64_t)W * H, V = sD * D, Vs = sD * Dn;
-  if (B > 8 || L > 2048 || (H & 3) || bcs < Vs || ldb < 2 * bcs + Vs) return LR_EUNSUPPORTED;  // larger batches: chunks of 8 (ops.pca_warp)
+  if (B > 256 || (B > 8 && ncc) || L > 2048 || (H & 3) || bcs < Vs || ldb < 2 * bcs + Vs) return LR_EUNSUPPORTED;  // with the moments: chunks of 8 (ops.pca_warp)
   if (!(V * 4 + sD * 4 <= 0x80000000LL && sD < (1 << 23) && sD / 4 <= (1 << 20) && D <= 65535)) return LR_EUNSUPPORTED;
   if (((reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(disp) | reinterpret_cast<uintptr_t>(phi) |
         reinterpret_cast<uintptr_t>(warped) | reinterpret_cast<uintptr_t>(id2) | reinterpret_cast<uintptr_t>(target)) & 15u) ||
       (reinterpret_cast<uintptr_t>(basis) & (bf ? 7u : 15u)) || (ldb & 3) || (bcs & 3))
     return LR_EALIGN;
-  const dim3 grid((unsigned)((sD / 4 + 255) / 256), (unsigned)Dn), block(256);
+  const int gx = (int)((sD / 4 + 255) / 256), nch = (B + 7) / 8;
+  const int64_t flat = ((int64_t)gx * Dn + 7) / 8 * 8 * nch;   // B > 8: one block per (tile, chunk of 8 rows), chunks of a tile on one XCD
+  if (flat > 0x7fffffffLL) return LR_EUNSUPPORTED;
+  const dim3 grid(nch > 1 ? (unsigned)flat : (unsigned)gx, nch > 1 ? 1u : (unsigned)Dn), block(256);
   const float rcp_hv = 1.0f / (float)(H / 4);
   hipStream_t st = lr_stream(stream);
   const bool sc = flags & LR_WARP_USING_SCALE;
-#define LR_PW2(BFV, SCV, BTV, NCV) hipLaunchKernelGGL((pca_warp_kernel<BFV, SCV, BTV, NCV>), grid, block, (size_t)L * BTV * sizeof(float), st, coefs, basis, mean, img, id0, id1, id2, disp, phi, warped, B, L, C, D, W, H, ldb, rcp_hv, bcs, target, ncc_partial)
+#define LR_PW2(BFV, SCV, BTV, NCV) hipLaunchKernelGGL((pca_warp_kernel<BFV, SCV, BTV, NCV>), grid, block, (size_t)L * BTV * sizeof(float), st, coefs, basis, mean, img, id0, id1, id2, disp, phi, warped, B, L, C, D, W, H, ldb, rcp_hv, bcs, target, ncc_partial, gx, Dn, nch)
 #define LR_PW1(BFV, SCV, BTV) do { if (ncc) LR_PW2(BFV, SCV, BTV, true); else LR_PW2(BFV, SCV, BTV, false); } while (0)
-#define LR_PW(BFV, SCV) do { if (B <= 4) LR_PW1(BFV, SCV, 4); else LR_PW1(BFV, SCV, 8); } while (0)
+#define LR_PWM(BFV, SCV) hipLaunchKernelGGL((pca_warp_kernel<BFV, SCV, 8, false, true>), grid, block, (size_t)L * 8 * sizeof(float), st, coefs, basis, mean, img, id0, id1, id2, disp, phi, warped, B, L, C, D, W, H, ldb, rcp_hv, bcs, target, ncc_partial, gx, Dn, nch)
+#define LR_PW(BFV, SCV) do { if (nch > 1) LR_PWM(BFV, SCV); else if (B <= 4) LR_PW1(BFV, SCV, 4); else LR_PW1(BFV, SCV, 8); } while (0)
   if (bf) { if (sc) LR_PW(true, true); else LR_PW(true, false); }
   else    { if (sc) LR_PW(false, true); else LR_PW(false, false); }
 #undef LR_PW
+#undef LR_PWM
 #undef LR_PW1
 #undef LR_PW2
   if (int e = lr_launch_status()) return e;

@@ -809,7 +809,7 @@ def pca_warp_supported(coefs, basis_LxM, img, d0=0, d1=None):
 def pca_warp(coefs, basis_LxM, mean, ids, img, *, using_scale=True, d0=0, d1=None, target=None):
     """disp = coefs·basis + mean ; phi = disp + identity ; warped = Bilinear(img, phi) in ONE kernel:
     the displacement field is written once and never read back.  Returns (disp, phi, warped), bit-identical to
-    `pca_reconstruct` followed by `warp`.  Batches above 8 run in chunks (the basis is re-read per chunk).
+    `pca_reconstruct` followed by `warp`.  Batches above 8: chunks of 8 rows inside one launch (basis read from HBM once).
     Replaces …Backproj.py:102 + :68-69 in inference.
 
     Rows [d0,d1) (z-slab sharding): outputs are slabs; `basis_LxM`/`mean` are the full (L,3V)/(3V,) arrays or a rank's
@@ -854,8 +854,11 @@ def pca_warp(coefs, basis_LxM, mean, ids, img, *, using_scale=True, d0=0, d1=Non
         nblk = ((W * H // 4 + 255) // 256) * Dn * 4        # one partial per wave
         partial = torch.empty((min(B, 8), nblk, 5), dtype=torch.float64, device=img.device)
         moments = torch.empty((B, 5), dtype=torch.float64, device=img.device)
-    for lo in range(0, B, 8):
-        hi = min(B, lo + 8)
+    # without the moments ONE launch takes the whole batch (chunks of 8 rows of one tile share an XCD's L2: the basis leaves HBM
+    # once); with them: a launch per chunk of 8 (the partials are indexed by block)
+    step = 8 if target is not None else 256
+    for lo in range(0, B, step):
+        hi = min(B, lo + step)
         nb = esz * L * 3 * Vs + 4 * 3 * Vs + (hi - lo) * 4 * Vs * (6 + 2 * C) + (4 * (hi - lo) * Vs if target is not None else 0)
         name = "pca_warp" + ("_ncc" if target is not None else "") + ("_bf16basis" if bf else "")
         with _timed(name, bytes=nb, samples=hi - lo):

@@ -57,15 +57,15 @@ def test_c4_full_size_distance_from_the_fp32_reference(c4):
     far the bf16 path is from the REFERENCE's fp32 arithmetic (oracle/ref_ops.model_forward, conv_dtype fp32; the bench line
     prints the same record as `vs_fp32_reference`).  Measured on bench.py's C4 inputs (round 4): displacement max 3.4e-7
     absolute = 8.5e-5 of the field's scale, coefficients 1.0e-4 of theirs — bf16 activations are averaged over 16 K-wide
-    sums before they reach a coefficient.  Bars: north_star's 1e-4 on the displacement in absolute units, and 2e-3 relative
-    (20 x the measured values: a lost block or a wrong layout moves these by O(1))."""
+    sums before they reach a coefficient.  Bars: north_star's 1e-4 on the displacement in absolute units (2.5 % of this synthetic
+    field's scale — weak), 5e-4 of the field's scale on the displacement (6 x the measured value) and 2e-3 on the coefficients."""
     import bench
     net, inp, out = c4
     rec = bench.vs_fp32_reference(net, inp, out)
     print("C4 bf16 path vs the fp32 reference forward:", rec)
     assert rec["max_abs_disp"] <= 1e-4, rec                  # north_star's bar, in the field's own units
     assert rec["max_rel_coefs"] <= 2e-3, rec
-    assert rec["max_rel_disp"] <= 2e-3, rec
+    assert rec["max_rel_disp"] <= 5e-4, rec                  # relative to the field's scale: the meaningful bar (measured 8.5e-5)
     assert rec["mean_abs_disp"] <= 5e-4 * rec["disp_scale"], rec
     assert rec["max_rel_coefs"] > 1e-6          # it IS another arithmetic: the record must not silently compare bf16 with bf16
 

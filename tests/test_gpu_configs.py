@@ -180,17 +180,26 @@ def test_c5_conv_backward_at_384(dev):
     assert abs(float(gx.abs().sum(dtype=torch.float64)) - abs_sum) < 1e-3 * abs_sum      # and nothing anywhere else
 
 
-def test_reference_native_size_160(dev):
+@pytest.mark.parametrize("B", [1, 9])
+def test_reference_native_size_160(dev, B):
     """The reference's own configuration (cur_task_setting.json: 160³ volumes, drr_feature_num 4, latent_dim 56;
     the hard-coded Linear(4000, 800) of …Backproj.py:36): whole forward + configured NCC against the CPU oracle.
-    160 → 80 → 40 → 20 → 10 → 5: both channels-last layouts (parity-split and plain) are on the path."""
+    160 → 80 → 40 → 20 → 10 → 5: both channels-last layouts (parity-split and plain) are on the path.  The fast path must be
+    the one that runs: encoder blocks 0 + 1 as the five-channel pair kernel (no 16-channel activation in memory) and — B = 9 —
+    the decode of a batch above 8 as ONE launch."""
+    from liftreg_amd import ops
     from liftreg_amd.layers.losses import NCCLoss
-    n, P, L, B = 160, 4, 56, 1
+    n, P, L = 160, 4, 56
     net = _net(n, P, L, dev, 33)
     assert net.encoders[6][1].fc.in_features == 4000
     inp = _inputs(n, P, 240, B, dev, 33)                       # 1.5x receptor, the reference's default detector size
     with torch.no_grad():
-        out = net(inp)
+        with ops.kernel_timer() as kt:
+            out = net(inp)
+            torch.cuda.synchronize()
+        names = {k: len(v["ms"]) for k, v in kt.summary().items()}
+        assert names.get("conv3d_pair01_c5x16x32_160") == 1 and names.get("pca_warp") == 1, names
+        assert not any(k.startswith("conv3d_c5x16") or k.startswith("conv3d_c16x32") for k in names), names
         loss = NCCLoss()(out["warped"], out["target"])
         ref = ro.model_forward({k: v.cpu() for k, v in net.state_dict().items()}, {k: v.cpu() for k, v in inp.items()},
                                net.pca_vectors_LxM.cpu(), net.pca_mean.cpu())
@@ -322,3 +331,27 @@ def test_c5_twin_first_step_gradients_vs_aten_autograd(dev, grad_dtype):
         assert rel <= tol, (k, rel)
         assert float(np.dot(g, w) / (np.linalg.norm(g) * np.linalg.norm(w))) > 0.999, k
     print(f"C5 twin (96^3, B=4, grad_dtype {grad_dtype}): worst parameter-gradient distance {worst:.2e} of the gradient's scale")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,n,L,C", [(19, 40, 11, 1), (30, 32, 56, 1), (9, 36, 6, 2)])
+def test_pca_warp_batches_above_eight_in_one_launch(B, n, L, C):
+    """ops.pca_warp with B > 8: ONE launch, chunks of 8 batch rows per (tile, chunk) block with the chunks of a tile dealt to one
+    XCD (the basis leaves HBM once per batch — the reference's shipped batch size is 30, cur_task_setting.json:57): the bits of
+    the launch-per-chunk form (…Backproj.py:102 + :68-69)."""
+    import torch
+    from liftreg_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(B * 100 + n)
+    V = n * n * n
+    basis = torch.randn(L, 3 * V, device=dev, generator=g) * (0.02 / L ** 0.5)
+    mean = torch.randn(3 * V, device=dev, generator=g) * 0.01
+    coefs = torch.randn(B, L, device=dev, generator=g)
+    img = torch.rand(B, C, n, n, n, device=dev, generator=g) * 2 - 1
+    ids = tuple(torch.linspace(-1, 1, n, device=dev) for _ in range(3))
+    got = ops.pca_warp(coefs, basis, mean, ids, img)
+    for lo in range(0, B, 8):
+        hi = min(B, lo + 8)
+        want = ops.pca_warp(coefs[lo:hi].contiguous(), basis, mean, ids, img[lo:hi].contiguous())
+        for gt, wt in zip(got, want):
+            assert torch.equal(gt[lo:hi], wt), (lo, hi)
