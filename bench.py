@@ -601,17 +601,21 @@ def main():
         vols = (inp["target"][:, 0] + 1) * 500 - 1000                   # back to HU: the projector folds HU→μ
         R = cfg["R"]
 
-        def project():
-            return [ops.drr_forward(vols[b], p32, (R, R), (2.2, 2.2, 2.2), hu_input=True, flip_w=True) for b in range(B)]
+        vols = vols.contiguous()
+
+        def project():        # B volumes of one geometry: ONE launch (lr_drr_forward_batch_f32)
+            return ops.drr_forward_batch(vols, p32, (R, R), (2.2, 2.2, 2.2), hu_input=True, flip_w=True)
 
         with torch.no_grad():
             project()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(5):
-                project()
-            torch.cuda.synchronize()
+            with ops.kernel_timer() as kt_d:
+                for _ in range(5):
+                    project()
+                torch.cuda.synchronize()
             t_drr = (time.perf_counter() - t0) / 5                       # B volumes, P views each
+            drr_kernel_ms = float(np.mean(kt_d.summary()["drr_forward_batch"]["ms"]))
             t0 = time.perf_counter()
             for _ in range(5):
                 project()
@@ -619,8 +623,34 @@ def main():
             torch.cuda.synchronize()
             t_both = (time.perf_counter() - t0) / 5
         drr = {"volumes_per_s": B / t_drr, "projections_per_s": B * P / t_drr, "ms_per_volume": t_drr / B * 1e3,
-               "simulate_plus_register_per_s": B / t_both,
-               "note": f"{P} views of {R}x{R} per {n}^3 volume, HU->mu and the axis-1 flip folded into the projector's tap loads (no prologue pass, no temporary volume)"}
+               "kernel_ms_per_volume": drr_kernel_ms / B, "simulate_plus_register_per_s": B / t_both,
+               "note": f"{B} volumes per launch, {P} views of {R}x{R} per {n}^3 volume, HU->mu and the axis-1 flip folded into the projector's tap loads (no prologue pass, no temporary volume)"}
+        # The projector is a gather kernel on a cache-resident volume: its algorithmic HBM traffic is tiny and what
+        # bounds it is the vector-instruction issue of its address / weight / conversion arithmetic.  roofline_drr prices the
+        # wave-level vector instructions it issues (SQ_INSTS_VALU per launch from the PMC pass over this command,
+        # profiles/traffic.json — stamped with the kernel source like the byte counts) against one instruction per SIMD and
+        # 2 cycles (wave64 on a 32-lane pipe, MI355X_MICROARCH.md) at the nominal 2.4 GHz, beside its HBM and texture-address shares.
+        samples = float(B) * P * R * R * n
+        ent = None
+        if os.path.exists(traffic_file):
+            import hashlib
+            with open(traffic_file) as fh:
+                ent = json.load(fh).get(args.config, {}).get("drr_forward_batch")
+            if ent:
+                src = os.path.join(ROOT, "liftreg_amd", "csrc", str(ent.get("source")))
+                if not (os.path.exists(src) and hashlib.sha256(open(src, "rb").read()).hexdigest() == ent.get("source_sha256")):
+                    ent = None
+        valu = ent.get("valu_insts") if ent else None
+        peak_issue = 1024 * 2.4e9 / 2
+        roofline_drr = {"kernel": "drr_forward_batch", "bound": "valu_issue", "unit": "wave-instructions/s", "peak": peak_issue,
+                        "avg_ms": drr_kernel_ms, "samples_per_launch": samples,
+                        "achieved": (valu / (drr_kernel_ms * 1e-3)) if valu else None,
+                        "frac": (valu / (drr_kernel_ms * 1e-3) / peak_issue) if valu else None,
+                        "valu_per_wave_sample": (valu / (samples / 64)) if valu else None,
+                        "hbm_frac": (ent["bytes"] / (drr_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ent else None,
+                        "hbm_bytes": ent["bytes"] if ent else None, "ta_busy_frac": ent.get("ta_busy_frac") if ent else None,
+                        "algorithmic_hbm_frac": 4.0 * B * (n ** 3 + P * R * R) / (drr_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "note": "PMC counters from profiles/traffic.json (null: no profile of this kernel source)"}
 
     # slab mode: the sharded projector leg of the north star ("RCCL all-reduce of slab-boundary partial sums"): every rank
     # integrates the taps of its rows [d0,d1) of each target volume, the partial (P,Rd,Rh) images sum over the ranks
@@ -700,6 +730,7 @@ def main():
         "traffic_stale": stale,
         "ncc_loss": float(loss),
         "drr_forward": drr,
+        **({"roofline_drr": roofline_drr} if drr is not None else {}),
         **({"drr_forward_sharded": drr_sharded} if drr_sharded is not None else {}),
     }
     if rank == 0 and world == 1 and args.fp32_ref_only and not slab:

@@ -116,12 +116,19 @@ const char* lr_switch_name(int id);
  * nseg     : 1,2,4 or 8 — each ray's W planes are split into nseg runs summed
  *            by separate lanes (deterministic order); 0 = library default.
  * out      : dev, (P,Rd,Rh) fp32.
+ * LR_DRR_HU_INPUT expects finite values (a tap outside the volume counts 0 through its weight, not its address).
  */
 #define LR_DRR_HU_INPUT 1
 #define LR_DRR_FLIP_W 2
 int lr_drr_forward_f32(const float* vol_slab, const float* poses, const float* spacing,
                        float* out, int D, int W, int H, int d0, int d1,
                        int P, int Rd, int Rh, int flags, int nseg, void* stream);
+/* B volumes (slabs) of ONE geometry in one launch: vol_slabs + b * vol_batch_stride (elements, >= (d1-d0)*W*H) ->
+ * out + b * P*Rd*Rh.  Same results as B calls of lr_drr_forward_f32 (tools/preprocessingDRR.py:123-154 projects source and
+ * target of every case with one geometry; the dataset's cases are independent).  B <= 65535. */
+int lr_drr_forward_batch_f32(const float* vol_slabs, int64_t vol_batch_stride, const float* poses,
+                             const float* spacing, float* out, int B, int D, int W, int H, int d0, int d1,
+                             int P, int Rd, int Rh, int flags, int nseg, void* stream);
 
 /* Parity / API compatibility (forward_grids_with_poses, sdct_projection_utils.py:252-265):
  * the sample coordinates the projector uses and dx.

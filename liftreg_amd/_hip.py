@@ -32,6 +32,7 @@ SIGNATURES = {
     "lr_reload_switches": (_i, []),
     "lr_switch_name": (C.c_char_p, [_i]),
     "lr_drr_forward_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "lr_drr_forward_batch_f32": (_i, [_p, _i64, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "lr_hu_to_mu_f32": (_i, [_p, _p, _i64, _p]),
     "lr_drr_sample_coords_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "lr_backproject_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _p]),

@@ -203,9 +203,9 @@ __device__ __forceinline__ f32x4 max4(const f32x4& a, const f32x4& b) {
 //   E x [w2c0 w2c1 w2c2 0]      (w2 d0 x3)                  F x [w0c1 w0c2 w0c0 w0c1]   (w0 d1 c1 c2, w0 d2 c0 c1)
 //   G x [w0c2 w1c1 w1c2 0]      (w0 d2 c2, w1 d1 c1 c2)
 // = the same 18 exact products per tap.  27 taps x 5 = 135 record slots = 17 MFMAs of 8 slots per 16-voxel tile (24 before):
-// per tap row ty, the 8 taps (tz, ty, tx) without (2, ty, 2) form one data fragment per record kind, used with three (E) or
+// per tap row ty, the 8 taps (tz, ty, tx) without (0, ty, 2) form one data fragment per record kind, used with three (E) or
 // one (F, G) weight fragments = 15 MFMAs whose fragments two vertically adjacent tiles SHARE (input row iy is tap row iy of
-// the upper and iy - 1 of the lower tile); the three taps (2, ty, 2) x 5 slots fill two more MFMAs.  A tile's chain runs from
+// the upper and iy - 1 of the lower tile); the three taps (0, ty, 2) x 5 slots fill two more MFMAs.  A tile's chain runs from
 // the small products to the large: G, E x w2, F, E x w1, the two leftover MFMAs, E x w0.
 __device__ __forceinline__ void dense_records(const unsigned (&p01)[3], const unsigned (&p2)[3], unsigned (&rec)[3][2]) {
   rec[0][0] = p01[0];
@@ -220,8 +220,8 @@ __device__ __forceinline__ void dense_records(const unsigned (&p01)[3], const un
 // and EIGHT record slots per tap, 30 exact products in 32 element slots:
 //   A1 x w0[c0..c3], A1 x w1[c0..c3], A1 x w2[c0..c3]          A2 x [w0c4 w0c0 w0c1 w0c2], A2 x [w1c4 w1c0 w1c1 w1c2]
 //   A3 x [w0c3 w0c4 w0c0 w0c1], A3 x [w1c3 w1c4 0 0]           A4 x [w0c2 w0c3 w0c4 w2c4]
-// 27 taps x 8 = 216 slots = 27 MFMAs per 16-voxel tile with no padding at all: per tap row ty the 8 taps without (2, ty, 2) form one
-// fragment per record kind (8 MFMAs), and the leftover tap (2, ty, 2) fills exactly one more (its 8 slots = the 8 patterns above).
+// 27 taps x 8 = 216 slots = 27 MFMAs per 16-voxel tile with no padding at all: per tap row ty the 8 taps without (0, ty, 2) form one
+// fragment per record kind (8 MFMAs), and the leftover tap (0, ty, 2) fills exactly one more (its 8 slots = the 8 patterns above).
 // Every fragment belongs to ONE tap row, so two vertically adjacent tiles share all of them.  Chain, small products first:
 // A1 w2, A4, A3 w1, A3 w0, A2 w1, A1 w1, leftover, A2 w0, A1 w0 (three tap rows each).
 __device__ __forceinline__ void dense5_records(const unsigned (&p01)[3], const unsigned (&p23)[3], const unsigned (&d4)[3], unsigned (&rec)[4][2]) {
@@ -529,10 +529,15 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
       const int st_p0 = RING1_OFF + (ry0 * RS1 + (int)qpos * QS1 + col) * 8, st_p1 = st_p0 + RS1 * 8;
       const int st_s = RING1_OFF + (sry * RS1 + (int)qpos * QS1 + srx) * 8;
       // DENSE: ring-0 byte offsets of this lane's two fragment halves inside (plane, tile row 0) — pair tiles | the single tile — and
-      // of its leftover halves [fragment w][half]: three channels: slot 8 w + 2 lq + h = tap (2, slot / 5, 2), kind slot % 5 = E x w0,
-      // E x w1, E x w2, F, G (slot 15: weight 0); five channels: slot 2 lq + h = the record array 0 0 0 1 1 2 2 3 of tap (2, ty, 2)
-      const unsigned dnA = (unsigned)((col + 2 + (lq == 3 ? 2 : 0)) * 8), dnB = (unsigned)((col + (lq == 3 ? 4 : 3)) * 8);
-      const unsigned dnAs = (unsigned)(sry * RB0 + (srx + 2 + (lq == 3 ? 2 : 0)) * 8), dnBs = (unsigned)(sry * RB0 + (srx + (lq == 3 ? 4 : 3)) * 8);
+      // of its leftover halves [fragment w][half]: three channels: slot 8 w + 2 lq + h = tap (0, slot / 5, 2), kind slot % 5 = E x w0,
+      // E x w1, E x w2, F, G (slot 15: weight 0); five channels: slot 2 lq + h = the record array 0 0 0 1 1 2 2 3 of tap (0, ty, 2)
+      // The 8 taps (tz, tx) of a tap row in a main fragment — first halves: lq 0..2: (lq, 0), lq 3: (2, 1); second halves: (0, 1),
+      // (1, 1), (2, 2), (1, 2); the leftover tap is (0, ty, 2).  In both ds_read_b64 of a fragment the lane groups that share an LDS
+      // cycle (lq 0 with 1, lq 2 with 3) then read either complementary bank halves (planes of opposite parity, same record) or
+      // the same run of records shifted by one: no bank conflict (the (tz = lq; tx 0 | 1) + (0, 2) | (1, 2) order of round 4
+      // cost an extra LDS cycle on every second read).
+      const unsigned dnA = (unsigned)((col + 2 + (lq == 3 ? 1 : 0)) * 8), dnB = (unsigned)((col + (lq < 2 ? 3 : 4)) * 8);
+      const unsigned dnAs = (unsigned)(sry * RB0 + (srx + 2 + (lq == 3 ? 1 : 0)) * 8), dnBs = (unsigned)(sry * RB0 + (srx + (lq < 2 ? 3 : 4)) * 8);
       unsigned dnL[2][2], dnLs[2][2];
 #pragma unroll
       for (int w = 0; w < 2; ++w)
@@ -711,7 +716,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
       if constexpr (DENSE && PA0 > 0) {   // the first fragments of the column's first step (later steps: requested ahead of the barrier)
         const int t0 = (e6 % NRING0) * PLB0, t1 = ((e6 + 1) % NRING0) * PLB0, t2 = ((e6 + 2) % NRING0) * PLB0;
         DBase b0;
-        b0.pA = (unsigned)((lq == 1 ? t1 : lq == 2 ? t2 : t0) + ry0 * RB0) + dnA;
+        b0.pA = (unsigned)((lq == 0 ? t0 : lq == 1 ? t1 : t2) + ry0 * RB0) + dnA;
         b0.pB = (unsigned)((lq == 0 ? t0 : lq == 2 ? t2 : t1) + ry0 * RB0) + dnB;
         static_for<DENSE_PRE>([&](auto nc) __attribute__((always_inline)) { dload(nc, b0, fa); });
       }
@@ -732,8 +737,8 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
           // The first six fragments of the step were requested before the barrier (ring 0 is staged a step ahead).
           const int sl0 = ((e6 + 0) % NRING0) * PLB0, sl1 = ((e6 + 1) % NRING0) * PLB0, sl2 = ((e6 + 2) % NRING0) * PLB0,
                     sl3 = ((e6 + 3) % NRING0) * PLB0, sl4 = ((e6 + 4) % NRING0) * PLB0;
-          // first half: lq < 3: tap (tz = lq, ty, 0); lq = 3: (0, ty, 2).  second half: lq < 3: (lq, ty, 1); lq = 3: (1, ty, 2)
-          const int plA0 = lq == 1 ? sl1 : lq == 2 ? sl2 : sl0, plA1 = lq == 1 ? sl2 : lq == 2 ? sl3 : sl1, plA2 = lq == 1 ? sl3 : lq == 2 ? sl4 : sl2;
+          // planes of the lane's taps: first half tz = 0, 1, 2, 2 (lq 0..3), second half tz = 0, 1, 2, 1
+          const int plA0 = lq == 0 ? sl0 : lq == 1 ? sl1 : sl2, plA1 = lq == 0 ? sl1 : lq == 1 ? sl2 : sl3, plA2 = lq == 0 ? sl2 : lq == 1 ? sl3 : sl4;
           const int plB0 = lq == 0 ? sl0 : lq == 2 ? sl2 : sl1, plB1 = lq == 0 ? sl1 : lq == 2 ? sl3 : sl2, plB2 = lq == 0 ? sl2 : lq == 2 ? sl4 : sl3;
           DBase bP0, bP1, bS, bN;
           bP0.pA = (unsigned)(plA0 + ry0 * RB0) + dnA; bP0.pB = (unsigned)(plB0 + ry0 * RB0) + dnB;
@@ -744,9 +749,9 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
           for (int w = 0; w < 2; ++w)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-              bP0.pL[w][h] = (unsigned)(sl2 + ry0 * RB0) + dnL[w][h];
-              bP1.pL[w][h] = (unsigned)(sl3 + ry0 * RB0) + dnL[w][h];
-              bS.pL[w][h] = (unsigned)(spl ? sl3 : sl2) + dnLs[w][h];
+              bP0.pL[w][h] = (unsigned)(sl0 + ry0 * RB0) + dnL[w][h];     // (the leftover taps lie in plane tz = 0)
+              bP1.pL[w][h] = (unsigned)(sl1 + ry0 * RB0) + dnL[w][h];
+              bS.pL[w][h] = (unsigned)(spl ? sl1 : sl0) + dnLs[w][h];
               bN.pL[w][h] = 0u;
             }
           DFr fb, fs;
@@ -1216,10 +1221,14 @@ __global__ void pack_c01_w1_kernel(const float* __restrict__ w, u32x4* __restric
 
 constexpr int64_t W1_FLOATS = (int64_t)4 * 4 * 2 * 3 * 64 * 4;
 
+// tap (tz, tx) of record slot (lane group lq, half h) of a dense main fragment (the kernel's dnA / dnB / plA / plB); leftover: (0, 2)
+__host__ __device__ constexpr int main_tap_tz(int lq, int h) { return h == 0 ? (lq < 3 ? lq : 2) : (lq < 3 ? lq : 1); }
+__host__ __device__ constexpr int main_tap_tx(int lq, int h) { return h == 0 ? (lq < 3 ? 0 : 1) : (lq < 2 ? 1 : 2); }
+
 // The 17 weight fragments of the DENSE block 0 (three input channels), in the order of a tile's chain: WG[ty] WE2[ty] WF[ty]
 // WE1[ty] WL0 WL1 WE0[ty].  Lane (co = lane & 15, lq = lane >> 4) holds the 8 bf16 of its two record slots (half h = e >> 2,
 // position e & 3).  Main fragments (tap row ty): slot (lq, h) = tap (tz = lq, ty, tx = h) for lq < 3, (tz = h, ty, 2) for lq = 3;
-// leftover fragments: slot s = 8 w + 2 lq + h = tap (2, s / 5, 2), kind s % 5 (dense_left_*); the patterns per kind are in
+// leftover fragments: slot s = 8 w + 2 lq + h = tap (0, s / 5, 2), kind s % 5; the patterns per kind are in
 // the comment of dense_records.
 __global__ void pack_c01_w0_dense_kernel(const float* __restrict__ w, u32x4* __restrict__ packed) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1233,12 +1242,12 @@ __global__ void pack_c01_w0_dense_kernel(const float* __restrict__ w, u32x4* __r
     if (f < 12 || f >= 14) {
       const int grp = f < 12 ? f / 3 : 4, ty = f < 12 ? f % 3 : f - 14;
       kind = grp == 0 ? 4 : grp == 1 ? 2 : grp == 2 ? 3 : grp == 3 ? 1 : 0;
-      const int tz = lq < 3 ? lq : h, tx = lq < 3 ? h : 2;
+      const int tz = main_tap_tz(lq, h), tx = main_tap_tx(lq, h);
       tap = (tz * 3 + ty) * 3 + tx;
     } else {
       const int sidx = (f - 12) * 8 + lq * 2 + h;
       kind = sidx > 14 ? -1 : sidx % 5;
-      tap = (2 * 3 + (sidx > 14 ? 0 : sidx / 5)) * 3 + 2;
+      tap = (0 * 3 + (sidx > 14 ? 0 : sidx / 5)) * 3 + 2;
     }
     int sp = -1, c = 0;   // weight split, channel
     if (kind >= 0 && kind <= 2) { if (pos < 3) { sp = kind; c = pos; } else if (kind < 2) { sp = kind; c = 0; } }
@@ -1254,7 +1263,7 @@ constexpr int64_t W0D_FLOATS = (int64_t)Chain<3>::NMF * 64 * 4;
 
 // The 27 weight fragments of block 0 with FIVE input channels, in the order of a tile's chain (Chain<5>): phase k / 3 = A1 w2, A4,
 // A3 w1, A3 w0, A2 w1, A1 w1, leftover, A2 w0, A1 w0; tap row ty = k % 3.  Slots of a main fragment as in pack_c01_w0_dense_kernel;
-// the leftover fragment of tap row ty: slot 2 lq + h = pattern A1 w0, A1 w1, A1 w2, A2 w0, A2 w1, A3 w0, A3 w1, A4 of tap (2, ty, 2).
+// the leftover fragment of tap row ty: slot 2 lq + h = pattern A1 w0, A1 w1, A1 w2, A2 w0, A2 w1, A3 w0, A3 w1, A4 of tap (0, ty, 2).
 // Patterns (weight split, channel) per position: comment of dense5_records.
 __global__ void pack_c01_w0_dense5_kernel(const float* __restrict__ w, u32x4* __restrict__ packed) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1268,10 +1277,10 @@ __global__ void pack_c01_w0_dense5_kernel(const float* __restrict__ w, u32x4* __
     int pat, tap;   // pattern 0..7 = A1 w0, A1 w1, A1 w2, A2 w0, A2 w1, A3 w0, A3 w1, A4
     if (phase == 6) {
       pat = lq * 2 + h;
-      tap = (2 * 3 + ty) * 3 + 2;
+      tap = (0 * 3 + ty) * 3 + 2;
     } else {
       pat = phase == 0 ? 2 : phase == 1 ? 7 : phase == 2 ? 6 : phase == 3 ? 5 : phase == 4 ? 4 : phase == 5 ? 1 : phase == 7 ? 3 : 0;
-      const int tz = lq < 3 ? lq : h, tx = lq < 3 ? h : 2;
+      const int tz = main_tap_tz(lq, h), tx = main_tap_tx(lq, h);
       tap = (tz * 3 + ty) * 3 + tx;
     }
     int sp = -1, c = 0;

@@ -67,6 +67,40 @@ __device__ __forceinline__ void sample_pix(const RaySetup& r, int j, float ex, f
   ph = lr_unnormalize(gz, H);
 }
 
+// x / d as q = x r, e = fma(-q, d, x), q' = fma(e, r, q) with r = RN(1 / d): the IEEE quotient for every divisor on the
+// launcher's whitelist and every |x| in [2^-20, 2^12] (checked exhaustively on the CPU: tests/test_oracle_golden_r2.py through
+// oracle/liftreg_oracle.c: or_fastdiv_mismatches) — sample coordinates are 0 or at least one ulp of the emitter distance
+// (> 2^-15) and stay below 2^12 voxels.  Three vector-ALU operations instead of the ~11 of the IEEE divide sequence.
+struct FastDiv {
+  float d, r;     // divisor, RN(1 / d)
+  int pow2;       // d is a power of two: x * r is the exact quotient
+};
+template <bool FD>
+__device__ __forceinline__ float div_by(float x, const FastDiv& f) {
+  if constexpr (FD) {   // (a power of two: q is already the exact quotient, e = 0, q' = q — no special case)
+    const float q = x * f.r;
+    const float e = fmaf(-q, f.d, x);
+    return fmaf(e, f.r, q);
+  } else {
+    return f.pow2 ? x * f.r : x / f.d;
+  }
+}
+template <bool FD>
+__device__ __forceinline__ void sample_pix_fd(const RaySetup& r, int j, float ex, float ey, float ez, int D, int W, int H,
+                                              const FastDiv& fD, const FastDiv& fW, const FastDiv& fH, float& pd, float& pw,
+                                              float& ph) {
+  const float t = r.rc * ((float)j - ey);
+  const float x = r.ihx * t + ex;
+  const float y = r.ihy * t + ey;
+  const float z = r.ihz * t + ez;
+  const float gx = div_by<FD>(x, fD) * 2.0f;
+  const float gy = div_by<FD>(y - 0.0f, fW) * 2.0f + -1.0f;
+  const float gz = div_by<FD>(z, fH) * 2.0f;
+  pd = lr_unnormalize(gx, D);
+  pw = lr_unnormalize(gy, W);
+  ph = lr_unnormalize(gz, H);
+}
+
 struct Axis {
   int i0, i1;
   float w0, w1;  // (i1 - pix), (pix - i0) — ATen's generic 3D kernel
@@ -125,6 +159,25 @@ __device__ __forceinline__ float mu_of_fast(float v) {
   const float e = fmaf(-q, 1000.0f, x);
   const float qc = fmaf(e, r, q);
   return qc * 0.2f;
+}
+
+// two conversions as packed fp32 operations (v_pk_add / v_pk_mul / v_pk_fma: the IEEE result of each element, as mu_of_fast)
+__device__ __forceinline__ void mu_of_fast2(float& a, float& b) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  // new_img[new_img < -1000] = -1000 as one v_max_f32 per value (finite input: the header's contract for LR_DRR_HU_INPUT; inline
+  // asm: llvm.maxnum on a loaded value first canonicalises it — a second instruction)
+  float ma, mb;
+  asm("v_max_f32 %0, %1, %2" : "=v"(ma) : "v"(a), "v"(-1000.0f));
+  asm("v_max_f32 %0, %1, %2" : "=v"(mb) : "v"(b), "v"(-1000.0f));
+  f32x2 v = {ma, mb};
+  const f32x2 k1000 = {1000.0f, 1000.0f}, r = {1.0f / 1000.0f, 1.0f / 1000.0f}, k02 = {0.2f, 0.2f};
+  const f32x2 x = v + k1000;
+  const f32x2 q = x * r;
+  const f32x2 e = __builtin_elementwise_fma(-q, k1000, x);
+  const f32x2 qc = __builtin_elementwise_fma(e, r, q);
+  const f32x2 m = qc * k02;
+  a = m[0];
+  b = m[1];
 }
 
 template <bool HU>
@@ -233,11 +286,18 @@ __global__ __launch_bounds__(1024) void drr_forward_kernel(
 //    outside the slab falls outside the resource by itself, an out-of-range y row is pushed outside with one select;
 //  * the x pair is one 8-byte load; only where a wave touches the x faces a wave-uniform branch re-bases it;
 //  * products and sums in the general kernel's order: same bits.
-template <bool FLIP, bool HU = false>
+//  * batches: blockIdx.y = the volume (vol_bs / P*Rd*Rh elements apart): one launch for B volumes of one geometry;
+//  * FD: the three normalising divisions by D, W - 1, H as a reciprocal multiplication + one correction step (div_by);
+//  * HU: the eight conversions of a sample as four PAIRS of packed fp32 operations (same IEEE roundings per element), and
+//    the y rows outside the volume need no address select (their weight is zeroed: whatever finite value is read counts 0).
+template <bool FLIP, bool HU = false, bool FD = false>
 __global__ __launch_bounds__(1024) void drr_forward_fast_kernel(
     const float* __restrict__ vol, LrPoses poses, float sp0, float sp1, float sp2,
-    float* __restrict__ out, int D, int W, int H, int d0, int d1, int P, int Rd, int Rh, int nseg) {
+    float* __restrict__ out, int D, int W, int H, int d0, int d1, int P, int Rd, int Rh, int nseg, int64_t vol_bs,
+    FastDiv fD, FastDiv fW, FastDiv fH) {
   extern __shared__ float part[];  // [R][64]
+  vol += (int64_t)blockIdx.y * vol_bs;
+  out += (int64_t)blockIdx.y * P * Rd * Rh;
   const int lane = threadIdx.x, row = threadIdx.y, R = blockDim.y;
   const int a_per_blk = R / nseg;
   const int nbx = (Rh + 63) >> 6;
@@ -266,7 +326,7 @@ __global__ __launch_bounds__(1024) void drr_forward_fast_kernel(
     const float zlo = (float)(d0 - 1), zhi = (float)d1, yhi = (float)W, xhi = (float)H;
     for (int j = j0; j < j1; ++j) {
       float pd, pw, ph;
-      sample_pix(rs, j, ex, ey, ez, D, W, H, pd, pw, ph);
+      sample_pix_fd<FD>(rs, j, ex, ey, ez, D, W, H, fD, fW, fH, pd, pw, ph);
       pd = __builtin_amdgcn_fmed3f(pd, zlo, zhi);   // NaN -> a bound; both bounds contribute nothing
       pw = __builtin_amdgcn_fmed3f(pw, -1.0f, yhi);
       ph = __builtin_amdgcn_fmed3f(ph, -1.0f, xhi);
@@ -284,8 +344,9 @@ __global__ __launch_bounds__(1024) void drr_forward_fast_kernel(
         wy1 = ((unsigned)(y0 + 1) < (unsigned)W) ? wy1 : 0.0f;
       }
       const int r0 = FLIP ? (W - 1 - y0) : y0, r1 = FLIP ? r0 - 1 : r0 + 1;
-      const int yo0 = ((unsigned)y0 < (unsigned)W) ? __mul24(r0, H) : OUTSIDE;
-      const int yo1 = ((unsigned)(y0 + 1) < (unsigned)W) ? __mul24(r1, H) : OUTSIDE;
+      // (HU: the weight of a row outside the volume is 0 and the buffer resource bounds whatever address results)
+      const int yo0 = (HU || (unsigned)y0 < (unsigned)W) ? __mul24(r0, H) : OUTSIDE;
+      const int yo1 = (HU || (unsigned)(y0 + 1) < (unsigned)W) ? __mul24(r1, H) : OUTSIDE;
       const int zo0 = __mul24(z0, sD), zo1 = zo0 + sD;
       const int xb = min(max(x0, 0), H - 2), shift = x0 - xb;
       const unsigned xb4 = (unsigned)xb << 2;
@@ -299,25 +360,23 @@ __global__ __launch_bounds__(1024) void drr_forward_fast_kernel(
                      __builtin_bit_cast(float, q11.x), __builtin_bit_cast(float, q11.y)};
       if constexpr (HU) {
 #pragma unroll
-        for (int t8 = 0; t8 < 8; ++t8) tp[t8] = mu_of_fast(tp[t8]);
+        for (int t8 = 0; t8 < 8; t8 += 2) mu_of_fast2(tp[t8], tp[t8 + 1]);
       }
-      if (__builtin_amdgcn_ballot_w64(shift != 0) != 0) {  // x0 in {-1, H-1, H}: re-base the pair, drop what is outside
-        const bool ok0 = (unsigned)x0 < (unsigned)H, ok1 = (unsigned)(x0 + 1) < (unsigned)H;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float px = tp[2 * r], py = tp[2 * r + 1];
-          tp[2 * r] = ok0 ? (shift > 0 ? py : px) : 0.0f;
-          tp[2 * r + 1] = ok1 ? (shift < 0 ? px : py) : 0.0f;
-        }
+      // x0 in {-1, H-1, H} (a wave at an x face): the loaded pair is (xb, xb+1) = x0 shifted by `shift`; instead of moving eight
+      // taps the two x weights move (a tap outside the volume gets weight 0; x + 0 = 0 + x, so the sum keeps its bits)
+      float wxa = wx0, wxb = wx1;
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(shift != 0) != 0, 0)) {
+        wxa = shift == 0 ? wx0 : shift < 0 ? wx1 : 0.0f;
+        wxb = shift == 0 ? wx1 : shift == 1 ? wx0 : 0.0f;
       }
-      float s = tp[0] * ((wx0 * wy0) * wz0);
-      s = s + tp[1] * ((wx1 * wy0) * wz0);
-      s = s + tp[2] * ((wx0 * wy1) * wz0);
-      s = s + tp[3] * ((wx1 * wy1) * wz0);
-      s = s + tp[4] * ((wx0 * wy0) * wz1);
-      s = s + tp[5] * ((wx1 * wy0) * wz1);
-      s = s + tp[6] * ((wx0 * wy1) * wz1);
-      s = s + tp[7] * ((wx1 * wy1) * wz1);
+      float s = tp[0] * ((wxa * wy0) * wz0);
+      s = s + tp[1] * ((wxb * wy0) * wz0);
+      s = s + tp[2] * ((wxa * wy1) * wz0);
+      s = s + tp[3] * ((wxb * wy1) * wz0);
+      s = s + tp[4] * ((wxa * wy0) * wz1);
+      s = s + tp[5] * ((wxb * wy0) * wz1);
+      s = s + tp[6] * ((wxa * wy1) * wz1);
+      s = s + tp[7] * ((wxb * wy1) * wz1);
       acc = acc + s;
     }
   }
@@ -378,17 +437,35 @@ int fill_poses(LrPoses& lp, const float* poses, int P) {
 
 }  // namespace
 
-extern "C" int lr_drr_forward_f32(const float* vol_slab, const float* poses, const float* spacing,
-                                  float* out, int D, int W, int H, int d0, int d1, int P, int Rd,
-                                  int Rh, int flags, int nseg, void* stream) {
+// divisors the reciprocal division of div_by is validated for (tests/test_oracle_golden_r2.py: every |x| in [2^-20, 2^12])
+static bool fastdiv_ok(int d) {
+  if (d > 0 && (d & (d - 1)) == 0) return true;
+  static const int ok[] = {31, 63, 95, 127, 159, 191, 255, 383, 511, 96, 160, 192, 384};
+  for (int v : ok)
+    if (v == d) return true;
+  return false;
+}
+static FastDiv make_fastdiv(int d) {
+  FastDiv f;
+  f.d = (float)d;
+  f.r = 1.0f / (float)d;
+  f.pow2 = (d > 0 && (d & (d - 1)) == 0) ? 1 : 0;
+  return f;
+}
+
+static int drr_forward_impl(const float* vol_slab, int64_t vol_batch_stride, const float* poses, const float* spacing,
+                            float* out, int B, int D, int W, int H, int d0, int d1, int P, int Rd,
+                            int Rh, int flags, int nseg, void* stream) {
   if (!vol_slab || !out || !spacing) return LR_ENULL;
-  if (D < 1 || W < 2 || H < 1 || Rd < 1 || Rh < 1) return LR_EINVAL;
+  if (B < 1 || B > 65535 || D < 1 || W < 2 || H < 1 || Rd < 1 || Rh < 1) return LR_EINVAL;
   if (d0 < 0 || d1 > D || d1 <= d0) return LR_EINVAL;
   if (flags & ~(LR_DRR_HU_INPUT | LR_DRR_FLIP_W)) return LR_EINVAL;
+  if (B > 1 && vol_batch_stride < (int64_t)(d1 - d0) * W * H) return LR_EINVAL;
   LrPoses lp;
   if (int e = fill_poses(lp, poses, P)) return e;
   if (nseg == 0) {
-    // enough lanes to fill 256 CUs x 32 waves, capped at 16 runs per ray
+    // enough lanes to fill 256 CUs x 32 waves with ONE volume, capped at 16 runs per ray (the batch size stays out of the rule: a
+    // volume's DRR has the same bits in a batch as alone)
     const int64_t rays = (int64_t)P * Rd * ((Rh + 63) / 64 * 64);
     nseg = 1;
     while (nseg < 16 && rays * nseg < 256LL * 4096 && W / (nseg * 2) >= 8) nseg *= 2;  // measured: 8 runs at 2x256^2
@@ -398,32 +475,55 @@ extern "C" int lr_drr_forward_f32(const float* vol_slab, const float* poses, con
   const int a_per_blk = R / nseg;
   const int64_t nblk = (int64_t)P * ((Rd + a_per_blk - 1) / a_per_blk) * ((Rh + 63) / 64);
   if (nblk > 0x7fffffffLL) return LR_EINVAL;
-  const dim3 grid((unsigned)nblk), block(64, R);
+  const dim3 grid((unsigned)nblk, (unsigned)B), block(64, R);
   const size_t lds = (size_t)R * 64 * sizeof(float);
   const bool hu = flags & LR_DRR_HU_INPUT, flip = flags & LR_DRR_FLIP_W;
-#define LR_LAUNCH(HUV, FLV)                                                                    \
-  hipLaunchKernelGGL((drr_forward_kernel<HUV, FLV>), grid, block, lds, lr_stream(stream),      \
-                     vol_slab, lp, spacing[0], spacing[1], spacing[2], out, D, W, H, d0, d1, P, \
-                     Rd, Rh, nseg)
   const int64_t sD64 = (int64_t)W * H;
   if (H >= 2 && (int64_t)(d1 - d0) * sD64 * 4 + sD64 * 8 <= 0x80000000LL && sD64 < (1 << 23) &&
       !lr_sw_set(LR_SW_DRR_GENERAL)) {
-#define LR_FAST(FLV, HUV)                                                                                            \
-  hipLaunchKernelGGL((drr_forward_fast_kernel<FLV, HUV>), grid, block, lds, lr_stream(stream), vol_slab, lp, spacing[0], \
-                     spacing[1], spacing[2], out, D, W, H, d0, d1, P, Rd, Rh, nseg)
+    const FastDiv fD = make_fastdiv(D), fW = make_fastdiv(W - 1), fH = make_fastdiv(H);
+    const bool fd = fastdiv_ok(D) && fastdiv_ok(W - 1) && fastdiv_ok(H);
+#define LR_FAST3(FLV, HUV, FDV)                                                                                          \
+  hipLaunchKernelGGL((drr_forward_fast_kernel<FLV, HUV, FDV>), grid, block, lds, lr_stream(stream), vol_slab, lp, spacing[0], \
+                     spacing[1], spacing[2], out, D, W, H, d0, d1, P, Rd, Rh, nseg, vol_batch_stride, fD, fW, fH)
+#define LR_FAST(FLV, HUV) do { if (fd) LR_FAST3(FLV, HUV, true); else LR_FAST3(FLV, HUV, false); } while (0)
     if (hu && flip) LR_FAST(true, true);
     else if (hu) LR_FAST(false, true);
     else if (flip) LR_FAST(true, false);
     else LR_FAST(false, false);
 #undef LR_FAST
+#undef LR_FAST3
     return lr_launch_status();
   }
-  if (hu && flip) LR_LAUNCH(true, true);
-  else if (hu) LR_LAUNCH(true, false);
-  else if (flip) LR_LAUNCH(false, true);
-  else LR_LAUNCH(false, false);
+  // the general kernel: one volume per launch
+  for (int b = 0; b < B; ++b) {
+    const float* vb = vol_slab + (int64_t)b * vol_batch_stride;
+    float* ob = out + (int64_t)b * P * Rd * Rh;
+    const dim3 grid1((unsigned)nblk);
+#define LR_LAUNCH(HUV, FLV)                                                                    \
+  hipLaunchKernelGGL((drr_forward_kernel<HUV, FLV>), grid1, block, lds, lr_stream(stream),      \
+                     vb, lp, spacing[0], spacing[1], spacing[2], ob, D, W, H, d0, d1, P, \
+                     Rd, Rh, nseg)
+    if (hu && flip) LR_LAUNCH(true, true);
+    else if (hu) LR_LAUNCH(true, false);
+    else if (flip) LR_LAUNCH(false, true);
+    else LR_LAUNCH(false, false);
 #undef LR_LAUNCH
-  return lr_launch_status();
+    if (int e = lr_launch_status()) return e;
+  }
+  return LR_OK;
+}
+
+extern "C" int lr_drr_forward_f32(const float* vol_slab, const float* poses, const float* spacing,
+                                  float* out, int D, int W, int H, int d0, int d1, int P, int Rd,
+                                  int Rh, int flags, int nseg, void* stream) {
+  return drr_forward_impl(vol_slab, 0, poses, spacing, out, 1, D, W, H, d0, d1, P, Rd, Rh, flags, nseg, stream);
+}
+
+extern "C" int lr_drr_forward_batch_f32(const float* vol_slabs, int64_t vol_batch_stride, const float* poses,
+                                        const float* spacing, float* out, int B, int D, int W, int H, int d0, int d1,
+                                        int P, int Rd, int Rh, int flags, int nseg, void* stream) {
+  return drr_forward_impl(vol_slabs, vol_batch_stride, poses, spacing, out, B, D, W, H, d0, d1, P, Rd, Rh, flags, nseg, stream);
 }
 
 extern "C" int lr_hu_to_mu_f32(const float* hu, float* mu, int64_t n, void* stream) {

@@ -150,6 +150,29 @@ def drr_forward(vol, poses, resolution, spacing=(2.2, 2.2, 2.2), *, d0=0, d1=Non
     return out
 
 
+def drr_forward_batch(vols, poses, resolution, spacing=(2.2, 2.2, 2.2), *, hu_input=False, flip_w=False, nseg=0, out=None):
+    """Cone-beam DRRs of B volumes `vols` (B,D,W,H) (or (B,1,D,W,H)) with ONE geometry in one launch → (B,P,Rd,Rh): the bits of
+    B calls of `drr_forward` (reference: tools/preprocessingDRR.py:123-154 projects every case's source and target with the same
+    emitter poses, sdct_projection_utils.py:59-100 each)."""
+    vols = _dev(vols, "vols")
+    if vols.dim() == 5 and vols.shape[1] == 1:
+        vols = vols[:, 0]
+    if vols.dim() != 4 or not vols[0].is_contiguous():
+        raise ValueError("vols must be (B,D,W,H) with dense (D,W,H) volumes")
+    B, D, W, H = vols.shape
+    poses = _host_f32(poses, (3,), "poses").reshape(-1, 3)
+    sp = _host_f32(spacing, (3,), "spacing")
+    P = poses.shape[0]
+    Rd, Rh = int(resolution[0]), int(resolution[1])
+    out = torch.empty((B, P, Rd, Rh), dtype=torch.float32, device=vols.device) if out is None else _out_arg(out, (B, P, Rd, Rh))
+    flags = (_hip.DRR_HU_INPUT if hu_input else 0) | (_hip.DRR_FLIP_W if flip_w else 0)
+    with _timed("drr_forward_batch", bytes=4 * B * (D * W * H + P * Rd * Rh), samples=B):
+        _hip.check(_hip.lib().lr_drr_forward_batch_f32(vols.data_ptr(), int(vols.stride(0)) if B > 1 else D * W * H,
+                                                       poses.ctypes.data, sp.ctypes.data, out.data_ptr(), B, D, W, H, 0, D, P,
+                                                       Rd, Rh, flags, nseg, _stream()), "lr_drr_forward_batch_f32")
+    return out
+
+
 def drr_sample_coords(poses, spacing, shape, resolution, device, normalized=False):
     """(pix (P,Rd,Rh,W,3) ordered (d,w,h), dx (P,Rd,Rh)) — the projector's sample grid."""
     D, W, H = (int(v) for v in shape)

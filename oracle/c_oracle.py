@@ -199,3 +199,13 @@ def ncc_moments(x, y, R):
     lib().or_ncc_moments_f32(x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)),
                              m.ctypes.data_as(C.POINTER(C.c_double)), R, C.c_int64(N))
     return m
+
+
+def fastdiv_mismatches(d, lo=2.0 ** -20, hi=2.0 ** 12):
+    """How many floats x, lo <= |x| < hi, have x / d != the projector's reciprocal division (drr_forward.hip: div_by)."""
+    import struct
+    f = lib().or_fastdiv_mismatches
+    f.restype = C.c_int64
+    f.argtypes = [C.c_float, C.c_uint32, C.c_uint32]
+    bits = lambda v: struct.unpack("I", struct.pack("f", v))[0]
+    return int(f(float(d), bits(lo), bits(hi)))

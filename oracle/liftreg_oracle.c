@@ -449,3 +449,27 @@ void or_ncc_moments_f32(const float* x, const float* y, double* moments, int R, 
     memcpy(moments + 5 * r, s, sizeof s);
   }
 }
+
+
+/* Test aid for the projector's reciprocal division (liftreg_amd/csrc/drr_forward.hip: div_by): how many floats x with bit patterns in
+ * [lo_bits, hi_bits) — both signs — have x / d != fma(fma(-q, d, x), r, q), q = x r, r = RN(1 / d).  0 = the three-operation
+ * sequence IS the IEEE division on that range. */
+#include <string.h>
+int64_t or_fastdiv_mismatches(float d, uint32_t lo_bits, uint32_t hi_bits) {
+  const float r = 1.0f / d;
+  int64_t bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+  for (int64_t u = (int64_t)lo_bits; u < (int64_t)hi_bits; ++u) {
+    for (int sgn = 0; sgn < 2; ++sgn) {
+      const uint32_t bits = (uint32_t)u | (sgn ? 0x80000000u : 0u);
+      float x;
+      memcpy(&x, &bits, 4);
+      const float q = x * r;
+      const float e = fmaf(-q, d, x);
+      const float qc = fmaf(e, r, q);
+      const float want = x / d;
+      if (memcmp(&qc, &want, 4) != 0) ++bad;
+    }
+  }
+  return bad;
+}

@@ -130,6 +130,30 @@ def test_drr_fast_kernel_equals_general_kernel(ops, dev, monkeypatch):
             assert fast.max() > 0 and (fast == 0).any()      # some rays cross the volume, some miss it
 
 
+@pytest.mark.parametrize("n,R,P", [(32, 40, 2), (96, 96, 3), (160, 240, 2), (40, 36, 2)])
+def test_drr_batch_and_reciprocal_division_equal_the_c_oracle(ops, dev, n, R, P):
+    """lr_drr_forward_batch_f32: B volumes of one geometry in ONE launch = B single launches = the C oracle bit for bit, HU input
+    with the flip folded (tools/preprocessingDRR.py:135-154) — at sizes whose normalising divisors (D, W - 1, H) are on the
+    projector's reciprocal-division whitelist (32: 31; 96: 96, 95; 160: 160, 159) and at one that is not (40: IEEE division)."""
+    rs = np.random.RandomState(n)
+    B = 3
+    hu = rs.uniform(-1100, 900, (B, n, n, n)).astype(np.float32)
+    p32 = ro.scan_poses(30, P, n).astype(np.float32)
+    sp = np.array((2.2, 2.2, 2.2), np.float32)
+    for nseg in (1, 0):          # one run per ray = the oracle's summation order | the library's choice of runs
+        got = ops.drr_forward_batch(T(hu, dev), p32, (R, R), sp, hu_input=True, flip_w=True, nseg=nseg).cpu().numpy()
+        for b in range(B):
+            one = ops.drr_forward(T(hu[b], dev), p32, (R, R), sp, hu_input=True, flip_w=True, nseg=nseg).cpu().numpy()
+            assert np.array_equal(got[b], one), b
+        want = co.drr_forward(hu[1][:, ::-1].copy(), p32, sp, (R, R), flags=1)      # the oracle on the flipped volume, HU input
+        if nseg == 1:
+            assert np.array_equal(got[1], want)
+        else:
+            np.testing.assert_allclose(got[1], want, rtol=1e-5, atol=1e-6)
+    mu = ops.drr_forward_batch(T(hu * 0 + 0.1, dev), p32, (R, R), sp).cpu().numpy()    # attenuation input, no flip
+    assert np.array_equal(mu[0], mu[2]) and mu.max() > 0
+
+
 # ------------------------------------------------------------------------------------- K2 backprojection
 @pytest.mark.parametrize("tag", ["bp_a", "bp_b", "bp_c"])
 def test_backproject_golden(golden, ops, dev, tag):

@@ -1,8 +1,12 @@
 """CPU: pin the oracle restatements of the rows closed in round 2 against golden vectors produced by importing the
 reference (tests/golden/make_golden_r2.py): forward_grids / forward_grids_with_poses (a5), the pose-less float64
 backproj_grids (a6'), the CSV geometry wrapper (a2') and the DirLab landmark sampler / TRE (f4)."""
+import os
+
 import numpy as np
 import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import ref_ops as ro
 
@@ -75,3 +79,19 @@ def test_regulariser_is_a_quadratic_form_of_the_pca_coefficients():
     ro.disp_reg(mean[None] + torch.einsum("bl,lcdwh->bcdwh", c, basis)).backward()
     gc = (2 * lin[None] + 2 * coefs @ G) / B
     assert float((c.grad - gc).abs().max()) <= 1e-12 * float(gc.abs().max())
+
+
+def test_projector_reciprocal_division_is_the_ieee_division_on_its_whitelist():
+    """liftreg_amd/csrc/drr_forward.hip normalises the sample coordinates (sdct_projection_utils.py:54-56: x / D, y / (W - 1),
+    z / H) with q = x r, e = fma(-q, d, x), q' = fma(e, r, q) for the divisors on its launcher's whitelist (fastdiv_ok): here
+    EVERY float 2^-20 <= |x| < 2^12 is divided both ways on the CPU — zero mismatches, so the three-operation sequence is the
+    IEEE division there (coordinates are 0 or at least an ulp of the emitter distance, > 2^-15, and below 2^12 voxels)."""
+    import re
+    from oracle import c_oracle as co
+    src = open(os.path.join(ROOT, "liftreg_amd", "csrc", "drr_forward.hip")).read()
+    listed = re.search(r"static const int ok\[\] = \{([0-9, ]+)\};", src)
+    assert listed, "whitelist not found in drr_forward.hip"
+    divisors = [int(v) for v in listed.group(1).split(",")]
+    assert len(divisors) >= 8
+    for d in divisors:
+        assert co.fastdiv_mismatches(d) == 0, d

@@ -9,7 +9,8 @@ TAG=$1; shift
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-drr --ramp-seconds 0 --steps 3 --warmup 1 $*"
+# PMC_DRR=1: keep the projector legs in the run (their kernel gets its own traffic.json entry, with SQ_INSTS_VALU for roofline_drr)
+ARGS="--no-cpu-baseline $([ "${PMC_DRR:-0}" = 1 ] || echo --no-drr) --ramp-seconds 0 --steps 3 --warmup 1 $*"
 i=0
 for G in \
   "FETCH_SIZE" \

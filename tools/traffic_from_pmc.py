@@ -19,7 +19,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "liftreg_amd", "csrc")
-CONFIG_N = {"c1": 64, "c2": 128, "c3": 256, "c4": 256}
+CONFIG_N = {"c1": 64, "c2": 128, "c3": 256, "c4": 256, "native160": 160}
 
 
 def short_name(k):
@@ -43,7 +43,7 @@ def sha256(path):
 def op_table(cfg, P, bf16):
     """(bench op name, kernel regex, rank among same-regex groups by descending grid size)."""
     n = CONFIG_N[cfg]
-    ops = [("backproject", r"^backproject_(tiled_)?kernel", 0), ("pca_warp", r"^pca_warp_kernel<.*, false>$", 0),
+    ops = [("drr_forward_batch", r"^drr_forward_fast_kernel", 0), ("backproject", r"^backproject_(tiled_)?kernel", 0), ("pca_warp", r"^pca_warp_kernel<.*, false(, (true|false))?>$", 0),
            ("pca_warp_ncc", r"^pca_warp_kernel<.*, true>$", 0), ("ncc_moments", r"^ncc_moments_kernel", 0),
            (f"conv3d_c{P + 1}x16_s1_{n}", r"^(conv3d_planar_kernel|conv0_split_f32_kernel<.*, 3, false, false>)", 0), (f"conv3d_bp_c{P + 1}x16_s1_{n}", r"^conv0_pc_kernel<.*, true>$", 0),
            (f"conv3d_c16x32_s2_{n}", r"^conv3d_rows_wlds_kernel<2, 1,", 0),
@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--bench-args", default="")
     a = ap.parse_args()
     cfg = (re.search(r"--config\s+(\w+)", a.bench_args) or [None, "c3"])[1]
-    P = 11 if cfg == "c4" else 2
+    P = 11 if cfg == "c4" else 4 if cfg == "native160" else 2
     agg = defaultdict(lambda: defaultdict(list))       # (kernel, grid) -> counter -> values
     meta = {}
     for f in glob.glob(os.path.join(a.out, "p*", "**", "*counter_collection.csv"), recursive=True):
@@ -127,6 +127,8 @@ def main():
         src = source_of(key[0])
         traffic[op] = {"bytes": int((2 * avg["FETCH_SIZE"] + avg["WRITE_SIZE"]) * 1024),
                        "fetch_kib": avg["FETCH_SIZE"], "write_kib": avg["WRITE_SIZE"],
+                       **({"valu_insts": int(avg["SQ_INSTS_VALU"])} if "SQ_INSTS_VALU" in avg else {}),
+                       **({"ta_busy_frac": avg["TA_BUSY_avr"] / (avg["GRBM_GUI_ACTIVE"] / 8)} if avg.get("GRBM_GUI_ACTIVE") and "TA_BUSY_avr" in avg else {}),
                        "kernel": key[0], "grid": key[1], "source": src,
                        "source_sha256": sha256(os.path.join(CSRC, src)) if src else None}
     doc = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes over bench.py itself (tools/pmc_bench.sh: separate "
