@@ -335,39 +335,57 @@ __global__ __launch_bounds__(1024) void drr_forward_fast_kernel(
       float wz0 = (fz + 1.0f) - pd, wz1 = pd - fz;   // (i1 - pix), (pix - i0) — ATen's generic 3D kernel
       float wy0 = (fy + 1.0f) - pw, wy1 = pw - fy;
       const float wx0 = (fx + 1.0f) - ph, wx1 = ph - fx;
-      if constexpr (HU) {
-        // HU input: a tap outside the slab / volume reads raw 0, which calc_relative_atten_coef would turn into 0.2 — its
-        // axis weight is zeroed instead (0 * mu = +0, the bits of the mu-input kernel where the tap itself is 0)
-        wz0 = ((unsigned)z0 < (unsigned)Dn) ? wz0 : 0.0f;
-        wz1 = ((unsigned)(z0 + 1) < (unsigned)Dn) ? wz1 : 0.0f;
-        wy0 = ((unsigned)y0 < (unsigned)W) ? wy0 : 0.0f;
-        wy1 = ((unsigned)(y0 + 1) < (unsigned)W) ? wy1 : 0.0f;
-      }
-      const int r0 = FLIP ? (W - 1 - y0) : y0, r1 = FLIP ? r0 - 1 : r0 + 1;
-      // (HU: the weight of a row outside the volume is 0 and the buffer resource bounds whatever address results)
-      const int yo0 = (HU || (unsigned)y0 < (unsigned)W) ? __mul24(r0, H) : OUTSIDE;
-      const int yo1 = (HU || (unsigned)(y0 + 1) < (unsigned)W) ? __mul24(r1, H) : OUTSIDE;
-      const int zo0 = __mul24(z0, sD), zo1 = zo0 + sD;
       const int xb = min(max(x0, 0), H - 2), shift = x0 - xb;
-      const unsigned xb4 = (unsigned)xb << 2;
-      const uint2 q00 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, ((unsigned)(zo0 + yo0) << 2) + xb4, 0, 0));
-      const uint2 q01 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, ((unsigned)(zo0 + yo1) << 2) + xb4, 0, 0));
-      const uint2 q10 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, ((unsigned)(zo1 + yo0) << 2) + xb4, 0, 0));
-      const uint2 q11 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, ((unsigned)(zo1 + yo1) << 2) + xb4, 0, 0));
-      float tp[8] = {__builtin_bit_cast(float, q00.x), __builtin_bit_cast(float, q00.y),
-                     __builtin_bit_cast(float, q01.x), __builtin_bit_cast(float, q01.y),
-                     __builtin_bit_cast(float, q10.x), __builtin_bit_cast(float, q10.y),
-                     __builtin_bit_cast(float, q11.x), __builtin_bit_cast(float, q11.y)};
+      float tp[8];
+      bool edge;   // some tap of this sample lies outside the slab / the volume
       if constexpr (HU) {
+        // HU input: ONE address per sample — (z0, lower row, xb) — and three scalar strides; a tap outside the slab / volume has
+        // its axis weight zeroed in the (rare, wave-uniform) edge branch below, so what its address reads does not matter: 0
+        // outside the buffer resource (raw 0 would convert to 0.2), some other finite voxel inside it.
+        const int rlo = FLIP ? (W - 2 - y0) : y0;
+        const unsigned o_lo = ((unsigned)__mul24(z0, sD) + (unsigned)__mul24(rlo, H) + (unsigned)xb) << 2;
+        const unsigned o_hi = o_lo + ((unsigned)H << 2), p_lo = o_lo + ((unsigned)sD << 2), p_hi = o_hi + ((unsigned)sD << 2);
+        const uint2 q00 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, FLIP ? o_hi : o_lo, 0, 0));
+        const uint2 q01 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, FLIP ? o_lo : o_hi, 0, 0));
+        const uint2 q10 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, FLIP ? p_hi : p_lo, 0, 0));
+        const uint2 q11 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, FLIP ? p_lo : p_hi, 0, 0));
+        tp[0] = __builtin_bit_cast(float, q00.x); tp[1] = __builtin_bit_cast(float, q00.y);
+        tp[2] = __builtin_bit_cast(float, q01.x); tp[3] = __builtin_bit_cast(float, q01.y);
+        tp[4] = __builtin_bit_cast(float, q10.x); tp[5] = __builtin_bit_cast(float, q10.y);
+        tp[6] = __builtin_bit_cast(float, q11.x); tp[7] = __builtin_bit_cast(float, q11.y);
 #pragma unroll
         for (int t8 = 0; t8 < 8; t8 += 2) mu_of_fast2(tp[t8], tp[t8 + 1]);
+        edge = (unsigned)z0 > (unsigned)(Dn - 2) || (unsigned)y0 > (unsigned)(W - 2) || shift != 0;
+      } else {
+        const int r0 = FLIP ? (W - 1 - y0) : y0, r1 = FLIP ? r0 - 1 : r0 + 1;
+        const int yo0 = ((unsigned)y0 < (unsigned)W) ? __mul24(r0, H) : OUTSIDE;
+        const int yo1 = ((unsigned)(y0 + 1) < (unsigned)W) ? __mul24(r1, H) : OUTSIDE;
+        const int zo0 = __mul24(z0, sD), zo1 = zo0 + sD;
+        const unsigned xb4 = (unsigned)xb << 2;
+        const uint2 q00 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, ((unsigned)(zo0 + yo0) << 2) + xb4, 0, 0));
+        const uint2 q01 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, ((unsigned)(zo0 + yo1) << 2) + xb4, 0, 0));
+        const uint2 q10 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, ((unsigned)(zo1 + yo0) << 2) + xb4, 0, 0));
+        const uint2 q11 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, ((unsigned)(zo1 + yo1) << 2) + xb4, 0, 0));
+        tp[0] = __builtin_bit_cast(float, q00.x); tp[1] = __builtin_bit_cast(float, q00.y);
+        tp[2] = __builtin_bit_cast(float, q01.x); tp[3] = __builtin_bit_cast(float, q01.y);
+        tp[4] = __builtin_bit_cast(float, q10.x); tp[5] = __builtin_bit_cast(float, q10.y);
+        tp[6] = __builtin_bit_cast(float, q11.x); tp[7] = __builtin_bit_cast(float, q11.y);
+        edge = shift != 0;
       }
-      // x0 in {-1, H-1, H} (a wave at an x face): the loaded pair is (xb, xb+1) = x0 shifted by `shift`; instead of moving eight
-      // taps the two x weights move (a tap outside the volume gets weight 0; x + 0 = 0 + x, so the sum keeps its bits)
+      // A wave at a face of the volume (rare): x0 in {-1, H-1, H} — the loaded pair is (xb, xb+1) = x0 shifted by `shift`; instead
+      // of moving eight taps the two x weights move (a tap outside the volume gets weight 0; x + 0 = 0 + x, so the sum keeps its
+      // bits); HU input: the z / y weights of taps outside are zeroed (0 * mu = +0, the bits of the mu-input kernel where the tap
+      // itself reads 0).
       float wxa = wx0, wxb = wx1;
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(shift != 0) != 0, 0)) {
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(edge) != 0, 0)) {
         wxa = shift == 0 ? wx0 : shift < 0 ? wx1 : 0.0f;
         wxb = shift == 0 ? wx1 : shift == 1 ? wx0 : 0.0f;
+        if constexpr (HU) {
+          wz0 = ((unsigned)z0 < (unsigned)Dn) ? wz0 : 0.0f;
+          wz1 = ((unsigned)(z0 + 1) < (unsigned)Dn) ? wz1 : 0.0f;
+          wy0 = ((unsigned)y0 < (unsigned)W) ? wy0 : 0.0f;
+          wy1 = ((unsigned)(y0 + 1) < (unsigned)W) ? wy1 : 0.0f;
+        }
       }
       float s = tp[0] * ((wxa * wy0) * wz0);
       s = s + tp[1] * ((wxb * wy0) * wz0);
