@@ -696,7 +696,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
       // ---- DENSE: fragment addressing and the MFMA chain of a tile (Chain<NC>)
       constexpr int NCH = DENSE ? NC : 3;
       using CH = Chain<NCH>;
-      struct DBase { unsigned pA, pB, pL[2][2]; };
+      struct DBase { unsigned pA, pB, pL[2][2]; int offL; };   // offL: byte offset of the leftover taps' plane (a constant per ring state)
       struct DFr { bf16x8 f[CH::NFP]; };
       auto dfrag = [&](unsigned pa, unsigned pb, int off) __attribute__((always_inline)) -> bf16x8 {
         const u32x2 a = *reinterpret_cast<const u32x2*>(lds + pa + off);
@@ -705,7 +705,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
       };
       auto dload = [&](auto nc, const DBase& b, DFr& q) __attribute__((always_inline)) {
         constexpr int n = decltype(nc)::value;
-        if constexpr (CH::is_left(n)) q.f[n] = dfrag(b.pL[CH::left_w(n)][0], b.pL[CH::left_w(n)][1], CH::left_row(n) * RB0);
+        if constexpr (CH::is_left(n)) q.f[n] = dfrag(b.pL[CH::left_w(n)][0], b.pL[CH::left_w(n)][1], CH::left_row(n) * RB0 + b.offL);
         else q.f[n] = dfrag(b.pA, b.pB, CH::iy(n) * RB0 + CH::arr(n) * SB0);
       };
       auto dmma = [&](auto kc, auto rc, const DFr& q, f32x4& acc) __attribute__((always_inline)) {
@@ -716,9 +716,36 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
       if constexpr (DENSE && PA0 > 0) {   // the first fragments of the column's first step (later steps: requested ahead of the barrier)
         const int t0 = (e6 % NRING0) * PLB0, t1 = ((e6 + 1) % NRING0) * PLB0, t2 = ((e6 + 2) % NRING0) * PLB0;
         DBase b0;
+        b0.offL = 0;
         b0.pA = (unsigned)((lq == 0 ? t0 : lq == 1 ? t1 : t2) + ry0 * RB0) + dnA;
         b0.pB = (unsigned)((lq == 0 ? t0 : lq == 2 ? t2 : t1) + ry0 * RB0) + dnB;
         static_for<DENSE_PRE>([&](auto nc) __attribute__((always_inline)) { dload(nc, b0, fa); });
+      }
+      // DENSE: the ring-0 state e6 = (2 s) mod NRING0 repeats every NRING0 / 2 steps; the step body exists once per state, so
+      // every plane offset is a constant of its copy and the per-lane fragment bases are LOOP INVARIANTS: plane slot v of tap
+      // plane tz = 0 -> the lane's first / second half address (pair tiles PVA / PVB; the single tile PSA / PSB for the states'
+      // plane spl), the leftover halves LB / LS.  (Computing them per step cost ~60 vector instructions on the producer
+      // waves, the kernel's critical path.)
+      unsigned PVA[NRING0], PVB[NRING0], PSA[NRING0 / 2], PSB[NRING0 / 2], LB[2][2], LS[2][2];
+      if constexpr (DENSE) {
+        const int dlA = lq < 3 ? lq : 2, dlB = lq < 3 ? lq : 1;
+#pragma unroll
+        for (int v = 0; v < NRING0; ++v) {
+          PVA[v] = (unsigned)(((v + dlA) % NRING0) * PLB0 + ry0 * RB0) + dnA;
+          PVB[v] = (unsigned)(((v + dlB) % NRING0) * PLB0 + ry0 * RB0) + dnB;
+        }
+#pragma unroll
+        for (int k = 0; k < NRING0 / 2; ++k) {
+          PSA[k] = (unsigned)(((2 * k + spl + dlA) % NRING0) * PLB0) + dnAs;
+          PSB[k] = (unsigned)(((2 * k + spl + dlB) % NRING0) * PLB0) + dnBs;
+        }
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            LB[w][h] = (unsigned)(ry0 * RB0) + dnL[w][h];
+            LS[w][h] = (unsigned)(spl * PLB0) + dnLs[w][h];    // (state e6 <= NRING0 - 2: slot e6 + spl never wraps)
+          }
       }
       for (int s = s0; s <= d.Do; ++s) {
         constexpr bool a_on = !(LR_C01_ABL & 2);
@@ -733,25 +760,22 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
           const int a10 = zok1 && ok_p0 ? st_p0 + so1 : dump1, a11 = zok1 && ok_p1 ? st_p1 + so1 : dump1;
           const int as_ = (spl ? zok1 : zok0) && ok_s ? st_s + (spl ? so1 : so0) : dump1;
           if constexpr (DENSE) {
-          // ---- dense K (three channels): five tiles x 17 MFMAs, one chain each; the epilogue of tile t rides beside tile t + 1.
-          // The first six fragments of the step were requested before the barrier (ring 0 is staged a step ahead).
-          const int sl0 = ((e6 + 0) % NRING0) * PLB0, sl1 = ((e6 + 1) % NRING0) * PLB0, sl2 = ((e6 + 2) % NRING0) * PLB0,
-                    sl3 = ((e6 + 3) % NRING0) * PLB0, sl4 = ((e6 + 4) % NRING0) * PLB0;
-          // planes of the lane's taps: first half tz = 0, 1, 2, 2 (lq 0..3), second half tz = 0, 1, 2, 1
-          const int plA0 = lq == 0 ? sl0 : lq == 1 ? sl1 : sl2, plA1 = lq == 0 ? sl1 : lq == 1 ? sl2 : sl3, plA2 = lq == 0 ? sl2 : lq == 1 ? sl3 : sl4;
-          const int plB0 = lq == 0 ? sl0 : lq == 2 ? sl2 : sl1, plB1 = lq == 0 ? sl1 : lq == 2 ? sl3 : sl2, plB2 = lq == 0 ? sl2 : lq == 2 ? sl4 : sl3;
+          // ---- dense K: five tiles x NMF MFMAs, one chain each; the epilogue of tile t rides beside tile t + 1.  (Ring 0 staged a
+          // step ahead: the first fragments of the step were requested before the barrier.)
+          auto dense_step = [&](auto ec) __attribute__((always_inline)) {
+          constexpr int E6 = decltype(ec)::value;
           DBase bP0, bP1, bS, bN;
-          bP0.pA = (unsigned)(plA0 + ry0 * RB0) + dnA; bP0.pB = (unsigned)(plB0 + ry0 * RB0) + dnB;
-          bP1.pA = (unsigned)(plA1 + ry0 * RB0) + dnA; bP1.pB = (unsigned)(plB1 + ry0 * RB0) + dnB;
-          bN.pA = (unsigned)(plA2 + ry0 * RB0) + dnA; bN.pB = (unsigned)(plB2 + ry0 * RB0) + dnB;   // the first pair of step s + 1
-          bS.pA = (unsigned)(spl ? plA1 : plA0) + dnAs; bS.pB = (unsigned)(spl ? plB1 : plB0) + dnBs;
+          bP0.pA = PVA[E6]; bP0.pB = PVB[E6]; bP0.offL = E6 * PLB0;
+          bP1.pA = PVA[(E6 + 1) % NRING0]; bP1.pB = PVB[(E6 + 1) % NRING0]; bP1.offL = ((E6 + 1) % NRING0) * PLB0;
+          bN.pA = PVA[(E6 + 2) % NRING0]; bN.pB = PVB[(E6 + 2) % NRING0]; bN.offL = 0;   // the first pair of step s + 1
+          bS.pA = PSA[E6 / 2]; bS.pB = PSB[E6 / 2]; bS.offL = E6 * PLB0;
 #pragma unroll
           for (int w = 0; w < 2; ++w)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-              bP0.pL[w][h] = (unsigned)(sl0 + ry0 * RB0) + dnL[w][h];     // (the leftover taps lie in plane tz = 0)
-              bP1.pL[w][h] = (unsigned)(sl1 + ry0 * RB0) + dnL[w][h];
-              bS.pL[w][h] = (unsigned)(spl ? sl1 : sl0) + dnLs[w][h];
+              bP0.pL[w][h] = LB[w][h];
+              bP1.pL[w][h] = LB[w][h];
+              bS.pL[w][h] = LS[w][h];
               bN.pL[w][h] = 0u;
             }
           DFr fb, fs;
@@ -794,6 +818,12 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
 #pragma unroll
           for (int k = 0; k < 7; ++k) epi_tile(std::integral_constant<int, 4>{}, k, acc0);
           C01_STAMP(5);
+          };
+          // one copy of the step per ring state (e6 is wave-uniform: a scalar branch)
+          if (e6 == 0) dense_step(std::integral_constant<int, 0>{});
+          else if (e6 == 2) dense_step(std::integral_constant<int, 2>{});
+          else if (e6 == 4) dense_step(std::integral_constant<int, 4>{});
+          else dense_step(std::integral_constant<int, (NRING0 - 2)>{});      // (6 of an eight-plane ring; a six-plane ring has no fourth state)
           } else {
           // ring-0 fragment bases: plane pl of the step, the lane's taps in plane (2s - 1 + pl) + tz
           const int f0 = ((e6 + dlF) % NRING0) * PLB0, f1 = ((e6 + 1 + dlF) % NRING0) * PLB0;

@@ -256,7 +256,7 @@ class SlabShardedRegistration:
     of the displacement field, phi and the warped image.  Replicated: the moving volume and the 2-D views
     (small), the FC head.  Exchanged: one activation plane per stride-2 block from the rank below (halo),
     the 32·(n/32)³ encoder features (all-gather), five NCC moments per sample (all-reduce).
-    Needs D % (32·world) == 0 so slabs stay aligned through the five stride-2 blocks.
+    Needs D % (m·world) == 0, m = the product of the strides of the blocks that run on slabs (`slab_multiple`: 8 at 256³).
     """
 
     GATHER_DEPTH = 32      # all-gather the activation behind the first block with at most this many output planes (SURVEY 8e)
@@ -264,8 +264,27 @@ class SlabShardedRegistration:
     def __init__(self, net, comm, sim_variant=NCC_CONFIGURED):
         self.net, self.comm, self.variant = net, comm, sim_variant
         D = net.img_sz[0]
-        if D % (32 * comm.world):
-            raise ValueError(f"D={D} must be a multiple of 32*world={32 * comm.world} for slab sharding")
+        need = self.slab_multiple(net) * comm.world
+        if D % need:
+            raise ValueError(f"D={D} must be a multiple of {need} (= {need // comm.world} planes per rank x world {comm.world}) for slab sharding")
+
+    @classmethod
+    def last_sharded_block(cls, net):
+        """The last encoder block that runs on slabs: the first one whose output has at most GATHER_DEPTH planes (behind it the
+        activation is all-gathered and the remaining blocks run replicated), or block 5."""
+        depth = [net.img_sz[0]]
+        for i in range(6):
+            depth.append((depth[-1] - 1) // net.strides[i] + 1)
+        return next((i for i in range(1, 6) if depth[i + 1] <= cls.GATHER_DEPTH), 5)
+
+    @classmethod
+    def slab_multiple(cls, net):
+        """Planes per rank must be a multiple of this: the product of the strides of the blocks that run on slabs (256^3: blocks
+        1..3 -> 8; 384^3: blocks 1..4 -> 16; volumes whose last block is still deeper than GATHER_DEPTH: 32)."""
+        m = 1
+        for i in range(cls.last_sharded_block(net) + 1):
+            m *= net.strides[i]
+        return m
 
     def _d_axis(self, layout):
         return 2 if layout == ops.LAYOUT_NCDHW else 1
@@ -423,10 +442,7 @@ class SlabShardedRegistration:
         # "gather once spatial <= 32^3" — behind the first block whose output has at most GATHER_DEPTH planes the
         # slabs are all-gathered (ONE collective) and the remaining blocks + the FC head run replicated on the whole (tiny)
         # activation: at 256^3 that is block 3 (32^3, 4 MB per sample), and the halo rounds of blocks 4 and 5 are gone.
-        depth = [D]
-        for i in range(6):
-            depth.append((depth[-1] - 1) // net.strides[i] + 1)
-        last_sharded = next((i for i in range(1, 6) if depth[i + 1] <= self.GATHER_DEPTH), 5)
+        last_sharded = self.last_sharded_block(net)
         for i in range(2, last_sharded + 1):
             tops = [a[:, 1 + r:2 + r].contiguous() for a, r in zip(acts_p, rows)]
             halos = comm.shift_up(tops)

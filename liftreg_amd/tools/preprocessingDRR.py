@@ -74,15 +74,26 @@ def main(argv=None):
     poses = None
     for i in parallel.shard_items(len(cases), world, rank):
         d = cases[i]
-        for kind in ("target", "source"):
-            vol = np.load(os.path.join(pre, f"{d}_{kind}.npy"))
-            if args.geo_path != "":
-                poses = genfromtxt(args.geo_path, delimiter=',')[1:] / np.asarray(args.spacing)
-            else:
-                poses = scan_poses(args.scan_range, args.scan_num, vol.shape[1])
-            res = _resolution(vol.shape, receptor)
-            proj = project_case(vol, poses, res, args.spacing, dev)
-            np.save(os.path.join(drr_folder, f"{d}_{kind}_proj.npy"), proj)
+        vols = {kind: np.load(os.path.join(pre, f"{d}_{kind}.npy")) for kind in ("target", "source")}
+        shape = vols["target"].shape
+        if args.geo_path != "":
+            poses = genfromtxt(args.geo_path, delimiter=',')[1:] / np.asarray(args.spacing)
+        else:
+            poses = scan_poses(args.scan_range, args.scan_num, shape[1])
+        if vols["source"].shape == shape:
+            # the case's two volumes share the geometry: ONE launch (lr_drr_forward_batch_f32; the bits of two separate ones)
+            both = torch.from_numpy(np.stack([np.ascontiguousarray(vols[k], dtype=np.float32) for k in ("target", "source")])).to(dev)
+            poses32 = torch.from_numpy(np.asarray(poses)).type(torch.float32).numpy()
+            projs = ops.drr_forward_batch(both, poses32, _resolution(shape, receptor), args.spacing, hu_input=True,
+                                          flip_w=True).cpu().numpy()
+            for k, kind in enumerate(("target", "source")):
+                np.save(os.path.join(drr_folder, f"{d}_{kind}_proj.npy"), projs[k])
+        else:
+            for kind in ("target", "source"):
+                if args.geo_path == "":
+                    poses = scan_poses(args.scan_range, args.scan_num, vols[kind].shape[1])
+                proj = project_case(vols[kind], poses, _resolution(vols[kind].shape, receptor), args.spacing, dev)
+                np.save(os.path.join(drr_folder, f"{d}_{kind}_proj.npy"), proj)
     if rank == 0 and cases:
         if poses is None:  # this rank owned no case (more ranks than cases): same geometry for every case
             vol = np.load(os.path.join(pre, f"{cases[0]}_target.npy"), mmap_mode="r")

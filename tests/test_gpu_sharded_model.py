@@ -9,7 +9,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,world,conv_dtype", [(64, 2, "fp32"), (128, 4, "fp32"), (128, 2, "fp32"), (128, 4, "bf16")])
+@pytest.mark.parametrize("n,world,conv_dtype", [(64, 2, "fp32"), (128, 4, "fp32"), (128, 2, "fp32"), (128, 4, "bf16"),
+                                                # the metric's largest world (BASELINE configs[2..4] at 8 ranks): C3's slabs are 32 planes
+                                                # = the gather depth, the pair kernel's front step runs on 7 of the 8 ranks
+                                                (256, 8, "fp32"), (256, 8, "bf16"), (384, 8, "bf16-c5")])
 def test_slab_sharded_forward_equals_unsharded(n, world, conv_dtype):
     from liftreg_amd import parallel as par
     from liftreg_amd.layers.losses import NCCLoss
@@ -19,15 +22,17 @@ def test_slab_sharded_forward_equals_unsharded(n, world, conv_dtype):
     torch.manual_seed(3)
     g = torch.Generator(device=dev)
     g.manual_seed(3)
-    P, L, B = 2, 12, 2
+    P, L, B, R = 2, 12, 2, n
     if conv_dtype == "bf16":
         P = 11      # C4: 11-view limited-angle DRR, bf16 convs, 4-way z-slab sharding (bf16 halo planes on the wire)
+    if conv_dtype == "bf16-c5":
+        conv_dtype, B, R = "bf16", 4, 512      # C5's shapes: 384^3, 2 x 512^2 views, 4 registrations per GPU, bf16 convs
     net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:9",
                             "conv_dtype": conv_dtype}).to(dev).eval()
     poses = scan_poses(30, P, n).astype(np.float32)
     inp = {"source": torch.rand((B, 1, n, n, n), generator=g, device=dev) * 2 - 1,
            "target": torch.rand((B, 1, n, n, n), generator=g, device=dev) * 2 - 1,
-           "target_proj": torch.rand((B, P, n, n), generator=g, device=dev) * 2 - 1,
+           "target_proj": torch.rand((B, P, R, R), generator=g, device=dev) * 2 - 1,
            "target_poses": torch.from_numpy(np.broadcast_to(poses, (B, P, 3)).copy())}
     with torch.no_grad():
         ref = net(inp)
@@ -41,6 +46,6 @@ def test_slab_sharded_forward_equals_unsharded(n, world, conv_dtype):
         assert torch.equal(out["params"], ref["params"][:, :, d0:d1])
         assert torch.equal(out["phi"], ref["phi"][:, :, d0:d1])
         assert torch.equal(out["warped"], ref["warped"][:, :, d0:d1])
-        assert abs(float(out["sim_loss"]) - float(ref_loss)) < 1e-6
+        assert abs(float(out["sim_loss"]) - float(ref_loss)) < 2e-7        # (fp64 moments summed in another order)
     with pytest.raises(ValueError):
-        par.SlabShardedRegistration(net, par.LocalComm(3))
+        par.SlabShardedRegistration(net, par.LocalComm(5 if n == 384 else 3))     # planes per rank: a multiple of slab_multiple(net)

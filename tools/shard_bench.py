@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--views", type=int, default=2)
     ap.add_argument("--conv-dtype", default="fp32")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--max-overhead", type=float, default=None, help="exit non-zero when sum_of_slabs / unsharded - 1 exceeds this")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     n, P, B = a.n, a.views, a.batch
@@ -72,6 +73,17 @@ def main():
         out = net(inp)
         return sim(out["warped"], out["target"])
 
+    # the decomposition must not change a bit: every rank's slab of the outputs equals the rows of the unsharded forward
+    with torch.no_grad():
+        ref = net(inp)
+        ref_loss = float(sim(ref["warped"], ref["target"]))
+        for r, o in enumerate(sh.forward([inp] * a.world)):
+            d0, d1 = par.slab_bounds(n, a.world, r)
+            assert torch.equal(o["pca_coefs"], ref["pca_coefs"]), f"rank {r}: coefficients differ"
+            for k in ("params", "phi", "warped"):
+                assert torch.equal(o[k], ref[k][:, :, d0:d1]), f"rank {r}: {k} differs"
+            assert abs(float(o["sim_loss"]) - ref_loss) < 2e-7, f"rank {r}: loss differs"
+        del ref
     if os.environ.get("SHARD_BENCH_TABLE"):
         print("unsharded", json.dumps(table(full)))
         print("sharded  ", json.dumps(table(lambda: sh.forward([inp] * a.world))))
@@ -79,7 +91,9 @@ def main():
     t_shard = timeit(lambda: sh.forward([inp] * a.world))
     print(json.dumps({"n": n, "views": P, "batch": B, "world": a.world, "conv_dtype": a.conv_dtype,
                       "unsharded_ms": round(t_full, 3), "sum_of_slabs_ms": round(t_shard, 3),
-                      "decomposition_overhead": round(t_shard / t_full - 1, 3)}))
+                      "decomposition_overhead": round(t_shard / t_full - 1, 3), "slabs_equal_unsharded": True}))
+    if a.max_overhead is not None and t_shard / t_full - 1 > a.max_overhead:
+        sys.exit(f"decomposition overhead {t_shard / t_full - 1:.3f} above --max-overhead {a.max_overhead}")
 
 
 if __name__ == "__main__":
