@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void backproject_tiled_kernel(
   float4* tyt = reinterpret_cast<float4*>(smem + BT_RCAP * RS);  // [TJ*TI] {row offset bits, e, w, -}
   __shared__ int s_lo, s_hi;
   const int tid = threadIdx.x;
+  const int NT = blockDim.x;   // 256, or the row length rounded up to whole waves when it is shorter (H = 160: 192 threads, not 256 with 96 idle)
   const int nI = (Ds + BT_TI - 1) / BT_TI, nJ = (W + BT_TJ - 1) / BT_TJ;
   const int jt = blockIdx.x % nJ, it = (blockIdx.x / nJ) % nI, p = blockIdx.x / nJ / nI;
   const int i_base = it * BT_TI, j_base = jt * BT_TJ;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void backproject_tiled_kernel(
   TapU txs[KC][BT_TJ];
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) {
-    const int k = tid + kc * 256;
+    const int k = tid + kc * NT;
     const float z = (float)k - 0.5f * (float)H;
 #pragma unroll
     for (int jj = 0; jj < BT_TJ; ++jj) {
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void backproject_tiled_kernel(
     for (int b = 0; b < B; ++b)
       for (int jj = 0; jj < BT_TJ && j_base + jj < W; ++jj)
         for (int ii = 0; ii < BT_TI && i_base + ii < Ds; ++ii)
-          for (int k = tid; k < H; k += 256)
+          for (int k = tid; k < H; k += NT)
             out[(int64_t)b * out_batch_stride + (((int64_t)p * Ds + i_base + ii) * W + j_base + jj) * H + k] = 0.0f;
     return;
   }
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256) void backproject_tiled_kernel(
     if (!direct) {
       if constexpr (VEC4) {
         const int RS4 = RS >> 2;
-        for (int idx = tid; idx < nrows * RS4; idx += 256) {
+        for (int idx = tid; idx < nrows * RS4; idx += NT) {
           const int row = idx / RS4, c4 = idx - row * RS4;
           const int grow = r_lo + row, col = c4 * 4 - BT_PAD;
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void backproject_tiled_kernel(
           *reinterpret_cast<float4*>(tile + row * RS + c4 * 4) = v;
         }
       } else {
-        for (int idx = tid; idx < nrows * RS; idx += 256) {
+        for (int idx = tid; idx < nrows * RS; idx += NT) {
           const int row = idx / RS, c = idx - row * RS;
           const int grow = r_lo + row, col = c - BT_PAD;
           tile[idx] = (grow >= 0 && grow < Pw && col >= 0 && col < Ph) ? pv[(int64_t)grow * Ph + col] : 0.0f;
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256) void backproject_tiled_kernel(
       if (j >= W) break;
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) {
-        const int k = tid + kc * 256;
+        const int k = tid + kc * NT;
         if (k >= H) continue;
         const TapU tx = txs[kc][jj];
         const int cb = tx.i0 + BT_PAD;
@@ -617,7 +618,7 @@ static int backproject_impl(const float* proj, const float* poses, float* out,
     if (nb > 0x7fffffffLL) return LR_EINVAL;
     const bool v4 = (Ph % 4 == 0) && ((reinterpret_cast<uintptr_t>(proj) & 15u) == 0);
     const int KC = (H + 255) / 256;
-    const dim3 grid((unsigned)nb), block(256);
+    const dim3 grid((unsigned)nb), block(H < 256 ? (unsigned)((H + 63) / 64 * 64 < 64 ? 64 : (H + 63) / 64 * 64) : 256u);
     hipStream_t st = lr_stream(stream);
 #define LR_BT(KCV)                                                                                   \
   do {                                                                                               \
