@@ -540,7 +540,8 @@ def main():
             ci, _, st_, dd = (int(g) for g in m.groups())
             if st_ == 1 and ci <= 3 and not os.environ.get("LIFTREG_CONV0_DIRECT"):
                 k["issued_share"] = 28.0 / 42.0
-            elif st_ == 2 and ((dd - 1) // 2 + 1) ** 2 >= 4096 and not os.environ.get("LIFTREG_CONV_DIRECT"):
+            elif st_ == 2 and not os.environ.get("LIFTREG_CONV_DIRECT") and \
+                    (((dd - 1) // 2 + 1) ** 2 >= 4096 or (((dd - 1) // 2 + 1) ** 2 >= 400 and B * ((dd - 1) // 2 + 1) ** 2 >= 10000)):
                 k["issued_share"] = 10.0 / 12.0
         if "issued_bf16_flops" in info:   # the fused split-operand pair kernel: fp32 results from six bf16 MFMAs per K block
             k["issued_bf16_tflops"] = info["issued_bf16_flops"] / (ms * 1e-3) / 1e12

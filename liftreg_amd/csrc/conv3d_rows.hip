@@ -389,7 +389,13 @@ int lr_internal_conv_rows_wlds(const float* in, const float* packed_w, const flo
   // hundred tiles cannot amortise the per-block fragment staging and the serial 27/54-row walk (measured at C3: 0.14 /
   // 0.07 / 0.07 ms here against 0.12 / 0.03 / 0.03 ms).  The rule looks at the PLANE only, so a z-slab of a volume takes
   // the same kernel as the whole volume (the sharded model is bit-identical to the unsharded one).
-  if ((int64_t)((W - 1) / 2 + 1) * ((H - 1) / 2 + 1) < 4096 && !lr_sw_set(LR_SW_CONV_ROWS_ALWAYS)) return LR_EUNSUPPORTED;
+  // Round 5: large batches amortise the staging on smaller planes too — the reference's shipped configuration (B = 30): 80^3 ->
+  // 40^3 0.98 -> 0.84 ms, 40^3 -> 20^3 0.169 -> 0.148 ms here; 20^3 -> 10^3 0.033 -> 0.074 (stays direct).  Batch x plane, not the
+  // depth: every z-slab of a sharded batch still takes the kernel of the whole volume.
+  {
+    const int64_t plane = (int64_t)((W - 1) / 2 + 1) * ((H - 1) / 2 + 1);
+    if (plane < 4096 && !(plane >= 400 && (int64_t)B * plane >= 10000) && !lr_sw_set(LR_SW_CONV_ROWS_ALWAYS)) return LR_EUNSUPPORTED;
+  }
   if (out_layout != LR_LAYOUT_NDHWC && out_layout != LR_LAYOUT_NDHWC_HPS && out_layout != LR_LAYOUT_NCDHW)
     return LR_EUNSUPPORTED;
   RowsDims d;

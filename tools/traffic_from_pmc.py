@@ -69,7 +69,7 @@ def op_table(cfg, P, bf16):
         return ops
     size, rank_w, rank_d = n // 2, 0, 0
     while size >= 16:
-        if (size // 2) ** 2 >= 4096:
+        if (size // 2) ** 2 >= 4096 or ((size // 2) ** 2 >= 400 and {"native160": 30}.get(cfg, 8) * (size // 2) ** 2 >= 10000):
             ops.append((f"conv3d_c32x32_s2_{size}", r"^conv3d_rows_wlds_kernel<2, 2,", rank_w))
             rank_w += 1
         else:
