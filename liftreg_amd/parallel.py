@@ -337,7 +337,7 @@ class SlabShardedRegistration:
         ngroups = 2 if (B >= 2 and comm.world > 1) else 1
         gb = [(g * B // ngroups, (g + 1) * B // ngroups) for g in range(ngroups)]
         c0, c1 = net.encoders[0].conv.out_channels, net.encoders[1].conv.out_channels
-        # fp32, <= 2 views: blocks 0 and 1 as the ONE fused kernel of the unsharded model (csrc/conv01_fused.hip) on the rank's
+        # fp32, <= 4 views: blocks 0 and 1 as the ONE fused kernel of the unsharded model (csrc/conv01_fused.hip) on the rank's
         # slab — output planes [d0/2, d1/2) read input planes d0-2 .. d1 of the replicated moving volume (a view) and of the
         # rank's OWN backprojection: no halo exchange for the two big blocks, no 16-channel activation, and the same bits as
         # the unsharded model
@@ -345,7 +345,7 @@ class SlabShardedRegistration:
         # The decision gates the block-0/1 halo collectives, so it must be the SAME on every rank: it looks at the slabs of ALL
         # ranks of the world (shapes only), never at this process's pointers.
         all_bounds = [slab_bounds(D, comm.world, r) for r in range(comm.world)]
-        pair = (not bf16 and getattr(net, "fuse_pair01", False) and P <= 3 and b1_.stride == 2 and
+        pair = (not bf16 and getattr(net, "fuse_pair01", False) and P <= getattr(net, "PAIR01_MAX_VIEWS", 2) and b1_.stride == 2 and
                 b0_.out_layout == b1_.in_layout and all(d0 % 2 == 0 and d1 % 2 == 0 for d0, d1 in all_bounds) and
                 all(ops.conv3d_pair01_shapes_supported(B, P + 1, min(d1 + 1, D) - max(d0 - 2, 0), W, H, b0_.conv.weight,
                                                        b1_.conv.weight, layouts(1)[1]) for d0, d1 in all_bounds))

@@ -12,7 +12,9 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("n,world,conv_dtype", [(64, 2, "fp32"), (128, 4, "fp32"), (128, 2, "fp32"), (128, 4, "bf16"),
                                                 # the metric's largest world (BASELINE configs[2..4] at 8 ranks): C3's slabs are 32 planes
                                                 # = the gather depth, the pair kernel's front step runs on 7 of the 8 ranks
-                                                (256, 8, "fp32"), (256, 8, "bf16"), (384, 8, "bf16-c5")])
+                                                (256, 8, "fp32"), (256, 8, "bf16"), (384, 8, "bf16-c5"),
+                                                # four views (the reference's shipped drr_feature_num): the five-channel pair kernel on slabs
+                                                (160, 2, "fp32-p4"), (128, 4, "fp32-p4")])
 def test_slab_sharded_forward_equals_unsharded(n, world, conv_dtype):
     from liftreg_amd import parallel as par
     from liftreg_amd.layers.losses import NCCLoss
@@ -25,6 +27,8 @@ def test_slab_sharded_forward_equals_unsharded(n, world, conv_dtype):
     P, L, B, R = 2, 12, 2, n
     if conv_dtype == "bf16":
         P = 11      # C4: 11-view limited-angle DRR, bf16 convs, 4-way z-slab sharding (bf16 halo planes on the wire)
+    if conv_dtype == "fp32-p4":
+        conv_dtype, P, R = "fp32", 4, int(1.5 * n)
     if conv_dtype == "bf16-c5":
         conv_dtype, B, R = "bf16", 4, 512      # C5's shapes: 384^3, 2 x 512^2 views, 4 registrations per GPU, bf16 convs
     net = model([n, n, n], {"drr_feature_num": P, "latent_dim": L, "pca_path": "synthetic:9",

@@ -5,6 +5,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from liftreg_amd import _hip  # noqa: E402
+if os.environ.get("LR_VARIANT"):      # a `make variant NAME=…` build of conv01_fused.hip (timing builds: LR_C01_SAVE_PARTS=0|1|2)
+    _hip.LIB_PATH = os.path.join(_hip.CSRC, f"libliftreg_hip_{os.environ['LR_VARIANT']}.so")
 from liftreg_amd import ops  # noqa: E402
 
 
