@@ -150,7 +150,7 @@ class model(nn.Module):
         # are one autograd node whose backward computes block 1's data gradient and block 0's weight gradient in one kernel
         # (autograd.ConvPair01Fn); False = one node per block (the gradient between them goes through memory)
         self.fuse_first_backward = bool(_opt(opt, "fuse_first_backward", True))
-        # optional (non-reference) key "fuse_pair01" (default True): in fp32 inference with P <= 2 views, encoder blocks 0 and 1
+        # optional (non-reference) key "fuse_pair01" (default True): in fp32 inference with P <= 4 views (PAIR01_MAX_VIEWS), encoder blocks 0 and 1
         # run as ONE kernel (csrc/conv01_fused.hip): both on the bf16 matrix pipe with exact three-way bf16 splits of their fp32
         # operands (six exact partial products, fp32 accumulation — closer to an fp64 convolution than the fp32 fmaf chain,
         # tests/test_gpu_conv01_fused.py); the 16-channel activation between them (8.6 GB per batch of 8 at 256^3) never reaches

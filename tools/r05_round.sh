@@ -22,3 +22,13 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/train" -
 find "$O" -name "*kernel_trace.csv" -delete
 find "$O" -name "*agent_info.csv" -delete
 find "$O" -name "*kernel_stats.csv"
+cd "$R"
+: > "$O/shard_bench.jsonl"
+for w in 1 2 4 8; do timeout 120 python3 tools/shard_bench.py --world $w 2>/dev/null | tail -n 1 >> "$O/shard_bench.jsonl"; done
+timeout 120 python3 tools/shard_bench.py --world 4 --views 11 --batch 4 --conv-dtype bf16 2>/dev/null | tail -n 1 >> "$O/shard_bench.jsonl"
+timeout 120 python3 tools/shard_bench.py --world 8 --views 11 --batch 4 --conv-dtype bf16 2>/dev/null | tail -n 1 >> "$O/shard_bench.jsonl"
+timeout 120 python3 tools/ab_drr.py > "$O/ab_drr.txt" 2>/dev/null
+timeout 200 python3 tools/ab_pair01_dense.py --reps 3 > "$O/ab_pair01_dense.txt" 2>/dev/null
+timeout 300 python3 bench.py --config native160 2>/dev/null | tail -n 1 > "$O/bench_native160.json"
+timeout 300 python3 tools/train_bench.py --config c3 2>/dev/null > "$O/train_c3_kernels.jsonl"
+cat "$O/shard_bench.jsonl"
