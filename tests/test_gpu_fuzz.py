@@ -590,3 +590,45 @@ def test_fuzz_fused_first_blocks_backward(dev):
         tag = str((D, W, H, B, cin0))
         assert float((gw0 - gw_ref).abs().max()) <= 3e-5 * max(1e-3, float(gw_ref.abs().max())), tag
         assert float((gb0 - gb_ref).abs().max()) <= 3e-5 * max(1e-3, float(gb_ref.abs().max())), tag
+
+
+def test_fuzz_pair_kernel_shapes_channels_and_slabs(dev):
+    """The fused blocks-0+1 kernel (csrc/conv01_fused.hip; layers.py:365-369 twice) on random shapes: every channel count it is built
+    for (2..5: padded K, dense K for three channels, the five-channel form), odd depths, ragged 4 x 8 columns, several units per
+    block (LIFTREG_PAIR01_BLOCKS), and a random z-slab — against an fp64 convolution (2e-6 of the scale) and, for the slab, the
+    bits of the whole-volume launch."""
+    import torch.nn.functional as F
+    from liftreg_amd import ops
+    rs = np.random.RandomState(1234 + SEED)
+    for case in range(N_CASES):
+        Cin = int(rs.randint(2, 6))
+        B = int(rs.randint(1, 4))
+        D, W = int(rs.randint(1, 19)), int(rs.randint(3, 41))
+        H = 4 * int(rs.randint(1, 14))
+        g = torch.Generator().manual_seed(int(rs.randint(1 << 30)))
+        x = torch.randn(B, Cin, D, W, H, generator=g)
+        w0 = torch.randn(16, Cin, 3, 3, 3, generator=g) * (2.0 / (27 * Cin)) ** 0.5
+        b0 = torch.randn(16, generator=g) * 0.1
+        w1 = torch.randn(32, 16, 3, 3, 3, generator=g) * (2.0 / 432) ** 0.5
+        b1 = torch.randn(32, generator=g) * 0.1
+        y = F.leaky_relu(F.conv3d(x.double(), w0.double(), b0.double(), padding=1), 0.2)
+        ref = F.leaky_relu(F.conv3d(y, w1.double(), b1.double(), stride=2, padding=1), 0.2)
+        xd, w0d, b0d, w1d, b1d = (t.to(dev) for t in (x, w0, b0, w1, b1))
+        x0, rest = xd[:, 0:1].contiguous(), xd[:, 1:].contiguous()
+        blocks = int(rs.choice([0, 1, 3]))
+        if blocks:
+            os.environ["LIFTREG_PAIR01_BLOCKS"] = str(blocks)
+        try:
+            got = ops.conv3d_pair01(x0, rest, w0d, b0d, w1d, b1d, out_layout=ops.LAYOUT_NDHWC)
+        finally:
+            os.environ.pop("LIFTREG_PAIR01_BLOCKS", None)
+        err = float((got.permute(0, 4, 1, 2, 3).double().cpu() - ref).abs().max())
+        assert err <= 2e-6 * float(ref.abs().max()), (case, Cin, B, D, W, H, blocks, err)
+        if D >= 8:        # a slab [d0, d1) with even bounds: output planes [d0/2, d1/2) from input planes d0-2 .. d1
+            d0 = 2 * int(rs.randint(0, D // 4 + 1))
+            d1 = min(D - D % 2, d0 + 2 * int(rs.randint(1, 4)))
+            if d1 > d0:
+                lo, hi = max(d0 - 2, 0), min(d1 + 1, D)
+                part = ops.conv3d_pair01(x0[:, :, lo:hi], rest[:, :, lo:hi].contiguous(), w0d, b0d, w1d, b1d, out_layout=ops.LAYOUT_NDHWC,
+                                         slab=(D, lo, d0 // 2, (d1 - d0) // 2))
+                assert torch.equal(part, got[:, d0 // 2:d1 // 2]), (case, Cin, D, d0, d1)
