@@ -478,11 +478,23 @@ class SlabShardedRegistration:
                     else:
                         x = blk(x, packed=net._packed_weight(j))
                 feats.append(x)                      # last block: NCDHW, so nn.Flatten sees the reference's element order
-        # ---- FC head (replicated), then the slab-local decode
+        # ---- FC head, then the slab-local decode.  The first layer (Linear(32 (n/32)^3, 800): 52 MB of weights at 256^3, …Backproj.py:34-36)
+        # is sharded by OUTPUT neurons — a rank reads 1/world of the weight and computes its neurons' dot products whole (the bits
+        # of the replicated layer: lr_linear_lrelu_f32 reduces every neuron on its own) — and the (B, 800/world) pieces meet in one
+        # small all-gather; layers 2 and 3 (0.9 MB) run replicated.
+        head = net.encoders[6]
+        fc1 = head[1]
+        O1 = fc1.fc.out_features
+        if comm.world > 1 and O1 % comm.world == 0 and len(head) == 4:
+            per = O1 // comm.world
+            pieces = [ops.linear_lrelu(f.contiguous().flatten(1), fc1.fc.weight[r * per:(r + 1) * per], fc1.fc.bias[r * per:(r + 1) * per],
+                                       fc1._slope) for r, f in zip(comm.ranks, feats)]
+            coefs_all = [head[3](head[2](h)) for h in comm.all_gather_cat(pieces, dim=1)]
+        else:
+            coefs_all = [head(f.contiguous()) for f in feats]
         outs = []
         moms = []
-        for inp, f, (d0, d1) in zip(inputs, feats, bounds):
-            coefs = net.encoders[6](f.contiguous())
+        for inp, coefs, (d0, d1) in zip(inputs, coefs_all, bounds):
             moving = inp["source"]
             tgt = None
             if "target" in inp:
