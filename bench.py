@@ -649,7 +649,7 @@ def main():
                         "frac": (valu / (drr_kernel_ms * 1e-3) / peak_issue) if valu else None,
                         "valu_per_wave_sample": (valu / (samples / 64)) if valu else None,
                         "hbm_frac": (ent["bytes"] / (drr_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ent else None,
-                        "hbm_bytes": ent["bytes"] if ent else None, "ta_busy_frac": ent.get("ta_busy_frac") if ent else None,
+                        "hbm_bytes": ent["bytes"] if ent else None, "ta_busy_over_gui_active": ent.get("ta_busy_over_gui_active") if ent else None,
                         "algorithmic_hbm_frac": 4.0 * B * (n ** 3 + P * R * R) / (drr_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "note": "PMC counters from profiles/traffic.json (null: no profile of this kernel source)"}
 

@@ -128,7 +128,7 @@ def main():
         traffic[op] = {"bytes": int((2 * avg["FETCH_SIZE"] + avg["WRITE_SIZE"]) * 1024),
                        "fetch_kib": avg["FETCH_SIZE"], "write_kib": avg["WRITE_SIZE"],
                        **({"valu_insts": int(avg["SQ_INSTS_VALU"])} if "SQ_INSTS_VALU" in avg else {}),
-                       **({"ta_busy_frac": avg["TA_BUSY_avr"] / (avg["GRBM_GUI_ACTIVE"] / 8)} if avg.get("GRBM_GUI_ACTIVE") and "TA_BUSY_avr" in avg else {}),
+                       **({"ta_busy_over_gui_active": avg["TA_BUSY_avr"] / avg["GRBM_GUI_ACTIVE"]} if avg.get("GRBM_GUI_ACTIVE") and "TA_BUSY_avr" in avg else {}),   # (both as rocprofv3 reports them)
                        "kernel": key[0], "grid": key[1], "source": src,
                        "source_sha256": sha256(os.path.join(CSRC, src)) if src else None}
     doc = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes over bench.py itself (tools/pmc_bench.sh: separate "
