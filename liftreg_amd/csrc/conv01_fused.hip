@@ -562,7 +562,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
         auto sv = [&](bool own, int y, int x, unsigned& so, unsigned& mo) __attribute__((always_inline)) {
           const int hp = d.save_hps ? (x & 1) * (dH >> 1) + (x >> 1) : x;
           so = own ? (unsigned)((y * dH + hp) * 64 + lq * 16) : OOR;
-          mo = (own && lq == 0) ? (unsigned)((y * dH + x) * 4) : OOR;
+          mo = own ? (unsigned)((y * dH + x) * 4 + lq) : OOR;     // every lane stores the byte of its own channel quad
         };
         sv(ok_p0 && ry0 >= 1 && col >= 1, Y1 + ry0, X1 + col, svo_p0, mko_p0);
         sv(ok_p1 && col >= 1, Y1 + ry0 + 1, X1 + col, svo_p1, mko_p1);
@@ -651,13 +651,10 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
             asm("v_med3_i32 %0, %1, 0, 1" : "=v"(r) : "v"(v));
             return r;
           };
+          // the four channel quads of a voxel sit in the four 16-lane rows: each lane stores ITS byte (a wave's 64 bytes are 16
+          // voxels x 4 consecutive bytes; round 4 gathered the nibbles into row 0 with three permlane swaps and stored dwords)
           const unsigned x = pos(E.x[0]) | (pos(E.x[1]) << 1) | (pos(E.x[2]) << 2) | (pos(E.x[3]) << 3);
-          const auto s1 = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-          const unsigned xa = s1[0], xb = s1[1];
-          const auto s2 = __builtin_amdgcn_permlane16_swap(xa, xa, false, false);
-          const auto s3 = __builtin_amdgcn_permlane16_swap(xb, xb, false, false);
-          const unsigned dw = x | (s2[1] << 8) | (xb << 16) | (s3[1] << 24);
-          __builtin_amdgcn_raw_buffer_store_b32(dw, rs_msk, (int)mo, zb * dW * dH * 4, 0);
+          __builtin_amdgcn_raw_buffer_store_b8((unsigned char)x, rs_msk, (int)mo, zb * dW * dH * 4, 0);
           const L12 t = lvl12(E.r); E.s1 = (u32x2){t.p1, 0u}; E.s2 = (u32x2){t.p2, 0u};
         }
         else if (sl == 2) { const L0 t = lvl0(E.x[0], E.x[1]); E.s0 = (u32x2){t.p, 0u}; E.r = t.r; }
