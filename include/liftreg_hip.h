@@ -43,7 +43,7 @@ const char* lr_strerror(int code);
 /* ABI version; bumped when a signature or a documented behaviour changes.  2 (round 5): the LIFTREG_* switches below are read
  * ONCE per process (version 1 read them at every call) — call lr_reload_switches() after changing the environment; the
  * register-light kernels (lr_backproject_light_f32, lr_pca_warp_light_f32) and the CU-masked stream calls (lr_stream_*) of
- * version 1 are gone; lr_drr_forward_batch_f32 is new. */
+ * version 1 are gone; lr_drr_forward_batch_f32 and lr_conv3d_dgrad_wgrad0_split_f32 are new. */
 int lr_abi_version(void);
 /* Name of the code object's target ("gfx950"). */
 const char* lr_target_arch(void);
@@ -253,6 +253,13 @@ int64_t lr_conv3d_dgrad_wgrad0_partial_floats(int Cin0);
 int lr_conv3d_dgrad_wgrad0_f32(const float* gpre1, const float* packed_w1T, const uint8_t* mask0, float slope0,
                                const float* x0, float* partial, float* gw0, float* gb0, int B, int Cin0, int D, int W,
                                int H, void* stream);
+/* The same with block 0's input in the two buffers the model holds (…Backproj.py:95-98 concatenates them): channel 0 (the
+ * moving image) at in0 + b*in0_batch_stride, channels 1..Cin0-1 (the backprojected views) at in_rest + b*rest_batch_stride +
+ * (c-1)*D*W*H (elements; strides even, pointers 8-byte aligned) — no concatenated copy of the moving image. */
+int lr_conv3d_dgrad_wgrad0_split_f32(const float* gpre1, const float* packed_w1T, const uint8_t* mask0, float slope0,
+                                     const float* in0, int64_t in0_batch_stride, const float* in_rest,
+                                     int64_t rest_batch_stride, float* partial, float* gw0, float* gb0, int B, int Cin0,
+                                     int D, int W, int H, void* stream);
 
 /* ------------------------------------------------------------------------
  * K4  Linear (+ optional LeakyReLU) for the small-batch FC head.

@@ -47,6 +47,7 @@ SIGNATURES = {
     "lr_conv3d_k3_lrelu_mask_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "lr_conv3d_dgrad_wgrad0_partial_floats": (_i64, [_i]),
     "lr_conv3d_dgrad_wgrad0_f32": (_i, [_p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "lr_conv3d_dgrad_wgrad0_split_f32": (_i, [_p, _p, _p, _f, _p, _i64, _p, _i64, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "lr_linear_lrelu_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _p]),
     "lr_pca_reconstruct_f32": (_i, [_p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _p]),
     "lr_pca_reconstruct_bf16basis_f32": (_i, [_p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _p]),

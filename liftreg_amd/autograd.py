@@ -59,32 +59,38 @@ class ConvPair01Fn(torch.autograd.Function):
     `premasked_grad`: as in ConvBlockFn, for block 1's output (block 2's data gradient applied block 1's mask already)."""
 
     @staticmethod
-    def forward(ctx, x, w0, b0, w1, b1, slope0, slope1, mid_layout, out_layout, packed0, packed1, premasked_grad, packed_pair=None):
+    def forward(ctx, x, w0, b0, w1, b1, slope0, slope1, mid_layout, out_layout, packed0, packed1, premasked_grad, packed_pair=None,
+                rest=None):
+        """`rest` (with `packed_pair`): `x` is the moving image (B,1,D,W,H) and `rest` the backprojected views (B,P,D,W,H) — the
+        encoder input cat([moving, target_volume]) (…Backproj.py:95-98) is read from the two buffers by the forward and by the
+        backward, never assembled."""
         B, _, D, W, H = x.shape
-        if packed_pair is not None and ops.conv3d_pair01_train_supported(x, w0, w1, mid_layout, out_layout):
+        if rest is not None and not (packed_pair is not None and ops.conv3d_pair01_train_supported(x, w0, w1, mid_layout, out_layout, rest)):
+            x, rest = torch.cat([x, rest], 1), None          # (shapes the fused kernel does not take: the concatenated input)
+        if packed_pair is not None and ops.conv3d_pair01_train_supported(x, w0, w1, mid_layout, out_layout, rest):
             # the forward as the fused pair kernel (exact bf16 operand splits, csrc/conv01_fused.hip) that also writes y0 and mask0
             y1, y0, mask0 = ops.conv3d_pair01_train(x, w0, b0, w1, b1, mid_layout=mid_layout, out_layout=out_layout, slope0=slope0,
-                                                    slope1=slope1, packed=packed_pair)
+                                                    slope1=slope1, packed=packed_pair, rest=rest)
         else:
             mask0 = torch.empty((B, D, W, H, w0.shape[0] // 4), dtype=torch.uint8, device=x.device)
             y0 = ops.conv3d_k3_lrelu(x, w0, b0, 1, in_layout=_hip.LAYOUT_NCDHW, out_layout=mid_layout, negative_slope=slope0,
                                      packed=packed0, mask_out=mask0)
             y1 = ops.conv3d_k3_lrelu(y0, w1, b1, 2, in_layout=mid_layout, out_layout=out_layout, negative_slope=slope1,
                                      packed=packed1)
-        ctx.save_for_backward(x, w0, w1, y0, y1, mask0)
-        ctx.cfg = (slope0, slope1, mid_layout, out_layout, b0 is not None, b1 is not None, premasked_grad)
+        ctx.save_for_backward(x, w0, w1, y0, y1, mask0, rest if rest is not None else x.new_empty(0))
+        ctx.cfg = (slope0, slope1, mid_layout, out_layout, b0 is not None, b1 is not None, premasked_grad, rest is not None)
         return y1
 
     @staticmethod
     def backward(ctx, gy1):
-        x, w0, w1, y0, y1, mask0 = ctx.saved_tensors
-        slope0, slope1, mid_layout, out_layout, has_b0, has_b1, premasked = ctx.cfg
+        x, w0, w1, y0, y1, mask0, rest = ctx.saved_tensors
+        slope0, slope1, mid_layout, out_layout, has_b0, has_b1, premasked, split = ctx.cfg
         gy1 = gy1.contiguous()
         gpre1 = gy1 if premasked else ops_bwd.lrelu_bwd(gy1, out_layout, y1, out_layout, slope1)
         _, gw1, gb1 = ops_bwd.conv3d_bwd(y0, mid_layout, w1, y1, out_layout, gpre1, _hip.LAYOUT_NDHWC, 2, slope1,
                                          need_gx=False, gy_is_gpre=True)
-        gw0, gb0 = ops_bwd.conv3d_dgrad_wgrad0(gpre1, w1, mask0, slope0, x)
-        return (None, gw0, gb0 if has_b0 else None, gw1, gb1 if has_b1 else None, None, None, None, None, None, None, None, None)
+        gw0, gb0 = ops_bwd.conv3d_dgrad_wgrad0(gpre1, w1, mask0, slope0, x, rest if split else None)
+        return (None, gw0, gb0 if has_b0 else None, gw1, gb1 if has_b1 else None, None, None, None, None, None, None, None, None, None)
 
 
 class EncoderBf16Fn(torch.autograd.Function):

@@ -41,11 +41,14 @@ constexpr int XZ = 18, XY = 6, XX = 36; // x0 window of a tile: planes, rows, fl
 
 template <int CIN0>
 __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __restrict__ gpre, const float4* __restrict__ wp,
-                                                              const unsigned* __restrict__ mask0, const float* __restrict__ x0,
+                                                              const unsigned* __restrict__ mask0, const float* __restrict__ in0,
+                                                              long long bs0, const float* __restrict__ in_rest, long long bsr,
                                                               float* __restrict__ partial, FzDims d, int ntiles) {
   constexpr int NVOX = 9 * (WMT + 1) * 17, NCH = NVOX * C4, NIT = (NCH + 511) / 512;
   constexpr int NWF = 27 * CB * 64;                  // float4 weight fragments (the first 27 taps of the packed buffer)
-  constexpr int NXP = CIN0 * XZ * XY * (XX / 2), NXI = (NXP + 511) / 512;  // 8-byte pairs of the x0 window
+  // 8-byte pairs of the x0 window, enumerated channel by channel (NPI thread-iterations each): the channel of an iteration is a
+  // compile-time constant, so channel 0 (the moving image) and channels 1.. (the backprojected views) may live in two buffers
+  constexpr int NPC = XZ * XY * (XX / 2), NPI = (NPC + 511) / 512, NXI = CIN0 * NPI;
   // columns (ci, tap) + the ones column (bias).  Cin0 = 3: 81 taps = 5 column tiles + ONE tap; that tap and the bias sum
   // are accumulated on the vector ALU (one broadcast LDS read + 2 flops per voxel and lane) instead of a sixth, 88 % empty
   // MFMA tile (VT); the partial buffer keeps the 6-tile layout.
@@ -85,9 +88,9 @@ __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __res
   }
 #pragma unroll
   for (int it = 0; it < NXI; ++it) {
-    const int q = it * 512 + tid;
-    const int xx2 = q % (XX / 2), row = q / (XX / 2), yy = row % XY, r2 = row / XY, zz = r2 % XZ, ci = r2 / XZ;
-    pkx[it] = q < NXP ? (unsigned)(xx2 | yy << 8 | zz << 16 | (xx2 == 0) << 24 | (yy == 0) << 25 | (zz == 0) << 26 | ci << 28)
+    const int q = (it % NPI) * 512 + tid;
+    const int xx2 = q % (XX / 2), row = q / (XX / 2), yy = row % XY, zz = row / XY;
+    pkx[it] = q < NPC ? (unsigned)(xx2 | yy << 8 | zz << 16 | (xx2 == 0) << 24 | (yy == 0) << 25 | (zz == 0) << 26)
                       : 0x08000000u;
   }
   auto prefetch = [&](int t) {
@@ -112,9 +115,10 @@ __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __res
     {
       // the first block's input around the tile (origin (2zq0-1, 2yq0-1, 2xq0-2)): one resource per batch element, zero
       // outside the volume (= the conv's padding); H is even, so an 8-byte pair never straddles the volume's edge
-      const float* xb = x0 + (int64_t)b * CIN0 * d.D * d.W * d.H;
-      const __amdgpu_buffer_rsrc_t rsx =
-          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), (short)0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs0 =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in0 + (int64_t)b * bs0), (short)0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsr =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_rest + (int64_t)b * bsr), (short)0, 0x7fffffff, 0x00020000);
       const int gz0 = 2 * zq0 - 1, gy0 = 2 * yq0 - 1, gx0 = 2 * xq0 - 2;
       const unsigned bias = bias7((d.H - gx0 + 1) >> 1) | bias7(d.W - gy0) << 8 | bias7(d.D - gz0) << 16;
       const unsigned lowm = 0x08808080u | (unsigned)(xq0 == 0) << 24 | (unsigned)(yq0 == 0) << 25 | (unsigned)(zq0 == 0) << 26;
@@ -122,10 +126,11 @@ __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __res
 #pragma unroll
       for (int it = 0; it < NXI; ++it) {
         const unsigned pk = pkx[it];
-        const unsigned xx2 = pk & 127u, yy = (pk >> 8) & 127u, zz = (pk >> 16) & 127u, ci = pk >> 28;
+        const unsigned xx2 = pk & 127u, yy = (pk >> 8) & 127u, zz = (pk >> 16) & 127u;
+        const unsigned ci = (unsigned)(it / NPI), cr = ci == 0 ? 0u : ci - 1u;      // channel | its index inside in_rest
         const bool ok = (((pk & 0x0fffffffu) + bias) & lowm) == 0u;
-        const unsigned voff = ok ? ((((ci * (unsigned)d.D + zz) * (unsigned)d.W + yy) * (unsigned)d.H + 2 * xx2) * 4 + org) : OOR;
-        xst[it] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsx, voff, 0, 0));
+        const unsigned voff = ok ? ((((cr * (unsigned)d.D + zz) * (unsigned)d.W + yy) * (unsigned)d.H + 2 * xx2) * 4 + org) : OOR;
+        xst[it] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(it / NPI == 0 ? rs0 : rsr, voff, 0, 0));
       }
     }
   };
@@ -173,8 +178,8 @@ __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __res
     }
 #pragma unroll
     for (int it = 0; it < NXI; ++it) {
-      const int q = it * 512 + tid;
-      if (q < NXP) *reinterpret_cast<float2*>(xs + q * 2) = xst[it];  // rows are XX floats: the pair index IS the layout
+      const int q = (it % NPI) * 512 + tid;
+      if (q < NPC) *reinterpret_cast<float2*>(xs + ((it / NPI) * NPC + q) * 2) = xst[it];  // rows are XX floats: the pair index IS the layout
     }
     __syncthreads();
     int b, zq0, yq0, xq0;
@@ -351,14 +356,15 @@ __global__ __launch_bounds__(1024) void wgrad0_finish_kernel(const float* __rest
 }
 
 template <int CIN0>
-int launch(const float* gpre1, const float* packed_w1T, const unsigned char* mask0, const float* x0, float* partial, float* gw0,
-           float* gb0, const FzDims& d, int ntiles, int blocks, hipStream_t st) {
+int launch(const float* gpre1, const float* packed_w1T, const unsigned char* mask0, const float* in0, long long bs0,
+           const float* in_rest, long long bsr, float* partial, float* gw0, float* gb0, const FzDims& d, int ntiles, int blocks,
+           hipStream_t st) {
   constexpr int NTP = (27 * CIN0 + 1 + 15) / 16;
   const size_t ldsb = ((size_t)27 * CB * 64 * 4 + (size_t)9 * (WMT + 1) * 17 * 32 + (size_t)CIN0 * XZ * XY * XX) * sizeof(float);
   static std::atomic<uint64_t> attr_done{0};  // per instantiation, one bit per device
   if (lr_raise_dyn_lds(reinterpret_cast<const void*>(&dgrad_wgrad0_kernel<CIN0>), ldsb, attr_done) != LR_OK) return LR_ELAUNCH;
   hipLaunchKernelGGL((dgrad_wgrad0_kernel<CIN0>), dim3((unsigned)blocks), dim3(512), ldsb, st, gpre1,
-                     reinterpret_cast<const float4*>(packed_w1T), reinterpret_cast<const unsigned*>(mask0), x0, partial, d, ntiles);
+                     reinterpret_cast<const float4*>(packed_w1T), reinterpret_cast<const unsigned*>(mask0), in0, bs0, in_rest, bsr, partial, d, ntiles);
   const int ncols = NTP * 16;
   hipLaunchKernelGGL(wgrad0_finish_kernel, dim3((16 * ncols + 63) / 64), dim3(1024), 0, st, partial, gw0, gb0, blocks * 8, CIN0, ncols);
   return lr_launch_status();
@@ -377,13 +383,20 @@ extern "C" int64_t lr_conv3d_dgrad_wgrad0_partial_floats(int Cin0) {
 //   to (16,32,3,3,3), layout NDHWC (what lr_conv3d_dgrad_f32 takes); mask0 (B,D,W,H,4) uint8 = block 0's LR_LAYOUT_SIGN4
 //   sign mask, 4-byte aligned; x0 (B,Cin0,D,W,H) fp32 NCDHW = block 0's input, Cin0 in {2,3}; H % 4 == 0.
 // Same results as lr_conv3d_dgrad_f32 (x_layout SIGN4) followed by lr_conv3d_wgrad_f32 up to fp32 summation order.
-extern "C" int lr_conv3d_dgrad_wgrad0_f32(const float* gpre1, const float* packed_w1T, const uint8_t* mask0, float slope0,
-                                          const float* x0, float* partial, float* gw0, float* gb0, int B, int Cin0, int D,
-                                          int W, int H, void* stream) {
-  if (!gpre1 || !packed_w1T || !mask0 || !x0 || !partial || !gw0) return LR_ENULL;
+// ... with block 0's input in TWO buffers, as the model holds it: channel 0 (the moving image) at in0 + b*in0_batch_stride,
+// channels 1..Cin0-1 (the backprojected views) at in_rest + b*rest_batch_stride + (c-1)*D*W*H (elements) — no concatenated copy
+// of the moving image (0.17 ms per C3 step).  The concatenated form below is this one with in_rest = x0 + D*W*H.
+extern "C" int lr_conv3d_dgrad_wgrad0_split_f32(const float* gpre1, const float* packed_w1T, const uint8_t* mask0, float slope0,
+                                                const float* in0, int64_t in0_batch_stride, const float* in_rest,
+                                                int64_t rest_batch_stride, float* partial, float* gw0, float* gb0, int B, int Cin0,
+                                                int D, int W, int H, void* stream) {
+  if (!gpre1 || !packed_w1T || !mask0 || !in0 || !in_rest || !partial || !gw0) return LR_ENULL;
   if (B < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
   if ((Cin0 != 2 && Cin0 != 3) || (H & 3)) return LR_EUNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(gpre1) & 15u) || (reinterpret_cast<uintptr_t>(mask0) & 3u) || (reinterpret_cast<uintptr_t>(x0) & 7u))
+  const int64_t V = (int64_t)D * W * H;
+  if (in0_batch_stride < V || rest_batch_stride < (int64_t)(Cin0 - 1) * V) return LR_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(gpre1) & 15u) || (reinterpret_cast<uintptr_t>(mask0) & 3u) || (reinterpret_cast<uintptr_t>(in0) & 7u) ||
+      (reinterpret_cast<uintptr_t>(in_rest) & 7u) || (in0_batch_stride & 1) || (rest_batch_stride & 1))
     return LR_EALIGN;
   FzDims d;
   d.B = B; d.D = D; d.W = W; d.H = H;
@@ -391,13 +404,22 @@ extern "C" int lr_conv3d_dgrad_wgrad0_f32(const float* gpre1, const float* packe
   d.nHq = ((H + 1) / 2 + 15) / 16; d.nWq = (d.Wo + WMT - 1) / WMT; d.nDq = (d.Do + 7) / 8;
   d.slope = slope0;
   if ((int64_t)10 * d.Wo * d.Ho * CG * 4 >= 0x7fffffffLL) return LR_EINVAL;       // 32-bit offsets of a gpre1 window
-  if ((int64_t)Cin0 * D * W * H * 4 >= 0x7fffffffLL) return LR_EUNSUPPORTED;       // ... and of one batch element of x0
+  if ((int64_t)Cin0 * V * 4 >= 0x7fffffffLL) return LR_EUNSUPPORTED;               // ... and of one batch element of the input
   const int64_t nt = (int64_t)B * d.nDq * d.nWq * d.nHq;
   if (nt > 0x7fffffffLL) return LR_EINVAL;
   int blocks = 256;  // one 8-wave block per CU; the partial buffer is sized for 256
   if (lr_sw_set(LR_SW_FUSED_BWD_BLOCKS)) { blocks = lr_sw_int(LR_SW_FUSED_BWD_BLOCKS, 256); if (blocks < 1 || blocks > 256) blocks = 256; }  // tuning aid
   if (nt < blocks) blocks = (int)nt;
   hipStream_t st = lr_stream(stream);
-  if (Cin0 == 3) return launch<3>(gpre1, packed_w1T, mask0, x0, partial, gw0, gb0, d, (int)nt, blocks, st);
-  return launch<2>(gpre1, packed_w1T, mask0, x0, partial, gw0, gb0, d, (int)nt, blocks, st);
+  if (Cin0 == 3) return launch<3>(gpre1, packed_w1T, mask0, in0, in0_batch_stride, in_rest, rest_batch_stride, partial, gw0, gb0, d, (int)nt, blocks, st);
+  return launch<2>(gpre1, packed_w1T, mask0, in0, in0_batch_stride, in_rest, rest_batch_stride, partial, gw0, gb0, d, (int)nt, blocks, st);
+}
+
+extern "C" int lr_conv3d_dgrad_wgrad0_f32(const float* gpre1, const float* packed_w1T, const uint8_t* mask0, float slope0,
+                                          const float* x0, float* partial, float* gw0, float* gb0, int B, int Cin0, int D,
+                                          int W, int H, void* stream) {
+  if (!x0) return LR_ENULL;
+  const int64_t V = (int64_t)D * W * H;
+  return lr_conv3d_dgrad_wgrad0_split_f32(gpre1, packed_w1T, mask0, slope0, x0, (int64_t)Cin0 * V, x0 + V, (int64_t)Cin0 * V, partial,
+                                          gw0, gb0, B, Cin0, D, W, H, stream);
 }

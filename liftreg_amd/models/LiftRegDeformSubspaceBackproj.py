@@ -156,6 +156,9 @@ class model(nn.Module):
         # tests/test_gpu_conv01_fused.py); the 16-channel activation between them (8.6 GB per batch of 8 at 256^3) never reaches
         # HBM.  False = one fp32-MFMA kernel per block (the round-3 path).
         self.fuse_pair01 = bool(_opt(opt, "fuse_pair01", True))
+        # optional key "split_encoder_input" (default True): fp32 training reads `moving` and the backprojected views from their own
+        # buffers in the fused forward and backward of blocks 0 + 1; False = the concatenated input of rounds 1-4 (A/B aid)
+        self.split_encoder_input = bool(_opt(opt, "split_encoder_input", True))
         # optional key "fuse_pair01_train" (default True): the TRAINING forward of blocks 0 + 1 through the same fused kernel, which
         # then also writes block 0's activation and sign mask for the backward (ops.conv3d_pair01_train); False = the two
         # fp32-MFMA kernels of rounds 2-3
@@ -412,6 +415,24 @@ class model(nn.Module):
                 x = ops.conv3d_k3_lrelu_bf16(x, blk.conv.weight, blk.conv.bias, blk.stride, in_layout=lin, out_layout=lout,
                                              negative_slope=blk._slope, packed=self._packed_weight(i, bf16=True))
             return self.encoders[6](x)
+        b0, b1 = self.encoders[0], self.encoders[1]
+        if (self.conv_dtype != "bf16" and needs_grad and self.fuse_first_backward and self.fuse_pair01 and self.fuse_pair01_train and
+                self.split_encoder_input and P <= 2 and b0.conv.weight.requires_grad and b1.conv.weight.requires_grad and b0.premasked_grad and b1.stride == 2 and
+                b0.out_layout == b1.in_layout and tuple(b1.conv.weight.shape[:2]) == (32, 16)):
+            # training, fp32: blocks 0 + 1 as one autograd node (fused pair forward; fused dgrad1 + wgrad0 backward) reading `moving`
+            # and the backprojected views from their OWN buffers — cat([moving, target_volume]) (:95-98) is never assembled (the
+            # copy of `moving` into a concatenated input cost 0.17 ms per C3 step)
+            mv = moving if moving.is_contiguous() else moving.contiguous()
+            tv = torch.empty((B, P, D, W, H), dtype=torch.float32, device=moving.device)
+            if ops.conv3d_pair01_train_supported(mv, b0.conv.weight, b1.conv.weight, b0.out_layout, b1.out_layout, tv):
+                ops.backproject(target_proj, self._poses, (D, W, H), out=tv, out_batch_stride=P * V)
+                x = ConvPair01Fn.apply(mv, b0.conv.weight, b0.conv.bias, b1.conv.weight, b1.conv.bias, b0._slope, b1._slope,
+                                       b0.out_layout, b1.out_layout, self._packed_weight(0), self._packed_weight(1), b1.premasked_grad,
+                                       self._packed_pair01(), tv)
+                for i in range(2, 6):
+                    x = self.encoders[i](x, packed=self._packed_weight(i))
+                return self.encoders[6](x)
+            del tv
         # encoder input = cat([moving, target_volume], dim=1) (:95-98), built in place
         x = torch.empty((B, P + 1, D, W, H), dtype=torch.float32, device=moving.device)
         x[:, 0:1].copy_(moving)

@@ -484,12 +484,22 @@ def conv3d_pair01(x0, rest, w0, b0, w1, b1, *, out_layout=LAYOUT_NDHWC_HPS, slop
     return y
 
 
-def conv3d_pair01_train_supported(x, w0, w1, mid_layout, out_layout):
-    """True when `conv3d_pair01_train` can take the (B,Cin,D,W,H) NCDHW input of the encoder (training forward)."""
-    if not (x.dim() == 5 and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] in (1, 2, 3, 4) and
-            x.shape[4] % 4 == 0 and x.data_ptr() % 16 == 0):
-        return False
-    B, Cin, D, W, H = x.shape
+def conv3d_pair01_train_supported(x, w0, w1, mid_layout, out_layout, rest=None):
+    """True when `conv3d_pair01_train` can take the encoder's input (training forward): `x` the (B,Cin,D,W,H) NCDHW input, or —
+    with `rest` (B,P,D,W,H) — `x` = the (B,1,D,W,H) moving image alone (dense per sample, any even batch stride)."""
+    if rest is None:
+        if not (x.dim() == 5 and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] in (1, 2, 3, 4) and
+                x.shape[4] % 4 == 0 and x.data_ptr() % 16 == 0):
+            return False
+        Cin = x.shape[1]
+    else:
+        if not (x.dim() == 5 and rest.dim() == 5 and x.is_cuda and rest.is_cuda and x.dtype == torch.float32 and rest.dtype == torch.float32 and
+                x.shape[1] == 1 and rest.shape[1] in (1, 2, 3) and x.shape[0] == rest.shape[0] and x.shape[2:] == rest.shape[2:] and
+                x[0].is_contiguous() and rest.is_contiguous() and x.shape[4] % 4 == 0 and x.data_ptr() % 16 == 0 and
+                rest.data_ptr() % 16 == 0 and (x.shape[0] == 1 or x.stride(0) % 4 == 0)):
+            return False
+        Cin = 1 + rest.shape[1]
+    B, _, D, W, H = x.shape
     if tuple(w0.shape) != (16, Cin, 3, 3, 3) or tuple(w1.shape) != (32, 16, 3, 3, 3):
         return False
     if mid_layout not in (LAYOUT_NDHWC, LAYOUT_NDHWC_HPS) or out_layout not in (LAYOUT_NDHWC, LAYOUT_NDHWC_HPS):
@@ -501,13 +511,16 @@ def conv3d_pair01_train_supported(x, w0, w1, mid_layout, out_layout):
 
 
 def conv3d_pair01_train(x, w0, b0, w1, b1, *, mid_layout=LAYOUT_NDHWC_HPS, out_layout=LAYOUT_NDHWC_HPS, slope0=0.2, slope1=0.2,
-                        packed=None):
+                        packed=None, rest=None):
     """Training forward of encoder blocks 0 and 1 as the fused pair kernel (conv3d_pair01) that also writes what the backward
-    reads: returns (y1 (B,Do,Wo,Ho,32), y0 (B,D,W,H,16) in mid_layout, mask0 (B,D,W,H,4) uint8)."""
-    x = _dev(x, "x")
-    if not conv3d_pair01_train_supported(x, w0, w1, mid_layout, out_layout):
+    reads: returns (y1 (B,Do,Wo,Ho,32), y0 (B,D,W,H,16) in mid_layout, mask0 (B,D,W,H,4) uint8).  `rest`: `x` is the moving image
+    alone and `rest` the backprojected views — the input is read from the two buffers, never concatenated."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32):
+        raise _hip.LiftRegHipError("x: must be a float32 GPU tensor (no CPU fallback)")
+    if not conv3d_pair01_train_supported(x, w0, w1, mid_layout, out_layout, rest):
         raise ValueError("conv3d_pair01_train: unsupported shapes (run the two blocks separately)")
-    B, Cin, D, W, H = x.shape
+    B, _, D, W, H = x.shape
+    Cin = x.shape[1] if rest is None else 1 + rest.shape[1]
     if packed is None:
         packed = conv3d_pair01_pack(w0, w1)
     b0 = None if b0 is None else _dev(b0.detach(), "b0")
@@ -519,9 +532,13 @@ def conv3d_pair01_train(x, w0, b0, w1, b1, *, mid_layout=LAYOUT_NDHWC_HPS, out_l
     V = D * W * H
     flops = 2.0 * 27 * B * (Cin * 16 * 2 * Do * W * H + 16 * 32 * Do * Wo * Ho)
     issued = 16384.0 * _pair01_mfmas_per_step(Cin) * Do * B * (-(-Wo // 4)) * (-(-Ho // 8))
+    if rest is None:
+        p0, s0, pr, sr = x.data_ptr(), Cin * V, x.data_ptr() + 4 * V, Cin * V
+    else:
+        p0, s0, pr, sr = x.data_ptr(), (int(x.stride(0)) if B > 1 else V), rest.data_ptr(), (Cin - 1) * V
     with _timed(f"conv3d_pair01_train_c{Cin}x16x32_{D}", flops=flops, issued_bf16_flops=issued,
-                bytes=4 * x.numel() + 4 * y1.numel() + 4 * y0.numel() + mask0.numel(), samples=B):
-        _hip.check(_hip.lib().lr_conv3d_pair01_train_f32(x.data_ptr(), Cin * V, x.data_ptr() + 4 * V, Cin * V, packed.data_ptr(),
+                bytes=4 * Cin * B * V + 4 * y1.numel() + 4 * y0.numel() + mask0.numel(), samples=B):
+        _hip.check(_hip.lib().lr_conv3d_pair01_train_f32(p0, s0, pr, sr, packed.data_ptr(),
                                                          _ptr(b0), _ptr(b1), y1.data_ptr(), y0.data_ptr(), mask0.data_ptr(), B, Cin,
                                                          D, W, H, mid_layout, out_layout, float(slope0), float(slope1), _stream()),
                    "lr_conv3d_pair01_train_f32")

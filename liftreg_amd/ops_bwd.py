@@ -257,39 +257,59 @@ def lrelu_bwd(gy, gy_layout, y, y_layout, negative_slope=0.2):
     return gpre
 
 
-def conv3d_dgrad_wgrad0_supported(x0, mask0, w1):
-    """True when `conv3d_dgrad_wgrad0` covers these tensors (the encoder's blocks 0/1 in fp32 training)."""
-    return (x0.dim() == 5 and x0.shape[1] in (2, 3) and x0.shape[4] % 4 == 0 and x0.is_contiguous() and x0.dtype == torch.float32 and
+def conv3d_dgrad_wgrad0_supported(x0, mask0, w1, rest=None):
+    """True when `conv3d_dgrad_wgrad0` covers these tensors (the encoder's blocks 0/1 in fp32 training).  `rest`: block 0's input
+    comes in two buffers — x0 (B,1,D,W,H) the moving image (dense per sample; a batch stride is fine), rest (B,P,D,W,H) the views."""
+    if rest is not None:
+        if not (x0.dim() == 5 and rest.dim() == 5 and x0.shape[1] == 1 and rest.shape[1] in (1, 2) and x0.shape[0] == rest.shape[0] and
+                x0.shape[2:] == rest.shape[2:] and x0[0].is_contiguous() and rest.is_contiguous() and rest.dtype == torch.float32 and
+                (x0.shape[0] == 1 or x0.stride(0) % 2 == 0)):
+            return False
+        cin, per = 1 + rest.shape[1], x0[0].numel()
+    else:
+        if not (x0.dim() == 5 and x0.shape[1] in (2, 3) and x0.is_contiguous()):
+            return False
+        cin, per = x0.shape[1], x0[0, :1].numel()
+    return (x0.shape[4] % 4 == 0 and x0.dtype == torch.float32 and
             mask0 is not None and mask0.dtype == torch.uint8 and mask0.is_contiguous() and mask0.shape[-1] == 4 and
-            tuple(w1.shape[:2]) == (32, 16) and x0.numel() // x0.shape[0] * 4 < 2 ** 31 - 1)
+            tuple(w1.shape[:2]) == (32, 16) and cin * per * 4 < 2 ** 31 - 1)
 
 
-def conv3d_dgrad_wgrad0(gpre1, w1, mask0, slope0, x0):
+def conv3d_dgrad_wgrad0(gpre1, w1, mask0, slope0, x0, rest=None):
     """(gw0 (16,Cin0,3,3,3), gb0 (16)) of the encoder's FIRST block from the pre-activation gradient `gpre1` (B,Do,Wo,Ho,32)
     of the SECOND one, w1 (32,16,3,3,3) its weight, mask0 the first block's (B,D,W,H,4) uint8 LeakyReLU sign mask
-    (ops.conv3d_k3_lrelu(mask_out=…)), x0 (B,Cin0,D,W,H) the first block's input.  One kernel (lr_conv3d_dgrad_wgrad0_f32):
-    block 1's data gradient, block 0's LeakyReLU mask and block 0's weight gradient — the (B,D,W,H,16) gradient between the
-    two never reaches memory.  Same results as conv3d_bwd(block 1, need_gx) + conv3d_bwd(block 0) up to summation order."""
-    gpre1, x0 = _dev(gpre1, "gpre1"), _dev(x0, "x0")
+    (ops.conv3d_k3_lrelu(mask_out=…)), x0 (B,Cin0,D,W,H) the first block's input — or, with `rest`, x0 (B,1,D,W,H) + rest
+    (B,Cin0-1,D,W,H) as the model holds them (no concatenated copy).  One kernel (lr_conv3d_dgrad_wgrad0[_split]_f32): block 1's
+    data gradient, block 0's LeakyReLU mask and block 0's weight gradient — the (B,D,W,H,16) gradient between the two never
+    reaches memory.  Same results as conv3d_bwd(block 1, need_gx) + conv3d_bwd(block 0) up to summation order."""
+    gpre1 = _dev(gpre1, "gpre1")
+    if not (isinstance(x0, torch.Tensor) and x0.is_cuda and x0.dtype == torch.float32):
+        raise _hip.LiftRegHipError("x0: must be a float32 GPU tensor (no CPU fallback)")
     w = _dev(w1.detach(), "w1")
-    B, Cin0, D, W, H = x0.shape
+    B, _, D, W, H = x0.shape
+    Cin0 = x0.shape[1] if rest is None else 1 + rest.shape[1]
     o = lambda n: (n - 1) // 2 + 1
-    if tuple(gpre1.shape) != (B, o(D), o(W), o(H), 32) or not conv3d_dgrad_wgrad0_supported(x0, mask0, w):
+    if tuple(gpre1.shape) != (B, o(D), o(W), o(H), 32) or not conv3d_dgrad_wgrad0_supported(x0, mask0, w, rest):
         raise ValueError("conv3d_dgrad_wgrad0: unsupported shapes")
     if tuple(mask0.shape) != (B, D, W, H, 4) or not mask0.is_cuda:
         raise ValueError(f"mask0 must be a uint8 GPU tensor of shape {(B, D, W, H, 4)}")
     from .ops import conv3d_pack_weights
     lib, dev = _hip.lib(), x0.device
+    V = D * W * H
     packed_t = conv3d_pack_weights(w.transpose(0, 1).contiguous(), _hip.LAYOUT_NDHWC)
     partial = torch.empty((lib.lr_conv3d_dgrad_wgrad0_partial_floats(Cin0),), dtype=torch.float32, device=dev)
     gw0 = torch.empty((16, Cin0, 3, 3, 3), dtype=torch.float32, device=dev)
     gb0 = torch.empty((16,), dtype=torch.float32, device=dev)
     nvo = B * o(D) * o(W) * o(H)
+    if rest is None:
+        p0, s0, pr, sr = x0.data_ptr(), Cin0 * V, x0.data_ptr() + 4 * V, Cin0 * V
+    else:
+        p0, s0, pr, sr = x0.data_ptr(), (int(x0.stride(0)) if B > 1 else V), rest.data_ptr(), (Cin0 - 1) * V
     with _timed(f"conv3d_dgrad_wgrad0_c32x16x{Cin0}_{D}", flops=2.0 * 27 * 16 * 32 * nvo + 2.0 * 27 * Cin0 * 16 * B * D * W * H,
-                bytes=4 * gpre1.numel() + mask0.numel() + 4 * x0.numel()):
-        _hip.check(lib.lr_conv3d_dgrad_wgrad0_f32(gpre1.data_ptr(), packed_t.data_ptr(), mask0.data_ptr(), float(slope0),
-                                                  x0.data_ptr(), partial.data_ptr(), gw0.data_ptr(), gb0.data_ptr(), B, Cin0, D,
-                                                  W, H, _stream()), "lr_conv3d_dgrad_wgrad0_f32")
+                bytes=4 * gpre1.numel() + mask0.numel() + 4 * Cin0 * B * V):
+        _hip.check(lib.lr_conv3d_dgrad_wgrad0_split_f32(gpre1.data_ptr(), packed_t.data_ptr(), mask0.data_ptr(), float(slope0),
+                                                        p0, s0, pr, sr, partial.data_ptr(), gw0.data_ptr(), gb0.data_ptr(), B, Cin0,
+                                                        D, W, H, _stream()), "lr_conv3d_dgrad_wgrad0_split_f32")
     return gw0, gb0
 
 
