@@ -1,4 +1,4 @@
-// conv01_fused.hip — the first TWO encoder blocks (Cin <= 4 planar fp32 channels -> 16 channels at stride 1 -> 32 channels at
+// conv01_fused.hip — the first TWO encoder blocks (Cin <= 5 planar fp32 channels -> 16 channels at stride 1 -> 32 channels at
 // stride 2, each Conv3d 3x3x3 + bias + LeakyReLU) as ONE z-marching kernel on the bf16 matrix pipe with EXACT three-way bf16
 // splits of every fp32 operand (conv0_split_f32.hip describes the split: x = x0 + x1 + x2, six of the nine partial products,
 // each exact in fp32, fp32 accumulation).  The 16-channel fp32 activation between the two blocks (8.6 GB written + 8.6 GB read
@@ -6,29 +6,29 @@
 //
 // Work decomposition: PRODUCER and CONSUMER waves.  A 512-thread block (one per CU: two waves per SIMD) owns a column of
 // 4 x 8 block-1 outputs and marches DOWN the output planes.  Waves 0..3 ("A") compute block 0, waves 4..7 ("B") block 1, one
-// plane of block-1 output apart, with ONE barrier per step; wave i and wave i + 4 share a SIMD, so every SIMD holds one wave
-// whose stream is MFMAs + vector ALU (the split epilogue) and one whose stream is MFMAs + LDS reads.  A single wave issues in
-// order — an MFMA holds the vector issue for 8 of its 16 cycles and every other instruction costs ~4 — and the first version
-// of this kernel (four waves doing both stages: 408 MFMAs + 770 vector + 316 LDS instructions per step) could not get below
-// ~11 k cycles per 6.5 k cycles of MFMAs, hand-scheduled or not; two specialised streams per SIMD overlap by themselves.
-//   step s:  A: planes z = 2s, 2s+1 of block 0's output on the (9 x 17) region the 4 x 8 tile needs, from the ring of 6 input
-//               planes in LDS ("ring 0": 8-byte records of 4 channels, one array per split — conv0_split_f32.hip's operand
-//               order: K = 8 taps x 4 channels, 4 k-blocks x 6 products = 24 MFMAs per 16-voxel tile; a wave: two row pairs
-//               sharing their window rows + one single tile = 120 MFMAs); bias + LeakyReLU, split into three bf16, stored into
-//               "ring 1" (5 planes: B reads 2s-3, 2s-2, 2s-1 meanwhile); voxels outside the volume keep ring 1's zero;
-//            B: output plane oz = s - 1: K = 27 taps x 16 channels = 13.5 k-blocks of 32; wave (c, kh) owns cout tile c and
-//               K half kh (taps 0..13 | 14..26: 7 k-blocks) of both 16-voxel tiles, its 21 weight fragments (three splits)
-//               stationary in 84 registers: 84 MFMAs, 3 fragments = 6 ds_read_b64 per 6 MFMAs; the K halves meet through LDS
-//               one step later (sum, bias, LeakyReLU, one 16-byte store per lane).  B also stages the input: it splits the
-//               planes 2s+3, 2s+4 it requested a step ago into ring 0 and requests 2s+5, 2s+6 (bounds-checked 16-byte
-//               buffer loads = the conv's zero padding).
-// 204 MFMAs of 16 cycles per SIMD and step against 2 x 4 KB of HBM traffic: the pair is bound by the matrix pipe.
+// plane of block-1 output apart, with ONE barrier per step; wave i and wave i + 4 share a SIMD.  Everything on a SIMD shares one
+// matrix pipe and one vector issue port, and a wave issues in order: the step time follows the SUM of what the two waves of
+// the busiest SIMD issue (ablation builds, profiles/NOTES_r05.md), so the work is dealt for equal sums.
+//   step s:  A: planes z = 2s, 2s+1 of block 0's output on the (9 x 17) region the 4 x 8 tile needs, from the ring of input
+//               planes in LDS ("ring 0": 8-byte records, three per voxel; three channels: the DENSE records E/F/G below, 17
+//               MFMAs per 16-voxel tile; five channels: four records, 27 MFMAs; other counts: conv0_split_f32.hip's order, 24);
+//               a wave: two pairs of vertically adjacent tiles sharing their fragments + one single tile = 85 MFMAs; bias +
+//               LeakyReLU, split into three bf16, stored into "ring 1" (5 planes: B reads 2s-3, 2s-2, 2s-1 meanwhile); voxels
+//               outside the volume keep ring 1's zero;
+//            B: output plane oz = s - 1: K = 27 taps x 16 channels = 13.5 k-blocks of 32 in four K quarters (taps 0..7 | 8..15 |
+//               16..21 | 22..26: 4, 4, 3, 3 k-blocks); wave kq computes its quarter of both 16-voxel tiles and both cout tiles
+//               (weights stationary in up to 96 registers; 96 | 72 MFMAs, 3 fragments = 6 ds_read_b64 per 12 MFMAs), owns
+//               accumulator kq and takes the three foreign quarters of it from LDS one step later (sum in quarter order, bias,
+//               LeakyReLU, one 16-byte store per lane).  The two 72-MFMA waves also stage the input: each splits the 55 items
+//               (11 rows x 5 quads of 4 voxels, every channel) of ONE plane it requested a step ago into ring 0 and requests
+//               the next (bounds-checked 8-byte buffer loads = the conv's zero padding).
+// 181 | 157 MFMAs of 16 cycles per SIMD and step against 2 x 4 KB of HBM traffic: the pair is bound by issue, not by memory.
 //
-// LDS (122.7 KB): ring 0 = 6 planes x 11 rows x [3 splits][24 records of 8 bytes]; ring 1 = 5 planes x 3 splits x 9 rows
-// x [4 channel quads][17 voxels] of 8 bytes, quads in the order 0,2,1,3 — a lane's two quads (8 channels) are a fixed 272 bytes
-// apart, the odd quad stride (17 chunks) and the row stride (72 chunks = 8 mod 16) make both the block-0 epilogue's
-// ds_write_b64 (16 lanes = 16 consecutive voxels) and block 1's ds_read_b64 (32 lanes = 8 voxels x 2 rows x 2 channel
-// halves) conflict-free.
+// LDS (<= 160 KB, Geo<NC>): ring 0 = 8 planes (five channels: 6) x 11 rows x [3 (4) record arrays][24 records of 8 bytes]; ring 1 =
+// 5 planes x 3 splits x 9 rows x [4 channel quads][17 voxels] of 8 bytes, quads in the order 0,2,1,3 — a lane's two quads (8
+// channels) are a fixed 272 bytes apart, the odd quad stride (17 chunks) and the row stride (72 chunks = 8 mod 16) make both the
+// block-0 epilogue's ds_write_b64 (16 lanes = 16 consecutive voxels) and block 1's ds_read_b64 (32 lanes = 8 voxels x 2 rows x
+// 2 channel halves) conflict-free; the exchange area of B's foreign accumulators (two step parities).
 //
 // Arithmetic: both stages are DIRECT convolutions whose products are exact; only the fp32 accumulation rounds (once per MFMA
 // and partial sum), so against an fp64 convolution the pair is closer than the fmaf chain of the fp32 kernels
@@ -55,6 +55,10 @@ constexpr int R1Y = 2 * TY + 1;          // 9 rows of block 0's output a plane o
 constexpr int R0Y = R1Y + 2;             // 11 input rows
 constexpr int NQ0 = 6;                   // aligned float4 quads of an input row: x = 2*ox0 - 4 .. 2*ox0 + 19 (record p = x - (2*ox0 - 4))
 constexpr int SB0 = NQ0 * 4 * 8;         // 192 bytes: one split of a ring-0 row
+// Staged: records 2 .. 21 only (the 19 a column reads are 2 .. 20) as FIVE quads that start 8 bytes off the 16-byte grid, each
+// fetched as two 8-byte halves (a half lies entirely inside or outside a row: H is even) — 110 items per step = two waves of
+// 55 lanes instead of three of 44 (records 0, 1, 22, 23 keep the zeros of the kernel's first fill)
+constexpr int NQS = 5, QS0 = 2;
 constexpr int QS1 = 17;                  // 8-byte chunks between the channel-quad runs of a ring-1 row (odd)
 constexpr int RS1 = 72;                  // chunks of a ring-1 row (= 8 mod 16)
 constexpr int SPB1 = R1Y * RS1 * 8;      // 5184 bytes: one split of a ring-1 plane
@@ -80,14 +84,14 @@ struct Geo {
   static constexpr int DUMP_OFF = SCR_OFF + SCR;  // where the threads without a staging item write
   static constexpr int DUMPB = 64 * 16 + (NARR - 1) * SB0 + 32;   // a 16-byte lane stride: the lanes without an item never write one address
   static constexpr int LDSB = DUMP_OFF + ((DUMPB + 255) / 256) * 256;
-  static_assert(NPRO0 * R0Y * NQ0 <= NTHR, "one staging item per thread");
+  static_assert(NPRO0 * R0Y * NQS <= NTHR, "one staging item per thread");
   static_assert((PLB0 & 255) == 128 && (RB0 & 127) == 64, "ring-0 bank geometry");
   static_assert(LDSB <= 160 * 1024, "LDS");
 };
-constexpr int NITEM = 2 * R0Y * NQ0;     // 132 staging items of a step: (plane, row, x-quad), all channels
+constexpr int NITEM = 2 * R0Y * NQS;     // 110 staging items of a step: (plane, row, x-quad), all channels
 constexpr int NKB1 = 4;   // k-blocks of block 0 | of a K quarter of block 1 (taps 0..7 | 8..15 | 16..21 | 22..26)
 constexpr unsigned OOR = 0x80000000u;
-static_assert(NITEM <= 3 * 44, "one staging item per thread");
+static_assert(NITEM == 2 * 55, "one staging item per thread: B waves 2 and 3, one plane each");
 static_assert(4 * QS1 <= RS1 && (QS1 & 1) == 1 && (RS1 & 15) == 8, "ring-1 bank geometry");
 
 struct FDims {
@@ -170,7 +174,8 @@ __device__ unsigned long long g_lr_c01_stamps[8 * 8];
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), b, c, 0, 0, 0)
 // timing-only ablation bits of a diagnostic build (`make abl`, tools/c01_abl.py; WRONG results): 1 B no MFMAs, 2 A idle, 4 A no
 // epilogue, 8 B no fragment reads, 16 A no MFMAs, 32 A no fragment reads, 64 fragments read ONCE per column and kept in registers
-// (every MFMA still runs on defined operands: the cost of the LDS reads alone)
+// (every MFMA still runs on defined operands: the cost of the LDS reads alone), 128 B: no split work in the staging (loads and
+// barriers stay)
 #ifndef LR_C01_ABL
 #define LR_C01_ABL 0
 #endif
@@ -207,13 +212,16 @@ __device__ __forceinline__ f32x4 max4(const f32x4& a, const f32x4& b) {
 // one (F, G) weight fragments = 15 MFMAs whose fragments two vertically adjacent tiles SHARE (input row iy is tap row iy of
 // the upper and iy - 1 of the lower tile); the three taps (0, ty, 2) x 5 slots fill two more MFMAs.  A tile's chain runs from
 // the small products to the large: G, E x w2, F, E x w1, the two leftover MFMAs, E x w0.
-__device__ __forceinline__ void dense_records(const unsigned (&p01)[3], const unsigned (&p2)[3], unsigned (&rec)[3][2]) {
+// The records of one voxel; channel 2 of TWO x-neighbours is split in one go (p2[s] = split s of voxel 0 | of voxel 1 << 16: half
+// the conversions of splitting it beside a zero) and HI selects the voxel.  v_perm_b32: selector bytes 0..3 pick S1's bytes, 4..7 S0's.
+template <int HI>
+__device__ __forceinline__ void dense_records_c2pair(const unsigned (&p01)[3], const unsigned (&p2)[3], unsigned (&rec)[3][2]) {
   rec[0][0] = p01[0];
-  rec[0][1] = p2[0] | (p01[1] << 16);
-  rec[1][0] = __builtin_amdgcn_alignbit(p2[1], p01[1], 16);
+  rec[0][1] = __builtin_amdgcn_perm(p01[1], p2[0], HI ? 0x05040302u : 0x05040100u);   // d0c2 | d1c0
+  rec[1][0] = __builtin_amdgcn_perm(p2[1], p01[1], HI ? 0x07060302u : 0x05040302u);   // d1c1 | d1c2
   rec[1][1] = p01[2];
-  rec[2][0] = (p01[1] & 0xffff0000u) | p2[2];
-  rec[2][1] = p2[1];
+  rec[2][0] = __builtin_amdgcn_perm(p01[1], p2[2], HI ? 0x07060302u : 0x07060100u);   // d2c2 | d1c1
+  rec[2][1] = HI ? p2[1] >> 16 : p2[1] & 0xffffu;
 }
 // FIVE input channels (the reference's shipped configuration: four views): the 15 bf16 of a voxel as FOUR records
 //   A1 = [d0c0 d0c1 d0c2 d0c3]   A2 = [d0c4 d1c0 d1c1 d1c2]   A3 = [d1c3 d1c4 d2c0 d2c1]   A4 = [d2c2 d2c3 d2c4 d0c4]
@@ -407,19 +415,25 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
     // (element access on the ext-vector result of the buffer-load builtin is narrowed by hipcc to a one-dword load with the
     // other elements undefined — DESIGN.md 6a: the quads are viewed through HIP's uint4, a struct, where they are used)
     auto issue_item = [&](bool live, int zi, int irow, int iq, u32x4 (&L)[NC]) __attribute__((always_inline)) {
-      const int yi = Y0 + irow, xi = X0a + 4 * iq;
+      const int yi = Y0 + irow, xi = X0a + QS0 + 4 * iq;
       const int zg = zi + zoff;
-      const int ok = (int)live & (int)(zg >= 0) & (int)(zg < Dg) & (int)(yi >= 0) & (int)(yi < dW) & (int)(xi >= 0) & (int)(xi < dH);
-      const unsigned dead = ((unsigned)ok - 1u) & OOR;   // dead item: bit 31 -> outside the resource -> 0
+      const int ok = (int)live & (int)(zg >= 0) & (int)(zg < Dg) & (int)(yi >= 0) & (int)(yi < dW);
+      const int ok_lo = ok & (int)(xi >= 0) & (int)(xi < dH), ok_hi = ok & (int)(xi + 2 >= 0) & (int)(xi + 2 < dH);
+      const unsigned dead_lo = ((unsigned)ok_lo - 1u) & OOR, dead_hi = ((unsigned)ok_hi - 1u) & OOR;   // dead half: bit 31 -> outside the resource -> 0
       const unsigned voff = (unsigned)((((zi + zrel) * dW + yi) * dH + xi) * 4);
-      L[0] = __builtin_amdgcn_raw_buffer_load_b128(r0, (int)(voff | dead), 0, 0);
+      auto halves = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned vo) __attribute__((always_inline)) -> u32x4 {
+        const uint2 a = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(vo | dead_lo), 0, 0));
+        const uint2 b = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)((vo + 8u) | dead_hi), 0, 0));
+        return (u32x4){a.x, a.y, b.x, b.y};
+      };
+      L[0] = halves(r0, voff);
 #pragma unroll
-      for (int c = 1; c < NC; ++c) L[c] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)((voff + (unsigned)(c - 1) * V4) | dead), 0, 0);
+      for (int c = 1; c < NC; ++c) L[c] = halves(rr, voff + (unsigned)(c - 1) * V4);
     };
     // ... -> split -> ring 0 (plane z sits in slot (z + 1) mod 6); a thread without an item writes zeros into the dump area
     auto write_item = [&](bool live, int zi, int irow, int iq, const u32x4 (&L)[NC]) __attribute__((always_inline)) {
       const int slot = (zi + 1 + NRING0) % NRING0;
-      unsigned char* const base = lds + (live ? slot * PLB0 + irow * RB0 + iq * 32 : DUMP_OFF + lane * 16);
+      unsigned char* const base = lds + (live ? slot * PLB0 + irow * RB0 + QS0 * 8 + iq * 32 : DUMP_OFF + lane * 16);
       if constexpr (NC == 5) {   // four records per voxel (dense5_records); channel 4 is split in voxel pairs
         auto val = [&](int c, int j) __attribute__((always_inline)) -> float {
           const uint4 q = __builtin_bit_cast(uint4, L[c]);
@@ -458,20 +472,29 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
         v[c][2] = c < NC ? __builtin_bit_cast(float, q.z) : 0.0f; v[c][3] = c < NC ? __builtin_bit_cast(float, q.w) : 0.0f;
       }
       unsigned rec[3][4][2];   // [split][voxel][channels 01 | 23]   (DENSE: [record E, F, G][voxel][half])
+      if constexpr (DENSE) {   // (three channels)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          unsigned p2[3], p01[3], r3[3][2];
+          split3(v[2][2 * jp], v[2][2 * jp + 1], p2);
+          split3(v[0][2 * jp], v[1][2 * jp], p01);
+          dense_records_c2pair<0>(p01, p2, r3);
+#pragma unroll
+          for (int s = 0; s < 3; ++s) { rec[s][2 * jp][0] = r3[s][0]; rec[s][2 * jp][1] = r3[s][1]; }
+          split3(v[0][2 * jp + 1], v[1][2 * jp + 1], p01);
+          dense_records_c2pair<1>(p01, p2, r3);
+#pragma unroll
+          for (int s = 0; s < 3; ++s) { rec[s][2 * jp + 1][0] = r3[s][0]; rec[s][2 * jp + 1][1] = r3[s][1]; }
+        }
+      } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         unsigned p01[3], p23[3] = {0u, 0u, 0u};
         split3(v[0][j], v[1][j], p01);
         if (NC > 2) split3(v[2][j], v[3][j], p23);
-        if constexpr (DENSE) {
-          unsigned r3[3][2];
-          dense_records(p01, p23, r3);
 #pragma unroll
-          for (int s = 0; s < 3; ++s) { rec[s][j][0] = r3[s][0]; rec[s][j][1] = r3[s][1]; }
-        } else {
-#pragma unroll
-          for (int s = 0; s < 3; ++s) { rec[s][j][0] = p01[s]; rec[s][j][1] = p23[s]; }
-        }
+        for (int s = 0; s < 3; ++s) { rec[s][j][0] = p01[s]; rec[s][j][1] = p23[s]; }
+      }
       }
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
@@ -482,15 +505,15 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
 
     // ---- unit prologue: ring 1 <- 0 (every voxel of the column outside the volume), ring 0 <- planes 2 s0 - 1 .. 2 s0 + 4
     // (NPRO0 x 66 items); the B threads also request planes 2 s0 + 5, + 6 (their items of the first step)
-    // staging items of a step: B waves 1..3 take 44 each (wave 0 = K quarter 0 has the most MFMAs and none)
-    const int bi = (wq - 1) * 44 + lane;
-    const bool item_live = !is_a && wq >= 1 && lane < 44;
-    const int ipl = item_live ? bi / (R0Y * NQ0) : 0, irow = item_live ? (bi % (R0Y * NQ0)) / NQ0 : 0, iq = item_live ? bi % NQ0 : 0;
+    // staging items of a step: B waves 2 and 3 (the K quarters with three k-blocks: 72 MFMAs against 96) take one plane = 55 each
+    const int bi = (wq - 2) * 55 + lane;
+    const bool item_live = !is_a && wq >= 2 && lane < 55;
+    const int ipl = item_live ? bi / (R0Y * NQS) : 0, irow = item_live ? (bi % (R0Y * NQS)) / NQS : 0, iq = item_live ? bi % NQS : 0;
     u32x4 ldn[NC];
     __syncthreads();   // (the zero fill of the whole LDS | every read of the unit before)
     {
-      const bool pl_live = tid < NPRO0 * R0Y * NQ0;
-      const int pz = pl_live ? tid / (R0Y * NQ0) - 1 + 2 * s0 : 0, prow = pl_live ? (tid % (R0Y * NQ0)) / NQ0 : 0, pq = pl_live ? tid % NQ0 : 0;
+      const bool pl_live = tid < NPRO0 * R0Y * NQS;
+      const int pz = pl_live ? tid / (R0Y * NQS) - 1 + 2 * s0 : 0, prow = pl_live ? (tid % (R0Y * NQS)) / NQS : 0, pq = pl_live ? tid % NQS : 0;
       u32x4 lp[NC];
       issue_item(pl_live, pz, prow, pq, lp);
       issue_item(item_live, 2 * s0 + 3 + PA0 + ipl, irow, iq, ldn);
@@ -702,14 +725,18 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
       };
       auto dload = [&](auto nc, const DBase& b, DFr& q) __attribute__((always_inline)) {
         constexpr int n = decltype(nc)::value;
+        if (!a_ld_g) return;
         if constexpr (CH::is_left(n)) q.f[n] = dfrag(b.pL[CH::left_w(n)][0], b.pL[CH::left_w(n)][1], CH::left_row(n) * RB0 + b.offL);
         else q.f[n] = dfrag(b.pA, b.pB, CH::iy(n) * RB0 + CH::arr(n) * SB0);
       };
       auto dmma = [&](auto kc, auto rc, const DFr& q, f32x4& acc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value, r = decltype(rc)::value;
-        acc = MFMA(wr[k], q.f[CH::frag(k, r)], acc);
+        if (a_mma_g) acc = MFMA(wr[k], q.f[CH::frag(k, r)], acc);
       };
       DFr fa;
+#if (LR_C01_ABL & (32 | 64))
+      for (int i = 0; i < CH::NFP; ++i) fa.f[i] = __builtin_bit_cast(bf16x8, (u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+#endif
       if constexpr (DENSE && PA0 > 0) {   // the first fragments of the column's first step (later steps: requested ahead of the barrier)
         const int t0 = (e6 % NRING0) * PLB0, t1 = ((e6 + 1) % NRING0) * PLB0, t2 = ((e6 + 2) % NRING0) * PLB0;
         DBase b0;
@@ -776,6 +803,9 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
               bN.pL[w][h] = 0u;
             }
           DFr fb, fs;
+#if (LR_C01_ABL & (32 | 64))
+          fb = fa; fs = fa;
+#endif
           f32x4 acc0, acc1;
           Epi E0;
           C01_STAMP(1);
@@ -908,19 +938,25 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
     // (element access on the ext-vector result of the buffer-load builtin is narrowed by hipcc to a one-dword load with the
     // other elements undefined — DESIGN.md 6a: the quads are viewed through HIP's uint4, a struct, where they are used)
     auto issue_item = [&](bool live, int zi, int irow, int iq, u32x4 (&L)[NC]) __attribute__((always_inline)) {
-      const int yi = Y0 + irow, xi = X0a + 4 * iq;
+      const int yi = Y0 + irow, xi = X0a + QS0 + 4 * iq;
       const int zg = zi + zoff;
-      const int ok = (int)live & (int)(zg >= 0) & (int)(zg < Dg) & (int)(yi >= 0) & (int)(yi < dW) & (int)(xi >= 0) & (int)(xi < dH);
-      const unsigned dead = ((unsigned)ok - 1u) & OOR;   // dead item: bit 31 -> outside the resource -> 0
+      const int ok = (int)live & (int)(zg >= 0) & (int)(zg < Dg) & (int)(yi >= 0) & (int)(yi < dW);
+      const int ok_lo = ok & (int)(xi >= 0) & (int)(xi < dH), ok_hi = ok & (int)(xi + 2 >= 0) & (int)(xi + 2 < dH);
+      const unsigned dead_lo = ((unsigned)ok_lo - 1u) & OOR, dead_hi = ((unsigned)ok_hi - 1u) & OOR;   // dead half: bit 31 -> outside the resource -> 0
       const unsigned voff = (unsigned)((((zi + zrel) * dW + yi) * dH + xi) * 4);
-      L[0] = __builtin_amdgcn_raw_buffer_load_b128(r0, (int)(voff | dead), 0, 0);
+      auto halves = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned vo) __attribute__((always_inline)) -> u32x4 {
+        const uint2 a = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(vo | dead_lo), 0, 0));
+        const uint2 b = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)((vo + 8u) | dead_hi), 0, 0));
+        return (u32x4){a.x, a.y, b.x, b.y};
+      };
+      L[0] = halves(r0, voff);
 #pragma unroll
-      for (int c = 1; c < NC; ++c) L[c] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)((voff + (unsigned)(c - 1) * V4) | dead), 0, 0);
+      for (int c = 1; c < NC; ++c) L[c] = halves(rr, voff + (unsigned)(c - 1) * V4);
     };
     // ... -> split -> ring 0 (plane z sits in slot (z + 1) mod 6); a thread without an item writes zeros into the dump area
     auto write_item = [&](bool live, int zi, int irow, int iq, const u32x4 (&L)[NC]) __attribute__((always_inline)) {
       const int slot = (zi + 1 + NRING0) % NRING0;
-      unsigned char* const base = lds + (live ? slot * PLB0 + irow * RB0 + iq * 32 : DUMP_OFF + lane * 16);
+      unsigned char* const base = lds + (live ? slot * PLB0 + irow * RB0 + QS0 * 8 + iq * 32 : DUMP_OFF + lane * 16);
       if constexpr (NC == 5) {   // four records per voxel (dense5_records); channel 4 is split in voxel pairs
         auto val = [&](int c, int j) __attribute__((always_inline)) -> float {
           const uint4 q = __builtin_bit_cast(uint4, L[c]);
@@ -959,20 +995,29 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
         v[c][2] = c < NC ? __builtin_bit_cast(float, q.z) : 0.0f; v[c][3] = c < NC ? __builtin_bit_cast(float, q.w) : 0.0f;
       }
       unsigned rec[3][4][2];   // [split][voxel][channels 01 | 23]   (DENSE: [record E, F, G][voxel][half])
+      if constexpr (DENSE) {   // (three channels)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          unsigned p2[3], p01[3], r3[3][2];
+          split3(v[2][2 * jp], v[2][2 * jp + 1], p2);
+          split3(v[0][2 * jp], v[1][2 * jp], p01);
+          dense_records_c2pair<0>(p01, p2, r3);
+#pragma unroll
+          for (int s = 0; s < 3; ++s) { rec[s][2 * jp][0] = r3[s][0]; rec[s][2 * jp][1] = r3[s][1]; }
+          split3(v[0][2 * jp + 1], v[1][2 * jp + 1], p01);
+          dense_records_c2pair<1>(p01, p2, r3);
+#pragma unroll
+          for (int s = 0; s < 3; ++s) { rec[s][2 * jp + 1][0] = r3[s][0]; rec[s][2 * jp + 1][1] = r3[s][1]; }
+        }
+      } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         unsigned p01[3], p23[3] = {0u, 0u, 0u};
         split3(v[0][j], v[1][j], p01);
         if (NC > 2) split3(v[2][j], v[3][j], p23);
-        if constexpr (DENSE) {
-          unsigned r3[3][2];
-          dense_records(p01, p23, r3);
 #pragma unroll
-          for (int s = 0; s < 3; ++s) { rec[s][j][0] = r3[s][0]; rec[s][j][1] = r3[s][1]; }
-        } else {
-#pragma unroll
-          for (int s = 0; s < 3; ++s) { rec[s][j][0] = p01[s]; rec[s][j][1] = p23[s]; }
-        }
+        for (int s = 0; s < 3; ++s) { rec[s][j][0] = p01[s]; rec[s][j][1] = p23[s]; }
+      }
       }
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
@@ -983,16 +1028,16 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
 
     // ---- unit prologue: ring 1 <- 0 (every voxel of the column outside the volume), ring 0 <- planes 2 s0 - 1 .. 2 s0 + 4
     // (NPRO0 x 66 items); the B threads also request planes 2 s0 + 5, + 6 (their items of the first step)
-    // staging items of a step: B waves 1..3 take 44 each (wave 0 = K quarter 0 has the most MFMAs and none)
-    const int bi = (wq - 1) * 44 + lane;
-    const bool item_live = !is_a && wq >= 1 && lane < 44;
-    const bool wave_stages = !is_a && wq >= 1;   // wave-uniform
-    const int ipl = item_live ? bi / (R0Y * NQ0) : 0, irow = item_live ? (bi % (R0Y * NQ0)) / NQ0 : 0, iq = item_live ? bi % NQ0 : 0;
+    // staging items of a step: B waves 2 and 3 (the K quarters with three k-blocks: 72 MFMAs against 96) take one plane = 55 each
+    const int bi = (wq - 2) * 55 + lane;
+    const bool item_live = !is_a && wq >= 2 && lane < 55;
+    const bool wave_stages = !is_a && wq >= 2;   // wave-uniform
+    const int ipl = item_live ? bi / (R0Y * NQS) : 0, irow = item_live ? (bi % (R0Y * NQS)) / NQS : 0, iq = item_live ? bi % NQS : 0;
     u32x4 ldn[NC];
     __syncthreads();   // (the zero fill of the whole LDS | every read of the unit before)
     {
-      const bool pl_live = tid < NPRO0 * R0Y * NQ0;
-      const int pz = pl_live ? tid / (R0Y * NQ0) - 1 + 2 * s0 : 0, prow = pl_live ? (tid % (R0Y * NQ0)) / NQ0 : 0, pq = pl_live ? tid % NQ0 : 0;
+      const bool pl_live = tid < NPRO0 * R0Y * NQS;
+      const int pz = pl_live ? tid / (R0Y * NQS) - 1 + 2 * s0 : 0, prow = pl_live ? (tid % (R0Y * NQS)) / NQS : 0, pq = pl_live ? tid % NQS : 0;
       u32x4 lp[NC];
       issue_item(pl_live, pz, prow, pq, lp);
       issue_item(item_live, 2 * s0 + 3 + PA0 + ipl, irow, iq, ldn);
@@ -1062,16 +1107,16 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
         }
         unsigned rec[3][2][2];
         if constexpr (DENSE) {
+          unsigned p01[3], p2[3], r3[3][2];
+          split3(lval(2, 2 * half), lval(2, 2 * half + 1), p2);
+          split3(lval(0, 2 * half), lval(1, 2 * half), p01);
+          dense_records_c2pair<0>(p01, p2, r3);
 #pragma unroll
-          for (int vv = 0; vv < 2; ++vv) {
-            const int vj = 2 * half + vv;
-            unsigned p01[3], p2[3], r3[3][2];
-            split3(lval(0, vj), lval(1, vj), p01);
-            split3(lval(2, vj), 0.0f, p2);
-            dense_records(p01, p2, r3);
+          for (int sp = 0; sp < 3; ++sp) { rec[sp][0][0] = r3[sp][0]; rec[sp][0][1] = r3[sp][1]; }
+          split3(lval(0, 2 * half + 1), lval(1, 2 * half + 1), p01);
+          dense_records_c2pair<1>(p01, p2, r3);
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp) { rec[sp][vv][0] = r3[sp][0]; rec[sp][vv][1] = r3[sp][1]; }
-          }
+          for (int sp = 0; sp < 3; ++sp) { rec[sp][1][0] = r3[sp][0]; rec[sp][1][1] = r3[sp][1]; }
         } else {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -1120,7 +1165,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
 #endif
       for (int s = s0; s <= d.Do; ++s) {
         C01_STAMP(0);
-        const int r0addr = item_live ? ((2 * s + 3 + PA0 + ipl + 1) % NRING0) * PLB0 + irow * RB0 + iq * 32 : DUMP_OFF + lane * 16;
+        const int r0addr = item_live ? ((2 * s + 3 + PA0 + ipl + 1) % NRING0) * PLB0 + irow * RB0 + QS0 * 8 + iq * 32 : DUMP_OFF + lane * 16;
         C01_STAMP(1);
         if (s >= 1) {
           const int oz = s - 1;
@@ -1163,7 +1208,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
             lo[t][0] = MFMA(C01_W(0, 0), f[2], lo[t][0]); lo[t][1] = MFMA(C01_W(1, 0), f[2], lo[t][1]);
             }
             C01_FENCE();
-            if (2 * g < NST) { if (wave_stages) stage_slice(2 * g, r0addr); } else if (2 * g < NSL) fin_slice(2 * g - NST, oz - 1);
+            if (2 * g < NST) { if (wave_stages && !(LR_C01_ABL & 128)) stage_slice(2 * g, r0addr); } else if (2 * g < NSL) fin_slice(2 * g - NST, oz - 1);
             C01_FENCE();
             if (b_mma) {
             lo[t][0] = MFMA(C01_W(0, 1), f[0], lo[t][0]); lo[t][1] = MFMA(C01_W(1, 1), f[0], lo[t][1]);
@@ -1172,7 +1217,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
             }
 #undef C01_W
             C01_FENCE();
-            if (2 * g + 1 < NST) { if (wave_stages) stage_slice(2 * g + 1, r0addr); } else if (2 * g + 1 < NSL) fin_slice(2 * g + 1 - NST, oz - 1);
+            if (2 * g + 1 < NST) { if (wave_stages && !(LR_C01_ABL & 128)) stage_slice(2 * g + 1, r0addr); } else if (2 * g + 1 < NSL) fin_slice(2 * g + 1 - NST, oz - 1);
             if (2 * g + 1 == NST - 1 && wave_stages) issue_item(item_live, 2 * s + 5 + PA0 + ipl, irow, iq, ldn);
             C01_FENCE();
           };
