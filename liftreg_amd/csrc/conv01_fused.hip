@@ -654,7 +654,10 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
       // (SAVE: so / mo = the tile's activation / mask offsets, zb = its plane (scalar); a plane below the volume never comes here
       // with live offsets: the caller passes OOR)
       auto epi_slice = [&](int sl, Epi& E, const f32x4& acc, int addr, unsigned so = OOR, unsigned mo = OOR, int zb = 0) __attribute__((always_inline)) {
-        if (!a_epi_g) return;
+        if (!a_epi_g) {   // (ablation: the chain stays alive through one store)
+          if (sl == 6) *reinterpret_cast<f32x4*>(lds + DUMP_OFF + lane * 16) = acc;
+          return;
+        }
         if (sl == 0) { E.x = acc; E.y = E.x * d.slope0; }
         else if (sl == 1) {
           E.x = max4(E.x, E.y);   // = LeakyReLU for 0 <= slope <= 1 (launcher)
@@ -725,13 +728,14 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
       };
       auto dload = [&](auto nc, const DBase& b, DFr& q) __attribute__((always_inline)) {
         constexpr int n = decltype(nc)::value;
-        if (!a_ld_g) return;
+        if (!a_ld_g) { asm volatile("" : "+v"(q.f[n])); return; }   // (ablation: opaque, so that no MFMA is hoisted)
         if constexpr (CH::is_left(n)) q.f[n] = dfrag(b.pL[CH::left_w(n)][0], b.pL[CH::left_w(n)][1], CH::left_row(n) * RB0 + b.offL);
         else q.f[n] = dfrag(b.pA, b.pB, CH::iy(n) * RB0 + CH::arr(n) * SB0);
       };
       auto dmma = [&](auto kc, auto rc, const DFr& q, f32x4& acc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value, r = decltype(rc)::value;
         if (a_mma_g) acc = MFMA(wr[k], q.f[CH::frag(k, r)], acc);
+        else asm volatile("" : "+v"(acc) : "v"(q.f[CH::frag(k, r)]));   // (ablation: the fragment reads stay alive)
       };
       DFr fa;
 #if (LR_C01_ABL & (32 | 64))
@@ -840,6 +844,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
             if constexpr (PA0 > 0 && g >= 5 * NMF - DENSE_PRE) dload(std::integral_constant<int, g - (5 * NMF - DENSE_PRE)>{}, bN, fa);
             if constexpr (t >= 1 && CH::epi_slice_at(k) >= 0) epi_tile(std::integral_constant<int, t - 1>{}, CH::epi_slice_at(k), prev);
             C01_FENCE();
+            if constexpr (k == NMF - 1 && t < 3) C01_STAMP(t == 0 ? 2 : t == 1 ? 3 : 7);   // (stamped build: the first three tiles)
           });
           C01_STAMP(4);
 #pragma unroll

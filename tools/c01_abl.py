@@ -5,9 +5,13 @@ import subprocess
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-names = {0: "everything", 1: "B: no MFMAs", 9: "B: no MFMAs, no fragment reads", 2: "A idle", 4: "A: no epilogue", 16: "A: no MFMAs",
-         32: "A: no fragment reads", 36: "A: MFMAs only", 3: "A idle, B no MFMAs (staging + barriers only)", 8: "B: no fragment reads",
-         20: "A: fragment reads only", 48: "A: epilogue only", 41: "MFMAs + A epilogue, no fragment reads at all", 5: "B no MFMAs, A no epilogue"}
+names = {0: "everything", 1: "B: no MFMAs", 2: "A idle", 3: "A idle, B no MFMAs (staging + barriers only)", 8: "B: no fragment reads",
+         128: "B: no split work in the staging", 129: "B: no MFMAs, no split work",
+         # A alone = 137 (B: no MFMAs, no fragment reads, no split work); its parts (the chains stay alive: one store per tile /
+         # opaque fragments): NOTE the skeleton alone (157) is bound by the HBM latency of the staging loads - shorter steps than that
+         # cannot be read off these builds
+         137: "A alone", 141: "A alone: no epilogue", 169: "A alone: no fragment reads", 173: "A alone: MFMAs only",
+         153: "A alone: no MFMAs", 157: "skeleton (barriers, staging loads, B's exchange)"}
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
     from liftreg_amd import _hip
     v = sys.argv[2]

@@ -23,7 +23,7 @@ for _ in range(3):
 torch.cuda.synchronize(); lib.lr_debug_read_c01_stamps(buf, 1)
 ops.conv3d_pair01(x0, rest, w0, b0, w1, b1, packed=pk)
 torch.cuda.synchronize(); lib.lr_debug_read_c01_stamps(buf, 0)
-names = ["0 step top", "1 A: first fragments | B: staging", "2 A stage 0 | B: finish", "3 A stage 1 | B: MFMAs", "4 A stage 2 | B: partial", "5 A tail", "6 barrier", "7"]
+names = ["0 step top", "1 A: first fragments | B: staging", "2 A tile 0", "3 A tile 1 | B: MFMAs", "4 A tiles 3, 4 | B: partial", "5 A tail", "6 barrier", "7 A tile 2"]
 steps = (256 * 8 * 2) * 129 / 256   # per block
 for w in range(8):
     tot = sum(buf[w * 8 + i] for i in range(8))
