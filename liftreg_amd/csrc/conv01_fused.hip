@@ -266,7 +266,7 @@ template <> struct Chain<3> {   // kinds: 0 G, 1 E, 2 F (arrays 2, 0, 1), 3 = th
     if (n < 14) return NMF + 2 + 3 * (n - 11);
     return NMF + 12 + (n - 14);
   }
-  static constexpr int epi_slice_at(int k) { return (k >= 2 && k <= 14 && (k & 1) == 0) ? k / 2 - 1 : -1; }
+  static constexpr int EPI_AT = 8;   // the MFMA slot of a tile behind which the epilogue of the tile before runs
 };
 template <> struct Chain<5> {   // load kinds: 0 A1, 1 A4, 2 A3, 3 A2 (arrays 0, 3, 2, 1), 4 = the leftover fragment of a tap row (shared like the others)
   static constexpr int NMF = 27, NFP = 20, NFS = 15;
@@ -283,7 +283,7 @@ template <> struct Chain<5> {   // load kinds: 0 A1, 1 A4, 2 A3, 3 A2 (arrays 0,
   }
   static constexpr int first_phase(int kind) { return kind == 0 ? 0 : kind == 1 ? 1 : kind == 2 ? 2 : kind == 3 ? 4 : 6; }
   static constexpr int need(int n) { return n < 15 ? first_phase(lk(n)) * 3 + iy(n) : NMF + first_phase(lk(n)) * 3 + 2; }
-  static constexpr int epi_slice_at(int k) { return (k >= 3 && k <= 21 && k % 3 == 0) ? k / 3 - 1 : -1; }
+  static constexpr int EPI_AT = 13;
 };
 template <int NC, bool DENSE> constexpr int block0_fragments() { if constexpr (DENSE) return Chain<NC>::NMF; else return 12; }
 // MFMA slot g = NMF t + k of a step (tiles t = 0..4: pair 0 upper / lower, pair 1 upper / lower, the single tile) issues at most one
@@ -291,37 +291,51 @@ template <int NC, bool DENSE> constexpr int block0_fragments() { if constexpr (D
 // slots away (LDS latency under load; lgkmcnt counts 15 operations = 7 fragments in flight).  The first DENSE_PRE fragments of the
 // step are requested in front (ahead of the barrier when ring 0 is staged a step early).
 #ifndef LR_C01_DENSE_AHEAD
-#define LR_C01_DENSE_AHEAD 8
+#define LR_C01_DENSE_AHEAD 12
 #endif
 constexpr int DENSE_PRE = 6, DENSE_AHEAD = LR_C01_DENSE_AHEAD;
+#ifndef LR_C01_LOAD_PERIOD
+#define LR_C01_LOAD_PERIOD 4   // fragment loads only behind every PERIOD-th MFMA slot, up to LR_C01_LOAD_BURST fragments there (one per slot: +1 %)
+#endif
+#ifndef LR_C01_LOAD_BURST
+#define LR_C01_LOAD_BURST 4
+#endif
 template <int NC>
-constexpr int dense_load_at(int g) {   // -1 | set * 32 + n: the fragment load issued behind MFMA slot g
+constexpr int dense_next(int pos) {   // the fragment after pos = set * 32 + n in load order (set 3 = none left)
   using C = Chain<NC>;
-  int set = 0, n = DENSE_PRE;
-  for (int s = 0; s <= g; ++s) {
-    if (set > 2) return -1;
-    const bool go = set * 2 * C::NMF + C::need(n) - s <= DENSE_AHEAD;
-    if (s == g) return go ? set * 32 + n : -1;
-    if (go) {
-      ++n;
-      if (n == (set == 2 ? C::NFS : C::NFP)) { n = 0; ++set; }
-    }
-  }
-  return -1;
+  int set = pos / 32, n = pos % 32 + 1;
+  if (n == (set == 2 ? C::NFS : C::NFP)) { n = 0; ++set; }
+  return set * 32 + n;
 }
 template <int NC>
-constexpr bool dense_schedule_ok() {   // every fragment is requested before the MFMA that first reads it (one replay of dense_load_at's walk)
+constexpr int dense_nth(int pos, int i) { for (int k = 0; k < i; ++k) pos = dense_next<NC>(pos); return pos; }
+template <int NC>
+constexpr int dense_load_at(int g) {   // count * 1024 + (set * 32 + n of the first): the fragment loads issued behind MFMA slot g
   using C = Chain<NC>;
-  int set = 0, n = DENSE_PRE;
-  for (int s = 0; s < 5 * C::NMF && set <= 2; ++s) {
-    const int need = set * 2 * C::NMF + C::need(n);
-    if (need - s <= DENSE_AHEAD) {
-      if (s >= need) return false;
-      ++n;
-      if (n == (set == 2 ? C::NFS : C::NFP)) { n = 0; ++set; }
+  int pos = DENSE_PRE;
+  for (int s = 0; s <= g; ++s) {
+    int cnt = 0, first = pos;
+    if (s % LR_C01_LOAD_PERIOD == 0)
+      while (pos / 32 <= 2 && (pos / 32) * 2 * C::NMF + C::need(pos % 32) - s <= DENSE_AHEAD && cnt < LR_C01_LOAD_BURST) { pos = dense_next<NC>(pos); ++cnt; }
+    if (s == g) return cnt * 1024 + first;
+  }
+  return 0;
+}
+template <int NC>
+constexpr bool dense_schedule_ok() {   // every fragment is requested before the MFMA that first reads it, and all are requested
+  using C = Chain<NC>;
+  int pos = DENSE_PRE;
+  for (int s = 0; s < 5 * C::NMF; ++s) {
+    const int b = dense_load_at<NC>(s);
+    int q = b % 1024;
+    for (int i = 0; i < b / 1024; ++i) {
+      if (q != pos) return false;
+      if (s >= (q / 32) * 2 * C::NMF + C::need(q % 32)) return false;
+      q = dense_next<NC>(q);
+      pos = q;
     }
   }
-  return set == 3;
+  return pos / 32 == 3;
 }
 static_assert(dense_schedule_ok<3>() && dense_schedule_ok<5>(), "dense fragment schedule");
 template <class F, int... Is>
@@ -835,14 +849,19 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
             else if constexpr (t < 4) dmma(std::integral_constant<int, k>{}, std::integral_constant<int, t - 2>{}, fb, acc);
             else dmma(std::integral_constant<int, k>{}, std::integral_constant<int, 0>{}, fs, acc);
             constexpr int ld = dense_load_at<NCH>(g);
-            if constexpr (ld >= 0) {
-              constexpr int set = ld / 32, n = ld % 32;
+            static_for<ld / 1024>([&](auto ic) __attribute__((always_inline)) {
+              constexpr int q = dense_nth<NCH>(ld % 1024, decltype(ic)::value), set = q / 32, n = q % 32;
               if constexpr (set == 0) dload(std::integral_constant<int, n>{}, bP0, fa);
               else if constexpr (set == 1) dload(std::integral_constant<int, n>{}, bP1, fb);
               else dload(std::integral_constant<int, n>{}, bS, fs);
-            }
+            });
             if constexpr (PA0 > 0 && g >= 5 * NMF - DENSE_PRE) dload(std::integral_constant<int, g - (5 * NMF - DENSE_PRE)>{}, bN, fa);
-            if constexpr (t >= 1 && CH::epi_slice_at(k) >= 0) epi_tile(std::integral_constant<int, t - 1>{}, CH::epi_slice_at(k), prev);
+            // the WHOLE epilogue of the tile before in ONE gap (seven gaps with four or five vector instructions each: +1.3 %;
+            // two instructions in every gap: +32 % — an MFMA that follows its chain's predecessor directly is the cheap case)
+            if constexpr (t >= 1 && k == CH::EPI_AT) {
+#pragma unroll
+              for (int q = 0; q < 7; ++q) epi_tile(std::integral_constant<int, t - 1>{}, q, prev);
+            }
             C01_FENCE();
             if constexpr (k == NMF - 1 && t < 3) C01_STAMP(t == 0 ? 2 : t == 1 ? 3 : 7);   // (stamped build: the first three tiles)
           });
