@@ -371,6 +371,8 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
   // a slab that does not start at the top of the volume: block-0 plane -1 (global zoff - 1) exists — one step s = -1 in front
   // computes it (A: planes -2, -1, the first into a slot nobody reads; B: staging only)
   const int s0 = __builtin_amdgcn_readfirstlane(zoff > 0 ? -1 : 0);
+  // ring-0 slots are counted from the unit's first step (plane z sits in slot (z + 1 + zsh) mod NRING0): the ring state of step s0 is 0
+  const int zsh = -2 * s0;
 
   // zero everything once: a "weight 0" operand slot multiplies whatever lies behind a row / plane and needs finite numbers
   for (int o = tid * 16; o < LDSB; o += NTHR * 16) *reinterpret_cast<u32x4*>(lds + o) = (u32x4){0u, 0u, 0u, 0u};
@@ -446,7 +448,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
     };
     // ... -> split -> ring 0 (plane z sits in slot (z + 1) mod 6); a thread without an item writes zeros into the dump area
     auto write_item = [&](bool live, int zi, int irow, int iq, const u32x4 (&L)[NC]) __attribute__((always_inline)) {
-      const int slot = (zi + 1 + NRING0) % NRING0;
+      const int slot = (zi + 1 + zsh + NRING0) % NRING0;
       unsigned char* const base = lds + (live ? slot * PLB0 + irow * RB0 + QS0 * 8 + iq * 32 : DUMP_OFF + lane * 16);
       if constexpr (NC == 5) {   // four records per voxel (dense5_records); channel 4 is split in voxel pairs
         auto val = [&](int c, int j) __attribute__((always_inline)) -> float {
@@ -729,7 +731,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
         for (int sp = 0; sp < 3; ++sp) fs.G[sp] = frag(gb + 2 * PLB0, sp * SB0, RB0);
       }
 #endif
-      int e6 = (2 * s0 + NRING0) % NRING0, m5 = (2 * s0 + NRING1) % NRING1;   // (2s) mod 8 = ring-0 slot of plane 2s-1; (2s) mod 5 = ring-1 slot of plane 2s
+      int e6 = 0, m5 = (2 * s0 + NRING1) % NRING1;   // (2s + zsh) mod 8 = ring-0 slot of plane 2s-1 (0 at s0); (2s) mod 5 = ring-1 slot of plane 2s
       // ---- DENSE: fragment addressing and the MFMA chain of a tile (Chain<NC>)
       constexpr int NCH = DENSE ? NC : 3;
       using CH = Chain<NCH>;
@@ -789,7 +791,9 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
             LS[w][h] = (unsigned)(spl * PLB0) + dnLs[w][h];    // (state e6 <= NRING0 - 2: slot e6 + spl never wraps)
           }
       }
-      for (int s = s0; s <= d.Do; ++s) {
+      // One step of the column.  ec: the ring-0 state as a compile-time constant, or -1 = dispatch on e6.
+      auto a_iter = [&](const int s, auto ec) __attribute__((always_inline)) {
+        constexpr int EC = decltype(ec)::value;
         constexpr bool a_on = !(LR_C01_ABL & 2);
         if (s < d.Do && a_on) {
           C01_STAMP(0);
@@ -871,7 +875,8 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
           C01_STAMP(5);
           };
           // one copy of the step per ring state (e6 is wave-uniform: a scalar branch)
-          if (e6 == 0) dense_step(std::integral_constant<int, 0>{});
+          if constexpr (EC >= 0) dense_step(std::integral_constant<int, EC>{});
+          else if (e6 == 0) dense_step(std::integral_constant<int, 0>{});
           else if (e6 == 2) dense_step(std::integral_constant<int, 2>{});
           else if (e6 == 4) dense_step(std::integral_constant<int, 4>{});
           else dense_step(std::integral_constant<int, (NRING0 - 2)>{});      // (6 of an eight-plane ring; a six-plane ring has no fourth state)
@@ -943,6 +948,20 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
         C01_STAMP(6);
         e6 = (e6 + 2) % NRING0;
         m5 = (m5 + 2) % NRING1;
+      };
+      if constexpr (DENSE && PA0 > 0 && NRING0 == 8) {
+        // The four ring states in program order (state 0 at s0): the fragments requested ahead of a barrier stay in the registers
+        // the next state reads them from.  (With one dispatching loop the four copies merged at the loop's latch: 24 register
+        // moves per step BEHIND a wait for those loads — their LDS latency, which the early request was to hide, came back.)
+        int s = s0;
+        for (;;) {
+          a_iter(s, std::integral_constant<int, 0>{}); if (++s > d.Do) break;
+          a_iter(s, std::integral_constant<int, 2>{}); if (++s > d.Do) break;
+          a_iter(s, std::integral_constant<int, 4>{}); if (++s > d.Do) break;
+          a_iter(s, std::integral_constant<int, 6>{}); if (++s > d.Do) break;
+        }
+      } else {
+        for (int s = s0; s <= d.Do; ++s) a_iter(s, std::integral_constant<int, -1>{});
       }
   }
   } else {
@@ -979,7 +998,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
     };
     // ... -> split -> ring 0 (plane z sits in slot (z + 1) mod 6); a thread without an item writes zeros into the dump area
     auto write_item = [&](bool live, int zi, int irow, int iq, const u32x4 (&L)[NC]) __attribute__((always_inline)) {
-      const int slot = (zi + 1 + NRING0) % NRING0;
+      const int slot = (zi + 1 + zsh + NRING0) % NRING0;
       unsigned char* const base = lds + (live ? slot * PLB0 + irow * RB0 + QS0 * 8 + iq * 32 : DUMP_OFF + lane * 16);
       if constexpr (NC == 5) {   // four records per voxel (dense5_records); channel 4 is split in voxel pairs
         auto val = [&](int c, int j) __attribute__((always_inline)) -> float {
@@ -1189,7 +1208,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
 #endif
       for (int s = s0; s <= d.Do; ++s) {
         C01_STAMP(0);
-        const int r0addr = item_live ? ((2 * s + 3 + PA0 + ipl + 1) % NRING0) * PLB0 + irow * RB0 + QS0 * 8 + iq * 32 : DUMP_OFF + lane * 16;
+        const int r0addr = item_live ? ((2 * s + 3 + PA0 + ipl + 1 + zsh) % NRING0) * PLB0 + irow * RB0 + QS0 * 8 + iq * 32 : DUMP_OFF + lane * 16;
         C01_STAMP(1);
         if (s >= 1) {
           const int oz = s - 1;
