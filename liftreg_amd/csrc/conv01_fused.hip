@@ -731,7 +731,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
         for (int sp = 0; sp < 3; ++sp) fs.G[sp] = frag(gb + 2 * PLB0, sp * SB0, RB0);
       }
 #endif
-      int e6 = 0, m5 = (2 * s0 + NRING1) % NRING1;   // (2s + zsh) mod 8 = ring-0 slot of plane 2s-1 (0 at s0); (2s) mod 5 = ring-1 slot of plane 2s
+      int e6 = 0, m5 = __builtin_amdgcn_readfirstlane((2 * s0 + NRING1) % NRING1);   // (2s + zsh) mod 8 = ring-0 slot of plane 2s-1 (0 at s0); (2s) mod 5 = ring-1 slot of plane 2s
       // ---- DENSE: fragment addressing and the MFMA chain of a tile (Chain<NC>)
       constexpr int NCH = DENSE ? NC : 3;
       using CH = Chain<NCH>;
@@ -947,7 +947,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
         __syncthreads();
         C01_STAMP(6);
         e6 = (e6 + 2) % NRING0;
-        m5 = (m5 + 2) % NRING1;
+        m5 = __builtin_amdgcn_readfirstlane(m5 + 2 >= NRING1 ? m5 + 2 - NRING1 : m5 + 2);   // (kept in a scalar register: the store addresses and the planes' validity hang on it)
       };
       if constexpr (DENSE && PA0 > 0 && NRING0 == 8) {
         // The four ring states in program order (state 0 at s0): the fragments requested ahead of a barrier stay in the registers
