@@ -266,7 +266,7 @@ template <> struct Chain<3> {   // kinds: 0 G, 1 E, 2 F (arrays 2, 0, 1), 3 = th
     if (n < 14) return NMF + 2 + 3 * (n - 11);
     return NMF + 12 + (n - 14);
   }
-  static constexpr int EPI_AT = 8;   // the MFMA slot of a tile behind which the epilogue of the tile before runs
+  static constexpr int EPI_AT = NMF - 1;   // the MFMA slot of a tile behind which the epilogue of the tile before runs
 };
 template <> struct Chain<5> {   // load kinds: 0 A1, 1 A4, 2 A3, 3 A2 (arrays 0, 3, 2, 1), 4 = the leftover fragment of a tap row (shared like the others)
   static constexpr int NMF = 27, NFP = 20, NFS = 15;
@@ -283,7 +283,7 @@ template <> struct Chain<5> {   // load kinds: 0 A1, 1 A4, 2 A3, 3 A2 (arrays 0,
   }
   static constexpr int first_phase(int kind) { return kind == 0 ? 0 : kind == 1 ? 1 : kind == 2 ? 2 : kind == 3 ? 4 : 6; }
   static constexpr int need(int n) { return n < 15 ? first_phase(lk(n)) * 3 + iy(n) : NMF + first_phase(lk(n)) * 3 + 2; }
-  static constexpr int EPI_AT = 13;
+  static constexpr int EPI_AT = NMF - 1;
 };
 template <int NC, bool DENSE> constexpr int block0_fragments() { if constexpr (DENSE) return Chain<NC>::NMF; else return 12; }
 // MFMA slot g = NMF t + k of a step (tiles t = 0..4: pair 0 upper / lower, pair 1 upper / lower, the single tile) issues at most one
@@ -860,8 +860,9 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
               else dload(std::integral_constant<int, n>{}, bS, fs);
             });
             if constexpr (PA0 > 0 && g >= 5 * NMF - DENSE_PRE) dload(std::integral_constant<int, g - (5 * NMF - DENSE_PRE)>{}, bN, fa);
-            // the WHOLE epilogue of the tile before in ONE gap (seven gaps with four or five vector instructions each: +1.3 %;
-            // two instructions in every gap: +32 % — an MFMA that follows its chain's predecessor directly is the cheap case)
+            // the WHOLE epilogue of the tile before in ONE gap, the one in front of the next chain's first MFMA (seven gaps with four or
+            // five vector instructions each: +3 %; two instructions in every gap: +32 %; one gap in the middle of the chain: +1.5 % —
+            // an MFMA that follows its chain's predecessor directly is the cheap case)
             if constexpr (t >= 1 && k == CH::EPI_AT) {
 #pragma unroll
               for (int q = 0; q < 7; ++q) epi_tile(std::integral_constant<int, t - 1>{}, q, prev);
