@@ -246,7 +246,7 @@ EXTRA = (  # (name, script, arguments): each line is measured in its OWN process
     ("c3_bf16", "bench.py", ["--config", "c3", "--conv-dtype", "bf16", "--no-drr", "--fp32-ref-only"]),
     ("c4_bf16", "bench.py", ["--config", "c4", "--conv-dtype", "bf16", "--no-drr", "--fp32-ref-only"]),
     ("native160_fp32", "bench.py", ["--config", "native160", "--no-drr", "--cpu-budget", "0"]),
-    ("train_c3_fp32", os.path.join("tools", "train_bench.py"), ["--config", "c3"]),
+    ("train_c3_fp32", os.path.join("tools", "train_bench.py"), ["--config", "c3", "--steps", "20", "--warmup", "5"]),
 )
 
 
