@@ -456,7 +456,7 @@ def main():
                 break
         # The W warm-up steps carry an event pair around every op: they name the step's live_op kernel.  In the K timed steps
         # ONLY that kernel is bracketed by HIP events (its live average duration is what `roofline` needs); an event pair costs
-        # ~4 us of stream time and twelve of them per step cost 1.0 % of the line (tools/kt_overhead.py: 832-837 against 824-825
+        # ~4 us of stream time and twelve of them per step cost 1.0 % of the line (measured in round 4: 832-837 against 824-825
         # reg/s).  The other kernels' table comes from 5 steps with every op bracketed, right after the timed region.
         with ops.kernel_timer() as kt_w:
             for _ in range(args.warmup):

@@ -120,7 +120,7 @@ def pca_bwd_coef(gdisp, basis_LxM, nblk=None):
     if B > 8:      # the kernel keeps 8 batch rows of accumulators per thread: larger batches go in chunks of 8
         return torch.cat([pca_bwd_coef(g2[i:i + 8], basis_LxM, nblk) for i in range(0, B, 8)], 0)
     if nblk is None:
-        nblk = max(1, min(256, M // 4096))   # one block per CU and l-group: 2.59 ms at C3 against 2.67 with 512, 2.82 with 1024 (tools/ab_pca_bwd.py)
+        nblk = max(1, min(256, M // 4096))   # one block per CU and l-group: 2.59 ms at C3 against 2.67 with 512, 2.82 with 1024 (NOTES_r03)
     partial = torch.empty((nblk, B, L), dtype=torch.float32, device=gdisp.device)
     gcoefs = torch.empty((B, L), dtype=torch.float32, device=gdisp.device)
     bf = basis_LxM.dtype == torch.bfloat16
