@@ -69,7 +69,7 @@ const char* lr_target_arch(void);
  *   LIFTREG_DRR_GENERAL            projector: the general kernel instead of the fast one (same bits)
  *   LIFTREG_REG_NOMARCH            displacement regulariser: the generic kernels instead of the marching ones
  *   LIFTREG_DGRAD_OLD              data gradient: the per-tile kernels instead of the persistent weights-in-LDS ones (tests cross-check both)
- *   LIFTREG_WGRAD_SPLIT            block 1's weight gradient on exact 3-way bf16 splits (opt-in)
+ *   LIFTREG_WGRAD_SPLIT=0          block 1's weight gradient on the fp32 MFMA (default since round 5: exact 3-way bf16 splits)
  *   LIFTREG_WGRAD_ROWS             weight gradient: bricks of 1 instead of 2 rows
  *   LIFTREG_WGRAD0_COPIES          bf16 training: first block's weight gradient through the three-copies kernel
  *   LIFTREG_CONV0_BLOCKS           persistent blocks of the fp32 first-block kernels

@@ -2143,12 +2143,12 @@ static int wgrad_impl(const float* x, int x_layout, const float* gpre, int gbf, 
 #undef LR_WB
         nparts = (int)grid;
       }
-    } else if (!gbf && !xbf && Cin == 16 && lr_sw_on(LR_SW_WGRAD_SPLIT) &&
+    } else if (!gbf && !xbf && Cin == 16 && lr_sw_int(LR_SW_WGRAD_SPLIT, 1) &&
                (int64_t)B * d.Do * d.Wo * ((d.Ho + 31) / 32) < 0x7fffffffLL) {
-      // LIFTREG_WGRAD_SPLIT=1, fp32 x and gradient, 16 input channels (block 1): exact bf16 splits on the bf16 MFMA
-      // (conv3d_wgrad_cl_split_kernel).  Alone it is 3.5 ms against the fp32-MFMA kernel's 4.35 at C3; in the training step most
-      // of that comes back as a slower neighbour (the step runs at the package power limit: DESIGN.md §6·7), 31.86 -> 31.59 ms
-      // in an interleaved A/B — so, like the forward's LIFTREG_CONV0_SPLIT, it is NOT the default.
+      // fp32 x and gradient, 16 input channels (block 1): exact bf16 splits on the bf16 MFMA (conv3d_wgrad_cl_split_kernel; at
+      // least as close to fp64 as the fp32-MFMA kernel: tests/test_gpu_round3.py).  Alone it is 3.5 ms against the fp32-MFMA
+      // kernel's 4.35 at C3; in the training step a third of that arrives (interleaved x 3, round 5: 28.13-28.62 against
+      // 28.43-28.77 ms) — the default since round 5; LIFTREG_WGRAD_SPLIT=0 selects the fp32-MFMA kernels.
       const int64_t nb32 = (int64_t)B * d.Do * d.Wo * ((d.Ho + 31) / 32);
       const unsigned grid = (unsigned)(nb32 < nblk ? nb32 : nblk);
       const bool hps = x_layout == LR_LAYOUT_NDHWC_HPS;

@@ -27,7 +27,7 @@ enum LrSwitch {
   LR_SW_DRR_GENERAL,   // LIFTREG_DRR_GENERAL: projector: the general kernel instead of the fast one (same bits)
   LR_SW_REG_NOMARCH,   // LIFTREG_REG_NOMARCH: displacement regulariser: the generic kernels instead of the marching ones
   LR_SW_DGRAD_OLD,   // LIFTREG_DGRAD_OLD: data gradient: the per-tile kernels instead of the persistent weights-in-LDS ones (tests cross-check both)
-  LR_SW_WGRAD_SPLIT,   // LIFTREG_WGRAD_SPLIT: block 1's weight gradient on exact 3-way bf16 splits (opt-in)
+  LR_SW_WGRAD_SPLIT,   // LIFTREG_WGRAD_SPLIT=0: block 1's weight gradient on the fp32 MFMA (default: exact 3-way bf16 splits)
   LR_SW_WGRAD_ROWS,   // LIFTREG_WGRAD_ROWS: weight gradient: bricks of 1 instead of 2 rows
   LR_SW_WGRAD0_COPIES,   // LIFTREG_WGRAD0_COPIES: bf16 training: first block's weight gradient through the three-copies kernel
   LR_SW_CONV0_BLOCKS,   // LIFTREG_CONV0_BLOCKS: persistent blocks of the fp32 first-block kernels

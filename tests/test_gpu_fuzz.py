@@ -524,14 +524,14 @@ def test_fuzz_round2_kernels(dev, monkeypatch):
         g_old, _, _ = ops_bwd.conv3d_bwd(y0, lay, w1, y1, ops.LAYOUT_NDHWC, gpre, ops.LAYOUT_NDHWC, 2, gy_is_gpre=True, mask_input_slope=0.2)
         monkeypatch.delenv("LIFTREG_DGRAD_OLD")
         assert torch.equal(g_old, g_act), ("weights-in-LDS data gradient vs per-tile kernel", case, D, W, H, Cout1, lay)
-        # the weight gradient's three kernels: fp32 MFMA with two-row bricks (default), with one-row bricks, and bf16-split
-        # operands on the bf16 MFMA (LIFTREG_WGRAD_SPLIT=1) — other summation orders, equal to rounding
-        monkeypatch.setenv("LIFTREG_WGRAD_SPLIT", "1")
+        # the weight gradient's three kernels: bf16-split operands on the bf16 MFMA (the default since round 5), fp32 MFMA with
+        # two-row bricks (LIFTREG_WGRAD_SPLIT=0) and with one-row bricks — other summation orders, equal to rounding
+        monkeypatch.setenv("LIFTREG_WGRAD_SPLIT", "0")
         _, gw_2, gb_2 = ops_bwd.conv3d_bwd(y0, lay, w1, y1, ops.LAYOUT_NDHWC, gpre, ops.LAYOUT_NDHWC, 2, gy_is_gpre=True, need_gx=False)
-        monkeypatch.delenv("LIFTREG_WGRAD_SPLIT")
         monkeypatch.setenv("LIFTREG_WGRAD_ROWS", "1")
         _, gw_1, gb_1 = ops_bwd.conv3d_bwd(y0, lay, w1, y1, ops.LAYOUT_NDHWC, gpre, ops.LAYOUT_NDHWC, 2, gy_is_gpre=True, need_gx=False)
         monkeypatch.delenv("LIFTREG_WGRAD_ROWS")
+        monkeypatch.delenv("LIFTREG_WGRAD_SPLIT")
         scale = float(gw_1.abs().max()) + 1e-20
         bscale = float(gb_1.abs().max()) + 1e-20
         for gw_v, gb_v in ((gw_a, gb_a), (gw_2, gb_2)):

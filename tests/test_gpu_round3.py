@@ -298,7 +298,7 @@ def test_bf16_training_sign_mask_of_first_block_gives_the_same_gradients(grad_dt
 
 def test_wgrad_split_operands_accuracy(monkeypatch):
     """Block 1's fp32 weight gradient on the bf16 MFMA with exact three-way bf16 splits of both operands
-    (conv3d_wgrad_cl_split_kernel, LIFTREG_WGRAD_SPLIT=1, 6 of the 9 partial products): against an fp64 reference it is at
+    (conv3d_wgrad_cl_split_kernel, the default; LIFTREG_WGRAD_SPLIT=0 = the fp32-MFMA kernel; 6 of the 9 partial products): against an fp64 reference it is at
     least as accurate as the default fp32-MFMA kernel, for plain and parity-split x, ragged row ends and
     both output widths."""
     from liftreg_amd import ops, ops_bwd
@@ -330,10 +330,10 @@ def test_wgrad_split_operands_accuracy(monkeypatch):
             _, gw, gb = ops_bwd.conv3d_bwd(xd, lay, w, y, ops.LAYOUT_NDHWC, gd, ops.LAYOUT_NDHWC, 2, gy_is_gpre=True, need_gx=False, nblk=16)
             return gw.cpu().numpy().astype(np.float64), gb.cpu().numpy().astype(np.float64)
 
+        monkeypatch.setenv("LIFTREG_WGRAD_SPLIT", "0")
         gw_f, gb_f = run()
-        monkeypatch.setenv("LIFTREG_WGRAD_SPLIT", "1")
-        gw_s, gb_s = run()
         monkeypatch.delenv("LIFTREG_WGRAD_SPLIT")
+        gw_s, gb_s = run()          # (the default since round 5)
         scale = np.abs(want).max()
         es, ef = np.abs(gw_s - want).max() / scale, np.abs(gw_f - want).max() / scale
         assert es <= 3e-6 and es <= 1.5 * ef + 2e-7, (cout, shape, es, ef)
