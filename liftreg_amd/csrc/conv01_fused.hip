@@ -293,7 +293,7 @@ template <int NC, bool DENSE> constexpr int block0_fragments() { if constexpr (D
 #ifndef LR_C01_DENSE_AHEAD
 #define LR_C01_DENSE_AHEAD 12
 #endif
-constexpr int DENSE_PRE = 6, DENSE_AHEAD = LR_C01_DENSE_AHEAD;
+constexpr int DENSE_PRE = 9, DENSE_AHEAD = LR_C01_DENSE_AHEAD;   // (9: every fragment the first tile's first nine MFMAs open; 6: +0.7 %, 4: +0.5 %)
 #ifndef LR_C01_LOAD_PERIOD
 #define LR_C01_LOAD_PERIOD 4   // fragment loads only behind every PERIOD-th MFMA slot, up to LR_C01_LOAD_BURST fragments there (one per slot: +1 %)
 #endif
@@ -859,7 +859,7 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
               else if constexpr (set == 1) dload(std::integral_constant<int, n>{}, bP1, fb);
               else dload(std::integral_constant<int, n>{}, bS, fs);
             });
-            if constexpr (PA0 > 0 && g >= 5 * NMF - DENSE_PRE) dload(std::integral_constant<int, g - (5 * NMF - DENSE_PRE)>{}, bN, fa);
+            if constexpr (PA0 > 0 && g >= 5 * NMF - DENSE_PRE) dload(std::integral_constant<int, g - (5 * NMF - DENSE_PRE)>{}, bN, fa);   // (two bursts instead: the same)
             // the WHOLE epilogue of the tile before in ONE gap, the one in front of the next chain's first MFMA (seven gaps with four or
             // five vector instructions each: +3 %; two instructions in every gap: +32 %; one gap in the middle of the chain: +1.5 % —
             // an MFMA that follows its chain's predecessor directly is the cheap case)
