@@ -286,10 +286,11 @@ template <> struct Chain<5> {   // load kinds: 0 A1, 1 A4, 2 A3, 3 A2 (arrays 0,
   static constexpr int EPI_AT = NMF - 1;
 };
 template <int NC, bool DENSE> constexpr int block0_fragments() { if constexpr (DENSE) return Chain<NC>::NMF; else return 12; }
-// MFMA slot g = NMF t + k of a step (tiles t = 0..4: pair 0 upper / lower, pair 1 upper / lower, the single tile) issues at most one
-// fragment load: the next one (sets 0, 1 = the pairs, 2 = the single tile, in the order above) whose first use is <= DENSE_AHEAD
-// slots away (LDS latency under load; lgkmcnt counts 15 operations = 7 fragments in flight).  The first DENSE_PRE fragments of the
-// step are requested in front (ahead of the barrier when ring 0 is staged a step early).
+// Fragment loads of a step (MFMA slot g = NMF t + k; tiles t = 0..4: pair 0 upper / lower, pair 1 upper / lower, the single
+// tile): behind every LR_C01_LOAD_PERIOD-th slot a burst of up to LR_C01_LOAD_BURST fragments — the next ones (sets 0, 1 = the
+// pairs, 2 = the single tile, in the order above) whose first use is <= DENSE_AHEAD slots away (lgkmcnt counts 15 operations;
+// more simply wait).  The first DENSE_PRE fragments of the step are requested in front (ahead of the barrier when ring 0 is
+// staged a step early).  Bursts, because a gap between two MFMAs of a chain that holds anything costs a toll (NOTES_r05 §6).
 #ifndef LR_C01_DENSE_AHEAD
 #define LR_C01_DENSE_AHEAD 12
 #endif
@@ -649,7 +650,8 @@ __global__ LR_C01_VGPR_CAP __launch_bounds__(NTHR) LR_C01_NO_DS_MERGE void conv0
         const bf16x8& f = kb == 3 ? q.G[fs] : q.F[kb][fs];
         if (a_mma_g) a.v[kb & 1] = MFMA(wr[kb * 3 + wt], f, a.v[kb & 1]);
       };
-      // the epilogue of one block-0 tile in 7 slices: LeakyReLU, the two three-way splits, the three stores into ring 1
+      // the epilogue of one block-0 tile in 7 slices (the dense path runs all seven in one MFMA gap): LeakyReLU, the two three-way
+      // splits, the three stores into ring 1
       struct Epi { f32x4 x, y; f32x2 r; u32x2 s0, s1, s2; };   // s_k = the 8-byte record of split k: (channels 01 | channels 23)
       struct L0 { unsigned p; f32x2 r; };
       struct L12 { unsigned p1, p2; };
