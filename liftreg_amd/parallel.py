@@ -254,7 +254,8 @@ class SlabShardedRegistration:
 
     Per rank: rows [d0,d1) of the feature volume, of every encoder activation (halved per stride-2 block),
     of the displacement field, phi and the warped image.  Replicated: the moving volume and the 2-D views
-    (small), the FC head.  Exchanged: one activation plane per stride-2 block from the rank below (halo),
+    (small), the FC head.  Exchanged: one activation plane per stride-2 block from block 2 on from the rank below (halo; blocks 0
+    and 1 recompute theirs from the replicated inputs),
     the 32·(n/32)³ encoder features (all-gather), five NCC moments per sample (all-reduce).
     Needs D % (m·world) == 0, m = the product of the strides of the blocks that run on slabs (`slab_multiple`: 8 at 256³).
     """
@@ -334,7 +335,7 @@ class SlabShardedRegistration:
         act_dt = torch.bfloat16 if bf16 else torch.float32
         o = lambda n: (n - 1) // 2 + 1
         B = inputs[0]["source"].shape[0]
-        ngroups = 2 if (B >= 2 and comm.world > 1) else 1
+        ngroups = 2 if (B >= 2 and comm.world > 1 and not getattr(self, "halo_free01", True)) else 1   # (two groups only to hide the exchange)
         gb = [(g * B // ngroups, (g + 1) * B // ngroups) for g in range(ngroups)]
         c0, c1 = net.encoders[0].conv.out_channels, net.encoders[1].conv.out_channels
         # fp32, <= 4 views: blocks 0 and 1 as the ONE fused kernel of the unsharded model (csrc/conv01_fused.hip) on the rank's
@@ -391,44 +392,57 @@ class SlabShardedRegistration:
                                   out_layout=layouts(1)[1], slope0=b0_._slope, slope1=b1_._slope, packed=net._packed_pair01(),
                                   out=t["nb"][:, 2:2 + rows1], slab=(D, lo2, d0 // 2, rows1))
                 del tv
+        def block0(inp, g0, g1, lo, hi, out):
+            """Block 0 of samples g0..g1 on input planes [lo, hi) (its own zero padding at both ends) into `out` (g1-g0, hi-lo, W, H, c0):
+            the kernels, and bits, of the unsharded model's first block."""
+            moving, proj = inp["source"], inp["target_proj"]
+            blk = net.encoders[0]
+            if (bf16 and P >= getattr(net, "ENCIN_MIN_VIEWS", 99) and c0 == 16 and ops.encoder_input_bf16_supported(moving, proj)):
+                # many views (C4): the slab's encoder input as bf16 channels-last records straight from the views and the
+                # replicated moving volume
+                mvg = moving[g0:g1] if moving[g0:g1].is_contiguous() else moving[g0:g1].contiguous()
+                e = ops.backproject_encoder_input_bf16(mvg, proj[g0:g1].contiguous(), net._poses, d0=lo, d1=hi)
+                ops.conv3d_first_clin_bf16(e, blk.conv.weight, blk.conv.bias, out_layout=layouts(0)[1], negative_slope=blk._slope,
+                                           packed=net._packed_weight(0, bf16=True), out=out)
+                return
+            mvs = moving[g0:g1, :, lo:hi]                      # a z-slab view of the replicated moving volume
+            if not bf16:
+                tv = torch.empty((g1 - g0, P, hi - lo, W, H), dtype=torch.float32, device=moving.device)
+                if ops.conv3d_first_split_supported(mvs, tv):
+                    # fp32, <= 2 views: the first block reads the moving slab in place (no copy, no concatenation)
+                    ops.backproject(proj[g0:g1].contiguous(), net._poses, (D, W, H), d0=lo, d1=hi, out=tv)
+                    ops.conv3d_first_split(mvs, tv, blk.conv.weight, blk.conv.bias, out_layout=layouts(0)[1], negative_slope=blk._slope,
+                                           packed=net._packed_weight(0), out=out)
+                    return
+                del tv
+            x = torch.empty((g1 - g0, P + 1, hi - lo, W, H), dtype=torch.float32, device=moving.device)
+            x[:, 0:1].copy_(mvs)
+            ops.backproject(proj[g0:g1].contiguous(), net._poses, (D, W, H), d0=lo, d1=hi, out=x[:, 1:],
+                            out_batch_stride=(P + 1) * (hi - lo) * W * H)
+            conv(0, x, out)
+
+        # Blocks 0 and 1 exchange NOTHING: block 1's halo plane (block 0's output plane d0 - 1) is recomputed here from input
+        # planes d0 - 2 .. d0 of the replicated moving volume and the rank's own backprojection — three planes of block 0
+        # instead of one point-to-point transfer per group (round 4 did this for the fused fp32 pair kernel only;
+        # `halo_free01 = False` keeps the exchange of the rank below's top plane: A/B aid).
+        halo_free = bool(getattr(self, "halo_free01", True))
         pend = []
-        for g0, g1 in (() if pair else gb):         # ---- block 0 of every group, its halo posted at once
+        for g0, g1 in (() if pair else gb):         # ---- block 0 of every group (exchange form: its halo posted at once)
             tops = []
             for inp, (d0, d1), t in zip(inputs, bounds, st):
-                moving, proj = inp["source"], inp["target_proj"]
                 lo, hi, n_real = t["lo"], t["hi"], t["hi"] - t["lo"]
-                if (bf16 and P >= getattr(net, "ENCIN_MIN_VIEWS", 99) and c0 == 16 and
-                        ops.encoder_input_bf16_supported(moving, proj)):
-                    # many views (C4): the slab's encoder input as bf16 channels-last records straight from the views and the
-                    # replicated moving volume — the same kernels, and bits, as the unsharded model's first block
-                    mvg = moving[g0:g1] if moving[g0:g1].is_contiguous() else moving[g0:g1].contiguous()
-                    e = ops.backproject_encoder_input_bf16(mvg, proj[g0:g1].contiguous(), net._poses, d0=lo, d1=hi)
-                    blk = net.encoders[0]
-                    ops.conv3d_first_clin_bf16(e, blk.conv.weight, blk.conv.bias, out_layout=layouts(0)[1], negative_slope=blk._slope,
-                                               packed=net._packed_weight(0, bf16=True), out=t["y0"][g0:g1, t["a0"]:t["a0"] + n_real])
-                    tops.append(t["y0"][g0:g1, t["r"]:t["r"] + 1])
-                    continue
-                mvs = moving[g0:g1, :, lo:hi]                      # a z-slab view of the replicated moving volume
-                blk = net.encoders[0]
-                if not bf16:
-                    tv = torch.empty((g1 - g0, P, n_real, W, H), dtype=torch.float32, device=moving.device)
-                    if ops.conv3d_first_split_supported(mvs, tv):
-                        # fp32, <= 2 views: the first block reads the moving slab in place (no copy, no concatenation) —
-                        # the same kernel, and bits, as the unsharded model's first block
-                        ops.backproject(proj[g0:g1].contiguous(), net._poses, (D, W, H), d0=lo, d1=hi, out=tv)
-                        ops.conv3d_first_split(mvs, tv, blk.conv.weight, blk.conv.bias, out_layout=layouts(0)[1], negative_slope=blk._slope,
-                                               packed=net._packed_weight(0), out=t["y0"][g0:g1, t["a0"]:t["a0"] + n_real])
-                        tops.append(t["y0"][g0:g1, t["r"]:t["r"] + 1])
-                        continue
-                    del tv
-                x = torch.empty((g1 - g0, P + 1, n_real, W, H), dtype=torch.float32, device=moving.device)
-                x[:, 0:1].copy_(mvs)
-                ops.backproject(proj[g0:g1].contiguous(), net._poses, (D, W, H), d0=lo, d1=hi, out=x[:, 1:],
-                                out_batch_stride=(P + 1) * n_real * W * H)
-                conv(0, x, t["y0"][g0:g1, t["a0"]:t["a0"] + n_real])
-                tops.append(t["y0"][g0:g1, t["r"]:t["r"] + 1])       # the slab's top plane (d1 - 1) -> the rank above
-            pend.append(comm.shift_up_start(tops))
-        for (g0, g1), h in zip(() if pair else gb, pend):   # ---- block 1 of every group, behind its halo
+                block0(inp, g0, g1, lo, hi, t["y0"][g0:g1, t["a0"]:t["a0"] + n_real])
+                if halo_free:
+                    if d0 > 0:
+                        h3 = torch.empty((g1 - g0, 3, W, H, c0), dtype=act_dt, device=t["y0"].device)
+                        block0(inp, g0, g1, d0 - 2, d0 + 1, h3)
+                        tops.append(h3[:, 1:2])
+                    else:
+                        tops.append(None)
+                else:
+                    tops.append(t["y0"][g0:g1, t["r"]:t["r"] + 1])       # the slab's top plane (d1 - 1) -> the rank above
+            pend.append(_Done(tops) if halo_free else comm.shift_up_start(tops))
+        for (g0, g1), h in zip(() if pair else gb, pend):   # ---- block 1 of every group, behind its halo plane
             halos = h.wait()
             for (d0, _), t, hl in zip(bounds, st, halos):
                 if hl is None:

@@ -14,7 +14,10 @@ pytestmark = pytest.mark.gpu
                                                 # = the gather depth, the pair kernel's front step runs on 7 of the 8 ranks
                                                 (256, 8, "fp32"), (256, 8, "bf16"), (384, 8, "bf16-c5"),
                                                 # four views (the reference's shipped drr_feature_num): the five-channel pair kernel on slabs
-                                                (160, 2, "fp32-p4"), (128, 4, "fp32-p4")])
+                                                (160, 2, "fp32-p4"), (128, 4, "fp32-p4"),
+                                                # six views in fp32: the general first block (no pair kernel), its halo plane recomputed;
+                                                # and the exchange form of blocks 0 / 1 (`halo_free01 = False`)
+                                                (64, 2, "fp32-p6"), (128, 4, "bf16-exchange"), (64, 2, "fp32-p6-exchange")])
 def test_slab_sharded_forward_equals_unsharded(n, world, conv_dtype):
     from liftreg_amd import parallel as par
     from liftreg_amd.layers.losses import NCCLoss
@@ -25,6 +28,10 @@ def test_slab_sharded_forward_equals_unsharded(n, world, conv_dtype):
     g = torch.Generator(device=dev)
     g.manual_seed(3)
     P, L, B, R = 2, 12, 2, n
+    exchange = conv_dtype.endswith("-exchange")
+    conv_dtype = conv_dtype[:-len("-exchange")] if exchange else conv_dtype
+    if conv_dtype == "fp32-p6":
+        conv_dtype, P = "fp32", 6
     if conv_dtype == "bf16":
         P = 11      # C4: 11-view limited-angle DRR, bf16 convs, 4-way z-slab sharding (bf16 halo planes on the wire)
     if conv_dtype == "fp32-p4":
@@ -42,6 +49,8 @@ def test_slab_sharded_forward_equals_unsharded(n, world, conv_dtype):
         ref = net(inp)
         ref_loss = NCCLoss()(ref["warped"], ref["target"])
         sharded = par.SlabShardedRegistration(net, par.LocalComm(world))
+        if exchange:
+            sharded.halo_free01 = False
         outs = sharded.forward([inp] * world)
     assert len(outs) == world
     for r, out in enumerate(outs):
