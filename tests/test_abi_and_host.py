@@ -177,3 +177,17 @@ def test_save_deformations_writes_npy_and_nifti(tmp_path):
         # Fortran order: the FIRST array index is the fastest on disk
         first = np.frombuffer(raw, np.float32, count=3, offset=352)
         assert np.array_equal(first, want[:, 0, 0, 0])
+
+
+def test_every_run_time_switch_is_documented_in_the_header():
+    """The LIFTREG_* environment switches the library reads (csrc/misc.hip's table, one entry per LR_SW_* id of lr_common.h) are
+    exactly the ones include/liftreg_hip.h documents — an integrator reads the header, not the source."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "liftreg_hip.h")).read()
+    table = open(os.path.join(root, "liftreg_amd", "csrc", "misc.hip")).read()
+    ids = open(os.path.join(root, "liftreg_amd", "csrc", "lr_common.h")).read()
+    documented = set(re.findall(r"LIFTREG_[A-Z0-9_]*[A-Z0-9]", header)) - {"LIFTREG_HIP_H"}
+    read = set(re.findall(r'"(LIFTREG_[A-Z0-9_]+)"', table))
+    assert read and documented == read, (sorted(documented - read), sorted(read - documented))
+    assert len(re.findall(r"^\s*LR_SW_[A-Z0-9_]+,", ids, flags=re.M)) == len(read)
