@@ -338,8 +338,8 @@ class model(nn.Module):
         return coefs, disp
 
     def backproject_views(self, target_proj, poses, img_shape, out=None):
-        """target_volume (:89-93) alone: the (B,P,D,W,H) backprojection of the views.  A pipeline computes it for batch
-        i+1 while batch i's MFMA-bound blocks run (liftreg_amd/pipeline.py) and hands it to encode(target_volume=…)."""
+        """target_volume (:89-93) alone: the (B,P,D,W,H) backprojection of the views, for a caller that hands it to
+        encode(target_volume=…)."""
         if self._poses is None:
             p = poses.detach().cpu().numpy() if isinstance(poses, torch.Tensor) else np.asarray(poses)
             self._poses = np.ascontiguousarray(p[0], dtype=np.float32)  # poses[0:1] (:87)
