@@ -106,3 +106,23 @@ def test_dense_convolution_sum_equals_the_six_product_sum():
     exact = float(np.sum(w.astype(np.float64) * x.astype(np.float64)))
     assert abs(dense - plain) <= 1e-15 * max(1.0, abs(plain))
     assert abs(dense - exact) <= 81 * 2.0 ** -22 * float(np.sum(np.abs(w.astype(np.float64) * x)))
+
+
+def test_staged_quads_cover_what_a_column_reads_and_half_quads_never_straddle_a_row():
+    """Ring 0 of a column of 4 x 8 block-1 outputs (TX = 8): record p of a row = volume x - (2 ox0 - 4).  Block 0's region needs
+    x = 2 ox0 - 2 .. 2 ox0 + 16 = records 2 .. 20; the staging fetches FIVE quads from record 2 on (records 2 .. 21) as 8-byte
+    halves.  For every column and every H the launcher accepts (H % 4 == 0) a half is wholly inside or wholly outside the row, so
+    one bounds flag per half is the convolution's zero padding."""
+    QS0, NQS = 2, 5
+    for H in (4, 8, 12, 16, 24, 32, 100, 160, 256):
+        for ox0 in range(0, (H // 2 + 7) // 8 * 8, 8):
+            X0a = 2 * ox0 - 4
+            need = {rx + tx + 2 for rx in range(17) for tx in range(3)}            # region voxel rx, tap tx -> record
+            staged = {QS0 + 4 * iq + e for iq in range(NQS) for e in range(4)}
+            assert need <= staged and min(need) == 2 and max(need) == 20
+            for iq in range(NQS):
+                xi = X0a + QS0 + 4 * iq
+                assert xi % 2 == 0                                               # 8-byte aligned halves (rows are 16-byte aligned)
+                for half in (xi, xi + 2):
+                    inside = [0 <= half + e < H for e in range(2)]
+                    assert inside[0] == inside[1], (H, ox0, iq, half)
