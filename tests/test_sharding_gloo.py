@@ -205,6 +205,13 @@ def _worker(rank, world_size, port, q):
         np.testing.assert_allclose(out["warped"].numpy(), ref["warped"][:, :, s0:s1].numpy(), rtol=1e-4, atol=1e-5)
         want_loss = ro.ncc_loss(ref["warped"], ref["target"])
         assert abs(float(out["sim_loss"]) - float(want_loss)) < 1e-5
+        # the exchange form of blocks 0 / 1 (the rank below's top plane over isend / irecv instead of the recomputed halo plane)
+        with torch.no_grad():
+            sh = par.SlabShardedRegistration(net, par.DistComm())
+            sh.halo_free01 = False
+            out2 = sh.forward([inp])[0]
+        for k in ("pca_coefs", "params", "warped"):
+            assert torch.equal(out2[k], out[k]), k
         q.put((rank, "ok"))
     except Exception as e:  # surface the failure in the parent
         import traceback
