@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--views", type=int, default=2)
     ap.add_argument("--conv-dtype", default="fp32")
-    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--max-overhead", type=float, default=None, help="exit non-zero when sum_of_slabs / unsharded - 1 exceeds this")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
