@@ -242,39 +242,181 @@ def cpu_baseline(cfg, net, inp, budget_s=30.0):
                       f"torch {torch.__version__} CPU ops, median of runs after the first; s/reg={best:.3f}"}, out
 
 
+
+FULL_PREFIX = "#full "      # verbose records travel on their OWN earlier stdout lines, never inside the final line
+LINE_BUDGET = 4096          # bytes: the driver keeps an 8 KB tail of stdout; the final JSON line must fit in half of it
+
+
+def _r(x, sig=5):
+    """Numbers at `sig` significant digits (the final line is a summary; the full-precision record is the #full line)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (str, int)):
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}") if np.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def _roof_short(r):
+    """The contract's roofline object: numbers + one short note; prose lives in DESIGN.md §6."""
+    if not r:
+        return r
+    keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_ms", "sclk_mhz", "frac_at_sclk",
+            "useful_mfma_share", "frac_bf16_issued", "frac_fp32_mfma", "traffic_over_compulsory", "frac_mfma_issued")
+    o = {k: r[k] for k in keep if r.get(k) is not None or k == "traffic"}
+    if "frac_bf16_issued" in r:
+        o["note"] = "fp32 conv as exact 3-way bf16 splits: peak = dense bf16 MFMA / 6 (DESIGN.md 6)"
+    elif "frac_mfma_issued" in r:
+        o["note"] = "algorithmic flops of the direct conv; fp32 Winograd kernel"
+    return o
+
+
+def _extra_short(name, d):
+    """One child line reduced to what the judge reads: value, ms/step, steps, dominant kernel + frac, parity numbers."""
+    if "error" in d:
+        return {"error": str(d["error"])[:120]}
+    o = {"value": d.get("value"), "unit": d.get("unit"), "ms_per_step": d.get("ms_per_step", d.get("ms_per_train_step")),
+         "steps": d.get("steps"), "wall_s": d.get("wall_s")}
+    cfg = d.get("config")
+    if isinstance(cfg, dict):
+        o["batch"] = cfg.get("global_batch")
+    elif d.get("global_batch") is not None:
+        o["batch"] = d.get("global_batch")
+    r = d.get("roofline")
+    if r:
+        o["kernel"] = {"name": r.get("kernel"), "ms": r.get("avg_ms"), "frac": r.get("frac"), "bound": r.get("bound")}
+    rb = d.get("roofline_backproject")
+    if rb:
+        o["backproject"] = {"ms": rb.get("avg_ms"), "frac": rb.get("frac")}
+    ks = d.get("kernels")
+    if isinstance(ks, list) and ks:          # tools/train_bench.py: rows sorted by time; the top two
+        o["kernels"] = [{"name": k.get("kernel"), "ms": k.get("ms"), **({"TFLOPs": k["TFLOP/s"]} if "TFLOP/s" in k else {"GBps": k.get("GB/s")})}
+                        for k in ks[:2]]
+    for key, want in (("vs_fp32_reference", ("max_abs_disp", "max_rel_disp", "max_rel_coefs")),
+                      ("parity_vs_cpu", ("max_abs_disp", "max_rel_coefs", "ncc_abs"))):
+        if isinstance(d.get(key), dict):
+            o[key] = {k: d[key].get(k) for k in want}
+    if d.get("peak_mem_GB") is not None:
+        o["peak_mem_GB"] = d["peak_mem_GB"]
+    if isinstance(d.get("cpu_baseline"), dict):
+        o["cpu_per_s"] = d["cpu_baseline"].get("value")
+    return o
+
+
+def compact_line(full):
+    """The ONE final JSON line (<= LINE_BUDGET bytes): the contract's keys with numbers at 5 significant digits, `roofline` /
+    `roofline_backproject` / `cpu_baseline` / `parity_vs_cpu` as numbers + short notes, `extra_lines` reduced per child to
+    {value, ms_per_step, steps, dominant kernel, frac, parity}.  Everything else is on the `#full` lines above it.  Should the
+    line still be over budget, the least important keys go first — the contract's own keys are never dropped."""
+    cfg = full.get("config") or {}
+    o = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                  "scaling", "vs_baseline")}
+    o["dtype"] = str(full.get("dtype", "")).split(";")[0][:80]
+    o["data"] = full.get("data")
+    if full.get("dry_run"):
+        o["dry_run"] = True
+    o["config"] = {"workload": str(cfg.get("workload", ""))[:160], "global_batch": cfg.get("global_batch"),
+                   "parallelism": str(cfg.get("parallelism", "")).split(" (")[0].split(":")[0][:60]}
+    o["roofline"] = _roof_short(full.get("roofline"))
+    o["roofline_backproject"] = _roof_short(full.get("roofline_backproject"))
+    cb = full.get("cpu_baseline")
+    o["cpu_baseline"] = ({"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                          "sample": str(cb.get("sample", ""))[:110]} if isinstance(cb, dict) else None)
+    pv = full.get("parity_vs_cpu")
+    if isinstance(pv, dict):
+        o["parity_vs_cpu"] = {k: pv.get(k) for k in ("max_abs_disp", "max_abs_phi", "max_rel_coefs", "max_abs_warped", "ncc_abs")}
+    if isinstance(full.get("vs_fp32_reference"), dict):
+        o["vs_fp32_reference"] = {k: full["vs_fp32_reference"].get(k) for k in ("max_abs_disp", "max_rel_disp", "max_rel_coefs")}
+    for k in ("ramp_seconds", "ramp_steps"):
+        if k in full:
+            o[k] = full[k]
+    o["backproj_hbm_GBps"] = full.get("backproj_hbm_GBps")
+    o["ncc_loss"] = full.get("ncc_loss")
+    d = full.get("drr_forward")
+    if isinstance(d, dict):
+        rd = full.get("roofline_drr") or {}
+        o["drr_forward"] = {"kernel_ms_per_volume": d.get("kernel_ms_per_volume"), "volumes_per_s": d.get("volumes_per_s"),
+                            "simulate_plus_register_per_s": d.get("simulate_plus_register_per_s"),
+                            "valu_issue_frac": rd.get("frac"), "hbm_frac": rd.get("hbm_frac")}
+    ds = full.get("drr_forward_sharded")
+    if isinstance(ds, dict):
+        o["drr_forward_sharded"] = {k: ds.get(k) for k in ("volumes_per_s", "ms_per_batch", "allreduce_bytes", "max_rel_vs_unsharded")}
+    ks = full.get("kernels")
+    if isinstance(ks, dict):                 # ms per launch of the step's kernels, by time
+        top = sorted(ks.items(), key=lambda kv: -(kv[1].get("ms") or 0) * (kv[1].get("n") or 1))[:4]
+        o["kernels_ms"] = {k: v.get("ms") for k, v in top}
+    ex = full.get("extra_lines")
+    if isinstance(ex, dict):
+        o["extra_lines"] = {k: _extra_short(k, v) for k, v in ex.items()}
+    o["full_record"] = "#full lines above"
+    o = _r(o)
+    drop_order = ("full_record", "kernels_ms", "ncc_loss", "drr_forward_sharded", "drr_forward")
+    line = json.dumps(o, separators=(",", ":"))
+    for k in drop_order:
+        if len(line) <= LINE_BUDGET:
+            break
+        o.pop(k, None)
+        line = json.dumps(o, separators=(",", ":"))
+    if len(line) > LINE_BUDGET and isinstance(o.get("extra_lines"), dict):
+        for v in o["extra_lines"].values():   # then the children's secondary records
+            for k in ("kernels", "backproject", "peak_mem_GB", "wall_s", "cpu_per_s"):
+                v.pop(k, None)
+        line = json.dumps(o, separators=(",", ":"))
+    assert len(line) <= LINE_BUDGET, f"final line {len(line)} bytes > {LINE_BUDGET}"
+    return line
+
+
+def emit(full, name="headline"):
+    """Rank 0's output: the verbose record on a `#full` line, then the compact final line (stdout, flushed in that order)."""
+    ex = full.get("extra_lines") or {}
+    print(FULL_PREFIX + json.dumps({"name": name, **{k: v for k, v in full.items() if k != "extra_lines"}}), flush=True)
+    for k, v in ex.items():
+        print(FULL_PREFIX + json.dumps({"name": k, **v}), flush=True)
+    print(compact_line(full), flush=True)
+
+
 EXTRA = (  # (name, script, arguments): each line is measured in its OWN process, after the headline's timed region
     ("c3_bf16", "bench.py", ["--config", "c3", "--conv-dtype", "bf16", "--no-drr", "--fp32-ref-only"]),
     ("c4_bf16", "bench.py", ["--config", "c4", "--conv-dtype", "bf16", "--no-drr", "--fp32-ref-only"]),
     ("native160_fp32", "bench.py", ["--config", "native160", "--no-drr", "--cpu-budget", "0"]),
-    ("train_c3_fp32", os.path.join("tools", "train_bench.py"), ["--config", "c3", "--steps", "20", "--warmup", "5"]),
+    ("train_c3_fp32", os.path.join("tools", "train_bench.py"), ["--config", "c3"]),
+    ("train_native160_fp32", os.path.join("tools", "train_bench.py"), ["--config", "native160"]),
+    ("train_c5_bf16", os.path.join("tools", "train_bench.py"),
+     ["--config", "c5", "--conv-dtype", "bf16", "--grad-dtype", "bf16", "--vs-fp32"]),
 )
 
 
-def extra_lines(timeout_s=170):
-    """The lines the driver would otherwise never see: every entry is the JSON line of a child process —
-    its own inputs, clock ramp, warm-up, timed steps, ms_per_step and dominant-kernel roofline — plus `wall_s`, the child's
-    whole run by this process's clock.  A child is an ordinary `python bench.py …` (or tools/train_bench.py) started AFTER the
-    headline is measured; nothing here touches the headline's numbers."""
+def extra_lines(steps, warmup, timeout_s=170, only=None):
+    """The lines the driver would otherwise never see: every entry is the record of a child process — its own inputs, clock
+    ramp, warm-up, timed steps, ms_per_step and dominant-kernel roofline — plus `wall_s`, the child's whole run by this
+    process's clock.  A child is an ordinary `python bench.py …` (or tools/train_bench.py) started AFTER the headline is
+    measured, with the parent's --steps / --warmup; nothing here touches the headline's numbers.  The full child records go to
+    `#full` stdout lines; the final line carries `_extra_short` of each."""
     import subprocess
     out = {}
-    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "ms_per_train_step", "dtype", "config", "roofline",
-            "roofline_backproject", "kernels", "vs_fp32_reference", "parity_vs_cpu", "cpu_baseline", "ncc_loss", "conv_dtype",
-            "grad_dtype", "global_batch", "losses", "peak_mem_GB", "samples_per_s")
     for name, script, argv in EXTRA:
+        if only is not None and name not in only:
+            continue
         t0 = time.perf_counter()
         try:
-            cmd = [sys.executable, os.path.join(ROOT, script)] + (["--extra-lines", "off"] if script == "bench.py" else []) + argv
+            cmd = [sys.executable, os.path.join(ROOT, script)] + (["--extra-lines", "off"] if script == "bench.py" else []) + argv + \
+                  ["--steps", str(steps), "--warmup", str(warmup)]
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
-            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if script == "bench.py":
+                lines = [ln[len(FULL_PREFIX):] for ln in r.stdout.splitlines() if ln.startswith(FULL_PREFIX)]
+            else:
+                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not lines:
                 out[name] = {"error": f"rc {r.returncode}: {r.stderr[-300:]}"}
             elif script == "bench.py":
-                d = json.loads(lines[-1])
-                out[name] = {k: d[k] for k in keep if k in d}
+                out[name] = json.loads(lines[0])
+                out[name].pop("name", None)
             else:   # tools/train_bench.py: the summary line, then one line per kernel
-                d = json.loads(lines[0])
-                out[name] = {k: d[k] for k in keep if k in d}
-                out[name]["ms_per_step"] = d.get("ms_per_train_step")
+                out[name] = json.loads(lines[0])
+                out[name]["ms_per_step"] = out[name].get("ms_per_train_step")
                 out[name]["kernels"] = [json.loads(ln) for ln in lines[1:]]
         except subprocess.TimeoutExpired:
             out[name] = {"error": f"timeout after {timeout_s} s"}
@@ -307,12 +449,17 @@ def dry_run(args, rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     if rank == 0:
-        print(json.dumps({"metric": "registrations/sec (256^3 CT, 2-view DRR)", "value": None, "unit": "registrations/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                          "higher_is_better": True, "scaling": "strong" if args.shard == "slab" else "weak",
-                          "vs_baseline": None, "dtype": "none", "data": "none", "dry_run": True,
-                          "config": {"workload": "control-path self-test: no GPU work, a sleep as the step",
-                                     "parallelism": f"{args.shard} x{world}"}}))
+        rec = {"metric": "registrations/sec (256^3 CT, 2-view DRR)", "value": None, "unit": "registrations/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "strong" if args.shard == "slab" else "weak",
+               "vs_baseline": None, "dtype": "none", "data": "none", "dry_run": True,
+               "config": {"workload": "control-path self-test: no GPU work, a sleep as the step",
+                          "parallelism": f"{args.shard} x{world}"}}
+        if args.stub_full:     # (CPU test hook) a recorded full line stands in for the measurement: exercises emit()'s size budget
+            with open(args.stub_full) as fh:
+                stub = json.load(fh)
+            rec = {**stub, **{k: rec[k] for k in ("n_gpus", "steps", "warmup", "ms_per_step", "dry_run")}}
+        emit(rec, name="dry_run")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -341,6 +488,8 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="control-path self-test WITHOUT a GPU (CPU tests): rendezvous over gloo, fences, max-over-ranks "
                          "timing and the single JSON line with a sleep as the step; the line says dry_run and carries no value")
+    ap.add_argument("--stub-full", default=None, help="(with --dry-run) a JSON file holding a full record to emit (test hook)")
+    ap.add_argument("--only-extra", action="append", default=None, help="restrict --extra-lines to the named children")
     ap.add_argument("--fuse-bp", action="store_true", help="A/B aid: backprojection computed inside block 0 (opt key "
                                                            "fuse_backproject; measured slower at C3, off by default)")
     ap.add_argument("--fuse-ncc", action="store_true", help="A/B aid: the similarity's moments in the decode's epilogue (opt key "
@@ -352,8 +501,9 @@ def main():
     ap.add_argument("--no-pair01", action="store_true",
                     help="A/B aid (fp32 lines): encoder blocks 0 and 1 as two fp32-MFMA kernels (the round-3 path) instead of the "
                          "fused split-operand pair kernel csrc/conv01_fused.hip (model opt key fuse_pair01)")
-    ap.add_argument("--cpu-budget", type=float, default=30.0,
-                    help="seconds of CPU-oracle forwards the cpu_baseline leg may spend after the first one")
+    ap.add_argument("--cpu-budget", type=float, default=12.0,
+                    help="the cpu_baseline leg repeats the CPU-oracle forward while the time spent so far is under this many seconds "
+                         "(C3: one forward is ~10 s on the GPU box's host cores, so the default gives two = ~20 s of CPU work)")
     ap.add_argument("--fp32-ref-only", action="store_true",
                     help="(extra lines) no timed CPU baseline: only the ONE fp32 CPU forward `vs_fp32_reference` needs (bf16 lines)")
     ap.add_argument("--extra-lines", default="auto", choices=("auto", "on", "off"),
@@ -761,9 +911,9 @@ def main():
              not args.no_drr)
     if rank == 0 and world == 1 and (args.extra_lines == "on" or (args.extra_lines == "auto" and plain)):
         torch.cuda.empty_cache()     # (the children allocate their own ~30 GB each; this process keeps its ~15 GB of live tensors)
-        result["extra_lines"] = extra_lines()
+        result["extra_lines"] = extra_lines(args.steps, args.warmup, only=args.only_extra)
     if rank == 0:
-        print(json.dumps(result))
+        emit(result, name=args.config)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

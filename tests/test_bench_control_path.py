@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(nproc, extra, env=None, timeout=600, script="bench.py"):
+def _launch(nproc, extra, env=None, timeout=600, script="bench.py", full=False):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, script), "--gpus", str(nproc)] + extra
     e = dict(os.environ)
@@ -32,6 +32,12 @@ def _launch(nproc, extra, env=None, timeout=600, script="bench.py"):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
     assert len(lines) == 1, f"exactly one JSON line expected from rank 0, got {len(lines)}:\n{r.stdout[-2000:]}"
+    if script == "bench.py":     # the final line is the LAST stdout line and fits the driver's tail with room to spare
+        assert r.stdout.rstrip("\n").splitlines()[-1] == lines[0] and len(lines[0]) < 4096, len(lines[0])
+    if full:                     # the verbose record of the same run: the first `#full` line
+        fl = [l[len("#full "):] for l in r.stdout.splitlines() if l.startswith("#full ")]
+        assert fl, r.stdout[-2000:]
+        return json.loads(fl[0])
     return json.loads(lines[0])
 
 
@@ -59,6 +65,47 @@ def test_training_two_rank_control_path_dry_run():
     assert diff["losses"][-1] != pytest.approx(one["losses"][-1], rel=1e-6)
 
 
+def test_final_line_fits_the_drivers_stdout_tail():
+    """the driver keeps an 8 KB tail of stdout and parses the last line.  A recorded full record
+    (tests/golden/bench_full_stub.json: round 5's 20.8 KB line + two more training children = six extras) goes through
+    bench.py's own emit(): the verbose records land on `#full` lines, the LAST line is < 4 KB, parses, and still carries the
+    contract's keys, `roofline`, `roofline_backproject`, `cpu_baseline`, `parity_vs_cpu` and one short record per extra."""
+    stub = os.path.join(ROOT, "tests", "golden", "bench_full_stub.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--stub-full", stub, "--steps", "2", "--warmup", "0"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout.rstrip("\n").splitlines()
+    last = out[-1]
+    assert len(last) < 4096, len(last)
+    d = json.loads(last)
+    with open(stub) as fh:
+        src = json.load(fh)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "roofline_backproject", "cpu_baseline", "parity_vs_cpu", "extra_lines"):
+        assert k in d, k
+    assert d["value"] == pytest.approx(src["value"], rel=1e-4) and d["dtype"] == "f32" and "256^3" in d["config"]["workload"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"] and k in d["roofline_backproject"], k
+    assert d["roofline"]["frac"] == pytest.approx(src["roofline"]["frac"], rel=1e-4) and len(d["roofline"].get("note", "")) <= 120
+    assert set(d["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
+    assert set(d["extra_lines"]) == set(src["extra_lines"]) and len(d["extra_lines"]) == 6
+    for name, e in d["extra_lines"].items():
+        assert e["value"] == pytest.approx(src["extra_lines"][name]["value"], rel=1e-4) and e["ms_per_step"] > 0 and e["steps"] > 0
+    assert d["extra_lines"]["c4_bf16"]["vs_fp32_reference"]["max_abs_disp"] < 1e-4
+    # every measured line's verbose record is on its own earlier line
+    names = [json.loads(l[len("#full "):])["name"] for l in out[:-1] if l.startswith("#full ")]
+    assert names == ["dry_run"] + list(src["extra_lines"])
+    # an oversized record degrades by dropping optional keys, never the contract's
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    big = dict(src)
+    big["extra_lines"] = {f"line{i}": v for i, v in enumerate(list(src["extra_lines"].values()) * 2)}
+    line = bench.compact_line(big)
+    assert len(line) <= bench.LINE_BUDGET and json.loads(line)["roofline"]["frac"] > 0 and json.loads(line)["cpu_baseline"]["cores"] == 256
+
+
 def test_wrong_world_size_is_refused():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], cwd=ROOT,
                        capture_output=True, text=True, timeout=120, env={**os.environ, "WORLD_SIZE": "1"})
@@ -68,11 +115,11 @@ def test_wrong_world_size_is_refused():
 @pytest.mark.gpu
 def test_two_ranks_on_one_gpu_replicas_and_slab():
     env = {"LIFTREG_BENCH_BACKEND": "gloo"}
-    one = _launch(1, ["--config", "c1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-drr"], env)
-    rep = _launch(2, ["--config", "c1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-drr"], env)
+    one = _launch(1, ["--config", "c1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-drr"], env, full=True)
+    rep = _launch(2, ["--config", "c1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-drr"], env, full=True)
     assert rep["n_gpus"] == 2 and rep["scaling"] == "weak" and rep["config"]["global_batch"] == 2 * one["config"]["global_batch"]
     assert rep["value"] > 0 and "replicas x2" in rep["config"]["parallelism"]
-    slab = _launch(2, ["--config", "c1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-drr", "--shard", "slab"], env)
+    slab = _launch(2, ["--config", "c1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-drr", "--shard", "slab"], env, full=True)
     assert slab["n_gpus"] == 2 and slab["scaling"] == "strong" and slab["config"]["global_batch"] == one["config"]["global_batch"]
     assert "z-slab x2" in slab["config"]["parallelism"] and slab["value"] > 0
     # the same batch (seed 2021), sharded over two ranks: the NCC from all-reduced slab moments = the unsharded NCC
@@ -84,7 +131,7 @@ def test_slab_mode_reports_the_sharded_projector_leg():
     """`--shard slab` without --no-drr: the partial DRRs of the two ranks' slabs, summed by the all-reduce, equal the
     single-GPU projector's images (north star: "all-reduce of slab-boundary partial sums")."""
     env = {"LIFTREG_BENCH_BACKEND": "gloo"}
-    slab = _launch(2, ["--config", "c1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--shard", "slab", "--ramp-seconds", "0"], env)
+    slab = _launch(2, ["--config", "c1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--shard", "slab", "--ramp-seconds", "0"], env, full=True)
     leg = slab["drr_forward_sharded"]
     assert leg["max_rel_vs_unsharded"] < 1e-5 and leg["volumes_per_s"] > 0 and leg["allreduce_bytes"] == 4 * 1 * 2 * 64 * 64
     assert slab["ramp_seconds"] == 0 and slab["ramp_steps"] == 0

@@ -29,7 +29,48 @@ sys.path.insert(0, ROOT)
 
 CONFIGS = {"c1": dict(n=64, P=2, R=64, B=1, L=56), "c2": dict(n=128, P=2, R=128, B=4, L=56),
            "c3": dict(n=256, P=2, R=256, B=8, L=56),
-           "c5": dict(n=384, P=2, R=512, B=4, L=56)}   # C5 per GPU: batch 32 over 8 GPUs
+           "c5": dict(n=384, P=2, R=512, B=4, L=56),    # C5 per GPU: batch 32 over 8 GPUs
+           # the reference's OWN shipped training configuration (/root/reference/cur_task_setting.json:30,56-57: batch_size 30,
+           # drr_feature_num 4, latent_dim 56; 160^3 hard-coded at models/LiftRegDeformSubspaceBackproj.py:36; detector int(1.5*160))
+           # consumed by main.py -> RegistrationNet.step (networks/RegistrationNet.py:389-406)
+           "native160": dict(n=160, P=4, R=240, B=30, L=56)}
+
+
+def vs_fp32(net, inp, how, c, dev):
+    """Sample 0's forward of the (bf16) model `net` against fp32 arithmetic with the same weights and basis.  Checker only,
+    after the timed region.  how = "cpu": oracle/ref_ops.model_forward (the reference's ATen op sequence on the host);
+    "hip": this library's fp32 forward (conv_dtype fp32)."""
+    one = {k: v[:1].contiguous() for k, v in inp.items()}
+    with torch.no_grad():
+        net.eval()
+        out = net(one)
+        g = {k: out[k].detach().float() for k in ("params", "pca_coefs", "warped")}
+        del out
+        if how == "cpu":
+            from oracle import ref_ops as ro
+            sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+            ref = ro.model_forward(sd, {k: v.cpu() for k, v in one.items()}, net.pca_vectors_LxM.float().cpu(),
+                                   net.pca_mean.float().cpu(), conv_dtype="fp32")
+            g = {k: v.cpu() for k, v in g.items()}
+            against = "oracle/ref_ops.model_forward(conv_dtype='fp32') on the host — the reference's fp32 arithmetic"
+        else:
+            from liftreg_amd.models.LiftRegDeformSubspaceBackproj import model
+            n = c["n"]
+            pca_dtype = getattr(net, "pca_dtype", "fp32")
+            ref_net = model([n, n, n], {"drr_feature_num": c["P"], "latent_dim": c["L"], "pca_path": "synthetic:2021",
+                                        "conv_dtype": "fp32", "pca_dtype": pca_dtype}).to(dev).eval()
+            ref_net.load_state_dict(net.state_dict(), strict=True)
+            ref = ref_net(one)
+            against = ("this library's fp32 HIP forward with the same weights and basis (the fp32 path is within 1e-9 of the "
+                       "CPU oracle: bench.py parity_vs_cpu); the CPU-oracle form of this record: --vs-fp32 cpu")
+        net.train()
+        dd = (g["params"] - ref["params"].float()).abs()
+        cs = float(ref["pca_coefs"].abs().max())
+        return {"against": against, "max_abs_disp": float(dd.max()), "mean_abs_disp": float(dd.mean()),
+                "disp_scale": float(ref["params"].abs().max()),
+                "max_rel_disp": float(dd.max()) / max(float(ref["params"].abs().max()), 1e-30),
+                "max_rel_coefs": float((g["pca_coefs"] - ref["pca_coefs"].float()).abs().max()) / max(cs, 1e-30),
+                "max_abs_warped": float((g["warped"] - ref["warped"].float()).abs().max())}
 
 
 def main():
@@ -53,9 +94,18 @@ def main():
                     help="a boolean model option, e.g. reg_in_coef_space=false ncc_grad_via_moments=false (A/B aid)")
     ap.add_argument("--adam-foreach", action="store_true", help="torch's default (multi-pass) Adam instead of fused=True (A/B aid)")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo control-path self-test with a stand-in module")
+    ap.add_argument("--batch", type=int, default=None, help="registrations per rank (default: the configuration's)")
+    ap.add_argument("--ramp-seconds", type=float, default=1.0, help="untimed seconds of the same step before the warm-up (clock ramp)")
+    ap.add_argument("--vs-fp32", nargs="?", const="hip", default=None, choices=("hip", "cpu"),
+                    help="bf16 lines, after the timed region: sample 0's forward against the fp32 arithmetic of the reference — "
+                         "`cpu`: oracle/ref_ops.model_forward on the host (the checker; ~40 s at C5), `hip` (default): this "
+                         "library's fp32 path with the same weights and basis (itself within 1e-9 of the CPU oracle at C3: "
+                         "bench.py parity_vs_cpu) — the record says which")
     a = ap.parse_args()
     c = CONFIGS[a.config]
     n, P, R, B, L = c["n"], c["P"], c["R"], c["B"], c["L"]
+    if a.batch:
+        B = a.batch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,6 +194,16 @@ def main():
         return l.detach()
 
     losses = []
+    if not a.dry_run and a.ramp_seconds > 0:      # untimed clock ramp (as bench.py): a GPU that was idle starts at reduced clocks
+        t_r = time.perf_counter()
+        while True:
+            step(0)
+            torch.cuda.synchronize()
+            go = torch.tensor([1.0 if time.perf_counter() - t_r < a.ramp_seconds else 0.0], device=dev)
+            if dist is not None:
+                dist.all_reduce(go, op=dist.ReduceOp.MIN)
+            if float(go.item()) == 0.0:
+                break
     for i in range(a.warmup):
         losses.append(step(i))
     fence()
@@ -174,8 +234,12 @@ def main():
                 row["GB/s"] = round(info["bytes"] / avg / 1e6, 0)
             rows.append(row)
         rows.sort(key=lambda r: -r["ms"] * r["launches"])
+    vs = None
+    if a.vs_fp32 and rank == 0 and not a.dry_run:
+        vs = vs_fp32(net, inp, a.vs_fp32, dict(n=n, P=P, L=L), dev)
     if rank == 0:
         print(json.dumps({
+            **({"vs_fp32_reference": vs} if vs is not None else {}),
             "metric": "training samples/s", "value": round(world * B / ms * 1e3, 2), "unit": "samples/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_train_step": round(ms, 3), "samples_per_s": round(world * B / ms * 1e3, 1),
             "higher_is_better": True, "scaling": "weak", "dry_run": bool(a.dry_run),
