@@ -246,7 +246,9 @@ int lr_conv3d_k3_lrelu_obs_f32(const float* in, const float* packed_w, const flo
  *   gpre1 (B,Do,Wo,Ho,32) fp32 plain channels-last = pre-activation gradient of block 1; packed_w1T =
  *   lr_conv3d_pack_weights_f32 of block 1's weight transposed to (16,32,3,3,3), layout NDHWC (as lr_conv3d_dgrad_f32 takes);
  *   mask0 (B,D,W,H,4) uint8 = block 0's LR_LAYOUT_SIGN4 mask (4-byte aligned); x0 (B,Cin0,D,W,H) fp32 = block 0's input,
- *   Cin0 in {2,3}; H % 4 == 0; partial: lr_conv3d_dgrad_wgrad0_partial_floats(Cin0) floats of scratch.
+ *   Cin0 in 2..5 (4, 5: tiles of 4 quotient planes, two waves per plane — the x0 window of the 8-plane tile does not fit the
+ *   LDS; 5 = the reference's shipped 4-view configuration, cur_task_setting.json:56); H % 4 == 0; partial:
+ *   lr_conv3d_dgrad_wgrad0_partial_floats(Cin0) floats of scratch.
  * Results: gw0 (16,Cin0,3,3,3), gb0 (16) = lr_conv3d_dgrad_f32(x_layout SIGN4) + lr_conv3d_wgrad_f32 up to fp32 summation
  * order.  Replaces autograd of layers.py:365-369 for blocks 0/1 (RegistrationNet.py:401). */
 int64_t lr_conv3d_dgrad_wgrad0_partial_floats(int Cin0);
@@ -457,7 +459,7 @@ int lr_conv3d_first_split_obs_f32(const float* in0, int64_t in0_batch_stride, co
  *              (Cout,Cin,3,3,3) weights
  *   out      : dev, (B,Do,Wo,Ho,32) in out_layout LR_LAYOUT_NDHWC or LR_LAYOUT_NDHWC_HPS, Xo = (X-1)/2+1;
  *              out_batch_stride in elements (0 = dense)
- * Cin in 1..4, H % 4 == 0, 16-byte aligned pointers, 0 <= slope <= 1 — otherwise LR_EUNSUPPORTED / LR_EALIGN and the
+ * Cin in 1..5, H % 4 == 0, 16-byte aligned pointers, 0 <= slope <= 1 — otherwise LR_EUNSUPPORTED / LR_EALIGN and the
  * caller runs the two blocks as two kernels. */
 int64_t lr_conv3d_pair01_packed_floats(int Cin, int C0, int C1);
 int lr_conv3d_pair01_pack_f32(const float* w0, const float* w1, float* packed, int Cin, int C0, int C1, void* stream);
@@ -481,7 +483,7 @@ int lr_conv3d_pair01_slab_f32(const float* in0, int64_t in0_batch_stride, const 
  *           fp32 values whose three-way splits fed block 1; what block 1's weight gradient reads;
  *   mask0 : dev (B,D,W,H,4) uint8 (LR_LAYOUT_SIGN4), its LeakyReLU sign mask as lr_conv3d_k3_lrelu_mask_f32 writes it — what
  *           the fused data-gradient + block-0 weight-gradient kernel (lr_conv3d_dgrad_wgrad0_f32) reads.
- * Whole volumes only; act0 16-byte, mask0 4-byte aligned; D*W*H*64 < 2^31.  Replaces layers.py:365-369 twice in the
+ * Whole volumes only; Cin in 1..5; act0 16-byte, mask0 4-byte aligned; D*W*H*64 < 2^31.  Replaces layers.py:365-369 twice in the
  * training forward (RegistrationNet.py:389-406 drives it). */
 int lr_conv3d_pair01_train_f32(const float* in0, int64_t in0_batch_stride, const float* in_rest, int64_t rest_batch_stride,
                                const float* packed, const float* bias0, const float* bias1, float* out, float* act0,

@@ -65,7 +65,8 @@ class ConvPair01Fn(torch.autograd.Function):
         encoder input cat([moving, target_volume]) (…Backproj.py:95-98) is read from the two buffers by the forward and by the
         backward, never assembled."""
         B, _, D, W, H = x.shape
-        if rest is not None and not (packed_pair is not None and ops.conv3d_pair01_train_supported(x, w0, w1, mid_layout, out_layout, rest)):
+        if rest is not None and not (packed_pair is not None and ops.conv3d_pair01_train_supported(x, w0, w1, mid_layout, out_layout, rest) and
+                                     ops_bwd.conv3d_dgrad_wgrad0_rest_ok(x, rest)):
             x, rest = torch.cat([x, rest], 1), None          # (shapes the fused kernel does not take: the concatenated input)
         if packed_pair is not None and ops.conv3d_pair01_train_supported(x, w0, w1, mid_layout, out_layout, rest):
             # the forward as the fused pair kernel (exact bf16 operand splits, csrc/conv01_fused.hip) that also writes y0 and mask0

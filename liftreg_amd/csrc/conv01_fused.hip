@@ -1481,7 +1481,7 @@ static int pair01_impl(const float* in0, int64_t in0_batch_stride, const float* 
     const int need_hi = 2 * (oz_lo + n_oz - 1) + 2 >= D_global ? D_global - 1 : 2 * (oz_lo + n_oz - 1) + 2;
     if (need_lo < z_lo || need_hi >= z_lo + D) return LR_EINVAL;
   }
-  if (Cin < 1 || Cin > 5 || (Cin == 5 && save)) return LR_EUNSUPPORTED;   // (five channels: inference form only)
+  if (Cin < 1 || Cin > 5) return LR_EUNSUPPORTED;
   if (out_layout != LR_LAYOUT_NDHWC && out_layout != LR_LAYOUT_NDHWC_HPS) return LR_EUNSUPPORTED;
   if (!(slope0 >= 0.0f && slope0 <= 1.0f) || !(slope1 >= 0.0f && slope1 <= 1.0f)) return LR_EUNSUPPORTED;   // LeakyReLU = max(v, slope v)
   if (H & 3) return LR_EUNSUPPORTED;
@@ -1533,7 +1533,8 @@ static int pair01_impl(const float* in0, int64_t in0_batch_stride, const float* 
     else if (Cin == 2) LR_C01(2, true, false);
     else if (Cin == 3 && densek) LR_C01(3, true, true);
     else if (Cin == 3) LR_C01(3, true, false);
-    else LR_C01(4, true, false);
+    else if (Cin == 4) LR_C01(4, true, false);
+    else LR_C01(5, true, true);
   } else {
     if (Cin == 1) LR_C01(1, false, false);
     else if (Cin == 2) LR_C01(2, false, false);

@@ -20,6 +20,13 @@
 // mask (one dword of the SIGN4 mask per voxel, bit = channel), then 4 x NTJ weight-gradient MFMAs into NTJ accumulators
 // that live for the whole kernel; one partial per wave, fixed-order double reduce (wgrad0_finish_kernel).
 //
+// Tile shapes (template NZ = quotient planes per tile).  Cin0 <= 3: NZ = 8, a wave owns one quotient plane and both quotient
+// rows (LDS 160.7 KB at Cin0 = 3).  Cin0 = 4, 5 (the reference's shipped 4-view configuration, cur_task_setting.json:56): the
+// x0 window of an 8-plane tile does not fit beside the weights (191.9 KB), so NZ = 4: a tile = 4 x 2 x 16 quotient voxels, TWO
+// waves per quotient plane, one quotient row each (gpre1 window 5 x 3 x 17 voxels, x0 window Cin0 x 10 x 6 x 36 floats: 131.1
+// KB at Cin0 = 5); a wave's single data-gradient chain then alternates between two accumulators (even / odd k quarters) so
+// that no MFMA waits for the one before it, as the two rows' chains do in the 8-plane form.
+//
 // Replaces: autograd of src/liftreg/layers/layers.py:365-369 for blocks 0 and 1 as wired at
 //   src/liftreg/models/LiftRegDeformSubspaceBackproj.py:29-33,95-100 (RegistrationNet.py:401 total_loss.backward()).
 #include "lr_common.h"
@@ -35,16 +42,21 @@ struct FzDims {
   float slope;                 // LeakyReLU slope of block 0
 };
 
-constexpr int WMT = 2;                 // quotient rows per wave
+constexpr int TR = 2;                  // quotient rows per tile
 constexpr int CB = 2, CG = 32, C4 = 8;  // block 1: 32 output channels = 2 channel blocks = 8 16-byte chunks per voxel
-constexpr int XZ = 18, XY = 6, XX = 36; // x0 window of a tile: planes, rows, floats per row (origin (-1,-1,-2))
+constexpr int XY = 2 * TR + 2, XX = 36; // x0 window of a tile: rows, floats per row (origin (-1,-1,-2)); planes: 2 NZ + 2
+constexpr int nz_of(int cin0) { return cin0 <= 3 ? 8 : 4; }   // quotient planes per tile (LDS: see the header comment)
 
-template <int CIN0>
+template <int CIN0, int NZ>
 __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __restrict__ gpre, const float4* __restrict__ wp,
                                                               const unsigned* __restrict__ mask0, const float* __restrict__ in0,
                                                               long long bs0, const float* __restrict__ in_rest, long long bsr,
                                                               float* __restrict__ partial, FzDims d, int ntiles) {
-  constexpr int NVOX = 9 * (WMT + 1) * 17, NCH = NVOX * C4, NIT = (NCH + 511) / 512;
+  constexpr int WPP = 8 / NZ;                        // waves per quotient plane
+  constexpr int WMT = TR / WPP;                      // quotient rows per wave
+  constexpr int XZ = 2 * NZ + 2;
+  static_assert(NZ == 8 || NZ == 4, "tile shape");
+  constexpr int NVOX = (NZ + 1) * (TR + 1) * 17, NCH = NVOX * C4, NIT = (NCH + 511) / 512;
   constexpr int NWF = 27 * CB * 64;                  // float4 weight fragments (the first 27 taps of the packed buffer)
   // 8-byte pairs of the x0 window, enumerated channel by channel (NPI thread-iterations each): the channel of an iteration is a
   // compile-time constant, so channel 0 (the moving image) and channels 1.. (the backprojected views) may live in two buffers
@@ -61,14 +73,15 @@ __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __res
   float* xs = ts + NVOX * 32;                    // [CIN0][XZ][XY][XX]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wz = wave / WPP, wy = (wave % WPP) * WMT;   // this wave's quotient plane and first quotient row inside the tile
   for (int i = tid; i < NWF; i += 512) wl[i] = wp[i];
-  const int nWq = (d.Wo + WMT - 1) / WMT, nDq = (d.Do + 7) / 8;
+  const int nWq = (d.Wo + TR - 1) / TR, nDq = (d.Do + NZ - 1) / NZ;
   auto tile_coords = [&](int t, int& b, int& zq0, int& yq0, int& xq0) {
     const int hq = t % d.nHq; t /= d.nHq;
     const int wq = t % nWq; t /= nWq;
     const int dq = t % nDq;
     b = t / nDq;
-    zq0 = dq * 8; yq0 = wq * WMT; xq0 = hq * 16;
+    zq0 = dq * NZ; yq0 = wq * TR; xq0 = hq * 16;
   };
   float4 st[NIT];
   float2 xst[NXI];
@@ -83,7 +96,7 @@ __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __res
   for (int it = 0; it < NIT; ++it) {
     const int q = it * 512 + tid;
     const int vox = q / C4, c4 = q % C4;
-    const int xx = vox % 17, r = vox / 17, yy = r % (WMT + 1), zz = r / (WMT + 1);
+    const int xx = vox % 17, r = vox / 17, yy = r % (TR + 1), zz = r / (TR + 1);
     pkg[it] = q < NCH ? (unsigned)(xx | yy << 8 | zz << 16 | c4 << 28) : 0x08000000u;  // bit 27: past the window
   }
 #pragma unroll
@@ -135,11 +148,11 @@ __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __res
     }
   };
   const int col = lane & 15, kq = lane >> 4;
-  // gpre1 window reads: voxel vi = c + u with u = wave*51 + col per lane and c a compile-time constant of the k-step;
+  // gpre1 window reads: voxel vi = c + u with u = (wz*3 + wy)*17 + col per lane and c a compile-time constant of the k-step;
   // chunk (cb*4 + kq) of voxel vi sits at rotation (cb*4 + kq + vi) & 7 = (kq + u + e) & 7 with e = (c + 4*cb) & 7
   unsigned prot[8];
   {
-    const int u = wave * 51 + col;
+    const int u = (wz * (TR + 1) + wy) * 17 + col;
 #pragma unroll
     for (int e = 0; e < 8; ++e) prot[e] = (unsigned)(u * 32 + ((kq + u + e) & 7) * 4);
   }
@@ -156,10 +169,10 @@ __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __res
       n = 27 * CIN0 - 1;
     }
     const int ci = n / 27, tap = n - ci * 27, tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
-    xbase[j] = (unsigned)((((ci * XZ + tz + 2 * wave) * XY + ty) * XX + tx + 8 * kq + 1));
+    xbase[j] = (unsigned)((((ci * XZ + tz + 2 * wz) * XY + ty + 2 * wy) * XX + tx + 8 * kq + 1));
   }
   // VT: the last tap (ci = Cin0-1, tz = ty = tx = 2) for this lane's voxels 4kq + r, and the two scalar accumulators
-  const unsigned xbase_t = (unsigned)(((((CIN0 - 1) * XZ + 2 + 2 * wave) * XY + 2) * XX + 2 + 8 * kq + 1));
+  const unsigned xbase_t = (unsigned)(((((CIN0 - 1) * XZ + 2 + 2 * wz) * XY + 2 + 2 * wy) * XX + 2 + 8 * kq + 1));
   float vt_tap = 0.0f, vt_bias = 0.0f;
   const unsigned msh = (unsigned)((col >> 2) * 8 + (col & 3));  // this lane's channel bit in a voxel's SIGN4 dword
   f32x4 gacc[NTJ];
@@ -173,7 +186,7 @@ __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __res
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const unsigned pk = pkg[it];
-      const unsigned vox = (((pk >> 16) & 127u) * (WMT + 1) + ((pk >> 8) & 127u)) * 17 + (pk & 127u), c4 = pk >> 28;
+      const unsigned vox = (((pk >> 16) & 127u) * (TR + 1) + ((pk >> 8) & 127u)) * 17 + (pk & 127u), c4 = pk >> 28;
       if (it * 512 + tid < NCH) *reinterpret_cast<float4*>(ts + vox * 32 + ((c4 + vox) & 7) * 4) = st[it];
     }
 #pragma unroll
@@ -185,8 +198,8 @@ __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __res
     int b, zq0, yq0, xq0;
     tile_coords(t, b, zq0, yq0, xq0);
     if (t + (int)gridDim.x < ntiles) prefetch(t + (int)gridDim.x);  // lands while this tile runs on the matrix pipe
-    const int zq = zq0 + wave;
-    const bool interior = 2 * (xq0 + 16) <= d.H && 2 * (yq0 + WMT) <= d.W;
+    const int zq = zq0 + wz;
+    const bool interior = 2 * (xq0 + 16) <= d.H && 2 * (yq0 + TR) <= d.W;
     const unsigned mvoff = (unsigned)(2 * (xq0 + 4 * kq) * 4);  // byte offset of this lane's first voxel in a mask row
 #pragma unroll
     for (int pp = 3; pp >= 0; --pp) {
@@ -194,13 +207,14 @@ __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __res
       const int z = 2 * zq + pz;
       if (z >= d.D) continue;  // wave-uniform; no barrier inside the class loop
       f32x4 accp[2][WMT];
+      f32x4 accq[2][WMT];   // (one row per wave) the chain's second accumulator: k quarters y, w
       unsigned mw[2][WMT][4];
       // the mask dwords of the class pair first, a whole pair ahead of their use: one resource per batch element, the
       // row as the scalar offset, the voxel (2*(xq0 + 4kq + r) + px) as one per-lane offset + immediates; a row outside
       // the volume reads through the zero-length resource, a voxel past its row reads a neighbour or, past the tensor, zeros (masked below)
 #pragma unroll
       for (int mt = 0; mt < WMT; ++mt) {
-        const int y = 2 * (yq0 + mt) + py;
+        const int y = 2 * (yq0 + wy + mt) + py;
         const __amdgpu_buffer_rsrc_t rsm = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<unsigned*>(mask0 + (int64_t)b * d.D * d.W * d.H), (short)0, y < d.W ? (int)((int64_t)d.D * d.W * d.H * 4) : 0, 0x00020000);
         const unsigned rowb = (unsigned)((z * d.W + y) * d.H * 4);
@@ -217,7 +231,7 @@ __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __res
 #pragma unroll
       for (int px = 1; px >= 0; --px) {
 #pragma unroll
-        for (int mt = 0; mt < WMT; ++mt) accp[px][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < WMT; ++mt) accp[px][mt] = accq[px][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int NS = (1 << (px + py + pz)) * CB;
         float4 a0[WMT], a1[WMT], b0, b1;
         auto load_step = [&](int s, float4 (&a)[WMT], float4& bw) __attribute__((always_inline)) {
@@ -230,21 +244,28 @@ __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __res
           bw = wl[sfull * 64 + lane];
 #pragma unroll
           for (int mt = 0; mt < WMT; ++mt) {
-            const int c = ((oz * (WMT + 1)) + oy + mt) * 17 + ox;  // voxel offset of this step inside the window
+            const int c = ((oz * (TR + 1)) + oy + mt) * 17 + ox;  // voxel offset of this step inside the window
             a[mt] = *reinterpret_cast<const float4*>(ts + prot[(c + 4 * cb) & 7] + c * 32);
           }
         };
         auto mfma_step = [&](const float4 (&a)[WMT], const float4& bw) __attribute__((always_inline)) {
           // A = the gpre1 voxels (rows = voxels), B = the weights (cols = gpre0 channels); the two quotient rows alternate
-          // on the matrix pipe so no MFMA waits for the one before it
+          // on the matrix pipe so no MFMA waits for the one before it (one row per wave: two accumulators alternate)
+          if constexpr (WMT == 1) {
+            accp[px][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0].x, bw.x, accp[px][0], 0, 0, 0);
+            accq[px][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0].y, bw.y, accq[px][0], 0, 0, 0);
+            accp[px][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0].z, bw.z, accp[px][0], 0, 0, 0);
+            accq[px][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0].w, bw.w, accq[px][0], 0, 0, 0);
+          } else {
 #pragma unroll
-          for (int mt = 0; mt < WMT; ++mt) accp[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, bw.x, accp[px][mt], 0, 0, 0);
+            for (int mt = 0; mt < WMT; ++mt) accp[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, bw.x, accp[px][mt], 0, 0, 0);
 #pragma unroll
-          for (int mt = 0; mt < WMT; ++mt) accp[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, bw.y, accp[px][mt], 0, 0, 0);
+            for (int mt = 0; mt < WMT; ++mt) accp[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, bw.y, accp[px][mt], 0, 0, 0);
 #pragma unroll
-          for (int mt = 0; mt < WMT; ++mt) accp[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, bw.z, accp[px][mt], 0, 0, 0);
+            for (int mt = 0; mt < WMT; ++mt) accp[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, bw.z, accp[px][mt], 0, 0, 0);
 #pragma unroll
-          for (int mt = 0; mt < WMT; ++mt) accp[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, bw.w, accp[px][mt], 0, 0, 0);
+            for (int mt = 0; mt < WMT; ++mt) accp[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, bw.w, accp[px][mt], 0, 0, 0);
+          }
         };
         load_step(0, a0, b0);
 #pragma unroll
@@ -262,7 +283,8 @@ __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __res
 #pragma unroll
         for (int mt = 0; mt < WMT; ++mt) {
           f32x4 v = accp[px][mt];
-          const bool yok = 2 * (yq0 + mt) + py < d.W;  // wave-uniform
+          if constexpr (WMT == 1) v += accq[px][mt];
+          const bool yok = 2 * (yq0 + wy + mt) + py < d.W;  // wave-uniform
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float m = ((mw[px][mt][r] >> msh) & 1u) ? 1.0f : d.slope;
@@ -276,7 +298,7 @@ __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __res
       // weight gradient: gacc[j][(ci,tap) rows][co cols] += x0(voxel + tap)^T gpre0(voxel); k-step r = voxels 4kq + r
       float xa[NTJ], xb[NTJ];
       auto ldx = [&](float (&xv)[NTJ], int g) __attribute__((always_inline)) {  // g = (px*WMT + mt)*4 + r
-        const int r = g & 3, mt = (g >> 2) % WMT, px = g >> 3;
+        const int r = g & 3, mt = (g >> 2) % WMT, px = g / (4 * WMT);
         const int off = (pz * XY + 2 * mt + py) * XX + 2 * r + px;
 #pragma unroll
         for (int j = 0; j < NTJ; ++j) xv[j] = xs[xbase[j] + off];
@@ -285,7 +307,7 @@ __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __res
       ldx(xa, 0);
 #pragma unroll
       for (int g = 0; g < 2 * WMT * 4; ++g) {
-        const int r = g & 3, mt = (g >> 2) % WMT, px = g >> 3;
+        const int r = g & 3, mt = (g >> 2) % WMT, px = g / (4 * WMT);
         ldx(xb, g + 1 < 2 * WMT * 4 ? g + 1 : g);
         const float bv = accp[px][mt][r];
         if constexpr (VT) {
@@ -360,10 +382,12 @@ int launch(const float* gpre1, const float* packed_w1T, const unsigned char* mas
            const float* in_rest, long long bsr, float* partial, float* gw0, float* gb0, const FzDims& d, int ntiles, int blocks,
            hipStream_t st) {
   constexpr int NTP = (27 * CIN0 + 1 + 15) / 16;
-  const size_t ldsb = ((size_t)27 * CB * 64 * 4 + (size_t)9 * (WMT + 1) * 17 * 32 + (size_t)CIN0 * XZ * XY * XX) * sizeof(float);
+  constexpr int NZ = nz_of(CIN0), XZ = 2 * NZ + 2;
+  constexpr size_t ldsb = ((size_t)27 * CB * 64 * 4 + (size_t)(NZ + 1) * (TR + 1) * 17 * 32 + (size_t)CIN0 * XZ * XY * XX) * sizeof(float);
+  static_assert(ldsb <= 160 * 1024, "LDS");
   static std::atomic<uint64_t> attr_done{0};  // per instantiation, one bit per device
-  if (lr_raise_dyn_lds(reinterpret_cast<const void*>(&dgrad_wgrad0_kernel<CIN0>), ldsb, attr_done) != LR_OK) return LR_ELAUNCH;
-  hipLaunchKernelGGL((dgrad_wgrad0_kernel<CIN0>), dim3((unsigned)blocks), dim3(512), ldsb, st, gpre1,
+  if (lr_raise_dyn_lds(reinterpret_cast<const void*>(&dgrad_wgrad0_kernel<CIN0, NZ>), ldsb, attr_done) != LR_OK) return LR_ELAUNCH;
+  hipLaunchKernelGGL((dgrad_wgrad0_kernel<CIN0, NZ>), dim3((unsigned)blocks), dim3(512), ldsb, st, gpre1,
                      reinterpret_cast<const float4*>(packed_w1T), reinterpret_cast<const unsigned*>(mask0), in0, bs0, in_rest, bsr, partial, d, ntiles);
   const int ncols = NTP * 16;
   hipLaunchKernelGGL(wgrad0_finish_kernel, dim3((16 * ncols + 63) / 64), dim3(1024), 0, st, partial, gw0, gb0, blocks * 8, CIN0, ncols);
@@ -374,14 +398,14 @@ int launch(const float* gpre1, const float* packed_w1T, const unsigned char* mas
 
 // Floats of `partial` lr_conv3d_dgrad_wgrad0_f32 needs (one 16 x NTJ*16 partial per wave of every persistent block).
 extern "C" int64_t lr_conv3d_dgrad_wgrad0_partial_floats(int Cin0) {
-  if (Cin0 != 2 && Cin0 != 3) return LR_EUNSUPPORTED;
+  if (Cin0 < 2 || Cin0 > 5) return LR_EUNSUPPORTED;
   return (int64_t)256 * 8 * 16 * ((27 * Cin0 + 1 + 15) / 16) * 16;
 }
 
 // gw0 (16,Cin0,3,3,3), gb0 (16) of the encoder's first block from the pre-activation gradient of the SECOND block:
 //   gpre1 (B,Do,Wo,Ho,32) fp32 plain channels-last; packed_w1T = lr_conv3d_pack_weights_f32 of block 1's weight transposed
 //   to (16,32,3,3,3), layout NDHWC (what lr_conv3d_dgrad_f32 takes); mask0 (B,D,W,H,4) uint8 = block 0's LR_LAYOUT_SIGN4
-//   sign mask, 4-byte aligned; x0 (B,Cin0,D,W,H) fp32 NCDHW = block 0's input, Cin0 in {2,3}; H % 4 == 0.
+//   sign mask, 4-byte aligned; x0 (B,Cin0,D,W,H) fp32 NCDHW = block 0's input, Cin0 in 2..5; H % 4 == 0.
 // Same results as lr_conv3d_dgrad_f32 (x_layout SIGN4) followed by lr_conv3d_wgrad_f32 up to fp32 summation order.
 // ... with block 0's input in TWO buffers, as the model holds it: channel 0 (the moving image) at in0 + b*in0_batch_stride,
 // channels 1..Cin0-1 (the backprojected views) at in_rest + b*rest_batch_stride + (c-1)*D*W*H (elements) — no concatenated copy
@@ -392,7 +416,7 @@ extern "C" int lr_conv3d_dgrad_wgrad0_split_f32(const float* gpre1, const float*
                                                 int D, int W, int H, void* stream) {
   if (!gpre1 || !packed_w1T || !mask0 || !in0 || !in_rest || !partial || !gw0) return LR_ENULL;
   if (B < 1 || D < 1 || W < 1 || H < 1) return LR_EINVAL;
-  if ((Cin0 != 2 && Cin0 != 3) || (H & 3)) return LR_EUNSUPPORTED;
+  if (Cin0 < 2 || Cin0 > 5 || (H & 3)) return LR_EUNSUPPORTED;
   const int64_t V = (int64_t)D * W * H;
   if (in0_batch_stride < V || rest_batch_stride < (int64_t)(Cin0 - 1) * V) return LR_EINVAL;
   if ((reinterpret_cast<uintptr_t>(gpre1) & 15u) || (reinterpret_cast<uintptr_t>(mask0) & 3u) || (reinterpret_cast<uintptr_t>(in0) & 7u) ||
@@ -401,7 +425,8 @@ extern "C" int lr_conv3d_dgrad_wgrad0_split_f32(const float* gpre1, const float*
   FzDims d;
   d.B = B; d.D = D; d.W = W; d.H = H;
   d.Do = (D - 1) / 2 + 1; d.Wo = (W - 1) / 2 + 1; d.Ho = (H - 1) / 2 + 1;
-  d.nHq = ((H + 1) / 2 + 15) / 16; d.nWq = (d.Wo + WMT - 1) / WMT; d.nDq = (d.Do + 7) / 8;
+  const int NZ = nz_of(Cin0);
+  d.nHq = ((H + 1) / 2 + 15) / 16; d.nWq = (d.Wo + TR - 1) / TR; d.nDq = (d.Do + NZ - 1) / NZ;
   d.slope = slope0;
   if ((int64_t)10 * d.Wo * d.Ho * CG * 4 >= 0x7fffffffLL) return LR_EINVAL;       // 32-bit offsets of a gpre1 window
   if ((int64_t)Cin0 * V * 4 >= 0x7fffffffLL) return LR_EUNSUPPORTED;               // ... and of one batch element of the input
@@ -411,6 +436,8 @@ extern "C" int lr_conv3d_dgrad_wgrad0_split_f32(const float* gpre1, const float*
   if (lr_sw_set(LR_SW_FUSED_BWD_BLOCKS)) { blocks = lr_sw_int(LR_SW_FUSED_BWD_BLOCKS, 256); if (blocks < 1 || blocks > 256) blocks = 256; }  // tuning aid
   if (nt < blocks) blocks = (int)nt;
   hipStream_t st = lr_stream(stream);
+  if (Cin0 == 5) return launch<5>(gpre1, packed_w1T, mask0, in0, in0_batch_stride, in_rest, rest_batch_stride, partial, gw0, gb0, d, (int)nt, blocks, st);
+  if (Cin0 == 4) return launch<4>(gpre1, packed_w1T, mask0, in0, in0_batch_stride, in_rest, rest_batch_stride, partial, gw0, gb0, d, (int)nt, blocks, st);
   if (Cin0 == 3) return launch<3>(gpre1, packed_w1T, mask0, in0, in0_batch_stride, in_rest, rest_batch_stride, partial, gw0, gb0, d, (int)nt, blocks, st);
   return launch<2>(gpre1, packed_w1T, mask0, in0, in0_batch_stride, in_rest, rest_batch_stride, partial, gw0, gb0, d, (int)nt, blocks, st);
 }

@@ -417,7 +417,7 @@ class model(nn.Module):
             return self.encoders[6](x)
         b0, b1 = self.encoders[0], self.encoders[1]
         if (self.conv_dtype != "bf16" and needs_grad and self.fuse_first_backward and self.fuse_pair01 and self.fuse_pair01_train and
-                self.split_encoder_input and P <= 2 and b0.conv.weight.requires_grad and b1.conv.weight.requires_grad and b0.premasked_grad and b1.stride == 2 and
+                self.split_encoder_input and P <= self.PAIR01_MAX_VIEWS and b0.conv.weight.requires_grad and b1.conv.weight.requires_grad and b0.premasked_grad and b1.stride == 2 and
                 b0.out_layout == b1.in_layout and tuple(b1.conv.weight.shape[:2]) == (32, 16)):
             # training, fp32: blocks 0 + 1 as one autograd node (fused pair forward; fused dgrad1 + wgrad0 backward) reading `moving`
             # and the backprojected views from their OWN buffers — cat([moving, target_volume]) (:95-98) is never assembled (the
@@ -462,7 +462,7 @@ class model(nn.Module):
         if (self.fuse_first_backward and needs_grad and b0.conv.weight.requires_grad and b1.conv.weight.requires_grad and
                 b0.premasked_grad and b1.stride == 2 and b0.out_layout == b1.in_layout and
                 ops.conv3d_mask_supported(x, b0.conv.weight, b0.stride, b0.in_layout, b0.out_layout) and
-                tuple(b1.conv.weight.shape[:2]) == (32, 16) and x.shape[1] in (2, 3) and x[0].numel() * 4 < 2 ** 31 - 1):
+                tuple(b1.conv.weight.shape[:2]) == (32, 16) and x.shape[1] in (2, 3, 4, 5) and x[0].numel() * 4 < 2 ** 31 - 1):
             # training, fp32: blocks 0 and 1 as one autograd node — the gradient between them never reaches memory
             x = ConvPair01Fn.apply(x, b0.conv.weight, b0.conv.bias, b1.conv.weight, b1.conv.bias, b0._slope, b1._slope,
                                    b0.out_layout, b1.out_layout, self._packed_weight(0), self._packed_weight(1), b1.premasked_grad,

@@ -488,13 +488,13 @@ def conv3d_pair01_train_supported(x, w0, w1, mid_layout, out_layout, rest=None):
     """True when `conv3d_pair01_train` can take the encoder's input (training forward): `x` the (B,Cin,D,W,H) NCDHW input, or —
     with `rest` (B,P,D,W,H) — `x` = the (B,1,D,W,H) moving image alone (dense per sample, any even batch stride)."""
     if rest is None:
-        if not (x.dim() == 5 and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] in (1, 2, 3, 4) and
+        if not (x.dim() == 5 and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] in (1, 2, 3, 4, 5) and
                 x.shape[4] % 4 == 0 and x.data_ptr() % 16 == 0):
             return False
         Cin = x.shape[1]
     else:
         if not (x.dim() == 5 and rest.dim() == 5 and x.is_cuda and rest.is_cuda and x.dtype == torch.float32 and rest.dtype == torch.float32 and
-                x.shape[1] == 1 and rest.shape[1] in (1, 2, 3) and x.shape[0] == rest.shape[0] and x.shape[2:] == rest.shape[2:] and
+                x.shape[1] == 1 and rest.shape[1] in (1, 2, 3, 4) and x.shape[0] == rest.shape[0] and x.shape[2:] == rest.shape[2:] and
                 x[0].is_contiguous() and rest.is_contiguous() and x.shape[4] % 4 == 0 and x.data_ptr() % 16 == 0 and
                 rest.data_ptr() % 16 == 0 and (x.shape[0] == 1 or x.stride(0) % 4 == 0)):
             return False
@@ -507,7 +507,7 @@ def conv3d_pair01_train_supported(x, w0, w1, mid_layout, out_layout, rest=None):
     if out_layout == LAYOUT_NDHWC_HPS and ((H - 1) // 2 + 1) % 2:
         return False
     V = D * W * H
-    return 64 * V < 2 ** 31 - 1 and 12 * V + 32 * W * H < 2 ** 31 - 1
+    return 64 * V < 2 ** 31 - 1 and 4 * max(3, Cin - 1) * V + 32 * W * H < 2 ** 31 - 1
 
 
 def conv3d_pair01_train(x, w0, b0, w1, b1, *, mid_layout=LAYOUT_NDHWC_HPS, out_layout=LAYOUT_NDHWC_HPS, slope0=0.2, slope1=0.2,

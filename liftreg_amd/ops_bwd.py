@@ -257,20 +257,30 @@ def lrelu_bwd(gy, gy_layout, y, y_layout, negative_slope=0.2):
     return gpre
 
 
+def conv3d_dgrad_wgrad0_rest_ok(x0, rest):
+    """The two-buffer input form of `conv3d_dgrad_wgrad0` (x0 = the moving image, rest = the views) as far as it can be judged in
+    the FORWARD, before a mask exists: autograd.ConvPair01Fn saves the split input only when the backward will take it."""
+    return (x0.dim() == 5 and rest.dim() == 5 and x0.shape[1] == 1 and rest.shape[1] in (1, 2, 3, 4) and x0.shape[0] == rest.shape[0] and
+            x0.shape[2:] == rest.shape[2:] and x0[0].is_contiguous() and rest.is_contiguous() and rest.dtype == torch.float32 and
+            x0.dtype == torch.float32 and x0.is_cuda and rest.is_cuda and (x0.shape[0] == 1 or x0.stride(0) % 2 == 0) and
+            x0.shape[4] % 4 == 0 and (1 + rest.shape[1]) * x0[0].numel() * 4 < 2 ** 31 - 1)
+
+
 def conv3d_dgrad_wgrad0_supported(x0, mask0, w1, rest=None):
     """True when `conv3d_dgrad_wgrad0` covers these tensors (the encoder's blocks 0/1 in fp32 training).  `rest`: block 0's input
     comes in two buffers — x0 (B,1,D,W,H) the moving image (dense per sample; a batch stride is fine), rest (B,P,D,W,H) the views."""
     if rest is not None:
-        if not (x0.dim() == 5 and rest.dim() == 5 and x0.shape[1] == 1 and rest.shape[1] in (1, 2) and x0.shape[0] == rest.shape[0] and
+        if not (x0.dim() == 5 and rest.dim() == 5 and x0.shape[1] == 1 and rest.shape[1] in (1, 2, 3, 4) and x0.shape[0] == rest.shape[0] and
                 x0.shape[2:] == rest.shape[2:] and x0[0].is_contiguous() and rest.is_contiguous() and rest.dtype == torch.float32 and
+                rest.is_cuda and
                 (x0.shape[0] == 1 or x0.stride(0) % 2 == 0)):
             return False
         cin, per = 1 + rest.shape[1], x0[0].numel()
     else:
-        if not (x0.dim() == 5 and x0.shape[1] in (2, 3) and x0.is_contiguous()):
+        if not (x0.dim() == 5 and x0.shape[1] in (2, 3, 4, 5) and x0.is_contiguous()):
             return False
         cin, per = x0.shape[1], x0[0, :1].numel()
-    return (x0.shape[4] % 4 == 0 and x0.dtype == torch.float32 and
+    return (x0.shape[4] % 4 == 0 and x0.dtype == torch.float32 and x0.is_cuda and
             mask0 is not None and mask0.dtype == torch.uint8 and mask0.is_contiguous() and mask0.shape[-1] == 4 and
             tuple(w1.shape[:2]) == (32, 16) and cin * per * 4 < 2 ** 31 - 1)
 

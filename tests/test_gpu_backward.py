@@ -253,18 +253,25 @@ def test_fused_first_blocks_backward_matches_two_kernels(dev):
     """lr_conv3d_dgrad_wgrad0_f32 (block 1's data gradient + block 0's LeakyReLU mask + block 0's weight / bias gradient in one
     kernel, the 16-channel gradient between them never written) against the two-kernel path it replaces
     (conv3d_bwd of block 1 with the sign mask -> gpre0, conv3d_bwd of block 0 on it) and against float64 torch autograd of the
-    same two blocks: ragged sizes (odd D / W, H not a multiple of 32, several tiles per axis), 2 and 3 input channels."""
+    same two blocks: ragged sizes (odd D / W, H not a multiple of 32, several tiles per axis), 2..5 input channels (4, 5: the
+    4-plane tile form with two waves per quotient plane — the reference's shipped 4-view configuration has 5)."""
     from liftreg_amd import ops, ops_bwd
     rs = np.random.RandomState(18)
-    for shape, B, cin0 in (((8, 8, 64), 2, 3), ((7, 9, 36), 1, 3), ((18, 6, 40), 1, 2), ((34, 10, 68), 1, 3)):
+    for shape, B, cin0 in (((8, 8, 64), 2, 3), ((7, 9, 36), 1, 3), ((18, 6, 40), 1, 2), ((34, 10, 68), 1, 3),
+                           ((8, 8, 64), 2, 5), ((7, 9, 36), 1, 4), ((18, 6, 40), 1, 5), ((34, 10, 68), 1, 5), ((11, 7, 36), 2, 4), ((3, 3, 8), 1, 5)):
         D, W, H = shape
         x0 = T(rs.uniform(-1, 1, (B, cin0) + shape).astype(np.float32), dev)
         w0 = T(rs.normal(0, 0.3, (16, cin0, 3, 3, 3)).astype(np.float32), dev)
         b0 = T(rs.normal(0, 0.1, 16).astype(np.float32), dev)
         w1 = T(rs.normal(0, 0.2, (32, 16, 3, 3, 3)).astype(np.float32), dev)
         lay = ops.LAYOUT_NDHWC_HPS
-        mask = torch.empty((B, D, W, H, 4), dtype=torch.uint8, device=dev)
-        y0 = ops.conv3d_k3_lrelu(x0, w0, b0, 1, in_layout=ops.LAYOUT_NCDHW, out_layout=lay, mask_out=mask)
+        if cin0 <= 3:
+            mask = torch.empty((B, D, W, H, 4), dtype=torch.uint8, device=dev)
+            y0 = ops.conv3d_k3_lrelu(x0, w0, b0, 1, in_layout=ops.LAYOUT_NCDHW, out_layout=lay, mask_out=mask)
+        else:    # (the generic first-block kernel writes no mask for 4 / 5 channels: bit r of byte q = "channel 4q + r > 0")
+            y0 = ops.conv3d_k3_lrelu(x0, w0, b0, 1, in_layout=ops.LAYOUT_NCDHW, out_layout=lay)
+            bits = (ops.hps_to_ndhwc(y0) > 0).view(B, D, W, H, 4, 4).to(torch.uint8)
+            mask = (bits[..., 0] | (bits[..., 1] << 1) | (bits[..., 2] << 2) | (bits[..., 3] << 3)).contiguous()
         y1 = ops.conv3d_k3_lrelu(y0, w1, None, 2, in_layout=lay, out_layout=ops.LAYOUT_NDHWC)
         gpre1 = T(rs.normal(0, 1, tuple(y1.shape)).astype(np.float32), dev)
         assert ops_bwd.conv3d_dgrad_wgrad0_supported(x0, mask, w1)

@@ -104,7 +104,9 @@ def test_pair_kernel_is_fp32_accurate(B, Cin, D, W, H, hps):
 
 
 @pytest.mark.parametrize("B,Cin,D,W,H,hps", [(2, 3, 12, 32, 32, True), (1, 3, 7, 36, 44, True), (1, 2, 6, 40, 24, False),
-                                             (1, 3, 4, 72, 136, True), (1, 3, 9, 34, 28, False)])
+                                             (1, 3, 4, 72, 136, True), (1, 3, 9, 34, 28, False),
+                                             (2, 5, 12, 32, 32, True), (1, 5, 7, 36, 44, True), (1, 4, 6, 40, 24, False),
+                                             (1, 5, 9, 34, 28, False), (1, 5, 5, 72, 136, True)])
 def test_pair_kernel_training_forward_writes_activation_and_mask(B, Cin, D, W, H, hps):
     """lr_conv3d_pair01_train_f32: the same block-1 output bit for bit, plus block 0's activation (every voxel written exactly
     once, fp32-accurate against an fp64 convolution) and its sign mask in the layout lr_conv3d_k3_lrelu_mask_f32 writes."""
@@ -126,7 +128,7 @@ def test_pair_kernel_training_forward_writes_activation_and_mask(B, Cin, D, W, H
     want_m = bits[..., 0] | (bits[..., 1] << 1) | (bits[..., 2] << 2) | (bits[..., 3] << 3)
     assert torch.equal(m0, want_m)
     # and against the two-kernel training forward's side outputs (same layout, fp32-close values)
-    if H % 4 == 0 and W * H >= 256:
+    if H % 4 == 0 and W * H >= 256 and Cin <= 3:      # (the generic first-block kernel writes a mask for <= 3 channels only)
         m_nat = torch.empty_like(m0)
         y_nat = ops.conv3d_k3_lrelu(xd, w0d, b0d, 1, in_layout=ops.LAYOUT_NCDHW, out_layout=mid_l, mask_out=m_nat)
         torch.testing.assert_close(y0, y_nat, rtol=0, atol=4e-6 * float(ref0.abs().max()))

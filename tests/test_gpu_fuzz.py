@@ -566,20 +566,25 @@ def test_fuzz_round2_kernels(dev, monkeypatch):
 
 
 def test_fuzz_fused_first_blocks_backward(dev):
-    """lr_conv3d_dgrad_wgrad0_f32 on random extents (odd D / W, H a multiple of 4 up to several tiles, 2 or 3 input channels,
+    """lr_conv3d_dgrad_wgrad0_f32 on random extents (odd D / W, H a multiple of 4 up to several tiles, 2 to 5 input channels,
     batch 1-2) against the two kernels it replaces."""
     from liftreg_amd import ops, ops_bwd
     rs = np.random.RandomState(733 + SEED)
     for case in range(max(6, N_CASES // 4)):
         D, W, H = int(rs.randint(2, 22)), int(rs.randint(2, 14)), 4 * int(rs.randint(2, 20))
-        B, cin0 = int(rs.randint(1, 3)), int(rs.choice([2, 3]))
+        B, cin0 = int(rs.randint(1, 3)), int(rs.choice([2, 3, 4, 5]))
         x0 = T(rs.uniform(-1, 1, (B, cin0, D, W, H)).astype(np.float32), dev)
         w0 = T(rs.normal(0, 0.3, (16, cin0, 3, 3, 3)).astype(np.float32), dev)
         b0 = T(rs.normal(0, 0.1, 16).astype(np.float32), dev)
         w1 = T(rs.normal(0, 0.2, (32, 16, 3, 3, 3)).astype(np.float32), dev)
         lay = ops.LAYOUT_NDHWC_HPS
-        mask = torch.empty((B, D, W, H, 4), dtype=torch.uint8, device=dev)
-        y0 = ops.conv3d_k3_lrelu(x0, w0, b0, 1, in_layout=ops.LAYOUT_NCDHW, out_layout=lay, mask_out=mask)
+        if cin0 <= 3:
+            mask = torch.empty((B, D, W, H, 4), dtype=torch.uint8, device=dev)
+            y0 = ops.conv3d_k3_lrelu(x0, w0, b0, 1, in_layout=ops.LAYOUT_NCDHW, out_layout=lay, mask_out=mask)
+        else:    # (the generic first-block kernel writes no mask for 4 / 5 channels: bit r of byte q = "channel 4q + r > 0")
+            y0 = ops.conv3d_k3_lrelu(x0, w0, b0, 1, in_layout=ops.LAYOUT_NCDHW, out_layout=lay)
+            bits = (ops.hps_to_ndhwc(y0) > 0).view(B, D, W, H, 4, 4).to(torch.uint8)
+            mask = (bits[..., 0] | (bits[..., 1] << 1) | (bits[..., 2] << 2) | (bits[..., 3] << 3)).contiguous()
         y1 = ops.conv3d_k3_lrelu(y0, w1, None, 2, in_layout=lay, out_layout=ops.LAYOUT_NDHWC)
         gpre1 = T(rs.normal(0, 1, tuple(y1.shape)).astype(np.float32), dev)
         gw0, gb0 = ops_bwd.conv3d_dgrad_wgrad0(gpre1, w1, mask, 0.2, x0)

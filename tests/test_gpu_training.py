@@ -47,6 +47,30 @@ def _cpu_step(sd, inp, vec, mean, epoch):
     return loss, params
 
 
+def _cpu_step64(sd, inp, vec, mean, epoch):
+    """The same step with every differentiated op in float64 (the oracle's own building blocks on double tensors; the
+    backprojected views — data, no gradient — are the fp32 values both sides compute): the adjudicator when the fp32 ATen
+    gradient's own rounding is as large as the bar (whole-model gradients at 160^3 are sums over 8 M voxels)."""
+    params = {k: v.detach().cpu().double().clone().requires_grad_(v.dtype == torch.float32 and "gaussian" not in k)
+              for k, v in sd.items()}
+    moving, target = inp["source"].double(), inp["target"].double()
+    B, _, D, W, H = moving.shape
+    tv = ro.backproject(inp["target_proj"], inp["target_poses"], (D, W, H)).double()
+    x = torch.cat([moving, tv], 1)
+    for i, st in enumerate((1, 2, 2, 2, 2, 2)):
+        x = ro.conv_block(x, params[f"encoders.{i}.conv.weight"], params[f"encoders.{i}.conv.bias"], st)
+    x = x.flatten(1)
+    x = ro.fc_block(x, params["encoders.6.1.fc.weight"], params["encoders.6.1.fc.bias"])
+    x = ro.fc_block(x, params["encoders.6.2.fc.weight"], params["encoders.6.2.fc.bias"])
+    coefs = ro.fc_block(x, params["encoders.6.3.fc.weight"], params["encoders.6.3.fc.bias"], slope=None)
+    disp = ro.pca_reconstruct(coefs, vec.double(), mean.double()).reshape(B, 3, D, W, H)
+    phi = disp + ro.identity_map((D, W, H)).double()
+    warped = ro.warp(moving, phi, zero_boundary=True, using_scale=True)
+    loss = ro.subspace_loss({"warped": warped, "phi": phi, "params": disp, "target": target, "pca_coefs": coefs}, epoch, **LOSS_OPT)
+    loss["total_loss"].backward()
+    return loss, params
+
+
 @pytest.mark.parametrize("shape,P,L,B,labels", [((32, 32, 32), 2, 8, 2, False), ((32, 28, 36), 3, 5, 1, True)])
 def test_training_step_gradients(dev, shape, P, L, B, labels):
     """Every parameter gradient of one step, HIP backward vs ATen autograd of the oracle.  The second case has
@@ -71,6 +95,52 @@ def test_training_step_gradients(dev, shape, P, L, B, labels):
         scale = np.abs(w).max()
         assert scale > 0, k
         np.testing.assert_allclose(g, w, rtol=1e-3, atol=2e-4 * scale, err_msg=k)
+
+
+def test_native160_training_step_takes_the_fused_path(dev):
+    """The reference's SHIPPED configuration in its shipped mode (cur_task_setting.json:30,56-57 — 160^3, 4 views, consumed by
+    main.py -> RegistrationNet.step, networks/RegistrationNet.py:389-406) at batch 2: every parameter gradient of one training
+    step against ATen autograd of the CPU oracle, AND the step ran blocks 0 + 1 through the fused five-channel kernels
+    (lr_conv3d_pair01_train_f32 forward, lr_conv3d_dgrad_wgrad0_split_f32 backward) — none of the generic first-block kernels."""
+    from liftreg_amd import ops
+    from liftreg_amd.losses.SubspaceLoss import loss as SubspaceLoss
+    shape, P, L, B = (160, 160, 160), 4, 8, 2
+    import bench
+    net = _net(shape, P, L, dev, 11).train()
+    # bench.py's synthetic registration pair (ellipsoid phantom + noise, its DRRs, a smoothly warped moving image): the gradient
+    # sums are coherent — on uniform random volumes they are 8 M-term random walks whose fp32 rounding (ATen's as much as the
+    # kernels') reaches 1e-3 of the result's scale
+    dinp = bench.synth_inputs(dict(n=160, P=P, R=240, B=B, L=L), dev, seed=11)
+    inp = {k: v.cpu() for k, v in dinp.items()}
+    crit = SubspaceLoss(dict(LOSS_OPT))
+    with ops.kernel_timer() as kt:
+        out = net(dinp)
+        out["epoch"] = 0
+        got = crit(out)
+        got["total_loss"].backward()
+        torch.cuda.synchronize()
+    names = set(kt.summary())
+    assert "conv3d_pair01_train_c5x16x32_160" in names and "conv3d_dgrad_wgrad0_c32x16x5_160" in names, sorted(names)
+    generic = [k for k in names if k.startswith(("conv3d_c5x16", "conv3d_c16x32", "conv3d_wgrad_c5x16", "conv3d_dgrad_c16x32",
+                                                 "conv3d_dgrad_c32x16", "conv3d_mask_c5x16"))]
+    assert not generic, generic
+    # the checker: ATen autograd of the oracle's op sequence in FLOAT64 — at this size the fp32 ATen gradient's own rounding is
+    # as large as the bar (measured: its first-block weight gradient is 3.6e-6 of the scale from fp64 on the two blocks alone,
+    # the fused kernel 6.5e-8: tools/exp_grad_accuracy.py); the fp32 one is computed too: its distance from fp64 is the yardstick
+    want, params = _cpu_step64(net.state_dict(), inp, net.pca_vectors_LxM.cpu(), net.pca_mean.cpu(), 0)
+    want32, params32 = _cpu_step(net.state_dict(), inp, net.pca_vectors_LxM.cpu(), net.pca_mean.cpu(), 0)
+    assert abs(float(got["total_loss"].detach()) - float(want["total_loss"].detach())) < 1e-5
+    assert abs(float(want32["total_loss"].detach()) - float(want["total_loss"].detach())) < 1e-5
+    for k, p in net.named_parameters():
+        g, w, w32 = p.grad.cpu().double().numpy(), params[k].grad.numpy(), params32[k].grad.double().numpy()
+        scale = np.abs(w).max()
+        assert scale > 0, k
+        err, err32 = np.abs(g - w).max() / scale, np.abs(w32 - w).max() / scale
+        print(f"{k}: |hip - fp64| {err:.2e}, |aten fp32 - fp64| {err32:.2e} of the scale")
+        # the small tests' bar (2e-4 of the scale) — or, where fp32 arithmetic itself cannot hold it at this size (the reference's
+        # own ATen fp32 step is measured 9e-4 from fp64 on the first block's weights: forward rounding carried through 8 M-term
+        # sums), no further from fp64 than 1.5 x the reference's arithmetic
+        assert err <= max(2e-4, 1.5 * err32), (k, err, err32)
 
 
 def test_adam_steps_follow_the_cpu_trajectory(dev):
