@@ -91,6 +91,8 @@ const char* lr_target_arch(void);
  *   LIFTREG_DGRAD_BLOCKS           persistent blocks of the data-gradient kernels
  *   LIFTREG_FUSED_BWD_BLOCKS       persistent blocks of the fused dgrad1 + wgrad0 kernel
  *   LIFTREG_REG_BWD_BLOCKS         block cap of the regulariser's gradient kernel
+ *   LIFTREG_BP_CHUNK               batch elements per block of the tiled backprojection (0 = the whole batch; same bits)
+ *   LIFTREG_BP_JP                  planes a backprojection block works on side by side (1 | 2 | 4; same bits)
  */
 int lr_reload_switches(void);
 const char* lr_switch_name(int id);

@@ -120,7 +120,10 @@ __global__ __launch_bounds__(256) void backproject_kernel(
 
 // ---------------------------------------------------------------------------
 // Tiled variant (the one that runs for every shape the model uses).
-// Block = one emitter p, TI=8 voxel rows (D axis) x TJ=4 coronal planes x all H.
+// Block = one emitter p, TI=8 voxel rows (D axis) x TJ=4 coronal planes x all H, for a CHUNK of the batch (blockIdx.y): the
+// reference's shipped shape (160^3, 4 views, batch 30) gave 3,200 blocks of 30 elements each on 2,048 resident slots — a
+// second round 56 % full; chunks of ~8 elements give 12,800 short blocks.  Rows shorter than 256 voxels: JP = 2 or 4 of the
+// tile's planes side by side (thread = (plane, k); H = 160: 320 threads, all lanes busy, instead of 192 with 32 idle).
 // Per batch element the <=RCAP detector rows the tile's shadows touch are staged
 // once into LDS (16-byte coalesced loads), zero-padded by PAD columns left/right
 // and by zero rows above/below the view, so 'zeros' padding needs no per-corner
@@ -158,17 +161,22 @@ __device__ __forceinline__ TapU make_tap_u(float pix, int size) {
   return t;
 }
 
-template <int KC, bool VEC4>
-__global__ __launch_bounds__(256) void backproject_tiled_kernel(
+template <int KC, bool VEC4, int JP>
+__global__ __launch_bounds__(JP == 1 ? 512 : 384) void backproject_tiled_kernel(
     const float* __restrict__ proj, LrPoses poses, float* __restrict__ out, int B, int P, int Pw,
-    int Ph, int D, int W, int H, int d0, int Ds, int64_t out_batch_stride) {
+    int Ph, int D, int W, int H, int d0, int Ds, int64_t out_batch_stride, int bchunk) {
+  static_assert(JP == 1 || KC == 1, "planes side by side: rows of at most one column per thread");
+  constexpr int NJ = BT_TJ / JP;                  // planes per thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int RS = Ph + 2 * BT_PAD;                 // padded row length (floats)
   float* tile = smem;                             // [BT_RCAP][RS]
   float4* tyt = reinterpret_cast<float4*>(smem + BT_RCAP * RS);  // [TJ*TI] {row offset bits, e, w, -}
   __shared__ int s_lo, s_hi;
   const int tid = threadIdx.x;
-  const int NT = blockDim.x;   // 256, or the row length rounded up to whole waves when it is shorter (H = 160: 192 threads, not 256 with 96 idle)
+  const int NT = blockDim.x;   // JP = 1: the row length / KC rounded up to whole waves (<= 512); JP > 1: JP * H
+  const int NK = JP == 1 ? NT : H;                // threads along a row
+  const int kt = JP == 1 ? tid : tid % H, jsub = JP == 1 ? 0 : tid / H;   // this thread's column | its first plane of the tile
+  const int b_lo = (int)blockIdx.y * bchunk, b_hi = min(B, b_lo + bchunk);
   const int nI = (Ds + BT_TI - 1) / BT_TI, nJ = (W + BT_TJ - 1) / BT_TJ;
   const int jt = blockIdx.x % nJ, it = (blockIdx.x / nJ) % nI, p = blockIdx.x / nJ / nI;
   const int i_base = it * BT_TI, j_base = jt * BT_TJ;
@@ -202,23 +210,24 @@ __global__ __launch_bounds__(256) void backproject_tiled_kernel(
     tyt[tid] = make_float4(__int_as_float(rel), myty.e, myty.w, 0.0f);
   }
   // column taps of this thread's k (per plane j): same for every row i and every batch element
-  TapU txs[KC][BT_TJ];
+  TapU txs[KC][NJ];
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) {
-    const int k = tid + kc * NT;
+    const int k = kt + kc * NK;
     const float z = (float)k - 0.5f * (float)H;
 #pragma unroll
-    for (int jj = 0; jj < BT_TJ; ++jj) {
+    for (int jn = 0; jn < NJ; ++jn) {
+      const int jj = jsub + jn * JP;
       const float y = (float)(W - 1 - (j_base + jj));
       const float scale = ey / (ey - y);
-      txs[kc][jj] = make_tap_u(shadow_pix(z, ez, scale, (float)Ph, Ph), Ph);
-      if (txs[kc][jj].i0 == BT_SENTINEL) txs[kc][jj].i0 = -1;  // weights are 0; any padded column
+      txs[kc][jn] = make_tap_u(shadow_pix(z, ez, scale, (float)Ph, Ph), Ph);
+      if (txs[kc][jn].i0 == BT_SENTINEL) txs[kc][jn].i0 = -1;  // weights are 0; any padded column
     }
   }
   __syncthreads();
 
   if (!any) {  // every shadow of this tile misses the detector: exact zeros, nothing to stage or read
-    for (int b = 0; b < B; ++b)
+    for (int b = b_lo; b < b_hi; ++b)
       for (int jj = 0; jj < BT_TJ && j_base + jj < W; ++jj)
         for (int ii = 0; ii < BT_TI && i_base + ii < Ds; ++ii)
           for (int k = tid; k < H; k += NT)
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(256) void backproject_tiled_kernel(
     return;
   }
   const int64_t view_sz = (int64_t)Pw * Ph;
-  for (int b = 0; b < B; ++b) {
+  for (int b = b_lo; b < b_hi; ++b) {
     const float* pv = proj + ((int64_t)b * P + p) * view_sz;
     if (!direct) {
       if constexpr (VEC4) {
@@ -250,14 +259,15 @@ __global__ __launch_bounds__(256) void backproject_tiled_kernel(
     }
     float* ob = out + (int64_t)b * out_batch_stride;
 #pragma unroll
-    for (int jj = 0; jj < BT_TJ; ++jj) {
+    for (int jn = 0; jn < NJ; ++jn) {
+      const int jj = jsub + jn * JP;
       const int j = j_base + jj;
       if (j >= W) break;
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) {
-        const int k = tid + kc * NT;
+        const int k = kt + kc * NK;
         if (k >= H) continue;
-        const TapU tx = txs[kc][jj];
+        const TapU tx = txs[kc][jn];
         const int cb = tx.i0 + BT_PAD;
         for (int ii = 0; ii < BT_TI; ++ii) {
           const int i = i_base + ii;
@@ -611,23 +621,43 @@ static int backproject_impl(const float* proj, const float* poses, float* out,
   if (int e = fill_poses(lp, poses, P)) return e;
   const int Ds = d1 - d0;
   if (out_batch_stride < (int64_t)P * Ds * W * H) return LR_EINVAL;
-  // Tiled kernel: H <= 1024 (<= 4 columns per thread) and the staged rows fit in LDS.
+  // Tiled kernel: H <= 1024 (<= 2 columns per thread of a 512-thread block) and the staged rows fit in LDS.
   const size_t tile_lds = ((size_t)BT_RCAP * (Ph + 2 * BT_PAD) + 4 * BT_TI * BT_TJ) * sizeof(float);
   if (H <= 1024 && tile_lds <= 64 * 1024) {
     const int64_t nb = (int64_t)P * ((Ds + BT_TI - 1) / BT_TI) * ((W + BT_TJ - 1) / BT_TJ);
     if (nb > 0x7fffffffLL) return LR_EINVAL;
     const bool v4 = (Ph % 4 == 0) && ((reinterpret_cast<uintptr_t>(proj) & 15u) == 0);
-    const int KC = (H + 255) / 256;
-    const dim3 grid((unsigned)nb), block(H < 256 ? (unsigned)((H + 63) / 64 * 64 < 64 ? 64 : (H + 63) / 64 * 64) : 256u);
+    // threads along a row: whole waves, at most 512; KC columns per thread (H = 384: 384 threads x 1, not 256 x 2 with a half-idle pass)
+    const int KC = (H + 511) / 512;
+    // planes side by side for short rows: the largest JP in {1, 2, 4} with JP * H <= 384 threads (H = 160 -> 2 x 160 = 320)
+    int JP = H >= 256 ? 1 : (4 * H <= 384 ? 4 : (2 * H <= 384 ? 2 : 1));
+    if (lr_sw_set(LR_SW_BP_JP)) { const int v = lr_sw_int(LR_SW_BP_JP, JP); if ((v == 1 || v == 2 || v == 4) && (v == 1 || v * H <= 384)) JP = v; }
+    if (JP * H < 64) JP = 1;   // (the tap tables are built by the first 32 threads; tiny rows keep the one-wave form)
+    // batch elements per block: short blocks fill the tail of the grid — at least ~6 blocks per resident slot (8 per CU), and
+    // not fewer than 4 elements per block (the prologue: tap tables, three barriers)
+    int bchunk = B;
+    {
+      const int64_t want = (int64_t)6 * 8 * 256;
+      int nch = (int)((want + nb - 1) / nb);
+      if (nch > (B + 3) / 4) nch = (B + 3) / 4;
+      if (nch < 1) nch = 1;
+      bchunk = (B + nch - 1) / nch;
+    }
+    if (lr_sw_set(LR_SW_BP_CHUNK)) { const int v = lr_sw_int(LR_SW_BP_CHUNK, 0); bchunk = v >= 1 && v < B ? v : B; }
+    const int nchunks = (B + bchunk - 1) / bchunk;
+    if (nchunks > 65535) return LR_EINVAL;
+    const unsigned nthr = JP > 1 ? (unsigned)(JP * H) : (unsigned)((((H + KC - 1) / KC) + 63) / 64 * 64);
+    const dim3 grid((unsigned)nb, (unsigned)nchunks), block(nthr);
     hipStream_t st = lr_stream(stream);
-#define LR_BT(KCV)                                                                                   \
+#define LR_BT(KCV, JPV)                                                                              \
   do {                                                                                               \
-    if (v4) hipLaunchKernelGGL((backproject_tiled_kernel<KCV, true>), grid, block, tile_lds, st, proj, lp, out, B, P, Pw, Ph, D, W, H, d0, Ds, out_batch_stride); \
-    else hipLaunchKernelGGL((backproject_tiled_kernel<KCV, false>), grid, block, tile_lds, st, proj, lp, out, B, P, Pw, Ph, D, W, H, d0, Ds, out_batch_stride);    \
+    if (v4) hipLaunchKernelGGL((backproject_tiled_kernel<KCV, true, JPV>), grid, block, tile_lds, st, proj, lp, out, B, P, Pw, Ph, D, W, H, d0, Ds, out_batch_stride, bchunk); \
+    else hipLaunchKernelGGL((backproject_tiled_kernel<KCV, false, JPV>), grid, block, tile_lds, st, proj, lp, out, B, P, Pw, Ph, D, W, H, d0, Ds, out_batch_stride, bchunk);    \
   } while (0)
-    if (KC == 1) LR_BT(1);
-    else if (KC == 2) LR_BT(2);
-    else LR_BT(4);
+    if (JP == 4) LR_BT(1, 4);
+    else if (JP == 2) LR_BT(1, 2);
+    else if (KC == 1) LR_BT(1, 1);
+    else LR_BT(2, 1);
 #undef LR_BT
     return lr_launch_status();
   }

@@ -49,6 +49,8 @@ enum LrSwitch {
   LR_SW_DGRAD_BLOCKS,   // LIFTREG_DGRAD_BLOCKS: persistent blocks of the data-gradient kernels
   LR_SW_FUSED_BWD_BLOCKS,   // LIFTREG_FUSED_BWD_BLOCKS: persistent blocks of the fused dgrad1 + wgrad0 kernel
   LR_SW_REG_BWD_BLOCKS,   // LIFTREG_REG_BWD_BLOCKS: block cap of the regulariser's gradient kernel
+  LR_SW_BP_CHUNK,   // LIFTREG_BP_CHUNK: batch elements per block of the tiled backprojection (default: chosen from the grid size; 0 = the whole batch)
+  LR_SW_BP_JP,   // LIFTREG_BP_JP: planes a block of the tiled backprojection works on side by side (1 | 2 | 4; default: by row length)
   LR_SW_COUNT
 };
 #define LR_SW_UNSET (-2147483647 - 1)

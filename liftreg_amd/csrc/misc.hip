@@ -57,7 +57,9 @@ const char* const kSwitchNames[LR_SW_COUNT] = {
     "LIFTREG_BF16_MARCH_ZC",
     "LIFTREG_DGRAD_BLOCKS",
     "LIFTREG_FUSED_BWD_BLOCKS",
-    "LIFTREG_REG_BWD_BLOCKS"
+    "LIFTREG_REG_BWD_BLOCKS",
+    "LIFTREG_BP_CHUNK",
+    "LIFTREG_BP_JP"
 };
 std::atomic<int> g_sw[LR_SW_COUNT];
 std::once_flag g_sw_once;

@@ -194,6 +194,30 @@ def test_backproject_into_concat_buffer_and_ragged(ops, dev):
         assert bool((buf[:, 0] == -7.0).all())                                     # channel 0 untouched
 
 
+def test_backproject_batch_chunks_and_side_by_side_planes_keep_the_bits(ops, dev, monkeypatch):
+    """lr_backproject_f32's tiled kernel deals the batch to blocks in chunks (blockIdx.y) and, for rows shorter than 256
+    voxels, works on 2 or 4 planes of its tile side by side: every split (LIFTREG_BP_CHUNK, LIFTREG_BP_JP) writes the bits of
+    the C oracle — incl. the reference's shipped row length 160 (JP = 2: 320 threads), ragged tiles and a chunk that does not
+    divide the batch."""
+    rs = np.random.RandomState(31)
+    for (D, W, H), (Pw, Ph), P, B in (((11, 10, 160), (18, 240), 4, 7), ((9, 6, 96), (12, 100), 2, 5), ((10, 9, 40), (14, 44), 3, 4),
+                                      ((8, 5, 256), (12, 256), 2, 3)):
+        proj = rs.uniform(-1, 1, (B, P, Pw, Ph)).astype(np.float32)
+        poses = ro.scan_poses(30, P, W).astype(np.float32)
+        want = co.backproject(proj, poses, (D, W, H))
+        for chunk in (None, "0", "1", "3"):
+            for jp in (None, "1", "2", "4"):
+                for name, v in (("LIFTREG_BP_CHUNK", chunk), ("LIFTREG_BP_JP", jp)):
+                    if v is None:
+                        monkeypatch.delenv(name, raising=False)
+                    else:
+                        monkeypatch.setenv(name, v)
+                got = ops.backproject(T(proj, dev), poses, (D, W, H)).cpu().numpy()
+                assert np.array_equal(got, want), ((D, W, H), chunk, jp)
+    monkeypatch.delenv("LIFTREG_BP_CHUNK", raising=False)
+    monkeypatch.delenv("LIFTREG_BP_JP", raising=False)
+
+
 # ------------------------------------------------------------------------------------- K6/K7 warp
 @pytest.mark.parametrize("tag", ["warp_a", "warp_b"])
 def test_warp_golden(golden, ops, dev, tag):
