@@ -387,11 +387,16 @@ int lr_internal_conv_rows_wlds(const float* in, const float* packed_w, const flo
   if ((Cin != 16 && Cin != 32) || (Cout != 16 && Cout != 32) || (H & 1)) return LR_EUNSUPPORTED;
   // Small planes (blocks 3..5 of the encoder: 32^2 outputs per plane and less) stay with conv3d.hip's direct kernels: a few
   // hundred tiles cannot amortise the per-block fragment staging and the serial 27/54-row walk (measured at C3: 0.14 /
-  // 0.07 / 0.07 ms here against 0.12 / 0.03 / 0.03 ms).  The rule looks at the PLANE only, so a z-slab of a volume takes
-  // the same kernel as the whole volume (the sharded model is bit-identical to the unsharded one).
+  // 0.07 / 0.07 ms here against 0.12 / 0.03 / 0.03 ms).  The rule never looks at the DEPTH, so a z-slab of a volume takes
+  // the same kernel as the whole volume.
   // Round 5: large batches amortise the staging on smaller planes too — the reference's shipped configuration (B = 30): 80^3 ->
-  // 40^3 0.98 -> 0.84 ms, 40^3 -> 20^3 0.169 -> 0.148 ms here; 20^3 -> 10^3 0.033 -> 0.074 (stays direct).  Batch x plane, not the
-  // depth: every z-slab of a sharded batch still takes the kernel of the whole volume.
+  // 40^3 0.98 -> 0.84 ms, 40^3 -> 20^3 0.169 -> 0.148 ms here; 20^3 -> 10^3 0.033 -> 0.074 (stays direct).
+  // CONSEQUENCE (documented in INTEGRATION.md, "batch-dependent kernel choice"): on planes of 400 .. 4095 outputs the choice
+  // depends on the BATCH SIZE of the call, and the two kernels round differently (Winograd F(2,2) rows vs the direct fmaf chain,
+  // both within 1e-6 of an fp64 convolution): a sample's encoder output can differ in the last bits between a full batch and a
+  // smaller last batch (160^3: Winograd for B >= 7 on the 40^2 planes), and a caller that splits a batch into groups (the
+  // sharded forward's exchange form) may land on the other kernel than the unsharded model.  LIFTREG_CONV_DIRECT=1 or
+  // LIFTREG_CONV_ROWS_ALWAYS=1 pins one kernel for every batch size (reproducible evaluation).
   {
     const int64_t plane = (int64_t)((W - 1) / 2 + 1) * ((H - 1) / 2 + 1);
     if (plane < 4096 && !(plane >= 400 && (int64_t)B * plane >= 10000) && !lr_sw_set(LR_SW_CONV_ROWS_ALWAYS)) return LR_EUNSUPPORTED;

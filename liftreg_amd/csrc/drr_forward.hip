@@ -355,7 +355,7 @@ __global__ __launch_bounds__(1024) void drr_forward_fast_kernel(
         tp[6] = __builtin_bit_cast(float, q11.x); tp[7] = __builtin_bit_cast(float, q11.y);
 #pragma unroll
         for (int t8 = 0; t8 < 8; t8 += 2) mu_of_fast2(tp[t8], tp[t8 + 1]);
-        edge = (unsigned)z0 > (unsigned)(Dn - 2) || (unsigned)y0 > (unsigned)(W - 2) || shift != 0;
+        edge = (unsigned)z0 > (unsigned)(Dn - 2) || (unsigned)y0 > (unsigned)(W - 2) || shift != 0;   // Dn >= 2, W >= 2: the launcher's conditions
       } else {
         const int r0 = FLIP ? (W - 1 - y0) : y0, r1 = FLIP ? r0 - 1 : r0 + 1;
         const int yo0 = ((unsigned)y0 < (unsigned)W) ? __mul24(r0, H) : OUTSIDE;
@@ -497,7 +497,8 @@ static int drr_forward_impl(const float* vol_slab, int64_t vol_batch_stride, con
   const size_t lds = (size_t)R * 64 * sizeof(float);
   const bool hu = flags & LR_DRR_HU_INPUT, flip = flags & LR_DRR_FLIP_W;
   const int64_t sD64 = (int64_t)W * H;
-  if (H >= 2 && (int64_t)(d1 - d0) * sD64 * 4 + sD64 * 8 <= 0x80000000LL && sD64 < (1 << 23) &&
+  // (HU input of a ONE-plane slab: the fast kernel's z-edge test `(unsigned)z0 > (unsigned)(Dn - 2)` would wrap — the general kernel)
+  if (H >= 2 && (int64_t)(d1 - d0) * sD64 * 4 + sD64 * 8 <= 0x80000000LL && sD64 < (1 << 23) && (!hu || d1 - d0 >= 2) &&
       !lr_sw_set(LR_SW_DRR_GENERAL)) {
     const FastDiv fD = make_fastdiv(D), fW = make_fastdiv(W - 1), fH = make_fastdiv(H);
     const bool fd = fastdiv_ok(D) && fastdiv_ok(W - 1) && fastdiv_ok(H);

@@ -306,17 +306,18 @@ class model(nn.Module):
     def _packed_weight(self, i, bf16=False):
         blk = self.encoders[i]
         w = blk.conv.weight
-        # the cache holds the weight TENSOR it was packed from and compares identity + version: an address-based key would
-        # accept a replaced Parameter that landed on the freed address with the same version counter
+        # the cache holds the weight TENSOR it was packed from and compares identity + version (an address-only key would accept a
+        # replaced Parameter that landed on the freed address with the same version counter) AND storage address + device: a
+        # rebind through `.data` (`p.data = ema_tensor`, the usual EMA swap-in for evaluation) keeps identity and version
         hit = self._packed.get((i, bf16))
         if self.training and w.requires_grad:
             hit = None                       # training: never trust the cache (see invalidate_packed)
-        if hit is None or hit[0] is not w or hit[1] != w._version:
+        if hit is None or hit[0] is not w or hit[1] != (w._version, w.data_ptr(), w.device):
             if bf16:
                 pk = ops.conv3d_pack_weights_bf16_planar(w) if i == 0 else ops.conv3d_pack_weights_bf16(w)
             else:
                 pk = ops.conv3d_pack_weights(w, blk.in_layout)
-            hit = (w, w._version, pk)
+            hit = (w, (w._version, w.data_ptr(), w.device), pk)
             self._packed[(i, bf16)] = hit
         return hit[2]
 
@@ -326,8 +327,9 @@ class model(nn.Module):
         hit = self._packed.get("pair01")
         if self.training and (w0.requires_grad or w1.requires_grad):
             hit = None
-        if hit is None or hit[0] is not w0 or hit[1] is not w1 or hit[2] != (w0._version, w1._version):
-            hit = (w0, w1, (w0._version, w1._version), ops.conv3d_pair01_pack(w0, w1))
+        key = (w0._version, w1._version, w0.data_ptr(), w1.data_ptr(), w0.device)
+        if hit is None or hit[0] is not w0 or hit[1] is not w1 or hit[2] != key:
+            hit = (w0, w1, key, ops.conv3d_pair01_pack(w0, w1))
             self._packed["pair01"] = hit
         return hit[3]
 

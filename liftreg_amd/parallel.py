@@ -497,9 +497,9 @@ class SlabShardedRegistration:
         # of the replicated layer: lr_linear_lrelu_f32 reduces every neuron on its own) — and the (B, 800/world) pieces meet in one
         # small all-gather; layers 2 and 3 (0.9 MB) run replicated.
         head = net.encoders[6]
-        fc1 = head[1]
-        O1 = fc1.fc.out_features
-        if comm.world > 1 and O1 % comm.world == 0 and len(head) == 4:
+        fc1 = head[1] if (len(head) == 4 and hasattr(head[1], "fc")) else None     # (another head shape: the replicated fallback)
+        O1 = fc1.fc.out_features if fc1 is not None else 0
+        if comm.world > 1 and fc1 is not None and O1 % comm.world == 0:
             per = O1 // comm.world
             pieces = [ops.linear_lrelu(f.contiguous().flatten(1), fc1.fc.weight[r * per:(r + 1) * per], fc1.fc.bias[r * per:(r + 1) * per],
                                        fc1._slope) for r, f in zip(comm.ranks, feats)]

@@ -422,6 +422,22 @@ def test_fuzz_warp_variants_and_slabs(dev):
             a = ops.drr_forward(T(vol[:cut], dev), poses, (Rd, Rh), sp, d0=0, d1=cut, full_D=D, nseg=1)
             b = ops.drr_forward(T(vol[cut:], dev), poses, (Rd, Rh), sp, d0=cut, d1=D, full_D=D, nseg=1)
             np.testing.assert_allclose((a + b).cpu().numpy(), full.cpu().numpy(), rtol=2e-5, atol=1e-6, err_msg=str(("drr slabs", shape, cut)))
+        # HU input (the HU -> mu conversion folded into the tap loads), cut into slabs incl. ONE-plane slabs (the fast
+        # kernel's z-edge test wrapped for a 1-plane slab and summed converted zeros, 0.2 each): every slab = the mu-input slab of
+        # the converted volume bit for bit, and the slabs add up to the whole
+        hu = rs.uniform(-1100, 400, shape).astype(np.float32)
+        flip = bool(rs.randint(0, 2))
+        mu = ops.hu_to_mu(T(hu, dev))
+        full_hu = ops.drr_forward(T(hu, dev), poses, (Rd, Rh), sp, nseg=1, hu_input=True, flip_w=flip)
+        assert torch.equal(full_hu, ops.drr_forward(mu, poses, (Rd, Rh), sp, nseg=1, flip_w=flip))
+        tot = torch.zeros_like(full_hu)
+        cuts = sorted({0, D, int(rs.randint(0, D + 1)), min(D, int(rs.randint(0, D + 1)) + 1)} | ({1, D - 1} if D >= 2 else set()))
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            part = ops.drr_forward(T(hu[lo:hi], dev), poses, (Rd, Rh), sp, d0=lo, d1=hi, full_D=D, nseg=1, hu_input=True, flip_w=flip)
+            want_p = ops.drr_forward(mu[lo:hi].contiguous(), poses, (Rd, Rh), sp, d0=lo, d1=hi, full_D=D, nseg=1, flip_w=flip)
+            assert torch.equal(part, want_p), ("drr HU slab", shape, lo, hi, flip)
+            tot += part
+        np.testing.assert_allclose(tot.cpu().numpy(), full_hu.cpu().numpy(), rtol=2e-5, atol=1e-6, err_msg=str(("drr HU slabs", shape, cuts)))
 
 
 def test_fuzz_small_backward_ops(dev):

@@ -62,3 +62,27 @@ def test_slab_sharded_forward_equals_unsharded(n, world, conv_dtype):
         assert abs(float(out["sim_loss"]) - float(ref_loss)) < 2e-7        # (fp64 moments summed in another order)
     with pytest.raises(ValueError):
         par.SlabShardedRegistration(net, par.LocalComm(5 if n == 384 else 3))     # planes per rank: a multiple of slab_multiple(net)
+
+
+@pytest.mark.parametrize("procs,n,conv_dtype", [(2, 128, "fp32"), (4, 128, "fp32"), (2, 128, "bf16")])
+def test_slab_sharding_across_real_processes_on_one_gpu(procs, n, conv_dtype):
+    """The sharded forward in SEPARATE processes joined by torch.distributed (parallel.DistComm, not the one-process LocalComm
+    of the tests above): tools/shard_bench.py --procs N starts N fresh children that all sit on cuda:0 (RCCL refuses several
+    ranks on one device — 'Duplicate GPU detected' — so the group is gloo and DistComm stages through the host; over RCCL the
+    same calls carry device pointers).  Every rank asserts its slab == the rows of its own unsharded forward, bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    views = "11" if conv_dtype == "bf16" else "2"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "shard_bench.py"), "--procs", str(procs), "--n", str(n), "--batch", "2",
+                        "--views", views, "--conv-dtype", conv_dtype, "--backend", "gloo", "--iters", "2"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    summary = rows[-1]
+    assert summary["procs"] == procs and summary["backend"] == "gloo" and summary["slabs_equal_unsharded"] is True
+    ranks = [x for x in rows if "rank" in x]
+    assert sorted(x["rank"] for x in ranks) == list(range(procs)) and all(x["slab_equals_unsharded"] for x in ranks)
+    assert [x["rows"] for x in sorted(ranks, key=lambda x: x["rank"])] == [[i * n // procs, (i + 1) * n // procs] for i in range(procs)]
