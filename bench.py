@@ -515,6 +515,9 @@ def main():
                     help="replay the step from one captured HIP graph (launch-bound small configs c1/c2); the "
                          "per-kernel table then comes from one extra eager step outside the timed region")
     args = ap.parse_args()
+    if (args.conv0_split or args.fuse_bp) and not os.environ.get("LIFTREG_HIP_LIB"):
+        sys.exit("--conv0-split / --fuse-bp time EXPERIMENTAL kernels: build them (make -C liftreg_amd/csrc exp) and set "
+                 "LIFTREG_HIP_LIB=liftreg_amd/csrc/libliftreg_hip_exp.so")
     if args.conv0_split:
         os.environ["LIFTREG_CONV0_SPLIT"] = "1"   # set before the library's first launch (switches are read once per process)
         args.no_pair01 = True                     # the pair kernel would run in front of it: the split block is what this flag measures

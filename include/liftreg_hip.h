@@ -59,8 +59,6 @@ const char* lr_target_arch(void);
  *   LIFTREG_HIP_DEBUG              print the HIP error text of a failed launch to stderr
  *   LIFTREG_CONV_DIRECT            stride-2 fp32 blocks: the direct row walk = the oracle's fmaf chain bit for bit (default: Winograd F(2,2) rows kernel)
  *   LIFTREG_CONV0_DIRECT           first fp32 block: the direct sweep = the oracle's fmaf chain (default: Winograd F(2,3) along H)
- *   LIFTREG_CONV0_SPLIT            first fp32 block alone on the bf16 MFMA with exact 3-way operand splits (conv0_split_f32.hip; A/B aid — the model's default is the fused pair kernel)
- *   LIFTREG_CONV0_PC               first fp32 block as the producer/consumer kernel (conv0_pc.hip; same bits)
  *   LIFTREG_CONV_TAPMAJOR          stride-2 blocks: the tap-major kernel instead of the row kernels (same bits as the direct walk)
  *   LIFTREG_CONV_ROWS_ALWAYS       persistent Winograd rows kernel also on planes below 64 x 64 outputs (tests)
  *   LIFTREG_CONV0_BF16_CL          bf16 first block: the all-channels brick kernel also for <= 3 channels
@@ -91,6 +89,8 @@ const char* lr_target_arch(void);
  *   LIFTREG_DGRAD_BLOCKS           persistent blocks of the data-gradient kernels
  *   LIFTREG_FUSED_BWD_BLOCKS       persistent blocks of the fused dgrad1 + wgrad0 kernel
  *   LIFTREG_REG_BWD_BLOCKS         block cap of the regulariser's gradient kernel
+ *   LIFTREG_FUSED_BWD_NZ           4: the fused dgrad1 + wgrad0 kernel's 4-plane tiles for <= 3 input channels too (default 8; A/B aid, same results up to summation order)
+ *   LIFTREG_FUSED_BWD_SPLIT        the fused dgrad1 + wgrad0 kernel's weight-gradient half on exact 3-way bf16 splits (1) or on the fp32 MFMA (0)
  *   LIFTREG_BP_CHUNK               batch elements per block of the tiled backprojection (0 = the whole batch; same bits)
  *   LIFTREG_BP_JP                  planes a backprojection block works on side by side (1 | 2 | 4; same bits)
  */
@@ -492,16 +492,6 @@ int lr_conv3d_pair01_train_f32(const float* in0, int64_t in0_batch_stride, const
                                uint8_t* mask0, int B, int Cin, int D, int W, int H, int mid_layout, int out_layout,
                                float slope0, float slope1, void* stream);
 
-/* f1 (SURVEY 8, "backproject -> conv0: never write the P*V volume"): the same first block with the backprojection
- * computed INSIDE its staging.  Channel 0 = in0 (B,1,D,W,H), channels 1..P = the backprojection of proj (B,P,Pw,Ph)
- * for `poses` (host, P x 3 fp32, ONE geometry for the batch, …Backproj.py:85-87) — sample for sample the arithmetic
- * of lr_backproject_f32 (sdct_projection_utils.py:227-250 + F.grid_sample 2-D, …Backproj.py:89-93), gathered from the
- * views (L2-resident).  Output bits = lr_backproject_f32 followed by lr_conv3d_first_split_f32; the (B,P,D,W,H)
- * feature volume is never written or read.  P in {1,2}, H % 4 == 0, in0 16-byte aligned, Cout = 16 — otherwise
- * LR_EUNSUPPORTED and the caller runs the two kernels. */
-int lr_conv3d_first_fused_bp_f32(const float* in0, const float* proj, const float* poses, const float* packed_w,
-                                 const float* bias, float* out, int B, int P, int Pw, int Ph, int Cout, int D, int W, int H,
-                                 int out_layout, float negative_slope, void* stream);
 
 /* ---- f1: PCA reconstruction + identity + trilinear warp in ONE pass (the model's decode half in inference).
  * Replaces the sequence …Backproj.py:102 (F.linear with the PCA basis) → :68 (disp + id) → :69 (Bilinear warp) and
@@ -607,6 +597,30 @@ int lr_label_overlap_f32(const float* pred, const float* gt, float label, int64_
                          int64_t* counts, void* stream);
 int lr_jacobi_det_stats_f32(const float* map, int B, int D, int W, int H, float sp0, float sp1, float sp2,
                             double* partial, int nblk, double* out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * EXPERIMENTAL — not part of the product build.  `make -C liftreg_amd/csrc exp` compiles the library with -DLR_EXPERIMENTAL
+ * (plus conv0_pc.hip) into libliftreg_hip_exp.so; LIFTREG_HIP_LIB=<that file> makes liftreg_amd load it (tests of these paths
+ * skip on the product library).  Both paths are bit-tested against the default ones and were measured no faster:
+ *   - the backprojection computed inside block 0's staging (conv0_pc.hip): slower than lr_backproject_f32 + the fused pair
+ *     kernel since round 2;
+ *   - the first fp32 block alone on exact bf16 splits (the fp32 route of conv0_split_f32.hip): superseded by the pair kernel.
+ * Switches read only by the experimental build:
+ *   LIFTREG_CONV0_SPLIT            first fp32 block alone on the bf16 MFMA with exact 3-way operand splits (conv0_split_f32.hip)
+ *   LIFTREG_CONV0_PC               first fp32 block as the producer/consumer kernel (conv0_pc.hip; same bits)
+ */
+#ifdef LR_EXPERIMENTAL
+/* f1 (SURVEY 8, "backproject -> conv0: never write the P*V volume"): the same first block with the backprojection
+ * computed INSIDE its staging.  Channel 0 = in0 (B,1,D,W,H), channels 1..P = the backprojection of proj (B,P,Pw,Ph)
+ * for `poses` (host, P x 3 fp32, ONE geometry for the batch, …Backproj.py:85-87) — sample for sample the arithmetic
+ * of lr_backproject_f32 (sdct_projection_utils.py:227-250 + F.grid_sample 2-D, …Backproj.py:89-93), gathered from the
+ * views (L2-resident).  Output bits = lr_backproject_f32 followed by lr_conv3d_first_split_f32; the (B,P,D,W,H)
+ * feature volume is never written or read.  P in {1,2}, H % 4 == 0, in0 16-byte aligned, Cout = 16 — otherwise
+ * LR_EUNSUPPORTED and the caller runs the two kernels. */
+int lr_conv3d_first_fused_bp_f32(const float* in0, const float* proj, const float* poses, const float* packed_w,
+                                 const float* bias, float* out, int B, int P, int Pw, int Ph, int Cout, int D, int W, int H,
+                                 int out_layout, float negative_slope, void* stream);
+#endif /* LR_EXPERIMENTAL */
 
 #ifdef __cplusplus
 }

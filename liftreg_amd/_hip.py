@@ -10,7 +10,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libliftreg_hip.so")
+# LIFTREG_HIP_LIB: another build of the SAME library (the experimental one, `make -C liftreg_amd/csrc exp`; A/B variants)
+LIB_PATH = os.environ.get("LIFTREG_HIP_LIB") or os.path.join(CSRC, "libliftreg_hip.so")
 
 LR_OK = 0
 LAYOUT_NCDHW, LAYOUT_NDHWC, LAYOUT_NDHWC_HPS = 0, 1, 2
@@ -59,7 +60,6 @@ SIGNATURES = {
     "lr_conv3d_pair01_f32": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _i64, _p]),
     "lr_conv3d_pair01_train_f32": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p]),
     "lr_conv3d_pair01_slab_f32": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _i64, _i, _i, _i, _i, _p]),
-    "lr_conv3d_first_fused_bp_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "lr_pca_warp_f32": (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _i, _i64, _i, _p]),
     "lr_pca_warp_bf16basis_f32": (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _i, _i64, _i, _p]),
     "lr_pca_warp_slab_f32": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i,
@@ -102,6 +102,12 @@ SIGNATURES = {
 }
 
 
+# the `#ifdef LR_EXPERIMENTAL` section of the header: bound only when the loaded library exports them (`make exp`)
+EXPERIMENTAL_SIGNATURES = {
+    "lr_conv3d_first_fused_bp_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+}
+
+
 class LiftRegHipError(RuntimeError):
     pass
 
@@ -134,10 +140,19 @@ def lib():
             fn = getattr(handle, name)  # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in EXPERIMENTAL_SIGNATURES.items():
+            if hasattr(handle, name):
+                fn = getattr(handle, name)
+                fn.restype, fn.argtypes = res, args
         if handle.lr_target_arch() != b"gfx950":
             raise LiftRegHipError("libliftreg_hip.so was not built for gfx950")
         _lib = handle
     return _lib
+
+
+def has_experimental():
+    """True when the loaded library is the experimental build (include/liftreg_hip.h, last section)."""
+    return all(hasattr(lib(), n) for n in EXPERIMENTAL_SIGNATURES)
 
 
 def reload_switches():

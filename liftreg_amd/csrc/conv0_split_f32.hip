@@ -578,12 +578,14 @@ static int launch_march(const float* in0, long long bs0, const float* in_rest, l
   return lr_launch_status();
 }
 
+#ifdef LR_EXPERIMENTAL   // the fp32 route of this kernel (three splits, fp32 output): superseded by conv01_fused.hip; `make exp` only
 int lr_internal_conv0_split_f32(const float* in0, long long bs0, const float* in_rest, long long bsr, const float* packed,
                                 const float* bias, float* out, int B, int Cin, int D, int W, int H, int out_layout, float slope,
                                 long long out_bs, hipStream_t st) {
   if (out_layout != LR_LAYOUT_NDHWC && out_layout != LR_LAYOUT_NDHWC_HPS) return LR_EUNSUPPORTED;
   return launch_march<3, false>(in0, bs0, in_rest, bsr, packed, bias, out, B, Cin, D, W, H, out_layout == LR_LAYOUT_NDHWC_HPS, slope, out_bs, st);
 }
+#endif
 
 // The 3-channel (Cin <= 4) first block of the bf16 variant: `in` is (B,Cin,D,W,H) fp32, `out` bf16 channels-last records;
 // `packed` = the buffer of lr_internal_conv0_split_pack (its first split IS the nearest-even bf16 weight).

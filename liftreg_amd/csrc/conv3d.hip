@@ -1105,6 +1105,7 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
     // LIFTREG_CONV0_SPLIT=1: conv0_split_f32.hip — the same block on the bf16 MFMA with exact three-way bf16 splits of its
     // fp32 operands (a direct conv, half the rounding error of the Winograd sweep).  Measured equal to the fp32-MFMA
     // Winograd kernel below at C3 (2.9-3.1 vs 3.0 ms: DESIGN.md §6·6), so it is NOT the default.
+#ifdef LR_EXPERIMENTAL   // (make exp: superseded by the fused pair kernel, kept as an A/B aid outside the product build)
     if (!bpa && !mask_out && stride == 1 && NT == 1 && Cin <= 4 && lr_sw_on(LR_SW_CONV0_SPLIT) && !lr_sw_set(LR_SW_CONV0_DIRECT) &&
         (out_layout == LR_LAYOUT_NDHWC || out_layout == LR_LAYOUT_NDHWC_HPS)) {
       const int64_t V = (int64_t)D * W * H;
@@ -1115,6 +1116,7 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
                                                        out_layout, negative_slope, d.out_bs, st);
       if (rc != LR_EUNSUPPORTED) return rc;
     }
+#endif
     int64_t resident = 256 * (single ? 3 : 2);  // persistent blocks per CU (registers: <=168 | <=256 per lane)
     if (single && !lr_sw_set(LR_SW_CONV0_DIRECT) && Cin <= 3 && stride == 1 && NT == 1 && (out_layout == LR_LAYOUT_NDHWC || out_layout == LR_LAYOUT_NDHWC_HPS))
       resident = 256 * LR_C0_WINO_BLOCKS;  // the Winograd instance (<=128 registers)
@@ -1134,6 +1136,7 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
     // conv0_pc.hip: the same block as a producer/consumer kernel with a double-buffered brick.  It carries the fused
     // backprojection (f1); for plain inputs it measured equal to the single-buffer kernel below (3.31-3.34 vs 3.29-3.30 ms
     // at C3, same bits), which therefore stays the default — LIFTREG_CONV0_PC=1 selects it (A/B aid).
+#ifdef LR_EXPERIMENTAL   // (make exp: conv0_pc.hip is not part of the product build — measured slower since round 2)
     const bool pc_on = bpa || (lr_sw_on(LR_SW_CONV0_PC));
     if (pc_on && d.out_bs == dense_bs && d.in0_bs == (long long)D * W * H && stride == 1 && NT == 1 && single && vec4 &&
         (out_layout == LR_LAYOUT_NDHWC || out_layout == LR_LAYOUT_NDHWC_HPS)) {
@@ -1150,6 +1153,7 @@ static int conv_impl(const float* in, const float* in0, const float* packed_w, c
                                   negative_slope, nullptr, nullptr, 0, 0, 0, st);
       if (rc != LR_EUNSUPPORTED || bpa) return rc;
     }
+#endif
     if (bpa) return LR_EUNSUPPORTED;
     // the Winograd F(2,3)-along-H sweep (default for the model's first block); LIFTREG_CONV0_DIRECT=1 selects the direct
     // sweep (the exact fmaf chain of the oracle; A/B aid)
@@ -1276,6 +1280,7 @@ extern "C" int lr_conv3d_first_split_obs_f32(const float* in0, int64_t in0_batch
 // 1..P = the backprojection of `proj` (B,P,Pw,Ph) for the emitter poses (host, P x 3 floats), sample for sample the
 // arithmetic of lr_backproject_f32.  Same bits as lr_backproject_f32 + lr_conv3d_first_split_f32.  P in {1,2},
 // H % 4 == 0, 16-byte aligned in0; otherwise LR_EUNSUPPORTED (the caller runs the two kernels).
+#ifdef LR_EXPERIMENTAL
 extern "C" int lr_conv3d_first_fused_bp_f32(const float* in0, const float* proj, const float* poses, const float* packed_w,
                                             const float* bias, float* out, int B, int P, int Pw, int Ph, int Cout, int D,
                                             int W, int H, int out_layout, float negative_slope, void* stream) {
@@ -1286,3 +1291,4 @@ extern "C" int lr_conv3d_first_fused_bp_f32(const float* in0, const float* proj,
   return conv_impl(nullptr, in0, packed_w, bias, out, B, P + 1, Cout, D, W, H, 1, LR_LAYOUT_NCDHW, out_layout, negative_slope,
                    stream, &a);
 }
+#endif

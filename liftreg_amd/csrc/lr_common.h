@@ -17,8 +17,6 @@ enum LrSwitch {
   LR_SW_HIP_DEBUG,   // LIFTREG_HIP_DEBUG: print the HIP error text of a failed launch to stderr
   LR_SW_CONV_DIRECT,   // LIFTREG_CONV_DIRECT: stride-2 fp32 blocks: the direct row walk = the oracle's fmaf chain bit for bit (default: Winograd F(2,2) rows kernel)
   LR_SW_CONV0_DIRECT,   // LIFTREG_CONV0_DIRECT: first fp32 block: the direct sweep = the oracle's fmaf chain (default: Winograd F(2,3) along H)
-  LR_SW_CONV0_SPLIT,   // LIFTREG_CONV0_SPLIT: first fp32 block alone on the bf16 MFMA with exact 3-way operand splits (conv0_split_f32.hip; A/B aid — the model's default is the fused pair kernel)
-  LR_SW_CONV0_PC,   // LIFTREG_CONV0_PC: first fp32 block as the producer/consumer kernel (conv0_pc.hip; same bits)
   LR_SW_CONV_TAPMAJOR,   // LIFTREG_CONV_TAPMAJOR: stride-2 blocks: the tap-major kernel instead of the row kernels (same bits as the direct walk)
   LR_SW_CONV_ROWS_ALWAYS,   // LIFTREG_CONV_ROWS_ALWAYS: persistent Winograd rows kernel also on planes below 64 x 64 outputs (tests)
   LR_SW_CONV0_BF16_CL,   // LIFTREG_CONV0_BF16_CL: bf16 first block: the all-channels brick kernel also for <= 3 channels
@@ -49,8 +47,14 @@ enum LrSwitch {
   LR_SW_DGRAD_BLOCKS,   // LIFTREG_DGRAD_BLOCKS: persistent blocks of the data-gradient kernels
   LR_SW_FUSED_BWD_BLOCKS,   // LIFTREG_FUSED_BWD_BLOCKS: persistent blocks of the fused dgrad1 + wgrad0 kernel
   LR_SW_REG_BWD_BLOCKS,   // LIFTREG_REG_BWD_BLOCKS: block cap of the regulariser's gradient kernel
+  LR_SW_FUSED_BWD_NZ,   // LIFTREG_FUSED_BWD_NZ: 4: the fused dgrad1 + wgrad0 kernel's 4-plane tile form (two waves per quotient plane) for <= 3 input channels too (default 8; 4 / 5 channels always 4)
+  LR_SW_FUSED_BWD_SPLIT,   // LIFTREG_FUSED_BWD_SPLIT: the fused dgrad1 + wgrad0 kernel's weight-gradient half on exact bf16 splits (1) or on the fp32 MFMA (0)
   LR_SW_BP_CHUNK,   // LIFTREG_BP_CHUNK: batch elements per block of the tiled backprojection (default: chosen from the grid size; 0 = the whole batch)
   LR_SW_BP_JP,   // LIFTREG_BP_JP: planes a block of the tiled backprojection works on side by side (1 | 2 | 4; default: by row length)
+#ifdef LR_EXPERIMENTAL   // (make exp)
+  LR_SW_CONV0_SPLIT,   // LIFTREG_CONV0_SPLIT: first fp32 block alone on the bf16 MFMA with exact 3-way operand splits (conv0_split_f32.hip; A/B aid — the model's default is the fused pair kernel)
+  LR_SW_CONV0_PC,   // LIFTREG_CONV0_PC: first fp32 block as the producer/consumer kernel (conv0_pc.hip; same bits)
+#endif
   LR_SW_COUNT
 };
 #define LR_SW_UNSET (-2147483647 - 1)

@@ -26,8 +26,6 @@ const char* const kSwitchNames[LR_SW_COUNT] = {
     "LIFTREG_HIP_DEBUG",
     "LIFTREG_CONV_DIRECT",
     "LIFTREG_CONV0_DIRECT",
-    "LIFTREG_CONV0_SPLIT",
-    "LIFTREG_CONV0_PC",
     "LIFTREG_CONV_TAPMAJOR",
     "LIFTREG_CONV_ROWS_ALWAYS",
     "LIFTREG_CONV0_BF16_CL",
@@ -58,8 +56,14 @@ const char* const kSwitchNames[LR_SW_COUNT] = {
     "LIFTREG_DGRAD_BLOCKS",
     "LIFTREG_FUSED_BWD_BLOCKS",
     "LIFTREG_REG_BWD_BLOCKS",
+    "LIFTREG_FUSED_BWD_NZ",
+    "LIFTREG_FUSED_BWD_SPLIT",
     "LIFTREG_BP_CHUNK",
-    "LIFTREG_BP_JP"
+    "LIFTREG_BP_JP",
+#ifdef LR_EXPERIMENTAL
+    "LIFTREG_CONV0_SPLIT",
+    "LIFTREG_CONV0_PC",
+#endif
 };
 std::atomic<int> g_sw[LR_SW_COUNT];
 std::once_flag g_sw_once;

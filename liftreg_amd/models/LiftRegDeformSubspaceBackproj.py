@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ops, ops_bwd
+from .. import _hip, ops, ops_bwd
 from ..autograd import ConvPair01Fn, DecodeFn, EncoderBf16Fn
 from ..layers.layers import convBlock, FullyConnectBlock, GaussianSmoothing
 from ..utils.net_utils import Bilinear, identity_axis_tables
@@ -145,7 +145,12 @@ class model(nn.Module):
         # matrix pipe, its 4x4x64 bricks recompute every sample 2.5x (window halo), and the vector-ALU work of those
         # samples takes issue slots from the MFMAs — 4.05 ms fused vs 3.31 + 0.27 ms as two kernels.
         # Worth it where HBM capacity/traffic matters more than the 4 % (the volume is 1.08 GB per batch of 8).
+        # EXPERIMENTAL since round 6: the kernel is only in the `make exp` build of the library (include/liftreg_hip.h, last
+        # section; LIFTREG_HIP_LIB selects it) — asking for it on the product library is an error, not a silent two-kernel run.
         self.fuse_backproject = bool(_opt(opt, "fuse_backproject", False))
+        if self.fuse_backproject and not _hip.has_experimental():
+            raise _hip.LiftRegHipError("fuse_backproject needs the experimental build of libliftreg_hip (make -C liftreg_amd/csrc exp; "
+                                       "LIFTREG_HIP_LIB=<libliftreg_hip_exp.so>)")
         # optional (non-reference) key "fuse_first_backward" (default True): in fp32 training the first two encoder blocks
         # are one autograd node whose backward computes block 1's data gradient and block 0's weight gradient in one kernel
         # (autograd.ConvPair01Fn); False = one node per block (the gradient between them goes through memory)

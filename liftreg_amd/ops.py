@@ -546,8 +546,9 @@ def conv3d_pair01_train(x, w0, b0, w1, b1, *, mid_layout=LAYOUT_NDHWC_HPS, out_l
 
 
 def conv3d_first_fused_bp_supported(x0, proj):
-    """True when `conv3d_first_fused_bp` can take these tensors (else: backproject + conv3d_first_split)."""
-    return (x0.dim() == 5 and proj.dim() == 4 and x0.shape[1] == 1 and proj.shape[1] in (1, 2) and x0.shape[4] % 4 == 0 and
+    """True when `conv3d_first_fused_bp` can take these tensors (else: backproject + conv3d_first_split).  EXPERIMENTAL: only the
+    `make exp` build of the library exports the kernel (include/liftreg_hip.h, last section); False on the product library."""
+    return (_hip.has_experimental() and x0.dim() == 5 and proj.dim() == 4 and x0.shape[1] == 1 and proj.shape[1] in (1, 2) and x0.shape[4] % 4 == 0 and
             x0.shape[0] == proj.shape[0] and x0.is_contiguous() and x0.data_ptr() % 16 == 0 and proj.shape[2] >= 2 and
             proj.shape[3] >= 2 and x0.shape[2] * x0.shape[3] * x0.shape[4] * 4 * 3 < 2 ** 31 - 2 ** 26)
 

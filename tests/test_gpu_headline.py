@@ -15,6 +15,15 @@ import torch
 from oracle import c_oracle as co
 from oracle import ref_ops as ro
 
+
+
+def _need_experimental():
+    """These paths live in the experimental build only (include/liftreg_hip.h, last section): `make -C liftreg_amd/csrc exp`,
+    then LIFTREG_HIP_LIB=liftreg_amd/csrc/libliftreg_hip_exp.so python -m pytest -m gpu -k 'fused_backprojection or conv0_split'."""
+    from liftreg_amd import _hip
+    if not _hip.has_experimental():
+        pytest.skip("experimental kernels are not in the product library (make exp + LIFTREG_HIP_LIB)")
+
 pytestmark = pytest.mark.gpu
 
 N, P, B, L = 256, 2, 8, 56
@@ -133,6 +142,7 @@ def test_c3_ncc_moments_in_the_decode_epilogue(decode_case):
 def test_c3_first_block_with_fused_backprojection_every_bit(dev):
     """The headline size: block 0 with the backprojection computed in its staging == backproject + block 0, all
     8·256³·16 outputs, on bench.py's own views and moving volumes."""
+    _need_experimental()
     import bench
     from liftreg_amd import ops
     from liftreg_amd.utils.sdct_projection_utils import scan_poses

@@ -14,6 +14,15 @@ from oracle import c_oracle as co
 from oracle import ref_ops as ro
 from util import pca_basis_32
 
+
+
+def _need_experimental():
+    """These paths live in the experimental build only (include/liftreg_hip.h, last section): `make -C liftreg_amd/csrc exp`,
+    then LIFTREG_HIP_LIB=liftreg_amd/csrc/libliftreg_hip_exp.so python -m pytest -m gpu -k 'fused_backprojection or conv0_split'."""
+    from liftreg_amd import _hip
+    if not _hip.has_experimental():
+        pytest.skip("experimental kernels are not in the product library (make exp + LIFTREG_HIP_LIB)")
+
 pytestmark = pytest.mark.gpu
 
 RTOL, ATOL = 1e-5, 2e-6
@@ -711,6 +720,7 @@ def test_first_block_with_fused_backprojection_equals_two_kernels(ops, dev):
     feature volume of …Backproj.py:89-93 never materialised) gives the bits of lr_backproject_f32 followed by
     lr_conv3d_first_split_f32 — detectors smaller / larger than the volume (shadows falling off every edge), oblique
     emitters, one and two views, ragged bricks, both channels-last output layouts."""
+    _need_experimental()
     rs = np.random.RandomState(41)
     cases = [((8, 8, 64), (8, 64), 2, 2), ((10, 6, 68), (14, 40), 2, 1), ((5, 9, 132), (6, 200), 1, 3),
              ((12, 12, 16), (30, 30), 2, 2), ((64, 64, 64), (64, 64), 2, 1)]
