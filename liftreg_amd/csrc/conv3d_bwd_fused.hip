@@ -34,27 +34,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-struct __attribute__((packed, aligned(2))) U128a2 { u32x4 v; };   // a 16-byte LDS read at a 2-byte aligned address (ds_read_b128; gfx950 takes it: tools/micro/lds_unaligned.hip)
 constexpr unsigned OOR = 0x80000000u;
-
-// (a, b) -> three packed bf16 pairs (a in the low half) with a = a0 + a1 + a2 and b = b0 + b1 + b2 exactly (conv01_fused.hip)
-__device__ __forceinline__ void split3(float a, float b, unsigned (&p)[3]) {
-  f32x2 v = {a, b};
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    const bf16x2 h = __builtin_convertvector(v, bf16x2);   // round to nearest even
-    const unsigned u = __builtin_bit_cast(unsigned, h);
-    p[s] = u;
-    if (s < 2) {
-      const f32x2 f = {__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
-      v = v - f;   // exact
-    }
-  }
-}
 
 struct FzDims {
   int B, D, W, H, Do, Wo, Ho;  // gpre0 / x0 / mask0 volume (D,W,H); gpre1 is (B,Do,Wo,Ho,32)
@@ -65,16 +45,9 @@ struct FzDims {
 constexpr int TR = 2;                  // quotient rows per tile
 constexpr int CB = 2, CG = 32, C4 = 8;  // block 1: 32 output channels = 2 channel blocks = 8 16-byte chunks per voxel
 constexpr int XY = 2 * TR + 2, XX = 36; // x0 window of a tile: rows, floats per row (origin (-1,-1,-2)); planes: 2 NZ + 2
-#ifndef LR_FUSED_BWD_SPLIT_DEFAULT
-#define LR_FUSED_BWD_SPLIT_DEFAULT 0
-#endif
 constexpr int nz_of(int cin0) { return cin0 <= 3 ? 8 : 4; }   // quotient planes per tile (LDS: see the header comment)
 
-// SPLITB: the weight-gradient MFMAs (phase B) on the bf16 matrix pipe with EXACT three-way bf16 splits of both operands (six of
-// the nine partial products, each exact, fp32 accumulation — conv01_fused.hip's arithmetic): the x0 window lives in LDS as three
-// bf16 arrays (rows of 36 elements), a lane's A operand = 8 consecutive elements of a row (one 2-byte aligned ds_read_b128), its B
-// operand = the masked gpre0 of the class pair (px = 0, 1) interleaved along x, split in registers.  One row per wave (NZ = 4).
-template <int CIN0, int NZ, bool SPLITB>
+template <int CIN0, int NZ>
 __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __restrict__ gpre, const float4* __restrict__ wp,
                                                               const unsigned* __restrict__ mask0, const float* __restrict__ in0,
                                                               long long bs0, const float* __restrict__ in_rest, long long bsr,
@@ -92,9 +65,7 @@ __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __res
   // are accumulated on the vector ALU (one broadcast LDS read + 2 flops per voxel and lane) instead of a sixth, 88 % empty
   // MFMA tile (VT); the partial buffer keeps the 6-tile layout.
   constexpr int NCOL = 27 * CIN0 + 1, NTP = (NCOL + 15) / 16;
-  constexpr bool VT = !SPLITB && (27 * CIN0) % 16 == 1;
-  static_assert(!SPLITB || NZ == 4, "the split weight gradient pairs the two x parities of ONE row per wave");
-  constexpr int XSD = CIN0 * (2 * NZ + 2) * XY * (XX / 2);   // dwords (bf16 pairs) of one split of the x0 window
+  constexpr bool VT = (27 * CIN0) % 16 == 1;
   constexpr int NTJ = VT ? NTP - 1 : NTP;
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   float4* wl = reinterpret_cast<float4*>(dsm);  // [27][CB][64 lanes]
@@ -221,14 +192,7 @@ __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __res
 #pragma unroll
     for (int it = 0; it < NXI; ++it) {
       const int q = (it % NPI) * 512 + tid;
-      if constexpr (SPLITB) {
-        unsigned p3[3];
-        split3(xst[it].x, xst[it].y, p3);
-        unsigned* xd = reinterpret_cast<unsigned*>(xs) + (it / NPI) * NPC + q;   // rows are XX / 2 pairs: the pair index IS the layout
-        if (q < NPC) { xd[0] = p3[0]; xd[XSD] = p3[1]; xd[2 * XSD] = p3[2]; }
-      } else {
-        if (q < NPC) *reinterpret_cast<float2*>(xs + ((it / NPI) * NPC + q) * 2) = xst[it];  // rows are XX floats: the pair index IS the layout
-      }
+      if (q < NPC) *reinterpret_cast<float2*>(xs + ((it / NPI) * NPC + q) * 2) = xst[it];  // rows are XX floats: the pair index IS the layout
     }
     __syncthreads();
     int b, zq0, yq0, xq0;
@@ -331,61 +295,32 @@ __global__ __launch_bounds__(512, 1) void dgrad_wgrad0_kernel(const float* __res
           accp[px][mt] = v;
         }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SPLITB) {
-        // weight gradient on exact bf16 splits: K = 32 voxels = this lane group's 8 consecutive voxels x = 2 (xq0 + 4 kq + r) + px of the
-        // row (slot 2 r + px); B = gpre0 (k = voxel, n = channel) as three split fragments from the two class accumulators
-        u32x4 gb3[3];
+      // weight gradient: gacc[j][(ci,tap) rows][co cols] += x0(voxel + tap)^T gpre0(voxel); k-step r = voxels 4kq + r
+      float xa[NTJ], xb[NTJ];
+      auto ldx = [&](float (&xv)[NTJ], int g) __attribute__((always_inline)) {  // g = (px*WMT + mt)*4 + r
+        const int r = g & 3, mt = (g >> 2) % WMT, px = g / (4 * WMT);
+        const int off = (pz * XY + 2 * mt + py) * XX + 2 * r + px;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          unsigned p3[3];
-          split3(accp[0][0][r], accp[1][0][r], p3);
-          gb3[0][r] = p3[0]; gb3[1][r] = p3[1]; gb3[2][r] = p3[2];
-        }
-        const unsigned char* xsb = reinterpret_cast<const unsigned char*>(xs) + (pz * XY + py) * XX * 2;
+        for (int j = 0; j < NTJ; ++j) xv[j] = xs[xbase[j] + off];
+        if (!VT && !xreal_last) xv[NTJ - 1] = xconst;
+      };
+      ldx(xa, 0);
 #pragma unroll
-        for (int j = 0; j < NTJ; ++j) {
-          u32x4 a3[3];
+      for (int g = 0; g < 2 * WMT * 4; ++g) {
+        const int r = g & 3, mt = (g >> 2) % WMT, px = g / (4 * WMT);
+        ldx(xb, g + 1 < 2 * WMT * 4 ? g + 1 : g);
+        const float bv = accp[px][mt][r];
+        if constexpr (VT) {
+          const float xt = xs[xbase_t + (pz * XY + 2 * mt + py) * XX + 2 * r + px];
+          vt_tap = fmaf(xt, bv, vt_tap);
+          vt_bias += bv;
+        }
 #pragma unroll
-          for (int sp = 0; sp < 3; ++sp) a3[sp] = reinterpret_cast<const U128a2*>(xsb + xbase[j] * 2 + sp * (XSD * 4))->v;
-          if (j == NTJ - 1 && !xreal_last) {   // the ones column (-> gb0) and the columns past it
-            const unsigned one2 = xconst != 0.0f ? 0x3f803f80u : 0u;
-            a3[0] = (u32x4){one2, one2, one2, one2};
-            a3[1] = a3[2] = (u32x4){0u, 0u, 0u, 0u};
-          }
-          auto mm = [&](const u32x4& av, const u32x4& bv) __attribute__((always_inline)) {
-            gacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), gacc[j], 0, 0, 0);
-          };
-          mm(a3[2], gb3[0]); mm(a3[1], gb3[1]); mm(a3[0], gb3[2]);   // small products first
-          mm(a3[1], gb3[0]); mm(a3[0], gb3[1]); mm(a3[0], gb3[0]);
-        }
-      } else {
-        // weight gradient: gacc[j][(ci,tap) rows][co cols] += x0(voxel + tap)^T gpre0(voxel); k-step r = voxels 4kq + r
-        float xa[NTJ], xb[NTJ];
-        auto ldx = [&](float (&xv)[NTJ], int g) __attribute__((always_inline)) {  // g = (px*WMT + mt)*4 + r
-          const int r = g & 3, mt = (g >> 2) % WMT, px = g / (4 * WMT);
-          const int off = (pz * XY + 2 * mt + py) * XX + 2 * r + px;
-  #pragma unroll
-          for (int j = 0; j < NTJ; ++j) xv[j] = xs[xbase[j] + off];
-          if (!VT && !xreal_last) xv[NTJ - 1] = xconst;
-        };
-        ldx(xa, 0);
-  #pragma unroll
-        for (int g = 0; g < 2 * WMT * 4; ++g) {
-          const int r = g & 3, mt = (g >> 2) % WMT, px = g / (4 * WMT);
-          ldx(xb, g + 1 < 2 * WMT * 4 ? g + 1 : g);
-          const float bv = accp[px][mt][r];
-          if constexpr (VT) {
-            const float xt = xs[xbase_t + (pz * XY + 2 * mt + py) * XX + 2 * r + px];
-            vt_tap = fmaf(xt, bv, vt_tap);
-            vt_bias += bv;
-          }
-  #pragma unroll
-          for (int j = 0; j < NTJ; ++j) gacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j], bv, gacc[j], 0, 0, 0);
-  #pragma unroll
-          for (int j = 0; j < NTJ; ++j) xa[j] = xb[j];
-          __builtin_amdgcn_sched_group_barrier(0x100, NTJ, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, NTJ, 0);
-        }
+        for (int j = 0; j < NTJ; ++j) gacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j], bv, gacc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NTJ; ++j) xa[j] = xb[j];
+        __builtin_amdgcn_sched_group_barrier(0x100, NTJ, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NTJ, 0);
       }
     }
   }
@@ -442,18 +377,17 @@ __global__ __launch_bounds__(1024) void wgrad0_finish_kernel(const float* __rest
   else if (n < 27 * Cin) gw[(int64_t)co * Cin * 27 + n] = (float)s;
 }
 
-template <int CIN0, int NZ, bool SPLITB>
+template <int CIN0, int NZ>
 int launch(const float* gpre1, const float* packed_w1T, const unsigned char* mask0, const float* in0, long long bs0,
            const float* in_rest, long long bsr, float* partial, float* gw0, float* gb0, const FzDims& d, int ntiles, int blocks,
            hipStream_t st) {
   constexpr int NTP = (27 * CIN0 + 1 + 15) / 16;
   constexpr int XZ = 2 * NZ + 2;
-  // x0 window: fp32 rows of XX floats | three bf16 split arrays of XX / 2 pairs per row
-  constexpr size_t ldsb = ((size_t)27 * CB * 64 * 4 + (size_t)(NZ + 1) * (TR + 1) * 17 * 32 + (size_t)CIN0 * XZ * XY * (SPLITB ? 3 * (XX / 2) : XX)) * sizeof(float);
+  constexpr size_t ldsb = ((size_t)27 * CB * 64 * 4 + (size_t)(NZ + 1) * (TR + 1) * 17 * 32 + (size_t)CIN0 * XZ * XY * XX) * sizeof(float);
   static_assert(ldsb <= 160 * 1024, "LDS");
   static std::atomic<uint64_t> attr_done{0};  // per instantiation, one bit per device
-  if (lr_raise_dyn_lds(reinterpret_cast<const void*>(&dgrad_wgrad0_kernel<CIN0, NZ, SPLITB>), ldsb, attr_done) != LR_OK) return LR_ELAUNCH;
-  hipLaunchKernelGGL((dgrad_wgrad0_kernel<CIN0, NZ, SPLITB>), dim3((unsigned)blocks), dim3(512), ldsb, st, gpre1,
+  if (lr_raise_dyn_lds(reinterpret_cast<const void*>(&dgrad_wgrad0_kernel<CIN0, NZ>), ldsb, attr_done) != LR_OK) return LR_ELAUNCH;
+  hipLaunchKernelGGL((dgrad_wgrad0_kernel<CIN0, NZ>), dim3((unsigned)blocks), dim3(512), ldsb, st, gpre1,
                      reinterpret_cast<const float4*>(packed_w1T), reinterpret_cast<const unsigned*>(mask0), in0, bs0, in_rest, bsr, partial, d, ntiles);
   const int ncols = NTP * 16;
   hipLaunchKernelGGL(wgrad0_finish_kernel, dim3((16 * ncols + 63) / 64), dim3(1024), 0, st, partial, gw0, gb0, blocks * 8, CIN0, ncols);
@@ -493,9 +427,6 @@ extern "C" int lr_conv3d_dgrad_wgrad0_split_f32(const float* gpre1, const float*
   d.Do = (D - 1) / 2 + 1; d.Wo = (W - 1) / 2 + 1; d.Ho = (H - 1) / 2 + 1;
   int NZ = nz_of(Cin0);
   if (Cin0 <= 3 && lr_sw_int(LR_SW_FUSED_BWD_NZ, 8) == 4) NZ = 4;   // A/B aid: the 4-plane tile form for <= 3 channels too
-  // the weight-gradient half on exact bf16 splits (always the 4-plane tiles); LIFTREG_FUSED_BWD_SPLIT=0: the fp32 MFMA (A/B aid)
-  const bool splitb = lr_sw_int(LR_SW_FUSED_BWD_SPLIT, LR_FUSED_BWD_SPLIT_DEFAULT) != 0;
-  if (splitb) NZ = 4;
   d.nHq = ((H + 1) / 2 + 15) / 16; d.nWq = (d.Wo + TR - 1) / TR; d.nDq = (d.Do + NZ - 1) / NZ;
   d.slope = slope0;
   if ((int64_t)10 * d.Wo * d.Ho * CG * 4 >= 0x7fffffffLL) return LR_EINVAL;       // 32-bit offsets of a gpre1 window
@@ -506,19 +437,13 @@ extern "C" int lr_conv3d_dgrad_wgrad0_split_f32(const float* gpre1, const float*
   if (lr_sw_set(LR_SW_FUSED_BWD_BLOCKS)) { blocks = lr_sw_int(LR_SW_FUSED_BWD_BLOCKS, 256); if (blocks < 1 || blocks > 256) blocks = 256; }  // tuning aid
   if (nt < blocks) blocks = (int)nt;
   hipStream_t st = lr_stream(stream);
-#define LR_FZ(C, Z, S) return launch<C, Z, S>(gpre1, packed_w1T, mask0, in0, in0_batch_stride, in_rest, rest_batch_stride, partial, gw0, gb0, d, (int)nt, blocks, st)
-  if (splitb) {
-    if (Cin0 == 5) LR_FZ(5, 4, true);
-    if (Cin0 == 4) LR_FZ(4, 4, true);
-    if (Cin0 == 3) LR_FZ(3, 4, true);
-    LR_FZ(2, 4, true);
-  }
-  if (Cin0 == 5) LR_FZ(5, 4, false);
-  if (Cin0 == 4) LR_FZ(4, 4, false);
-  if (Cin0 == 3 && NZ == 4) LR_FZ(3, 4, false);
-  if (Cin0 == 2 && NZ == 4) LR_FZ(2, 4, false);
-  if (Cin0 == 3) LR_FZ(3, 8, false);
-  LR_FZ(2, 8, false);
+#define LR_FZ(C, Z) return launch<C, Z>(gpre1, packed_w1T, mask0, in0, in0_batch_stride, in_rest, rest_batch_stride, partial, gw0, gb0, d, (int)nt, blocks, st)
+  if (Cin0 == 5) LR_FZ(5, 4);
+  if (Cin0 == 4) LR_FZ(4, 4);
+  if (Cin0 == 3 && NZ == 4) LR_FZ(3, 4);
+  if (Cin0 == 2 && NZ == 4) LR_FZ(2, 4);
+  if (Cin0 == 3) LR_FZ(3, 8);
+  LR_FZ(2, 8);
 #undef LR_FZ
 }
 

@@ -116,16 +116,18 @@ def hu_to_mu(vol):
 
 
 def drr_forward(vol, poses, resolution, spacing=(2.2, 2.2, 2.2), *, d0=0, d1=None, full_D=None,
-                hu_input=False, flip_w=False, nseg=0, out=None, fold_hu=True):
+                hu_input=False, flip_w=False, nseg=0, out=None, fold_hu=None):
     """Cone-beam DRR of `vol` (Ds,W,H) = rows [d0,d1) of a (D,W,H) volume → (P,Rd,Rh).
 
     Replaces calculate_projection (reference sdct_projection_utils.py:59-100).  `hu_input`: the volume is in HU;
     calc_relative_atten_coef (:6-9) is folded into the projector's tap loads (the division by 1000 as a multiplication +
     one exact correction step, lr_drr_forward_f32 with LR_DRR_HU_INPUT: same bits, no temporary volume, no extra pass);
-    `fold_hu=False` converts once per voxel with `hu_to_mu` first (A/B aid: 0.139-0.152 vs 0.133-0.139 ms per volume at C3).
+    `fold_hu=False` converts once per voxel with `hu_to_mu` first — same bits; `fold_hu=None` (default) picks by `_fold_hu_pays`.
     """
     vol = _dev(vol, "vol")
-    if hu_input and not fold_hu:
+    if hu_input and fold_hu is None and vol.dim() == 3:
+        fold_hu = _fold_hu_pays(np.asarray(poses).reshape(-1, 3).shape[0], resolution, vol.shape[0], vol.shape[2])
+    if hu_input and fold_hu is False:
         vol, hu_input = hu_to_mu(vol), False
     if vol.dim() != 3:
         raise ValueError("vol must be (D,W,H)")
@@ -150,7 +152,15 @@ def drr_forward(vol, poses, resolution, spacing=(2.2, 2.2, 2.2), *, d0=0, d1=Non
     return out
 
 
-def drr_forward_batch(vols, poses, resolution, spacing=(2.2, 2.2, 2.2), *, hu_input=False, flip_w=False, nseg=0, out=None):
+def _fold_hu_pays(P, resolution, Dn, H):
+    """HU input: convert inside the projector's tap loads (8 conversions per SAMPLE, no temporary volume) or once per VOXEL in a
+    pass of its own (lr_hu_to_mu_f32: read + write of the volume)?  Measured (tools/ab_drr.py, round 6): C3 (2 views of 256^2 on
+    256^3: 2 samples per voxel) folded 0.104-0.108 vs 0.116 ms per volume; the reference's shipped shape (4 views of 240^2 on 160^3:
+    9 samples per voxel) folded 0.117 vs 0.105 — the pass pays above ~4 samples per voxel.  Same bits either way."""
+    return int(P) * int(resolution[0]) * int(resolution[1]) <= 4 * int(Dn) * int(H)
+
+
+def drr_forward_batch(vols, poses, resolution, spacing=(2.2, 2.2, 2.2), *, hu_input=False, flip_w=False, nseg=0, out=None, fold_hu=None):
     """Cone-beam DRRs of B volumes `vols` (B,D,W,H) (or (B,1,D,W,H)) with ONE geometry in one launch → (B,P,Rd,Rh): the bits of
     B calls of `drr_forward` (reference: tools/preprocessingDRR.py:123-154 projects every case's source and target with the same
     emitter poses, sdct_projection_utils.py:59-100 each)."""
@@ -164,6 +174,8 @@ def drr_forward_batch(vols, poses, resolution, spacing=(2.2, 2.2, 2.2), *, hu_in
     sp = _host_f32(spacing, (3,), "spacing")
     P = poses.shape[0]
     Rd, Rh = int(resolution[0]), int(resolution[1])
+    if hu_input and (fold_hu is False or (fold_hu is None and not _fold_hu_pays(P, (Rd, Rh), D, H))):
+        vols, hu_input = hu_to_mu(vols.contiguous()), False     # one conversion per voxel (same bits as the folded form)
     out = torch.empty((B, P, Rd, Rh), dtype=torch.float32, device=vols.device) if out is None else _out_arg(out, (B, P, Rd, Rh))
     flags = (_hip.DRR_HU_INPUT if hu_input else 0) | (_hip.DRR_FLIP_W if flip_w else 0)
     with _timed("drr_forward_batch", bytes=4 * B * (D * W * H + P * Rd * Rh), samples=B):

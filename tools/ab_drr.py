@@ -1,5 +1,7 @@
 """A/B on one box: the batched projector (lr_drr_forward_batch_f32, HU input, flip folded) at C3 / native sizes — kernel ms per
-volume (HIP events), also with the general kernel (LIFTREG_DRR_GENERAL=1).  Usage: python tools/ab_drr.py"""
+volume (HIP events), also with the general kernel (LIFTREG_DRR_GENERAL=1), and (round 6) the two-pass form: one HU -> mu pass
+over the volumes (lr_hu_to_mu_f32, one conversion per VOXEL) + the mu-input projector (no conversion per TAP).
+Usage: python tools/ab_drr.py"""
 import os
 import sys
 
@@ -31,4 +33,24 @@ for n, P, R, B in ((256, 2, 256, 8), (160, 4, 240, 30)):
             e1.record()
             torch.cuda.synchronize()
             print(f"{n}^3 P={P} R={R} B={B} {'general' if gen else 'fast'}: {e0.elapsed_time(e1) / 5 / B:.4f} ms per volume")
-os.environ.pop("LIFTREG_DRR_GENERAL", None)
+    os.environ.pop("LIFTREG_DRR_GENERAL", None)
+    _hip.lib().lr_reload_switches()
+
+    def two_pass():
+        return ops.drr_forward_batch(ops.hu_to_mu(vols), p32, (R, R), hu_input=False, flip_w=True)
+
+    for rep in range(3):
+        for _ in range(2):
+            two_pass()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        for _ in range(5):
+            two_pass()
+        e1.record()
+        mu = ops.hu_to_mu(vols)
+        for _ in range(5):
+            ops.drr_forward_batch(mu, p32, (R, R), hu_input=False, flip_w=True)
+        e2.record()
+        torch.cuda.synchronize()
+        print(f"{n}^3 P={P} R={R} B={B} two-pass (hu_to_mu + mu projector): {e0.elapsed_time(e1) / 5 / B:.4f} ms per volume; "
+              f"mu projector alone {e1.elapsed_time(e2) / 5 / B:.4f}")
