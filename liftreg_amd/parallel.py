@@ -175,6 +175,37 @@ class DistComm:
         full = buf.view((self.world, B) + tuple(mine.shape[1:])).transpose(0, 1).reshape((B, self.world * rows) + tuple(mine.shape[2:]))
         return [full.to(src.device)]
 
+    def all_to_all_samples(self, slabs):
+        """slabs[0] = this rank's (B, rows, ...) plane slab of a channels-last activation -> [the WHOLE (nb, world*rows, ...) activation
+        of the nb = |slab_bounds(B, world, rank)| samples this rank owns].  ONE `all_to_all_single`: a rank sends every peer that
+        peer's samples of its planes (1 / world of what `all_gather_planes` moves) and receives its own samples' planes from all."""
+        if self.world == 1:
+            return [slabs[0]]
+        src = slabs[0].contiguous()
+        mine = src.cpu() if (self.host_stage and src.is_cuda) else src
+        B, rows = mine.shape[0], mine.shape[1]
+        cnt = [slab_bounds(B, self.world, q)[1] - slab_bounds(B, self.world, q)[0] for q in range(self.world)]
+        nb = cnt[self.rank]
+        buf = torch.empty((self.world * nb,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)   # sender-major
+        dist.all_to_all_single(buf, mine, output_split_sizes=[nb] * self.world, input_split_sizes=cnt, group=self.group)
+        full = buf.view((self.world, nb) + tuple(mine.shape[1:])).transpose(0, 1).reshape((nb, self.world * rows) + tuple(mine.shape[2:]))
+        return [full.to(src.device)]
+
+    def all_gather_rows(self, pieces, counts):
+        """pieces[0] = this rank's (counts[rank], L) rows -> [the (sum(counts), L) matrix, rank-major] on every rank (rows padded to
+        max(counts) on the wire: one small `all_gather_into_tensor`)."""
+        if self.world == 1:
+            return [pieces[0]]
+        src = pieces[0]
+        nmax = max(counts)
+        pad = torch.zeros((nmax,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        pad[:src.shape[0]].copy_(src)
+        mine = pad.cpu() if (self.host_stage and pad.is_cuda) else pad
+        buf = torch.empty((self.world * nmax,) + tuple(src.shape[1:]), dtype=src.dtype, device=mine.device)
+        dist.all_gather_into_tensor(buf, mine, group=self.group)
+        rows = torch.cat([buf[q * nmax:q * nmax + c] for q, c in enumerate(counts)], dim=0)
+        return [rows.to(src.device)]
+
     def all_reduce_sum(self, ts):
         if self.world == 1:
             return ts
@@ -243,6 +274,15 @@ class LocalComm:
     def all_gather_planes(self, slabs):
         full = torch.cat(slabs, dim=1)
         return [full for _ in slabs]
+
+    def all_to_all_samples(self, slabs):
+        full = torch.cat(slabs, dim=1)
+        B = full.shape[0]
+        return [full[slice(*slab_bounds(B, self.world, r))] for r in self.ranks]
+
+    def all_gather_rows(self, pieces, counts):
+        rows = torch.cat(pieces, dim=0)
+        return [rows for _ in pieces]
 
     def all_reduce_sum(self, ts):
         total = sum(ts[1:], ts[0].clone())
@@ -479,7 +519,32 @@ class SlabShardedRegistration:
         if last_sharded == 5:
             # (volumes whose last block still has more than GATHER_DEPTH planes) the features themselves are gathered
             feats = [f.permute(0, 2, 1, 3, 4) for f in comm.all_gather_planes([a.permute(0, 2, 1, 3, 4) for a in acts_p])]
-        else:
+        coefs_all = None
+        Bfull = inputs[0]["source"].shape[0]
+        if last_sharded < 5 and getattr(self, "sample_sharded_tail", True) and hasattr(comm, "all_to_all_samples"):
+            # ---- the small tail (blocks behind the gather depth + the FC head) SHARDED BY SAMPLE: one all-to-all hands every rank the
+            # whole (<= GATHER_DEPTH planes deep) activation of ITS B / world samples — 1 / world of the bytes an all-gather moves —,
+            # the rank runs the remaining blocks and the three Linear layers on them (the kernels, and bits, of the unsharded model:
+            # none of them reduces over the batch), and the (B, L) coefficients meet in one small all-gather.  Replicated (round 5)
+            # every rank ran these latency-bound launches on the WHOLE batch: 8 x the work at 8 ranks for the same wall time.
+            mine = comm.all_to_all_samples([a[:, 2:2 + r] for a, r in zip(acts_p, rows)])
+            counts = [slab_bounds(Bfull, comm.world, q)[1] - slab_bounds(Bfull, comm.world, q)[0] for q in range(comm.world)]
+            pieces = []
+            for x in mine:
+                if x.shape[0] == 0:
+                    pieces.append(torch.empty((0, net.latent_dim), dtype=torch.float32, device=x.device))
+                    continue
+                for j in range(last_sharded + 1, 6):
+                    blk = net.encoders[j]
+                    if bf16:
+                        lin, lout = layouts(j)
+                        x = ops.conv3d_k3_lrelu_bf16(x, blk.conv.weight, blk.conv.bias, blk.stride, in_layout=lin, out_layout=lout,
+                                                     negative_slope=blk._slope, packed=net._packed_weight(j, bf16=True))
+                    else:
+                        x = blk(x, packed=net._packed_weight(j))
+                pieces.append(net.encoders[6](x.contiguous()))
+            coefs_all = comm.all_gather_rows(pieces, counts)
+        elif last_sharded < 5:
             whole = comm.all_gather_planes([a[:, 2:2 + r] for a, r in zip(acts_p, rows)])   # real planes sit behind [filler | halo]
             feats = []
             for x in whole:
@@ -497,15 +562,16 @@ class SlabShardedRegistration:
         # of the replicated layer: lr_linear_lrelu_f32 reduces every neuron on its own) — and the (B, 800/world) pieces meet in one
         # small all-gather; layers 2 and 3 (0.9 MB) run replicated.
         head = net.encoders[6]
-        fc1 = head[1] if (len(head) == 4 and hasattr(head[1], "fc")) else None     # (another head shape: the replicated fallback)
-        O1 = fc1.fc.out_features if fc1 is not None else 0
-        if comm.world > 1 and fc1 is not None and O1 % comm.world == 0:
-            per = O1 // comm.world
-            pieces = [ops.linear_lrelu(f.contiguous().flatten(1), fc1.fc.weight[r * per:(r + 1) * per], fc1.fc.bias[r * per:(r + 1) * per],
-                                       fc1._slope) for r, f in zip(comm.ranks, feats)]
-            coefs_all = [head[3](head[2](h)) for h in comm.all_gather_cat(pieces, dim=1)]
-        else:
-            coefs_all = [head(f.contiguous()) for f in feats]
+        if coefs_all is None:      # (the replicated tail: `sample_sharded_tail = False`, or volumes still deeper than GATHER_DEPTH at block 5)
+            fc1 = head[1] if (len(head) == 4 and hasattr(head[1], "fc")) else None     # (another head shape: the replicated fallback)
+            O1 = fc1.fc.out_features if fc1 is not None else 0
+            if comm.world > 1 and fc1 is not None and O1 % comm.world == 0:
+                per = O1 // comm.world
+                pieces = [ops.linear_lrelu(f.contiguous().flatten(1), fc1.fc.weight[r * per:(r + 1) * per], fc1.fc.bias[r * per:(r + 1) * per],
+                                           fc1._slope) for r, f in zip(comm.ranks, feats)]
+                coefs_all = [head[3](head[2](h)) for h in comm.all_gather_cat(pieces, dim=1)]
+            else:
+                coefs_all = [head(f.contiguous()) for f in feats]
         outs = []
         moms = []
         for inp, coefs, (d0, d1) in zip(inputs, coefs_all, bounds):

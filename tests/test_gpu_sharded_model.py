@@ -17,7 +17,11 @@ pytestmark = pytest.mark.gpu
                                                 (160, 2, "fp32-p4"), (128, 4, "fp32-p4"),
                                                 # six views in fp32: the general first block (no pair kernel), its halo plane recomputed;
                                                 # and the exchange form of blocks 0 / 1 (`halo_free01 = False`)
-                                                (64, 2, "fp32-p6"), (128, 4, "bf16-exchange"), (64, 2, "fp32-p6-exchange")])
+                                                (64, 2, "fp32-p6"), (128, 4, "bf16-exchange"), (64, 2, "fp32-p6-exchange"),
+                                                # round 6: the tail behind the gather depth is sharded by SAMPLE (all-to-all); the
+                                                # replicated tail of round 5 (all-gather + FC1 by neurons) stays selectable; B = 3 on 4
+                                                # ranks leaves one rank without a sample
+                                                (256, 8, "fp32-reptail"), (128, 4, "bf16-reptail"), (128, 4, "fp32-b3")])
 def test_slab_sharded_forward_equals_unsharded(n, world, conv_dtype):
     from liftreg_amd import parallel as par
     from liftreg_amd.layers.losses import NCCLoss
@@ -30,6 +34,10 @@ def test_slab_sharded_forward_equals_unsharded(n, world, conv_dtype):
     P, L, B, R = 2, 12, 2, n
     exchange = conv_dtype.endswith("-exchange")
     conv_dtype = conv_dtype[:-len("-exchange")] if exchange else conv_dtype
+    reptail = conv_dtype.endswith("-reptail")
+    conv_dtype = conv_dtype[:-len("-reptail")] if reptail else conv_dtype
+    if conv_dtype == "fp32-b3":
+        conv_dtype, B = "fp32", 3
     if conv_dtype == "fp32-p6":
         conv_dtype, P = "fp32", 6
     if conv_dtype == "bf16":
@@ -51,6 +59,8 @@ def test_slab_sharded_forward_equals_unsharded(n, world, conv_dtype):
         sharded = par.SlabShardedRegistration(net, par.LocalComm(world))
         if exchange:
             sharded.halo_free01 = False
+        if reptail:
+            sharded.sample_sharded_tail = False
         outs = sharded.forward([inp] * world)
     assert len(outs) == world
     for r, out in enumerate(outs):

@@ -212,6 +212,19 @@ def _worker(rank, world_size, port, q):
             out2 = sh.forward([inp])[0]
         for k in ("pca_coefs", "params", "warped"):
             assert torch.equal(out2[k], out[k]), k
+        # the tail behind the gather depth: sharded by SAMPLE (all_to_all_single + one small all-gather of the coefficients; with
+        # B = 1 rank 1 owns no sample) == the replicated tail of round 5 (all-gather of the activation, FC1 sharded by neurons)
+        with torch.no_grad():
+            sh = par.SlabShardedRegistration(net, par.DistComm())
+            sh.sample_sharded_tail = False
+            out3 = sh.forward([inp])[0]
+            inp3 = {k: (torch.cat([v, v.flip(-1), v * 0.5], 0) if k != "target_poses" else v.repeat(3, 1, 1)) for k, v in inp.items()}   # B = 3: 2 + 1 samples
+            ref3 = net(inp3)
+            out4 = par.SlabShardedRegistration(net, par.DistComm()).forward([inp3])[0]
+        for k in ("pca_coefs", "params", "warped"):
+            assert torch.equal(out3[k], out[k]), k
+        np.testing.assert_allclose(out4["pca_coefs"].numpy(), ref3["pca_coefs"].numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(out4["warped"].numpy(), ref3["warped"][:, :, s0:s1].numpy(), rtol=1e-4, atol=1e-5)
         q.put((rank, "ok"))
     except Exception as e:  # surface the failure in the parent
         import traceback

@@ -15,7 +15,15 @@ from liftreg_amd.utils.sdct_projection_utils import scan_poses
 dev = torch.device("cuda:0")
 
 
+POLLUTE = "--pollute" in sys.argv     # a 2 GB device copy in front of every timed launch: the in-step situation (other kernels'
+# buffers have gone through the caches / TLBs since this kernel last ran), not the back-to-back loop
+_big = None
+
+
 def run(n, P, R, B, env, reps=20):
+    global _big
+    if POLLUTE and _big is None:
+        _big = torch.empty(2 * 1024 ** 3 // 4, device=dev), torch.empty(2 * 1024 ** 3 // 4, device=dev)
     for k in ("LIFTREG_BP_CHUNK", "LIFTREG_BP_JP"):
         os.environ.pop(k, None)
     os.environ.update(env)
@@ -29,6 +37,8 @@ def run(n, P, R, B, env, reps=20):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ts = []
     for _ in range(reps):
+        if POLLUTE:
+            _big[1].copy_(_big[0])
         e0.record()
         ops.backproject(proj, poses, (n, n, n), out=out)
         e1.record()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""A/B of lr_conv3d_dgrad_wgrad0_split_f32's forms in one process: tile depth (LIFTREG_FUSED_BWD_NZ) and the weight-gradient half on
-exact bf16 splits (LIFTREG_FUSED_BWD_SPLIT), at C3 (256^3, 3 channels, B = 8) and the reference's shipped shape (160^3, 5, B = 30);
-each form's gw0 / gb0 against the fp32 8-plane form (relative to the scale)."""
+"""A/B of lr_conv3d_dgrad_wgrad0_split_f32's tile depth (LIFTREG_FUSED_BWD_NZ: 8 quotient planes per tile, or 4 with two waves per
+plane) in one process, at C3 (256^3, 3 channels, B = 8) and the reference's shipped shape (160^3, 5 channels, B = 30: always 4);
+the 4-plane form's gw0 / gb0 against the 8-plane form (relative to the scale).  (Round 6 also measured the weight-gradient half on
+exact bf16 splits here: 12.2 vs 6.9 ms at C3 — commit 4ae0fef, profiles/NOTES_r06.md.)"""
 import os, sys
 import numpy as np
 import torch
@@ -11,7 +12,7 @@ dev = torch.device("cuda:0")
 
 
 def run(n, cin0, B, env, ref=None, reps=8):
-    for k in ("LIFTREG_FUSED_BWD_NZ", "LIFTREG_FUSED_BWD_SPLIT"):
+    for k in ("LIFTREG_FUSED_BWD_NZ",):
         os.environ.pop(k, None)
     os.environ.update(env); _hip.reload_switches()
     g = torch.Generator(device=dev); g.manual_seed(1)
@@ -34,8 +35,7 @@ def run(n, cin0, B, env, ref=None, reps=8):
 
 for name, (n, c, B) in {"c3": (256, 3, 8), "native160": (160, 5, 30)}.items():
     ref = None
-    for env in ({"LIFTREG_FUSED_BWD_SPLIT": "0"}, {"LIFTREG_FUSED_BWD_SPLIT": "0", "LIFTREG_FUSED_BWD_NZ": "4"}, {"LIFTREG_FUSED_BWD_SPLIT": "1"},
-                {"LIFTREG_FUSED_BWD_SPLIT": "0"}, {"LIFTREG_FUSED_BWD_SPLIT": "1"}):
+    for env in ({}, {"LIFTREG_FUSED_BWD_NZ": "4"}, {}, {"LIFTREG_FUSED_BWD_NZ": "4"}):
         ms, out, err = run(n, c, B, env, ref)
         if ref is None:
             ref = out

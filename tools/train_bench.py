@@ -168,8 +168,12 @@ def main():
         g.manual_seed(2021 if a.same_data else 2021 + rank)
         rnd = lambda *s: torch.rand(*s, generator=g, device=dev) * 2 - 1
         poses = scan_poses(30, P, n).astype(np.float32)
-        inp = {"source": rnd(B, 1, n, n, n), "target": rnd(B, 1, n, n, n), "target_proj": rnd(B, P, R, R),
-               "target_poses": torch.from_numpy(np.broadcast_to(poses, (B, P, 3)).copy())}
+        if a.vs_fp32:      # the accuracy record needs a REGISTRATION (bench.py's phantom pair and its DRRs): on uniform random
+            import bench   # volumes the coefficients are ~0 and every relative figure is meaningless; timings do not depend on the data
+            inp = bench.synth_inputs(dict(n=n, P=P, R=R, B=B, L=L), dev, seed=2021 if a.same_data else 2021 + rank)
+        else:
+            inp = {"source": rnd(B, 1, n, n, n), "target": rnd(B, 1, n, n, n), "target_proj": rnd(B, P, R, R),
+                   "target_poses": torch.from_numpy(np.broadcast_to(poses, (B, P, 3)).copy())}
 
         def loss_of(ep):
             out = net(inp)
