@@ -17,6 +17,8 @@ dev = torch.device("cuda:0")
 
 POLLUTE = "--pollute" in sys.argv     # a 2 GB device copy in front of every timed launch: the in-step situation (other kernels'
 # buffers have gone through the caches / TLBs since this kernel last ran), not the back-to-back loop
+# --pollute-mode copy2g (default) | copy256m | fill2g | read2g | altbuf (no other kernel: the output alternates between two buffers)
+MODE = sys.argv[sys.argv.index("--pollute-mode") + 1] if "--pollute-mode" in sys.argv else "copy2g"
 _big = None
 
 
@@ -36,9 +38,19 @@ def run(n, P, R, B, env, reps=20):
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ts = []
-    for _ in range(reps):
+    out2 = torch.empty_like(out) if (POLLUTE and MODE == "altbuf") else None
+    for it in range(reps):
         if POLLUTE:
-            _big[1].copy_(_big[0])
+            if MODE == "copy2g":
+                _big[1].copy_(_big[0])
+            elif MODE == "copy256m":
+                _big[1][:64 * 1024 ** 2].copy_(_big[0][:64 * 1024 ** 2])
+            elif MODE == "fill2g":
+                _big[1].fill_(1.0)
+            elif MODE == "read2g":
+                _big[0].sum()
+            elif MODE == "altbuf" and it % 2:
+                out, out2 = out2, out
         e0.record()
         ops.backproject(proj, poses, (n, n, n), out=out)
         e1.record()
