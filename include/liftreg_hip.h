@@ -90,6 +90,7 @@ const char* lr_target_arch(void);
  *   LIFTREG_FUSED_BWD_BLOCKS       persistent blocks of the fused dgrad1 + wgrad0 kernel
  *   LIFTREG_REG_BWD_BLOCKS         block cap of the regulariser's gradient kernel
  *   LIFTREG_FUSED_BWD_NZ           4: the fused dgrad1 + wgrad0 kernel's 4-plane tiles for <= 3 input channels too (default 8; A/B aid, same results up to summation order)
+ *   LIFTREG_BP_TOUCH               0: no streaming pass over the views in front of the tiled backprojection (A/B aid; same bits)
  *   LIFTREG_BP_CHUNK               batch elements per block of the tiled backprojection (0 = the whole batch; same bits)
  *   LIFTREG_BP_JP                  planes a backprojection block works on side by side (1 | 2 | 4; same bits)
  */

@@ -48,6 +48,7 @@ enum LrSwitch {
   LR_SW_FUSED_BWD_BLOCKS,   // LIFTREG_FUSED_BWD_BLOCKS: persistent blocks of the fused dgrad1 + wgrad0 kernel
   LR_SW_REG_BWD_BLOCKS,   // LIFTREG_REG_BWD_BLOCKS: block cap of the regulariser's gradient kernel
   LR_SW_FUSED_BWD_NZ,   // LIFTREG_FUSED_BWD_NZ: 4: the fused dgrad1 + wgrad0 kernel's 4-plane tile form (two waves per quotient plane) for <= 3 input channels too (default 8; 4 / 5 channels always 4)
+  LR_SW_BP_TOUCH,   // LIFTREG_BP_TOUCH: 0: no streaming pass over the views in front of the tiled backprojection (default 1)
   LR_SW_BP_CHUNK,   // LIFTREG_BP_CHUNK: batch elements per block of the tiled backprojection (default: chosen from the grid size; 0 = the whole batch)
   LR_SW_BP_JP,   // LIFTREG_BP_JP: planes a block of the tiled backprojection works on side by side (1 | 2 | 4; default: by row length)
 #ifdef LR_EXPERIMENTAL   // (make exp)

@@ -57,6 +57,7 @@ const char* const kSwitchNames[LR_SW_COUNT] = {
     "LIFTREG_FUSED_BWD_BLOCKS",
     "LIFTREG_REG_BWD_BLOCKS",
     "LIFTREG_FUSED_BWD_NZ",
+    "LIFTREG_BP_TOUCH",
     "LIFTREG_BP_CHUNK",
     "LIFTREG_BP_JP",
 #ifdef LR_EXPERIMENTAL

@@ -26,7 +26,7 @@ def run(n, P, R, B, env, reps=20):
     global _big
     if POLLUTE and _big is None:
         _big = torch.empty(2 * 1024 ** 3 // 4, device=dev), torch.empty(2 * 1024 ** 3 // 4, device=dev)
-    for k in ("LIFTREG_BP_CHUNK", "LIFTREG_BP_JP"):
+    for k in ("LIFTREG_BP_CHUNK", "LIFTREG_BP_JP", "LIFTREG_BP_TOUCH"):
         os.environ.pop(k, None)
     os.environ.update(env)
     _hip.reload_switches()
@@ -51,6 +51,9 @@ def run(n, P, R, B, env, reps=20):
                 _big[0].sum()
             elif MODE == "altbuf" and it % 2:
                 out, out2 = out2, out
+            elif MODE == "copy2g_then_touch_views":      # the polluter, then one pass over the views: are they what the kernel misses?
+                _big[1].copy_(_big[0])
+                proj.sum()
         e0.record()
         ops.backproject(proj, poses, (n, n, n), out=out)
         e1.record()
@@ -61,7 +64,7 @@ def run(n, P, R, B, env, reps=20):
 
 
 SHAPES = {"native160": (160, 4, 240, 30), "c3": (256, 2, 256, 8), "c2": (128, 2, 128, 4), "c4": (256, 11, 256, 4), "c5": (384, 2, 512, 4)}
-ENVS = ({"LIFTREG_BP_CHUNK": "0", "LIFTREG_BP_JP": "1"}, {"LIFTREG_BP_CHUNK": "0"}, {"LIFTREG_BP_JP": "1"}, {},
+ENVS = ({"LIFTREG_BP_CHUNK": "0", "LIFTREG_BP_JP": "1"}, {"LIFTREG_BP_CHUNK": "0"}, {"LIFTREG_BP_JP": "1"}, {}, {"LIFTREG_BP_TOUCH": "0"},
         {"LIFTREG_BP_CHUNK": "4"}, {"LIFTREG_BP_CHUNK": "2"}, {"LIFTREG_BP_CHUNK": "1"})
 for name, (n, P, R, B) in SHAPES.items():
     for env in ENVS:
