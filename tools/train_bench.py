@@ -197,6 +197,10 @@ def main():
         opt.step()
         return l.detach()
 
+    vs = None
+    if a.vs_fp32 and rank == 0 and not a.dry_run:      # at the INITIAL weights (seed 2021), before any optimizer step: a reproducible record
+        vs = vs_fp32(net, inp, a.vs_fp32, dict(n=n, P=P, L=L), dev)
+        torch.cuda.empty_cache()
     losses = []
     if not a.dry_run and a.ramp_seconds > 0:      # untimed clock ramp (as bench.py): a GPU that was idle starts at reduced clocks
         t_r = time.perf_counter()
@@ -238,9 +242,6 @@ def main():
                 row["GB/s"] = round(info["bytes"] / avg / 1e6, 0)
             rows.append(row)
         rows.sort(key=lambda r: -r["ms"] * r["launches"])
-    vs = None
-    if a.vs_fp32 and rank == 0 and not a.dry_run:
-        vs = vs_fp32(net, inp, a.vs_fp32, dict(n=n, P=P, L=L), dev)
     if rank == 0:
         print(json.dumps({
             **({"vs_fp32_reference": vs} if vs is not None else {}),
