@@ -667,7 +667,9 @@ static int backproject_impl(const float* proj, const float* poses, float* out,
     hipStream_t st = lr_stream(stream);
     {   // the views into the caches first (touch_views_kernel); LIFTREG_BP_TOUCH=0: off (A/B aid)
       const int64_t nview = (int64_t)B * P * Pw * Ph;
-      if (v4 && nview * 4 <= 128LL * 1024 * 1024 && nview >= 64 * 1024 && lr_sw_int(LR_SW_BP_TOUCH, 1) != 0) {
+      // (only where it pays: the pass costs a launch, ~5 us; small launches — a z-slab of 1/8 of C3 writes 135 MB — save less than that)
+      const int64_t out_bytes = (int64_t)B * P * Ds * W * H * 4;
+      if (v4 && nview * 4 <= 128LL * 1024 * 1024 && nview >= 64 * 1024 && out_bytes >= 256LL * 1024 * 1024 && lr_sw_int(LR_SW_BP_TOUCH, 1) != 0) {
         const int64_t nb4 = (nview / 4 + 255) / 256;
         hipLaunchKernelGGL(touch_views_kernel, dim3((unsigned)(nb4 < 1024 ? nb4 : 1024)), dim3(256), 0, st, proj, nview);
       }
