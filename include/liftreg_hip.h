@@ -390,8 +390,10 @@ int lr_warp_bwd_disp_ncc_f32(const float* img, const float* disp, const float* i
                              const float* id2, const float* warped, const float* target, const double* gmoments,
                              const float* gadd, float* gdisp, int B, int D, int W, int H, int d0, int d1,
                              int flags, void* stream);
-/* d/d coefs of lr_pca_reconstruct_f32: gcoefs (B,L) = gdisp (B,M) · basis^T.  B <= 8.
- * partial: dev workspace nblk*B*L floats. */
+/* d/d coefs of lr_pca_reconstruct_f32: gcoefs (B,L) = gdisp (B,M) · basis^T.  B <= 64: above 8 rows the launch carries
+ * ceil(B/8) row chunks per (m-range, l-group), dealt to one XCD so that the basis leaves HBM once (16-byte aligned inputs,
+ * M, ldb, gdisp_batch_stride multiples of 4 — LR_EUNSUPPORTED otherwise: call in chunks of 8 rows); the bits of chunk-by-chunk
+ * calls.  partial: dev workspace nblk*B*L floats. */
 int lr_pca_bwd_coef_f32(const float* gdisp, const float* basis, float* partial, float* gcoefs, int B,
                         int L, int64_t M, int64_t ldb, int64_t gdisp_batch_stride, int nblk, void* stream);
 /* Backward of lr_linear_lrelu_f32: y = its (post-activation) output, gy = upstream gradient.

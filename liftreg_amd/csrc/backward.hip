@@ -335,11 +335,20 @@ __global__ __launch_bounds__(256) void pca_bwd_kernel(const float* __restrict__ 
                                                       int64_t ldb, int64_t gstride, int nblk) {
   // 1-D launch order: the l-groups of one m-range are issued together and land on the SAME XCD (ids 8 apart), so the
   // gradient rows they all read come from HBM once and from that XCD's L2 afterwards (they walk m in near lockstep).
-  const unsigned ng = (unsigned)((L + LG - 1) / LG), per8 = ng * 8u;
+  // Batches above BT rows (round 6; the reference's shipped batch is 30): ceil(B / BT) row chunks per (m-range, l-group), all of
+  // them in that same run of ids — the chunks of an l-group stream the same basis rows at the same time, so the basis leaves HBM
+  // once per launch, not once per chunk (four launches of 0.52 ms at 160^3 / B = 30 before).  Each (chunk, l-group) block is the
+  // block of a stand-alone launch on that chunk: same sums, same bits.
+  const int Btot = B;
+  const unsigned nch = (unsigned)((B + BT - 1) / BT);
+  const unsigned ng = (unsigned)((L + LG - 1) / LG), per8 = ng * nch * 8u;
   const unsigned q = blockIdx.x / per8, r = blockIdx.x - q * per8;
   const unsigned bx = q * 8u + (r & 7u);
   if (bx >= (unsigned)nblk) return;
-  const int l0 = (int)(r >> 3) * LG;
+  const unsigned cg = r >> 3;                       // (l-group, chunk): the chunks of an l-group next to each other
+  const int l0 = (int)(cg / nch) * LG, b0 = (int)(cg % nch) * BT;
+  g += (int64_t)b0 * gstride;
+  B = B - b0 < BT ? B - b0 : BT;
   float acc[LG][BT];
 #pragma unroll
   for (int a = 0; a < LG; ++a)
@@ -364,13 +373,15 @@ __global__ __launch_bounds__(256) void pca_bwd_kernel(const float* __restrict__ 
     for (int a = 0; a < LG; ++a) {
       if (BF) {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        const u32x2 raw = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(brow[a]) + m));
+        const u32x2* bp2 = reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(brow[a]) + m);
+        const u32x2 raw = nch > 1 ? *bp2 : __builtin_nontemporal_load(bp2);
         bv[a][0] = __builtin_bit_cast(float, raw.x << 16);
         bv[a][1] = __builtin_bit_cast(float, raw.x & 0xffff0000u);
         bv[a][2] = __builtin_bit_cast(float, raw.y << 16);
         bv[a][3] = __builtin_bit_cast(float, raw.y & 0xffff0000u);
       } else {
-        bv[a] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(brow[a] + m));
+        // (several row chunks: plain loads — the other chunks of this l-group find the rows in the XCD's L2; non-temporal ones do not stay)
+        bv[a] = nch > 1 ? *reinterpret_cast<const f32x4*>(brow[a] + m) : __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(brow[a] + m));
       }
     }
 #pragma unroll
@@ -394,7 +405,7 @@ __global__ __launch_bounds__(256) void pca_bwd_kernel(const float* __restrict__ 
   if (threadIdx.x < LG * BT) {
     const int a = threadIdx.x / BT, b = threadIdx.x % BT;
     if (l0 + a < L && b < B)
-      partial[((int64_t)bx * B + b) * L + l0 + a] =
+      partial[((int64_t)bx * Btot + b0 + b) * L + l0 + a] =
           (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
   }
 }
@@ -628,17 +639,19 @@ static int pca_bwd_impl(bool bf, const float* gdisp, const float* basis, float* 
                                    int L, int64_t M, int64_t ldb, int64_t gdisp_batch_stride, int nblk,
                                    void* stream) {
   if (!gdisp || !basis || !partial || !gcoefs) return LR_ENULL;
-  if (B < 1 || B > 8 || L < 1 || M < 1 || ldb < M || gdisp_batch_stride < M || nblk < 1 || nblk > 65535)
-    return B > 8 ? LR_EUNSUPPORTED : LR_EINVAL;
+  if (B < 1 || B > 64 || L < 1 || M < 1 || ldb < M || gdisp_batch_stride < M || nblk < 1 || nblk > 65535)
+    return B > 64 ? LR_EUNSUPPORTED : LR_EINVAL;
   hipStream_t st = lr_stream(stream);
   const dim3 grid((unsigned)nblk, (unsigned)((L + LG - 1) / LG));
   const bool vec_ok = !((M & 3) || (ldb & 3) || (gdisp_batch_stride & 3)) && !(reinterpret_cast<uintptr_t>(gdisp) & 15u) &&
                       !(reinterpret_cast<uintptr_t>(basis) & (bf ? 7u : 15u));
   if (!vec_ok) {  // odd voxel counts (3·D·W·H not a multiple of 4), sliced views
+    if (B > 8) return LR_EUNSUPPORTED;   // (the scalar kernel keeps 8 rows: the caller goes in chunks of 8)
     if (bf) hipLaunchKernelGGL(pca_bwd_scalar_kernel<true>, grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
     else hipLaunchKernelGGL(pca_bwd_scalar_kernel<false>, grid, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride);
   } else {
-    const dim3 g1((unsigned)((nblk + 7) / 8) * 8u * (unsigned)((L + LG - 1) / LG));
+    const unsigned nchunk = B > 8 ? (unsigned)((B + 7) / 8) : 1u;   // (B <= 4: one chunk of the 4-row kernel)
+    const dim3 g1((unsigned)((nblk + 7) / 8) * 8u * (unsigned)((L + LG - 1) / LG) * nchunk);
     if (B > 4 && bf) hipLaunchKernelGGL((pca_bwd_kernel<8, true>), g1, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride, nblk);
     else if (B > 4) hipLaunchKernelGGL((pca_bwd_kernel<8, false>), g1, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride, nblk);
     else if (bf) hipLaunchKernelGGL((pca_bwd_kernel<4, true>), g1, dim3(256), 0, st, gdisp, basis, partial, B, L, M, ldb, gdisp_batch_stride, nblk);

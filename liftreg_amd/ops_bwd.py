@@ -117,7 +117,10 @@ def pca_bwd_coef(gdisp, basis_LxM, nblk=None):
     L, M = basis_LxM.shape
     if g2.shape[1] != M or basis_LxM.stride(1) != 1:
         raise ValueError("gdisp/basis shape mismatch")
-    if B > 8:      # the kernel keeps 8 batch rows of accumulators per thread: larger batches go in chunks of 8
+    one_launch = (M % 4 == 0 and basis_LxM.stride(0) % 4 == 0 and g2.stride(0) % 4 == 0 and g2.data_ptr() % 16 == 0 and
+                  basis_LxM.data_ptr() % 16 == 0)
+    if B > 64 or (B > 8 and not one_launch):      # the kernel keeps 8 batch rows of accumulators per thread; up to 64 rows go as row
+        # chunks of ONE launch (the chunks of an l-group on one XCD: the basis leaves HBM once), more — or unaligned views — in chunks of 8
         return torch.cat([pca_bwd_coef(g2[i:i + 8], basis_LxM, nblk) for i in range(0, B, 8)], 0)
     if nblk is None:
         nblk = max(1, min(256, M // 4096))   # one block per CU and l-group: 2.59 ms at C3 against 2.67 with 512, 2.82 with 1024 (NOTES_r03)
@@ -129,7 +132,7 @@ def pca_bwd_coef(gdisp, basis_LxM, nblk=None):
     # run together on one XCD and take their re-reads from that L2 — they are not HBM traffic and are not counted)
     with _timed("pca_bwd_coef" + ("_bf16basis" if bf else ""), bytes=(2 if bf else 4) * L * M + 4 * B * M):
         _hip.check(fn(g2.data_ptr(), basis_LxM.data_ptr(), partial.data_ptr(), gcoefs.data_ptr(), B, L, M,
-                      basis_LxM.stride(0), M, nblk, _stream()), "lr_pca_bwd_coef_f32")
+                      basis_LxM.stride(0), int(g2.stride(0)), nblk, _stream()), "lr_pca_bwd_coef_f32")
     return gcoefs
 
 

@@ -92,6 +92,18 @@ def test_pca_backward_wrt_coefficients(dev):
         want = g.astype(np.float64) @ basis.astype(np.float64).T
         got = ops_bwd.pca_bwd_coef(T(g, dev), T(basis, dev)).cpu().numpy()
         np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+    # batches above 8 rows (the reference's shipped batch is 30): row chunks of ONE launch — the bits of chunk-by-chunk launches
+    for B, L, M in ((30, 56, 3 * 20 ** 3), (9, 13, 4096), (64, 8, 2048), (17, 56, 3 * 16 * 16 * 12)):
+        g = T(rs.normal(0, 1, (B, M)).astype(np.float32), dev)
+        basis = T(rs.normal(0, 0.02, (L, M)).astype(np.float32), dev)
+        got = ops_bwd.pca_bwd_coef(g, basis)
+        chunks = torch.cat([ops_bwd.pca_bwd_coef(g[i:i + 8].contiguous(), basis) for i in range(0, B, 8)], 0)
+        assert torch.equal(got, chunks), (B, L, M)
+        np.testing.assert_allclose(got.cpu().numpy(), g.cpu().double().numpy() @ basis.cpu().double().numpy().T, rtol=1e-4, atol=1e-5)
+    # ... an unaligned leading dimension keeps the chunk-by-chunk route (the scalar kernel holds 8 rows)
+    g = T(rs.normal(0, 1, (11, 1001)).astype(np.float32), dev)
+    basis = T(rs.normal(0, 0.02, (5, 1001)).astype(np.float32), dev)
+    np.testing.assert_allclose(ops_bwd.pca_bwd_coef(g, basis).cpu().numpy(), g.cpu().double().numpy() @ basis.cpu().double().numpy().T, rtol=1e-4, atol=1e-5)
 
 
 def test_linear_backward(dev):
