@@ -499,6 +499,7 @@ __global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* __restri
                                                            const float* __restrict__ gy, float* __restrict__ gx,
                                                            int B, int b_lo, int K, int O, float slope) {
   extern __shared__ float gpre[];  // [O][BT]
+  b_lo += (int)blockIdx.y * BT;   // the row chunks of a batch above BT rows: blockIdx.y of one launch
   for (int t = threadIdx.x; t < O * BT; t += 256) {
     const int o = t / BT, b = b_lo + t % BT;
     gpre[t] = b < B ? lrelu_grad(gy[(int64_t)b * O + o], y[(int64_t)b * O + o], slope) : 0.0f;
@@ -689,11 +690,9 @@ extern "C" int lr_linear_bwd_f32(const float* x, const float* w, const float* y,
   }
   if (gx) {
     const unsigned nb = (unsigned)((K + 255) / 256);
-    for (int b_lo = 0; b_lo < B; b_lo += 8) {
-      if ((size_t)O * 8 * 4 > 64 * 1024) return LR_EUNSUPPORTED;
-      hipLaunchKernelGGL(linear_bwd_x_kernel<8>, dim3(nb), dim3(256), (size_t)O * 8 * 4, st, w, y, gy, gx, B, b_lo, K, O, negative_slope);
-      if (int e = lr_launch_status()) return e;
-    }
+    if ((size_t)O * 8 * 4 > 64 * 1024) return LR_EUNSUPPORTED;
+    hipLaunchKernelGGL(linear_bwd_x_kernel<8>, dim3(nb, (unsigned)((B + 7) / 8)), dim3(256), (size_t)O * 8 * 4, st, w, y, gy, gx, B, 0, K, O, negative_slope);
+    if (int e = lr_launch_status()) return e;
   }
   return LR_OK;
 }

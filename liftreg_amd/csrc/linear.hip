@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
                                                      float* __restrict__ y, int B, int b_lo, int K,
                                                      int O, float slope, int vec_ok) {
   const int o0 = blockIdx.x * OT;
+  b_lo += (int)blockIdx.y * BT;   // batches above BT rows: the row chunks are blockIdx.y of ONE launch (round 6: B = 30 was four launches per layer)
   float acc[OT][BT];
 #pragma unroll
   for (int o = 0; o < OT; ++o)
@@ -99,18 +100,18 @@ extern "C" int lr_linear_lrelu_f32(const float* x, const float* w, const float* 
   const bool wide = (O + OT4 - 1) / OT4 < 512;  // few neurons: one per block
   const unsigned nblk = wide ? (unsigned)O : (unsigned)((O + OT4 - 1) / OT4);
   hipStream_t st = lr_stream(stream);
+  dim3 grid(nblk);
 #define LR_LIN(BTV)                                                                                                          \
   do {                                                                                                                      \
-    if (wide) hipLaunchKernelGGL((linear_kernel<BTV, 1>), dim3(nblk), dim3(256), 0, st, x, w, bias, y, B, b_lo, K, O, negative_slope, vec_ok); \
-    else hipLaunchKernelGGL((linear_kernel<BTV, OT4>), dim3(nblk), dim3(256), 0, st, x, w, bias, y, B, b_lo, K, O, negative_slope, vec_ok);    \
+    if (wide) hipLaunchKernelGGL((linear_kernel<BTV, 1>), grid, dim3(256), 0, st, x, w, bias, y, B, b_lo, K, O, negative_slope, vec_ok); \
+    else hipLaunchKernelGGL((linear_kernel<BTV, OT4>), grid, dim3(256), 0, st, x, w, bias, y, B, b_lo, K, O, negative_slope, vec_ok);    \
   } while (0)
-  for (int b_lo = 0; b_lo < B;) {
-    const int rem = B - b_lo;
-    if (rem > 4) { LR_LIN(8); b_lo += 8; }
-    else if (rem > 1) { LR_LIN(4); b_lo += 4; }
-    else { LR_LIN(1); b_lo += 1; }
-    if (int e = lr_launch_status()) return e;
+  {
+    const int b_lo = 0;
+    if (B > 4) { grid.y = (unsigned)((B + 7) / 8); LR_LIN(8); }   // rows past B are clamped on the way in and not written
+    else if (B > 1) LR_LIN(4);
+    else LR_LIN(1);
   }
 #undef LR_LIN
-  return LR_OK;
+  return lr_launch_status();
 }
