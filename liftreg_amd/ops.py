@@ -125,21 +125,19 @@ def drr_forward(vol, poses, resolution, spacing=(2.2, 2.2, 2.2), *, d0=0, d1=Non
     `fold_hu=False` converts once per voxel with `hu_to_mu` first — same bits; `fold_hu=None` (default) picks by `_fold_hu_pays`.
     """
     vol = _dev(vol, "vol")
-    if hu_input and fold_hu is None and vol.dim() == 3:
-        fold_hu = _fold_hu_pays(np.asarray(poses).reshape(-1, 3).shape[0], resolution, vol.shape[0], vol.shape[2])
-    if hu_input and fold_hu is False:
-        vol, hu_input = hu_to_mu(vol), False
     if vol.dim() != 3:
         raise ValueError("vol must be (D,W,H)")
+    poses = _host_f32(poses, (3,), "poses").reshape(-1, 3)
+    sp = _host_f32(spacing, (3,), "spacing")
+    P = poses.shape[0]
+    Rd, Rh = int(resolution[0]), int(resolution[1])
+    if hu_input and (fold_hu is False or (fold_hu is None and not _fold_hu_pays(P, (Rd, Rh), vol.shape[0], vol.shape[2]))):
+        vol, hu_input = hu_to_mu(vol), False       # one conversion per voxel (same bits as the folded form)
     Ds, W, H = vol.shape
     D = Ds if full_D is None else int(full_D)
     d1 = D if d1 is None else int(d1)
     if d1 - d0 != Ds:
         raise ValueError(f"slab rows [{d0},{d1}) do not match vol.shape[0]={Ds}")
-    poses = _host_f32(poses, (3,), "poses").reshape(-1, 3)
-    sp = _host_f32(spacing, (3,), "spacing")
-    P = poses.shape[0]
-    Rd, Rh = int(resolution[0]), int(resolution[1])
     if out is None:
         out = torch.empty((P, Rd, Rh), dtype=torch.float32, device=vol.device)
     else:
