@@ -507,12 +507,15 @@ class SlabShardedRegistration:
                     a[:, 1].zero_()
                 else:
                     a[:, 1].copy_(h[:, 0])
-                y = conv(i, a, None, d0)          # (B, 1 + r/2, ...) channels-last, or (B, 32, 1 + r/2, ...) for the last block
                 if i == 5:
+                    y = conv(i, a, None, d0)      # (B, 32, 1 + r/2, ...): the last block writes NCDHW
                     nxt.append(y[:, :, 1:].contiguous())
                 else:
-                    nb = torch.empty((y.shape[0], 1 + y.shape[1]) + tuple(y.shape[2:]), dtype=y.dtype, device=y.device)
-                    nb[:, 1:].copy_(y)
+                    # (B, 1 + r/2, ...) channels-last, written straight behind the next block's filler plane (strided-batch output:
+                    # no copy of the block's output)
+                    cout = net.encoders[i].conv.out_channels
+                    nb = torch.empty((a.shape[0], 2 + (a.shape[1] - 1) // 2, o(a.shape[2]), o(a.shape[3]), cout), dtype=act_dt, device=a.device)
+                    conv(i, a, nb[:, 1:], d0)
                     nxt.append(nb)
                 nrows.append(r // 2)
             acts_p, rows = nxt, nrows
